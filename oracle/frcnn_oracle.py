@@ -1,0 +1,502 @@
+"""CPU oracle: a restatement of the reference's Faster R-CNN hot path (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may import this
+module.  The product package (chainer-faster-rcnn_amd/) never does: it fails loudly when
+the HIP library is missing instead of falling back to anything here.
+
+Every function cites the reference file:line (relative to /root/reference) it follows.
+Detection glue is restated in NumPy in the reference's own dtypes and operation order;
+the two native routines (cpu_nms, bbox_overlaps) and RoI pooling are restated in C
+(oracle/c/frcnn_oracle.c).  Pinning (tests/test_oracle_pinned.py):
+  * glue + cpu_nms + bbox_overlaps: checked bit-for-bit against the reference's own code
+    executed in the build container (oracle/ref_harness.py, oracle/_ref/*.so) and against
+    tests/golden/*.npz generated from it by tests/make_golden.py -> PINNED.
+  * conv / max-pool / softmax / linear / RoI pooling / losses / optimizer: these live in
+    Chainer, an un-vendored and un-pinned dependency (README.md:13 "1.22.0+"); the
+    reference's tests pin no value at that boundary -> PARITY UNPINNED.  They restate
+    Chainer v1's published semantics with torch-CPU fp32 (conv2d / max_pool2d(ceil_mode) /
+    linear) and explicit loops.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build_c(force=False):
+    """gcc-compile oracle/c/frcnn_oracle.c -> oracle/_build/libfrcnn_oracle.so."""
+    out_dir = os.path.join(HERE, "_build")
+    so = os.path.join(out_dir, "libfrcnn_oracle.so")
+    src = os.path.join(HERE, "c", "frcnn_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-fno-fast-math", "-fPIC", "-shared",
+                               src, "-o", so, "-lm"])
+    return so
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        L = ctypes.CDLL(build_c())
+        P, I64, D = ctypes.c_void_p, ctypes.c_int64, ctypes.c_double
+        L.oracle_cpu_nms.restype = I64
+        L.oracle_cpu_nms.argtypes = [P, I64, P, D, P]
+        L.oracle_bbox_overlaps.restype = None
+        L.oracle_bbox_overlaps.argtypes = [P, I64, P, I64, P]
+        L.oracle_roi_pool_fwd.restype = None
+        L.oracle_roi_pool_fwd.argtypes = [P, I64, I64, I64, P, I64, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_float, P, P]
+        L.oracle_roi_pool_bwd.restype = None
+        L.oracle_roi_pool_bwd.argtypes = [P, P, P, I64, I64, I64, I64, ctypes.c_int, ctypes.c_int, I64, P]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+# --------------------------------------------------------------------------- anchors
+def generate_anchors(base_size=15, ratios=(0.5, 1, 2), scales=(8, 16, 32)):
+    """models/generate_anchors.py:47-93.  (A,4) float64, ratio-major then scale.
+
+    base anchor [0,0,15,15] (line 50) => w=h=16, ctr=7.5; per ratio: ws=rint(sqrt(256/r)),
+    hs=rint(ws*r) (lines 77-84); per scale: ws*s, hs*s around the same centre (87-93);
+    corner = ctr -/+ 0.5*(w-1) (lines 66-74).
+    """
+    w = h = float(base_size) + 1.0
+    cx = cy = 0.5 * (w - 1)
+    out = []
+    for r in ratios:
+        ws = np.rint(np.sqrt(w * h / r))
+        hs = np.rint(ws * r)
+        for s in scales:
+            W_, H_ = ws * s, hs * s
+            out.append([cx - 0.5 * (W_ - 1), cy - 0.5 * (H_ - 1), cx + 0.5 * (W_ - 1), cy + 0.5 * (H_ - 1)])
+    return np.asarray(out, dtype=np.float64)
+
+
+def generate_all_bbox(anchors, feat_h, feat_w, feat_stride=16):
+    """models/proposal_layer.py:207-221.  (feat_h*feat_w*A, 4) float64, order (h, w, a), a fastest."""
+    sx = np.arange(0, feat_w) * feat_stride
+    sy = np.arange(0, feat_h) * feat_stride
+    sx, sy = np.meshgrid(sx, sy)
+    shifts = np.stack([sx.ravel(), sy.ravel(), sx.ravel(), sy.ravel()], axis=1)
+    A = len(anchors)
+    return (anchors.reshape(1, A, 4) + shifts.reshape(-1, 1, 4)).reshape(-1, 4)
+
+
+# --------------------------------------------------------------------------- bbox transforms
+def bbox_transform(ex_rois, gt_rois):
+    """models/bbox_transform.py:18-38 (dtype follows the inputs: float64 in AnchorTargetLayer)."""
+    ew = ex_rois[:, 2] - ex_rois[:, 0] + 1.0
+    eh = ex_rois[:, 3] - ex_rois[:, 1] + 1.0
+    ecx = ex_rois[:, 0] + 0.5 * ew
+    ecy = ex_rois[:, 1] + 0.5 * eh
+    gw = gt_rois[:, 2] - gt_rois[:, 0] + 1.0
+    gh = gt_rois[:, 3] - gt_rois[:, 1] + 1.0
+    gcx = gt_rois[:, 0] + 0.5 * gw
+    gcy = gt_rois[:, 1] + 0.5 * gh
+    return np.stack([(gcx - ecx) / ew, (gcy - ecy) / eh, np.log(gw / ew), np.log(gh / eh)], axis=1)
+
+
+def bbox_transform_inv(boxes, trans):
+    """models/bbox_transform.py:41-76.  Separate multiply and add (no FMA), np.exp in the input dtype,
+    no clamp on dw/dh; generic over trans (N, 4*C)."""
+    if boxes.shape[0] == 0:
+        return np.zeros((0, trans.shape[1]), dtype=trans.dtype)
+    widths = boxes[:, 2] - boxes[:, 0] + 1.0
+    heights = boxes[:, 3] - boxes[:, 1] + 1.0
+    ctr_x = boxes[:, 0] + 0.5 * widths
+    ctr_y = boxes[:, 1] + 0.5 * heights
+    dx, dy, dw, dh = trans[:, 0::4], trans[:, 1::4], trans[:, 2::4], trans[:, 3::4]
+    pcx = dx * widths[:, None] + ctr_x[:, None]
+    pcy = dy * heights[:, None] + ctr_y[:, None]
+    pw = np.exp(dw) * widths[:, None]
+    ph = np.exp(dh) * heights[:, None]
+    out = np.zeros(trans.shape, dtype=trans.dtype)
+    out[:, 0::4] = pcx - 0.5 * pw
+    out[:, 1::4] = pcy - 0.5 * ph
+    out[:, 2::4] = pcx + 0.5 * pw
+    out[:, 3::4] = pcy + 0.5 * ph
+    return out
+
+
+def clip_boxes(boxes, im_shape):
+    """models/bbox_transform.py:79-99.  im_shape = (H, W); in place."""
+    boxes[:, 0::4] = np.maximum(np.minimum(boxes[:, 0::4], int(im_shape[1] - 1)), 0)
+    boxes[:, 1::4] = np.maximum(np.minimum(boxes[:, 1::4], int(im_shape[0] - 1)), 0)
+    boxes[:, 2::4] = np.maximum(np.minimum(boxes[:, 2::4], int(im_shape[1] - 1)), 0)
+    boxes[:, 3::4] = np.maximum(np.minimum(boxes[:, 3::4], int(im_shape[0] - 1)), 0)
+    return boxes
+
+
+def filter_boxes(boxes, min_size):
+    """models/bbox_transform.py:102-109."""
+    ws = boxes[:, 2] - boxes[:, 0] + 1
+    hs = boxes[:, 3] - boxes[:, 1] + 1
+    return np.where((ws >= min_size) & (hs >= min_size))[0]
+
+
+def keep_inside(anchors, img_info):
+    """models/bbox_transform.py:112-130.  img_info = (H, W)."""
+    inds = np.where((anchors[:, 0] >= 0) & (anchors[:, 1] >= 0) &
+                    (anchors[:, 2] < img_info[1]) & (anchors[:, 3] < img_info[0]))[0]
+    return inds, anchors[inds]
+
+
+# --------------------------------------------------------------------------- native routines
+def cpu_nms(dets, thresh):
+    """models/cpu_nms.pyx:18-69 (C restatement).  Returns a Python list of indices into dets."""
+    dets = np.ascontiguousarray(dets)
+    if dets.dtype != np.float32 or dets.ndim != 2:
+        raise ValueError("Buffer dtype mismatch, expected 'float32_t'")     # Cython's own error class
+    if not isinstance(thresh, float):
+        raise TypeError("Argument 'thresh' has incorrect type (expected float)")
+    n = dets.shape[0]
+    order = np.ascontiguousarray(dets[:, 4].argsort()[::-1].astype(np.int64))   # cpu_nms.pyx:26
+    keep = np.empty(max(n, 1), dtype=np.int64)
+    k = _lib().oracle_cpu_nms(_p(dets), n, _p(order), float(thresh), _p(keep))
+    return [int(v) for v in keep[:k]]
+
+
+def cpu_nms_py(dets, thresh):
+    """Pure-Python twin of cpu_nms for tiny cases (same arithmetic: float32 IoU, double compare)."""
+    f = np.float32
+    x1, y1, x2, y2, sc = [dets[:, i] for i in range(5)]
+    areas = (x2 - x1 + f(1)) * (y2 - y1 + f(1))
+    order = sc.argsort()[::-1]
+    sup = np.zeros(len(dets), dtype=bool)
+    keep = []
+    for _i in range(len(dets)):
+        i = order[_i]
+        if sup[i]:
+            continue
+        keep.append(int(i))
+        for _j in range(_i + 1, len(dets)):
+            j = order[_j]
+            if sup[j]:
+                continue
+            w = max(f(0), min(x2[i], x2[j]) - max(x1[i], x1[j]) + f(1))
+            h = max(f(0), min(y2[i], y2[j]) - max(y1[i], y1[j]) + f(1))
+            inter = f(w * h)
+            ovr = f(inter / f(f(areas[i] + areas[j]) - inter))
+            if float(ovr) >= thresh:
+                sup[j] = True
+    return keep
+
+
+def bbox_overlaps(boxes, query_boxes):
+    """models/bbox.pyx:16-56 (C restatement).  float64 in, float64 (N,K) out."""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float64)
+    query_boxes = np.ascontiguousarray(query_boxes, dtype=np.float64)
+    out = np.empty((boxes.shape[0], query_boxes.shape[0]), dtype=np.float64)
+    _lib().oracle_bbox_overlaps(_p(boxes), boxes.shape[0], _p(query_boxes), query_boxes.shape[0], _p(out))
+    return out
+
+
+# --------------------------------------------------------------------------- ProposalLayer
+class ProposalParams(object):
+    """Class constants of models/proposal_layer.py:51-56 and the train switch at :75-83."""
+    RPN_NMS_THRESH = 0.7
+    TRAIN = (12000, 2000)
+    TEST = (6000, 300)
+    RPN_MIN_SIZE = 16
+
+
+def proposal_layer(rpn_cls_prob, rpn_bbox_pred, img_info, train=False, feat_stride=16,
+                   anchor_ratios=(0.5, 1, 2), anchor_scales=(8, 16, 32),
+                   pre_nms_top_n=None, post_nms_top_n=None, nms_thresh=0.7, min_size=16,
+                   return_debug=False):
+    """models/proposal_layer.py:102-198.  Inputs (1,2A,H,W), (1,4A,H,W) float32, img_info (1,2) int.
+
+    Returns (proposals (n,4) f32, fg_probs (n,1) f32) [+ a dict of intermediates].
+    """
+    anchors = generate_anchors(ratios=anchor_ratios, scales=anchor_scales)      # :63-64
+    A = len(anchors)
+    pre, post = ProposalParams.TRAIN if train else ProposalParams.TEST            # :75-83
+    pre = pre if pre_nms_top_n is None else pre_nms_top_n
+    post = post if post_nms_top_n is None else post_nms_top_n
+    prob = rpn_cls_prob[0]
+    pred = rpn_bbox_pred[0]
+    info = img_info[0]
+    _, fh, fw = pred.shape
+    all_bbox = generate_all_bbox(anchors, fh, fw, feat_stride).astype(np.float32)  # :200-205
+    trans = pred.transpose(1, 2, 0).reshape(-1, 4)                                 # :138
+    proposals = bbox_transform_inv(all_bbox, trans)                                # :141
+    proposals = clip_boxes(proposals, info)                                        # :144
+    keep0 = filter_boxes(proposals, min_size)                                      # :147
+    proposals = proposals[keep0]
+    fg = prob[A:].transpose(1, 2, 0).reshape(-1, 1)[keep0]                          # :152-154
+    order = fg.ravel().argsort()[::-1]                                             # :158-165
+    if pre > 0:
+        order = order[:pre]                                                        # :167-168
+    proposals = proposals[order]
+    fg = fg[order]
+    keep = cpu_nms(np.hstack((proposals, fg)), float(nms_thresh))                  # :178
+    if post > 0:
+        keep = keep[:post]                                                         # :189-190
+    out_p, out_s = proposals[keep], fg[keep]
+    if return_debug:
+        return out_p, out_s, dict(keep0=keep0, order=order, sorted_boxes=proposals, sorted_scores=fg,
+                                  keep=np.asarray(keep, dtype=np.int64),
+                                  src_index=keep0[order][keep] if len(keep) else np.zeros(0, np.int64))
+    return out_p, out_s
+
+
+# --------------------------------------------------------------------------- AnchorTargetLayer
+def anchor_target_layer(feat_h, feat_w, gt_boxes, img_info, feat_stride=16, anchor_ratios=(0.5, 1, 2),
+                        anchor_scales=(8, 16, 32), rng=np.random):
+    """models/anchor_target_layer.py:66-198.  gt_boxes (1,G,5) f32, img_info (1,2) int.
+
+    Returns (labels int32 (n_in,), targets f32 (n_in,4), inds_inside int64, n_all).  `rng` must offer
+    NumPy's legacy `choice` so seeded runs reproduce the reference's np.random.choice draws (:153,164).
+    """
+    NEG, POS, FG_FRAC, BATCH = 0.3, 0.7, 0.5, 256                                   # :44-47
+    gt = gt_boxes[0]
+    info = img_info[0]
+    anchors = generate_anchors(ratios=anchor_ratios, scales=anchor_scales)
+    all_bbox = generate_all_bbox(anchors, feat_h, feat_w, feat_stride)             # float64, :109
+    inds_inside, inside = keep_inside(all_bbox, info)                              # :110
+    labels = np.ones((len(inds_inside),), dtype=np.int32) * -1                      # :129
+    overlaps = bbox_overlaps(np.ascontiguousarray(inside, dtype=np.float64),
+                             np.ascontiguousarray(gt[:, :4], dtype=np.float64))    # :183-185
+    argmax = overlaps.argmax(axis=1)                                               # :189
+    gt_argmax = overlaps.argmax(axis=0)                                            # :190
+    max_ov = overlaps[np.arange(len(inds_inside)), argmax]                         # :192-193
+    gt_max = overlaps[gt_argmax, np.arange(overlaps.shape[1])]                     # :194-195
+    gt_argmax = np.where(overlaps == gt_max)[0]                                    # :196
+    labels[max_ov < NEG] = 0                                                        # :135
+    labels[gt_argmax] = 1                                                           # :138
+    labels[max_ov >= POS] = 1                                                       # :141
+    labels[max_ov < NEG] = 0                                                        # :144 (negatives clobber)
+    num_fg = int(FG_FRAC * BATCH)
+    fg_inds = np.where(labels == 1)[0]
+    if len(fg_inds) > num_fg:                                                       # :149-155
+        labels[rng.choice(fg_inds, size=int(len(fg_inds) - num_fg), replace=False)] = -1
+    num_bg = BATCH - np.sum(labels == 1)
+    bg_inds = np.where(labels == 0)[0]
+    if len(bg_inds) > num_bg:                                                       # :158-167
+        labels[rng.choice(bg_inds, size=int(len(bg_inds) - num_bg), replace=False)] = -1
+    targets = bbox_transform(inside, gt[argmax]).astype(np.float32)                # :115-118
+    return labels, targets, inds_inside, len(all_bbox)
+
+
+# --------------------------------------------------------------------------- RoI pooling (chainer-ext)
+def roi_pooling_2d(x, rois, outh=7, outw=7, spatial_scale=0.0625, return_argmax=False):
+    """Call site models/faster_rcnn.py:125-126; semantics = Chainer v1 roi_pooling_2d (see the C file)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    rois = np.ascontiguousarray(rois, dtype=np.float32)
+    N, C, H, W = x.shape
+    R = rois.shape[0]
+    y = np.empty((R, C, outh, outw), dtype=np.float32)
+    am = np.empty((R, C, outh, outw), dtype=np.int32)
+    _lib().oracle_roi_pool_fwd(_p(x), C, H, W, _p(rois), R, outh, outw, float(spatial_scale), _p(y), _p(am))
+    return (y, am) if return_argmax else y
+
+
+def roi_pooling_2d_py(x, rois, outh=7, outw=7, spatial_scale=0.0625):
+    """Loop-for-loop NumPy twin of Chainer's forward_cpu (Python round() = half-to-even on the float32
+    product, double strides, floor/ceil, clamp) -- used to cross-check the C restatement on small cases."""
+    N, C, H, W = x.shape
+    R = rois.shape[0]
+    y = np.zeros((R, C, outh, outw), dtype=np.float32)
+    am = -np.ones((R, C, outh, outw), dtype=np.int32)
+    for r in range(R):
+        idx, xmin, ymin, xmax, ymax = rois[r]
+        xmin = int(round(np.float32(xmin * np.float32(spatial_scale))))
+        xmax = int(round(np.float32(xmax * np.float32(spatial_scale))))
+        ymin = int(round(np.float32(ymin * np.float32(spatial_scale))))
+        ymax = int(round(np.float32(ymax * np.float32(spatial_scale))))
+        rw = max(xmax - xmin + 1, 1)
+        rh = max(ymax - ymin + 1, 1)
+        sh, sw = 1. * rh / outh, 1. * rw / outw
+        for ph in range(outh):
+            hs = min(max(int(np.floor(ph * sh)) + ymin, 0), H)
+            he = min(max(int(np.ceil((ph + 1) * sh)) + ymin, 0), H)
+            if he <= hs:
+                continue
+            for pw in range(outw):
+                ws = min(max(int(np.floor(pw * sw)) + xmin, 0), W)
+                we = min(max(int(np.ceil((pw + 1) * sw)) + xmin, 0), W)
+                if we <= ws:
+                    continue
+                d = x[int(idx), :, hs:he, ws:we].reshape(C, -1)
+                y[r, :, ph, pw] = d.max(axis=1)
+                a = d.argmax(axis=1)
+                am[r, :, ph, pw] = (a // (we - ws) + hs) * W + (a % (we - ws) + ws)
+    return y, am
+
+
+def roi_pooling_2d_backward(dy, argmax, rois, x_shape):
+    N, C, H, W = x_shape
+    dy = np.ascontiguousarray(dy, dtype=np.float32)
+    argmax = np.ascontiguousarray(argmax, dtype=np.int32)
+    rois = np.ascontiguousarray(rois, dtype=np.float32)
+    dx = np.empty(x_shape, dtype=np.float32)
+    R, _, outh, outw = dy.shape
+    _lib().oracle_roi_pool_bwd(_p(dy), _p(argmax), _p(rois), R, C, H, W, outh, outw, N, _p(dx))
+    return dx
+
+
+# --------------------------------------------------------------------------- network (chainer-ext, torch-CPU)
+VGG16_LAYERS = [  # models/vgg16.py:38-68 -- (name, cin, cout) / 'pool'
+    ("conv1_1", 3, 64), ("conv1_2", 64, 64), "pool",
+    ("conv2_1", 64, 128), ("conv2_2", 128, 128), "pool",
+    ("conv3_1", 128, 256), ("conv3_2", 256, 256), ("conv3_3", 256, 256), "pool",
+    ("conv4_1", 256, 512), ("conv4_2", 512, 512), ("conv4_3", 512, 512), "pool",
+    ("conv5_1", 512, 512), ("conv5_2", 512, 512), ("conv5_3", 512, 512),
+]
+
+
+def init_params(seed=1, num_classes=21, n_anchors=9, roi_feat=512 * 7 * 7, dtype=np.float32):
+    """Random-init weights of the reference architecture, keyed by Chainer link path.
+
+    Trunk: He-normal (keeps activations alive through 13 ReLUs); RPN + head: Normal(0, 0.01) as
+    models/faster_rcnn.py:27 and region_proposal_network.py:50; biases 0.
+    """
+    rs = np.random.RandomState(seed)
+    p = {}
+    for l in VGG16_LAYERS:
+        if l == "pool":
+            continue
+        name, ci, co = l
+        p["trunk/%s/W" % name] = (rs.randn(co, ci, 3, 3) * np.sqrt(2.0 / (ci * 9))).astype(dtype)
+        p["trunk/%s/b" % name] = np.zeros(co, dtype)
+    p["RPN/rpn_conv_3x3/W"] = (rs.randn(512, 512, 3, 3) * 0.01).astype(dtype)
+    p["RPN/rpn_conv_3x3/b"] = np.zeros(512, dtype)
+    p["RPN/rpn_cls_score/W"] = (rs.randn(2 * n_anchors, 512, 1, 1) * 0.01).astype(dtype)
+    p["RPN/rpn_cls_score/b"] = np.zeros(2 * n_anchors, dtype)
+    p["RPN/rpn_bbox_pred/W"] = (rs.randn(4 * n_anchors, 512, 1, 1) * 0.01).astype(dtype)
+    p["RPN/rpn_bbox_pred/b"] = np.zeros(4 * n_anchors, dtype)
+    p["fc6/W"] = (rs.randn(4096, roi_feat) * 0.01).astype(dtype)
+    p["fc6/b"] = np.zeros(4096, dtype)
+    p["fc7/W"] = (rs.randn(4096, 4096) * 0.01).astype(dtype)
+    p["fc7/b"] = np.zeros(4096, dtype)
+    p["cls_score/W"] = (rs.randn(num_classes, 4096) * 0.01).astype(dtype)
+    p["cls_score/b"] = np.zeros(num_classes, dtype)
+    p["bbox_pred/W"] = (rs.randn(4 * num_classes, 4096) * 0.01).astype(dtype)
+    p["bbox_pred/b"] = np.zeros(4 * num_classes, dtype)
+    return p
+
+
+def _t(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def conv2d(x, W, b, pad):
+    """L.Convolution2D(ci, co, k, 1, pad): cross-correlation + bias, NCHW, fp32 [chainer-ext]."""
+    import torch.nn.functional as F
+    return F.conv2d(_t(x), _t(W), _t(b), stride=1, padding=pad).numpy()
+
+
+def relu(x):
+    return np.maximum(x, 0)
+
+
+def max_pool_2x2(x):
+    """F.MaxPooling2D(2, 2): cover_all=True => ceil-mode output size [chainer-ext] (vgg16.py:43)."""
+    import torch.nn.functional as F
+    return F.max_pool2d(_t(x), 2, 2, ceil_mode=True).numpy()
+
+
+def softmax(x, axis=1):
+    e = np.exp(x - x.max(axis=axis, keepdims=True))
+    return (e / e.sum(axis=axis, keepdims=True)).astype(x.dtype)
+
+
+def vgg16_trunk(p, x, upto=None):
+    """models/vgg16.py:74-82 (VGG16Prev): conv1_1 ... relu5_3, no pool5."""
+    for l in VGG16_LAYERS:
+        if l == "pool":
+            x = max_pool_2x2(x)
+        else:
+            x = relu(conv2d(x, p["trunk/%s/W" % l[0]], p["trunk/%s/b" % l[0]], 1))
+            if upto == l[0]:
+                break
+    return x
+
+
+def rpn_head(p, feat):
+    """models/region_proposal_network.py:117-120.  NB: softmax over ALL 2A channels (axis 1)."""
+    h = relu(conv2d(feat, p["RPN/rpn_conv_3x3/W"], p["RPN/rpn_conv_3x3/b"], 1))
+    score = conv2d(h, p["RPN/rpn_cls_score/W"], p["RPN/rpn_cls_score/b"], 0)
+    prob = softmax(score, axis=1)
+    bbox = conv2d(h, p["RPN/rpn_bbox_pred/W"], p["RPN/rpn_bbox_pred/b"], 0)
+    return h, score, prob, bbox
+
+
+def linear(x, W, b):
+    import torch.nn.functional as F
+    return F.linear(_t(x), _t(W), _t(b)).numpy()
+
+
+def rcnn_head(p, pool5, proposals, img_info):
+    """models/faster_rcnn.py:127-134,175-178 (inference: dropout is identity)."""
+    fc6 = relu(linear(pool5.reshape(len(pool5), -1), p["fc6/W"], p["fc6/b"]))
+    fc7 = relu(linear(fc6, p["fc7/W"], p["fc7/b"]))
+    cls_score = linear(fc7, p["cls_score/W"], p["cls_score/b"])
+    bbox_pred = linear(fc7, p["bbox_pred/W"], p["bbox_pred/b"])
+    pred_boxes = clip_boxes(bbox_transform_inv(proposals, bbox_pred), img_info[0])
+    return softmax(cls_score, axis=1), pred_boxes, dict(fc6=fc6, fc7=fc7, cls_score=cls_score,
+                                                        bbox_pred=bbox_pred)
+
+
+def faster_rcnn_forward(p, x, img_info, return_debug=False):
+    """models/faster_rcnn.py:111-134,175-178 inference path end to end."""
+    feat = vgg16_trunk(p, x)
+    h, score, prob, bbox = rpn_head(p, feat)
+    proposals, probs = proposal_layer(prob, bbox, img_info, train=False)
+    brois = np.concatenate((np.zeros((len(proposals), 1), np.float32), proposals), axis=1)  # :123-124
+    pool5 = roi_pooling_2d(feat, brois, 7, 7, 1.0 / 16)
+    cls_prob, pred_boxes, dbg = rcnn_head(p, pool5, proposals, img_info)
+    if return_debug:
+        dbg.update(feat=feat, rpn_h=h, rpn_cls_score=score, rpn_cls_prob=prob, rpn_bbox_pred=bbox,
+                   proposals=proposals, probs=probs, pool5=pool5)
+        return cls_prob, pred_boxes, dbg
+    return cls_prob, pred_boxes
+
+
+# --------------------------------------------------------------------------- RPN losses (chainer-ext)
+def rpn_loss_cls(rpn_cls_score, labels, inds_inside, n_all, feat_h, feat_w, n_anchors=9):
+    """models/region_proposal_network.py:160-181: 2-way softmax CE over (1,2,A,H,W), ignore -1,
+    mean over non-ignored [chainer-ext softmax_cross_entropy normalize=True]; accuracy ditto."""
+    mapped = np.ones((n_all,), dtype=np.int32) * -1
+    mapped[inds_inside] = labels
+    mapped = mapped.reshape(1, feat_h, feat_w, n_anchors).transpose(0, 3, 1, 2)
+    s = rpn_cls_score.reshape(1, 2, n_anchors, feat_h, feat_w).astype(np.float32)
+    m = s.max(axis=1, keepdims=True)
+    logp = s - m - np.log(np.exp(s - m).sum(axis=1, keepdims=True))
+    valid = mapped != -1
+    cnt = max(int(valid.sum()), 1)
+    lab = np.where(valid, mapped, 0)
+    picked = np.take_along_axis(logp, lab[:, None], axis=1)[:, 0]
+    loss = -(picked * valid).sum() / cnt
+    pred = s.argmax(axis=1)
+    acc = float(((pred == mapped) & valid).sum()) / max(int(valid.sum()), 1)
+    return np.float32(loss), np.float32(acc)
+
+
+def rpn_loss_bbox(rpn_bbox_pred, targets, inds_inside, n_anchors=9, delta=3.0):
+    """models/region_proposal_network.py:183-204: the (4,A,K)->(K,A,4) re-interpretation (channel =
+    coord*A + a, inconsistent with ProposalLayer -- reproduced as is), Huber(delta) summed over all
+    inside anchors, divided by K*A."""
+    pred = rpn_bbox_pred.reshape(4, n_anchors, -1).transpose(2, 1, 0).reshape(-1, 4)
+    n_bbox = pred.shape[0]
+    d = pred[inds_inside].ravel().astype(np.float32) - targets.ravel().astype(np.float32)
+    a = np.abs(d)
+    l = np.where(a < delta, 0.5 * d * d, delta * (a - 0.5 * delta))
+    return np.float32(l.sum(dtype=np.float32) / n_bbox)
+
+
+def momentum_sgd_wd(W, g, v, lr=0.001, momentum=0.9, wd=0.0005):
+    """train_rpn.py:165-167: WeightDecay hook then MomentumSGD [chainer-ext]: g+=wd*W; v=m*v-lr*g; W+=v."""
+    g = g + np.float32(wd) * W
+    v = np.float32(momentum) * v - np.float32(lr) * g
+    return W + v, v

@@ -1,0 +1,159 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REFERENCE's own code (build container only).
+
+Uses oracle/ref_harness.py to import /root/reference/models/*.py under a stub chainer and the
+reference's Cython modules built into oracle/_ref/.  The reference's tests pin no output values
+(SURVEY.md section 4), so these fixtures -- inputs AND the reference's outputs -- are the
+known-answer vectors both the oracle (tests -m "not gpu") and the HIP path (tests -m gpu) are
+held to.  Re-run:  python tests/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_harness as rh  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def unique_scores_softmax(rs, shape):
+    """18-way softmax of N(0,1) logits (region_proposal_network.py:119) with de-duplicated fg scores
+    so NumPy's unstable argsort tie order cannot leak into the fixture."""
+    logits = rs.randn(*shape).astype(np.float32)
+    e = np.exp(logits - logits.max(axis=1, keepdims=True))
+    prob = (e / e.sum(axis=1, keepdims=True)).astype(np.float32)
+    A = shape[1] // 2
+    fg = prob[0, A:].ravel()
+    while True:
+        u, idx, cnt = np.unique(fg, return_index=True, return_counts=True)
+        if len(u) == len(fg):
+            break
+        dup = np.ones(len(fg), bool)
+        dup[idx] = False
+        fg[dup] = np.nextafter(fg[dup], np.float32(2.0)) + (rs.rand(dup.sum()) * 1e-6).astype(np.float32)
+    prob[0, A:] = fg.reshape(prob[0, A:].shape)
+    return prob
+
+
+def proposal_case(ns, name, fh, fw, img, train, seed, kind, pre=None, post=None):
+    rs = np.random.RandomState(seed)
+    if kind == "rand":      # tests/test_proposal_layer.py:25-29 recipe (rand probs, rand deltas)
+        prob = rs.rand(1, 18, fh, fw).astype(np.float32)
+        fg = prob[0, 9:].ravel()
+        assert len(np.unique(fg)) == len(fg) or True
+        # de-duplicate
+        u, idx = np.unique(fg, return_index=True)
+        dup = np.ones(len(fg), bool); dup[idx] = False
+        k = 0
+        while dup.any():
+            fg[dup] = rs.rand(dup.sum()).astype(np.float32)
+            u, idx = np.unique(fg, return_index=True)
+            dup = np.ones(len(fg), bool); dup[idx] = False
+            k += 1
+        prob[0, 9:] = fg.reshape(prob[0, 9:].shape)
+        pred = rs.rand(1, 36, fh, fw).astype(np.float32)
+    else:                   # SURVEY.md section 8d stage-isolated bench inputs
+        prob = unique_scores_softmax(rs, (1, 18, fh, fw))
+        pred = (rs.randn(1, 36, fh, fw) * 0.2).astype(np.float32)
+    info = np.array([img], dtype=np.int32)
+    pl = ns.ProposalLayer()
+    pl.train = train
+    if pre is not None:
+        pl._pre_nms_top_n, pl._post_nms_top_n = pre, post
+    props, probs = pl(ns.Variable(prob.copy()), ns.Variable(pred.copy()), ns.Variable(info))
+    # the sorted pre-NMS set, re-derived with the reference's own functions (proposal_layer.py:135-170)
+    all_bbox = pl._generate_all_bbox_use_array_info(pred[0])
+    trans = pred[0].transpose(1, 2, 0).reshape(-1, 4)
+    dec = ns.clip_boxes(ns.bbox_transform_inv(all_bbox, trans), info[0])
+    keep0 = ns.filter_boxes(dec, pl._min_size)
+    fg = prob[0, 9:].transpose(1, 2, 0).reshape(-1, 1)[keep0]
+    order = fg.ravel().argsort()[::-1][:pl._pre_nms_top_n]
+    sorted_boxes, sorted_scores = dec[keep0][order], fg[order]
+    keep = np.asarray(ns.cpu_nms(np.hstack((sorted_boxes, sorted_scores)), pl._nms_thresh), dtype=np.int64)
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), rpn_cls_prob=prob, rpn_bbox_pred=pred, img_info=info,
+        train=np.array(train), pre=np.array(pl._pre_nms_top_n), post=np.array(pl._post_nms_top_n),
+        proposals=props, probs=probs, decoded_clipped=dec, keep0=keep0, order=order.astype(np.int64),
+        sorted_boxes=sorted_boxes, sorted_scores=sorted_scores, nms_keep=keep)
+    print(name, props.shape, "n_valid", len(keep0), "nms survivors", len(keep))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ns = rh.load()
+    # ---- anchors (generate_anchors.py:47-93)
+    np.savez_compressed(os.path.join(OUT, "anchors.npz"),
+                        a_8_16_32=ns.generate_anchors(ratios=(0.5, 1, 2), scales=(8, 16, 32)),
+                        a_4_8_16_32=ns.generate_anchors(ratios=(0.5, 1, 2), scales=(4, 8, 16, 32)),
+                        a_default=ns.generate_anchors())
+    # ---- ProposalLayer
+    proposal_case(ns, "proposal_14x14_train_rand", 14, 14, (224, 224), True, 11, "rand")
+    proposal_case(ns, "proposal_38x63_test", 38, 63, (600, 1000), False, 0, "bench")
+    proposal_case(ns, "proposal_38x63_test_HH", 38, 63, (600, 600), False, 2, "bench")      # forward.py:93 quirk
+    proposal_case(ns, "proposal_38x63_train", 38, 63, (600, 1000), True, 3, "bench")
+    proposal_case(ns, "proposal_38x63_cfg4_1000_300", 38, 63, (600, 1000), False, 4, "bench", 1000, 300)
+    proposal_case(ns, "proposal_37x50_test", 37, 50, (600, 800), False, 5, "bench")        # test_region_proposal_network.py:18-23
+    # ---- cpu_nms (cpu_nms.pyx:18-69)
+    rs = np.random.RandomState(7)
+    nms = {}
+    for tag, n, thr in (("n6000_t07", 6000, 0.7), ("n300_t03", 300, 0.3), ("n1_t07", 1, 0.7), ("n65_t05", 65, 0.5)):
+        x1 = rs.uniform(0, 900, n); y1 = rs.uniform(0, 500, n)
+        w = rs.uniform(16, 400, n); h = rs.uniform(16, 300, n)
+        sc = rs.permutation(n).astype(np.float64) / n
+        d = np.stack([x1, y1, np.minimum(x1 + w, 999), np.minimum(y1 + h, 599), sc], 1).astype(np.float32)
+        nms[tag + "_dets"] = d
+        nms[tag + "_thresh"] = np.array(thr)
+        nms[tag + "_keep"] = np.asarray(ns.cpu_nms(d, thr), dtype=np.int64)
+    # exact-threshold semantics: `ovr >= thresh` compared in double (cpu_nms.pyx:18,66)
+    edge = np.array([[0, 0, 9, 0, 0.9], [0, 0, 6, 0, 0.8],      # IoU = 7/10 -> 0.7f < 0.7  => kept at 0.7
+                     [100, 0, 109, 0, 0.7], [100, 0, 104, 0, 0.6],  # IoU = 0.5 exactly      => suppressed at 0.5
+                     [200, 0, 209, 0, 0.5], [200, 0, 202, 0, 0.4]],  # IoU = 3/10 -> 0.3f > 0.3 => suppressed at 0.3
+                    dtype=np.float32)
+    nms["edge_dets"] = edge
+    for thr in (0.7, 0.5, 0.3):
+        nms["edge_keep_%02d" % int(thr * 10)] = np.asarray(ns.cpu_nms(edge, thr), dtype=np.int64)
+    nms["empty_keep"] = np.asarray(ns.cpu_nms(np.zeros((0, 5), np.float32), 0.7), dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "cpu_nms.npz"), **nms)
+    print("cpu_nms survivors", {k: len(v) for k, v in nms.items() if k.endswith("keep") or "_keep_" in k})
+    # ---- bbox_overlaps (bbox.pyx:16-56)
+    rs = np.random.RandomState(8)
+    b = np.sort(rs.uniform(0, 600, (500, 2, 2)), axis=1).transpose(0, 2, 1).reshape(500, 4)
+    b = np.stack([b[:, 0], b[:, 2], b[:, 1], b[:, 3]], 1)
+    q = b[rs.choice(500, 7, replace=False)] + rs.randint(-5, 5, (7, 4))
+    np.savez_compressed(os.path.join(OUT, "bbox_overlaps.npz"), boxes=b, query=q, overlaps=ns.bbox_overlaps(b, q))
+    # ---- bbox transforms (bbox_transform.py)
+    rs = np.random.RandomState(9)
+    xy = rs.uniform(0, 400, (200, 2))
+    boxes = np.hstack([xy, xy + rs.uniform(30, 400, (200, 2))]).astype(np.float32)
+    trans = (rs.randn(200, 84) * 0.3).astype(np.float32)
+    inv = ns.bbox_transform_inv(boxes, trans)
+    clipped = ns.clip_boxes(inv.copy(), np.array([600, 1000], np.int32))
+    gtb = (boxes + rs.randint(-10, 10, boxes.shape)).astype(np.float64)
+    np.savez_compressed(os.path.join(OUT, "bbox_transform.npz"), boxes=boxes, trans=trans, inv=inv, clipped=clipped,
+                        filt=ns.filter_boxes(clipped[:, :4], 16), gt=gtb,
+                        fwd=ns.bbox_transform(boxes.astype(np.float64), gtb))
+    # ---- AnchorTargetLayer (anchor_target_layer.py:66-198)
+    atl = ns.AnchorTargetLayer(16, [0.5, 1, 2], [8, 16, 32])
+    gt = np.array([[[10, 10, 60, 200, 0], [50, 100, 210, 210, 1], [160, 40, 200, 70, 2]]], dtype=np.float32)  # tests/test_anchor_target_layer.py:23-27
+    info = np.array([[224, 224]], dtype=np.int32)
+    np.random.seed(21)
+    l, t, ii, n_all = atl(14, 14, ns.Variable(gt), ns.Variable(info))
+    at = dict(a_gt=gt, a_info=info, a_seed=np.array(21), a_labels=l, a_targets=t, a_inds=ii, a_nall=np.array(n_all))
+    rs = np.random.RandomState(22)
+    G = 5
+    x1 = rs.uniform(0, 700, G); y1 = rs.uniform(0, 350, G)
+    gt2 = np.stack([x1, y1, x1 + rs.uniform(32, 300, G), y1 + rs.uniform(32, 240, G), rs.randint(1, 21, G)], 1)[None].astype(np.float32)
+    info2 = np.array([[600, 1000]], dtype=np.int32)
+    np.random.seed(23)
+    l, t, ii, n_all = atl(38, 63, ns.Variable(gt2), ns.Variable(info2))
+    at.update(b_gt=gt2, b_info=info2, b_seed=np.array(23), b_labels=l, b_targets=t, b_inds=ii, b_nall=np.array(n_all))
+    np.savez_compressed(os.path.join(OUT, "anchor_target.npz"), **at)
+    print("anchor target:", at["a_labels"].shape, (at["a_labels"] == 1).sum(), at["b_labels"].shape,
+          (at["b_labels"] == 1).sum(), (at["b_labels"] == 0).sum())
+
+
+if __name__ == "__main__":
+    main()
