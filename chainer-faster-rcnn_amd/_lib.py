@@ -1,0 +1,79 @@
+"""ctypes binding of the C ABI declared in include/frcnn_hip.h (libfrcnn_hip.so).
+
+The library is built in-tree by csrc/build.py (hipcc --offload-arch=gfx950).  There is no CPU
+fallback: if the shared object is missing, or no MI355X is visible, `load()` raises.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfrcnn_hip.so")
+
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+_D = ctypes.c_double
+_F = ctypes.c_float
+_S = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/frcnn_hip.h one to one
+SIGNATURES = {
+    "frcnn_abi_version": (_I, []),
+    "frcnn_device_count": (_I, []),
+    "frcnn_nms_workspace_bytes": (_S, [_I]),
+    "frcnn_nms": (_I, [_P, _I, _D, _I, _P, _P, _P, _S, _P]),
+    "frcnn_nms_batched_workspace_bytes": (_S, [_I, _I]),
+    "frcnn_nms_batched": (_I, [_P, _I, _I, _D, _I, _P, _P, _P, _S, _P]),
+    "frcnn_proposals_workspace_bytes": (_S, [_I, _I, _I, _I]),
+    "frcnn_proposals": (_I, [_P, _P, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _D, _P, _P, _P, _P, _P, _S, _P]),
+    "frcnn_roi_pool_workspace_bytes": (_S, [_I, _I, _I]),
+    "frcnn_chw_to_hwc": (_I, [_P, _I, _I, _I, _P, _P]),
+    "frcnn_roi_pool_fwd_hwc": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "frcnn_roi_pool_fwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _F, _P, _P, _P, _S, _P]),
+    "frcnn_roi_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "frcnn_pack_conv3x3_w": (_I, [_P, _I, _I, _P, _P]),
+    "frcnn_conv3x3_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "frcnn_conv3x3_f32_cfg": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "frcnn_maxpool2x2_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "frcnn_rpn_heads_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "frcnn_linear_workspace_bytes": (_S, [_I, _I, _I]),
+    "frcnn_linear_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _S, _P]),
+    "frcnn_head_decode": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+}
+
+
+class FrcnnError(RuntimeError):
+    pass
+
+
+def check(status, what):
+    if status != 0:
+        if status == -1:
+            raise ValueError("%s: invalid argument (FRCNN_ERR_INVALID)" % what)
+        raise FrcnnError("%s failed: hipError_t %d" % (what, -status - 1000))
+
+
+def bind(path):
+    """dlopen `path` and attach the prototypes of every entry point the header declares."""
+    if not os.path.exists(path):
+        raise FrcnnError("HIP library not built: %s (run `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def load():
+    """The product library.  Raises when it is missing or when no GPU is visible -- never falls back."""
+    global _lib
+    if _lib is None:
+        lib = bind(LIB_PATH)
+        n = lib.frcnn_device_count()
+        if n <= 0:
+            raise FrcnnError("libfrcnn_hip.so loaded but no HIP device is visible (frcnn_device_count=%d)" % n)
+        _lib = lib
+    return _lib

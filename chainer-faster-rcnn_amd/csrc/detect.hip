@@ -1,0 +1,450 @@
+// detect.hip -- ProposalLayer + greedy IoU NMS for gfx950, results identical to the reference's CPU path.
+//
+// Replaces /root/reference/models/proposal_layer.py:102-198 (ProposalLayer.__call__), the helpers it
+// calls in models/bbox_transform.py (bbox_transform_inv :41-76, clip_boxes :79-99, filter_boxes :102-109)
+// and models/cpu_nms.pyx:18-69.  Not a translation of the dead models/nms_kernel.cu: that kernel compares
+// `>` in fp32, leaves the reduction to the host and is never called (proposal_layer.py:180-187).
+//
+// Device pipeline (one stream, no host round trip, caller-owned workspace):
+//   proposal_decode_kernel  anchor (h,w,a) -> decode -> clip -> min-size test; writes the box, the fg score
+//                           and a 64-bit sort key  (ordered score bits << 32) | ~index   (0 = filtered out)
+//   tile_sort_kernel        bitonic sort of 1024-key tiles in LDS (descending)
+//   rank_scatter_kernel     global rank of a key = its position in its own tile + the number of larger
+//                           keys in every other tile (branch-free binary searches, L2 resident);
+//                           ranks < min(n_valid, pre_nms_top_n) are gathered into score order
+//   nms_mask_kernel         upper-triangular 64x64 IoU tiles -> one uint64 suppression word per
+//                           (row box, column chunk); lane = row box, column boxes broadcast from LDS
+//   nms_scan_kernel         one workgroup walks the chunks in score order; the diagonal 64x64 block is
+//                           resolved with scalar bit operations on one wave, survivors' mask rows are OR-ed
+//                           into the `removed` bitmap by all waves; stops at post_nms_top_n and writes
+//                           the final RoIs / scores / indices
+// Ties between equal scores resolve to ascending index (canonical rule; NumPy's argsort()[::-1] leaves
+// tie order implementation-defined).  +NaN scores sort first, as NumPy's do after the reversal.
+//
+// Arithmetic parity: fp32 with the reference's operation order, no FMA contraction (this file is built
+// with -ffp-contract=off), IEEE division, exp evaluated in double and rounded to fp32, IoU threshold test
+// `(double)iou >= thresh` (cpu_nms.pyx:18,66).
+#include "frcnn_common.h"
+
+namespace {
+
+constexpr int kSortTile = 1024;   // keys per bitonic tile
+constexpr int kChunk = 64;        // NMS chunk = wave width
+
+__device__ __forceinline__ uint32_t ordered_bits(float f) {
+    uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // unsigned order == float order, +NaN on top
+}
+__device__ __forceinline__ unsigned long long make_key(float score, uint32_t index) {
+    return ((unsigned long long)ordered_bits(score) << 32) | (uint32_t)(~index);
+}
+__device__ __forceinline__ uint32_t key_index(unsigned long long k) { return ~(uint32_t)k; }
+
+// np.maximum(np.minimum(v, hi), 0) -- NumPy propagates NaN, fminf/fmaxf would swallow it
+__device__ __forceinline__ float clip_like_numpy(float v, float hi) { return (v != v) ? v : fmaxf(fminf(v, hi), 0.0f); }
+
+// Batched problems: every group owns one `slab` bytes of workspace with identical internal offsets.
+template <typename T>
+__device__ __forceinline__ T *slab_ptr(T *p, size_t slab) { return (T *)((char *)p + (size_t)blockIdx.z * slab); }
+template <typename T>
+__device__ __forceinline__ const T *slab_ptr(const T *p, size_t slab) { return (const T *)((const char *)p + (size_t)blockIdx.z * slab); }
+
+struct Anchors {           // generate_anchors output, passed by value in the kernel arguments
+    double a[32][4];
+};
+
+// ------------------------------------------------------------------------------------------------
+// proposal_layer.py:135-154 + bbox_transform.py:41-109, one thread per anchor.
+// Thread t -> (a = t / HW, p = t % HW) so the 4 delta reads and the score read are coalesced over p; the
+// anchor's position in the reference's enumeration is idx = p*A + a (proposal_layer.py:219-220).
+__global__ void __launch_bounds__(256)
+proposal_decode_kernel(const float *__restrict__ cls_prob, const float *__restrict__ bbox_pred, int A, int H, int W,
+                       Anchors anchors, int feat_stride, int im_h, int im_w, float min_size,
+                       float *__restrict__ boxes, float *__restrict__ scores, unsigned long long *__restrict__ keys,
+                       int n_pad, int *__restrict__ counters) {
+    const int HW = H * W;
+    const int n = A * HW;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int valid = 0;
+    if (t < n) {
+        const int a = t / HW, p = t - a * HW;
+        const int h = p / W, w = p - h * W;
+        const uint32_t idx = (uint32_t)(p * A + a);
+        // all_bbox = anchors + shifts in float64, then .astype(float32) (proposal_layer.py:200-221)
+        const double sx = (double)(w * feat_stride), sy = (double)(h * feat_stride);
+        const float bx1 = (float)(anchors.a[a][0] + sx), by1 = (float)(anchors.a[a][1] + sy);
+        const float bx2 = (float)(anchors.a[a][2] + sx), by2 = (float)(anchors.a[a][3] + sy);
+        // rpn_bbox_pred.transpose(1,2,0).reshape(-1,4): channel = a*4 + coord (proposal_layer.py:138)
+        const float dx = bbox_pred[(size_t)(a * 4 + 0) * HW + p], dy = bbox_pred[(size_t)(a * 4 + 1) * HW + p];
+        const float dw = bbox_pred[(size_t)(a * 4 + 2) * HW + p], dh = bbox_pred[(size_t)(a * 4 + 3) * HW + p];
+        // bbox_transform_inv (bbox_transform.py:51-74): separate multiplies and adds, no clamp on dw/dh
+        const float widths = bx2 - bx1 + 1.0f, heights = by2 - by1 + 1.0f;
+        const float ctr_x = bx1 + 0.5f * widths, ctr_y = by1 + 0.5f * heights;
+        const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+        const float pw = (float)exp((double)dw) * widths, ph = (float)exp((double)dh) * heights;
+        float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+        // clip_boxes (bbox_transform.py:88-98): maximum(minimum(v, int(dim-1)), 0)
+        const float mx = (float)(im_w - 1), my = (float)(im_h - 1);
+        x1 = clip_like_numpy(x1, mx); y1 = clip_like_numpy(y1, my);
+        x2 = clip_like_numpy(x2, mx); y2 = clip_like_numpy(y2, my);
+        // filter_boxes (bbox_transform.py:105-108); NaN compares false -> dropped
+        const float ws = x2 - x1 + 1.0f, hs = y2 - y1 + 1.0f;
+        valid = (ws >= min_size) && (hs >= min_size);
+        // fg score: rpn_cls_prob[A:].transpose(1,2,0) (proposal_layer.py:152-153)
+        const float sc = cls_prob[(size_t)(A + a) * HW + p];
+        reinterpret_cast<float4 *>(boxes)[idx] = make_float4(x1, y1, x2, y2);
+        scores[idx] = sc;
+        keys[idx] = valid ? make_key(sc, idx) : 0ull;
+    } else if (t < n_pad) {
+        keys[t] = 0ull;   // padding of the last sort tile
+    }
+    // n_valid: one atomic per wave
+    const unsigned long long bal = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counters[0], (int)__popcll(bal));
+}
+
+// keys for frcnn_nms(): every row of the (n,5) dets array takes part.
+__global__ void __launch_bounds__(256)
+dets_keys_kernel(const float *__restrict__ dets, int n, int n_pad, unsigned long long *__restrict__ keys,
+                 int *__restrict__ counters, size_t dets_gs, size_t slab) {
+    dets += blockIdx.z * dets_gs;
+    keys = slab_ptr(keys, slab);
+    counters = slab_ptr(counters, slab);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) keys[i] = make_key(dets[5 * (size_t)i + 4], (uint32_t)i);
+    else if (i < n_pad) keys[i] = 0ull;
+    if (i == 0) counters[0] = n;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bitonic sort (descending) of one 1024-key tile in LDS.
+__global__ void __launch_bounds__(256)
+tile_sort_kernel(unsigned long long *__restrict__ keys, size_t slab) {
+    __shared__ unsigned long long s[kSortTile];
+    keys = slab_ptr(keys, slab);
+    unsigned long long *g = keys + (size_t)blockIdx.x * kSortTile;
+    for (int t = threadIdx.x; t < kSortTile; t += 256) s[t] = g[t];
+    __syncthreads();
+    for (int k = 2; k <= kSortTile; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int q = threadIdx.x; q < kSortTile / 2; q += 256) {
+                const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
+                const int l = i | j;
+                const unsigned long long x = s[i], y = s[l];
+                const bool desc = (i & k) == 0;
+                if (desc ? (x < y) : (x > y)) { s[i] = y; s[l] = x; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int t = threadIdx.x; t < kSortTile; t += 256) g[t] = s[t];
+}
+
+// number of elements of the descending-sorted tile that are > key
+__device__ __forceinline__ int count_greater(const unsigned long long *__restrict__ tile, unsigned long long key) {
+    int pos = 0;
+#pragma unroll
+    for (int s = kSortTile / 2; s >= 1; s >>= 1)
+        if (tile[pos + s - 1] > key) pos += s;
+    if (tile[pos] > key) pos += 1;
+    return pos;
+}
+
+// Global rank by merging: rank = own position + sum over the other tiles of count_greater().
+// Writes order / sorted boxes / sorted scores for ranks below limit = min(n_valid, top_k).
+__global__ void __launch_bounds__(256)
+rank_scatter_kernel(const unsigned long long *__restrict__ keys, int n_tiles, const float *__restrict__ boxes_in, int box_stride,
+                    const float *__restrict__ scores_in, int score_stride, int top_k, const int *__restrict__ counters,
+                    int32_t *__restrict__ order, float *__restrict__ sorted_boxes, float *__restrict__ sorted_scores,
+                    size_t in_gs, size_t slab) {
+    boxes_in += blockIdx.z * in_gs; scores_in += blockIdx.z * in_gs;
+    keys = slab_ptr(keys, slab); counters = slab_ptr(counters, slab);
+    order = slab_ptr(order, slab); sorted_boxes = slab_ptr(sorted_boxes, slab); sorted_scores = slab_ptr(sorted_scores, slab);
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;       // position in the tile-sorted key array
+    if (t >= n_tiles * kSortTile) return;
+    const unsigned long long key = keys[t];
+    if (key == 0ull) return;
+    // keys are unique, so in the element's own tile count_greater() is just its position there
+    int rank = 0;
+    for (int o = 0; o < n_tiles; ++o) rank += count_greater(keys + (size_t)o * kSortTile, key);
+    int limit = counters[0];
+    if (top_k > 0 && top_k < limit) limit = top_k;
+    if (rank < limit) {
+        const uint32_t idx = key_index(key);
+        order[rank] = (int32_t)idx;
+        const float *b = boxes_in + (size_t)idx * box_stride;
+        reinterpret_cast<float4 *>(sorted_boxes)[rank] = make_float4(b[0], b[1], b[2], b[3]);
+        sorted_scores[rank] = scores_in[(size_t)idx * score_stride];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Suppression bitmask.  Block = 4 waves; wave w of block (bx,by) handles row chunk by against column
+// chunk 4*bx+w.  Lane = row box.  mask[row*pitch + colchunk] bit t  <=>  box (colchunk*64+t) comes later
+// in score order than `row` and IoU(row, it) >= thresh in the reference's arithmetic.
+__device__ __forceinline__ float ref_max(float a, float b) { return a >= b ? a : b; }   // cpu_nms.pyx:12-13
+__device__ __forceinline__ float ref_min(float a, float b) { return a <= b ? a : b; }   // cpu_nms.pyx:15-16
+
+__global__ void __launch_bounds__(256)
+nms_mask_kernel(const float *__restrict__ sorted_boxes, const int *__restrict__ counters, int top_k, double thresh,
+                unsigned long long *__restrict__ mask, int pitch, size_t slab) {
+    __shared__ float cbox[4][kChunk][5];
+    sorted_boxes = slab_ptr(sorted_boxes, slab); counters = slab_ptr(counters, slab); mask = slab_ptr(mask, slab);
+    int m = counters[0];
+    if (top_k > 0 && top_k < m) m = top_k;
+    const int n_chunks = (m + kChunk - 1) / kChunk;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rc = blockIdx.y, cc = blockIdx.x * 4 + wave;
+    const bool active = (rc < n_chunks) && (cc < n_chunks) && (cc >= rc);
+    if (active) {
+        const int c = cc * kChunk + lane;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < m) b = reinterpret_cast<const float4 *>(sorted_boxes)[c];
+        cbox[wave][lane][0] = b.x; cbox[wave][lane][1] = b.y; cbox[wave][lane][2] = b.z; cbox[wave][lane][3] = b.w;
+        cbox[wave][lane][4] = (b.z - b.x + 1.0f) * (b.w - b.y + 1.0f);     // areas, cpu_nms.pyx:25
+    }
+    __syncthreads();
+    if (!active) return;
+    const int r = rc * kChunk + lane;
+    if (r >= m) return;
+    const float4 rb = reinterpret_cast<const float4 *>(sorted_boxes)[r];
+    const float rarea = (rb.z - rb.x + 1.0f) * (rb.w - rb.y + 1.0f);
+    const float thr_f = (float)thresh;
+    const bool fast_ok = (thresh > 1e-6) && (rarea > 0.0f);
+    unsigned long long bits = 0ull;
+    const int t_end = min(kChunk, m - cc * kChunk);
+    const int t_begin = (cc == rc) ? lane + 1 : 0;        // only later boxes can be suppressed by `r`
+    for (int t = 0; t < t_end; ++t) {
+        const float cx1 = cbox[wave][t][0], cy1 = cbox[wave][t][1], cx2 = cbox[wave][t][2], cy2 = cbox[wave][t][3];
+        const float carea = cbox[wave][t][4];
+        const float xx1 = ref_max(rb.x, cx1), yy1 = ref_max(rb.y, cy1);          // cpu_nms.pyx:58-61
+        const float xx2 = ref_min(rb.z, cx2), yy2 = ref_min(rb.w, cy2);
+        const float w = ref_max(0.0f, xx2 - xx1 + 1.0f), h = ref_max(0.0f, yy2 - yy1 + 1.0f);   // :62-63
+        const float inter = w * h;                                               // :64
+        const float uni = rarea + carea - inter;                                 // :65
+        bool sup;
+        const float tt = thr_f * uni;
+        if (fast_ok && carea > 0.0f && inter >= tt * 1.0001f) sup = true;         // clear of the rounding band
+        else if (fast_ok && carea > 0.0f && inter <= tt * 0.9999f) sup = false;
+        else sup = (double)(inter / uni) >= thresh;                              // exact: IEEE divide, double compare (:65-66)
+        if (sup && t >= t_begin) bits |= 1ull << t;
+    }
+    mask[(size_t)r * pitch + cc] = bits;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sequential part of greedy NMS, one workgroup (256 threads).
+//   removed[c] (LDS)  bit t set <=> box c*64+t is suppressed by an already-kept box
+// Per chunk c: wave 0 resolves the diagonal block with scalar ops -- walk the still-alive bits in order,
+// keep the lowest, clear what its diagonal word suppresses -- then all waves OR the kept rows' words
+// for chunks > c into removed[].  Outputs are written at the end by the whole block.
+constexpr int kMaxChunks = 1024;   // up to 65536 boxes
+
+__global__ void __launch_bounds__(256)
+nms_scan_kernel(const unsigned long long *__restrict__ mask, int pitch, const int *__restrict__ counters_in, int top_k,
+                int max_out, const int32_t *__restrict__ order, const float *__restrict__ sorted_boxes,
+                const float *__restrict__ sorted_scores, int32_t *__restrict__ keep_pos, int32_t *__restrict__ out_index,
+                float *__restrict__ out_boxes, float *__restrict__ out_scores, int32_t *__restrict__ n_out,
+                int out_capacity, size_t slab, size_t out_gs) {
+    __shared__ unsigned long long removed[kMaxChunks];
+    __shared__ unsigned long long kept_word;
+    __shared__ int n_kept_s;
+    const int gz = blockIdx.z;
+    counters_in = slab_ptr(counters_in, slab); mask = slab_ptr(mask, slab); order = slab_ptr(order, slab);
+    sorted_boxes = slab_ptr(sorted_boxes, slab); sorted_scores = slab_ptr(sorted_scores, slab); keep_pos = slab_ptr(keep_pos, slab);
+    if (out_index) out_index += gz * out_gs;
+    if (out_boxes) out_boxes += gz * out_gs * 4;
+    if (out_scores) out_scores += gz * out_gs;
+    n_out += gz;
+    int m = counters_in[0];
+    if (top_k > 0 && top_k < m) m = top_k;
+    const int limit = (max_out > 0 && max_out < m) ? max_out : m;
+    const int n_chunks = (m + kChunk - 1) / kChunk;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int c = threadIdx.x; c < n_chunks; c += blockDim.x) removed[c] = 0ull;
+    if (threadIdx.x == 0) n_kept_s = 0;
+    __syncthreads();
+    int n_kept = 0;
+    for (int c = 0; c < n_chunks && n_kept < limit; ++c) {
+        if (wave == 0) {
+            const int r = c * kChunk + lane;
+            const unsigned long long diag = (r < m) ? mask[(size_t)r * pitch + c] : 0ull;
+            const int dlo = (int)(uint32_t)diag, dhi = (int)(uint32_t)(diag >> 32);
+            const int in_chunk = min(kChunk, m - c * kChunk);
+            const unsigned long long valid = in_chunk == 64 ? ~0ull : ((1ull << in_chunk) - 1ull);
+            unsigned long long alive = ~removed[c] & valid;
+            unsigned long long kept = 0ull;
+            int budget = limit - n_kept;
+            // alive is wave-uniform (every lane reads the same LDS word); make that explicit for readlane
+            uint32_t alo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)alive);
+            uint32_t ahi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(alive >> 32));
+            alive = ((unsigned long long)ahi << 32) | alo;
+            while (alive != 0ull && budget > 0) {
+                const int i = __ffsll((long long)alive) - 1;
+                kept |= 1ull << i;
+                --budget;
+                const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane(dlo, i);
+                const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane(dhi, i);
+                alive &= ~(((unsigned long long)shi << 32) | slo);
+                alive &= ~(1ull << i);
+            }
+            if ((kept >> lane) & 1ull) keep_pos[n_kept + __popcll(kept & ((1ull << lane) - 1ull))] = r;
+            if (lane == 0) { kept_word = kept; n_kept_s = n_kept + __popcll(kept); }
+        }
+        __syncthreads();
+        const unsigned long long kept = kept_word;
+        n_kept = n_kept_s;
+        if (n_kept < limit && kept != 0ull) {
+            // OR the kept rows' words for the later chunks into removed[]: wave w takes every 4th kept row
+            unsigned long long kk = kept;
+            int ord = 0;
+            while (kk != 0ull) {
+                const int i = __ffsll((long long)kk) - 1;
+                kk &= kk - 1ull;
+                if ((ord & 3) == wave) {
+                    const unsigned long long *row = mask + (size_t)(c * kChunk + i) * pitch;
+                    for (int w = c + 1 + lane; w < n_chunks; w += 64) {
+                        const unsigned long long v = row[w];
+                        if (v) atomicOr(&removed[w], v);
+                    }
+                }
+                ++ord;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) n_out[0] = n_kept;
+    __syncthreads();   // keep_pos written by wave 0 through global memory: same workgroup, made visible by the barrier
+    for (int k = threadIdx.x; k < n_kept; k += blockDim.x) {
+        const int pos = keep_pos[k];
+        if (out_index) out_index[k] = order[pos];
+        if (out_boxes) reinterpret_cast<float4 *>(out_boxes)[k] = reinterpret_cast<const float4 *>(sorted_boxes)[pos];
+        if (out_scores) out_scores[k] = sorted_scores[pos];
+    }
+    // rows past the survivors are defined (zero box / zero score / index -1) so fixed-capacity consumers
+    // (RoI pooling over post_nms_top_n rows) never read stale memory
+    for (int k = n_kept + threadIdx.x; k < out_capacity; k += blockDim.x) {
+        if (out_index) out_index[k] = -1;
+        if (out_boxes) reinterpret_cast<float4 *>(out_boxes)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (out_scores) out_scores[k] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct Layout {   // carve-up of the caller's workspace (per group)
+    size_t counters, keys, boxes, scores, order, sboxes, sscores, keep_pos, mask, total;
+    int n_pad, n_tiles, m_max, pitch;
+};
+
+static Layout make_layout(int n_total, int top_k, bool own_boxes) {
+    Layout L;
+    L.n_tiles = frcnn_cdiv(n_total > 0 ? n_total : 1, kSortTile);
+    L.n_pad = L.n_tiles * kSortTile;
+    L.m_max = (top_k > 0 && top_k < n_total) ? top_k : n_total;
+    if (L.m_max < 1) L.m_max = 1;
+    L.pitch = frcnn_cdiv(L.m_max, kChunk);
+    size_t o = 0;
+    L.counters = o; o += 256;
+    L.keys = o; o += frcnn_align256((size_t)L.n_pad * 8);
+    L.boxes = o; o += own_boxes ? frcnn_align256((size_t)(n_total > 0 ? n_total : 1) * 16) : 0;
+    L.scores = o; o += own_boxes ? frcnn_align256((size_t)(n_total > 0 ? n_total : 1) * 4) : 0;
+    L.order = o; o += frcnn_align256((size_t)L.m_max * 4);
+    L.sboxes = o; o += frcnn_align256((size_t)L.m_max * 16);
+    L.sscores = o; o += frcnn_align256((size_t)L.m_max * 4);
+    L.keep_pos = o; o += frcnn_align256((size_t)L.m_max * 4);
+    L.mask = o; o += frcnn_align256((size_t)L.m_max * L.pitch * 8);
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t frcnn_nms_batched_workspace_bytes(int groups, int n) {
+    if (groups < 1 || n < 0) return 0;
+    return make_layout(n, 0, false).total * (size_t)groups;
+}
+size_t frcnn_nms_workspace_bytes(int n) { return frcnn_nms_batched_workspace_bytes(1, n); }
+
+int frcnn_nms_batched(const float *dets, int groups, int n, double thresh, int max_out, int32_t *keep, int32_t *n_keep,
+                      void *workspace, size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (groups < 1 || n < 0 || !n_keep || (n > 0 && (!dets || !keep))) return FRCNN_ERR_INVALID;
+    if (n > kMaxChunks * kChunk) return FRCNN_ERR_INVALID;
+    if (n == 0) { FRCNN_HIP_TRY(hipMemsetAsync(n_keep, 0, sizeof(int32_t) * groups, stream)); return FRCNN_OK; }
+    const Layout L = make_layout(n, 0, false);
+    if (!workspace || workspace_bytes < L.total * (size_t)groups) return FRCNN_ERR_INVALID;
+    char *ws = (char *)workspace;
+    const size_t gs = L.total;   // bytes of workspace per group (a multiple of 256)
+    int *counters = (int *)(ws + L.counters);
+    unsigned long long *keys = (unsigned long long *)(ws + L.keys);
+    int32_t *order = (int32_t *)(ws + L.order);
+    float *sboxes = (float *)(ws + L.sboxes);
+    float *sscores = (float *)(ws + L.sscores);
+    int32_t *keep_pos = (int32_t *)(ws + L.keep_pos);
+    unsigned long long *mask = (unsigned long long *)(ws + L.mask);
+    const dim3 blk(256);
+    hipLaunchKernelGGL(dets_keys_kernel, dim3(frcnn_cdiv(L.n_pad, 256), 1, groups), blk, 0, stream, dets, n, L.n_pad, keys,
+                       counters, (size_t)n * 5, gs);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(L.n_tiles, 1, groups), blk, 0, stream, keys, gs);
+    hipLaunchKernelGGL(rank_scatter_kernel, dim3(frcnn_cdiv(L.n_pad, 256), 1, groups), blk, 0, stream, keys, L.n_tiles, dets, 5,
+                       dets + 4, 5, 0, counters, order, sboxes, sscores, (size_t)n * 5, gs);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(frcnn_cdiv(L.pitch, 4), L.pitch, groups), blk, 0, stream, sboxes, counters, 0, thresh,
+                       mask, L.pitch, gs);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1, 1, groups), blk, 0, stream, mask, L.pitch, counters, 0, max_out, order, sboxes,
+                       sscores, keep_pos, keep, (float *)nullptr, (float *)nullptr, n_keep,
+                       (max_out > 0 && max_out < n) ? max_out : n, gs, (size_t)n);
+    return frcnn_launch_status();
+}
+
+int frcnn_nms(const float *dets, int n, double thresh, int max_out, int32_t *keep, int32_t *n_keep, void *workspace,
+              size_t workspace_bytes, void *stream) {
+    return frcnn_nms_batched(dets, 1, n, thresh, max_out, keep, n_keep, workspace, workspace_bytes, stream);
+}
+
+size_t frcnn_proposals_workspace_bytes(int A, int H, int W, int pre_nms_top_n) {
+    if (A < 1 || H < 1 || W < 1) return 0;
+    return make_layout(A * H * W, pre_nms_top_n, true).total;
+}
+
+int frcnn_proposals(const float *rpn_cls_prob, const float *rpn_bbox_pred, int A, int H, int W, const double *anchors_host,
+                    int feat_stride, int im_h, int im_w, float min_size, int pre_nms_top_n, int post_nms_top_n, double nms_thresh,
+                    float *rois, float *probs, int32_t *n_out, int32_t *src_index, void *workspace, size_t workspace_bytes,
+                    void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!rpn_cls_prob || !rpn_bbox_pred || !anchors_host || !rois || !probs || !n_out) return FRCNN_ERR_INVALID;
+    if (A < 1 || A > 32 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    const int n = A * H * W;
+    const Layout L = make_layout(n, pre_nms_top_n, true);
+    if (L.m_max > kMaxChunks * kChunk) return FRCNN_ERR_INVALID;
+    if (!workspace || workspace_bytes < L.total) return FRCNN_ERR_INVALID;
+    char *ws = (char *)workspace;
+    int *counters = (int *)(ws + L.counters);
+    unsigned long long *keys = (unsigned long long *)(ws + L.keys);
+    float *boxes = (float *)(ws + L.boxes);
+    float *scores = (float *)(ws + L.scores);
+    int32_t *order = (int32_t *)(ws + L.order);
+    float *sboxes = (float *)(ws + L.sboxes);
+    float *sscores = (float *)(ws + L.sscores);
+    int32_t *keep_pos = (int32_t *)(ws + L.keep_pos);
+    unsigned long long *mask = (unsigned long long *)(ws + L.mask);
+    Anchors anc;
+    for (int a = 0; a < A; ++a)
+        for (int c = 0; c < 4; ++c) anc.a[a][c] = anchors_host[a * 4 + c];
+    FRCNN_HIP_TRY(hipMemsetAsync(counters, 0, 256, stream));
+    const dim3 blk(256);
+    hipLaunchKernelGGL(proposal_decode_kernel, dim3(frcnn_cdiv(L.n_pad, 256)), blk, 0, stream, rpn_cls_prob, rpn_bbox_pred, A, H, W,
+                       anc, feat_stride, im_h, im_w, min_size, boxes, scores, keys, L.n_pad, counters);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(L.n_tiles), blk, 0, stream, keys, (size_t)0);
+    hipLaunchKernelGGL(rank_scatter_kernel, dim3(frcnn_cdiv(L.n_pad, 256)), blk, 0, stream, keys, L.n_tiles, boxes, 4, scores, 1,
+                       pre_nms_top_n, counters, order, sboxes, sscores, (size_t)0, (size_t)0);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(frcnn_cdiv(L.pitch, 4), L.pitch), blk, 0, stream, sboxes, counters, pre_nms_top_n,
+                       nms_thresh, mask, L.pitch, (size_t)0);
+    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), blk, 0, stream, mask, L.pitch, counters, pre_nms_top_n, post_nms_top_n, order,
+                       sboxes, sscores, keep_pos, src_index, rois, probs, n_out,
+                       (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
+    return frcnn_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,237 @@
+"""Runtime = the C-ABI library + a device-memory provider + the thin typed wrappers over each entry point.
+
+PyTorch-ROCm is used for device memory and streams only (torch.empty on cuda, data_ptr, current stream);
+all arithmetic happens inside libfrcnn_hip.so.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+_NP = {"f32": np.float32, "i32": np.int32, "u8": np.uint8, "f64": np.float64, "i64": np.int64}
+
+
+class TorchDeviceMemory(object):
+    """Device arrays are torch tensors on an MI355X; the stream is torch's current HIP stream."""
+
+    def __init__(self, device="cuda:0"):
+        import torch
+        if not torch.cuda.is_available():
+            raise _lib.FrcnnError("no HIP device visible to PyTorch: the MI355X path cannot run (no CPU fallback)")
+        self.torch = torch
+        self.device = torch.device(device)
+        self._dt = {"f32": torch.float32, "i32": torch.int32, "u8": torch.uint8, "f64": torch.float64,
+                    "i64": torch.int64}
+
+    def empty(self, shape, dtype="f32"):
+        return self.torch.empty(shape, dtype=self._dt[dtype], device=self.device)
+
+    def zeros(self, shape, dtype="f32"):
+        return self.torch.zeros(shape, dtype=self._dt[dtype], device=self.device)
+
+    def from_numpy(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
+    def to_numpy(self, t):
+        return t.detach().cpu().numpy()
+
+    def is_array(self, a):
+        return isinstance(a, self.torch.Tensor) and a.is_cuda
+
+    def ptr(self, t):
+        if t is None:
+            return None
+        if not (t.is_cuda and t.is_contiguous()):
+            raise ValueError("expected a contiguous device tensor")
+        return ctypes.c_void_p(t.data_ptr())
+
+    def stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def synchronize(self):
+        self.torch.cuda.current_stream(self.device).synchronize()
+
+    def dtype_of(self, t):
+        return {v: k for k, v in self._dt.items()}[t.dtype]
+
+
+class Runtime(object):
+    def __init__(self, lib, mem):
+        self.lib = lib
+        self.mem = mem
+        self._ws = {}
+
+    # ------------------------------------------------------------------ helpers
+    def workspace(self, tag, nbytes):
+        w = self._ws.get(tag)
+        if w is None or w.shape[0] < nbytes:
+            w = self.mem.empty((max(int(nbytes), 256),), "u8")
+            self._ws[tag] = w
+        return w
+
+    def asarray(self, a, dtype="f32"):
+        """Accept device arrays, NumPy arrays or anything with `.data` (chainer.Variable-like)."""
+        if hasattr(a, "data") and not isinstance(a, np.ndarray) and not self.mem.is_array(a):
+            a = a.data
+        if self.mem.is_array(a):
+            if self.mem.dtype_of(a) != dtype:
+                raise ValueError("expected dtype %s, got %s" % (dtype, self.mem.dtype_of(a)))
+            return a if a.is_contiguous() else a.contiguous()
+        a = np.asarray(a)
+        if a.dtype != _NP[dtype]:
+            raise ValueError("expected dtype %s, got %s" % (dtype, a.dtype))
+        return self.mem.from_numpy(a)
+
+    # ------------------------------------------------------------------ NMS
+    def nms(self, dets, thresh, max_out=0):
+        """-> (keep (cap,) i32 device, n_keep (1,) i32 device)"""
+        m, L = self.mem, self.lib
+        n = int(dets.shape[0])
+        cap = min(n, max_out) if max_out > 0 else n
+        keep = m.empty((max(cap, 1),), "i32")
+        n_keep = m.empty((1,), "i32")
+        wsb = L.frcnn_nms_workspace_bytes(n)
+        ws = self.workspace("nms", wsb)
+        _lib.check(L.frcnn_nms(m.ptr(dets) if n else None, n, float(thresh), int(max_out), m.ptr(keep), m.ptr(n_keep),
+                               m.ptr(ws), ws.shape[0], m.stream()), "frcnn_nms")
+        return keep, n_keep
+
+    def nms_batched(self, dets, thresh, max_out=0):
+        """dets (G,n,5) -> (keep (G,cap) i32, n_keep (G,) i32)"""
+        m, L = self.mem, self.lib
+        G, n = int(dets.shape[0]), int(dets.shape[1])
+        cap = min(n, max_out) if max_out > 0 else n
+        keep = m.empty((G, max(cap, 1)), "i32")
+        n_keep = m.empty((G,), "i32")
+        ws = self.workspace("nmsb", L.frcnn_nms_batched_workspace_bytes(G, n))
+        _lib.check(L.frcnn_nms_batched(m.ptr(dets), G, n, float(thresh), int(max_out), m.ptr(keep), m.ptr(n_keep),
+                                       m.ptr(ws), ws.shape[0], m.stream()), "frcnn_nms_batched")
+        return keep, n_keep
+
+    # ------------------------------------------------------------------ proposals
+    def proposals(self, cls_prob, bbox_pred, anchors, feat_stride, im_h, im_w, min_size, pre_nms_top_n,
+                  post_nms_top_n, nms_thresh, want_index=False):
+        """cls_prob (2A,H,W), bbox_pred (4A,H,W) device f32; anchors (A,4) float64 host.
+        -> rois (cap,4), probs (cap,), n_out (1,) [, src_index (cap,)] device arrays."""
+        m, L = self.mem, self.lib
+        A = int(anchors.shape[0])
+        _, H, W = [int(v) for v in bbox_pred.shape]
+        n = A * H * W
+        m_max = min(n, pre_nms_top_n) if pre_nms_top_n > 0 else n
+        cap = min(post_nms_top_n, m_max) if post_nms_top_n > 0 else m_max
+        rois = m.empty((cap, 4), "f32")
+        probs = m.empty((cap,), "f32")
+        n_out = m.empty((1,), "i32")
+        src = m.empty((cap,), "i32") if want_index else None
+        ws = self.workspace("proposals", L.frcnn_proposals_workspace_bytes(A, H, W, int(pre_nms_top_n)))
+        anc = np.ascontiguousarray(anchors, dtype=np.float64)
+        _lib.check(L.frcnn_proposals(m.ptr(cls_prob), m.ptr(bbox_pred), A, H, W, anc.ctypes.data_as(ctypes.c_void_p),
+                                     int(feat_stride), int(im_h), int(im_w), float(min_size), int(pre_nms_top_n),
+                                     int(post_nms_top_n), float(nms_thresh), m.ptr(rois), m.ptr(probs), m.ptr(n_out),
+                                     m.ptr(src), m.ptr(ws), ws.shape[0], m.stream()), "frcnn_proposals")
+        return (rois, probs, n_out, src) if want_index else (rois, probs, n_out)
+
+    # ------------------------------------------------------------------ RoI pooling
+    def roi_pool_fwd(self, x, rois, outh, outw, scale, want_argmax=False):
+        m, L = self.mem, self.lib
+        C, H, W = [int(v) for v in x.shape[-3:]]
+        R = int(rois.shape[0])
+        y = m.empty((R, C, outh, outw), "f32")
+        am = m.empty((R, C, outh, outw), "i32") if want_argmax else None
+        ws = self.workspace("roi_pool", L.frcnn_roi_pool_workspace_bytes(C, H, W))
+        _lib.check(L.frcnn_roi_pool_fwd(m.ptr(x), C, H, W, m.ptr(rois), R, outh, outw, float(scale), m.ptr(y),
+                                        m.ptr(am), m.ptr(ws), ws.shape[0], m.stream()), "frcnn_roi_pool_fwd")
+        return (y, am) if want_argmax else y
+
+    def chw_to_hwc(self, x):
+        m, L = self.mem, self.lib
+        C, H, W = [int(v) for v in x.shape[-3:]]
+        xt = m.empty((H * W, C), "f32")
+        _lib.check(L.frcnn_chw_to_hwc(m.ptr(x), C, H, W, m.ptr(xt), m.stream()), "frcnn_chw_to_hwc")
+        return xt
+
+    def roi_pool_fwd_hwc(self, xt, C, H, W, rois, outh, outw, scale, want_argmax=False, out=None):
+        m, L = self.mem, self.lib
+        R = int(rois.shape[0])
+        y = out if out is not None else m.empty((R, C, outh, outw), "f32")
+        am = m.empty((R, C, outh, outw), "i32") if want_argmax else None
+        _lib.check(L.frcnn_roi_pool_fwd_hwc(m.ptr(xt), C, H, W, m.ptr(rois), R, outh, outw, float(scale), m.ptr(y),
+                                            m.ptr(am), m.stream()), "frcnn_roi_pool_fwd_hwc")
+        return (y, am) if want_argmax else y
+
+    def roi_pool_bwd(self, dy, argmax, C, H, W):
+        m, L = self.mem, self.lib
+        R, _, outh, outw = [int(v) for v in dy.shape]
+        dx = m.empty((1, C, H, W), "f32")
+        _lib.check(L.frcnn_roi_pool_bwd(m.ptr(dy), m.ptr(argmax), R, C, H, W, outh, outw, m.ptr(dx), m.stream()),
+                   "frcnn_roi_pool_bwd")
+        return dx
+
+    # ------------------------------------------------------------------ convolution stack
+    def pack_conv3x3_w(self, w):
+        m, L = self.mem, self.lib
+        co, ci = int(w.shape[0]), int(w.shape[1])
+        wp = m.empty((ci * 9, co), "f32")
+        _lib.check(L.frcnn_pack_conv3x3_w(m.ptr(w), co, ci, m.ptr(wp), m.stream()), "frcnn_pack_conv3x3_w")
+        return wp
+
+    def conv3x3(self, x, w_packed, bias, relu=True, out=None, cfg=-1):
+        m, L = self.mem, self.lib
+        ci, H, W = [int(v) for v in x.shape[-3:]]
+        co = int(w_packed.shape[1])
+        assert int(w_packed.shape[0]) == ci * 9
+        y = out if out is not None else m.empty((1, co, H, W), "f32")
+        _lib.check(L.frcnn_conv3x3_f32_cfg(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(y), ci, co, H, W,
+                                           int(bool(relu)), int(cfg), m.stream()), "frcnn_conv3x3_f32")
+        return y
+
+    def maxpool2x2(self, x, out=None):
+        m, L = self.mem, self.lib
+        C, H, W = [int(v) for v in x.shape[-3:]]
+        y = out if out is not None else m.empty((1, C, (H + 1) // 2, (W + 1) // 2), "f32")
+        _lib.check(L.frcnn_maxpool2x2_f32(m.ptr(x), m.ptr(y), C, H, W, m.stream()), "frcnn_maxpool2x2_f32")
+        return y
+
+    def rpn_heads(self, h, w_cls, b_cls, w_bbox, b_bbox, want_score=True):
+        m, L = self.mem, self.lib
+        C, H, W = [int(v) for v in h.shape[-3:]]
+        A = int(w_cls.shape[0]) // 2
+        score = m.empty((1, 2 * A, H, W), "f32") if want_score else None
+        prob = m.empty((1, 2 * A, H, W), "f32")
+        bbox = m.empty((1, 4 * A, H, W), "f32")
+        _lib.check(L.frcnn_rpn_heads_f32(m.ptr(h), C, H, W, A, m.ptr(w_cls), m.ptr(b_cls), m.ptr(w_bbox), m.ptr(b_bbox),
+                                         m.ptr(score), m.ptr(prob), m.ptr(bbox), m.stream()), "frcnn_rpn_heads_f32")
+        return score, prob, bbox
+
+    # ------------------------------------------------------------------ head
+    def linear(self, x, w, bias, relu=False):
+        m, L = self.mem, self.lib
+        M, K = int(x.shape[0]), int(np.prod(x.shape[1:]))
+        N = int(w.shape[0])
+        assert int(w.shape[1]) == K
+        y = m.empty((M, N), "f32")
+        ws = self.workspace("linear", L.frcnn_linear_workspace_bytes(M, N, K))
+        _lib.check(L.frcnn_linear_f32(m.ptr(x), m.ptr(w), m.ptr(bias), m.ptr(y), M, N, K, int(bool(relu)), m.ptr(ws),
+                                      ws.shape[0], m.stream()), "frcnn_linear_f32")
+        return y
+
+    def head_decode(self, boxes, deltas, cls_score, im_h, im_w):
+        m, L = self.mem, self.lib
+        R, ncls = int(cls_score.shape[0]), int(cls_score.shape[1])
+        pred = m.empty((R, 4 * ncls), "f32")
+        prob = m.empty((R, ncls), "f32")
+        _lib.check(L.frcnn_head_decode(m.ptr(boxes), m.ptr(deltas), m.ptr(cls_score), R, ncls, int(im_h), int(im_w),
+                                       m.ptr(pred), m.ptr(prob), m.stream()), "frcnn_head_decode")
+        return pred, prob
+
+
+_default = None
+
+
+def default_runtime():
+    """The MI355X runtime.  Raises (never falls back) if the HIP library or the GPU is missing."""
+    global _default
+    if _default is None:
+        _default = Runtime(_lib.load(), TorchDeviceMemory())
+    return _default

@@ -1,0 +1,138 @@
+/*
+ * frcnn_hip.h -- C ABI of libfrcnn_hip.so: the MI355X (gfx950) Faster R-CNN hot path.
+ *
+ * Drop-in boundary for mitmul/chainer-faster-rcnn's per-image forward (and RPN training step).
+ * The reference's only C FFI on this path is
+ *     void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num,
+ *               int boxes_dim, float nms_overlap_thresh, int device_id);      (models/gpu_nms.hpp:9-10)
+ * plus the Cython entry points cpu_nms(dets, thresh) (models/cpu_nms.pyx:18) and
+ * bbox_overlaps(boxes, query_boxes) (models/bbox.pyx:16); everything else on the path is a Python
+ * object boundary (ProposalLayer / AnchorTargetLayer / F.roi_pooling_2d / L.Convolution2D ...).
+ * Each entry point below names the reference interface it replaces.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", plain pointers and sizes; no torch / chainer types.
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *     never calls hipSetDevice, hipMalloc or hipFree, never synchronises unless documented;
+ *   - scratch memory is caller-owned: query the size with the matching *_workspace_bytes();
+ *   - returns 0 on success, FRCNN_ERR_INVALID (-1) for bad arguments, or -(1000 + hipError_t) when a
+ *     launch fails.  Errors are returned, never printed-and-swallowed (contrast nms_kernel.cu:12-19).
+ *   - tensors are C-contiguous, NCHW, batch 1 (the reference asserts batch==1: faster_rcnn.py:77).
+ */
+#ifndef FRCNN_HIP_H
+#define FRCNN_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FRCNN_OK 0
+#define FRCNN_ERR_INVALID (-1)
+
+/* Library identification: returns the ABI version (bumped on any signature change). */
+int frcnn_abi_version(void);
+/* Number of HIP devices visible to the library (hipGetDeviceCount), or -(1000+hipError_t). */
+int frcnn_device_count(void);
+
+/* ---- greedy IoU NMS ------------------------------------------------------------------------------
+ * Replaces cpu_nms(dets, thresh) (models/cpu_nms.pyx:18-69; live caller models/proposal_layer.py:176-178,
+ * second caller forward.py:54) and the dead gpu_nms/_nms (models/gpu_nms.hpp:9-10).
+ *   dets    (n,5) f32 rows [x1,y1,x2,y2,score], any order (re-sorted by score descending internally,
+ *           ties by ascending index, as cpu_nms.pyx:26 does with NumPy's argsort)
+ *   thresh  compared in DOUBLE against the float32 IoU with `>=` (cpu_nms.pyx:18,66)
+ *   max_out stop after this many survivors (<=0: all) -- the caller's keep[:post_nms_top_n]
+ *   keep    (cap) int32 out, cap = max_out>0 ? min(n,max_out) : n: indices into dets in descending-score
+ *           order; entries past n_keep are set to -1
+ *   n_keep  (1) int32 out
+ */
+size_t frcnn_nms_workspace_bytes(int n);
+int frcnn_nms(const float *dets, int n, double thresh, int max_out, int32_t *keep, int32_t *n_keep,
+              void *workspace, size_t workspace_bytes, void *stream);
+
+/* Batched NMS over `groups` independent problems laid out back to back ((groups, n, 5) dets,
+ * (groups, n) keep, (groups) n_keep): forward.py:48-58's 20 per-class cpu_nms(thresh 0.3) calls. */
+size_t frcnn_nms_batched_workspace_bytes(int groups, int n);
+int frcnn_nms_batched(const float *dets, int groups, int n, double thresh, int max_out, int32_t *keep,
+                      int32_t *n_keep, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ---- ProposalLayer ---------------------------------------------------------------------------------
+ * Replaces ProposalLayer.__call__ (models/proposal_layer.py:102-198): anchor enumeration (:200-221),
+ * bbox_transform_inv (bbox_transform.py:41-76), clip_boxes (:79-99), filter_boxes (:102-109), fg-score
+ * gather (proposal_layer.py:150-154), descending top-K sort (:156-170), cpu_nms (:176-178), top-N
+ * (:189-193) -- all on device, no host round trip.
+ *   rpn_cls_prob (2A,H,W) f32, fg scores in channels [A,2A); rpn_bbox_pred (4A,H,W) f32, channel a*4+c
+ *   anchors_host (A,4) float64 HOST pointer (generate_anchors output; copied by value into the launch)
+ *   im_h, im_w   img_info (H, W) exactly as the caller passes it (forward.py:93 passes (H,H))
+ *   rois (cap,4) f32 out; probs (cap) f32 out; n_out (1) int32 out; cap = post_nms_top_n if >0 else
+ *   min(A*H*W, pre_nms_top_n); rows past n_out are zero-filled so fixed-capacity consumers stay defined
+ *   src_index (cap) int32 out or NULL: index of each RoI in the (H*W*A) anchor enumeration (-1 past n_out)
+ */
+size_t frcnn_proposals_workspace_bytes(int A, int H, int W, int pre_nms_top_n);
+int frcnn_proposals(const float *rpn_cls_prob, const float *rpn_bbox_pred, int A, int H, int W,
+                    const double *anchors_host, int feat_stride, int im_h, int im_w, float min_size,
+                    int pre_nms_top_n, int post_nms_top_n, double nms_thresh, float *rois, float *probs,
+                    int32_t *n_out, int32_t *src_index, void *workspace, size_t workspace_bytes,
+                    void *stream);
+
+/* ---- RoIPooling2D ----------------------------------------------------------------------------------
+ * Replaces F.roi_pooling_2d(x, rois, outh, outw, spatial_scale) (call site models/faster_rcnn.py:125-126;
+ * Chainer v1 ROIPooling2D forward / backward).  x (C,H,W) f32 NCHW batch 1 (the batch index in rois is
+ * ignored: the reference asserts batch==1); rois (R,5) f32 [batch,x1,y1,x2,y2]; y (R,C,outh,outw) f32;
+ * argmax same shape int32 (flat h*W+w, -1 for an empty bin) or NULL (inference).  outh,outw <= 7.
+ *   frcnn_roi_pool_fwd      = frcnn_chw_to_hwc into `workspace` + frcnn_roi_pool_fwd_hwc
+ *   frcnn_roi_pool_fwd_hwc  takes the feature map channel-last, xt (H*W, C) -- the fused pipeline's path
+ */
+size_t frcnn_roi_pool_workspace_bytes(int C, int H, int W);
+int frcnn_chw_to_hwc(const float *x, int C, int H, int W, float *xt, void *stream);
+int frcnn_roi_pool_fwd_hwc(const float *xt, int C, int H, int W, const float *rois, int R, int outh, int outw,
+                           float spatial_scale, float *y, int32_t *argmax, void *stream);
+int frcnn_roi_pool_fwd(const float *x, int C, int H, int W, const float *rois, int R, int outh, int outw,
+                       float spatial_scale, float *y, int32_t *argmax, void *workspace,
+                       size_t workspace_bytes, void *stream);
+int frcnn_roi_pool_bwd(const float *dy, const int32_t *argmax, int R, int C, int H, int W, int outh,
+                       int outw, float *dx, void *stream);
+
+/* ---- convolution stack -----------------------------------------------------------------------------
+ * Replaces L.Convolution2D(ci,co,3,1,1)+F.ReLU (models/vgg16.py:39-68, region_proposal_network.py:53,117)
+ * and F.MaxPooling2D(2,2) (cover_all => ceil-mode) on the batch-1 NCHW path.
+ *   frcnn_pack_conv3x3_w: (Cout,Cin,3,3) Chainer layout -> packed [(ci*9+tap)][Cout] f32 (once, at load)
+ *   frcnn_conv3x3_f32:    y = act(conv3x3(x, pad 1, stride 1) + b); x (Cin,H,W), y (Cout,H,W);
+ *                         f32 operands, exact-f32 MFMA accumulation (v_mfma_f32_32x32x2_f32)
+ *   frcnn_maxpool2x2_f32: (C,H,W) -> (C,ceil(H/2),ceil(W/2))
+ */
+int frcnn_pack_conv3x3_w(const float *w, int Cout, int Cin, float *w_packed, void *stream);
+int frcnn_conv3x3_f32(const float *x, const float *w_packed, const float *bias, float *y, int Cin,
+                      int Cout, int H, int W, int relu, void *stream);
+/* same, with an explicit work-decomposition id (0..3; -1 = automatic): the tuning hook bench.py sweeps */
+int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bias, float *y, int Cin,
+                          int Cout, int H, int W, int relu, int cfg, void *stream);
+int frcnn_maxpool2x2_f32(const float *x, float *y, int C, int H, int W, void *stream);
+
+/* ---- RPN 1x1 heads + the reference's 18-way softmax ------------------------------------------------
+ * Replaces rpn_cls_score / F.softmax / rpn_bbox_pred (models/region_proposal_network.py:118-120).
+ * h (Cmid,H,W); w_cls (2A,Cmid), w_bbox (4A,Cmid) (Chainer (out,in,1,1) layout); softmax over ALL 2A
+ * channels (axis 1), as the reference does.  cls_score may be NULL when only probabilities are needed.
+ */
+int frcnn_rpn_heads_f32(const float *h, int Cmid, int H, int W, int A, const float *w_cls,
+                        const float *b_cls, const float *w_bbox, const float *b_bbox, float *cls_score,
+                        float *cls_prob, float *bbox_pred, void *stream);
+
+/* ---- fully connected head --------------------------------------------------------------------------
+ * Replaces L.Linear + F.relu (models/faster_rcnn.py:33-36,127-134): y(M,N) = act(x(M,K) @ W(N,K)^T + b).
+ */
+size_t frcnn_linear_workspace_bytes(int M, int N, int K);
+int frcnn_linear_f32(const float *x, const float *w, const float *bias, float *y, int M, int N, int K,
+                     int relu, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Replaces bbox_transform_inv + clip_boxes + F.softmax on the head outputs (faster_rcnn.py:175-178):
+ * boxes (R,4), deltas (R,4*ncls) -> pred_boxes (R,4*ncls); cls_score (R,ncls) -> cls_prob (R,ncls). */
+int frcnn_head_decode(const float *boxes, const float *deltas, const float *cls_score, int R, int ncls,
+                      int im_h, int im_w, float *pred_boxes, float *cls_prob, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FRCNN_HIP_H */

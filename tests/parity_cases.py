@@ -1,0 +1,208 @@
+"""Parity checks of the C-ABI entry points against the oracle, written once and run twice:
+  * tests/test_kernels_emulated.py  -- on the host-emulated kernels (CPU, -m "not gpu"): kernel LOGIC
+  * tests/test_gpu_parity.py        -- on libfrcnn_hip.so on a real MI355X (-m gpu): the parity tests proper
+Every function takes a Runtime (`rt`).  Tolerances are stated where they are used:
+  indices / survivors / argmax: bit-exact;  fp32 features: <= 1e-3 relative (north_star)."""
+import os
+
+import numpy as np
+
+from oracle import frcnn_oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def g(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def dev(rt, a):
+    return rt.mem.from_numpy(np.ascontiguousarray(a))
+
+
+def host(rt, a):
+    return rt.mem.to_numpy(a)
+
+
+# ------------------------------------------------------------------------------------------- NMS
+def check_nms_golden(rt, tags=("n6000_t07", "n300_t03", "n1_t07", "n65_t05")):
+    G = g("cpu_nms")
+    for tag in tags:
+        dets, thr, want = G[tag + "_dets"], float(G[tag + "_thresh"]), G[tag + "_keep"]
+        keep, n = rt.nms(dev(rt, dets), thr)
+        n = int(host(rt, n)[0])
+        assert n == len(want), (tag, n, len(want))
+        assert np.array_equal(host(rt, keep)[:n], want.astype(np.int32)), tag          # bit-exact survivors
+        # keep[:k] semantics of proposal_layer.py:189-190
+        keep2, n2 = rt.nms(dev(rt, dets), thr, max_out=10)
+        k = min(10, len(want))
+        assert int(host(rt, n2)[0]) == k and np.array_equal(host(rt, keep2)[:k], want[:k].astype(np.int32))
+
+
+def check_nms_edges(rt):
+    G = g("cpu_nms")
+    for thr in (0.7, 0.5, 0.3):      # `ovr >= thresh` compared in double (cpu_nms.pyx:18,66)
+        keep, n = rt.nms(dev(rt, G["edge_dets"]), thr)
+        n = int(host(rt, n)[0])
+        assert host(rt, keep)[:n].tolist() == G["edge_keep_%02d" % int(thr * 10)].tolist(), thr
+    keep, n = rt.nms(rt.mem.empty((0, 5), "f32"), 0.7)       # empty input
+    assert int(host(rt, n)[0]) == 0
+    # ties in score: canonical rule = ascending index among equals
+    d = np.array([[0, 0, 10, 10, 0.5], [100, 100, 110, 110, 0.5], [200, 200, 210, 210, 0.9],
+                  [1, 1, 11, 11, 0.5]], np.float32)
+    keep, n = rt.nms(dev(rt, d), 0.5)
+    assert host(rt, keep)[:int(host(rt, n)[0])].tolist() == [2, 0, 1]
+    # all boxes identical -> one survivor; thresh 0 -> `0 >= 0` suppresses even disjoint boxes
+    same = np.tile(np.array([[5, 5, 50, 50, 0.0]], np.float32), (130, 1))
+    same[:, 4] = np.linspace(1, 0, 130)
+    keep, n = rt.nms(dev(rt, same), 0.7)
+    assert int(host(rt, n)[0]) == 1 and int(host(rt, keep)[0]) == 0
+    assert O.cpu_nms(d, 0.0) == host(rt, rt.nms(dev(rt, d), 0.0)[0])[:1].tolist() == [2]
+
+
+def check_nms_random(rt, n=700, seeds=(0, 1), thrs=(0.3, 0.5, 0.7)):
+    for seed in seeds:
+        rs = np.random.RandomState(seed)
+        x1 = rs.uniform(0, 300, n); y1 = rs.uniform(0, 300, n)
+        d = np.stack([x1, y1, x1 + rs.uniform(1, 200, n), y1 + rs.uniform(1, 200, n),
+                      rs.permutation(n) / float(n)], 1).astype(np.float32)
+        for thr in thrs:
+            want = O.cpu_nms(d, thr)
+            keep, nk = rt.nms(dev(rt, d), thr)
+            nk = int(host(rt, nk)[0])
+            assert host(rt, keep)[:nk].tolist() == want, (seed, thr)
+
+
+def check_nms_batched(rt, groups=5, n=300):
+    """forward.py:48-58: per-class cpu_nms(thresh=0.3) on (300,5) -- all classes in one call."""
+    rs = np.random.RandomState(5)
+    x1 = rs.uniform(0, 500, (groups, n)); y1 = rs.uniform(0, 400, (groups, n))
+    d = np.stack([x1, y1, x1 + rs.uniform(10, 300, (groups, n)), y1 + rs.uniform(10, 200, (groups, n)),
+                  rs.rand(groups, n)], 2).astype(np.float32)
+    keep, nk = rt.nms_batched(dev(rt, d), 0.3)
+    keep, nk = host(rt, keep), host(rt, nk)
+    for k in range(groups):
+        want = O.cpu_nms(d[k], 0.3)
+        assert nk[k] == len(want) and keep[k, :nk[k]].tolist() == want and (keep[k, nk[k]:] == -1).all()
+
+
+# ------------------------------------------------------------------------------------------- proposals
+def check_proposals_golden(rt, case):
+    G = g(case)
+    anchors = O.generate_anchors()
+    pre, post = int(G["pre"]), int(G["post"])
+    im_h, im_w = [int(v) for v in G["img_info"][0]]
+    rois, probs, n_out, src = rt.proposals(dev(rt, G["rpn_cls_prob"][0]), dev(rt, G["rpn_bbox_pred"][0]), anchors, 16,
+                                           im_h, im_w, 16.0, pre, post, 0.7, want_index=True)
+    n = int(host(rt, n_out)[0])
+    want_p, want_s = G["proposals"], G["probs"].ravel()
+    want_src = G["keep0"][G["order"]][G["nms_keep"][:len(want_p)]]
+    assert n == len(want_p), (case, n, len(want_p))
+    got_src = host(rt, src)[:n]
+    assert np.array_equal(got_src, want_src.astype(np.int32)), case                 # bit-exact proposal indices
+    assert np.array_equal(host(rt, probs)[:n], want_s), case                         # scores are copied, exact
+    # coordinates: exp() is evaluated in double then rounded (NumPy's SIMD fp32 exp is ~1-2 ulp) -> 4 ulp slack
+    got = host(rt, rois)[:n]
+    assert np.allclose(got, want_p, rtol=5e-7, atol=1e-4), (case, np.abs(got - want_p).max())
+    assert (host(rt, rois)[n:] == 0).all() and (host(rt, src)[n:] == -1).all()
+    return n
+
+
+# ------------------------------------------------------------------------------------------- RoI pooling
+def roi_case(rs, R, C=512, H=38, W=63):
+    x = np.abs(rs.randn(1, C, H, W)).astype(np.float32)
+    rois = np.zeros((R, 5), np.float32)
+    x1 = rs.uniform(0, (W - 2) * 16, R); y1 = rs.uniform(0, (H - 2) * 16, R)
+    rois[:, 1], rois[:, 2] = x1, y1
+    rois[:, 3] = np.minimum(x1 + rs.uniform(0, 500, R), W * 16 - 9)
+    rois[:, 4] = np.minimum(y1 + rs.uniform(0, 400, R), H * 16 - 9)
+    k = max(R // 5, 1)
+    rois[:k, 1:] = np.round(rois[:k, 1:] / 8) * 8      # exact .5 after *1/16: round-half-even cases
+    if R > 3:
+        rois[k] = [0, (W - 1) * 16, (H - 1) * 16, W * 16 - 9, H * 16 - 9]   # tiny
+        rois[k + 1] = [0, W * 16 + 200, H * 16 + 100, W * 16 + 300, H * 16 + 200]   # outside: empty bins
+        rois[k + 2] = [0, 0, 0, W * 16 - 9, H * 16 - 9]                      # whole map
+    return x, rois
+
+
+def check_roi_pool(rt, R=12, C=128, H=38, W=63, seed=0):
+    rs = np.random.RandomState(seed)
+    x, rois = roi_case(rs, R, C, H, W)
+    want_y, want_am = O.roi_pooling_2d(x, rois, 7, 7, 0.0625, return_argmax=True)
+    y, am = rt.roi_pool_fwd(dev(rt, x[0]), dev(rt, rois), 7, 7, 0.0625, want_argmax=True)
+    assert np.array_equal(host(rt, am), want_am)            # bit-exact argmax
+    assert np.array_equal(host(rt, y), want_y)              # max of fp32 values: exact (tolerance 1e-3 unused)
+    y2 = rt.roi_pool_fwd(dev(rt, x[0]), dev(rt, rois), 7, 7, 0.0625)          # inference path (no argmax)
+    assert np.array_equal(host(rt, y2), want_y)
+    dy = rs.randn(*want_y.shape).astype(np.float32)
+    dx = rt.roi_pool_bwd(dev(rt, dy), am, C, H, W)
+    want_dx = O.roi_pooling_2d_backward(dy, want_am, rois, x.shape)
+    assert np.allclose(host(rt, dx), want_dx, rtol=1e-4, atol=1e-4)    # atomics: summation order differs
+
+
+# ------------------------------------------------------------------------------------------- conv stack
+def check_conv3x3(rt, Cin, Cout, H, W, cfg=-1, seed=0, relu=True):
+    rs = np.random.RandomState(seed)
+    x = rs.randn(1, Cin, H, W).astype(np.float32)
+    w = (rs.randn(Cout, Cin, 3, 3) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32) * 0.1
+    want = O.conv2d(x, w, b, 1)
+    if relu:
+        want = O.relu(want)
+    wp = rt.pack_conv3x3_w(dev(rt, w))
+    assert np.array_equal(host(rt, wp), w.reshape(Cout, Cin * 9).T)
+    y = rt.conv3x3(dev(rt, x), wp, dev(rt, b), relu=relu, cfg=cfg)
+    got = host(rt, y)
+    err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-6)
+    assert got.shape == want.shape and err < 1e-4, (Cin, Cout, H, W, cfg, err)     # well inside the 1e-3 budget
+    return err
+
+
+def check_maxpool(rt, C, H, W, seed=0):
+    rs = np.random.RandomState(seed)
+    x = rs.randn(1, C, H, W).astype(np.float32)
+    assert np.array_equal(host(rt, rt.maxpool2x2(dev(rt, x))), O.max_pool_2x2(x))
+
+
+def check_rpn_heads(rt, Cmid=128, H=9, W=13, A=9, seed=0):
+    rs = np.random.RandomState(seed)
+    h = np.abs(rs.randn(1, Cmid, H, W)).astype(np.float32)
+    p = {"RPN/rpn_cls_score/W": (rs.randn(2 * A, Cmid, 1, 1) * 0.05).astype(np.float32),
+         "RPN/rpn_cls_score/b": (rs.randn(2 * A) * 0.1).astype(np.float32),
+         "RPN/rpn_bbox_pred/W": (rs.randn(4 * A, Cmid, 1, 1) * 0.05).astype(np.float32),
+         "RPN/rpn_bbox_pred/b": (rs.randn(4 * A) * 0.1).astype(np.float32)}
+    score = O.conv2d(h, p["RPN/rpn_cls_score/W"], p["RPN/rpn_cls_score/b"], 0)
+    prob = O.softmax(score, axis=1)        # 18-way, region_proposal_network.py:119
+    bbox = O.conv2d(h, p["RPN/rpn_bbox_pred/W"], p["RPN/rpn_bbox_pred/b"], 0)
+    s, pr, bb = rt.rpn_heads(dev(rt, h), dev(rt, p["RPN/rpn_cls_score/W"].reshape(2 * A, Cmid)), dev(rt, p["RPN/rpn_cls_score/b"]),
+                             dev(rt, p["RPN/rpn_bbox_pred/W"].reshape(4 * A, Cmid)), dev(rt, p["RPN/rpn_bbox_pred/b"]))
+    assert np.allclose(host(rt, s), score, rtol=1e-4, atol=1e-5)
+    assert np.allclose(host(rt, pr), prob, rtol=1e-4, atol=1e-6)
+    assert np.allclose(host(rt, bb), bbox, rtol=1e-4, atol=1e-5)
+    assert np.allclose(host(rt, pr).sum(axis=1), 1.0, atol=1e-5)
+
+
+def check_linear(rt, M, N, K, relu, seed=0):
+    rs = np.random.RandomState(seed)
+    x = rs.randn(M, K).astype(np.float32)
+    w = (rs.randn(N, K) / np.sqrt(K)).astype(np.float32)
+    b = rs.randn(N).astype(np.float32) * 0.1
+    want = O.linear(x, w, b)
+    if relu:
+        want = O.relu(want)
+    got = host(rt, rt.linear(dev(rt, x), dev(rt, w), dev(rt, b), relu=relu))
+    err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-6)
+    assert got.shape == want.shape and err < 1e-4, (M, N, K, err)
+
+
+def check_head_decode(rt, R=37, ncls=21, seed=0):
+    rs = np.random.RandomState(seed)
+    xy = rs.uniform(0, 500, (R, 2))
+    boxes = np.hstack([xy, xy + rs.uniform(16, 400, (R, 2))]).astype(np.float32)
+    deltas = (rs.randn(R, 4 * ncls) * 0.3).astype(np.float32)
+    score = rs.randn(R, ncls).astype(np.float32) * 3
+    want_boxes = O.clip_boxes(O.bbox_transform_inv(boxes, deltas), np.array([600, 1000]))
+    want_prob = O.softmax(score, axis=1)
+    pb, pp = rt.head_decode(dev(rt, boxes), dev(rt, deltas), dev(rt, score), 600, 1000)
+    assert np.allclose(host(rt, pb), want_boxes, rtol=5e-7, atol=1e-4)
+    assert np.allclose(host(rt, pp), want_prob, rtol=1e-5, atol=1e-7)

@@ -1,0 +1,78 @@
+"""Kernel LOGIC tests on the host emulator (tests/hipemu): the unmodified .hip sources compiled for the CPU,
+checked against the oracle.  These are CPU tests of indexing / wave collectives / MFMA fragment layouts /
+barriers; the parity tests proper run the same checks on the real library under -m gpu."""
+import sys
+import os
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+import parity_cases as P  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def rt():
+    from emu_runtime import emu_runtime
+    return emu_runtime()
+
+
+def test_emu_exports_every_declared_symbol(rt):
+    import re
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "frcnn_hip.h")).read()
+    names = set(re.findall(r"\b(frcnn_[a-z0-9_]+)\s*\(", hdr))
+    for n in names:
+        assert hasattr(rt.lib, n), n
+
+
+def test_nms_golden_small(rt):
+    P.check_nms_golden(rt, tags=("n300_t03", "n1_t07", "n65_t05"))
+
+
+def test_nms_edges(rt):
+    P.check_nms_edges(rt)
+
+
+def test_nms_random(rt):
+    P.check_nms_random(rt, n=700, seeds=(0,), thrs=(0.3, 0.7))
+
+
+def test_nms_batched(rt):
+    P.check_nms_batched(rt, groups=3, n=150)
+
+
+def test_proposals_14x14(rt):
+    P.check_proposals_golden(rt, "proposal_14x14_train_rand")
+
+
+def test_roi_pool(rt):
+    P.check_roi_pool(rt, R=9, C=128, H=12, W=17)
+    P.check_roi_pool(rt, R=5, C=64, H=38, W=63, seed=1)     # VEC=1 path (C % 128 != 0)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+def test_conv3x3_cfg(rt, cfg):
+    P.check_conv3x3(rt, 8, 128 if cfg == 1 else 64, 7, 37, cfg=cfg)
+
+
+def test_conv3x3_cin3_and_norelu(rt):
+    P.check_conv3x3(rt, 3, 64, 9, 33, cfg=0)               # conv1_1: K = 27, padded to a 4-channel chunk
+    P.check_conv3x3(rt, 5, 64, 5, 70, cfg=3, relu=False)   # odd Cin, width > 2 tiles
+
+
+def test_maxpool(rt):
+    P.check_maxpool(rt, 3, 7, 9)
+    P.check_maxpool(rt, 2, 8, 6)
+
+
+def test_rpn_heads(rt):
+    P.check_rpn_heads(rt, Cmid=128, H=5, W=15)
+
+
+def test_linear(rt):
+    P.check_linear(rt, 70, 140, 256, True)
+    P.check_linear(rt, 9, 21, 64, False)
+    P.check_linear(rt, 130, 84, 128, False)
+
+
+def test_head_decode(rt):
+    P.check_head_decode(rt)
