@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""Benchmark of the Faster R-CNN hot path on MI355X (BASELINE.json metric: images/sec, VGG16, 600x1000).
+
+  python bench.py --gpus N --steps K --warmup W
+N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
+
+A "step" = one full inference forward of one synthetic 600x1000 image per GPU (trunk -> RPN -> proposals ->
+NMS -> RoI pooling -> FC head -> decode), inputs and weights resident in HBM before the timed region.
+Workload = BASELINE.json configs[1]: "VGG16 inference, 1xMI355X, batch 1, 300 proposals post-NMS, fp32".
+Images shard one per GPU with no collective on the data path (weak scaling).
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel family (the fp32 MFMA conv3x3: 14
+launches per image) -- algorithmic FLOPs / HIP-event time measured inside the timed region on the launch
+stream -- against the dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).  `cpu_baseline` times the
+CPU oracle (oracle/frcnn_oracle.py: torch-CPU convs + the reference's proposal/NMS/RoI arithmetic) on this
+box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak BW (spec)
+IM_H, IM_W = 600, 1000
+
+
+class EventTimer(object):
+    """Records a HIP event (torch.cuda.Event on the current stream = the stream our kernels launch on) at
+    every stage boundary; durations are read after the timed region."""
+
+    def __init__(self, torch):
+        self.torch = torch
+        self.steps = []
+        self.cur = None
+
+    def begin(self):
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.cur = [("_start", e)]
+
+    def mark(self, name):
+        e = self.torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.cur.append((name, e))
+
+    def end(self):
+        self.steps.append(self.cur)
+        self.cur = None
+
+    def averages_ms(self):
+        acc = {}
+        for st in self.steps:
+            for (n0, e0), (n1, e1) in zip(st[:-1], st[1:]):
+                acc.setdefault(n1, []).append(e0.elapsed_time(e1))
+        return {k: float(np.mean(v)) for k, v in acc.items()}
+
+
+def conv_flops(model_layers, h, w):
+    """Algorithmic FLOPs (2*MAC) of every 3x3 conv at a h x w input; bias/ReLU/pool excluded."""
+    out = {}
+    for l in model_layers:
+        if l == "pool":
+            h, w = (h + 1) // 2, (w + 1) // 2
+        else:
+            name, ci, co = l
+            out[name] = 2.0 * h * w * co * ci * 9
+    out["rpn_conv_3x3"] = 2.0 * h * w * 512 * 512 * 9
+    return out, (h, w)
+
+
+def cpu_baseline(params, x, samples):
+    import torch
+    from oracle import frcnn_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    info = np.array([[IM_H, IM_W]], dtype=np.int32)
+    O.build_c()
+    O.faster_rcnn_forward(params, x, info)                      # warm-up (thread pools, page faults)
+    t0 = time.perf_counter()
+    for _ in range(samples):
+        O.faster_rcnn_forward(params, x, info)
+    dt = (time.perf_counter() - t0) / samples
+    return {"value": 1.0 / dt, "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d full 600x1000 forwards after 1 warm-up (oracle: torch-CPU fp32 convs/linears on all cores, "
+                      "single-threaded C restatement of the reference's proposal/NMS/RoI code)" % samples,
+            "ms_per_image": dt * 1e3}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cpu-samples", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-stage-events", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import chainer_faster_rcnn_amd as pkg
+    from chainer_faster_rcnn_amd import synthetic
+    from chainer_faster_rcnn_amd.models import FasterRCNN
+    from chainer_faster_rcnn_amd.models.vgg16 import LAYERS
+    rt = pkg.runtime.Runtime(pkg._lib.load(), pkg.runtime.TorchDeviceMemory("cuda:%d" % local_rank))
+    params = synthetic.params(seed=1)
+    model = FasterRCNN(runtime=rt)
+    model.load_params(params)
+    x_host = synthetic.image(seed=rank, h=IM_H, w=IM_W)          # every rank its own image (1 img / GPU)
+    x = rt.mem.from_numpy(x_host)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.forward_device(x, IM_H, IM_W)
+    timer = None if args.no_stage_events else EventTimer(torch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if timer:
+            timer.begin()
+        out = model.forward_device(x, IM_H, IM_W, timer=timer)
+        if timer:
+            timer.end()
+    barrier()
+    dt = time.perf_counter() - t0
+    n_rois = int(out["n_out"].cpu()[0])
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * args.steps / dt
+        res = {"metric": "images/sec VGG16 Faster R-CNN 600x1000", "value": value, "unit": "img/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "VGG16 inference, 1xMI355X per image, batch 1, 300 proposals post-NMS, fp32 "
+                                      "(BASELINE.json configs[1]); 1 image per GPU per step",
+                          "image": "1x3x600x1000", "global_batch": world, "parallelism": "dp%d (images sharded, no collective)" % world,
+                          "n_rois_last_step": n_rois}}
+        if timer:
+            avg = timer.averages_ms()
+            flops, (fh, fw) = conv_flops(LAYERS, IM_H, IM_W)
+            conv_ms = sum(avg[k] for k in flops)
+            conv_tf = sum(flops.values()) / (conv_ms * 1e-3) / 1e12
+            res["roofline"] = {"bound": "mfma", "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "kernel": "conv3x3_mfma_f32_kernel (14 launches/image: 13 VGG-16 convs + rpn_conv_3x3)",
+                               "algorithmic_gflop_per_image": sum(flops.values()) / 1e9, "conv_ms_per_image": conv_ms}
+            roi_bytes = (512 * fh * fw + 300 * 512 * 49) * 4 + 300 * 16
+            res["stages_ms"] = {k: round(v, 4) for k, v in avg.items()}
+            res["per_layer_tflops"] = {k: round(flops[k] / (avg[k] * 1e-3) / 1e12, 2) for k in flops}
+            res["nms_roi"] = {"proposals_nms_us": avg["proposals"] * 1e3, "roi_pool_us": avg["roi_pool"] * 1e3,
+                              "roi_pool_algorithmic_mb": roi_bytes / 1e6,
+                              "roi_pool_gbps": roi_bytes / (avg["roi_pool"] * 1e-3) / 1e9,
+                              "roi_pool_frac_of_hbm_peak": roi_bytes / (avg["roi_pool"] * 1e-3) / 1e9 / PEAK_HBM_GBPS}
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(params, x_host, args.cpu_samples)
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

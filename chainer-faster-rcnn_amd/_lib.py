@@ -27,7 +27,7 @@ SIGNATURES = {
     "frcnn_proposals": (_I, [_P, _P, _I, _I, _I, _P, _I, _I, _I, _F, _I, _I, _D, _P, _P, _P, _P, _P, _S, _P]),
     "frcnn_roi_pool_workspace_bytes": (_S, [_I, _I, _I]),
     "frcnn_chw_to_hwc": (_I, [_P, _I, _I, _I, _P, _P]),
-    "frcnn_roi_pool_fwd_hwc": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _F, _P, _P, _P]),
+    "frcnn_roi_pool_fwd_hwc": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "frcnn_roi_pool_fwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _F, _P, _P, _P, _S, _P]),
     "frcnn_roi_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "frcnn_pack_conv3x3_w": (_I, [_P, _I, _I, _P, _P]),
@@ -38,6 +38,9 @@ SIGNATURES = {
     "frcnn_linear_workspace_bytes": (_S, [_I, _I, _I]),
     "frcnn_linear_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_head_decode": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "frcnn_bbox_transform_inv": (_I, [_P, _P, _I, _I, _P, _P]),
+    "frcnn_clip_boxes": (_I, [_P, _I, _I, _I, _P]),
+    "frcnn_softmax_rows": (_I, [_P, _I, _I, _P, _P]),
 }
 
 

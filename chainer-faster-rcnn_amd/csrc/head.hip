@@ -9,7 +9,7 @@ namespace {
 __device__ __forceinline__ float clip_like_numpy(float v, float hi) { return (v != v) ? v : fmaxf(fminf(v, hi), 0.0f); }
 
 __global__ void __launch_bounds__(256)
-head_decode_kernel(const float *__restrict__ boxes, const float *__restrict__ deltas, int R, int ncls, int im_h, int im_w,
+head_decode_kernel(const float *__restrict__ boxes, const float *__restrict__ deltas, int R, int ncls, int clip, int im_h, int im_w,
                    float *__restrict__ pred) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R * ncls) return;
@@ -21,12 +21,24 @@ head_decode_kernel(const float *__restrict__ boxes, const float *__restrict__ de
     const float pcx = d.x * widths + ctr_x, pcy = d.y * heights + ctr_y;
     const float pw = (float)exp((double)d.z) * widths, ph = (float)exp((double)d.w) * heights;
     const float mx = (float)(im_w - 1), my = (float)(im_h - 1);
-    float4 o;
-    o.x = clip_like_numpy(pcx - 0.5f * pw, mx);
-    o.y = clip_like_numpy(pcy - 0.5f * ph, my);
-    o.z = clip_like_numpy(pcx + 0.5f * pw, mx);
-    o.w = clip_like_numpy(pcy + 0.5f * ph, my);
+    float4 o = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+    if (clip) {
+        o.x = clip_like_numpy(o.x, mx); o.y = clip_like_numpy(o.y, my);
+        o.z = clip_like_numpy(o.z, mx); o.w = clip_like_numpy(o.w, my);
+    }
     reinterpret_cast<float4 *>(pred)[i] = o;
+}
+
+// clip_boxes (bbox_transform.py:79-99) on n boxes of 4 floats, in place
+__global__ void __launch_bounds__(256)
+clip_boxes_kernel(float *__restrict__ boxes, int n, int im_h, int im_w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float mx = (float)(im_w - 1), my = (float)(im_h - 1);
+    float4 b = reinterpret_cast<float4 *>(boxes)[i];
+    b.x = clip_like_numpy(b.x, mx); b.y = clip_like_numpy(b.y, my);
+    b.z = clip_like_numpy(b.z, mx); b.w = clip_like_numpy(b.w, my);
+    reinterpret_cast<float4 *>(boxes)[i] = b;
 }
 
 __global__ void __launch_bounds__(256)
@@ -43,13 +55,39 @@ row_softmax_kernel(const float *__restrict__ s, int R, int n, float *__restrict_
 
 }  // namespace
 
-extern "C" int frcnn_head_decode(const float *boxes, const float *deltas, const float *cls_score, int R, int ncls, int im_h, int im_w,
-                                 float *pred_boxes, float *cls_prob, void *stream_) {
+extern "C" {
+
+int frcnn_bbox_transform_inv(const float *boxes, const float *deltas, int R, int ncls, float *pred_boxes, void *stream) {
+    if (!boxes || !deltas || !pred_boxes || R < 0 || ncls < 1) return FRCNN_ERR_INVALID;
+    if (R == 0) return FRCNN_OK;
+    hipLaunchKernelGGL(head_decode_kernel, dim3(frcnn_cdiv(R * ncls, 256)), dim3(256), 0, (hipStream_t)stream, boxes, deltas, R, ncls, 0,
+                       1, 1, pred_boxes);
+    return frcnn_launch_status();
+}
+
+int frcnn_clip_boxes(float *boxes, int n_boxes, int im_h, int im_w, void *stream) {
+    if (!boxes || n_boxes < 0) return FRCNN_ERR_INVALID;
+    if (n_boxes == 0) return FRCNN_OK;
+    hipLaunchKernelGGL(clip_boxes_kernel, dim3(frcnn_cdiv(n_boxes, 256)), dim3(256), 0, (hipStream_t)stream, boxes, n_boxes, im_h, im_w);
+    return frcnn_launch_status();
+}
+
+int frcnn_softmax_rows(const float *scores, int R, int n, float *probs, void *stream) {
+    if (!scores || !probs || R < 0 || n < 1) return FRCNN_ERR_INVALID;
+    if (R == 0) return FRCNN_OK;
+    hipLaunchKernelGGL(row_softmax_kernel, dim3(frcnn_cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, scores, R, n, probs);
+    return frcnn_launch_status();
+}
+
+int frcnn_head_decode(const float *boxes, const float *deltas, const float *cls_score, int R, int ncls, int im_h, int im_w,
+                      float *pred_boxes, float *cls_prob, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!boxes || !deltas || !cls_score || !pred_boxes || !cls_prob || R < 0 || ncls < 1) return FRCNN_ERR_INVALID;
     if (R == 0) return FRCNN_OK;
-    hipLaunchKernelGGL(head_decode_kernel, dim3(frcnn_cdiv(R * ncls, 256)), dim3(256), 0, stream, boxes, deltas, R, ncls, im_h, im_w,
+    hipLaunchKernelGGL(head_decode_kernel, dim3(frcnn_cdiv(R * ncls, 256)), dim3(256), 0, stream, boxes, deltas, R, ncls, 1, im_h, im_w,
                        pred_boxes);
     hipLaunchKernelGGL(row_softmax_kernel, dim3(frcnn_cdiv(R, 256)), dim3(256), 0, stream, cls_score, R, ncls, cls_prob);
     return frcnn_launch_status();
 }
+
+}  // extern "C"

@@ -60,15 +60,16 @@ __device__ __forceinline__ void bin_range(int p, int extent, int out, int offset
 // One block = one RoI x (64*VEC) channels; OUTH waves, wave ph computes output row ph.
 template <int VEC, bool ARGMAX>
 __global__ void __launch_bounds__(448)
-roi_pool_hwc_kernel(const float *__restrict__ xt, int C, int H, int W, const float *__restrict__ rois, int outh, int outw,
-                    float scale, float *__restrict__ y, int32_t *__restrict__ argmax) {
+roi_pool_hwc_kernel(const float *__restrict__ xt, int C, int H, int W, const float *__restrict__ rois, int roi_cols, int outh,
+                    int outw, float scale, float *__restrict__ y, int32_t *__restrict__ argmax) {
     constexpr int CB = 64 * VEC;
     __shared__ __attribute__((aligned(16))) float s_val[CB * 49];
     __shared__ int32_t s_idx[ARGMAX ? CB * 49 : 1];
     const int r = blockIdx.x, c0 = blockIdx.y * CB;
     const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
     const int bins = outh * outw;
-    const RoiGeom g = roi_geometry(rois + 5 * (size_t)r, scale);
+    // rows are [batch,x1,y1,x2,y2] (roi_cols 5) or bare [x1,y1,x2,y2] (roi_cols 4, ProposalLayer's output)
+    const RoiGeom g = roi_geometry(rois + (size_t)roi_cols * r + (roi_cols - 5), scale);
     if (ph < outh) {
         int hs, he;
         bin_range(ph, g.rh, outh, g.ys, H, hs, he);
@@ -148,21 +149,21 @@ int frcnn_chw_to_hwc(const float *x, int C, int H, int W, float *xt, void *strea
     return frcnn_launch_status();
 }
 
-int frcnn_roi_pool_fwd_hwc(const float *xt, int C, int H, int W, const float *rois, int R, int outh, int outw, float spatial_scale,
-                           float *y, int32_t *argmax, void *stream_) {
+int frcnn_roi_pool_fwd_hwc(const float *xt, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
+                           float spatial_scale, float *y, int32_t *argmax, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!xt || !rois || !y || C < 1 || H < 1 || W < 1 || R < 0) return FRCNN_ERR_INVALID;
-    if (outh < 1 || outw < 1 || outh > 7 || outw > 7) return FRCNN_ERR_INVALID;   // LDS tile is sized for <= 7x7 bins
+    if (outh < 1 || outw < 1 || outh > 7 || outw > 7 || (roi_cols != 4 && roi_cols != 5)) return FRCNN_ERR_INVALID;   // LDS tile is sized for <= 7x7 bins
     if (R == 0) return FRCNN_OK;
     const dim3 blk(64 * outh);
     if (C % 128 == 0) {
         const dim3 grid(R, C / 128);
-        if (argmax) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_hwc_kernel<2, true>), grid, blk, 0, stream, xt, C, H, W, rois, outh, outw, spatial_scale, y, argmax);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_hwc_kernel<2, false>), grid, blk, 0, stream, xt, C, H, W, rois, outh, outw, spatial_scale, y, argmax);
+        if (argmax) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_hwc_kernel<2, true>), grid, blk, 0, stream, xt, C, H, W, rois, roi_cols, outh, outw, spatial_scale, y, argmax);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_hwc_kernel<2, false>), grid, blk, 0, stream, xt, C, H, W, rois, roi_cols, outh, outw, spatial_scale, y, argmax);
     } else {
         const dim3 grid(R, frcnn_cdiv(C, 64));
-        if (argmax) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_hwc_kernel<1, true>), grid, blk, 0, stream, xt, C, H, W, rois, outh, outw, spatial_scale, y, argmax);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_hwc_kernel<1, false>), grid, blk, 0, stream, xt, C, H, W, rois, outh, outw, spatial_scale, y, argmax);
+        if (argmax) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_hwc_kernel<1, true>), grid, blk, 0, stream, xt, C, H, W, rois, roi_cols, outh, outw, spatial_scale, y, argmax);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_hwc_kernel<1, false>), grid, blk, 0, stream, xt, C, H, W, rois, roi_cols, outh, outw, spatial_scale, y, argmax);
     }
     return frcnn_launch_status();
 }
@@ -172,7 +173,7 @@ int frcnn_roi_pool_fwd(const float *x, int C, int H, int W, const float *rois, i
     if (!workspace || workspace_bytes < frcnn_roi_pool_workspace_bytes(C, H, W)) return FRCNN_ERR_INVALID;
     int st = frcnn_chw_to_hwc(x, C, H, W, (float *)workspace, stream);
     if (st != FRCNN_OK) return st;
-    return frcnn_roi_pool_fwd_hwc((const float *)workspace, C, H, W, rois, R, outh, outw, spatial_scale, y, argmax, stream);
+    return frcnn_roi_pool_fwd_hwc((const float *)workspace, C, H, W, rois, R, 5, outh, outw, spatial_scale, y, argmax, stream);
 }
 
 int frcnn_roi_pool_bwd(const float *dy, const int32_t *argmax, int R, int C, int H, int W, int outh, int outw, float *dx,

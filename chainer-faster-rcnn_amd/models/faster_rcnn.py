@@ -1,0 +1,133 @@
+"""FasterRCNN assembly with the reference's interface (models/faster_rcnn.py:19-178): trunk -> RPN ->
+RoI pooling -> fc6/fc7 -> cls_score / bbox_pred -> decode + clip + softmax, every stage a HIP kernel of
+libfrcnn_hip.so.  `model(x, img_info)` returns (softmax(cls_score) (R,21), pred_boxes (R,84)) and leaves
+`rpn_proposals` / `rpn_probs` on the object, as the reference does (:119-120,175-178).
+
+`forward_device()` is the sync-free form the benchmark drives: fixed capacity R = post_nms_top_n rows
+(rows past n_out are zero boxes), so nothing between the image upload and the final read-back waits on
+the host.
+"""
+import os
+
+import numpy as np
+
+from ..chainer_compat import Variable, is_variable, kind, unwrap
+from ..runtime import default_runtime
+from .region_proposal_network import RegionProposalNetwork
+from .vgg16 import VGG16Prev
+
+
+class Linear(object):
+    """L.Linear: W (out, in), b (out)."""
+
+    def __init__(self, rt):
+        self.rt = rt
+        self.W = self.b = None
+
+    def set(self, W, b):
+        self.W = self.rt.asarray(np.ascontiguousarray(W, dtype=np.float32) if isinstance(W, np.ndarray) else W, "f32")
+        self.b = self.rt.asarray(np.ascontiguousarray(b, dtype=np.float32) if isinstance(b, np.ndarray) else b, "f32")
+
+    def __call__(self, x, relu=False):
+        return self.rt.linear(x, self.W, self.b, relu=relu)
+
+
+class FasterRCNN(object):
+    type_check_enable = int(os.environ.get('CHAINER_TYPE_CHECK', '1')) != 0
+
+    def __init__(self, trunk_class=VGG16Prev, rpn_in_ch=512, rpn_mid_ch=512, feat_stride=16, anchor_ratios=(0.5, 1, 2),
+                 anchor_scales=(8, 16, 32), num_classes=21, loss_lambda=1, rpn_delta=3, rcnn_delta=1, runtime=None):
+        self.rt = runtime or default_runtime()
+        self.trunk = trunk_class(runtime=self.rt)
+        self.RPN = RegionProposalNetwork(rpn_in_ch, rpn_mid_ch, feat_stride, anchor_ratios, anchor_scales, num_classes,
+                                         loss_lambda, rpn_delta, runtime=self.rt)
+        self.fc6, self.fc7 = Linear(self.rt), Linear(self.rt)
+        self.cls_score, self.bbox_pred = Linear(self.rt), Linear(self.rt)
+        self._feat_stride = feat_stride
+        self._num_classes = num_classes
+        self.RPN.train = False                               # faster_rcnn.py:42
+        self._rcnn_train = False
+        self._spatial_scale = 1. / feat_stride
+        self.rpn_proposals = self.rpn_probs = None
+
+    # mode switches, faster_rcnn.py:48-74
+    @property
+    def rcnn_train(self):
+        return self._rcnn_train
+
+    @rcnn_train.setter
+    def rcnn_train(self, val):
+        self._rcnn_train = val
+        if val:
+            self.RPN.train = not val
+        self.trunk.train = bool(self.rcnn_train or self.rpn_train)
+
+    @property
+    def rpn_train(self):
+        return self.RPN.train
+
+    @rpn_train.setter
+    def rpn_train(self, val):
+        self.RPN.train = val
+        if val:
+            self._rcnn_train = not val
+        self.trunk.train = bool(self.rcnn_train or self.rpn_train)
+
+    def load_params(self, params):
+        """params: dict keyed by Chainer link path ('trunk/conv1_1/W', 'RPN/rpn_conv_3x3/b', 'fc6/W', ...) --
+        the key scheme of the reference's .npz snapshots (forward.py:29)."""
+        self.trunk.load_params(params, "trunk/")
+        self.RPN.load_params(params, "RPN/")
+        for name in ("fc6", "fc7", "cls_score", "bbox_pred"):
+            getattr(self, name).set(params[name + "/W"], params[name + "/b"])
+
+    def _check_data_type_forward(self, x, img_info, gt_boxes):
+        assert x.shape[0] == 1
+        assert kind(x) == 'f'
+        assert is_variable(x)
+        assert tuple(img_info.shape) == (1, 2)
+        assert kind(img_info) in 'iu'
+        assert is_variable(img_info)
+        if gt_boxes is not None:
+            assert gt_boxes.shape[0] == 1 and gt_boxes.shape[1] > 0 and gt_boxes.shape[2] == 5
+            assert kind(gt_boxes) == 'f' and is_variable(gt_boxes)
+
+    def forward_device(self, x, im_h, im_w, keep=False, timer=None):
+        """Sync-free inference.  Returns dict(cls_prob (R,ncls), pred_boxes (R,4*ncls), rois (R,4), probs (R,),
+        n_out (1,) int32) -- all device arrays, R = post_nms_top_n; rows >= n_out are padding.
+        `timer.mark(name)` (optional) is called after every stage: bench.py records a HIP event there."""
+        rt = self.rt
+        mark = timer.mark if timer else (lambda name: None)
+        feat = self.trunk(x, timer=timer)
+        C, H, W = [int(v) for v in feat.shape[1:]]
+        _, score, prob, bbox = self.RPN.heads(feat, want_score=False, timer=timer)
+        rois, probs, n_out = self.RPN.proposal_layer.forward_device(prob, bbox, im_h, im_w)
+        mark("proposals")
+        xt = rt.chw_to_hwc(feat)
+        pool5 = rt.roi_pool_fwd_hwc(xt, C, H, W, rois, 7, 7, self._spatial_scale)    # rois (R,4): concat folded in
+        mark("roi_pool")
+        fc6 = self.fc6(pool5, relu=True)        # dropout is the identity in inference (faster_rcnn.py:127-128)
+        mark("fc6")
+        fc7 = self.fc7(fc6, relu=True)
+        mark("fc7")
+        cls_score = self.cls_score(fc7)
+        bbox_pred = self.bbox_pred(fc7)
+        pred_boxes, cls_prob = rt.head_decode(rois, bbox_pred, cls_score, im_h, im_w)
+        mark("head_out")
+        out = dict(cls_prob=cls_prob, pred_boxes=pred_boxes, rois=rois, probs=probs, n_out=n_out)
+        if keep:
+            out.update(feat=feat, rpn_cls_prob=prob, rpn_bbox_pred=bbox, pool5=pool5, fc6=fc6, fc7=fc7,
+                       cls_score=cls_score, bbox_pred=bbox_pred)
+        return out
+
+    def __call__(self, x, img_info, gt_boxes=None):
+        if self.type_check_enable:
+            self._check_data_type_forward(x, img_info, gt_boxes)
+        if gt_boxes is not None and (self.rpn_train or self.rcnn_train):
+            raise NotImplementedError("training modes are the next scope row")
+        im_h, im_w = self.RPN.proposal_layer._img_hw(img_info)
+        out = self.forward_device(x, im_h, im_w)
+        n = int(self.rt.mem.to_numpy(out["n_out"])[0])
+        self.rpn_proposals = out["rois"][:n]
+        self.rpn_probs = out["probs"][:n].reshape(n, 1)
+        return Variable(out["cls_prob"][:n]), out["pred_boxes"][:n]

@@ -1,0 +1,74 @@
+"""RegionProposalNetwork with the reference's interface (models/region_proposal_network.py:16-204):
+rpn_conv_3x3 (+ReLU) -> rpn_cls_score / 18-way softmax / rpn_bbox_pred -> ProposalLayer.
+Inference path on device; children keep Chainer's names (rpn_conv_3x3, rpn_cls_score, rpn_bbox_pred)."""
+import os
+
+import numpy as np
+
+from ..chainer_compat import Variable, is_variable, kind, unwrap
+from ..runtime import default_runtime
+from .proposal_layer import ProposalLayer
+from .vgg16 import Conv3x3
+
+
+class RegionProposalNetwork(object):
+    type_check_enable = int(os.environ.get('CHAINER_TYPE_CHECK', '1')) != 0
+
+    def __init__(self, in_ch=512, mid_ch=512, feat_stride=16, anchor_ratios=(0.5, 1, 2), anchor_scales=(8, 16, 32),
+                 num_classes=21, loss_lambda=1., delta=3, runtime=None):
+        self.rt = runtime or default_runtime()
+        self.n_anchors = len(anchor_ratios) * len(anchor_scales)
+        self.mid_ch = mid_ch
+        self.rpn_conv_3x3 = Conv3x3(self.rt, in_ch, mid_ch)
+        self.rpn_cls_score = dict(W=None, b=None)       # (2A, mid, 1, 1)
+        self.rpn_bbox_pred = dict(W=None, b=None)       # (4A, mid, 1, 1)
+        self.proposal_layer = ProposalLayer(feat_stride, anchor_ratios, anchor_scales, runtime=self.rt)
+        self._loss_lambda = loss_lambda
+        self._delta = delta
+        self._train = True
+        self.train = True                               # region_proposal_network.py:64
+
+    @property
+    def train(self):
+        return self._train
+
+    @train.setter
+    def train(self, val):
+        self._train = val
+        self.proposal_layer.train = val                 # :71-74
+
+    def load_params(self, params, prefix="RPN/"):
+        rt = self.rt
+        self.rpn_conv_3x3.set(params[prefix + "rpn_conv_3x3/W"], params[prefix + "rpn_conv_3x3/b"])
+        for name, store in (("rpn_cls_score", self.rpn_cls_score), ("rpn_bbox_pred", self.rpn_bbox_pred)):
+            W = np.ascontiguousarray(params[prefix + name + "/W"], dtype=np.float32)
+            store["W"] = rt.asarray(W.reshape(W.shape[0], -1), "f32")
+            store["b"] = rt.asarray(np.ascontiguousarray(params[prefix + name + "/b"], dtype=np.float32), "f32")
+
+    def _check_data_type_forward(self, x, img_info, gt_boxes):
+        assert x.shape[0] == 1
+        assert kind(x) == 'f'
+        assert tuple(img_info.shape) == (1, 2)
+        assert kind(img_info) in 'iu'
+        assert is_variable(x) and is_variable(img_info)
+        if gt_boxes is not None:
+            assert gt_boxes.shape[0] == 1 and gt_boxes.shape[2] == 5 and kind(gt_boxes) == 'f'
+
+    def heads(self, x, want_score=True, timer=None):
+        """(h, rpn_cls_score, rpn_cls_prob, rpn_bbox_pred) -- region_proposal_network.py:117-120."""
+        h = self.rpn_conv_3x3(self.rt.asarray(unwrap(x), "f32"), relu=True)
+        if timer:
+            timer.mark("rpn_conv_3x3")
+        score, prob, bbox = self.rt.rpn_heads(h, self.rpn_cls_score["W"], self.rpn_cls_score["b"],
+                                              self.rpn_bbox_pred["W"], self.rpn_bbox_pred["b"], want_score=want_score)
+        if timer:
+            timer.mark("rpn_heads")
+        return h, score, prob, bbox
+
+    def __call__(self, x, img_info, gt_boxes=None):
+        if self.type_check_enable:
+            self._check_data_type_forward(x, img_info, gt_boxes)
+        if self.train and gt_boxes is not None:
+            raise NotImplementedError("RPN training step (anchor targets + losses + backward) is the next scope row")
+        _, _, prob, bbox = self.heads(x, want_score=False)
+        return self.proposal_layer(Variable(prob), Variable(bbox), img_info)

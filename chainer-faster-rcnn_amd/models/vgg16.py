@@ -1,0 +1,74 @@
+"""VGG-16 trunk with the reference's layer list (models/vgg16.py:38-82, class VGG16Prev): 13 x
+[conv3x3 pad 1 + ReLU], 4 x max-pool 2x2 (ceil mode), stops after relu5_3 -- on the fp32 MFMA conv kernel
+(csrc/conv.hip).  Parameters keep Chainer's link paths (`conv1_1/W` (co,ci,3,3), `conv1_1/b`)."""
+import numpy as np
+
+from ..chainer_compat import unwrap
+from ..runtime import default_runtime
+
+LAYERS = [
+    ("conv1_1", 3, 64), ("conv1_2", 64, 64), "pool",
+    ("conv2_1", 64, 128), ("conv2_2", 128, 128), "pool",
+    ("conv3_1", 128, 256), ("conv3_2", 256, 256), ("conv3_3", 256, 256), "pool",
+    ("conv4_1", 256, 512), ("conv4_2", 512, 512), ("conv4_3", 512, 512), "pool",
+    ("conv5_1", 512, 512), ("conv5_2", 512, 512), ("conv5_3", 512, 512),
+]
+
+
+class Conv3x3(object):
+    """L.Convolution2D(ci, co, 3, 1, 1): holds W (co,ci,3,3) + b on device and the kernel's packed copy."""
+
+    def __init__(self, rt, cin, cout):
+        self.rt, self.cin, self.cout = rt, cin, cout
+        self.W = self.b = self.Wp = None
+
+    def set(self, W, b):
+        rt = self.rt
+        W = np.ascontiguousarray(W, dtype=np.float32) if isinstance(W, np.ndarray) else W
+        assert tuple(W.shape) == (self.cout, self.cin, 3, 3), (tuple(W.shape), self.cout, self.cin)
+        self.W = rt.asarray(W, "f32")
+        self.b = rt.asarray(np.ascontiguousarray(b, dtype=np.float32) if isinstance(b, np.ndarray) else b, "f32")
+        self.Wp = rt.pack_conv3x3_w(self.W)
+
+    def __call__(self, x, relu=True, out=None, cfg=-1):
+        return self.rt.conv3x3(x, self.Wp, self.b, relu=relu, out=out, cfg=cfg)
+
+
+class VGG16Prev(object):
+    def __init__(self, train=False, runtime=None):
+        self.rt = runtime or default_runtime()
+        self.train = train
+        self.links = {}
+        for l in LAYERS:
+            if l != "pool":
+                self.links[l[0]] = Conv3x3(self.rt, l[1], l[2])
+                setattr(self, l[0], self.links[l[0]])
+
+    def load_params(self, params, prefix="trunk/"):
+        for name, link in self.links.items():
+            link.set(params[prefix + name + "/W"], params[prefix + name + "/b"])
+
+    def namedparams(self, prefix="trunk/"):
+        for name, link in self.links.items():
+            yield prefix + name + "/W", link.W
+            yield prefix + name + "/b", link.b
+
+    def __call__(self, x, timer=None):
+        rt = self.rt
+        h = rt.asarray(unwrap(x), "f32")
+        assert h.ndim == 4 and int(h.shape[0]) == 1, "batch size 1 (models/faster_rcnn.py:77)"
+        n_pool = 0
+        for l in LAYERS:
+            if l == "pool":
+                h = rt.maxpool2x2(h)
+                n_pool += 1
+                if timer:
+                    timer.mark("pool%d" % n_pool)
+            else:
+                h = self.links[l[0]](h, relu=True)
+                if timer:
+                    timer.mark(l[0])
+        return h
+
+
+VGG16 = VGG16Prev   # the reference's default trunk_class needs a caffemodel download; same network

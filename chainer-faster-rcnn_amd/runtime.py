@@ -39,6 +39,9 @@ class TorchDeviceMemory(object):
     def is_array(self, a):
         return isinstance(a, self.torch.Tensor) and a.is_cuda
 
+    def contiguous(self, t):
+        return t if t.is_contiguous() else t.contiguous()
+
     def ptr(self, t):
         if t is None:
             return None
@@ -77,7 +80,7 @@ class Runtime(object):
         if self.mem.is_array(a):
             if self.mem.dtype_of(a) != dtype:
                 raise ValueError("expected dtype %s, got %s" % (dtype, self.mem.dtype_of(a)))
-            return a if a.is_contiguous() else a.contiguous()
+            return self.mem.contiguous(a)
         a = np.asarray(a)
         if a.dtype != _NP[dtype]:
             raise ValueError("expected dtype %s, got %s" % (dtype, a.dtype))
@@ -156,8 +159,8 @@ class Runtime(object):
         R = int(rois.shape[0])
         y = out if out is not None else m.empty((R, C, outh, outw), "f32")
         am = m.empty((R, C, outh, outw), "i32") if want_argmax else None
-        _lib.check(L.frcnn_roi_pool_fwd_hwc(m.ptr(xt), C, H, W, m.ptr(rois), R, outh, outw, float(scale), m.ptr(y),
-                                            m.ptr(am), m.stream()), "frcnn_roi_pool_fwd_hwc")
+        _lib.check(L.frcnn_roi_pool_fwd_hwc(m.ptr(xt), C, H, W, m.ptr(rois), R, int(rois.shape[1]), outh, outw,
+                                            float(scale), m.ptr(y), m.ptr(am), m.stream()), "frcnn_roi_pool_fwd_hwc")
         return (y, am) if want_argmax else y
 
     def roi_pool_bwd(self, dy, argmax, C, H, W):
@@ -224,6 +227,28 @@ class Runtime(object):
         _lib.check(L.frcnn_head_decode(m.ptr(boxes), m.ptr(deltas), m.ptr(cls_score), R, ncls, int(im_h), int(im_w),
                                        m.ptr(pred), m.ptr(prob), m.stream()), "frcnn_head_decode")
         return pred, prob
+
+
+    def bbox_transform_inv(self, boxes, deltas):
+        m, L = self.mem, self.lib
+        R, c4 = int(deltas.shape[0]), int(deltas.shape[1])
+        pred = m.empty((R, c4), "f32")
+        _lib.check(L.frcnn_bbox_transform_inv(m.ptr(boxes), m.ptr(deltas), R, c4 // 4, m.ptr(pred), m.stream()),
+                   "frcnn_bbox_transform_inv")
+        return pred
+
+    def clip_boxes_(self, boxes, im_h, im_w):
+        m, L = self.mem, self.lib
+        n = int(np.prod(boxes.shape)) // 4
+        _lib.check(L.frcnn_clip_boxes(m.ptr(boxes), n, int(im_h), int(im_w), m.stream()), "frcnn_clip_boxes")
+        return boxes
+
+    def softmax_rows(self, scores):
+        m, L = self.mem, self.lib
+        R, n = int(scores.shape[0]), int(scores.shape[1])
+        out = m.empty((R, n), "f32")
+        _lib.check(L.frcnn_softmax_rows(m.ptr(scores), R, n, m.ptr(out), m.stream()), "frcnn_softmax_rows")
+        return out
 
 
 _default = None

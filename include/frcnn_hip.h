@@ -83,12 +83,14 @@ int frcnn_proposals(const float *rpn_cls_prob, const float *rpn_bbox_pred, int A
  * ignored: the reference asserts batch==1); rois (R,5) f32 [batch,x1,y1,x2,y2]; y (R,C,outh,outw) f32;
  * argmax same shape int32 (flat h*W+w, -1 for an empty bin) or NULL (inference).  outh,outw <= 7.
  *   frcnn_roi_pool_fwd      = frcnn_chw_to_hwc into `workspace` + frcnn_roi_pool_fwd_hwc
- *   frcnn_roi_pool_fwd_hwc  takes the feature map channel-last, xt (H*W, C) -- the fused pipeline's path
+ *   frcnn_roi_pool_fwd_hwc  takes the feature map channel-last, xt (H*W, C) -- the fused pipeline's path;
+ *                           roi_cols = 5 ([batch,x1,y1,x2,y2] rows) or 4 (ProposalLayer's bare (R,4)
+ *                           output, i.e. the concat at faster_rcnn.py:123-124 folded into the read)
  */
 size_t frcnn_roi_pool_workspace_bytes(int C, int H, int W);
 int frcnn_chw_to_hwc(const float *x, int C, int H, int W, float *xt, void *stream);
-int frcnn_roi_pool_fwd_hwc(const float *xt, int C, int H, int W, const float *rois, int R, int outh, int outw,
-                           float spatial_scale, float *y, int32_t *argmax, void *stream);
+int frcnn_roi_pool_fwd_hwc(const float *xt, int C, int H, int W, const float *rois, int R, int roi_cols,
+                           int outh, int outw, float spatial_scale, float *y, int32_t *argmax, void *stream);
 int frcnn_roi_pool_fwd(const float *x, int C, int H, int W, const float *rois, int R, int outh, int outw,
                        float spatial_scale, float *y, int32_t *argmax, void *workspace,
                        size_t workspace_bytes, void *stream);
@@ -131,6 +133,12 @@ int frcnn_linear_f32(const float *x, const float *w, const float *bias, float *y
  * boxes (R,4), deltas (R,4*ncls) -> pred_boxes (R,4*ncls); cls_score (R,ncls) -> cls_prob (R,ncls). */
 int frcnn_head_decode(const float *boxes, const float *deltas, const float *cls_score, int R, int ncls,
                       int im_h, int im_w, float *pred_boxes, float *cls_prob, void *stream);
+/* the three pieces on their own: bbox_transform_inv (bbox_transform.py:41-76), clip_boxes (:79-99, in
+ * place on n_boxes x 4 floats), and a row-wise softmax (F.softmax on (R,n)) */
+int frcnn_bbox_transform_inv(const float *boxes, const float *deltas, int R, int ncls, float *pred_boxes,
+                             void *stream);
+int frcnn_clip_boxes(float *boxes, int n_boxes, int im_h, int im_w, void *stream);
+int frcnn_softmax_rows(const float *scores, int R, int n, float *probs, void *stream);
 
 #ifdef __cplusplus
 }

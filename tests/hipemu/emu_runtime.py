@@ -31,6 +31,9 @@ class HostMemory(object):
     def is_array(self, a):
         return isinstance(a, np.ndarray)
 
+    def contiguous(self, a):
+        return np.ascontiguousarray(a)
+
     def ptr(self, a):
         if a is None:
             return None

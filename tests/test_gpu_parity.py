@@ -1,0 +1,126 @@
+"""The parity tests proper: libfrcnn_hip.so on a real MI355X, through the C ABI, against the oracle and the
+golden vectors the reference produced.  Run with `-m gpu` on the GPU box."""
+import numpy as np
+import pytest
+
+import parity_cases as P
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rt():
+    import chainer_faster_rcnn_amd as pkg
+    return pkg.runtime.default_runtime()          # raises (no fallback) if the library or the GPU is missing
+
+
+def test_library_is_the_device_build(rt):
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 1
+
+
+def test_nms_golden(rt):
+    P.check_nms_golden(rt)
+
+
+def test_nms_edges(rt):
+    P.check_nms_edges(rt)
+
+
+def test_nms_random(rt):
+    P.check_nms_random(rt, n=3000, seeds=(0, 1, 2))
+
+
+def test_nms_batched(rt):
+    P.check_nms_batched(rt, groups=20, n=300)
+
+
+@pytest.mark.parametrize("case", ["proposal_14x14_train_rand", "proposal_38x63_test", "proposal_38x63_test_HH",
+                                  "proposal_38x63_train", "proposal_38x63_cfg4_1000_300", "proposal_37x50_test"])
+def test_proposals_golden(rt, case):
+    P.check_proposals_golden(rt, case)
+
+
+def test_proposals_repeatable(rt):
+    """idempotence: the same inputs give the same RoIs on every call (workspace reuse, no stale state)."""
+    G = P.g("proposal_38x63_test")
+    from oracle import frcnn_oracle as O
+    a = [rt.mem.to_numpy(v) for v in rt.proposals(P.dev(rt, G["rpn_cls_prob"][0]), P.dev(rt, G["rpn_bbox_pred"][0]),
+                                                  O.generate_anchors(), 16, 600, 1000, 16.0, 6000, 300, 0.7)]
+    for _ in range(3):
+        b = [rt.mem.to_numpy(v) for v in rt.proposals(P.dev(rt, G["rpn_cls_prob"][0]), P.dev(rt, G["rpn_bbox_pred"][0]),
+                                                      O.generate_anchors(), 16, 600, 1000, 16.0, 6000, 300, 0.7)]
+        assert all(np.array_equal(u, v) for u, v in zip(a, b))
+
+
+def test_roi_pool_full_size(rt):
+    P.check_roi_pool(rt, R=300, C=512, H=38, W=63)        # BASELINE config: 300 x 512 x 7 x 7
+    P.check_roi_pool(rt, R=7, C=64, H=19, W=32, seed=2)   # VEC=1 path
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, -1])
+def test_conv3x3_cfgs(rt, cfg):
+    P.check_conv3x3(rt, 64, 128 if cfg == 1 else 64, 75, 125, cfg=cfg)
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(3, 64, 120, 200), (64, 64, 60, 100), (128, 256, 75, 125), (512, 512, 38, 63),
+                                          (256, 512, 19, 32)])
+def test_conv3x3_vgg_shapes(rt, cin, cout, h, w):
+    P.check_conv3x3(rt, cin, cout, h, w)
+
+
+def test_maxpool(rt):
+    P.check_maxpool(rt, 64, 75, 125)
+    P.check_maxpool(rt, 8, 600, 1000)
+
+
+def test_rpn_heads(rt):
+    P.check_rpn_heads(rt, Cmid=512, H=38, W=63)
+
+
+def test_linear(rt):
+    P.check_linear(rt, 300, 4096, 25088, True)       # fc6
+    P.check_linear(rt, 300, 4096, 4096, True)        # fc7
+    P.check_linear(rt, 300, 21, 4096, False)         # cls_score
+    P.check_linear(rt, 300, 84, 4096, False)         # bbox_pred
+    P.check_linear(rt, 17, 33, 100, False)
+
+
+def test_head_decode(rt):
+    P.check_head_decode(rt, R=300)
+
+
+def test_models_surface_and_end_to_end(rt):
+    """The reference's call surface: FasterRCNN(trunk_class=VGG16Prev)(Variable(img), Variable(img_info))."""
+    from chainer_faster_rcnn_amd import synthetic
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.models import FasterRCNN, VGG16Prev, cpu_nms
+    from oracle import frcnn_oracle as O
+    params = synthetic.params(seed=1)
+    h, w = 224, 320
+    x = synthetic.image(seed=5, h=h, w=w)
+    info = np.array([[h, w]], dtype=np.int32)
+    model = FasterRCNN(trunk_class=VGG16Prev, runtime=rt)
+    model.rcnn_train = False
+    model.rpn_train = False
+    model.load_params(params)
+    cls_score, bbox_pred = model(Variable(x, volatile=True), Variable(info))
+    cls, boxes, dbg = O.faster_rcnn_forward(params, x, info, return_debug=True)
+    out = model.forward_device(rt.mem.from_numpy(x), h, w, keep=True)
+    feat = rt.mem.to_numpy(out["feat"])
+    assert np.abs(feat - dbg["feat"]).max() / np.abs(dbg["feat"]).max() < 1e-3          # fp32 features, 1e-3 rel
+    # proposals: exact given the device's own RPN maps
+    p2, s2, d2 = O.proposal_layer(rt.mem.to_numpy(out["rpn_cls_prob"]), rt.mem.to_numpy(out["rpn_bbox_pred"]), info,
+                                  train=False, return_debug=True)
+    n = int(rt.mem.to_numpy(out["n_out"])[0])
+    assert n == len(p2) and np.allclose(rt.mem.to_numpy(out["rois"])[:n], p2, rtol=5e-7, atol=1e-4)
+    assert cls_score.data.shape == (n, 21) and tuple(bbox_pred.shape) == (n, 84)
+    # head: compare on the device's own RoIs
+    rois = rt.mem.to_numpy(out["rois"])[:n]
+    pool5 = O.roi_pooling_2d(feat, np.concatenate([np.zeros((n, 1), np.float32), rois], 1), 7, 7, 1 / 16.)
+    assert np.array_equal(rt.mem.to_numpy(out["pool5"])[:n], pool5)
+    cp, pb, _ = O.rcnn_head(params, pool5, rois, info)
+    assert np.allclose(rt.mem.to_numpy(out["cls_prob"])[:n], cp, rtol=1e-3, atol=1e-5)
+    assert np.allclose(rt.mem.to_numpy(out["pred_boxes"])[:n], pb, rtol=1e-3, atol=1e-2)
+    # forward.py:48-58 style post-processing through the cpu_nms-compatible entry point
+    dets = np.hstack([pb[:, 4:8], cp[:, 1:2]]).astype(np.float32)
+    assert cpu_nms(dets, 0.3, runtime=rt) == O.cpu_nms(dets, 0.3)

@@ -1,0 +1,115 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every declared symbol, the product never
+falls back when the GPU is absent, the models/ mirror keeps the reference's names and error behaviour."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "frcnn_hip.h")).read()
+    return sorted(set(re.findall(r"\b(frcnn_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_device_library_builds_and_exports_every_declared_symbol():
+    import __graft_entry__ as ge
+    so = ge.build()                                   # hipcc cross-compiles gfx950 without a GPU
+    import ctypes
+    lib = ctypes.CDLL(so)
+    for name in _declared():
+        assert hasattr(lib, name), name
+    import chainer_faster_rcnn_amd as pkg
+    assert sorted(pkg._lib.SIGNATURES) == _declared()   # the binding table mirrors the header one to one
+    assert lib.frcnn_abi_version() == 1
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import chainer_faster_rcnn_amd as pkg
+    with pytest.raises(pkg._lib.FrcnnError):
+        pkg.runtime.default_runtime()
+    from chainer_faster_rcnn_amd.models import cpu_nms
+    with pytest.raises(pkg._lib.FrcnnError):
+        cpu_nms(np.zeros((3, 5), np.float32), 0.7)
+
+
+def test_product_never_imports_the_oracle():
+    pkg_dir = os.path.join(ROOT, "chainer-faster-rcnn_amd")
+    for d, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), os.path.join(d, f)
+                assert "hipemu" not in src, os.path.join(d, f)
+
+
+def test_models_surface_matches_reference_names():
+    from chainer_faster_rcnn_amd import models
+    for name in ("ProposalLayer", "cpu_nms", "gpu_nms", "roi_pooling_2d", "ROIPooling2D", "generate_anchors",
+                 "bbox_transform_inv", "clip_boxes", "VGG16Prev", "VGG16", "RegionProposalNetwork", "FasterRCNN"):
+        assert hasattr(models, name)
+    PL = models.ProposalLayer
+    assert (PL.RPN_NMS_THRESH, PL.TRAIN_RPN_PRE_NMS_TOP_N, PL.TRAIN_RPN_POST_NMS_TOP_N, PL.TEST_RPN_PRE_NMS_TOP_N,
+            PL.TEST_RPN_POST_NMS_TOP_N, PL.RPN_MIN_SIZE) == (0.7, 12000, 2000, 6000, 300, 16)
+
+
+def test_proposal_layer_mirror_on_emulated_kernels(golden):
+    """Same call as the reference's tests/test_proposal_layer.py:20-33 (train-mode default, Variables in)."""
+    from emu_runtime import emu_runtime
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.models import ProposalLayer, generate_anchors
+    rt = emu_runtime()
+    G = golden("proposal_14x14_train_rand")
+    pl = ProposalLayer(runtime=rt)
+    assert pl.train and pl._num_anchors == 9 and (pl._pre_nms_top_n, pl._post_nms_top_n) == (12000, 2000)
+    assert np.array_equal(pl._anchors, golden("anchors")["a_8_16_32"])
+    assert np.array_equal(generate_anchors(), golden("anchors")["a_default"])
+    p, s = pl(Variable(G["rpn_cls_prob"]), Variable(G["rpn_bbox_pred"]), Variable(G["img_info"]))
+    assert p.shape == G["proposals"].shape and s.shape == G["probs"].shape
+    assert np.allclose(p, G["proposals"], rtol=5e-7, atol=1e-4) and np.array_equal(s, G["probs"])
+    pl.train = False
+    assert (pl._pre_nms_top_n, pl._post_nms_top_n) == (6000, 300)
+    with pytest.raises(AssertionError):       # the reference's type checks (proposal_layer.py:85-100)
+        pl(Variable(G["rpn_cls_prob"][:, :10]), Variable(G["rpn_bbox_pred"]), Variable(G["img_info"]))
+    with pytest.raises(AssertionError):
+        pl(G["rpn_cls_prob"], Variable(G["rpn_bbox_pred"]), Variable(G["img_info"]))      # not a Variable
+
+
+def test_cpu_nms_mirror_errors_and_result(golden):
+    from emu_runtime import emu_runtime
+    from chainer_faster_rcnn_amd.models import cpu_nms
+    rt = emu_runtime()
+    G = golden("cpu_nms")
+    assert cpu_nms(G["n65_t05_dets"], 0.5, runtime=rt) == G["n65_t05_keep"].tolist()
+    with pytest.raises(ValueError):
+        cpu_nms(G["n65_t05_dets"].astype(np.float64), 0.5, runtime=rt)      # Cython: "Buffer dtype mismatch"
+    with pytest.raises(TypeError):
+        cpu_nms(G["n65_t05_dets"], 1, runtime=rt)                           # thresh must be a Python float
+    assert rt.lib.frcnn_nms(None, -1, 0.5, 0, None, None, None, 0, None) == -1   # FRCNN_ERR_INVALID, not a crash
+
+
+def test_roi_pooling_function_object(golden):
+    from emu_runtime import emu_runtime
+    from chainer_faster_rcnn_amd.models import ROIPooling2D, roi_pooling_2d
+    from oracle import frcnn_oracle as O
+    rt = emu_runtime()
+    rs = np.random.RandomState(0)
+    x = rs.randn(1, 64, 10, 12).astype(np.float32)
+    rois = np.array([[0, 0, 0, 100, 90], [0, 32, 16, 150, 140]], np.float32)
+    y = roi_pooling_2d(x, rois, 7, 7, 1 / 16., runtime=rt)
+    want, am = O.roi_pooling_2d(x, rois, return_argmax=True)
+    assert np.array_equal(y, want)
+    f = ROIPooling2D(7, 7, 1 / 16., runtime=rt)
+    y2, = f.forward((x, rois))
+    gx, none = f.backward((x, rois), (np.ones_like(y2),))
+    assert none is None and np.array_equal(f.argmax_data, am)
+    assert np.allclose(gx, O.roi_pooling_2d_backward(np.ones_like(want), am, rois, x.shape))
+    with pytest.raises(ValueError):
+        roi_pooling_2d(x, rois[:, :4], 7, 7, 1 / 16., runtime=rt)
