@@ -78,9 +78,23 @@ def conv_flops(model_layers, h, w):
 def cpu_baseline(params, x, samples):
     import torch
     from oracle import frcnn_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
     info = np.array([[IM_H, IM_W]], dtype=np.int32)
     O.build_c()
+    # batch-1 convs do not scale to hundreds of threads: pick the thread count that is fastest on one mid-size
+    # layer (conv3_2 at 150x250) and report it as `cores`
+    xs = np.random.RandomState(0).randn(1, 256, 150, 250).astype(np.float32)
+    best = None
+    for nt in sorted(set([8, 16, 32, 64, os.cpu_count() or 1])):
+        if nt > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(nt)
+        O.conv2d(xs, params["trunk/conv3_2/W"], params["trunk/conv3_2/b"], 1)
+        t0 = time.perf_counter()
+        O.conv2d(xs, params["trunk/conv3_2/W"], params["trunk/conv3_2/b"], 1)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, nt)
+    torch.set_num_threads(best[1])
     O.faster_rcnn_forward(params, x, info)                      # warm-up (thread pools, page faults)
     t0 = time.perf_counter()
     for _ in range(samples):

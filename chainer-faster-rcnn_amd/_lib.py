@@ -34,7 +34,9 @@ SIGNATURES = {
     "frcnn_conv3x3_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "frcnn_conv3x3_f32_cfg": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "frcnn_maxpool2x2_f32": (_I, [_P, _P, _I, _I, _I, _P]),
-    "frcnn_rpn_heads_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "frcnn_rpn_heads_padded_channels": (_I, [_I]),
+    "frcnn_rpn_heads_pack": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "frcnn_rpn_heads_f32": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "frcnn_linear_workspace_bytes": (_S, [_I, _I, _I]),
     "frcnn_linear_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_head_decode": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
@@ -74,6 +76,13 @@ def load():
     """The product library.  Raises when it is missing or when no GPU is visible -- never falls back."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm ships its own libamdhip64.so.7 (same soname as /opt/rocm's).  The process must hold ONE
+        # HIP runtime -- the one torch allocates from -- so make torch load and initialise its copy first;
+        # libfrcnn_hip.so's NEEDED entry then resolves to that already-loaded runtime.  (The other order
+        # leaves torch bound to a runtime it was not built for and torch.cuda reports no device.)
+        import torch
+        if not torch.cuda.is_available():
+            raise FrcnnError("no HIP device visible to PyTorch: the MI355X path cannot run (no CPU fallback)")
         lib = bind(LIB_PATH)
         n = lib.frcnn_device_count()
         if n <= 0:

@@ -28,17 +28,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int kHaloPitch = 34;   // 32 pixels + left/right halo
-
-template <int WCO, int WPX, int ACO, int APX, int CK>
+// KS = 3: 3x3 / pad 1 (the VGG and RPN convs);  KS = 1: 1x1 / pad 0 (the RPN heads) -- same machinery, no halo.
+template <int KS, int WCO, int WPX, int ACO, int APX, int CK>
 __global__ void __launch_bounds__(64 * WCO * WPX)
-conv3x3_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
+conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
                         float *__restrict__ y, int Cin, int Cout, int H, int W, int relu) {
     constexpr int NT = 64 * WCO * WPX;
     constexpr int BCO = 32 * ACO * WCO;
     constexpr int BROWS = APX * WPX;
-    constexpr int HR = BROWS + 2;
-    constexpr int KR = CK * 9;
+    constexpr int TAPS = KS * KS, PAD = KS / 2;
+    constexpr int kHaloPitch = 32 + KS - 1;          // 32 pixels + left/right halo
+    constexpr int HR = BROWS + KS - 1;
+    constexpr int KR = CK * TAPS;
     constexpr int WV = KR * BCO / 4;                 // float4s of weights per chunk
     constexpr int WIT = (WV + NT - 1) / NT;
     constexpr int HV = CK * HR * kHaloPitch;         // halo floats per chunk
@@ -51,7 +52,7 @@ conv3x3_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ w
     const int wco = wave % WCO, wpx = wave / WCO;
     const int x0 = blockIdx.x * 32, y0 = blockIdx.y * BROWS, co0 = blockIdx.z * BCO;
     const int HW = H * W;
-    const int K = Cin * 9;
+    const int K = Cin * TAPS;
     const int nchunks = (Cin + CK - 1) / CK;
 
     float4 wreg[WIT];
@@ -76,7 +77,7 @@ conv3x3_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ w
             if (e < HV) {
                 const int c = e / (HR * kHaloPitch), rem = e % (HR * kHaloPitch);
                 const int hr = rem / kHaloPitch, hx = rem % kHaloPitch;
-                const int gc = chunk * CK + c, gy = y0 - 1 + hr, gx = x0 - 1 + hx;
+                const int gc = chunk * CK + c, gy = y0 - PAD + hr, gx = x0 - PAD + hx;
                 if (gc < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) val = x[(size_t)gc * HW + gy * W + gx];
             }
             hreg[it] = val;
@@ -115,14 +116,14 @@ conv3x3_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ w
         const bool more = chunk + 1 < nchunks;
         if (more) fetch(chunk + 1);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / KS, kx = tap % KS;
 #pragma unroll
             for (int cp = 0; cp < CK / 2; ++cp) {
                 const int c = 2 * cp + khalf;
                 float a[ACO], b[APX];
 #pragma unroll
-                for (int i = 0; i < ACO; ++i) a[i] = w_lds[cur][c * 9 + tap][a_col + 32 * i];
+                for (int i = 0; i < ACO; ++i) a[i] = w_lds[cur][c * TAPS + tap][a_col + 32 * i];
 #pragma unroll
                 for (int j = 0; j < APX; ++j) b[j] = in_lds[cur][c][b_row + j + ky][l31 + kx];
 #pragma unroll
@@ -182,73 +183,34 @@ maxpool2x2_kernel(const float *__restrict__ x, float *__restrict__ y, int C, int
     }
 }
 
-// RPN heads: score(2A) and bbox(4A) 1x1 convolutions of h (Cmid,HW) + softmax over the 2A score channels.
-// Block = 64 pixels x 8 waves; wave s reduces channels [s*Cmid/8, (s+1)*Cmid/8): lane = pixel (coalesced
-// reads of h), weights are wave-uniform (scalar loads); partial sums meet in LDS, then threads with
-// tid < 64 finish bias + softmax.  NOUT = 6A <= 64.
-template <int NOUT_MAX>
-__global__ void __launch_bounds__(512)
-rpn_heads_kernel(const float *__restrict__ h, int Cmid, int HW, int A, const float *__restrict__ w_cls, const float *__restrict__ b_cls,
-                 const float *__restrict__ w_bbox, const float *__restrict__ b_bbox, float *__restrict__ cls_score,
-                 float *__restrict__ cls_prob, float *__restrict__ bbox_pred) {
-    __shared__ float part[8][NOUT_MAX][64];
-    const int lane = threadIdx.x & 63;
-    const int s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int p = blockIdx.x * 64 + lane;
-    const int n_cls = 2 * A, n_out = 6 * A;
-    const int per = (Cmid + 7) / 8;
-    const int c_lo = s * per, c_hi = min(Cmid, c_lo + per);
-    float acc[NOUT_MAX];
-#pragma unroll
-    for (int o = 0; o < NOUT_MAX; ++o) acc[o] = 0.0f;
-    // 16 channels at a time: 16 coalesced vector loads of h, then for every output one run of 16
-    // consecutive (wave-uniform -> scalar-loaded) weights
-    for (int c = c_lo; c < c_hi; c += 16) {
-        float hv[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) hv[q] = (p < HW && c + q < c_hi) ? h[(size_t)(c + q) * HW + p] : 0.0f;
-#pragma unroll
-        for (int o = 0; o < NOUT_MAX; ++o) {
-            if (o < n_out) {
-                const float *wr = ((o < n_cls) ? w_cls + (size_t)o * Cmid : w_bbox + (size_t)(o - n_cls) * Cmid) + c;
-#pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    if (c + q < c_hi) acc[o] = fmaf(wr[q], hv[q], acc[o]);
-            }
-        }
+// RPN heads.  rpn_cls_score (2A) and rpn_bbox_pred (4A) are ONE 1x1 convolution with the two weight matrices
+// stacked and zero-padded to NP = 64 output channels (rpn_heads_pack_kernel, once at load); it runs on the
+// MFMA kernel above (KS = 1) and writes raw[(NP, HW)]: rows [0,2A) are rpn_cls_score, rows [2A,6A) are
+// rpn_bbox_pred -- both contiguous NCHW blocks, handed out as views.  softmax_channels_kernel then applies
+// the reference's softmax over ALL 2A score channels (region_proposal_network.py:119), one thread per pixel.
+__global__ void __launch_bounds__(256)
+rpn_heads_pack_kernel(const float *__restrict__ w_cls, const float *__restrict__ b_cls, const float *__restrict__ w_bbox,
+                      const float *__restrict__ b_bbox, int Cmid, int A, int NP, float *__restrict__ wp, float *__restrict__ bp) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < Cmid * NP) {
+        const int o = i % NP, c = i / NP;
+        float v = 0.0f;
+        if (o < 2 * A) v = w_cls[(size_t)o * Cmid + c];
+        else if (o < 6 * A) v = w_bbox[(size_t)(o - 2 * A) * Cmid + c];
+        wp[i] = v;
     }
-#pragma unroll
-    for (int o = 0; o < NOUT_MAX; ++o) part[s][o][lane] = acc[o];
-    __syncthreads();
-    if (threadIdx.x < 64 && p < HW) {
-        float out[NOUT_MAX];
-#pragma unroll
-        for (int o = 0; o < NOUT_MAX; ++o) {
-            float v = 0.0f;
-            if (o < n_out) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v += part[q][o][lane];
-                v += (o < n_cls) ? b_cls[o] : b_bbox[o - n_cls];
-            }
-            out[o] = v;
-        }
-        float m = out[0];
-#pragma unroll
-        for (int o = 1; o < NOUT_MAX; ++o) if (o < n_cls) m = fmaxf(m, out[o]);
-        float e[NOUT_MAX];
-        float sum = 0.0f;
-#pragma unroll
-        for (int o = 0; o < NOUT_MAX; ++o) if (o < n_cls) { e[o] = expf(out[o] - m); sum += e[o]; }
-#pragma unroll
-        for (int o = 0; o < NOUT_MAX; ++o) {
-            if (o < n_cls) {
-                if (cls_score) cls_score[(size_t)o * HW + p] = out[o];
-                cls_prob[(size_t)o * HW + p] = e[o] / sum;
-            } else if (o < n_out) {
-                bbox_pred[(size_t)(o - n_cls) * HW + p] = out[o];
-            }
-        }
-    }
+    if (i < NP) bp[i] = (i < 2 * A) ? b_cls[i] : (i < 6 * A ? b_bbox[i - 2 * A] : 0.0f);
+}
+
+__global__ void __launch_bounds__(256)
+softmax_channels_kernel(const float *__restrict__ score, int n_ch, int HW, float *__restrict__ prob) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    float m = score[p];
+    for (int c = 1; c < n_ch; ++c) m = fmaxf(m, score[(size_t)c * HW + p]);
+    float sum = 0.0f;
+    for (int c = 0; c < n_ch; ++c) sum += expf(score[(size_t)c * HW + p] - m);
+    for (int c = 0; c < n_ch; ++c) prob[(size_t)c * HW + p] = expf(score[(size_t)c * HW + p] - m) / sum;
 }
 
 // ---- per-layer work decomposition ------------------------------------------------------------------
@@ -256,13 +218,13 @@ rpn_heads_kernel(const float *__restrict__ h, int Cmid, int HW, int A, const flo
 // cfg 1: 128co x (4 rows x 32 px), 4 waves 2x2, wave 64co x 2 rows  -- large maps
 // cfg 2: 64co x (4 rows x 32 px), 4 waves 2x2, wave 32co x 2 rows   -- mid maps (more, smaller units)
 // cfg 3: 64co x (2 rows x 32 px), 4 waves 2x2, wave 32co x 1 row    -- 38x63 / 75x125 maps
-template <int WCO, int WPX, int ACO, int APX, int CK>
+template <int KS, int WCO, int WPX, int ACO, int APX, int CK>
 static int launch_conv(const float *x, const float *wp, const float *bias, float *y, int Cin, int Cout, int H, int W, int relu,
                        hipStream_t stream) {
     constexpr int BCO = 32 * ACO * WCO, BROWS = APX * WPX;
     if (Cout % BCO != 0) return FRCNN_ERR_INVALID;
     const dim3 grid(frcnn_cdiv(W, 32), frcnn_cdiv(H, BROWS), Cout / BCO);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv3x3_mfma_f32_kernel<WCO, WPX, ACO, APX, CK>), grid, dim3(64 * WCO * WPX), 0, stream, x, wp,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_f32_kernel<KS, WCO, WPX, ACO, APX, CK>), grid, dim3(64 * WCO * WPX), 0, stream, x, wp,
                        bias, y, Cin, Cout, H, W, relu);
     return frcnn_launch_status();
 }
@@ -280,6 +242,8 @@ static int pick_conv_config(int Cin, int Cout, int H, int W) {
 
 extern "C" {
 
+int frcnn_rpn_heads_padded_channels(int A) { return ((6 * A + 63) / 64) * 64; }
+
 int frcnn_pack_conv3x3_w(const float *w, int Cout, int Cin, float *w_packed, void *stream) {
     if (!w || !w_packed || Cout < 1 || Cin < 1) return FRCNN_ERR_INVALID;
     const int total = Cout * Cin * 9;
@@ -293,10 +257,10 @@ int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bi
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (Cout % 4) != 0) return FRCNN_ERR_INVALID;
     if (cfg < 0) cfg = pick_conv_config(Cin, Cout, H, W);
     switch (cfg) {
-        case 0: return launch_conv<1, 4, 2, 2, 4>(x, w_packed, bias, y, Cin, Cout, H, W, relu, stream);
-        case 1: return launch_conv<2, 2, 2, 2, 4>(x, w_packed, bias, y, Cin, Cout, H, W, relu, stream);
-        case 2: return launch_conv<2, 2, 1, 2, 8>(x, w_packed, bias, y, Cin, Cout, H, W, relu, stream);
-        case 3: return launch_conv<2, 2, 1, 1, 8>(x, w_packed, bias, y, Cin, Cout, H, W, relu, stream);
+        case 0: return launch_conv<3, 1, 4, 2, 2, 4>(x, w_packed, bias, y, Cin, Cout, H, W, relu, stream);
+        case 1: return launch_conv<3, 2, 2, 2, 2, 4>(x, w_packed, bias, y, Cin, Cout, H, W, relu, stream);
+        case 2: return launch_conv<3, 2, 2, 1, 2, 8>(x, w_packed, bias, y, Cin, Cout, H, W, relu, stream);
+        case 3: return launch_conv<3, 2, 2, 1, 1, 8>(x, w_packed, bias, y, Cin, Cout, H, W, relu, stream);
         default: return FRCNN_ERR_INVALID;
     }
 }
@@ -315,13 +279,23 @@ int frcnn_maxpool2x2_f32(const float *x, float *y, int C, int H, int W, void *st
     return frcnn_launch_status();
 }
 
-int frcnn_rpn_heads_f32(const float *h, int Cmid, int H, int W, int A, const float *w_cls, const float *b_cls, const float *w_bbox,
-                        const float *b_bbox, float *cls_score, float *cls_prob, float *bbox_pred, void *stream) {
-    if (!h || !w_cls || !b_cls || !w_bbox || !b_bbox || !cls_prob || !bbox_pred) return FRCNN_ERR_INVALID;
-    if (Cmid < 1 || H < 1 || W < 1 || A < 1 || 6 * A > 54) return FRCNN_ERR_INVALID;
-    const int HW = H * W;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(rpn_heads_kernel<54>), dim3(frcnn_cdiv(HW, 64)), dim3(512), 0, (hipStream_t)stream, h, Cmid, HW, A,
-                       w_cls, b_cls, w_bbox, b_bbox, cls_score, cls_prob, bbox_pred);
+int frcnn_rpn_heads_pack(const float *w_cls, const float *b_cls, const float *w_bbox, const float *b_bbox, int Cmid, int A,
+                         float *w_packed, float *b_packed, void *stream) {
+    if (!w_cls || !b_cls || !w_bbox || !b_bbox || !w_packed || !b_packed || Cmid < 1 || A < 1) return FRCNN_ERR_INVALID;
+    const int NP = frcnn_rpn_heads_padded_channels(A);
+    hipLaunchKernelGGL(rpn_heads_pack_kernel, dim3(frcnn_cdiv(Cmid * NP, 256)), dim3(256), 0, (hipStream_t)stream, w_cls, b_cls, w_bbox,
+                       b_bbox, Cmid, A, NP, w_packed, b_packed);
+    return frcnn_launch_status();
+}
+
+int frcnn_rpn_heads_f32(const float *h, int Cmid, int H, int W, int A, const float *w_packed, const float *b_packed, float *raw,
+                        float *cls_prob, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!h || !w_packed || !b_packed || !raw || !cls_prob || Cmid < 1 || H < 1 || W < 1 || A < 1) return FRCNN_ERR_INVALID;
+    const int NP = frcnn_rpn_heads_padded_channels(A);
+    const int st = launch_conv<1, 2, 2, 1, 1, 8>(h, w_packed, b_packed, raw, Cmid, NP, H, W, 0, stream);
+    if (st != FRCNN_OK) return st;
+    hipLaunchKernelGGL(softmax_channels_kernel, dim3(frcnn_cdiv(H * W, 256)), dim3(256), 0, stream, raw, 2 * A, H * W, cls_prob);
     return frcnn_launch_status();
 }
 

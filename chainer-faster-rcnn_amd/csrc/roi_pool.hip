@@ -37,6 +37,8 @@ chw_to_hwc_kernel(const float *__restrict__ x, float *__restrict__ xt, int C, in
     }
 }
 
+constexpr int kBatch = 8;   // bin cells fetched per round
+
 struct RoiGeom { int xs, ys, rw, rh; };
 
 __device__ __forceinline__ RoiGeom roi_geometry(const float *__restrict__ roi, float scale) {
@@ -83,18 +85,31 @@ roi_pool_hwc_kernel(const float *__restrict__ xt, int C, int H, int W, const flo
 #pragma unroll
             for (int v = 0; v < VEC; ++v) { m[v] = 0.0f; mi[v] = -1; }
             if (!empty && cl < C) {
-                bool first = true;
-                for (int h = hs; h < he; ++h)
-                    for (int w = ws; w < we; ++w) {
-                        const float *src = xt + ((size_t)h * W + w) * C + cl;
-                        float val[VEC];
-                        if constexpr (VEC == 2) { const float2 q = *reinterpret_cast<const float2 *>(src); val[0] = q.x; val[1] = q.y; }
-                        else val[0] = src[0];
+                // Cells of the bin in row-major order, kBatch independent loads in flight at a time (the wave
+                // is latency-bound otherwise).  The tail re-reads the bin's last cell: with the strict `>`
+                // below a duplicate can never displace the first maximum, so no predication is needed.
+                const int bw = we - ws, ncell = (he - hs) * bw;
+                const float *base = xt + cl;
+                int hh = hs, ww = ws;                       // wave-uniform cursor
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) { m[v] = 0.0f; mi[v] = hs * W + ws; }
+                for (int i0 = 0; i0 < ncell; i0 += kBatch) {
+                    float val[kBatch][VEC];
+                    int pos[kBatch];
+#pragma unroll
+                    for (int q = 0; q < kBatch; ++q) {
+                        pos[q] = hh * W + ww;
+                        const float *src = base + (size_t)pos[q] * C;
+                        if constexpr (VEC == 2) { const float2 t2 = *reinterpret_cast<const float2 *>(src); val[q][0] = t2.x; val[q][1] = t2.y; }
+                        else val[q][0] = src[0];
+                        if (i0 + q + 1 < ncell) { if (++ww == we) { ww = ws; ++hh; } }   // stay on the last cell past the end
+                    }
+#pragma unroll
+                    for (int q = 0; q < kBatch; ++q)
 #pragma unroll
                         for (int v = 0; v < VEC; ++v)
-                            if (first || val[v] > m[v]) { m[v] = val[v]; mi[v] = h * W + w; }   // first maximum wins
-                        first = false;
-                    }
+                            if ((i0 == 0 && q == 0) || val[q][v] > m[v]) { m[v] = val[q][v]; mi[v] = pos[q]; }   // first maximum wins
+                }
             }
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {

@@ -44,6 +44,8 @@ class RegionProposalNetwork(object):
             W = np.ascontiguousarray(params[prefix + name + "/W"], dtype=np.float32)
             store["W"] = rt.asarray(W.reshape(W.shape[0], -1), "f32")
             store["b"] = rt.asarray(np.ascontiguousarray(params[prefix + name + "/b"], dtype=np.float32), "f32")
+        self._heads_packed = rt.rpn_heads_pack(self.rpn_cls_score["W"], self.rpn_cls_score["b"],
+                                               self.rpn_bbox_pred["W"], self.rpn_bbox_pred["b"])
 
     def _check_data_type_forward(self, x, img_info, gt_boxes):
         assert x.shape[0] == 1
@@ -59,8 +61,7 @@ class RegionProposalNetwork(object):
         h = self.rpn_conv_3x3(self.rt.asarray(unwrap(x), "f32"), relu=True)
         if timer:
             timer.mark("rpn_conv_3x3")
-        score, prob, bbox = self.rt.rpn_heads(h, self.rpn_cls_score["W"], self.rpn_cls_score["b"],
-                                              self.rpn_bbox_pred["W"], self.rpn_bbox_pred["b"], want_score=want_score)
+        score, prob, bbox = self.rt.rpn_heads(h, self._heads_packed)
         if timer:
             timer.mark("rpn_heads")
         return h, score, prob, bbox

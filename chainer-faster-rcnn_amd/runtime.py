@@ -196,16 +196,27 @@ class Runtime(object):
         _lib.check(L.frcnn_maxpool2x2_f32(m.ptr(x), m.ptr(y), C, H, W, m.stream()), "frcnn_maxpool2x2_f32")
         return y
 
-    def rpn_heads(self, h, w_cls, b_cls, w_bbox, b_bbox, want_score=True):
+    def rpn_heads_pack(self, w_cls, b_cls, w_bbox, b_bbox):
+        """Chainer-layout head weights -> (w_packed (Cmid,NP), b_packed (NP,), A); once, at load time."""
         m, L = self.mem, self.lib
+        A, Cmid = int(w_cls.shape[0]) // 2, int(w_cls.shape[1])
+        NP = L.frcnn_rpn_heads_padded_channels(A)
+        wp, bp = m.empty((Cmid, NP), "f32"), m.empty((NP,), "f32")
+        _lib.check(L.frcnn_rpn_heads_pack(m.ptr(w_cls), m.ptr(b_cls), m.ptr(w_bbox), m.ptr(b_bbox), Cmid, A, m.ptr(wp),
+                                          m.ptr(bp), m.stream()), "frcnn_rpn_heads_pack")
+        return wp, bp, A
+
+    def rpn_heads(self, h, packed):
+        """-> (rpn_cls_score (1,2A,H,W), rpn_cls_prob (1,2A,H,W), rpn_bbox_pred (1,4A,H,W)); score and bbox are
+        views of one (NP,H,W) buffer."""
+        m, L = self.mem, self.lib
+        wp, bp, A = packed
         C, H, W = [int(v) for v in h.shape[-3:]]
-        A = int(w_cls.shape[0]) // 2
-        score = m.empty((1, 2 * A, H, W), "f32") if want_score else None
+        raw = m.empty((int(wp.shape[1]), H, W), "f32")
         prob = m.empty((1, 2 * A, H, W), "f32")
-        bbox = m.empty((1, 4 * A, H, W), "f32")
-        _lib.check(L.frcnn_rpn_heads_f32(m.ptr(h), C, H, W, A, m.ptr(w_cls), m.ptr(b_cls), m.ptr(w_bbox), m.ptr(b_bbox),
-                                         m.ptr(score), m.ptr(prob), m.ptr(bbox), m.stream()), "frcnn_rpn_heads_f32")
-        return score, prob, bbox
+        _lib.check(L.frcnn_rpn_heads_f32(m.ptr(h), C, H, W, A, m.ptr(wp), m.ptr(bp), m.ptr(raw), m.ptr(prob), m.stream()),
+                   "frcnn_rpn_heads_f32")
+        return raw[:2 * A].reshape(1, 2 * A, H, W), prob, raw[2 * A:6 * A].reshape(1, 4 * A, H, W)
 
     # ------------------------------------------------------------------ head
     def linear(self, x, w, bias, relu=False):

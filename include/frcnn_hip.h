@@ -115,12 +115,17 @@ int frcnn_maxpool2x2_f32(const float *x, float *y, int C, int H, int W, void *st
 
 /* ---- RPN 1x1 heads + the reference's 18-way softmax ------------------------------------------------
  * Replaces rpn_cls_score / F.softmax / rpn_bbox_pred (models/region_proposal_network.py:118-120).
- * h (Cmid,H,W); w_cls (2A,Cmid), w_bbox (4A,Cmid) (Chainer (out,in,1,1) layout); softmax over ALL 2A
- * channels (axis 1), as the reference does.  cls_score may be NULL when only probabilities are needed.
+ *   frcnn_rpn_heads_pack (once, at load): w_cls (2A,Cmid), w_bbox (4A,Cmid) in Chainer's (out,in,1,1)
+ *       layout -> one stacked, zero-padded (Cmid, NP) matrix + (NP) bias, NP = frcnn_rpn_heads_padded_channels(A)
+ *   frcnn_rpn_heads_f32: h (Cmid,H,W) -> raw (NP,H,W): rows [0,2A) = rpn_cls_score, rows [2A,6A) =
+ *       rpn_bbox_pred (contiguous NCHW blocks, use them in place); cls_prob (2A,H,W) = softmax over ALL
+ *       2A score channels (axis 1), as the reference does.
  */
-int frcnn_rpn_heads_f32(const float *h, int Cmid, int H, int W, int A, const float *w_cls,
-                        const float *b_cls, const float *w_bbox, const float *b_bbox, float *cls_score,
-                        float *cls_prob, float *bbox_pred, void *stream);
+int frcnn_rpn_heads_padded_channels(int A);
+int frcnn_rpn_heads_pack(const float *w_cls, const float *b_cls, const float *w_bbox, const float *b_bbox,
+                         int Cmid, int A, float *w_packed, float *b_packed, void *stream);
+int frcnn_rpn_heads_f32(const float *h, int Cmid, int H, int W, int A, const float *w_packed,
+                        const float *b_packed, float *raw, float *cls_prob, void *stream);
 
 /* ---- fully connected head --------------------------------------------------------------------------
  * Replaces L.Linear + F.relu (models/faster_rcnn.py:33-36,127-134): y(M,N) = act(x(M,K) @ W(N,K)^T + b).

@@ -174,8 +174,9 @@ def check_rpn_heads(rt, Cmid=128, H=9, W=13, A=9, seed=0):
     score = O.conv2d(h, p["RPN/rpn_cls_score/W"], p["RPN/rpn_cls_score/b"], 0)
     prob = O.softmax(score, axis=1)        # 18-way, region_proposal_network.py:119
     bbox = O.conv2d(h, p["RPN/rpn_bbox_pred/W"], p["RPN/rpn_bbox_pred/b"], 0)
-    s, pr, bb = rt.rpn_heads(dev(rt, h), dev(rt, p["RPN/rpn_cls_score/W"].reshape(2 * A, Cmid)), dev(rt, p["RPN/rpn_cls_score/b"]),
-                             dev(rt, p["RPN/rpn_bbox_pred/W"].reshape(4 * A, Cmid)), dev(rt, p["RPN/rpn_bbox_pred/b"]))
+    packed = rt.rpn_heads_pack(dev(rt, p["RPN/rpn_cls_score/W"].reshape(2 * A, Cmid)), dev(rt, p["RPN/rpn_cls_score/b"]),
+                               dev(rt, p["RPN/rpn_bbox_pred/W"].reshape(4 * A, Cmid)), dev(rt, p["RPN/rpn_bbox_pred/b"]))
+    s, pr, bb = rt.rpn_heads(dev(rt, h), packed)
     assert np.allclose(host(rt, s), score, rtol=1e-4, atol=1e-5)
     assert np.allclose(host(rt, pr), prob, rtol=1e-4, atol=1e-6)
     assert np.allclose(host(rt, bb), bbox, rtol=1e-4, atol=1e-5)
