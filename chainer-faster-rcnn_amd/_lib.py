@@ -31,8 +31,9 @@ SIGNATURES = {
     "frcnn_roi_pool_fwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _F, _P, _P, _P, _S, _P]),
     "frcnn_roi_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "frcnn_pack_conv3x3_w": (_I, [_P, _I, _I, _P, _P]),
-    "frcnn_conv3x3_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "frcnn_conv3x3_f32_cfg": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "frcnn_conv3x3_workspace_bytes": (_S, [_I, _I, _I, _I]),
+    "frcnn_conv3x3_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),
+    "frcnn_conv3x3_f32_cfg": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_maxpool2x2_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "frcnn_rpn_heads_padded_channels": (_I, [_I]),
     "frcnn_rpn_heads_pack": (_I, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),

@@ -23,16 +23,32 @@
 //
 // Roofline: compute-bound everywhere except conv1_1 (K = 27: 153.6 MB of output for 2 GFLOP).
 #include "frcnn_common.h"
+#include <frcnn_sync.h>   // angle brackets: the test emulator shadows this header via its include path
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
 // KS = 3: 3x3 / pad 1 (the VGG and RPN convs);  KS = 1: 1x1 / pad 0 (the RPN heads) -- same machinery, no halo.
-template <int KS, int WCO, int WPX, int ACO, int APX, int CK>
-__global__ void __launch_bounds__(64 * WCO * WPX)
+//
+// Work distribution ("stream-K").  The unit of work is one K-chunk of one output tile; a layer has
+// total = ntiles * nchunks of them.  Workgroup g of G processes the contiguous range
+// [g*total/G, (g+1)*total/G): with G = ntiles every workgroup owns exactly one tile (the classic
+// decomposition); with G = (CUs x resident workgroups per CU) every workgroup gets the SAME amount of matrix
+// work regardless of how the tile count divides the chip -- at batch 1 the tile count of a VGG layer is only
+// 1-5x the number of workgroup slots, and whole-tile scheduling leaves 10-40 % of the MFMA cycles idle in
+// the last partial round.  A tile whose chunks are shared by P > 1 workgroups is finished by whichever of them
+// arrives last: every piece stores its partial accumulators (fragment-linear, coalesced) in its own workspace
+// slot, publishes with an agent-scope release and takes a ticket on the tile's counter; the holder of
+// ticket P-1 acquires, adds the P pieces IN PIECE ORDER (so the result does not depend on arrival order)
+// and runs the bias/ReLU epilogue.  Nobody ever waits, so residency is irrelevant to correctness.
+// BPC = workgroups meant to be co-resident per CU; it is the register budget handed to the compiler
+// (__launch_bounds__'s second argument is waves per SIMD = BPC * threads / 256).
+template <int KS, int WCO, int WPX, int ACO, int APX, int CK, bool PIPE, int BPC>
+__global__ void __launch_bounds__(64 * WCO * WPX, (BPC * 64 * WCO * WPX) / 256)
 conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
-                        float *__restrict__ y, int Cin, int Cout, int H, int W, int relu) {
+                     float *__restrict__ y, int Cin, int Cout, int H, int W, int relu, int xtiles, int ytiles, int nchunks,
+                     long long total, float *__restrict__ partial_ws, int *__restrict__ tile_counters) {
     constexpr int NT = 64 * WCO * WPX;
     constexpr int BCO = 32 * ACO * WCO;
     constexpr int BROWS = APX * WPX;
@@ -44,117 +60,204 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
     constexpr int WIT = (WV + NT - 1) / NT;
     constexpr int HV = CK * HR * kHaloPitch;         // halo floats per chunk
     constexpr int HIT = (HV + NT - 1) / NT;
+    constexpr int FRAG = ACO * APX * 16;             // accumulator floats per thread
     __shared__ __attribute__((aligned(16))) float w_lds[2][KR][BCO];
     __shared__ __attribute__((aligned(16))) float in_lds[2][CK][HR][kHaloPitch];
+    __shared__ int s_ticket;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave % WCO, wpx = wave / WCO;
-    const int x0 = blockIdx.x * 32, y0 = blockIdx.y * BROWS, co0 = blockIdx.z * BCO;
     const int HW = H * W;
     const int K = Cin * TAPS;
-    const int nchunks = (Cin + CK - 1) / CK;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int a_col = wco * (32 * ACO) + l31;
+    const int b_row = wpx * APX;
+    const long long G = gridDim.x, g = blockIdx.x;
+    const long long it_begin = g * total / G, it_end = (g + 1) * total / G;
 
     float4 wreg[WIT];
     float hreg[HIT];
 
-    auto fetch = [&](int chunk) {
+    for (long long it = it_begin; it < it_end;) {
+        const int tile = (int)(it / nchunks);
+        const int c_begin = (int)(it - (long long)tile * nchunks);
+        const int c_end = (int)((long long)nchunks < c_begin + (it_end - it) ? (long long)nchunks : c_begin + (it_end - it));
+        const int tx = tile % xtiles, ty = (tile / xtiles) % ytiles, cot = tile / (xtiles * ytiles);
+        const int x0 = tx * 32, y0 = ty * BROWS, co0 = cot * BCO;
+
+        auto fetch = [&](int chunk) {
 #pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-            const int v = tid + it * NT;
-            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (v < WV) {
-                const int row = v / (BCO / 4), c4 = v % (BCO / 4);
-                const int grow = chunk * KR + row;
-                if (grow < K) q = *reinterpret_cast<const float4 *>(wp + (size_t)grow * Cout + co0 + c4 * 4);
+            for (int q = 0; q < WIT; ++q) {
+                const int v = tid + q * NT;
+                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (v < WV) {
+                    const int row = v / (BCO / 4), c4 = v % (BCO / 4);
+                    const int grow = chunk * KR + row;
+                    if (grow < K) f = *reinterpret_cast<const float4 *>(wp + (size_t)grow * Cout + co0 + c4 * 4);
+                }
+                wreg[q] = f;
             }
-            wreg[it] = q;
-        }
 #pragma unroll
-        for (int it = 0; it < HIT; ++it) {
-            const int e = tid + it * NT;
-            float val = 0.0f;
-            if (e < HV) {
-                const int c = e / (HR * kHaloPitch), rem = e % (HR * kHaloPitch);
-                const int hr = rem / kHaloPitch, hx = rem % kHaloPitch;
-                const int gc = chunk * CK + c, gy = y0 - PAD + hr, gx = x0 - PAD + hx;
-                if (gc < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) val = x[(size_t)gc * HW + gy * W + gx];
+            for (int q = 0; q < HIT; ++q) {
+                const int e = tid + q * NT;
+                float val = 0.0f;
+                if (e < HV) {
+                    const int c = e / (HR * kHaloPitch), rem = e % (HR * kHaloPitch);
+                    const int hr = rem / kHaloPitch, hx = rem % kHaloPitch;
+                    const int gc = chunk * CK + c, gy = y0 - PAD + hr, gx = x0 - PAD + hx;
+                    if (gc < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) val = x[(size_t)gc * HW + gy * W + gx];
+                }
+                hreg[q] = val;
             }
-            hreg[it] = val;
-        }
-    };
-    auto stage = [&](int buf) {
+        };
+        auto stage = [&](int buf) {
 #pragma unroll
-        for (int it = 0; it < WIT; ++it) {
-            const int v = tid + it * NT;
-            if (v < WV) reinterpret_cast<float4 *>(&w_lds[buf][0][0])[v] = wreg[it];
-        }
+            for (int q = 0; q < WIT; ++q) {
+                const int v = tid + q * NT;
+                if (v < WV) reinterpret_cast<float4 *>(&w_lds[buf][0][0])[v] = wreg[q];
+            }
 #pragma unroll
-        for (int it = 0; it < HIT; ++it) {
-            const int e = tid + it * NT;
-            if (e < HV) (&in_lds[buf][0][0][0])[e] = hreg[it];
-        }
-    };
+            for (int q = 0; q < HIT; ++q) {
+                const int e = tid + q * NT;
+                if (e < HV) (&in_lds[buf][0][0][0])[e] = hreg[q];
+            }
+        };
 
-    f32x16 acc[ACO][APX];
+        f32x16 acc[ACO][APX];
 #pragma unroll
-    for (int i = 0; i < ACO; ++i)
+        for (int i = 0; i < ACO; ++i)
 #pragma unroll
-        for (int j = 0; j < APX; ++j)
+            for (int j = 0; j < APX; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    fetch(0);
-    stage(0);
-    __syncthreads();
-
-    const int l31 = lane & 31, khalf = lane >> 5;
-    const int a_col = wco * (32 * ACO) + l31;
-    const int b_row = wpx * APX;
-    int cur = 0;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const bool more = chunk + 1 < nchunks;
-        if (more) fetch(chunk + 1);
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int ky = tap / KS, kx = tap % KS;
-#pragma unroll
-            for (int cp = 0; cp < CK / 2; ++cp) {
+        fetch(c_begin);
+        stage(0);
+        __syncthreads();
+        int cur = 0;
+        for (int chunk = c_begin; chunk < c_end; ++chunk) {
+            const bool more = chunk + 1 < c_end;
+            if (more) fetch(chunk + 1);
+            constexpr int NSTEP = TAPS * (CK / 2);       // k-steps per chunk: step s = (tap, channel pair)
+            auto frag = [&](int s, float *a, float *b) {
+                const int tap = s / (CK / 2), cp = s % (CK / 2);
+                const int ky = tap / KS, kx = tap % KS;
                 const int c = 2 * cp + khalf;
-                float a[ACO], b[APX];
 #pragma unroll
                 for (int i = 0; i < ACO; ++i) a[i] = w_lds[cur][c * TAPS + tap][a_col + 32 * i];
 #pragma unroll
                 for (int j = 0; j < APX; ++j) b[j] = in_lds[cur][c][b_row + j + ky][l31 + kx];
+            };
+            if constexpr (PIPE) {
+                // fragments of step s+1 are read before the MFMAs of step s are issued (register double
+                // buffer): the LDS latency sits under 64*ACO*APX cycles of matrix work, not in front of it
+                float a[2][ACO], b[2][APX];
+                frag(0, a[0], b[0]);
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s) {
+                    if (s + 1 < NSTEP) frag(s + 1, a[(s + 1) & 1], b[(s + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);       // keep the prefetch ahead of this step's MFMAs
+#pragma unroll
+                    for (int i = 0; i < ACO; ++i)
+#pragma unroll
+                        for (int j = 0; j < APX; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s & 1][i], b[s & 1][j], acc[i][j], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s) {
+                    float a[ACO], b[APX];
+                    frag(s, a, b);
+#pragma unroll
+                    for (int i = 0; i < ACO; ++i)
+#pragma unroll
+                        for (int j = 0; j < APX; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                }
+            }
+            if (more) stage(cur ^ 1);
+            __syncthreads();
+            cur ^= 1;
+        }
+
+        bool finish = true;
+        if (c_begin != 0 || c_end != nchunks) {
+            // ---- this workgroup holds one of P pieces of the tile
+            auto start_of = [&](long long b) { return b * total / G; };
+            auto owner_of = [&](long long i) {          // the workgroup whose range contains iteration i
+                long long b = i * G / total;
+                while (start_of(b + 1) <= i) ++b;
+                while (start_of(b) > i) --b;
+                return b;
+            };
+            const long long t_first = (long long)tile * nchunks, t_last = t_first + nchunks - 1;
+            const long long g_first = owner_of(t_first), g_last = owner_of(t_last);
+            const int P = (int)(g_last - g_first + 1), p = (int)(g - g_first);
+            // slot 0 = the piece a workgroup starts with, slot 1 = the piece it ends with
+            const int my_slot = (it == it_begin) ? 0 : 1;
+            float *mine = partial_ws + ((size_t)g * 2 + my_slot) * ((size_t)NT * FRAG);
+#pragma unroll
+            for (int i = 0; i < ACO; ++i)
+#pragma unroll
+                for (int j = 0; j < APX; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mine[(size_t)((i * APX + j) * 16 + r) * NT + tid] = acc[i][j][r];
+            frcnn_drain_vmem();
+            __syncthreads();
+            if (tid == 0) {
+                frcnn_release_agent();
+                s_ticket = frcnn_ticket(&tile_counters[tile]);
+            }
+            __syncthreads();
+            finish = (s_ticket == P - 1);
+            if (finish) {
+                if (tid == 0) frcnn_acquire_agent();
+                __syncthreads();
+                // re-accumulate ALL P pieces (this workgroup's own one included, read back from its slot) in
+                // piece order: the sum is then independent of which piece happened to arrive last, and no
+                // second accumulator set is needed
 #pragma unroll
                 for (int i = 0; i < ACO; ++i)
 #pragma unroll
                     for (int j = 0; j < APX; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-        }
-        if (more) stage(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    // epilogue: D register r of lane l = cout (r&3) + 8*(r>>2) + 4*(l>>5), pixel l&31
-    const int px = x0 + l31;
 #pragma unroll
-    for (int i = 0; i < ACO; ++i) {
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+                for (int q = 0; q < P; ++q) {
+                    const long long b = g_first + q;
+                    const int slot = (q == 0 && start_of(b) != t_first) ? 1 : 0;
+                    const float *piece = partial_ws + ((size_t)b * 2 + slot) * ((size_t)NT * FRAG);
 #pragma unroll
-        for (int j = 0; j < APX; ++j) {
-            const int py = y0 + b_row + j;
-            if (px < W && py < H) {
+                    for (int i = 0; i < ACO; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + wco * (32 * ACO) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                    float v = acc[i][j][r] + bias[co];
-                    if (relu) v = fmaxf(v, 0.0f);
-                    y[(size_t)co * HW + (size_t)py * W + px] = v;
+                        for (int j = 0; j < APX; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[i][j][r] += piece[(size_t)((i * APX + j) * 16 + r) * NT + tid];
                 }
             }
         }
+
+        if (finish) {
+            // epilogue: D register r of lane l = cout (r&3) + 8*(r>>2) + 4*(l>>5), pixel l&31
+            const int px = x0 + l31;
+#pragma unroll
+            for (int i = 0; i < ACO; ++i) {
+#pragma unroll
+                for (int j = 0; j < APX; ++j) {
+                    const int py = y0 + b_row + j;
+                    if (px < W && py < H) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int co = co0 + wco * (32 * ACO) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                            float v = acc[i][j][r] + bias[co];
+                            if (relu) v = fmaxf(v, 0.0f);
+                            y[(size_t)co * HW + (size_t)py * W + px] = v;
+                        }
+                    }
+                }
+            }
+        }
+        it += c_end - c_begin;
     }
 }
 
@@ -218,24 +321,65 @@ softmax_channels_kernel(const float *__restrict__ score, int n_ch, int HW, float
 // cfg 1: 128co x (4 rows x 32 px), 4 waves 2x2, wave 64co x 2 rows  -- large maps
 // cfg 2: 64co x (4 rows x 32 px), 4 waves 2x2, wave 32co x 2 rows   -- mid maps (more, smaller units)
 // cfg 3: 64co x (2 rows x 32 px), 4 waves 2x2, wave 32co x 1 row    -- 38x63 / 75x125 maps
-template <int KS, int WCO, int WPX, int ACO, int APX, int CK>
+// Workspace of the stream-K distribution: tile counters (one int per tile) followed by two partial-tile slots
+// per workgroup.  Sized for the worst case over all decompositions; owned by the caller.
+struct ConvPlan { int xtiles, ytiles, cotiles, nchunks, ntiles, G; long long total; size_t counters_bytes, ws_bytes; };
+
+static int frcnn_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else cus = 256;
+    }
+    return cus;
+}
+
+template <int WCO, int WPX, int ACO, int APX, int CK>
+static ConvPlan plan_conv(int Cin, int Cout, int H, int W, int blocks_per_cu, int streamk) {
+    constexpr int BCO = 32 * ACO * WCO, BROWS = APX * WPX, NT = 64 * WCO * WPX, FRAG = ACO * APX * 16;
+    ConvPlan p;
+    p.xtiles = frcnn_cdiv(W, 32); p.ytiles = frcnn_cdiv(H, BROWS); p.cotiles = Cout / BCO;
+    p.nchunks = frcnn_cdiv(Cin, CK);
+    p.ntiles = p.xtiles * p.ytiles * p.cotiles;
+    p.total = (long long)p.ntiles * p.nchunks;
+    const int slots = frcnn_cu_count() * blocks_per_cu;
+    // stream-K only pays when whole-tile scheduling would leave a ragged last round
+    p.G = (streamk && p.ntiles > slots && p.total >= slots) ? slots : p.ntiles;
+    if (streamk == 2 && p.total >= slots) p.G = slots;          // forced (tests / tuning)
+    p.counters_bytes = frcnn_align256((size_t)p.ntiles * sizeof(int));
+    p.ws_bytes = p.counters_bytes + (p.G == p.ntiles ? 0 : (size_t)p.G * 2 * NT * FRAG * sizeof(float));
+    return p;
+}
+
+template <int KS, int WCO, int WPX, int ACO, int APX, int CK, bool PIPE, int BPC>
 static int launch_conv(const float *x, const float *wp, const float *bias, float *y, int Cin, int Cout, int H, int W, int relu,
-                       hipStream_t stream) {
-    constexpr int BCO = 32 * ACO * WCO, BROWS = APX * WPX;
+                       int streamk, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+    constexpr int blocks_per_cu = BPC;
+    constexpr int BCO = 32 * ACO * WCO;
     if (Cout % BCO != 0) return FRCNN_ERR_INVALID;
-    const dim3 grid(frcnn_cdiv(W, 32), frcnn_cdiv(H, BROWS), Cout / BCO);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_f32_kernel<KS, WCO, WPX, ACO, APX, CK>), grid, dim3(64 * WCO * WPX), 0, stream, x, wp,
-                       bias, y, Cin, Cout, H, W, relu);
+    ConvPlan p = plan_conv<WCO, WPX, ACO, APX, CK>(Cin, Cout, H, W, blocks_per_cu, streamk);
+    if (p.G != p.ntiles && (!workspace || workspace_bytes < p.ws_bytes)) {     // no workspace: fall back to whole tiles
+        p.G = p.ntiles;
+    }
+    int *counters = nullptr;
+    float *partials = nullptr;
+    if (p.G != p.ntiles) {
+        counters = (int *)workspace;
+        partials = (float *)((char *)workspace + p.counters_bytes);
+        FRCNN_HIP_TRY(hipMemsetAsync(counters, 0, p.counters_bytes, stream));
+    }
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_f32_kernel<KS, WCO, WPX, ACO, APX, CK, PIPE, BPC>), dim3(p.G), dim3(64 * WCO * WPX), 0,
+                       stream, x, wp, bias, y, Cin, Cout, H, W, relu, p.xtiles, p.ytiles, p.nchunks, p.total, partials, counters);
     return frcnn_launch_status();
 }
 
+// Chosen from scripts/conv_sweep.py on MI355X (profiles/r01_conv_sweep.json).
 static int pick_conv_config(int Cin, int Cout, int H, int W) {
-    (void)Cin;
-    const long units22 = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 2) * (Cout / 64);   // 64co x 2rows wave units
-    if (Cout % 128 == 0 && units22 >= 4096) return 1;
-    if (Cout == 64 && units22 >= 4096) return 0;
-    if (units22 >= 4096) return 2;
-    return 3;
+    if (Cin < 8) return 8;                                     // conv1_1: K = 27, output-write bound
+    const long px_tiles = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4);
+    if (px_tiles * (Cout / 64) >= 1536) return 10;             // 64co x 4 rows, wave 32co x 2 rows
+    return 5;                                                  // 64co x 2 rows, wave 32co x 1 row
 }
 
 }  // namespace
@@ -251,23 +395,51 @@ int frcnn_pack_conv3x3_w(const float *w, int Cout, int Cin, float *w_packed, voi
     return frcnn_launch_status();
 }
 
+// cfg = decomposition id + 100 * stream-K mode (0 = whole tiles, 1 = stream-K when it pays, 2 = forced)
+#define FRCNN_CONV_CASES(X)                                  \
+    X(0, 1, 4, 2, 2, 4, false, 2)                             \
+    X(1, 2, 2, 2, 2, 4, false, 2)                             \
+    X(2, 2, 2, 1, 2, 8, false, 3)                             \
+    X(3, 2, 2, 1, 1, 8, false, 3)                             \
+    X(4, 2, 2, 2, 2, 4, true, 2)                              \
+    X(5, 2, 2, 1, 1, 8, true, 3)                              \
+    X(8, 1, 4, 2, 2, 4, true, 2)                              \
+    X(10, 2, 2, 1, 2, 8, true, 3)                             \
+    X(11, 1, 4, 2, 1, 8, true, 3)
+
+size_t frcnn_conv3x3_workspace_bytes(int Cin, int Cout, int H, int W) {
+    if (Cin < 1 || Cout < 1 || H < 1 || W < 1) return 0;
+    size_t best = 256;
+#define X(id, wco, wpx, aco, apx, ck, pipe, bpc)                                                        \
+    if (Cout % (32 * aco * wco) == 0) {                                                                 \
+        const ConvPlan p = plan_conv<wco, wpx, aco, apx, ck>(Cin, Cout, H, W, bpc, 2);                   \
+        if (p.ws_bytes > best) best = p.ws_bytes;                                                       \
+    }
+    FRCNN_CONV_CASES(X)
+#undef X
+    return best;
+}
+
 int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bias, float *y, int Cin, int Cout, int H, int W,
-                          int relu, int cfg, void *stream_) {
+                          int relu, int cfg, void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (Cout % 4) != 0) return FRCNN_ERR_INVALID;
-    if (cfg < 0) cfg = pick_conv_config(Cin, Cout, H, W);
+    int streamk = 1;
+    if (cfg >= 0) { streamk = cfg / 100; cfg %= 100; }
+    else cfg = pick_conv_config(Cin, Cout, H, W);
     switch (cfg) {
-        case 0: return launch_conv<3, 1, 4, 2, 2, 4>(x, w_packed, bias, y, Cin, Cout, H, W, relu, stream);
-        case 1: return launch_conv<3, 2, 2, 2, 2, 4>(x, w_packed, bias, y, Cin, Cout, H, W, relu, stream);
-        case 2: return launch_conv<3, 2, 2, 1, 2, 8>(x, w_packed, bias, y, Cin, Cout, H, W, relu, stream);
-        case 3: return launch_conv<3, 2, 2, 1, 1, 8>(x, w_packed, bias, y, Cin, Cout, H, W, relu, stream);
+#define X(id, wco, wpx, aco, apx, ck, pipe, bpc)                                                                          \
+    case id: return launch_conv<3, wco, wpx, aco, apx, ck, pipe, bpc>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, \
+                                                                      workspace, workspace_bytes, stream);
+        FRCNN_CONV_CASES(X)
+#undef X
         default: return FRCNN_ERR_INVALID;
     }
 }
 
 int frcnn_conv3x3_f32(const float *x, const float *w_packed, const float *bias, float *y, int Cin, int Cout, int H, int W, int relu,
-                      void *stream) {
-    return frcnn_conv3x3_f32_cfg(x, w_packed, bias, y, Cin, Cout, H, W, relu, -1, stream);
+                      void *workspace, size_t workspace_bytes, void *stream) {
+    return frcnn_conv3x3_f32_cfg(x, w_packed, bias, y, Cin, Cout, H, W, relu, -1, workspace, workspace_bytes, stream);
 }
 
 int frcnn_maxpool2x2_f32(const float *x, float *y, int C, int H, int W, void *stream) {
@@ -293,7 +465,7 @@ int frcnn_rpn_heads_f32(const float *h, int Cmid, int H, int W, int A, const flo
     hipStream_t stream = (hipStream_t)stream_;
     if (!h || !w_packed || !b_packed || !raw || !cls_prob || Cmid < 1 || H < 1 || W < 1 || A < 1) return FRCNN_ERR_INVALID;
     const int NP = frcnn_rpn_heads_padded_channels(A);
-    const int st = launch_conv<1, 2, 2, 1, 1, 8>(h, w_packed, b_packed, raw, Cmid, NP, H, W, 0, stream);
+    const int st = launch_conv<1, 2, 2, 1, 1, 8, true, 3>(h, w_packed, b_packed, raw, Cmid, NP, H, W, 0, 0, nullptr, 0, stream);
     if (st != FRCNN_OK) return st;
     hipLaunchKernelGGL(softmax_channels_kernel, dim3(frcnn_cdiv(H * W, 256)), dim3(256), 0, stream, raw, 2 * A, H * W, cls_prob);
     return frcnn_launch_status();

@@ -185,8 +185,10 @@ class Runtime(object):
         co = int(w_packed.shape[1])
         assert int(w_packed.shape[0]) == ci * 9
         y = out if out is not None else m.empty((1, co, H, W), "f32")
+        ws = self.workspace("conv3x3", L.frcnn_conv3x3_workspace_bytes(ci, co, H, W))
         _lib.check(L.frcnn_conv3x3_f32_cfg(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(y), ci, co, H, W,
-                                           int(bool(relu)), int(cfg), m.stream()), "frcnn_conv3x3_f32")
+                                           int(bool(relu)), int(cfg), m.ptr(ws), ws.shape[0], m.stream()),
+                   "frcnn_conv3x3_f32")
         return y
 
     def maxpool2x2(self, x, out=None):

@@ -102,15 +102,21 @@ int frcnn_roi_pool_bwd(const float *dy, const int32_t *argmax, int R, int C, int
  * and F.MaxPooling2D(2,2) (cover_all => ceil-mode) on the batch-1 NCHW path.
  *   frcnn_pack_conv3x3_w: (Cout,Cin,3,3) Chainer layout -> packed [(ci*9+tap)][Cout] f32 (once, at load)
  *   frcnn_conv3x3_f32:    y = act(conv3x3(x, pad 1, stride 1) + b); x (Cin,H,W), y (Cout,H,W);
- *                         f32 operands, exact-f32 MFMA accumulation (v_mfma_f32_32x32x2_f32)
+ *                         f32 operands, exact-f32 MFMA accumulation (v_mfma_f32_32x32x2_f32); the
+ *                         workspace holds the partial tiles of the stream-K work distribution
  *   frcnn_maxpool2x2_f32: (C,H,W) -> (C,ceil(H/2),ceil(W/2))
  */
 int frcnn_pack_conv3x3_w(const float *w, int Cout, int Cin, float *w_packed, void *stream);
+size_t frcnn_conv3x3_workspace_bytes(int Cin, int Cout, int H, int W);
 int frcnn_conv3x3_f32(const float *x, const float *w_packed, const float *bias, float *y, int Cin,
-                      int Cout, int H, int W, int relu, void *stream);
-/* same, with an explicit work-decomposition id (0..3; -1 = automatic): the tuning hook bench.py sweeps */
+                      int Cout, int H, int W, int relu, void *workspace, size_t workspace_bytes,
+                      void *stream);
+/* same, with an explicit work decomposition: cfg = tile-shape id (0..11) + 100 * mode, mode 0 = one
+ * workgroup per tile, 1 = stream-K when the tile count is ragged, 2 = stream-K forced; -1 = automatic.
+ * The tuning hook scripts/conv_sweep.py drives.  workspace may be NULL (then whole tiles are used). */
 int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bias, float *y, int Cin,
-                          int Cout, int H, int W, int relu, int cfg, void *stream);
+                          int Cout, int H, int W, int relu, int cfg, void *workspace,
+                          size_t workspace_bytes, void *stream);
 int frcnn_maxpool2x2_f32(const float *x, float *y, int C, int H, int W, void *stream);
 
 /* ---- RPN 1x1 heads + the reference's 18-way softmax ------------------------------------------------

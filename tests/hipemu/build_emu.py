@@ -16,7 +16,7 @@ def build(force=False, sources=None):
     os.makedirs(OUT, exist_ok=True)
     so = os.path.join(OUT, "libfrcnn_emu.so")
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip"))) if sources is None else sources
-    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "hip", "hip_runtime.h"),
+    deps = srcs + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(HERE, "shadow", "*.h")) + [os.path.join(HERE, "hip", "hip_runtime.h"),
                                                           os.path.join(ROOT, "include", "frcnn_hip.h")]
     if not force and os.path.exists(so) and all(os.path.getmtime(so) >= os.path.getmtime(d) for d in deps):
         return so
@@ -27,7 +27,8 @@ def build(force=False, sources=None):
         objs.append(o)
         procs.append(subprocess.Popen([CLANG if os.path.exists(CLANG) else "g++", "-x", "c++", "-std=c++17", "-O1", "-g",
                                        "-ffp-contract=off", "-fPIC", "-Wno-unused-function", "-Wno-unused-value",
-                                       "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", s, "-o", o]))
+                                       "-I", os.path.join(HERE, "shadow"), "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+                                       "-c", s, "-o", o]))
     for p in procs:
         if p.wait() != 0:
             raise RuntimeError("hipemu build failed")

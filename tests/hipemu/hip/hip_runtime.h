@@ -59,6 +59,10 @@ static inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 0; return hipSuccess; }  // the emulator is not a device
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+// a deliberately odd, tiny "chip" so persistent / stream-K decompositions split tiles unevenly under test
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 3; return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 

@@ -57,15 +57,30 @@ def test_roi_pool_full_size(rt):
     P.check_roi_pool(rt, R=7, C=64, H=19, W=32, seed=2)   # VEC=1 path
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, -1])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 8, 10, 11, 104, 105, 108, 110, 205, 210, -1])
 def test_conv3x3_cfgs(rt, cfg):
-    P.check_conv3x3(rt, 64, 128 if cfg == 1 else 64, 75, 125, cfg=cfg)
+    P.check_conv3x3(rt, 64, 128, 75, 125, cfg=cfg)
 
 
 @pytest.mark.parametrize("cin,cout,h,w", [(3, 64, 120, 200), (64, 64, 60, 100), (128, 256, 75, 125), (512, 512, 38, 63),
                                           (256, 512, 19, 32)])
 def test_conv3x3_vgg_shapes(rt, cin, cout, h, w):
     P.check_conv3x3(rt, cin, cout, h, w)
+
+
+def test_conv3x3_streamk_is_deterministic(rt):
+    """Split tiles are summed in piece order by whichever workgroup arrives last: repeated launches must agree
+    bit for bit, and with the whole-tile schedule to rounding."""
+    import numpy as np
+    rs = np.random.RandomState(0)
+    x = P.dev(rt, rs.randn(1, 256, 150, 250).astype(np.float32))
+    w = P.dev(rt, (rs.randn(256, 256, 3, 3) * 0.02).astype(np.float32))
+    b = P.dev(rt, rs.randn(256).astype(np.float32))
+    wp = rt.pack_conv3x3_w(w)
+    ref = P.host(rt, rt.conv3x3(x, wp, b, cfg=10))
+    outs = [P.host(rt, rt.conv3x3(x, wp, b, cfg=210)) for _ in range(4)]
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
+    assert np.abs(outs[0] - ref).max() <= 1e-4 * np.abs(ref).max()
 
 
 def test_maxpool(rt):

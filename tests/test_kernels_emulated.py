@@ -49,9 +49,17 @@ def test_roi_pool(rt):
     P.check_roi_pool(rt, R=5, C=64, H=38, W=63, seed=1)     # VEC=1 path (C % 128 != 0)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 8, 10, 11])
 def test_conv3x3_cfg(rt, cfg):
-    P.check_conv3x3(rt, 8, 128 if cfg == 1 else 64, 7, 37, cfg=cfg)
+    P.check_conv3x3(rt, 8, 128, 9, 37, cfg=cfg)
+
+
+@pytest.mark.parametrize("cfg", [201, 205, 210, 104, 110])
+def test_conv3x3_streamk(rt, cfg):
+    """stream-K work distribution: the emulated chip has 3 CUs, so tiles split unevenly into 2..4 pieces and the
+    last-arriver fix-up (partial slots, tickets, piece-ordered sum) is exercised."""
+    P.check_conv3x3(rt, 24, 128, 9, 70, cfg=cfg)
+    P.check_conv3x3(rt, 8, 64 if cfg % 100 != 1 and cfg % 100 != 4 else 128, 21, 33, cfg=cfg, seed=1)
 
 
 def test_conv3x3_cin3_and_norelu(rt):
