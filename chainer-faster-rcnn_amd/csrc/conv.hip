@@ -23,7 +23,8 @@
 //
 // Roofline: compute-bound everywhere except conv1_1 (K = 27: 153.6 MB of output for 2 GFLOP).
 #include "frcnn_common.h"
-#include <frcnn_sync.h>   // angle brackets: the test emulator shadows this header via its include path
+#include <frcnn_sync.h>   // angle brackets: the test emulator shadows these headers via its include path
+#include <frcnn_buffer.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -44,7 +45,7 @@ namespace {
 // and runs the bias/ReLU epilogue.  Nobody ever waits, so residency is irrelevant to correctness.
 // BPC = workgroups meant to be co-resident per CU; it is the register budget handed to the compiler
 // (__launch_bounds__'s second argument is waves per SIMD = BPC * threads / 256).
-template <int KS, int WCO, int WPX, int ACO, int APX, int CK, bool PIPE, int BPC>
+template <int KS, int WCO, int WPX, int ACO, int APX, int CK, bool PIPE, int BPC, int ABL = 0>
 __global__ void __launch_bounds__(64 * WCO * WPX, (BPC * 64 * WCO * WPX) / 256)
 conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
                      float *__restrict__ y, int Cin, int Cout, int H, int W, int relu, int xtiles, int ytiles, int nchunks,
@@ -78,6 +79,11 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
 
     float4 wreg[WIT];
     float hreg[HIT];
+    // Global reads go through buffer descriptors: rows past K, channels past Cin, the zero padding around the image
+    // and lanes without an element all resolve to out-of-range offsets, which load 0 -- no branches in the loop.
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)Cin * HW * sizeof(float)));
+    const frcnn_buf_t wbuf = frcnn_make_buf(wp, (uint32_t)((size_t)K * Cout * sizeof(float)));
+    const uint32_t w_chunk_bytes = (uint32_t)(KR * Cout) * 4u, x_chunk_bytes = (uint32_t)(CK * HW) * 4u;
 
     for (long long it = it_begin; it < it_end;) {
         const int tile = (int)(it / nchunks);
@@ -86,30 +92,29 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
         const int tx = tile % xtiles, ty = (tile / xtiles) % ytiles, cot = tile / (xtiles * ytiles);
         const int x0 = tx * 32, y0 = ty * BROWS, co0 = cot * BCO;
 
+        // byte offsets of this thread's staging elements within chunk 0 of the tile (chunk c adds c * chunk_bytes)
+        uint32_t woff[WIT], hoff[HIT];
+#pragma unroll
+        for (int q = 0; q < WIT; ++q) {
+            const int v = tid + q * NT;
+            const int row = v / (BCO / 4), c4 = v % (BCO / 4);
+            woff[q] = (v < WV) ? (uint32_t)(row * Cout + co0 + c4 * 4) * 4u : kBufOob;
+        }
+#pragma unroll
+        for (int q = 0; q < HIT; ++q) {
+            const int e = tid + q * NT;
+            const int c = e / (HR * kHaloPitch), rem = e % (HR * kHaloPitch);
+            const int hr = rem / kHaloPitch, hx = rem % kHaloPitch;
+            const int gy = y0 - PAD + hr, gx = x0 - PAD + hx;
+            const bool inside = e < HV && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            hoff[q] = inside ? (uint32_t)(c * HW + gy * W + gx) * 4u : kBufOob;
+        }
         auto fetch = [&](int chunk) {
+            const uint32_t wb = (uint32_t)chunk * w_chunk_bytes, xb = (uint32_t)chunk * x_chunk_bytes;
 #pragma unroll
-            for (int q = 0; q < WIT; ++q) {
-                const int v = tid + q * NT;
-                float4 f = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (v < WV) {
-                    const int row = v / (BCO / 4), c4 = v % (BCO / 4);
-                    const int grow = chunk * KR + row;
-                    if (grow < K) f = *reinterpret_cast<const float4 *>(wp + (size_t)grow * Cout + co0 + c4 * 4);
-                }
-                wreg[q] = f;
-            }
+            for (int q = 0; q < WIT; ++q) wreg[q] = frcnn_buf_load_f32x4(wbuf, woff[q] + wb);
 #pragma unroll
-            for (int q = 0; q < HIT; ++q) {
-                const int e = tid + q * NT;
-                float val = 0.0f;
-                if (e < HV) {
-                    const int c = e / (HR * kHaloPitch), rem = e % (HR * kHaloPitch);
-                    const int hr = rem / kHaloPitch, hx = rem % kHaloPitch;
-                    const int gc = chunk * CK + c, gy = y0 - PAD + hr, gx = x0 - PAD + hx;
-                    if (gc < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) val = x[(size_t)gc * HW + gy * W + gx];
-                }
-                hreg[q] = val;
-            }
+            for (int q = 0; q < HIT; ++q) hreg[q] = frcnn_buf_load_f32(xbuf, hoff[q] + xb);
         };
         auto stage = [&](int buf) {
 #pragma unroll
@@ -138,12 +143,19 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
         int cur = 0;
         for (int chunk = c_begin; chunk < c_end; ++chunk) {
             const bool more = chunk + 1 < c_end;
-            if (more) fetch(chunk + 1);
+            if (more && ABL == 0) fetch(chunk + 1);
             constexpr int NSTEP = TAPS * (CK / 2);       // k-steps per chunk: step s = (tap, channel pair)
             auto frag = [&](int s, float *a, float *b) {
                 const int tap = s / (CK / 2), cp = s % (CK / 2);
                 const int ky = tap / KS, kx = tap % KS;
                 const int c = 2 * cp + khalf;
+                if constexpr (ABL == 3) {       // timing ablation only: operands from registers
+#pragma unroll
+                    for (int i = 0; i < ACO; ++i) a[i] = (float)(lane + s + i);
+#pragma unroll
+                    for (int j = 0; j < APX; ++j) b[j] = (float)(lane - s - j);
+                    return;
+                }
 #pragma unroll
                 for (int i = 0; i < ACO; ++i) a[i] = w_lds[cur][c * TAPS + tap][a_col + 32 * i];
 #pragma unroll
@@ -176,8 +188,8 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
                 }
             }
-            if (more) stage(cur ^ 1);
-            __syncthreads();
+            if (more && ABL == 0) stage(cur ^ 1);
+            if (ABL < 2) __syncthreads();
             cur ^= 1;
         }
 
@@ -352,7 +364,7 @@ static ConvPlan plan_conv(int Cin, int Cout, int H, int W, int blocks_per_cu, in
     return p;
 }
 
-template <int KS, int WCO, int WPX, int ACO, int APX, int CK, bool PIPE, int BPC>
+template <int KS, int WCO, int WPX, int ACO, int APX, int CK, bool PIPE, int BPC, int ABL = 0>
 static int launch_conv(const float *x, const float *wp, const float *bias, float *y, int Cin, int Cout, int H, int W, int relu,
                        int streamk, void *workspace, size_t workspace_bytes, hipStream_t stream) {
     constexpr int blocks_per_cu = BPC;
@@ -369,17 +381,24 @@ static int launch_conv(const float *x, const float *wp, const float *bias, float
         partials = (float *)((char *)workspace + p.counters_bytes);
         FRCNN_HIP_TRY(hipMemsetAsync(counters, 0, p.counters_bytes, stream));
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_f32_kernel<KS, WCO, WPX, ACO, APX, CK, PIPE, BPC>), dim3(p.G), dim3(64 * WCO * WPX), 0,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_f32_kernel<KS, WCO, WPX, ACO, APX, CK, PIPE, BPC, ABL>), dim3(p.G), dim3(64 * WCO * WPX), 0,
                        stream, x, wp, bias, y, Cin, Cout, H, W, relu, p.xtiles, p.ytiles, p.nchunks, p.total, partials, counters);
     return frcnn_launch_status();
 }
 
-// Chosen from scripts/conv_sweep.py on MI355X (profiles/r01_conv_sweep.json).
+// Chosen from scripts/conv_sweep.py on MI355X (profiles/r01_conv_sweep*.json).  Returns decomposition id + 100 * mode.
+//   conv1_1 (Cin = 3): 4-channel chunks (K = 27 padded to 36, not 72), four workgroups per CU -- output-write bound.
+//   Everything else 64 couts x 32 px wide: 4 rows per workgroup (wave = 32co x 2 rows) as whole tiles while the
+//   layer has at least one full round of them; stream-K once the tile count drops below the number of
+//   workgroup slots (75x125 maps), and stream-K over 2-row tiles for the 38x63 maps, where whole tiles would
+//   leave 20-80 % of the SIMDs idle.
 static int pick_conv_config(int Cin, int Cout, int H, int W) {
-    if (Cin < 8) return 8;                                     // conv1_1: K = 27, output-write bound
-    const long px_tiles = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4);
-    if (px_tiles * (Cout / 64) >= 1536) return 10;             // 64co x 4 rows, wave 32co x 2 rows
-    return 5;                                                  // 64co x 2 rows, wave 32co x 1 row
+    if (Cin < 8) return 14;
+    const long ntiles = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4) * (Cout / 64);
+    const long slots = (long)frcnn_cu_count() * 3;
+    if (ntiles >= slots) return 10;
+    if (2 * ntiles >= slots) return 210;
+    return 205;
 }
 
 }  // namespace
@@ -405,7 +424,11 @@ int frcnn_pack_conv3x3_w(const float *w, int Cout, int Cin, float *w_packed, voi
     X(5, 2, 2, 1, 1, 8, true, 3)                              \
     X(8, 1, 4, 2, 2, 4, true, 2)                              \
     X(10, 2, 2, 1, 2, 8, true, 3)                             \
-    X(11, 1, 4, 2, 1, 8, true, 3)
+    X(11, 1, 4, 2, 1, 8, true, 3)                             \
+    X(12, 2, 2, 1, 4, 8, true, 2)                             \
+    X(14, 2, 2, 1, 2, 4, true, 4)                             \
+    X(15, 2, 4, 1, 2, 8, true, 2)                             \
+    X(16, 4, 2, 1, 2, 8, true, 1)
 
 size_t frcnn_conv3x3_workspace_bytes(int Cin, int Cout, int H, int W) {
     if (Cin < 1 || Cout < 1 || H < 1 || W < 1) return 0;
@@ -424,15 +447,20 @@ int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bi
                           int relu, int cfg, void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (Cout % 4) != 0) return FRCNN_ERR_INVALID;
-    int streamk = 1;
-    if (cfg >= 0) { streamk = cfg / 100; cfg %= 100; }
-    else cfg = pick_conv_config(Cin, Cout, H, W);
+    if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cin * 9 * Cout * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;   // 32-bit buffer offsets
+    if (cfg < 0) cfg = pick_conv_config(Cin, Cout, H, W);
+    const int streamk = cfg / 100;
+    cfg %= 100;
     switch (cfg) {
 #define X(id, wco, wpx, aco, apx, ck, pipe, bpc)                                                                          \
     case id: return launch_conv<3, wco, wpx, aco, apx, ck, pipe, bpc>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, \
                                                                       workspace, workspace_bytes, stream);
         FRCNN_CONV_CASES(X)
 #undef X
+        // timing ablations of decomposition 10 (WRONG results by construction; scripts/conv_sweep.py only)
+        case 51: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 1>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 52: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 2>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 53: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 3>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         default: return FRCNN_ERR_INVALID;
     }
 }

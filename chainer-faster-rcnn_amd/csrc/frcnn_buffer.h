@@ -1,0 +1,25 @@
+// frcnn_buffer.h -- bounds-checked global loads through a gfx950 buffer descriptor (SRD).
+// A raw buffer load whose byte offset is >= the descriptor's size returns 0 instead of faulting, so halo
+// padding, ragged channel counts and "this lane has nothing to fetch" (offset = kBufOob) need no branch and no
+// per-element predicate: the staging code of the implicit-GEMM kernels is straight-line.  The descriptor is
+// built from kernel arguments only (wave-uniform by construction -> it lives in SGPRs, no waterfall loop).
+// Offsets are 32-bit byte offsets: a tensor behind a descriptor must be smaller than 2 GiB.
+// (the test emulator shadows this header with a host version)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __amdgpu_buffer_rsrc_t frcnn_buf_t;
+typedef unsigned frcnn_u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kBufOob = 0x80000000u;      // any offset with this bit set is out of range
+
+__device__ __forceinline__ frcnn_buf_t frcnn_make_buf(const void *base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float frcnn_buf_load_f32(frcnn_buf_t b, uint32_t byte_off) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b, (int)byte_off, 0, 0));
+}
+__device__ __forceinline__ float4 frcnn_buf_load_f32x4(frcnn_buf_t b, uint32_t byte_off) {
+    const frcnn_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--cfgs", type=int, nargs="*", default=[0, 1, 2, 3, 4, 5, 8, 10, 11, 104, 105, 108, 110, 111, 205, 210, -1])
     ap.add_argument("--layers", nargs="*", default=None)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     rt = pkg.runtime.default_runtime()
@@ -36,21 +37,27 @@ def main():
         wp = rt.pack_conv3x3_w(wt)
         y = rt.mem.empty((1, co, h, w), "f32")
         flops = 2.0 * h * w * co * ci * 9
-        row = {}
+        cfgs = []
         for cfg in a.cfgs:
             try:
                 rt.conv3x3(x, wp, b, relu=True, out=y, cfg=cfg)
+                cfgs.append(cfg)
             except ValueError:
                 continue
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(a.iters):
-                rt.conv3x3(x, wp, b, relu=True, out=y, cfg=cfg)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / a.iters
-            row[cfg] = round(flops / (ms * 1e-3) / 1e12, 1)
+        for _ in range(30):                                   # clocks and caches warm before anything is timed
+            rt.conv3x3(x, wp, b, relu=True, out=y, cfg=cfgs[0])
+        samples = {c: [] for c in cfgs}
+        for _ in range(a.rounds):                             # interleaved rounds: variants see the same chip state
+            for cfg in cfgs:
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    rt.conv3x3(x, wp, b, relu=True, out=y, cfg=cfg)
+                e1.record()
+                torch.cuda.synchronize()
+                samples[cfg].append(e0.elapsed_time(e1) / a.iters)
+        row = {c: round(flops / (float(np.median(v)) * 1e-3) / 1e12, 1) for c, v in samples.items()}
         res[name] = row
         print(name, " ".join("%d:%.1f" % (k, v) for k, v in row.items()), flush=True)
     if a.out:

@@ -1,0 +1,16 @@
+// Emulator stand-in for csrc/frcnn_buffer.h: a descriptor is (base, size); out-of-range loads return 0,
+// per dword, as the hardware's raw-buffer range check does.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+struct frcnn_buf_t { const char *base; uint32_t bytes; };
+constexpr uint32_t kBufOob = 0x80000000u;
+static inline frcnn_buf_t frcnn_make_buf(const void *base, uint32_t bytes) { return frcnn_buf_t{(const char *)base, bytes}; }
+static inline float frcnn_buf_load_f32(frcnn_buf_t b, uint32_t off) {
+    float v = 0.0f;
+    if ((uint64_t)off + 4 <= b.bytes) memcpy(&v, b.base + off, 4);
+    return v;
+}
+static inline float4 frcnn_buf_load_f32x4(frcnn_buf_t b, uint32_t off) {
+    return make_float4(frcnn_buf_load_f32(b, off), frcnn_buf_load_f32(b, off + 4), frcnn_buf_load_f32(b, off + 8), frcnn_buf_load_f32(b, off + 12));
+}
