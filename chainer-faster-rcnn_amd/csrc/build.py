@@ -29,7 +29,12 @@ def build(force=False, verbose=False):
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd)))
     for s, p in procs:
-        if p.wait() != 0:
+        try:
+            rc = p.wait(timeout=900)          # a pathological unroll must fail loudly, not hang the build
+        except subprocess.TimeoutExpired:
+            p.kill()
+            raise RuntimeError("hipcc timed out on %s" % s)
+        if rc != 0:
             raise RuntimeError("hipcc failed on %s" % s)
     if procs or not os.path.exists(OUT_SO):
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT_SO] + objs)

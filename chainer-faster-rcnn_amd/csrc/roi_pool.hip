@@ -18,6 +18,7 @@
 // double -- NOT integer division (7*(29/7.) = 29.000000000000004 -> ceil 30; see
 // tests/test_oracle_pinned.py::test_roi_bin_edges_need_double_arithmetic).  Empty bins give 0 / argmax -1.
 #include "frcnn_common.h"
+#include <frcnn_intrin.h>   // angle brackets: shadowed by the test emulator
 
 namespace {
 
@@ -134,6 +135,223 @@ roi_pool_hwc_kernel(const float *__restrict__ xt, int C, int H, int W, const flo
         for (int i = threadIdx.x; i < total; i += blockDim.x) argmax[base + i] = s_idx[i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Plane-resident forward (the fast path; NCHW in, no transpose).  The 300 RoIs of an image overlap ~50x: summed
+// over RoIs the bins cover 56 M cells (x 4 B = 225 MB) of a 4.9 MB map, so the kernel is bound by how fast cells
+// can be re-read, not by HBM.  Each workgroup therefore copies CG whole channel planes into LDS ONCE (row pitch
+// 64, plane stride H*64+8 dwords: ~2-way bank conflicts on real RoI sets) and serves a slice of the RoIs from there:
+//   * grid = (C/CG channel groups) x (RoI groups); 1024 threads = 16 waves, one workgroup per CU;
+//   * while the plane loads are in flight every 16-lane group works out one RoI's bin edges (double arithmetic,
+//     once per RoI and workgroup); after ONE barrier the waves never synchronise again;
+//   * a wave pulls the next RoI from an LDS counter; lane = (channel, pw) walks the RoI's rows ONCE: per row the
+//     maximum over the lane's column range (clamped columns min(k, bw-1): re-reading the last column cannot
+//     displace the first maximum under strict `>`, so all lanes run the same wave-uniform loops, two rows =
+//     up to eight independent ds_read_b32 in flight), and a row that two adjacent output rows share (floor/ceil
+//     edges overlap by one) is read once and carried over;
+//   * the RoI's [CG][7][7] block is staged in the wave's own LDS slot and leaves as ONE contiguous
+//     float4-coalesced run of CG*49 floats -- HBM sees only full-line writes.
+// Exactly the oracle's scan order: first cell, then strict `>` row-major (first maximum wins; later NaNs never win).
+constexpr int kRowPitch = 64;            // LDS row pitch (dwords)
+constexpr int kPlanePad = 8;
+constexpr int kPlaneFloats = 19584;      // 8 planes of 38 x 64 + pad (+ slack for the clamped over-reads)
+constexpr int kMaxBins = 49;
+constexpr int kPlaneWaves = 16;
+constexpr int kMaxRoisPerBlock = 128;
+constexpr int kMaxBinW = 12;             // columns of one bin (<= ceil(64/outw)+1 for outw >= 6; checked on the host)
+constexpr int kMaxBinH = 8;              // rows of one bin (ceil(H/outh)+1; checked on the host)
+
+__device__ __forceinline__ void frcnn_wave_sync() { __builtin_amdgcn_wave_barrier(); }
+
+// running (max, argmax) under the oracle's rule: replace only on strictly greater
+// (inference: the index is not tracked and the update is one v_max_f32; a NaN in m is restored by the caller)
+template <bool ARGMAX>
+__device__ __forceinline__ void take_gt(float &m, int &mi, float v, int vi) {
+    if constexpr (ARGMAX) {
+        const bool gt = v > m;
+        m = gt ? v : m;
+        mi = gt ? vi : mi;
+    } else {
+        m = frcnn_max_f32(m, v);
+    }
+}
+
+// One RoI, one lane = (channel, pw): walk the RoI's map rows once and emit the outh bin maxima of this lane's column
+// range into the wave's staging slot.  NC = columns read per row (the wave's widest bin rounded up to 4; columns past
+// the lane's own width are clamped duplicates).  Every branch is wave-uniform (scalar) and the loops are real loops:
+// the kernel's code must stay far below the 64 KB instruction cache -- a fully unrolled version of this scan ran
+// 8 k cycles per RoI on instruction fetch alone.
+template <bool ARGMAX, int NC>
+__device__ __forceinline__ void roi_scan_lane(const float *pc, int ws, int bw, int W, const int *hr, int outh, int outw,
+                                              bool lane_on, float *sv_lane, int32_t *si_lane) {
+    const int bw1 = max(bw, 1);
+    int off[NC];
+    const float *col[NC];
+#pragma unroll
+    for (int k = 0; k < NC; ++k) { off[k] = min(k, bw1 - 1); col[k] = pc + off[k]; }
+    // maximum of one map row over the lane's columns, left to right; advances the row pointers
+    auto row_max = [&](const float *(&b)[NC], float &rm, int &ri, float &f) {
+        float v[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) { v[k] = *b[k]; b[k] += kRowPitch; }
+        rm = v[0];
+        ri = 0;
+        f = v[0];
+#pragma unroll
+        for (int k = 1; k < NC; ++k) take_gt<ARGMAX>(rm, ri, v[k], off[k]);
+    };
+    float carry_m = 0.0f, carry_f = 0.0f;      // last map row the previous bin read: its maximum and its first cell
+    int carry_i = -1, carry_h = -1;
+    int hr_next = hr[0];
+#pragma unroll 1
+    for (int ph = 0; ph < outh; ++ph) {
+        const int hrv = hr_next;
+        if (ph + 1 < outh) hr_next = hr[ph + 1];                            // one bin ahead: hides the LDS latency
+        const int hs = hrv & 0xffff, bh = (hrv >> 16) - hs;
+        float m = 0.0f, first = 0.0f;
+        int mi = -1;
+        if (bh > 0) {                                                       // wave-uniform
+            const float *b[NC];
+            int dh = 0;
+            if (carry_h == hs) {                                            // first row already read by the bin above
+                m = carry_m; mi = carry_i; first = carry_f; dh = 1;
+#pragma unroll
+                for (int k = 0; k < NC; ++k) b[k] = col[k] + (hs + 1) * kRowPitch;
+            } else {
+#pragma unroll
+                for (int k = 0; k < NC; ++k) b[k] = col[k] + hs * kRowPitch;
+                row_max(b, m, mi, first);
+                if (ARGMAX) mi += hs * W + ws;
+                carry_m = m; carry_i = mi; carry_f = first; carry_h = hs; dh = 1;
+            }
+#pragma unroll 1
+            for (; dh < bh; ++dh) {
+                float rm, f;
+                int ri;
+                row_max(b, rm, ri, f);
+                if (ARGMAX) ri += (hs + dh) * W + ws;
+                take_gt<ARGMAX>(m, mi, rm, ri);
+                carry_m = rm; carry_i = ri; carry_f = f; carry_h = hs + dh;
+            }
+            if (!ARGMAX && first != first) m = first;                       // a NaN first cell stays (`>` never replaces it)
+        }
+        if (bw <= 0) { m = 0.0f; mi = -1; }
+        if (lane_on) {
+            sv_lane[ph * outw] = m;
+            if (ARGMAX) si_lane[ph * outw] = mi;
+        }
+    }
+}
+
+template <bool ARGMAX>
+__global__ void __launch_bounds__(64 * kPlaneWaves)
+roi_pool_planes_kernel(const float *__restrict__ x, int C, int H, int W, const float *__restrict__ rois, int roi_cols, int R,
+                       int outh, int outw, float scale, float *__restrict__ y, int32_t *__restrict__ argmax, int CG,
+                       int rois_per_block) {
+    __shared__ __attribute__((aligned(16))) float planes[kPlaneFloats];
+    __shared__ __attribute__((aligned(16))) float stage_val[kPlaneWaves][8 * kMaxBins];
+    __shared__ __attribute__((aligned(16))) int32_t stage_idx[ARGMAX ? kPlaneWaves : 1][ARGMAX ? 8 * kMaxBins : 4];
+    __shared__ int hrange[kMaxRoisPerBlock][8], wrange[kMaxRoisPerBlock][8], wmax[kMaxRoisPerBlock];
+    __shared__ int cost[kMaxRoisPerBlock], order[kMaxRoisPerBlock];
+    __shared__ int next_roi;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = H * W, bins = outh * outw;
+    const int pstride = H * kRowPitch + kPlanePad;
+    const int c0 = blockIdx.x * CG;
+    const int cg = min(CG, C - c0);                 // channels this workgroup really has
+    // RoI group g of ng takes RoIs g, g + ng, g + 2 ng, ...: sizes are unrelated to rank, so the groups carry equal work
+    const int ng = gridDim.y, g0 = blockIdx.y;
+    const int nr = (R - g0 + ng - 1) / ng;
+    (void)rois_per_block;
+
+    // ---- channel planes -> LDS, one map row per wave and step (rows are contiguous in NCHW: coalesced); the
+    //      loads of the first kLoadRows rows are issued before the bin-edge arithmetic below and land during it
+    constexpr int kLoadRows = 20;     // 8 planes x 38 rows / 16 waves = 19 rows per wave: one batch, one round of HBM latency
+    const float *src = x + (size_t)c0 * HW;
+    const int nrows = cg * H;
+    if (tid == 0) next_roi = 0;
+    for (int row0 = wave; row0 < nrows; row0 += kPlaneWaves * kLoadRows) {
+        float v[kLoadRows];
+#pragma unroll
+        for (int q = 0; q < kLoadRows; ++q) {
+            const int row = row0 + q * kPlaneWaves;
+            v[q] = (row < nrows && lane < W) ? src[(size_t)row * W + lane] : 0.0f;
+        }
+        if (row0 == wave) {
+            // bin edges of every RoI of this workgroup: 16 lanes per RoI (k < outh: row bins, 8 <= k < 8 + outw: column bins)
+            for (int rl0 = 0; rl0 < nr; rl0 += 64) {
+                const int rl = rl0 + (tid >> 4), k = tid & 15;
+                int bw = 0;
+                if (rl < nr) {
+                    const RoiGeom g = roi_geometry(rois + (size_t)roi_cols * (g0 + rl * ng) + (roi_cols - 5), scale);
+                    int lo, hi;
+                    if (k < outh) { bin_range(k, g.rh, outh, g.ys, H, lo, hi); hrange[rl][k] = lo | (hi << 16); }
+                    else if (k >= 8 && k < 8 + outw) { bin_range(k - 8, g.rw, outw, g.xs, W, lo, hi); wrange[rl][k - 8] = lo | (hi << 16); bw = max(hi - lo, 0); }
+                    if (k == 15) cost[rl] = min(g.rh, H) * 64 + min(g.rw, W);      // rows dominate the scan time
+                }
+                for (int d = 1; d < 16; d <<= 1) bw = max(bw, __shfl_xor(bw, d, 16));
+                if (k == 0 && rl < nr) wmax[rl] = bw;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kLoadRows; ++q) {
+            const int row = row0 + q * kPlaneWaves;
+            if (row < nrows && lane < W) { const int c = row / H; planes[c * pstride + (row - c * H) * kRowPitch + lane] = v[q]; }
+        }
+    }
+    __syncthreads();
+    // longest RoIs first (rank sort): the dynamic hand-out below then ends with the cheap ones and the waves finish together
+    if (tid < nr) {
+        const int mine = cost[tid];
+        int rank = 0;
+        for (int j = 0; j < nr; ++j) { const int cj = cost[j]; rank += (cj > mine) || (cj == mine && j < tid); }
+        order[rank] = tid;
+    }
+    __syncthreads();
+
+    const int cpp = min(cg, 64 / outw);            // channels per wave pass
+    const int lc = lane / outw, pw = lane - lc * outw;
+    const int run = cg * bins;
+    float *sv = stage_val[wave];
+    int32_t *si = stage_idx[ARGMAX ? wave : 0];
+
+    for (;;) {
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&next_roi, 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (slot >= nr) break;
+        const int rl = order[slot];
+        const int bwm = wmax[rl];
+        for (int cb = 0; cb < cg; cb += cpp) {
+            const int c = cb + lc;
+            const bool lane_on = lc < cpp && c < cg;
+            int ws = 0, bw = 0;
+            if (lane_on) { const int wr = wrange[rl][pw]; ws = wr & 0xffff; bw = (wr >> 16) - ws; }
+            const float *pc = planes + (lane_on ? c : 0) * pstride + min(ws, W - 1);
+            float *svl = sv + (lane_on ? c * bins + pw : 0);
+            int32_t *sil = si + ((ARGMAX && lane_on) ? c * bins + pw : 0);
+            if (bwm <= 4) roi_scan_lane<ARGMAX, 4>(pc, ws, bw, W, hrange[rl], outh, outw, lane_on, svl, sil);
+            else if (bwm <= 8) roi_scan_lane<ARGMAX, 8>(pc, ws, bw, W, hrange[rl], outh, outw, lane_on, svl, sil);
+            else roi_scan_lane<ARGMAX, 12>(pc, ws, bw, W, hrange[rl], outh, outw, lane_on, svl, sil);
+        }
+        frcnn_wave_sync();     // the wave's own LDS writes above are read by other lanes below (DS ops of a wave are in order)
+        // ---- (r, c0 .. c0 + cg, :, :) is one contiguous run of cg*bins floats of y
+        const size_t dst = ((size_t)(g0 + rl * ng) * C + c0) * bins;
+        if ((run & 3) == 0 && (dst & 3) == 0) {
+            for (int i = lane; i < run / 4; i += 64) {
+                reinterpret_cast<float4 *>(y + dst)[i] = reinterpret_cast<const float4 *>(sv)[i];
+                if (ARGMAX) reinterpret_cast<int4 *>(argmax + dst)[i] = reinterpret_cast<const int4 *>(si)[i];
+            }
+        } else {
+            for (int i = lane; i < run; i += 64) {
+                y[dst + i] = sv[i];
+                if (ARGMAX) argmax[dst + i] = si[i];
+            }
+        }
+        frcnn_wave_sync();     // staging slot is rewritten by the next RoI only after these reads were issued
+    }
+}
+
 // dx[c, argmax] += dy for every (roi, c, bin) with argmax >= 0 (Chainer backward_cpu).  fp32 atomics:
 // the accumulation order differs from the reference's roi-major loop only in rounding.
 __global__ void __launch_bounds__(256)
@@ -146,6 +364,16 @@ roi_pool_bwd_kernel(const float *__restrict__ dy, const int32_t *__restrict__ ar
             atomicAdd(&dx[(size_t)c * HW + a], dy[i]);
         }
     }
+}
+
+static int frcnn_roi_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else cus = 256;
+    }
+    return cus;
 }
 
 }  // namespace
@@ -183,12 +411,44 @@ int frcnn_roi_pool_fwd_hwc(const float *xt, int C, int H, int W, const float *ro
     return frcnn_launch_status();
 }
 
+// Channel planes per workgroup for the plane-resident kernel, or 0 when a plane does not fit in LDS.
+static int roi_planes_per_group(int C, int H, int W, int outh, int outw) {
+    if (W > kRowPitch || frcnn_cdiv(W, outw) + 1 > kMaxBinW || frcnn_cdiv(H, outh) + 1 > kMaxBinH) return 0;
+    for (int cg = 8; cg >= 1; cg >>= 1)
+        if ((size_t)cg * (H * kRowPitch + kPlanePad) + kRowPitch <= (size_t)kPlaneFloats) return cg < C ? cg : C;
+    return 0;
+}
+
+int frcnn_roi_pool_fwd_chw(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
+                           float spatial_scale, float *y, int32_t *argmax, void *workspace, size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !rois || !y || C < 1 || H < 1 || W < 1 || R < 0) return FRCNN_ERR_INVALID;
+    if (outh < 1 || outw < 1 || outh > 7 || outw > 7 || (roi_cols != 4 && roi_cols != 5)) return FRCNN_ERR_INVALID;
+    if (R == 0) return FRCNN_OK;
+    const int cg = roi_planes_per_group(C, H, W, outh, outw);
+    if (cg == 0) {     // map too large for LDS-resident planes: channel-last gather kernel
+        if (!workspace || workspace_bytes < frcnn_roi_pool_workspace_bytes(C, H, W)) return FRCNN_ERR_INVALID;
+        const int st = frcnn_chw_to_hwc(x, C, H, W, (float *)workspace, stream);
+        if (st != FRCNN_OK) return st;
+        return frcnn_roi_pool_fwd_hwc((const float *)workspace, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, y, argmax, stream);
+    }
+    const int cgroups = frcnn_cdiv(C, cg);
+    int rgroups = frcnn_cdiv(frcnn_roi_cu_count(), cgroups);           // about one workgroup per CU
+    const int max_rgroups = frcnn_cdiv(R, kPlaneWaves);                  // at least one RoI per wave
+    if (rgroups > max_rgroups) rgroups = max_rgroups;
+    if (rgroups < frcnn_cdiv(R, kMaxRoisPerBlock)) rgroups = frcnn_cdiv(R, kMaxRoisPerBlock);
+    if (rgroups < 1) rgroups = 1;
+    if (rgroups > R) rgroups = R;
+    const int per_block = frcnn_cdiv(R, rgroups);
+    const dim3 grid(cgroups, rgroups), blk(64 * kPlaneWaves);
+    if (argmax) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_planes_kernel<true>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, spatial_scale, y, argmax, cg, per_block);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_planes_kernel<false>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, spatial_scale, y, argmax, cg, per_block);
+    return frcnn_launch_status();
+}
+
 int frcnn_roi_pool_fwd(const float *x, int C, int H, int W, const float *rois, int R, int outh, int outw, float spatial_scale,
                        float *y, int32_t *argmax, void *workspace, size_t workspace_bytes, void *stream) {
-    if (!workspace || workspace_bytes < frcnn_roi_pool_workspace_bytes(C, H, W)) return FRCNN_ERR_INVALID;
-    int st = frcnn_chw_to_hwc(x, C, H, W, (float *)workspace, stream);
-    if (st != FRCNN_OK) return st;
-    return frcnn_roi_pool_fwd_hwc((const float *)workspace, C, H, W, rois, R, 5, outh, outw, spatial_scale, y, argmax, stream);
+    return frcnn_roi_pool_fwd_chw(x, C, H, W, rois, R, 5, outh, outw, spatial_scale, y, argmax, workspace, workspace_bytes, stream);
 }
 
 int frcnn_roi_pool_bwd(const float *dy, const int32_t *argmax, int R, int C, int H, int W, int outh, int outw, float *dx,

@@ -103,8 +103,7 @@ class FasterRCNN(object):
         _, score, prob, bbox = self.RPN.heads(feat, want_score=False, timer=timer)
         rois, probs, n_out = self.RPN.proposal_layer.forward_device(prob, bbox, im_h, im_w)
         mark("proposals")
-        xt = rt.chw_to_hwc(feat)
-        pool5 = rt.roi_pool_fwd_hwc(xt, C, H, W, rois, 7, 7, self._spatial_scale)    # rois (R,4): concat folded in
+        pool5 = rt.roi_pool_fwd_chw(feat, rois, 7, 7, self._spatial_scale)    # rois (R,4): concat (:123-124) folded in
         mark("roi_pool")
         fc6 = self.fc6(pool5, relu=True)        # dropout is the identity in inference (faster_rcnn.py:127-128)
         mark("fc6")

@@ -82,8 +82,11 @@ int frcnn_proposals(const float *rpn_cls_prob, const float *rpn_bbox_pred, int A
  * Chainer v1 ROIPooling2D forward / backward).  x (C,H,W) f32 NCHW batch 1 (the batch index in rois is
  * ignored: the reference asserts batch==1); rois (R,5) f32 [batch,x1,y1,x2,y2]; y (R,C,outh,outw) f32;
  * argmax same shape int32 (flat h*W+w, -1 for an empty bin) or NULL (inference).  outh,outw <= 7.
- *   frcnn_roi_pool_fwd      = frcnn_chw_to_hwc into `workspace` + frcnn_roi_pool_fwd_hwc
- *   frcnn_roi_pool_fwd_hwc  takes the feature map channel-last, xt (H*W, C) -- the fused pipeline's path;
+ *   frcnn_roi_pool_fwd_chw  the fast path: NCHW in, channel planes resident in LDS, no transpose (falls back to
+ *                           frcnn_chw_to_hwc into `workspace` + frcnn_roi_pool_fwd_hwc when one H*W plane exceeds
+ *                           the LDS budget; workspace may be NULL otherwise)
+ *   frcnn_roi_pool_fwd      = frcnn_roi_pool_fwd_chw with roi_cols = 5 (Chainer's (R,5) rois)
+ *   frcnn_roi_pool_fwd_hwc  takes the feature map channel-last, xt (H*W, C) -- any map size;
  *                           roi_cols = 5 ([batch,x1,y1,x2,y2] rows) or 4 (ProposalLayer's bare (R,4)
  *                           output, i.e. the concat at faster_rcnn.py:123-124 folded into the read)
  */
@@ -91,6 +94,9 @@ size_t frcnn_roi_pool_workspace_bytes(int C, int H, int W);
 int frcnn_chw_to_hwc(const float *x, int C, int H, int W, float *xt, void *stream);
 int frcnn_roi_pool_fwd_hwc(const float *xt, int C, int H, int W, const float *rois, int R, int roi_cols,
                            int outh, int outw, float spatial_scale, float *y, int32_t *argmax, void *stream);
+int frcnn_roi_pool_fwd_chw(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols,
+                           int outh, int outw, float spatial_scale, float *y, int32_t *argmax, void *workspace,
+                           size_t workspace_bytes, void *stream);
 int frcnn_roi_pool_fwd(const float *x, int C, int H, int W, const float *rois, int R, int outh, int outw,
                        float spatial_scale, float *y, int32_t *argmax, void *workspace,
                        size_t workspace_bytes, void *stream);

@@ -315,6 +315,13 @@ __attribute__((noinline)) static int __builtin_amdgcn_readlane(int v, int lane) 
     return r;
 }
 
+// a wave-level rendezvous: on hardware this is only a scheduling barrier (DS operations of one wave are in order);
+// here lanes run one after the other, so cross-lane LDS traffic inside a wave needs a real meeting point
+__attribute__((noinline)) static void __builtin_amdgcn_wave_barrier() {
+    int z = 0;
+    hipemu::wave_exchange(&z, sizeof(z), HIPEMU_SITE());
+}
+
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i=l&31][k=l>>5] and B[k=l>>5][j=l&31]; register r of lane l
 // holds D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31]; a k-ordered fmaf chain (cdna_hip_programming.md section 3).
 typedef float hipemu_f32x16 __attribute__((ext_vector_type(16)));

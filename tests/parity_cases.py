@@ -134,6 +134,11 @@ def check_roi_pool(rt, R=12, C=128, H=38, W=63, seed=0):
     assert np.array_equal(host(rt, y), want_y)              # max of fp32 values: exact (tolerance 1e-3 unused)
     y2 = rt.roi_pool_fwd(dev(rt, x[0]), dev(rt, rois), 7, 7, 0.0625)          # inference path (no argmax)
     assert np.array_equal(host(rt, y2), want_y)
+    y3 = rt.roi_pool_fwd_chw(dev(rt, x[0]), dev(rt, np.ascontiguousarray(rois[:, 1:])), 7, 7, 0.0625)   # bare (R,4) rois
+    assert np.array_equal(host(rt, y3), want_y)
+    xt = rt.chw_to_hwc(dev(rt, x[0]))                                          # channel-last gather kernel (any map size)
+    y4, am4 = rt.roi_pool_fwd_hwc(xt, C, H, W, dev(rt, rois), 7, 7, 0.0625, want_argmax=True)
+    assert np.array_equal(host(rt, y4), want_y) and np.array_equal(host(rt, am4), want_am)
     dy = rs.randn(*want_y.shape).astype(np.float32)
     dx = rt.roi_pool_bwd(dev(rt, dy), am, C, H, W)
     want_dx = O.roi_pooling_2d_backward(dy, want_am, rois, x.shape)

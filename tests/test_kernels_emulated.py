@@ -47,6 +47,8 @@ def test_proposals_14x14(rt):
 def test_roi_pool(rt):
     P.check_roi_pool(rt, R=9, C=128, H=12, W=17)
     P.check_roi_pool(rt, R=5, C=64, H=38, W=63, seed=1)     # VEC=1 path (C % 128 != 0)
+    P.check_roi_pool(rt, R=40, C=8, H=12, W=17, seed=2)     # 3 RoI groups x 1 channel group, ragged last batch
+    P.check_roi_pool(rt, R=6, C=6, H=70, W=90, seed=3)      # 3 planes per group (odd sizes: scalar copies)
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 8, 10, 11])
