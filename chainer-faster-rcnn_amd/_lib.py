@@ -45,6 +45,18 @@ SIGNATURES = {
     "frcnn_bbox_transform_inv": (_I, [_P, _P, _I, _I, _P, _P]),
     "frcnn_clip_boxes": (_I, [_P, _I, _I, _I, _P]),
     "frcnn_softmax_rows": (_I, [_P, _I, _I, _P, _P]),
+    "frcnn_conv_f32_ex": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
+    "frcnn_bbox_overlaps_f64": (_I, [_P, _I, _P, _I, _P, _P]),
+    "frcnn_anchor_target_workspace_bytes": (_S, [_I, _I, _I, _I]),
+    "frcnn_anchor_target": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _S, _P]),
+    "frcnn_rpn_loss": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
+    "frcnn_maxpool2x2_bwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "frcnn_bias_grad_f32": (_I, [_P, _I, _I, _P, _P]),
+    "frcnn_pack_conv_dgrad_w": (_I, [_P, _I, _I, _I, _P, _P]),
+    "frcnn_conv_wgrad_workspace_bytes": (_S, [_I, _I, _I, _I, _I]),
+    "frcnn_conv_wgrad_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),
+    "frcnn_sgd_momentum_wd": (_I, [_P, _P, _P, _S, _F, _F, _F, _P]),
+    "frcnn_transpose_f32": (_I, [_P, _I, _I, _P, _P]),
 }
 
 

@@ -49,7 +49,8 @@ template <int KS, int WCO, int WPX, int ACO, int APX, int CK, bool PIPE, int BPC
 __global__ void __launch_bounds__(64 * WCO * WPX, (BPC * 64 * WCO * WPX) / 256)
 conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
                      float *__restrict__ y, int Cin, int Cout, int H, int W, int relu, int xtiles, int ytiles, int nchunks,
-                     long long total, float *__restrict__ partial_ws, int *__restrict__ tile_counters) {
+                     long long total, float *__restrict__ partial_ws, int *__restrict__ tile_counters,
+                     const float *__restrict__ mask) {
     constexpr int NT = 64 * WCO * WPX;
     constexpr int BCO = 32 * ACO * WCO;
     constexpr int BROWS = APX * WPX;
@@ -262,8 +263,10 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
                         for (int r = 0; r < 16; ++r) {
                             const int co = co0 + wco * (32 * ACO) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
                             float v = acc[i][j][r] + bias[co];
-                            if (relu) v = fmaxf(v, 0.0f);
-                            y[(size_t)co * HW + (size_t)py * W + px] = v;
+                            const size_t o = (size_t)co * HW + (size_t)py * W + px;
+                            if (relu == 1) v = fmaxf(v, 0.0f);
+                            else if (relu == 2) v = mask[o] > 0.0f ? v : 0.0f;      // backward through the ReLU that produced `mask`
+                            y[o] = v;
                         }
                     }
                 }
@@ -366,7 +369,7 @@ static ConvPlan plan_conv(int Cin, int Cout, int H, int W, int blocks_per_cu, in
 
 template <int KS, int WCO, int WPX, int ACO, int APX, int CK, bool PIPE, int BPC, int ABL = 0>
 static int launch_conv(const float *x, const float *wp, const float *bias, float *y, int Cin, int Cout, int H, int W, int relu,
-                       int streamk, void *workspace, size_t workspace_bytes, hipStream_t stream) {
+                       int streamk, void *workspace, size_t workspace_bytes, hipStream_t stream, const float *mask = nullptr) {
     constexpr int blocks_per_cu = BPC;
     constexpr int BCO = 32 * ACO * WCO;
     if (Cout % BCO != 0) return FRCNN_ERR_INVALID;
@@ -382,7 +385,7 @@ static int launch_conv(const float *x, const float *wp, const float *bias, float
         FRCNN_HIP_TRY(hipMemsetAsync(counters, 0, p.counters_bytes, stream));
     }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_f32_kernel<KS, WCO, WPX, ACO, APX, CK, PIPE, BPC, ABL>), dim3(p.G), dim3(64 * WCO * WPX), 0,
-                       stream, x, wp, bias, y, Cin, Cout, H, W, relu, p.xtiles, p.ytiles, p.nchunks, p.total, partials, counters);
+                       stream, x, wp, bias, y, Cin, Cout, H, W, relu, p.xtiles, p.ytiles, p.nchunks, p.total, partials, counters, mask);
     return frcnn_launch_status();
 }
 
@@ -462,6 +465,22 @@ int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bi
         case 52: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 2>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 53: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 3>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         default: return FRCNN_ERR_INVALID;
+    }
+}
+
+int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, const float *mask, float *y, int Cin, int Cout,
+                      int H, int W, int ksize, int act, void *workspace, size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (Cout % 64) != 0) return FRCNN_ERR_INVALID;
+    if (act < 0 || act > 2 || (act == 2 && !mask) || (ksize != 1 && ksize != 3)) return FRCNN_ERR_INVALID;
+    if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cin * ksize * ksize * Cout * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;
+    if (ksize == 1) return launch_conv<1, 2, 2, 1, 1, 8, true, 3>(x, w_packed, bias, y, Cin, Cout, H, W, act, 0, nullptr, 0, stream, mask);
+    const int cfg = pick_conv_config(Cin, Cout, H, W);
+    const int streamk = cfg / 100;
+    switch (cfg % 100) {
+        case 14: return launch_conv<3, 2, 2, 1, 2, 4, true, 4>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
+        case 5: return launch_conv<3, 2, 2, 1, 1, 8, true, 3>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
+        default: return launch_conv<3, 2, 2, 1, 2, 8, true, 3>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
     }
 }
 

@@ -1,0 +1,544 @@
+// train.hip -- the RPN training step's kernels for gfx950.
+//
+// Replaces, on the device:
+//   AnchorTargetLayer.__call__ / _create_bbox_labels / _calc_overlaps   /root/reference/models/anchor_target_layer.py:66-198
+//   keep_inside, bbox_transform                                         models/bbox_transform.py:18-38,112-130
+//   bbox_overlaps (float64 IoU matrix)                                  models/bbox.pyx:16-56
+//   _calc_rpn_loss_cls / _calc_rpn_loss_bbox + their gradients          models/region_proposal_network.py:160-204
+//   backward of L.Convolution2D (weight + bias gradients), F.max_pooling_2d  (Chainer v1 semantics)
+//   MomentumSGD + WeightDecay                                           train_rpn.py:165-167
+// The random fg/bg subsample of the labels (anchor_target_layer.py:147-167) stays on the host: it draws from NumPy's
+// global RNG and the draws must be reproducible seed for seed (models/anchor_target_layer.py in the host package).
+// The input gradient of a convolution is the forward MFMA kernel (conv.hip) run on re-packed weights
+// (frcnn_pack_conv3x3_dgrad_w) with the producing ReLU's mask fused into its epilogue.
+//
+// Arithmetic parity: float64 where the reference is float64 (anchors, IoU, targets), float32 where it is float32
+// (the ground-truth side of bbox_transform), no FMA contraction (built with -ffp-contract=off).
+#include "frcnn_common.h"
+#include <frcnn_buffer.h>   // angle brackets: shadowed by the test emulator
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+struct AnchorsD { double a[32][4]; };
+
+// all_bbox[i] = anchors[a] + shift(k), i = k*A + a, k = h*W + w  (proposal_layer.py:207-221, kept in float64)
+__device__ __forceinline__ void anchor_box(const AnchorsD &anc, int i, int A, int W, int stride, double &x1, double &y1, double &x2, double &y2) {
+    const int k = i / A, a = i - k * A;
+    const int h = k / W, w = k - h * W;
+    const double sx = (double)(w * stride), sy = (double)(h * stride);
+    x1 = anc.a[a][0] + sx; y1 = anc.a[a][1] + sy; x2 = anc.a[a][2] + sx; y2 = anc.a[a][3] + sy;
+}
+
+// keep_inside (bbox_transform.py:124-129): ascending indices of the anchors that lie completely inside the image.
+// One workgroup; ordered compaction = wave ballot + per-wave offsets.
+__global__ void __launch_bounds__(1024)
+atl_inside_kernel(AnchorsD anc, int A, int H, int W, int stride, int im_h, int im_w, int32_t *__restrict__ inds, int32_t *__restrict__ n_inside) {
+    __shared__ int wave_cnt[16];
+    __shared__ int base_s;
+    const int n_all = A * H * W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) base_s = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n_all; i0 += 1024) {
+        const int i = i0 + tid;
+        int in = 0;
+        if (i < n_all) {
+            double x1, y1, x2, y2;
+            anchor_box(anc, i, A, W, stride, x1, y1, x2, y2);
+            in = (x1 >= 0.0) && (y1 >= 0.0) && (x2 < (double)im_w) && (y2 < (double)im_h);
+        }
+        const unsigned long long bal = __ballot(in);
+        if (lane == 0) wave_cnt[wave] = __popcll(bal);
+        __syncthreads();
+        int off = base_s;
+        for (int w = 0; w < wave; ++w) off += wave_cnt[w];
+        if (in) inds[off + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (tid == 0) { int t = 0; for (int w = 0; w < 16; ++w) t += wave_cnt[w]; base_s += t; }
+        __syncthreads();
+    }
+    if (tid == 0) n_inside[0] = base_s;
+}
+
+// bbox.pyx:24-55 for one (box, query) pair
+__device__ __forceinline__ double iou_f64(double bx1, double by1, double bx2, double by2, double qx1, double qy1, double qx2, double qy2) {
+    const double box_area = (qx2 - qx1 + 1) * (qy2 - qy1 + 1);
+    const double iw = (bx2 < qx2 ? bx2 : qx2) - (bx1 > qx1 ? bx1 : qx1) + 1;
+    if (iw > 0) {
+        const double ih = (by2 < qy2 ? by2 : qy2) - (by1 > qy1 ? by1 : qy1) + 1;
+        if (ih > 0) {
+            const double ua = (bx2 - bx1 + 1) * (by2 - by1 + 1) + box_area - iw * ih;
+            return iw * ih / ua;
+        }
+    }
+    return 0.0;
+}
+
+__global__ void __launch_bounds__(256)
+bbox_overlaps_kernel(const double *__restrict__ boxes, int N, const double *__restrict__ query, int K, double *__restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)N * K) return;
+    const int n = (int)(t / K), k = (int)(t - (size_t)n * K);
+    out[t] = iou_f64(boxes[4 * n], boxes[4 * n + 1], boxes[4 * n + 2], boxes[4 * n + 3], query[4 * k], query[4 * k + 1], query[4 * k + 2],
+                     query[4 * k + 3]);
+}
+
+// overlaps of every inside anchor with every gt box + row max / first argmax (anchor_target_layer.py:183-193)
+__global__ void __launch_bounds__(256)
+atl_overlap_kernel(AnchorsD anc, int A, int W, int stride, const int32_t *__restrict__ inds, const int32_t *__restrict__ n_inside,
+                   const float *__restrict__ gt, int G, double *__restrict__ overlaps, double *__restrict__ max_ov, int32_t *__restrict__ argmax) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_inside[0]) return;
+    double x1, y1, x2, y2;
+    anchor_box(anc, inds[j], A, W, stride, x1, y1, x2, y2);
+    double best = 0.0;
+    int bi = 0;
+    for (int g = 0; g < G; ++g) {
+        const double o = iou_f64(x1, y1, x2, y2, (double)gt[5 * g], (double)gt[5 * g + 1], (double)gt[5 * g + 2], (double)gt[5 * g + 3]);
+        overlaps[(size_t)j * G + g] = o;
+        if (g == 0 || o > best) { best = o; bi = g; }      // numpy argmax: first maximum
+    }
+    max_ov[j] = best;
+    argmax[j] = bi;
+}
+
+// column maxima: gt_max_overlaps (anchor_target_layer.py:190-195); one workgroup per gt box
+__global__ void __launch_bounds__(256)
+atl_gtmax_kernel(const double *__restrict__ overlaps, const int32_t *__restrict__ n_inside, int G, double *__restrict__ gt_max) {
+    __shared__ double red[256];
+    const int g = blockIdx.x, n = n_inside[0];
+    double m = -1.0;
+    for (int j = threadIdx.x; j < n; j += 256) { const double o = overlaps[(size_t)j * G + g]; m = o > m ? o : m; }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x + s] > red[threadIdx.x] ? red[threadIdx.x + s] : red[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) gt_max[g] = red[0];
+}
+
+// labels before the random subsample (anchor_target_layer.py:129-145) and regression targets (:113-118)
+__global__ void __launch_bounds__(256)
+atl_label_kernel(AnchorsD anc, int A, int W, int stride, const int32_t *__restrict__ inds, const int32_t *__restrict__ n_inside,
+                 const float *__restrict__ gt, int G, const double *__restrict__ overlaps, const double *__restrict__ max_ov,
+                 const int32_t *__restrict__ argmax, const double *__restrict__ gt_max, double neg_thr, double pos_thr,
+                 int32_t *__restrict__ labels, float *__restrict__ targets) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_inside[0]) return;
+    bool is_gt_argmax = false;                                    // xp.where(overlaps == gt_max_overlaps)[0]: ties included
+    for (int g = 0; g < G; ++g) is_gt_argmax |= overlaps[(size_t)j * G + g] == gt_max[g];
+    const double mo = max_ov[j];
+    int lab = -1;
+    if (mo < neg_thr) lab = 0;
+    if (is_gt_argmax) lab = 1;
+    if (mo >= pos_thr) lab = 1;
+    if (mo < neg_thr) lab = 0;                                    // negatives clobber positives (:144-145)
+    labels[j] = lab;
+    // bbox_transform(ex = float64 anchors, gt = float32 rows): the gt side is float32 arithmetic, then promoted
+    double x1, y1, x2, y2;
+    anchor_box(anc, inds[j], A, W, stride, x1, y1, x2, y2);
+    const float *q = gt + 5 * argmax[j];
+    const double ew = x2 - x1 + 1.0, eh = y2 - y1 + 1.0;
+    const double ecx = x1 + 0.5 * ew, ecy = y1 + 0.5 * eh;
+    const float gw = q[2] - q[0] + 1.0f, gh = q[3] - q[1] + 1.0f;
+    const float gcx = q[0] + 0.5f * gw, gcy = q[1] + 0.5f * gh;
+    float4 t;
+    t.x = (float)(((double)gcx - ecx) / ew);
+    t.y = (float)(((double)gcy - ecy) / eh);
+    t.z = (float)log((double)gw / ew);
+    t.w = (float)log((double)gh / eh);
+    reinterpret_cast<float4 *>(targets)[j] = t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// RPN losses and their gradients, one workgroup (the sums are over <= A*H*W anchors; a fixed reduction tree
+// keeps the result bit-reproducible).  out[0] = rpn_loss_cls, out[1] = rpn_loss_bbox, out[2] = rpn_cls_accuracy.
+__global__ void __launch_bounds__(1024)
+rpn_loss_kernel(const float *__restrict__ score, const float *__restrict__ bbox_pred, const int32_t *__restrict__ labels,
+                const float *__restrict__ targets, const int32_t *__restrict__ inds, int n_in, int A, int HW, float delta, float lambda,
+                float *__restrict__ out, float *__restrict__ dscore, float *__restrict__ dbbox) {
+    __shared__ double red[4][1024];
+    const int tid = threadIdx.x;
+    const int n_all = A * HW;
+    double s_cls = 0.0, s_box = 0.0, s_acc = 0.0, s_cnt = 0.0;
+    for (int j = tid; j < n_in; j += 1024) {
+        const int idx = inds[j], lab = labels[j];
+        const int k = idx / A, a = idx - k * A;
+        // F.softmax_cross_entropy on score.reshape(1,2,A,H,W): classes = channels a (bg) and A+a (fg) (:175-178)
+        const float s0 = score[(size_t)a * HW + k], s1 = score[(size_t)(A + a) * HW + k];
+        if (lab != -1) {
+            const float m = fmaxf(s0, s1);
+            const float logz = m + logf(expf(s0 - m) + expf(s1 - m));
+            s_cls += (double)(logz - (lab == 1 ? s1 : s0));
+            s_cnt += 1.0;
+            s_acc += ((s1 > s0 ? 1 : 0) == lab) ? 1.0 : 0.0;
+        }
+        // Huber over ALL inside anchors; channel = coord*A + a (:187-201 -- the reference's own re-interpretation)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float d = bbox_pred[(size_t)(c * A + a) * HW + k] - targets[4 * j + c];
+            const float ad = fabsf(d);
+            s_box += (double)(ad < delta ? 0.5f * d * d : delta * (ad - 0.5f * delta));
+        }
+    }
+    red[0][tid] = s_cls; red[1][tid] = s_box; red[2][tid] = s_acc; red[3][tid] = s_cnt;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[q][tid] += red[q][tid + s];
+        }
+        __syncthreads();
+    }
+    const double cnt = red[3][0] > 1.0 ? red[3][0] : 1.0;
+    if (tid == 0) {
+        out[0] = (float)(red[0][0] / cnt);
+        out[1] = (float)(red[1][0] / (double)n_all);
+        out[2] = (float)(red[2][0] / cnt);
+    }
+    if (!dscore || !dbbox) return;
+    const float inv_cnt = (float)(1.0 / cnt), inv_all = lambda / (float)n_all;
+    for (int j = tid; j < n_in; j += 1024) {
+        const int idx = inds[j], lab = labels[j];
+        const int k = idx / A, a = idx - k * A;
+        if (lab != -1) {
+            const float s0 = score[(size_t)a * HW + k], s1 = score[(size_t)(A + a) * HW + k];
+            const float m = fmaxf(s0, s1);
+            const float e0 = expf(s0 - m), e1 = expf(s1 - m);
+            const float z = e0 + e1;
+            dscore[(size_t)a * HW + k] = (e0 / z - (lab == 0 ? 1.0f : 0.0f)) * inv_cnt;
+            dscore[(size_t)(A + a) * HW + k] = (e1 / z - (lab == 1 ? 1.0f : 0.0f)) * inv_cnt;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float d = bbox_pred[(size_t)(c * A + a) * HW + k] - targets[4 * j + c];
+            const float g = fabsf(d) < delta ? d : (d > 0.0f ? delta : -delta);
+            dbbox[(size_t)(c * A + a) * HW + k] = g * inv_all;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// F.max_pooling_2d(2, 2) backward, gather form: an input cell receives the window's gradient iff it is the FIRST
+// maximum of its window in (ky, kx) scan order (Chainer's im2col argmax); windows do not overlap, so no atomics.
+__global__ void __launch_bounds__(256)
+maxpool2x2_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx, int C, int H, int W, int OH, int OW) {
+    const size_t total = (size_t)C * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int w = (int)(i % W), h = (int)((i / W) % H), c = (int)(i / ((size_t)W * H));
+        const int oh = h >> 1, ow = w >> 1;
+        const float *p = x + ((size_t)c * H + 2 * oh) * W + 2 * ow;
+        const bool hasx = 2 * ow + 1 < W, hasy = 2 * oh + 1 < H;
+        float m = p[0];
+        int arg = 0;
+        if (hasx && p[1] > m) { m = p[1]; arg = 1; }
+        if (hasy && p[W] > m) { m = p[W]; arg = 2; }
+        if (hasx && hasy && p[W + 1] > m) { m = p[W + 1]; arg = 3; }
+        const int me = (h & 1) * 2 + (w & 1);
+        dx[i] = (me == arg) ? dy[((size_t)c * OH + oh) * OW + ow] : 0.0f;
+    }
+}
+
+// db[c] = sum over pixels of dy[c][:]; one workgroup per channel, fixed reduction tree
+__global__ void __launch_bounds__(256)
+bias_grad_kernel(const float *__restrict__ dy, int HW, float *__restrict__ db) {
+    __shared__ float red[256];
+    const float *p = dy + (size_t)blockIdx.x * HW;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int q = 128; q > 0; q >>= 1) {
+        if (threadIdx.x < q) red[threadIdx.x] += red[threadIdx.x + q];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[blockIdx.x] = red[0];
+}
+
+// forward-packed (Cin*9, Cout) -> the packed weights of the input-gradient convolution: (Cout*9, Cin) with the taps
+// rotated by 180 degrees: wd[(co*9 + t)][ci] = wp[(ci*9 + 8 - t)][co]
+__global__ void __launch_bounds__(256)
+pack_dgrad_w_kernel(const float *__restrict__ wp, int Cin, int Cout, int taps, float *__restrict__ wd) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)Cin * Cout * taps;
+    if (i >= total) return;
+    const int ci = (int)(i % Cin);
+    const int t = (int)((i / Cin) % taps), co = (int)(i / ((size_t)Cin * taps));
+    wd[i] = wp[((size_t)ci * taps + (taps - 1 - t)) * Cout + co];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of a KS x KS / stride 1 / pad KS/2 convolution on v_mfma_f32_32x32x2_f32:
+//   dWp[(ci*T + tap)][co] = sum over pixels p of x[ci][p + offset(tap)] * dy[co][p]         (T = KS*KS)
+// GEMM with the PIXELS as the reduction axis.  MFMA A = activations: lane l supplies x[ci0 + (l&31)][pixel (l>>5)]
+// for one tap; B = output gradients: lane l supplies dy[co0 + (l&31)][pixel (l>>5)]; D[ci][co] per tap, so a wave
+// holds T accumulators for a 32 ci x 32 co block and every LDS fragment read has the 32 lanes on 32 different
+// channels at one pixel -- conflict-free because the per-channel pitches are odd.  A workgroup (4 waves = 2 ci x 2 co
+// blocks) walks its share of the image in tiles of WG_ROWS rows x 32 px, staging the tile's halo of 64 input channels
+// and 64 output-gradient channels in LDS (global reads through buffer descriptors: zero padding for free).
+// The pixel range of the image is split over `splits` workgroups per (ci, co) tile; every split writes its partial
+// dWp tile to its own slab and wgrad_reduce_kernel adds the slabs in a fixed order (deterministic).
+constexpr int WG_ROWS = 2;
+
+template <int KS>
+__global__ void __launch_bounds__(256)
+conv_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slabs, int Cin, int Cout, int H, int W,
+                       int xtiles, int nblocks, int splits) {
+    constexpr int T = KS * KS, PAD = KS / 2;
+    constexpr int HP = 32 + KS - 1;                        // halo row pitch
+    constexpr int HR = WG_ROWS + KS - 1;
+    constexpr int CHP = HR * HP + ((HR * HP) % 2 == 0 ? 1 : 0);     // per-channel pitch, odd
+    constexpr int DP = WG_ROWS * 32 + 1;                   // dy per-channel pitch, odd
+    __shared__ float x_lds[64 * CHP];
+    __shared__ float dy_lds[64 * DP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wci = wave & 1, wco = wave >> 1;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int HWs = H * W;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
+    const int b_begin = (int)((long long)split * nblocks / splits), b_end = (int)((long long)(split + 1) * nblocks / splits);
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)Cin * HWs * sizeof(float)));
+    const frcnn_buf_t dbuf = frcnn_make_buf(dy, (uint32_t)((size_t)Cout * HWs * sizeof(float)));
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    for (int b = b_begin; b < b_end; ++b) {
+        const int tx = b % xtiles, ty = b / xtiles;
+        const int x0 = tx * 32, y0 = ty * WG_ROWS;
+        // ---- stage: 64 input channels' halo and 64 output-gradient channels' tile
+        for (int e = tid; e < 64 * HR * HP; e += 256) {
+            const int c = e / (HR * HP), rem = e - c * (HR * HP);
+            const int hr = rem / HP, hx = rem - hr * HP;
+            const int gy = y0 - PAD + hr, gx = x0 - PAD + hx, gc = ci0 + c;
+            const bool inside = gc < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            x_lds[c * CHP + hr * HP + hx] = frcnn_buf_load_f32(xbuf, inside ? (uint32_t)(gc * HWs + gy * W + gx) * 4u : kBufOob);
+        }
+        for (int e = tid; e < 64 * WG_ROWS * 32; e += 256) {
+            const int c = e / (WG_ROWS * 32), rem = e - c * (WG_ROWS * 32);
+            const int r = rem >> 5, px = rem & 31;
+            const int gy = y0 + r, gx = x0 + px, gc = co0 + c;
+            const bool inside = gc < Cout && gy < H && gx < W;
+            dy_lds[c * DP + rem] = frcnn_buf_load_f32(dbuf, inside ? (uint32_t)(gc * HWs + gy * W + gx) * 4u : kBufOob);
+        }
+        __syncthreads();
+        const float *xa = x_lds + (wci * 32 + l31) * CHP + khalf;
+        const float *db = dy_lds + (wco * 32 + l31) * DP + khalf;
+#pragma unroll 1
+        for (int r = 0; r < WG_ROWS; ++r) {
+#pragma unroll 4
+            for (int pp = 0; pp < 16; ++pp) {
+                const float bv = db[r * 32 + 2 * pp];
+#pragma unroll
+                for (int t = 0; t < T; ++t) {
+                    const int ky = t / KS, kx = t % KS;
+                    const float av = xa[(r + ky) * HP + 2 * pp + kx];
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- partial tile -> slab `split`, in dWp's own layout: row (ci*T + tap), column co
+    float *slab = slabs + (size_t)split * ((size_t)Cin * T * Cout);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            const int co = co0 + wco * 32 + l31;
+            if (ci < Cin && co < Cout) slab[((size_t)ci * T + t) * Cout + co] = acc[t][r];
+        }
+}
+
+__global__ void __launch_bounds__(256)
+wgrad_reduce_kernel(const float *__restrict__ slabs, size_t n, int splits, float *__restrict__ dwp) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int q = 0; q < splits; ++q) s += slabs[(size_t)q * n + i];
+        dwp[i] = s;
+    }
+}
+
+// WeightDecay hook, then MomentumSGD (Chainer v1): g += wd*W; v = momentum*v - lr*g; W += v
+__global__ void __launch_bounds__(256)
+sgd_momentum_wd_kernel(float *__restrict__ w, const float *__restrict__ g, float *__restrict__ v, size_t n, float lr, float momentum, float wd) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float wi = w[i];
+        const float gi = g[i] + wd * wi;
+        const float vi = momentum * v[i] - lr * gi;
+        v[i] = vi;
+        w[i] = wi + vi;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+transpose_kernel(const float *__restrict__ src, int R, int Cc, float *__restrict__ dst) {
+    __shared__ float tile[64][65];
+    const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) tile[i][tx] = (r0 + i < R && c0 + tx < Cc) ? src[(size_t)(r0 + i) * Cc + c0 + tx] : 0.0f;
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4)
+        if (c0 + i < Cc && r0 + tx < R) dst[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
+struct WgradPlan { int xtiles, nblocks, splits, ci_tiles, co_tiles; size_t slab_floats; };
+
+static WgradPlan plan_wgrad(int Cin, int Cout, int H, int W, int ks) {
+    WgradPlan p;
+    p.xtiles = frcnn_cdiv(W, 32);
+    p.nblocks = p.xtiles * frcnn_cdiv(H, WG_ROWS);
+    p.ci_tiles = frcnn_cdiv(Cin, 64);
+    p.co_tiles = frcnn_cdiv(Cout, 64);
+    int s = frcnn_cdiv(512, p.ci_tiles * p.co_tiles);          // about two workgroups per CU
+    if (s > p.nblocks) s = p.nblocks;
+    if (s < 1) s = 1;
+    p.splits = s;
+    p.slab_floats = (size_t)Cin * ks * ks * Cout;
+    return p;
+}
+
+static AnchorsD load_anchors(const double *anchors_host, int A) {
+    AnchorsD anc;
+    for (int a = 0; a < 32; ++a)
+        for (int c = 0; c < 4; ++c) anc.a[a][c] = a < A ? anchors_host[a * 4 + c] : 0.0;
+    return anc;
+}
+
+struct AtlLayout { size_t overlaps, max_ov, gt_max, total; };
+static AtlLayout atl_layout(int n_all, int G) {
+    AtlLayout L;
+    size_t o = 0;
+    L.overlaps = o; o += frcnn_align256((size_t)n_all * G * sizeof(double));
+    L.max_ov = o; o += frcnn_align256((size_t)n_all * sizeof(double));
+    L.gt_max = o; o += frcnn_align256((size_t)G * sizeof(double));
+    L.total = o;
+    return L;
+}
+
+}  // namespace
+
+extern "C" {
+
+int frcnn_bbox_overlaps_f64(const double *boxes, int N, const double *query_boxes, int K, double *overlaps, void *stream) {
+    if (N < 0 || K < 0 || (N > 0 && K > 0 && (!boxes || !query_boxes || !overlaps))) return FRCNN_ERR_INVALID;
+    if (N == 0 || K == 0) return FRCNN_OK;
+    const size_t total = (size_t)N * K;
+    hipLaunchKernelGGL(bbox_overlaps_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes, N, query_boxes, K,
+                       overlaps);
+    return frcnn_launch_status();
+}
+
+size_t frcnn_anchor_target_workspace_bytes(int A, int H, int W, int G) {
+    if (A < 1 || H < 1 || W < 1 || G < 1) return 0;
+    return atl_layout(A * H * W, G).total;
+}
+
+int frcnn_anchor_target(const double *anchors_host, int A, int H, int W, int feat_stride, int im_h, int im_w, const float *gt_boxes, int G,
+                        int32_t *inds_inside, int32_t *n_inside, int32_t *labels, float *targets, int32_t *argmax_overlaps,
+                        void *workspace, size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!anchors_host || !gt_boxes || !inds_inside || !n_inside || !labels || !targets || !argmax_overlaps) return FRCNN_ERR_INVALID;
+    if (A < 1 || A > 32 || H < 1 || W < 1 || G < 1) return FRCNN_ERR_INVALID;
+    const int n_all = A * H * W;
+    const AtlLayout L = atl_layout(n_all, G);
+    if (!workspace || workspace_bytes < L.total) return FRCNN_ERR_INVALID;
+    char *ws = (char *)workspace;
+    double *overlaps = (double *)(ws + L.overlaps), *max_ov = (double *)(ws + L.max_ov), *gt_max = (double *)(ws + L.gt_max);
+    const AnchorsD anc = load_anchors(anchors_host, A);
+    hipLaunchKernelGGL(atl_inside_kernel, dim3(1), dim3(1024), 0, stream, anc, A, H, W, feat_stride, im_h, im_w, inds_inside, n_inside);
+    const dim3 grid(frcnn_cdiv(n_all, 256)), blk(256);
+    hipLaunchKernelGGL(atl_overlap_kernel, grid, blk, 0, stream, anc, A, W, feat_stride, inds_inside, n_inside, gt_boxes, G, overlaps, max_ov,
+                       argmax_overlaps);
+    hipLaunchKernelGGL(atl_gtmax_kernel, dim3(G), blk, 0, stream, overlaps, n_inside, G, gt_max);
+    hipLaunchKernelGGL(atl_label_kernel, grid, blk, 0, stream, anc, A, W, feat_stride, inds_inside, n_inside, gt_boxes, G, overlaps, max_ov,
+                       argmax_overlaps, gt_max, 0.3, 0.7, labels, targets);
+    return frcnn_launch_status();
+}
+
+int frcnn_rpn_loss(const float *rpn_cls_score, const float *rpn_bbox_pred, const int32_t *labels, const float *targets,
+                   const int32_t *inds_inside, int n_inside, int A, int H, int W, float delta, float loss_lambda, float *losses,
+                   float *d_cls_score, float *d_bbox_pred, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!rpn_cls_score || !rpn_bbox_pred || !losses || A < 1 || H < 1 || W < 1 || n_inside < 0) return FRCNN_ERR_INVALID;
+    if (n_inside > 0 && (!labels || !targets || !inds_inside)) return FRCNN_ERR_INVALID;
+    if ((d_cls_score == nullptr) != (d_bbox_pred == nullptr)) return FRCNN_ERR_INVALID;
+    const size_t HW = (size_t)H * W;
+    if (d_cls_score) {
+        FRCNN_HIP_TRY(hipMemsetAsync(d_cls_score, 0, sizeof(float) * 2 * A * HW, stream));
+        FRCNN_HIP_TRY(hipMemsetAsync(d_bbox_pred, 0, sizeof(float) * 4 * A * HW, stream));
+    }
+    hipLaunchKernelGGL(rpn_loss_kernel, dim3(1), dim3(1024), 0, stream, rpn_cls_score, rpn_bbox_pred, labels, targets, inds_inside, n_inside, A,
+                       (int)HW, delta, loss_lambda, losses, d_cls_score, d_bbox_pred);
+    return frcnn_launch_status();
+}
+
+int frcnn_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int C, int H, int W, void *stream) {
+    if (!x || !dy || !dx || C < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+    const size_t total = (size_t)C * H * W;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dy, dx, C, H, W, OH, OW);
+    return frcnn_launch_status();
+}
+
+int frcnn_bias_grad_f32(const float *dy, int C, int HW, float *db, void *stream) {
+    if (!dy || !db || C < 1 || HW < 1) return FRCNN_ERR_INVALID;
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, HW, db);
+    return frcnn_launch_status();
+}
+
+int frcnn_pack_conv_dgrad_w(const float *w_packed, int Cin, int Cout, int ksize, float *w_dgrad, void *stream) {
+    if (!w_packed || !w_dgrad || Cin < 1 || Cout < 1 || (ksize != 1 && ksize != 3)) return FRCNN_ERR_INVALID;
+    const size_t total = (size_t)Cin * Cout * ksize * ksize;
+    hipLaunchKernelGGL(pack_dgrad_w_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_packed, Cin, Cout,
+                       ksize * ksize, w_dgrad);
+    return frcnn_launch_status();
+}
+
+size_t frcnn_conv_wgrad_workspace_bytes(int Cin, int Cout, int H, int W, int ksize) {
+    if (Cin < 1 || Cout < 1 || H < 1 || W < 1 || (ksize != 1 && ksize != 3)) return 0;
+    const WgradPlan p = plan_wgrad(Cin, Cout, H, W, ksize);
+    return frcnn_align256(p.slab_floats * p.splits * sizeof(float));
+}
+
+int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int Cin, int Cout, int H, int W, int ksize, void *workspace,
+                         size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !dy || !dw_packed || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (ksize != 1 && ksize != 3)) return FRCNN_ERR_INVALID;
+    if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cout * H * W * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;
+    const WgradPlan p = plan_wgrad(Cin, Cout, H, W, ksize);
+    if (!workspace || workspace_bytes < p.slab_floats * p.splits * sizeof(float)) return FRCNN_ERR_INVALID;
+    float *slabs = (float *)workspace;
+    const dim3 grid(p.ci_tiles, p.co_tiles, p.splits);
+    if (ksize == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<3>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<1>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
+    const size_t n = p.slab_floats;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, n, p.splits, dw_packed);
+    return frcnn_launch_status();
+}
+
+int frcnn_sgd_momentum_wd(float *w, const float *grad, float *velocity, size_t n, float lr, float momentum, float weight_decay, void *stream) {
+    if (n == 0) return FRCNN_OK;
+    if (!w || !grad || !velocity) return FRCNN_ERR_INVALID;
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(sgd_momentum_wd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, grad, velocity, n, lr, momentum, weight_decay);
+    return frcnn_launch_status();
+}
+
+int frcnn_transpose_f32(const float *src, int rows, int cols, float *dst, void *stream) {
+    if (!src || !dst || rows < 1 || cols < 1) return FRCNN_ERR_INVALID;
+    hipLaunchKernelGGL(transpose_kernel, dim3(frcnn_cdiv(cols, 64), frcnn_cdiv(rows, 64)), dim3(256), 0, (hipStream_t)stream, src, rows, cols, dst);
+    return frcnn_launch_status();
+}
+
+}  // extern "C"

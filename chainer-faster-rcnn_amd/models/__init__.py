@@ -1,6 +1,8 @@
 """Host-side mirror of the reference's `models/` package: same module / class / function names
 (ProposalLayer, cpu_nms, roi_pooling_2d, VGG16Prev, RegionProposalNetwork, FasterRCNN, ...), each backed by
 the HIP kernels in libfrcnn_hip.so."""
+from .anchor_target_layer import AnchorTargetLayer  # noqa: F401
+from .bbox import bbox_overlaps  # noqa: F401
 from .bbox_transform import bbox_transform_inv, clip_boxes  # noqa: F401
 from .cpu_nms import cpu_nms, gpu_nms  # noqa: F401
 from .faster_rcnn import FasterRCNN  # noqa: F401

@@ -35,11 +35,12 @@ class Conv3x3(object):
 
 
 class VGG16Prev(object):
-    def __init__(self, train=False, runtime=None):
+    def __init__(self, train=False, runtime=None, layers=None):
         self.rt = runtime or default_runtime()
         self.train = train
+        self.layers = list(layers) if layers is not None else LAYERS     # (tests build narrow / shallow variants)
         self.links = {}
-        for l in LAYERS:
+        for l in self.layers:
             if l != "pool":
                 self.links[l[0]] = Conv3x3(self.rt, l[1], l[2])
                 setattr(self, l[0], self.links[l[0]])
@@ -58,7 +59,7 @@ class VGG16Prev(object):
         h = rt.asarray(unwrap(x), "f32")
         assert h.ndim == 4 and int(h.shape[0]) == 1, "batch size 1 (models/faster_rcnn.py:77)"
         n_pool = 0
-        for l in LAYERS:
+        for l in self.layers:
             if l == "pool":
                 h = rt.maxpool2x2(h)
                 n_pool += 1

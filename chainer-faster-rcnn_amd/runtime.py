@@ -42,6 +42,11 @@ class TorchDeviceMemory(object):
     def contiguous(self, t):
         return t if t.is_contiguous() else t.contiguous()
 
+    def view(self, flat, offset, shape):
+        """A contiguous window of a flat buffer, reshaped (shares memory)."""
+        n = int(np.prod(shape))
+        return flat[offset:offset + n].view(*shape)
+
     def ptr(self, t):
         if t is None:
             return None
@@ -274,6 +279,103 @@ class Runtime(object):
         out = m.empty((R, n), "f32")
         _lib.check(L.frcnn_softmax_rows(m.ptr(scores), R, n, m.ptr(out), m.stream()), "frcnn_softmax_rows")
         return out
+
+
+    # ------------------------------------------------------------------ training step (csrc/train.hip)
+    def conv_ex(self, x, w_packed, bias, ksize=3, act=1, mask=None, out=None):
+        """Generic conv entry: act 0 none / 1 ReLU / 2 masked by (mask > 0) (the input-gradient convolution)."""
+        m, L = self.mem, self.lib
+        ci, H, W = [int(v) for v in x.shape[-3:]]
+        co = int(w_packed.shape[1])
+        assert int(w_packed.shape[0]) == ci * ksize * ksize
+        y = out if out is not None else m.empty((1, co, H, W), "f32")
+        ws = self.workspace("conv3x3", L.frcnn_conv3x3_workspace_bytes(ci, co, H, W))
+        _lib.check(L.frcnn_conv_f32_ex(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(mask), m.ptr(y), ci, co, H, W, int(ksize),
+                                       int(act), m.ptr(ws), ws.shape[0], m.stream()), "frcnn_conv_f32_ex")
+        return y
+
+    def bbox_overlaps(self, boxes, query_boxes):
+        m, L = self.mem, self.lib
+        N, K = int(boxes.shape[0]), int(query_boxes.shape[0])
+        out = m.zeros((N, K), "f64")
+        _lib.check(L.frcnn_bbox_overlaps_f64(m.ptr(boxes) if N else None, N, m.ptr(query_boxes) if K else None, K,
+                                             m.ptr(out) if N * K else None, m.stream()), "frcnn_bbox_overlaps_f64")
+        return out
+
+    def anchor_target(self, anchors, H, W, feat_stride, im_h, im_w, gt_boxes):
+        """gt_boxes (G,5) f32 device.  -> (inds_inside, n_inside (1,), labels (pre-subsample), targets, argmax): capacity A*H*W."""
+        m, L = self.mem, self.lib
+        A, G = int(anchors.shape[0]), int(gt_boxes.shape[0])
+        n_all = A * H * W
+        inds, n_in = m.empty((n_all,), "i32"), m.empty((1,), "i32")
+        labels, targets, argmax = m.empty((n_all,), "i32"), m.empty((n_all, 4), "f32"), m.empty((n_all,), "i32")
+        ws = self.workspace("anchor_target", L.frcnn_anchor_target_workspace_bytes(A, H, W, G))
+        anc = np.ascontiguousarray(anchors, dtype=np.float64)
+        _lib.check(L.frcnn_anchor_target(anc.ctypes.data_as(ctypes.c_void_p), A, int(H), int(W), int(feat_stride), int(im_h), int(im_w),
+                                         m.ptr(gt_boxes), G, m.ptr(inds), m.ptr(n_in), m.ptr(labels), m.ptr(targets), m.ptr(argmax),
+                                         m.ptr(ws), ws.shape[0], m.stream()), "frcnn_anchor_target")
+        return inds, n_in, labels, targets, argmax
+
+    def rpn_loss(self, score, bbox_pred, labels, targets, inds, n_inside, A, H, W, delta=3.0, loss_lambda=1.0, want_grad=True,
+                 d_score=None, d_bbox=None):
+        """-> (losses (3,) device [cls, bbox, accuracy], d_score (2A,H,W), d_bbox (4A,H,W))"""
+        m, L = self.mem, self.lib
+        losses = m.empty((3,), "f32")
+        if want_grad:
+            d_score = d_score if d_score is not None else m.empty((2 * A, H, W), "f32")
+            d_bbox = d_bbox if d_bbox is not None else m.empty((4 * A, H, W), "f32")
+        _lib.check(L.frcnn_rpn_loss(m.ptr(score), m.ptr(bbox_pred), m.ptr(labels), m.ptr(targets), m.ptr(inds), int(n_inside), A, H, W,
+                                    float(delta), float(loss_lambda), m.ptr(losses), m.ptr(d_score) if want_grad else None,
+                                    m.ptr(d_bbox) if want_grad else None, m.stream()), "frcnn_rpn_loss")
+        return (losses, d_score, d_bbox) if want_grad else losses
+
+    def maxpool2x2_bwd(self, x, dy, out=None):
+        m, L = self.mem, self.lib
+        C, H, W = [int(v) for v in x.shape[-3:]]
+        dx = out if out is not None else m.empty((1, C, H, W), "f32")
+        _lib.check(L.frcnn_maxpool2x2_bwd_f32(m.ptr(x), m.ptr(dy), m.ptr(dx), C, H, W, m.stream()), "frcnn_maxpool2x2_bwd_f32")
+        return dx
+
+    def bias_grad(self, dy, out=None):
+        m, L = self.mem, self.lib
+        C = int(dy.shape[-3])
+        HW = int(dy.shape[-2]) * int(dy.shape[-1])
+        db = out if out is not None else m.empty((C,), "f32")
+        _lib.check(L.frcnn_bias_grad_f32(m.ptr(dy), C, HW, m.ptr(db), m.stream()), "frcnn_bias_grad_f32")
+        return db
+
+    def pack_conv_dgrad_w(self, w_packed, ksize=3, out=None):
+        """(Cin*k*k, Cout) forward-packed -> (Cout*k*k, Cin): weights of the input-gradient convolution."""
+        m, L = self.mem, self.lib
+        co = int(w_packed.shape[1])
+        ci = int(w_packed.shape[0]) // (ksize * ksize)
+        wd = out if out is not None else m.empty((co * ksize * ksize, ci), "f32")
+        _lib.check(L.frcnn_pack_conv_dgrad_w(m.ptr(w_packed), ci, co, int(ksize), m.ptr(wd), m.stream()), "frcnn_pack_conv_dgrad_w")
+        return wd
+
+    def conv_wgrad(self, x, dy, ksize=3, out=None):
+        """dW in the forward-packed layout (Cin*k*k, Cout)."""
+        m, L = self.mem, self.lib
+        ci, H, W = [int(v) for v in x.shape[-3:]]
+        co = int(dy.shape[-3])
+        dw = out if out is not None else m.empty((ci * ksize * ksize, co), "f32")
+        ws = self.workspace("wgrad", L.frcnn_conv_wgrad_workspace_bytes(ci, co, H, W, int(ksize)))
+        _lib.check(L.frcnn_conv_wgrad_f32(m.ptr(x), m.ptr(dy), m.ptr(dw), ci, co, H, W, int(ksize), m.ptr(ws), ws.shape[0], m.stream()),
+                   "frcnn_conv_wgrad_f32")
+        return dw
+
+    def sgd_momentum_wd(self, w, grad, velocity, lr, momentum, weight_decay):
+        m, L = self.mem, self.lib
+        n = int(np.prod(w.shape))
+        _lib.check(L.frcnn_sgd_momentum_wd(m.ptr(w), m.ptr(grad), m.ptr(velocity), n, float(lr), float(momentum), float(weight_decay),
+                                           m.stream()), "frcnn_sgd_momentum_wd")
+
+    def transpose(self, src, out=None):
+        m, L = self.mem, self.lib
+        R, C = int(src.shape[0]), int(src.shape[1])
+        dst = out if out is not None else m.empty((C, R), "f32")
+        _lib.check(L.frcnn_transpose_f32(m.ptr(src), R, C, m.ptr(dst), m.stream()), "frcnn_transpose_f32")
+        return dst
 
 
 _default = None

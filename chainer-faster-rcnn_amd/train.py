@@ -1,0 +1,187 @@
+"""The RPN training step of train_rpn.py (train_rpn.py:140-182 + chainer's StandardUpdater / ParallelUpdater and
+MomentumSGD(lr=0.001) + WeightDecay(0.0005)) as one object over the HIP kernels.
+
+    trainer = RPNTrainer(model)                       # model: models.FasterRCNN with parameters loaded
+    out = trainer.step(x, img_info, gt_boxes)         # forward, AnchorTargetLayer, losses, backward, all-reduce, update
+
+What runs where:
+  forward         trunk + rpn_conv_3x3 + heads on the MFMA conv kernel (csrc/conv.hip), activations kept in HBM
+  targets         AnchorTargetLayer (device: csrc/train.hip; host: the NumPy-RNG subsample, as in the reference)
+  losses          frcnn_rpn_loss: softmax-CE + Huber and their gradients w.r.t. the two head outputs
+  backward        per conv: weight gradient (MFMA, pixels as the reduction axis), bias gradient, input gradient = the forward
+                  kernel on 180-degree-rotated weights with the ReLU mask fused into the epilogue; max-pool: gather
+  data parallel   ONE all_reduce(SUM) of the flat fp32 gradient buffer per step (RCCL over xGMI; gloo on CPU), i.e. the
+                  gradients are summed over replicas exactly as ParallelUpdater's addgrads does, then every rank applies
+                  the identical update (replaces gather-to-main + copyparams broadcast)
+  update          one fused MomentumSGD + WeightDecay launch over the flat parameter / gradient / velocity buffers
+
+Trained parameters are the trunk and the RPN (in rpn_train mode FasterRCNN.__call__ returns before the head:
+models/faster_rcnn.py:115-116).  Convolution weights live in the kernels' packed layout (Cin*9, Cout) while training;
+`sync_params()` writes them back to Chainer's (Cout, Cin, 3, 3) arrays for snapshots.
+ProposalLayer is NOT run in the training step (the reference runs it and discards the result:
+region_proposal_network.py:123-126).
+"""
+import numpy as np
+
+from .chainer_compat import unwrap
+from .models.anchor_target_layer import AnchorTargetLayer
+
+
+class _Seg(object):
+    def __init__(self, name, shape, offset):
+        self.name, self.shape, self.offset = name, tuple(shape), offset
+        self.size = int(np.prod(shape))
+
+
+class RPNTrainer(object):
+    def __init__(self, model, lr=0.001, momentum=0.9, weight_decay=0.0005, comm=None):
+        self.model, self.rt = model, model.rt
+        self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        self.comm = comm
+        rt = self.rt
+        rpn = model.RPN
+        self.atl = AnchorTargetLayer(rpn.proposal_layer._feat_stride, runtime=rt)
+        self.atl._anchors = rpn.proposal_layer._anchors
+        self.atl._num_anchors = rpn.proposal_layer._num_anchors
+        self.layers = model.trunk.layers
+        self.convs = [(l[0], model.trunk.links[l[0]]) for l in self.layers if l != "pool"] + [("rpn_conv_3x3", rpn.rpn_conv_3x3)]
+        # ---- one flat buffer each for parameters, gradients, velocities; every segment 256-byte aligned
+        segs, off = [], 0
+        def add(name, shape):
+            nonlocal off
+            s = _Seg(name, shape, off)
+            segs.append(s)
+            off += (s.size + 63) // 64 * 64
+            return s
+        self.seg = {}
+        for name, link in self.convs:
+            self.seg[name + "/W"] = add(name + "/W", link.Wp.shape)
+            self.seg[name + "/b"] = add(name + "/b", link.b.shape)
+        wp, bp, self.A = rpn._heads_packed
+        self.seg["heads/W"] = add("heads/W", wp.shape)
+        self.seg["heads/b"] = add("heads/b", bp.shape)
+        self.n_flat = off
+        self.W = rt.mem.zeros((off,), "f32")
+        self.G = rt.mem.zeros((off,), "f32")
+        self.V = rt.mem.zeros((off,), "f32")
+        def adopt(seg, src):
+            v = rt.mem.view(self.W, seg.offset, seg.shape)
+            v[...] = src
+            return v
+        for name, link in self.convs:
+            link.Wp = adopt(self.seg[name + "/W"], link.Wp)
+            link.b = adopt(self.seg[name + "/b"], link.b)
+        rpn._heads_packed = (adopt(self.seg["heads/W"], wp), adopt(self.seg["heads/b"], bp), self.A)
+        self.grad = {k: rt.mem.view(self.G, s.offset, s.shape) for k, s in self.seg.items()}
+        # weights of the input-gradient convolutions (re-packed from the current weights every step)
+        self.wd = {name: rt.mem.empty((int(link.Wp.shape[1]) * 9, int(link.Wp.shape[0]) // 9), "f32") for name, link in self.convs[1:]}
+        self.wd_heads = rt.mem.empty((int(wp.shape[1]), int(wp.shape[0])), "f32")
+        self.zero_bias = rt.mem.zeros((512,), "f32")
+        self._draw = None
+        self.iteration = 0
+
+    # ------------------------------------------------------------------
+    def forward_backward(self, x, img_info, gt_boxes):
+        """Fills self.G with this replica's gradients; returns dict(loss, loss_cls, loss_bbox, accuracy) (device scalars)."""
+        rt, model, rpn = self.rt, self.model, self.model.RPN
+        x = rt.asarray(unwrap(x), "f32")
+        im_h, im_w = rpn.proposal_layer._img_hw(img_info)
+        # ---- forward, keeping every layer's input
+        inputs, h = [], x
+        for l in self.layers:
+            inputs.append(h)
+            h = rt.maxpool2x2(h) if l == "pool" else model.trunk.links[l[0]](h, relu=True)
+        feat = h
+        mid = rpn.rpn_conv_3x3(feat, relu=True)
+        score, _, bbox = rt.rpn_heads(mid, rpn._heads_packed)
+        A = self.A
+        H, W = int(feat.shape[2]), int(feat.shape[3])
+        NP = int(rpn._heads_packed[0].shape[1])
+        # ---- targets and losses
+        labels, targets, inds, n_in, _ = self.atl.forward_device(H, W, gt_boxes, im_h, im_w)
+        if self._draw is None or tuple(self._draw.shape) != (NP, H, W):
+            self._draw = rt.mem.zeros((NP, H, W), "f32")             # rows >= 6A (channel padding) stay zero
+        draw = self._draw
+        losses, _, _ = rt.rpn_loss(score[0], bbox[0], labels, targets, inds, n_in, A, H, W, rpn._delta, rpn._loss_lambda,
+                                   d_score=draw[:2 * A], d_bbox=draw[2 * A:6 * A])
+        # ---- backward: heads (one 1x1 convolution over the stacked cls|bbox matrix)
+        rt.conv_wgrad(mid, draw, 1, out=self.grad["heads/W"])
+        rt.bias_grad(draw, out=self.grad["heads/b"])
+        rt.pack_conv_dgrad_w(rpn._heads_packed[0], 1, out=self.wd_heads)
+        g = rt.conv_ex(draw.reshape(1, NP, H, W), self.wd_heads, self.zero_bias, 1, act=2, mask=mid)
+        # ---- rpn_conv_3x3, then the trunk in reverse
+        layer_inputs = list(zip(self.layers, inputs)) + [(("rpn_conv_3x3", 0, 0), feat)]
+        for l, xin in reversed(layer_inputs):
+            if l == "pool":
+                g = rt.maxpool2x2_bwd(xin, g)
+                continue
+            name = l[0]
+            link = dict(self.convs)[name]
+            rt.conv_wgrad(xin, g, 3, out=self.grad[name + "/W"])
+            rt.bias_grad(g, out=self.grad[name + "/b"])
+            if name != self.convs[0][0]:                                # the image needs no gradient
+                rt.pack_conv_dgrad_w(link.Wp, 3, out=self.wd[name])
+                g = rt.conv_ex(g, self.wd[name], self.zero_bias, 3, act=2, mask=xin)
+        return dict(losses=losses)
+
+    def all_reduce(self):
+        """Sum the gradient buffer over the replicas (ParallelUpdater: grads are added, not averaged)."""
+        if self.comm is not None and self.comm.world_size > 1:
+            self.comm.all_reduce_sum(self.G)
+
+    def update(self):
+        self.rt.sgd_momentum_wd(self.W, self.G, self.V, self.lr, self.momentum, self.weight_decay)
+        self.iteration += 1
+
+    def step(self, x, img_info, gt_boxes):
+        out = self.forward_backward(x, img_info, gt_boxes)
+        self.all_reduce()
+        self.update()
+        return out
+
+    def losses_host(self, out):
+        l = self.rt.mem.to_numpy(out["losses"])
+        return dict(rpn_loss_cls=float(l[0]), rpn_loss_bbox=float(l[1]), rpn_cls_accuracy=float(l[2]),
+                    rpn_loss=float(l[0] + self.model.RPN._loss_lambda * l[1]))
+
+    # ------------------------------------------------------------------
+    def sync_params(self):
+        """Packed training weights -> Chainer-layout arrays on the links (for snapshots / inference objects)."""
+        rt = self.rt
+        for name, link in self.convs:
+            co, ci = link.cout, link.cin
+            link.W = rt.transpose(link.Wp).reshape(co, ci, 3, 3)
+        wp, bp, A = self.model.RPN._heads_packed
+        wt = rt.transpose(wp)                                        # (NP, Cmid)
+        rpn = self.model.RPN
+        rpn.rpn_cls_score["W"], rpn.rpn_cls_score["b"] = wt[:2 * A], bp[:2 * A]
+        rpn.rpn_bbox_pred["W"], rpn.rpn_bbox_pred["b"] = wt[2 * A:6 * A], bp[2 * A:6 * A]
+
+    def grads_chainer_layout(self):
+        """{link path: gradient in Chainer's layout} (host arrays) -- for tests and inspection."""
+        rt, out = self.rt, {}
+        for name, link in self.convs:
+            prefix = "RPN/" if name == "rpn_conv_3x3" else "trunk/"
+            g = rt.mem.to_numpy(self.grad[name + "/W"])
+            out[prefix + name + "/W"] = np.ascontiguousarray(g.T).reshape(link.cout, link.cin, 3, 3)
+            out[prefix + name + "/b"] = rt.mem.to_numpy(self.grad[name + "/b"])
+        A = self.A
+        gw, gb = rt.mem.to_numpy(self.grad["heads/W"]).T, rt.mem.to_numpy(self.grad["heads/b"])
+        out["RPN/rpn_cls_score/W"], out["RPN/rpn_cls_score/b"] = gw[:2 * A].reshape(2 * A, -1, 1, 1), gb[:2 * A]
+        out["RPN/rpn_bbox_pred/W"], out["RPN/rpn_bbox_pred/b"] = gw[2 * A:6 * A].reshape(4 * A, -1, 1, 1), gb[2 * A:6 * A]
+        return out
+
+
+class TorchComm(object):
+    """torch.distributed as the collective layer: backend "nccl" is RCCL on ROCm (xGMI), "gloo" on CPU."""
+
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+
+    def all_reduce_sum(self, buf):
+        t = buf if isinstance(buf, self.torch.Tensor) else self.torch.from_numpy(buf)      # NumPy buffers are reduced in place
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)

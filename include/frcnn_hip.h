@@ -157,6 +157,52 @@ int frcnn_bbox_transform_inv(const float *boxes, const float *deltas, int R, int
 int frcnn_clip_boxes(float *boxes, int n_boxes, int im_h, int im_w, void *stream);
 int frcnn_softmax_rows(const float *scores, int R, int n, float *probs, void *stream);
 
+/* generic form of the convolution entry: ksize 1 or 3 (stride 1, pad ksize/2), act 0 = none, 1 = ReLU,
+ * 2 = y = (mask > 0) ? conv + bias : 0  -- the input-gradient convolution of the backward pass with the producing
+ * ReLU's mask fused in (mask has y's shape).  Cout % 64 == 0. */
+int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, const float *mask, float *y, int Cin,
+                      int Cout, int H, int W, int ksize, int act, void *workspace, size_t workspace_bytes,
+                      void *stream);
+
+/* ---- RPN training step --------------------------------------------------------
+ * frcnn_bbox_overlaps_f64: bbox_overlaps(boxes (N,4) f64, query_boxes (K,4) f64) -> (N,K) f64   (models/bbox.pyx:16-56)
+ *
+ * frcnn_anchor_target: AnchorTargetLayer.__call__ up to (not including) the random subsample
+ *   (models/anchor_target_layer.py:66-145,183-198; keep_inside bbox_transform.py:112-130; bbox_transform :18-38).
+ *   gt_boxes (G,5) f32 [x1,y1,x2,y2,cls]; out (capacity A*H*W each): inds_inside int32 ascending, n_inside (1),
+ *   labels int32 in {-1,0,1} BEFORE the fg/bg subsample (:147-167 draws from NumPy's global RNG: host side),
+ *   targets (n,4) f32, argmax_overlaps (n) int32.
+ *
+ * frcnn_rpn_loss: _calc_rpn_loss_cls + _calc_rpn_loss_bbox (models/region_proposal_network.py:160-204) and their
+ *   gradients.  labels are the SUBSAMPLED labels of the n_inside inside anchors.  losses (3) f32 =
+ *   [rpn_loss_cls, rpn_loss_bbox, rpn_cls_accuracy]; d_cls_score (2A,H,W), d_bbox_pred (4A,H,W) = gradients of
+ *   rpn_loss_cls + loss_lambda * rpn_loss_bbox (both NULL: losses only).
+ *
+ * Backward pieces: frcnn_maxpool2x2_bwd_f32 (x = the pool's input), frcnn_bias_grad_f32 (db[c] = sum_p dy[c][p]),
+ *   frcnn_pack_conv_dgrad_w (forward-packed (Cin*k*k,Cout) -> packed weights (Cout*k*k,Cin) of the input-gradient
+ *   convolution, taps rotated 180 degrees; run it through frcnn_conv_f32_ex), frcnn_conv_wgrad_f32 (weight gradient in
+ *   the forward-packed layout, MFMA, deterministic split over the pixels).
+ * frcnn_sgd_momentum_wd: WeightDecay hook + MomentumSGD (train_rpn.py:165-167): g += wd*w; v = m*v - lr*g; w += v. */
+int frcnn_bbox_overlaps_f64(const double *boxes, int N, const double *query_boxes, int K, double *overlaps,
+                            void *stream);
+size_t frcnn_anchor_target_workspace_bytes(int A, int H, int W, int G);
+int frcnn_anchor_target(const double *anchors_host, int A, int H, int W, int feat_stride, int im_h, int im_w,
+                        const float *gt_boxes, int G, int32_t *inds_inside, int32_t *n_inside, int32_t *labels,
+                        float *targets, int32_t *argmax_overlaps, void *workspace, size_t workspace_bytes,
+                        void *stream);
+int frcnn_rpn_loss(const float *rpn_cls_score, const float *rpn_bbox_pred, const int32_t *labels,
+                   const float *targets, const int32_t *inds_inside, int n_inside, int A, int H, int W, float delta,
+                   float loss_lambda, float *losses, float *d_cls_score, float *d_bbox_pred, void *stream);
+int frcnn_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int C, int H, int W, void *stream);
+int frcnn_bias_grad_f32(const float *dy, int C, int HW, float *db, void *stream);
+int frcnn_pack_conv_dgrad_w(const float *w_packed, int Cin, int Cout, int ksize, float *w_dgrad, void *stream);
+size_t frcnn_conv_wgrad_workspace_bytes(int Cin, int Cout, int H, int W, int ksize);
+int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int Cin, int Cout, int H, int W, int ksize,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int frcnn_sgd_momentum_wd(float *w, const float *grad, float *velocity, size_t n, float lr, float momentum,
+                          float weight_decay, void *stream);
+int frcnn_transpose_f32(const float *src, int rows, int cols, float *dst, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

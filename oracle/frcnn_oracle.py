@@ -500,3 +500,71 @@ def momentum_sgd_wd(W, g, v, lr=0.001, momentum=0.9, wd=0.0005):
     g = g + np.float32(wd) * W
     v = np.float32(momentum) * v - np.float32(lr) * g
     return W + v, v
+
+
+# --------------------------------------------------------------------------- backward pass (chainer-ext; torch-CPU autograd)
+def conv2d_backward(x, W, b, dy, pad):
+    """Gradients of L.Convolution2D(ksize, stride 1, pad) [chainer-ext]: (dx, dW, db) for upstream gradient dy."""
+    import torch
+    xt = _t(x).clone().requires_grad_(True)
+    Wt = _t(W).clone().requires_grad_(True)
+    bt = _t(b).clone().requires_grad_(True)
+    y = torch.nn.functional.conv2d(xt, Wt, bt, stride=1, padding=pad)
+    y.backward(_t(dy))
+    return xt.grad.numpy(), Wt.grad.numpy(), bt.grad.numpy()
+
+
+def max_pool_2x2_backward(x, dy):
+    """F.max_pooling_2d(2, 2) (cover_all) backward: the gradient goes to the first maximum of each window."""
+    import torch
+    xt = _t(x).clone().requires_grad_(True)
+    y = torch.nn.functional.max_pool2d(xt, 2, 2, ceil_mode=True)
+    y.backward(_t(dy))
+    return xt.grad.numpy()
+
+
+def _torch_rpn_losses(score, bbox_pred, labels, targets, inds_inside, n_all, feat_h, feat_w, n_anchors, delta, lam):
+    """models/region_proposal_network.py:160-204 with torch ops (so autograd yields the gradients)."""
+    import torch
+    mapped = np.ones((n_all,), dtype=np.int64) * -1
+    mapped[inds_inside] = labels
+    mapped = torch.from_numpy(mapped.reshape(1, feat_h, feat_w, n_anchors).transpose(0, 3, 1, 2).copy())
+    s = score.reshape(1, 2, n_anchors, feat_h, feat_w)
+    loss_cls = torch.nn.functional.cross_entropy(s, mapped, ignore_index=-1, reduction="sum") / max(int((mapped != -1).sum()), 1)
+    pred = bbox_pred.reshape(4, n_anchors, -1).permute(2, 1, 0).reshape(-1, 4)
+    d = pred[torch.from_numpy(np.asarray(inds_inside, dtype=np.int64))].reshape(-1) - torch.from_numpy(
+        np.ascontiguousarray(targets, dtype=np.float32).ravel())
+    a = d.abs()
+    loss_bbox = torch.where(a < delta, 0.5 * d * d, delta * (a - 0.5 * delta)).sum() / pred.shape[0]
+    return loss_cls, loss_bbox, loss_cls + lam * loss_bbox
+
+
+def rpn_loss_grads(rpn_cls_score, rpn_bbox_pred, labels, targets, inds_inside, n_all, feat_h, feat_w, n_anchors=9, delta=3.0, lam=1.0):
+    """-> (loss_cls, loss_bbox, d rpn_cls_score, d rpn_bbox_pred) of rpn_loss = cls + lam * bbox."""
+    s = _t(rpn_cls_score).clone().requires_grad_(True)
+    p = _t(rpn_bbox_pred).clone().requires_grad_(True)
+    lc, lb, total = _torch_rpn_losses(s, p, labels, targets, inds_inside, n_all, feat_h, feat_w, n_anchors, delta, lam)
+    total.backward()
+    return np.float32(lc.item()), np.float32(lb.item()), s.grad.numpy(), p.grad.numpy()
+
+
+def rpn_train_grads(p, x, labels, targets, inds_inside, n_all, delta=3.0, lam=1.0, layers=None):
+    """One RPN-mode forward/backward of FasterRCNN (faster_rcnn.py:110-116 -> region_proposal_network.py:116-145):
+    -> (rpn_loss, {chainer link path: gradient}) for the trunk and RPN parameters, given the anchor targets."""
+    import torch
+    F = torch.nn.functional
+    from_names = [k for k in p if k.startswith("trunk/") or k.startswith("RPN/")]
+    tp = {k: _t(p[k]).clone().requires_grad_(True) for k in from_names}
+    h = _t(x)
+    layers = layers or ["conv1_1", "conv1_2", "pool", "conv2_1", "conv2_2", "pool", "conv3_1", "conv3_2", "conv3_3", "pool",
+                        "conv4_1", "conv4_2", "conv4_3", "pool", "conv5_1", "conv5_2", "conv5_3"]
+    for l in layers:
+        h = F.max_pool2d(h, 2, 2, ceil_mode=True) if l == "pool" else F.relu(F.conv2d(h, tp["trunk/%s/W" % l], tp["trunk/%s/b" % l], padding=1))
+    hh = F.relu(F.conv2d(h, tp["RPN/rpn_conv_3x3/W"], tp["RPN/rpn_conv_3x3/b"], padding=1))
+    score = F.conv2d(hh, tp["RPN/rpn_cls_score/W"], tp["RPN/rpn_cls_score/b"])
+    bbox = F.conv2d(hh, tp["RPN/rpn_bbox_pred/W"], tp["RPN/rpn_bbox_pred/b"])
+    fh, fw = int(score.shape[2]), int(score.shape[3])
+    A = int(score.shape[1]) // 2
+    lc, lb, total = _torch_rpn_losses(score, bbox, labels, targets, inds_inside, n_all, fh, fw, A, delta, lam)
+    total.backward()
+    return np.float32(total.item()), {k: v.grad.numpy() for k, v in tp.items()}

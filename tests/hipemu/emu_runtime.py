@@ -34,6 +34,10 @@ class HostMemory(object):
     def contiguous(self, a):
         return np.ascontiguousarray(a)
 
+    def view(self, flat, offset, shape):
+        n = int(np.prod(shape))
+        return flat[offset:offset + n].reshape(shape)
+
     def ptr(self, a):
         if a is None:
             return None

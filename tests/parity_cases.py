@@ -212,3 +212,99 @@ def check_head_decode(rt, R=37, ncls=21, seed=0):
     pb, pp = rt.head_decode(dev(rt, boxes), dev(rt, deltas), dev(rt, score), 600, 1000)
     assert np.allclose(host(rt, pb), want_boxes, rtol=5e-7, atol=1e-4)
     assert np.allclose(host(rt, pp), want_prob, rtol=1e-5, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------- training step
+def gt_case(rs, G, im_h, im_w):
+    """VOC-shaped ground truth (datasets/pascal_voc_dataset.py:44-47): (1,G,5) float32 [x1,y1,x2,y2,cls]."""
+    w = rs.uniform(32, min(400, im_w - 2), G); h = rs.uniform(32, min(400, im_h - 2), G)
+    x1 = rs.uniform(0, im_w - 1 - w); y1 = rs.uniform(0, im_h - 1 - h)
+    return np.stack([x1, y1, x1 + w, y1 + h, rs.randint(1, 21, G)], axis=1).astype(np.float32)[None]
+
+
+def check_bbox_overlaps(rt, N=500, K=7, seed=0):
+    rs = np.random.RandomState(seed)
+    a = rs.uniform(0, 300, (N, 2)); b = rs.uniform(0, 300, (K, 2))
+    boxes = np.hstack([a, a + rs.uniform(0, 200, (N, 2))]); q = np.hstack([b, b + rs.uniform(0, 200, (K, 2))])
+    got = host(rt, rt.bbox_overlaps(dev(rt, boxes), dev(rt, q)))
+    assert np.array_equal(got, O.bbox_overlaps(boxes, q))                      # float64, same operation order: exact
+
+
+def check_anchor_target(rt, fh, fw, im_h, im_w, G, seed=0):
+    rs = np.random.RandomState(seed)
+    gt = gt_case(rs, G, im_h, im_w)
+    info = np.array([[im_h, im_w]], dtype=np.int32)
+
+    class NoSubsample(object):          # the device entry point stops before the random subsample
+        @staticmethod
+        def choice(a, size, replace):
+            return a[:0]
+    want_l, want_t, want_i, n_all = O.anchor_target_layer(fh, fw, gt, info, rng=NoSubsample)
+    inds, n_in, labels, targets, argmax = rt.anchor_target(O.generate_anchors(), fh, fw, 16, im_h, im_w, dev(rt, gt[0]))
+    n = int(host(rt, n_in)[0])
+    assert n == len(want_i) and n_all == 9 * fh * fw
+    assert np.array_equal(host(rt, inds)[:n], want_i)
+    assert np.array_equal(host(rt, labels)[:n], want_l)
+    assert np.allclose(host(rt, targets)[:n], want_t, rtol=2e-7, atol=1e-7)    # float64 log, then rounded to float32
+    return n
+
+
+def check_rpn_loss(rt, fh=14, fw=14, im=224, G=3, seed=0):
+    rs = np.random.RandomState(seed)
+    gt = gt_case(rs, G, im, im)
+    info = np.array([[im, im]], dtype=np.int32)
+    labels, targets, inds, n_all = O.anchor_target_layer(fh, fw, gt, info, rng=np.random.RandomState(seed))
+    score = rs.randn(1, 18, fh, fw).astype(np.float32)
+    bbox = (rs.randn(1, 36, fh, fw) * 2).astype(np.float32)                    # some |d| beyond delta = 3
+    lc, acc = O.rpn_loss_cls(score, labels, inds, n_all, fh, fw)
+    lb = O.rpn_loss_bbox(bbox, targets, inds)
+    _, _, gs, gb = O.rpn_loss_grads(score, bbox, labels, targets, inds, n_all, fh, fw)
+    losses, ds, db = rt.rpn_loss(dev(rt, score[0]), dev(rt, bbox[0]), dev(rt, labels), dev(rt, targets), dev(rt, inds.astype(np.int32)),
+                                 len(inds), 9, fh, fw)
+    got = host(rt, losses)
+    assert np.allclose(got, [lc, lb, acc], rtol=1e-5, atol=1e-6), (got, lc, lb, acc)
+    assert np.allclose(host(rt, ds), gs[0], rtol=1e-4, atol=1e-7)
+    assert np.allclose(host(rt, db), gb[0], rtol=1e-4, atol=1e-9)
+    only = host(rt, rt.rpn_loss(dev(rt, score[0]), dev(rt, bbox[0]), dev(rt, labels), dev(rt, targets), dev(rt, inds.astype(np.int32)),
+                                len(inds), 9, fh, fw, want_grad=False))
+    assert np.array_equal(only, got)
+
+
+def check_conv_backward(rt, Cin, Cout, H, W, ksize=3, seed=0):
+    rs = np.random.RandomState(seed)
+    x = np.maximum(rs.randn(1, Cin, H, W), 0).astype(np.float32)               # a ReLU output: the mask of the fused epilogue
+    w = (rs.randn(Cout, Cin, ksize, ksize) * np.sqrt(2.0 / (Cin * ksize * ksize))).astype(np.float32)
+    b = np.zeros(Cout, np.float32)
+    dy = rs.randn(1, Cout, H, W).astype(np.float32)
+    want_dx, want_dw, want_db = O.conv2d_backward(x, w, b, dy, ksize // 2)
+    wp = dev(rt, np.ascontiguousarray(w.reshape(Cout, Cin * ksize * ksize).T))   # forward-packed (Cin*k*k, Cout)
+    # weight gradient, forward-packed layout
+    dwp = host(rt, rt.conv_wgrad(dev(rt, x), dev(rt, dy), ksize))
+    want_dwp = want_dw.reshape(Cout, Cin * ksize * ksize).T
+    assert np.abs(dwp - want_dwp).max() <= 1e-4 * max(np.abs(want_dwp).max(), 1e-6), np.abs(dwp - want_dwp).max()
+    # bias gradient
+    db = host(rt, rt.bias_grad(dev(rt, dy)))
+    assert np.allclose(db, want_db, rtol=1e-4, atol=1e-3)
+    # input gradient = the forward kernel on re-packed weights, ReLU mask of x fused in (needs Cin % 64 == 0)
+    if Cin % 64 == 0:
+        wd = rt.pack_conv_dgrad_w(wp, ksize)
+        zero = dev(rt, np.zeros(Cin, np.float32))
+        dx = host(rt, rt.conv_ex(dev(rt, dy), wd, zero, ksize, act=2, mask=dev(rt, x)))
+        want = want_dx * (x > 0)
+        assert np.abs(dx - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6)
+
+
+def check_maxpool_bwd(rt, C, H, W, seed=0):
+    rs = np.random.RandomState(seed)
+    x = np.maximum(rs.randn(1, C, H, W), 0).astype(np.float32)                 # many exact ties at 0
+    dy = rs.randn(1, C, (H + 1) // 2, (W + 1) // 2).astype(np.float32)
+    assert np.array_equal(host(rt, rt.maxpool2x2_bwd(dev(rt, x), dev(rt, dy))), O.max_pool_2x2_backward(x, dy))
+
+
+def check_sgd(rt, n=100003, seed=0):
+    rs = np.random.RandomState(seed)
+    w, g, v = [rs.randn(n).astype(np.float32) for _ in range(3)]
+    want_w, want_v = O.momentum_sgd_wd(w, g, v)
+    dw, dv = dev(rt, w), dev(rt, v)
+    rt.sgd_momentum_wd(dw, dev(rt, g), dv, 0.001, 0.9, 0.0005)
+    assert np.array_equal(host(rt, dw), want_w) and np.array_equal(host(rt, dv), want_v)      # same operation order: exact

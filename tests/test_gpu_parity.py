@@ -15,7 +15,7 @@ def rt():
 
 
 def test_library_is_the_device_build(rt):
-    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 2
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 3
 
 
 def test_nms_golden(rt):
@@ -139,3 +139,46 @@ def test_models_surface_and_end_to_end(rt):
     # forward.py:48-58 style post-processing through the cpu_nms-compatible entry point
     dets = np.hstack([pb[:, 4:8], cp[:, 1:2]]).astype(np.float32)
     assert cpu_nms(dets, 0.3, runtime=rt) == O.cpu_nms(dets, 0.3)
+
+
+# ---- RPN training step (csrc/train.hip)
+def test_bbox_overlaps(rt):
+    P.check_bbox_overlaps(rt, N=8151, K=20)
+
+
+@pytest.mark.parametrize("fh,fw,im_h,im_w,G", [(14, 14, 224, 224, 3), (38, 63, 600, 1000, 8), (38, 63, 600, 1000, 1), (37, 50, 600, 800, 40)])
+def test_anchor_target(rt, fh, fw, im_h, im_w, G):
+    n = P.check_anchor_target(rt, fh, fw, im_h, im_w, G, seed=G)
+    if (fh, fw) == (38, 63):
+        assert n == 8151                                            # SURVEY.md 8a-17 [probe]
+
+
+def test_rpn_loss(rt):
+    P.check_rpn_loss(rt)
+    P.check_rpn_loss(rt, fh=38, fw=63, im=600, G=6, seed=3)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,ks", [(64, 64, 60, 100, 3), (3, 64, 120, 200, 3), (128, 256, 38, 63, 3), (512, 512, 19, 32, 3),
+                                             (512, 64, 38, 63, 1)])
+def test_conv_backward(rt, cin, cout, h, w, ks):
+    P.check_conv_backward(rt, cin, cout, h, w, ksize=ks)
+
+
+def test_maxpool_bwd(rt):
+    P.check_maxpool_bwd(rt, 64, 75, 125)
+    P.check_maxpool_bwd(rt, 8, 600, 1000)
+
+
+def test_sgd(rt):
+    P.check_sgd(rt, n=17100003)
+
+
+def test_rpn_train_step_small(rt):
+    import train_cases as T
+    T.check_small_step(rt)
+
+
+def test_rpn_train_step_vgg16(rt):
+    import train_cases as T
+    losses, worst = T.check_vgg_step(rt)
+    assert losses["rpn_loss"] > 0 and worst <= 1e-3

@@ -86,3 +86,32 @@ def test_linear(rt):
 
 def test_head_decode(rt):
     P.check_head_decode(rt)
+
+
+# ---- RPN training step kernels (csrc/train.hip)
+def test_bbox_overlaps(rt):
+    P.check_bbox_overlaps(rt, N=300, K=5)
+
+
+def test_anchor_target(rt):
+    P.check_anchor_target(rt, 14, 14, 224, 224, 3)              # the reference's own test geometry (tests/test_anchor_target_layer.py:18-28)
+    P.check_anchor_target(rt, 19, 32, 300, 500, 6, seed=1)
+
+
+def test_rpn_loss(rt):
+    P.check_rpn_loss(rt)
+
+
+def test_conv_backward(rt):
+    P.check_conv_backward(rt, 64, 64, 9, 37)
+    P.check_conv_backward(rt, 3, 64, 7, 33, seed=1)             # conv1_1: channel padding, no input gradient
+    P.check_conv_backward(rt, 64, 64, 5, 40, ksize=1, seed=2)   # the RPN heads' 1x1
+
+
+def test_maxpool_bwd(rt):
+    P.check_maxpool_bwd(rt, 3, 7, 9)
+    P.check_maxpool_bwd(rt, 2, 8, 6)
+
+
+def test_sgd(rt):
+    P.check_sgd(rt, n=5000)

@@ -1,0 +1,110 @@
+"""The RPN training step on the host-emulated kernels (CPU): gradients vs the oracle's autograd, the fused update,
+and the world-size-2 data-parallel step over gloo."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "hipemu"))
+sys.path.insert(0, HERE)
+import train_cases as T  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def rt():
+    from emu_runtime import emu_runtime
+    return emu_runtime()
+
+
+def test_anchor_target_layer_mirror_matches_reference_rng(rt):
+    """AnchorTargetLayer(...)(feat_h, feat_w, Variable(gt), Variable(img_info)) with the reference's own test geometry
+    (tests/test_anchor_target_layer.py:18-28); the subsample consumes NumPy's global RNG exactly as the reference does."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.models import AnchorTargetLayer
+    from oracle import frcnn_oracle as O
+    gt = np.array([[[10, 10, 60, 200, 0], [50, 100, 210, 210, 1], [160, 40, 200, 70, 2]]], dtype=np.float32)
+    info = np.array([[224, 224]], dtype=np.int32)
+    layer = AnchorTargetLayer(16, [0.5, 1, 2], [8, 16, 32], runtime=rt)
+    np.random.seed(7)
+    labels, targets, inds, n_all = layer(14, 14, Variable(gt), Variable(info))
+    np.random.seed(7)
+    wl, wt, wi, wn = O.anchor_target_layer(14, 14, gt, info)
+    assert n_all == wn == 14 * 14 * 9
+    assert np.array_equal(rt.mem.to_numpy(inds), wi) and np.array_equal(rt.mem.to_numpy(labels), wl)
+    assert np.allclose(rt.mem.to_numpy(targets), wt, rtol=2e-7, atol=1e-7)
+    assert (wl == 1).sum() <= 128 and (wl >= 0).sum() <= 256          # the invariants the reference's test asserts (:76-77,88)
+
+
+def test_bbox_overlaps_mirror(rt):
+    from chainer_faster_rcnn_amd.models import bbox_overlaps
+    from oracle import frcnn_oracle as O
+    rs = np.random.RandomState(0)
+    a = rs.uniform(0, 100, (40, 2)); b = rs.uniform(0, 100, (4, 2))
+    boxes, q = np.hstack([a, a + 30]), np.hstack([b, b + 50])
+    assert np.array_equal(rt.mem.to_numpy(bbox_overlaps(boxes, q, runtime=rt)), O.bbox_overlaps(boxes, q))
+    with pytest.raises(ValueError):
+        bbox_overlaps(boxes.astype(np.float32), q, runtime=rt)
+
+
+def test_rpn_train_step_small(rt):
+    T.check_small_step(rt)
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.join(HERE, "hipemu")); sys.path.insert(0, HERE)
+        from emu_runtime import emu_runtime
+        from chainer_faster_rcnn_amd.chainer_compat import Variable
+        from chainer_faster_rcnn_amd.train import RPNTrainer, TorchComm
+        import parity_cases as P
+        rt = emu_runtime()
+        params = T.small_params()
+        info = np.array([[40, 56]], dtype=np.int32)
+
+        def sample(i):
+            rs = np.random.RandomState(100 + i)
+            gt = P.gt_case(rs, 2, 40, 56)
+            gt[0, :, 2] = np.minimum(gt[0, :, 0] + 20, 55); gt[0, :, 3] = np.minimum(gt[0, :, 1] + 20, 39)
+            return rs.randn(1, 3, 40, 56).astype(np.float32), gt
+        # data parallel: rank r takes image r (batch[i::n]), one all-reduce, identical update everywhere
+        tr = RPNTrainer(T.build_small(rt, params), comm=TorchComm())
+        x, gt = sample(rank)
+        np.random.seed(5 + rank)
+        tr.step(Variable(x), Variable(info), Variable(gt))
+        w_dp = rt.mem.to_numpy(tr.W)
+        # single-process reference: both images' gradients added, one update
+        ref = RPNTrainer(T.build_small(rt, params))
+        gsum = None
+        for r in range(world):
+            x, gt = sample(r)
+            np.random.seed(5 + r)
+            ref.forward_backward(Variable(x), Variable(info), Variable(gt))
+            g = rt.mem.to_numpy(ref.G)
+            gsum = g if gsum is None else gsum + g
+        ref.G[...] = gsum
+        ref.update()
+        q.put((rank, bool(np.array_equal(w_dp, rt.mem.to_numpy(ref.W))), float(np.abs(w_dp).sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_gloo_world2():
+    """N > 1 path on CPU: two ranks, gloo, gradients summed by ONE all_reduce, weights stay bit-identical across ranks
+    and equal the single-process update with the summed gradient."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == res[1][2]

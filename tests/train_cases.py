@@ -1,0 +1,121 @@
+"""RPN training-step cases shared by the CPU (host-emulated kernels, narrow trunk) and GPU (real VGG-16) suites."""
+import functools
+
+import numpy as np
+
+from oracle import frcnn_oracle as O
+import parity_cases as P
+
+SMALL_LAYERS = [("conv1_1", 3, 64), "pool", ("conv2_1", 64, 64), ("conv2_2", 64, 64), "pool"]     # stride 4, 64 channels
+
+
+def small_params(seed=1, ch=64, n_anchors=9):
+    rs = np.random.RandomState(seed)
+    p = {}
+    for l in SMALL_LAYERS:
+        if l == "pool":
+            continue
+        name, ci, co = l
+        p["trunk/%s/W" % name] = (rs.randn(co, ci, 3, 3) * np.sqrt(2.0 / (ci * 9))).astype(np.float32)
+        p["trunk/%s/b" % name] = (rs.randn(co) * 0.01).astype(np.float32)
+    p["RPN/rpn_conv_3x3/W"] = (rs.randn(ch, ch, 3, 3) * np.sqrt(2.0 / (ch * 9))).astype(np.float32)
+    p["RPN/rpn_conv_3x3/b"] = (rs.randn(ch) * 0.01).astype(np.float32)
+    p["RPN/rpn_cls_score/W"] = (rs.randn(2 * n_anchors, ch, 1, 1) * 0.05).astype(np.float32)
+    p["RPN/rpn_cls_score/b"] = (rs.randn(2 * n_anchors) * 0.01).astype(np.float32)
+    p["RPN/rpn_bbox_pred/W"] = (rs.randn(4 * n_anchors, ch, 1, 1) * 0.05).astype(np.float32)
+    p["RPN/rpn_bbox_pred/b"] = (rs.randn(4 * n_anchors) * 0.01).astype(np.float32)
+    return p
+
+
+def build_small(rt, params):
+    from chainer_faster_rcnn_amd.models import FasterRCNN, VGG16Prev
+    model = FasterRCNN(trunk_class=functools.partial(VGG16Prev, layers=SMALL_LAYERS), rpn_in_ch=64, rpn_mid_ch=64, feat_stride=4,
+                       anchor_scales=(2, 4, 8), runtime=rt)
+    model.trunk.load_params(params, "trunk/")
+    model.RPN.load_params(params, "RPN/")
+    model.rpn_train = True
+    return model
+
+
+def oracle_step(params, x, gt, info, layers, feat_stride, scales, seed):
+    """The oracle's forward/backward for one image: anchor targets with the SAME NumPy RNG state, then autograd."""
+    names = [l if l == "pool" else l[0] for l in layers]
+    h, w = x.shape[2], x.shape[3]
+    for l in layers:
+        if l == "pool":
+            h, w = (h + 1) // 2, (w + 1) // 2
+    np.random.seed(seed)
+    labels, targets, inds, n_all = O.anchor_target_layer(h, w, gt, info, feat_stride=feat_stride, anchor_scales=scales)
+    loss, grads = O.rpn_train_grads(params, x, labels, targets, inds, n_all, layers=names)
+    return loss, grads
+
+
+def check_small_step(rt, seed=0, im_h=40, im_w=56):
+    """forward + AnchorTargetLayer + losses + backward on the narrow trunk vs the oracle, then the SGD update."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.train import RPNTrainer
+    rs = np.random.RandomState(seed)
+    params = small_params()
+    x = rs.randn(1, 3, im_h, im_w).astype(np.float32)
+    gt = P.gt_case(rs, 3, im_h, im_w)
+    gt[0, :, 2] = np.minimum(gt[0, :, 0] + rs.uniform(8, 30, 3), im_w - 1)
+    gt[0, :, 3] = np.minimum(gt[0, :, 1] + rs.uniform(8, 30, 3), im_h - 1)
+    info = np.array([[im_h, im_w]], dtype=np.int32)
+    model = build_small(rt, params)
+    tr = RPNTrainer(model)
+    w0 = rt.mem.to_numpy(tr.W)
+    np.random.seed(123)
+    out = tr.forward_backward(Variable(x), Variable(info), Variable(gt))
+    want_loss, want = oracle_step(params, x, gt, info, SMALL_LAYERS, 4, (2, 4, 8), 123)
+    got = tr.grads_chainer_layout()
+    l = tr.losses_host(out)
+    assert abs(l["rpn_loss"] - want_loss) <= 1e-4 * abs(want_loss), (l, want_loss)
+    for k in sorted(want):
+        scale = max(np.abs(want[k]).max(), 1e-8)
+        assert np.abs(got[k] - want[k]).max() <= 1e-3 * scale, (k, np.abs(got[k] - want[k]).max(), scale)     # fp32, 1e-3 relative
+    # update: W1 = W0 + v1, v1 = -lr * (g + wd * W0)   (velocity starts at 0)
+    g = rt.mem.to_numpy(tr.G)
+    tr.update()
+    w1, v1 = O.momentum_sgd_wd(w0, g, np.zeros_like(w0))
+    assert np.array_equal(rt.mem.to_numpy(tr.W), w1) and np.array_equal(rt.mem.to_numpy(tr.V), v1)
+    # the links see the updated weights (views of the flat buffer), and sync_params() restores Chainer's layout
+    name, link = tr.convs[1]
+    seg = tr.seg[name + "/W"]
+    assert np.array_equal(rt.mem.to_numpy(link.Wp), w1[seg.offset:seg.offset + seg.size].reshape(seg.shape))
+    tr.sync_params()
+    assert np.array_equal(rt.mem.to_numpy(link.W).reshape(link.cout, -1), rt.mem.to_numpy(link.Wp).T)
+    return l
+
+
+def check_vgg_step(rt, im_h=160, im_w=224, seed=0):
+    """One RPN training step of the real VGG-16 FasterRCNN (GPU suite): loss and every gradient vs the oracle's autograd."""
+    from chainer_faster_rcnn_amd import synthetic
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.models import FasterRCNN
+    from chainer_faster_rcnn_amd.models.vgg16 import LAYERS
+    from chainer_faster_rcnn_amd.train import RPNTrainer
+    rs = np.random.RandomState(seed)
+    params = synthetic.params(seed=1)
+    for k in list(params):
+        if k.endswith("/b") and (k.startswith("trunk/") or k.startswith("RPN/")):
+            params[k] = (rs.randn(*params[k].shape) * 0.01).astype(np.float32)
+    x = synthetic.image(seed=4, h=im_h, w=im_w)
+    gt = P.gt_case(rs, 4, im_h, im_w)
+    info = np.array([[im_h, im_w]], dtype=np.int32)
+    model = FasterRCNN(runtime=rt)
+    model.load_params(params)
+    model.rpn_train = True
+    tr = RPNTrainer(model)
+    np.random.seed(11)
+    out = tr.forward_backward(Variable(x), Variable(info), Variable(gt))
+    want_loss, want = oracle_step(params, x, gt, info, LAYERS, 16, (8, 16, 32), 11)
+    l = tr.losses_host(out)
+    assert abs(l["rpn_loss"] - want_loss) <= 1e-4 * abs(want_loss), (l, want_loss)
+    got = tr.grads_chainer_layout()
+    worst = 0.0
+    for k in sorted(want):
+        scale = max(np.abs(want[k]).max(), 1e-8)
+        err = np.abs(got[k] - want[k]).max() / scale
+        worst = max(worst, err)
+        assert err <= 1e-3, (k, err)
+    return l, worst
