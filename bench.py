@@ -106,6 +106,60 @@ def cpu_baseline(params, x, samples):
             "ms_per_image": dt * 1e3}
 
 
+def train_mode(args, torch, dist, rt, model, x, rank, world, barrier):
+    """BASELINE.json configs[4]: train_rpn.py's step -- forward, anchor targets, losses, backward, ONE all-reduce of the
+    flat gradient buffer (RCCL), fused MomentumSGD+WD -- one synthetic VOC-shaped image per GPU per step."""
+    from chainer_faster_rcnn_amd.train import RPNTrainer, TorchComm
+    model.rpn_train = True
+    tr = RPNTrainer(model, comm=TorchComm() if dist is not None else None)
+    rs = np.random.RandomState(rank)
+    G = 4
+    w, h = rs.uniform(32, 400, G), rs.uniform(32, 400, G)
+    x1, y1 = rs.uniform(0, IM_W - 1 - w), rs.uniform(0, IM_H - 1 - h)
+    gt = np.stack([x1, y1, x1 + w, y1 + h, rs.randint(1, 21, G)], axis=1).astype(np.float32)[None]
+    gt_dev = rt.mem.from_numpy(gt)
+    info = np.array([[IM_H, IM_W]], dtype=np.int32)
+    np.random.seed(rank)
+    ev = {}
+
+    def mark(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        ev.setdefault(name, []).append(e)
+
+    for _ in range(args.warmup):
+        out = tr.step(x, info, gt_dev)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        mark("start")
+        out = tr.forward_backward(x, info, gt_dev)
+        mark("fwd_bwd")
+        tr.all_reduce()
+        mark("all_reduce")
+        tr.update()
+        mark("update")
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        st = {k: float(np.mean([a.elapsed_time(b) for a, b in zip(ev[p], ev[k])])) for p, k in
+              (("start", "fwd_bwd"), ("fwd_bwd", "all_reduce"), ("all_reduce", "update"))}
+        print(json.dumps({"metric": "images/sec RPN training step VGG16 600x1000", "value": world * args.steps / dt, "unit": "img/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "train_rpn.py end-to-end RPN training step, 1 image per GPU, one all-reduce of the "
+                                                 "flat fp32 gradient buffer per step (BASELINE.json configs[4])",
+                                     "grad_buffer_mb": tr.n_flat * 4 / 1e6, "global_batch": world},
+                          "stages_ms": st, "losses": tr.losses_host(out)}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -114,6 +168,8 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true")
+    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
+                    help="infer = BASELINE.json configs[1] (the contract line); train = configs[4], the RPN training step")
     args = ap.parse_args()
 
     import torch
@@ -145,6 +201,9 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+
+    if args.mode == "train":
+        return train_mode(args, torch, dist, rt, model, x, rank, world, barrier)
 
     for _ in range(args.warmup):
         model.forward_device(x, IM_H, IM_W)

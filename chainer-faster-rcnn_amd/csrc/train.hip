@@ -242,20 +242,33 @@ maxpool2x2_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
     }
 }
 
-// db[c] = sum over pixels of dy[c][:]; one workgroup per channel, fixed reduction tree
+// db[c] = sum over pixels of dy[c][:].  Two fixed-shape stages (deterministic): `parts` workgroups per channel each reduce a
+// contiguous slice (float4 loads), then one wave per channel adds the partials in order.
 __global__ void __launch_bounds__(256)
-bias_grad_kernel(const float *__restrict__ dy, int HW, float *__restrict__ db) {
+bias_grad_partial_kernel(const float *__restrict__ dy, int HW, int parts, float *__restrict__ partial) {
     __shared__ float red[256];
-    const float *p = dy + (size_t)blockIdx.x * HW;
+    const int c = blockIdx.x, part = blockIdx.y;
+    const int per = (HW + parts - 1) / parts;
+    const int begin = part * per, end = min(HW, begin + per);
+    const float *p = dy + (size_t)c * HW;
     float s = 0.0f;
-    for (int i = threadIdx.x; i < HW; i += 256) s += p[i];
+    for (int i = begin + threadIdx.x; i < end; i += 256) s += p[i];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int q = 128; q > 0; q >>= 1) {
         if (threadIdx.x < q) red[threadIdx.x] += red[threadIdx.x + q];
         __syncthreads();
     }
-    if (threadIdx.x == 0) db[blockIdx.x] = red[0];
+    if (threadIdx.x == 0) partial[(size_t)c * parts + part] = red[0];
+}
+
+__global__ void __launch_bounds__(256)
+bias_grad_final_kernel(const float *__restrict__ partial, int C, int parts, float *__restrict__ db) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.0f;
+    for (int q = 0; q < parts; ++q) s += partial[(size_t)c * parts + q];
+    db[c] = s;
 }
 
 // forward-packed (Cin*9, Cout) -> the packed weights of the input-gradient convolution: (Cout*9, Cin) with the taps
@@ -490,9 +503,25 @@ int frcnn_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int C, 
     return frcnn_launch_status();
 }
 
-int frcnn_bias_grad_f32(const float *dy, int C, int HW, float *db, void *stream) {
+static int bias_grad_parts(int C, int HW) {
+    int parts = frcnn_cdiv(1024, C);                      // about four workgroups per CU in total
+    const int max_parts = frcnn_cdiv(HW, 2048);
+    if (parts > max_parts) parts = max_parts;
+    return parts < 1 ? 1 : parts;
+}
+
+size_t frcnn_bias_grad_workspace_bytes(int C, int HW) {
+    if (C < 1 || HW < 1) return 0;
+    return frcnn_align256((size_t)C * bias_grad_parts(C, HW) * sizeof(float));
+}
+
+int frcnn_bias_grad_f32(const float *dy, int C, int HW, float *db, void *workspace, size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
     if (!dy || !db || C < 1 || HW < 1) return FRCNN_ERR_INVALID;
-    hipLaunchKernelGGL(bias_grad_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, dy, HW, db);
+    const int parts = bias_grad_parts(C, HW);
+    if (!workspace || workspace_bytes < (size_t)C * parts * sizeof(float)) return FRCNN_ERR_INVALID;
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3(C, parts), dim3(256), 0, stream, dy, HW, parts, (float *)workspace);
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3(frcnn_cdiv(C, 256)), dim3(256), 0, stream, (const float *)workspace, C, parts, db);
     return frcnn_launch_status();
 }
 

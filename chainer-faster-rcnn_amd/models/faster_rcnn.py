@@ -122,8 +122,10 @@ class FasterRCNN(object):
     def __call__(self, x, img_info, gt_boxes=None):
         if self.type_check_enable:
             self._check_data_type_forward(x, img_info, gt_boxes)
-        if gt_boxes is not None and (self.rpn_train or self.rcnn_train):
-            raise NotImplementedError("training modes are the next scope row")
+        if self.rpn_train and gt_boxes is not None:                  # faster_rcnn.py:115-116: RPN training mode returns rpn_loss
+            return self.RPN(Variable(self.trunk(x)), img_info, gt_boxes)
+        if self.rcnn_train and gt_boxes is not None:
+            raise NotImplementedError("stage-2 (rcnn_train) losses: SURVEY.md 8(f) rank 2, not on this round's path")
         im_h, im_w = self.RPN.proposal_layer._img_hw(img_info)
         out = self.forward_device(x, im_h, im_w)
         n = int(self.rt.mem.to_numpy(out["n_out"])[0])

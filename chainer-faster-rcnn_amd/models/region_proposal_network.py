@@ -25,6 +25,7 @@ class RegionProposalNetwork(object):
         self.proposal_layer = ProposalLayer(feat_stride, anchor_ratios, anchor_scales, runtime=self.rt)
         self._loss_lambda = loss_lambda
         self._delta = delta
+        self.anchor_target_layer = None
         self._train = True
         self.train = True                               # region_proposal_network.py:64
 
@@ -69,7 +70,22 @@ class RegionProposalNetwork(object):
     def __call__(self, x, img_info, gt_boxes=None):
         if self.type_check_enable:
             self._check_data_type_forward(x, img_info, gt_boxes)
+        _, score, prob, bbox = self.heads(x, want_score=True)
         if self.train and gt_boxes is not None:
-            raise NotImplementedError("RPN training step (anchor targets + losses + backward) is the next scope row")
-        _, _, prob, bbox = self.heads(x, want_score=False)
+            # region_proposal_network.py:127-158: anchor targets, the two losses, rpn_loss = cls + lambda * bbox.  (The
+            # reference also runs ProposalLayer here and discards the result; the backward pass and the update live in
+            # chainer_faster_rcnn_amd.train.RPNTrainer, which plays chainer's optimizer.update(lossfun).)
+            if self.anchor_target_layer is None:
+                from .anchor_target_layer import AnchorTargetLayer
+                self.anchor_target_layer = AnchorTargetLayer(self.proposal_layer._feat_stride, runtime=self.rt)
+                self.anchor_target_layer._anchors = self.proposal_layer._anchors
+                self.anchor_target_layer._num_anchors = self.proposal_layer._num_anchors
+            feat_h, feat_w = int(prob.shape[2]), int(prob.shape[3])
+            im_h, im_w = self.proposal_layer._img_hw(img_info)
+            labels, targets, inds, n_in, _ = self.anchor_target_layer.forward_device(feat_h, feat_w, gt_boxes, im_h, im_w)
+            losses = self.rt.rpn_loss(score[0], bbox[0], labels, targets, inds, n_in, self.n_anchors, feat_h, feat_w, self._delta,
+                                      self._loss_lambda, want_grad=False)
+            l = self.rt.mem.to_numpy(losses)
+            self.rpn_loss_cls, self.rpn_loss_bbox, self.rpn_cls_accuracy = float(l[0]), float(l[1]), float(l[2])
+            return Variable(np.float32(l[0] + self._loss_lambda * l[1]), name='rpn_loss')
         return self.proposal_layer(Variable(prob), Variable(bbox), img_info)

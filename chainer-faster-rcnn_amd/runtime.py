@@ -341,7 +341,8 @@ class Runtime(object):
         C = int(dy.shape[-3])
         HW = int(dy.shape[-2]) * int(dy.shape[-1])
         db = out if out is not None else m.empty((C,), "f32")
-        _lib.check(L.frcnn_bias_grad_f32(m.ptr(dy), C, HW, m.ptr(db), m.stream()), "frcnn_bias_grad_f32")
+        ws = self.workspace("bias_grad", L.frcnn_bias_grad_workspace_bytes(C, HW))
+        _lib.check(L.frcnn_bias_grad_f32(m.ptr(dy), C, HW, m.ptr(db), m.ptr(ws), ws.shape[0], m.stream()), "frcnn_bias_grad_f32")
         return db
 
     def pack_conv_dgrad_w(self, w_packed, ksize=3, out=None):

@@ -194,7 +194,8 @@ int frcnn_rpn_loss(const float *rpn_cls_score, const float *rpn_bbox_pred, const
                    const float *targets, const int32_t *inds_inside, int n_inside, int A, int H, int W, float delta,
                    float loss_lambda, float *losses, float *d_cls_score, float *d_bbox_pred, void *stream);
 int frcnn_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int C, int H, int W, void *stream);
-int frcnn_bias_grad_f32(const float *dy, int C, int HW, float *db, void *stream);
+size_t frcnn_bias_grad_workspace_bytes(int C, int HW);
+int frcnn_bias_grad_f32(const float *dy, int C, int HW, float *db, void *workspace, size_t workspace_bytes, void *stream);
 int frcnn_pack_conv_dgrad_w(const float *w_packed, int Cin, int Cout, int ksize, float *w_dgrad, void *stream);
 size_t frcnn_conv_wgrad_workspace_bytes(int Cin, int Cout, int H, int W, int ksize);
 int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int Cin, int Cout, int H, int W, int ksize,
