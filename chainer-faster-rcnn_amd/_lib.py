@@ -46,6 +46,9 @@ SIGNATURES = {
     "frcnn_clip_boxes": (_I, [_P, _I, _I, _I, _P]),
     "frcnn_softmax_rows": (_I, [_P, _I, _I, _P, _P]),
     "frcnn_conv_f32_ex": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
+    "frcnn_im2col7x7s2_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
+    "frcnn_maxpool3x3s2_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "frcnn_subsample2_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "frcnn_bbox_overlaps_f64": (_I, [_P, _I, _P, _I, _P, _P]),
     "frcnn_anchor_target_workspace_bytes": (_S, [_I, _I, _I, _I]),
     "frcnn_anchor_target": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _S, _P]),

@@ -266,6 +266,7 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
                             const size_t o = (size_t)co * HW + (size_t)py * W + px;
                             if (relu == 1) v = fmaxf(v, 0.0f);
                             else if (relu == 2) v = mask[o] > 0.0f ? v : 0.0f;      // backward through the ReLU that produced `mask`
+                            else if (relu == 3) v = fmaxf(v + mask[o], 0.0f);       // residual add + ReLU (ResNet bottleneck tail)
                             y[o] = v;
                         }
                     }
@@ -329,6 +330,52 @@ softmax_channels_kernel(const float *__restrict__ score, int n_ch, int HW, float
     float sum = 0.0f;
     for (int c = 0; c < n_ch; ++c) sum += expf(score[(size_t)c * HW + p] - m);
     for (int c = 0; c < n_ch; ++c) prob[(size_t)c * HW + p] = expf(score[(size_t)c * HW + p] - m) / sum;
+}
+
+// ---- ResNet stem / stride helpers (models/resnet.py -> chainer ResNetLayers: conv1 7x7/2 pad 3, max-pool 3x3/2, stride-2 1x1) ----
+// im2col of the 7x7 / stride 2 / pad 3 stem: cols[(ci*49 + ky*7 + kx)][oy*OW + ox] = x[ci][2*oy - 3 + ky][2*ox - 3 + kx] (0 outside);
+// rows Cin*49 .. Kp-1 are zero padding.  The stem then runs as a 1x1 convolution on the MFMA kernel.
+__global__ void __launch_bounds__(256)
+im2col7x7s2_kernel(const float *__restrict__ x, int Cin, int H, int W, int OH, int OW, int Kp, float *__restrict__ cols) {
+    const size_t total = (size_t)Kp * OH * OW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % ((size_t)OH * OW)), k = (int)(i / ((size_t)OH * OW));
+        float v = 0.0f;
+        if (k < Cin * 49) {
+            const int ci = k / 49, t = k - ci * 49, ky = t / 7, kx = t - ky * 7;
+            const int oy = p / OW, ox = p - oy * OW;
+            const int iy = 2 * oy - 3 + ky, ix = 2 * ox - 3 + kx;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((size_t)ci * H + iy) * W + ix];
+        }
+        cols[i] = v;
+    }
+}
+
+// F.max_pooling_2d(3, stride 2) with cover_all=True: OH = ceil((H-3)/2)+1, windows clipped at the border
+__global__ void __launch_bounds__(256)
+maxpool3x3s2_kernel(const float *__restrict__ x, float *__restrict__ y, int C, int H, int W, int OH, int OW) {
+    const size_t total = (size_t)C * OH * OW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ow = (int)(i % OW), oh = (int)((i / OW) % OH), c = (int)(i / ((size_t)OW * OH));
+        const float *p = x + (size_t)c * H * W;
+        float m = p[(size_t)(2 * oh) * W + 2 * ow];
+        for (int dy = 0; dy < 3; ++dy)
+            for (int dx = 0; dx < 3; ++dx) {
+                const int iy = 2 * oh + dy, ix = 2 * ow + dx;
+                if (iy < H && ix < W) m = fmaxf(m, p[(size_t)iy * W + ix]);
+            }
+        y[i] = m;
+    }
+}
+
+// every second pixel in both directions: the input view of a stride-2 1x1 convolution (pad 0): OH = (H-1)/2+1
+__global__ void __launch_bounds__(256)
+subsample2_kernel(const float *__restrict__ x, float *__restrict__ y, int C, int H, int W, int OH, int OW) {
+    const size_t total = (size_t)C * OH * OW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ow = (int)(i % OW), oh = (int)((i / OW) % OH), c = (int)(i / ((size_t)OW * OH));
+        y[i] = x[((size_t)c * H + 2 * oh) * W + 2 * ow];
+    }
 }
 
 // ---- per-layer work decomposition ------------------------------------------------------------------
@@ -472,7 +519,7 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
                       int H, int W, int ksize, int act, void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (Cout % 64) != 0) return FRCNN_ERR_INVALID;
-    if (act < 0 || act > 2 || (act == 2 && !mask) || (ksize != 1 && ksize != 3)) return FRCNN_ERR_INVALID;
+    if (act < 0 || act > 3 || (act >= 2 && !mask) || (ksize != 1 && ksize != 3)) return FRCNN_ERR_INVALID;
     if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cin * ksize * ksize * Cout * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;
     if (ksize == 1) return launch_conv<1, 2, 2, 1, 1, 8, true, 3>(x, w_packed, bias, y, Cin, Cout, H, W, act, 0, nullptr, 0, stream, mask);
     const int cfg = pick_conv_config(Cin, Cout, H, W);
@@ -487,6 +534,33 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
 int frcnn_conv3x3_f32(const float *x, const float *w_packed, const float *bias, float *y, int Cin, int Cout, int H, int W, int relu,
                       void *workspace, size_t workspace_bytes, void *stream) {
     return frcnn_conv3x3_f32_cfg(x, w_packed, bias, y, Cin, Cout, H, W, relu, -1, workspace, workspace_bytes, stream);
+}
+
+int frcnn_im2col7x7s2_f32(const float *x, int Cin, int H, int W, int Kp, float *cols, void *stream) {
+    if (!x || !cols || Cin < 1 || H < 1 || W < 1 || Kp < Cin * 49) return FRCNN_ERR_INVALID;
+    const int OH = (H + 6 - 7) / 2 + 1, OW = (W + 6 - 7) / 2 + 1;
+    const size_t total = (size_t)Kp * OH * OW;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(im2col7x7s2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, Cin, H, W, OH, OW, Kp, cols);
+    return frcnn_launch_status();
+}
+
+int frcnn_maxpool3x3s2_f32(const float *x, float *y, int C, int H, int W, void *stream) {
+    if (!x || !y || C < 1 || H < 3 || W < 3) return FRCNN_ERR_INVALID;
+    const int OH = (H - 3 + 1) / 2 + 1, OW = (W - 3 + 1) / 2 + 1;
+    const size_t total = (size_t)C * OH * OW;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, C, H, W, OH, OW);
+    return frcnn_launch_status();
+}
+
+int frcnn_subsample2_f32(const float *x, float *y, int C, int H, int W, void *stream) {
+    if (!x || !y || C < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const size_t total = (size_t)C * OH * OW;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(subsample2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, C, H, W, OH, OW);
+    return frcnn_launch_status();
 }
 
 int frcnn_maxpool2x2_f32(const float *x, float *y, int C, int H, int W, void *stream) {

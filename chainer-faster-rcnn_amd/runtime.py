@@ -294,6 +294,29 @@ class Runtime(object):
                                        int(act), m.ptr(ws), ws.shape[0], m.stream()), "frcnn_conv_f32_ex")
         return y
 
+    # ------------------------------------------------------------------ ResNet trunk pieces
+    def im2col7x7s2(self, x, Kp):
+        m, L = self.mem, self.lib
+        C, H, W = [int(v) for v in x.shape[-3:]]
+        OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        cols = m.empty((1, Kp, OH, OW), "f32")
+        _lib.check(L.frcnn_im2col7x7s2_f32(m.ptr(x), C, H, W, int(Kp), m.ptr(cols), m.stream()), "frcnn_im2col7x7s2_f32")
+        return cols
+
+    def maxpool3x3s2(self, x):
+        m, L = self.mem, self.lib
+        C, H, W = [int(v) for v in x.shape[-3:]]
+        y = m.empty((1, C, (H - 2) // 2 + 1, (W - 2) // 2 + 1), "f32")
+        _lib.check(L.frcnn_maxpool3x3s2_f32(m.ptr(x), m.ptr(y), C, H, W, m.stream()), "frcnn_maxpool3x3s2_f32")
+        return y
+
+    def subsample2(self, x):
+        m, L = self.mem, self.lib
+        C, H, W = [int(v) for v in x.shape[-3:]]
+        y = m.empty((1, C, (H - 1) // 2 + 1, (W - 1) // 2 + 1), "f32")
+        _lib.check(L.frcnn_subsample2_f32(m.ptr(x), m.ptr(y), C, H, W, m.stream()), "frcnn_subsample2_f32")
+        return y
+
     def bbox_overlaps(self, boxes, query_boxes):
         m, L = self.mem, self.lib
         N, K = int(boxes.shape[0]), int(query_boxes.shape[0])

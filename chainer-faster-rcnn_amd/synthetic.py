@@ -54,3 +54,19 @@ def load_npz(path, model):
     """serializers.load_npz(path, model) for the reference's snapshot format (forward.py:29)."""
     with np.load(path) as f:
         model.load_params({k: f[k] for k in f.files})
+
+
+def resnet_params(n_layers=101, seed=2, blocks=None, prefix="trunk/"):
+    """Random-init ResNet trunk in chainer's ResNetLayers naming: He-normal convolutions (no bias) and BatchNormalization
+    statistics drawn so that test-mode activations stay O(1) through 100 layers."""
+    from .models.resnet import BLOCKS, conv_specs
+    rs = np.random.RandomState(seed)
+    p = {}
+    for conv, bn, ci, co, k in conv_specs(tuple(blocks) if blocks is not None else BLOCKS[n_layers]):
+        gain = 0.5 if conv.endswith("conv3") or conv.endswith("conv4") else 1.0      # the two summands of a block: keep the sum O(1)
+        p[prefix + conv + "/W"] = (rs.randn(co, ci, k, k) * gain * np.sqrt(2.0 / (ci * k * k))).astype(np.float32)
+        p[prefix + bn + "/gamma"] = rs.uniform(0.5, 1.0, co).astype(np.float32)
+        p[prefix + bn + "/beta"] = (rs.randn(co) * 0.1).astype(np.float32)
+        p[prefix + bn + "/avg_mean"] = (rs.randn(co) * 0.1).astype(np.float32)
+        p[prefix + bn + "/avg_var"] = rs.uniform(0.5, 1.5, co).astype(np.float32)
+    return p

@@ -158,11 +158,21 @@ int frcnn_clip_boxes(float *boxes, int n_boxes, int im_h, int im_w, void *stream
 int frcnn_softmax_rows(const float *scores, int R, int n, float *probs, void *stream);
 
 /* generic form of the convolution entry: ksize 1 or 3 (stride 1, pad ksize/2), act 0 = none, 1 = ReLU,
- * 2 = y = (mask > 0) ? conv + bias : 0  -- the input-gradient convolution of the backward pass with the producing
+ * 3 = y = relu(conv + bias + mask) (residual add), 2 = y = (mask > 0) ? conv + bias : 0  -- the input-gradient convolution of the backward pass with the producing
  * ReLU's mask fused in (mask has y's shape).  Cout % 64 == 0. */
 int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, const float *mask, float *y, int Cin,
                       int Cout, int H, int W, int ksize, int act, void *workspace, size_t workspace_bytes,
                       void *stream);
+
+/* ---- ResNet trunk pieces (models/resnet.py -> chainer ResNetLayers) ------------------
+ * frcnn_conv_f32_ex with act = 3 is the bottleneck tail: y = relu(conv + bias + residual), residual passed as `mask`.
+ * frcnn_im2col7x7s2_f32: the 7x7 / stride 2 / pad 3 stem as an explicit im2col (Kp >= Cin*49 rows, zero padded) so that
+ *   it runs as a 1x1 convolution on the MFMA kernel; frcnn_maxpool3x3s2_f32: F.max_pooling_2d(3, stride=2), cover_all;
+ * frcnn_subsample2_f32: the input view of a stride-2 1x1 convolution.  BatchNormalization (test mode) is folded into
+ * the convolution weights and bias on the host at load time. */
+int frcnn_im2col7x7s2_f32(const float *x, int Cin, int H, int W, int Kp, float *cols, void *stream);
+int frcnn_maxpool3x3s2_f32(const float *x, float *y, int C, int H, int W, void *stream);
+int frcnn_subsample2_f32(const float *x, float *y, int C, int H, int W, void *stream);
 
 /* ---- RPN training step --------------------------------------------------------
  * frcnn_bbox_overlaps_f64: bbox_overlaps(boxes (N,4) f64, query_boxes (K,4) f64) -> (N,K) f64   (models/bbox.pyx:16-56)

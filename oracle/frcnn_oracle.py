@@ -568,3 +568,35 @@ def rpn_train_grads(p, x, labels, targets, inds_inside, n_all, delta=3.0, lam=1.
     lc, lb, total = _torch_rpn_losses(score, bbox, labels, targets, inds_inside, n_all, fh, fw, A, delta, lam)
     total.backward()
     return np.float32(total.item()), {k: v.grad.numpy() for k, v in tp.items()}
+
+
+# --------------------------------------------------------------------------- ResNet trunk (chainer-ext)
+def resnet_forward(p, x, blocks=(3, 4, 23, 3), prefix="trunk/", eps=2e-5):
+    """models/resnet.py:43-45 -> chainer ResNetLayers(...)(x, ['res5'], test=True)['res5'] [chainer-ext], restated with
+    torch-CPU fp32 and EXPLICIT (unfolded) test-mode BatchNormalization: conv1 7x7/2 pad 3 -> bn1 -> relu ->
+    max_pooling_2d(3, stride=2) (cover_all) -> res2..res5; BottleNeckA: stride on conv1 and on the projection conv4;
+    h = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + shortcut)."""
+    import torch
+    F = torch.nn.functional
+
+    def bn(h, name):
+        g, b, m, v = [_t(p[prefix + name + "/" + n]) for n in ("gamma", "beta", "avg_mean", "avg_var")]
+        return F.batch_norm(h, m, v, g, b, training=False, eps=eps)
+
+    def conv(h, name, stride=1, pad=0):
+        return F.conv2d(h, _t(p[prefix + name + "/W"]), None, stride=stride, padding=pad)
+
+    with torch.no_grad():
+        h = F.relu(bn(conv(_t(x), "conv1", 2, 3), "bn1"))
+        h = F.max_pool2d(h, 3, 2, ceil_mode=True)
+        stages = [("res2", 1), ("res3", 2), ("res4", 2), ("res5", 2)]
+        for (stage, stride), n in zip(stages, blocks):
+            for i in range(n):
+                b = "a" if i == 0 else "b%d" % i
+                q = "%s/%s/" % (stage, b)
+                s = stride if i == 0 else 1
+                sc = bn(conv(h, q + "conv4", s), q + "bn4") if i == 0 else h
+                t = F.relu(bn(conv(h, q + "conv1", s), q + "bn1"))
+                t = F.relu(bn(conv(t, q + "conv2", 1, 1), q + "bn2"))
+                h = F.relu(bn(conv(t, q + "conv3"), q + "bn3") + sc)
+        return h.numpy()

@@ -308,3 +308,33 @@ def check_sgd(rt, n=100003, seed=0):
     dw, dv = dev(rt, w), dev(rt, v)
     rt.sgd_momentum_wd(dw, dev(rt, g), dv, 0.001, 0.9, 0.0005)
     assert np.array_equal(host(rt, dw), want_w) and np.array_equal(host(rt, dv), want_v)      # same operation order: exact
+
+
+# ------------------------------------------------------------------------------------------- ResNet trunk
+def check_resnet(rt, blocks, im_h, im_w, n_layers=101, seed=2, tol=1e-3):
+    from chainer_faster_rcnn_amd import synthetic
+    from chainer_faster_rcnn_amd.models import ResNet
+    params = synthetic.resnet_params(n_layers, seed=seed, blocks=blocks)
+    x = synthetic.image(seed=6, h=im_h, w=im_w) / 64.0
+    want = O.resnet_forward(params, x, blocks=blocks)
+    model = ResNet(n_layers, runtime=rt, blocks=blocks)
+    model.load_params(params)
+    got = host(rt, model(dev(rt, x)))
+    assert got.shape == want.shape, (got.shape, want.shape)
+    err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-6)
+    assert err < tol, err
+    assert np.abs(want).max() > 1e-3 and np.isfinite(want).all()       # the comparison is not vacuous
+    return err
+
+
+def check_resnet_pieces(rt, seed=0):
+    import torch
+    rs = np.random.RandomState(seed)
+    x = rs.randn(1, 5, 13, 18).astype(np.float32)
+    want = torch.nn.functional.max_pool2d(torch.from_numpy(x), 3, 2, ceil_mode=True).numpy()
+    assert np.array_equal(host(rt, rt.maxpool3x3s2(dev(rt, x))), want)
+    assert np.array_equal(host(rt, rt.subsample2(dev(rt, x))), x[:, :, ::2, ::2])
+    x3 = rs.randn(1, 3, 21, 30).astype(np.float32)
+    cols = host(rt, rt.im2col7x7s2(dev(rt, x3), 152))
+    want = torch.nn.functional.unfold(torch.from_numpy(x3), 7, padding=3, stride=2).numpy().reshape(1, 147, 11, 15)
+    assert np.array_equal(cols[:, :147], want) and not cols[:, 147:].any()

@@ -15,7 +15,7 @@ def rt():
 
 
 def test_library_is_the_device_build(rt):
-    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 3
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 4
 
 
 def test_nms_golden(rt):
@@ -182,3 +182,52 @@ def test_rpn_train_step_vgg16(rt):
     import train_cases as T
     losses, worst = T.check_vgg_step(rt)
     assert losses["rpn_loss"] > 0 and worst <= 1e-3
+
+
+# ---- ResNet-101 trunk and BASELINE config 4 (ResNet-101 backbone, 1000 pre-NMS / 300 post-NMS proposals)
+def test_resnet_pieces(rt):
+    P.check_resnet_pieces(rt)
+
+
+def test_resnet101_trunk(rt):
+    err = P.check_resnet(rt, blocks=(3, 4, 23, 3), im_h=224, im_w=320)
+    assert err < 1e-3
+
+
+def test_faster_rcnn_resnet101_config4(rt):
+    """FasterRCNN(trunk_class=ResNet101, rpn_in_ch=2048, feat_stride=32) with ProposalLayer's class constants overridden to
+    1000 / 300 (config 4): trunk vs the oracle's explicit-BN restatement, proposals exact given the device's RPN maps, RoI
+    pooling (scale 1/32) exact, head within 1e-3."""
+    from chainer_faster_rcnn_amd import synthetic
+    from chainer_faster_rcnn_amd.models import FasterRCNN, ResNet101
+    from oracle import frcnn_oracle as O
+    h, w = 320, 480
+    params = synthetic.resnet_params(101, seed=2)
+    rs = np.random.RandomState(3)
+    head = synthetic.params(seed=1, rpn_ch=512, roi_feat=2048 * 49)
+    for k in ("fc6", "fc7", "cls_score", "bbox_pred"):
+        params[k + "/W"], params[k + "/b"] = head[k + "/W"], head[k + "/b"]
+    params["RPN/rpn_conv_3x3/W"] = (rs.randn(512, 2048, 3, 3) * 0.01).astype(np.float32)
+    params["RPN/rpn_conv_3x3/b"] = np.zeros(512, np.float32)
+    for k in ("rpn_cls_score", "rpn_bbox_pred"):
+        params["RPN/%s/W" % k], params["RPN/%s/b" % k] = head["RPN/%s/W" % k], head["RPN/%s/b" % k]
+    model = FasterRCNN(trunk_class=ResNet101, rpn_in_ch=2048, rpn_mid_ch=512, feat_stride=32, runtime=rt)
+    model.load_params(params)
+    model.RPN.proposal_layer._pre_nms_top_n, model.RPN.proposal_layer._post_nms_top_n = 1000, 300
+    x = synthetic.image(seed=6, h=h, w=w) / 64.0
+    info = np.array([[h, w]], dtype=np.int32)
+    out = model.forward_device(rt.mem.from_numpy(x), h, w, keep=True)
+    feat = rt.mem.to_numpy(out["feat"])
+    want_feat = O.resnet_forward(params, x)
+    assert feat.shape == want_feat.shape == (1, 2048, 10, 15)
+    assert np.abs(feat - want_feat).max() / np.abs(want_feat).max() < 1e-3
+    n = int(rt.mem.to_numpy(out["n_out"])[0])
+    p2, s2 = O.proposal_layer(rt.mem.to_numpy(out["rpn_cls_prob"]), rt.mem.to_numpy(out["rpn_bbox_pred"]), info, train=False,
+                              feat_stride=32, pre_nms_top_n=1000, post_nms_top_n=300)
+    assert n == len(p2) and np.allclose(rt.mem.to_numpy(out["rois"])[:n], p2, rtol=5e-7, atol=1e-4)
+    rois = rt.mem.to_numpy(out["rois"])[:n]
+    pool5 = O.roi_pooling_2d(feat, np.concatenate([np.zeros((n, 1), np.float32), rois], 1), 7, 7, 1 / 32.)
+    assert np.array_equal(rt.mem.to_numpy(out["pool5"])[:n], pool5)
+    cp, pb, _ = O.rcnn_head(params, pool5, rois, info)
+    assert np.allclose(rt.mem.to_numpy(out["cls_prob"])[:n], cp, rtol=1e-3, atol=1e-5)
+    assert np.allclose(rt.mem.to_numpy(out["pred_boxes"])[:n], pb, rtol=1e-3, atol=1e-2)

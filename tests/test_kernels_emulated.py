@@ -115,3 +115,12 @@ def test_maxpool_bwd(rt):
 
 def test_sgd(rt):
     P.check_sgd(rt, n=5000)
+
+
+# ---- ResNet trunk (BASELINE config 4)
+def test_resnet_pieces(rt):
+    P.check_resnet_pieces(rt)
+
+
+def test_resnet_tiny(rt):
+    P.check_resnet(rt, blocks=(2, 1, 1, 1), im_h=40, im_w=70)     # one `a` + one `b` block, all four stages, odd sizes
