@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix)
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: Peak BF16 MFMA, dense
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak BW (spec)
 IM_H, IM_W = 600, 1000
 
@@ -168,6 +169,11 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the forward as ONE captured hipGraph in the timed region (auto: on for bf16, where the ~45 launches "
+                         "of a step are shorter than the host can issue them; off for f32, which is GPU-bound in eager mode)")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32 = BASELINE.json configs[1] (the contract line); bf16 = configs[2]: bf16 convolutions, fp32 RoI / head")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = BASELINE.json configs[1] (the contract line); train = configs[4], the RPN training step")
     args = ap.parse_args()
@@ -191,7 +197,7 @@ def main():
     from chainer_faster_rcnn_amd.models.vgg16 import LAYERS
     rt = pkg.runtime.Runtime(pkg._lib.load(), pkg.runtime.TorchDeviceMemory("cuda:%d" % local_rank))
     params = synthetic.params(seed=1)
-    model = FasterRCNN(runtime=rt)
+    model = FasterRCNN(runtime=rt, conv_dtype=args.dtype)
     model.load_params(params)
     x_host = synthetic.image(seed=rank, h=IM_H, w=IM_W)          # every rank its own image (1 img / GPU)
     x = rt.mem.from_numpy(x_host)
@@ -205,19 +211,40 @@ def main():
     if args.mode == "train":
         return train_mode(args, torch, dist, rt, model, x, rank, world, barrier)
 
+    use_graph = args.graph == "on" or (args.graph == "auto" and args.dtype == "bf16")
     for _ in range(args.warmup):
         model.forward_device(x, IM_H, IM_W)
     timer = None if args.no_stage_events else EventTimer(torch)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    if use_graph:
+        # Stage events come from an eager pass (they cannot be read out of a replayed graph); the TIMED region below is
+        # K replays of one captured hipGraph of the whole forward: no Python, no per-launch host cost inside it.
         if timer:
-            timer.begin()
-        out = model.forward_device(x, IM_H, IM_W, timer=timer)
-        if timer:
-            timer.end()
-    barrier()
-    dt = time.perf_counter() - t0
+            for _ in range(max(3, args.steps // 3)):
+                timer.begin()
+                model.forward_device(x, IM_H, IM_W, timer=timer)
+                timer.end()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = model.forward_device(x, IM_H, IM_W)
+        graph.replay()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        barrier()
+        dt = time.perf_counter() - t0
+    else:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            if timer:
+                timer.begin()
+            out = model.forward_device(x, IM_H, IM_W, timer=timer)
+            if timer:
+                timer.end()
+        barrier()
+        dt = time.perf_counter() - t0
     n_rois = int(out["n_out"].cpu()[0])
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -229,19 +256,22 @@ def main():
         value = world * args.steps / dt
         res = {"metric": "images/sec VGG16 Faster R-CNN 600x1000", "value": value, "unit": "img/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "VGG16 inference, 1xMI355X per image, batch 1, 300 proposals post-NMS, fp32 "
-                                      "(BASELINE.json configs[1]); 1 image per GPU per step",
-                          "image": "1x3x600x1000", "global_batch": world, "parallelism": "dp%d (images sharded, no collective)" % world,
+               "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": ("VGG16 inference, 1xMI355X per image, batch 1, 300 proposals post-NMS, fp32 "
+                                       "(BASELINE.json configs[1]); 1 image per GPU per step") if args.dtype == "f32" else
+                                      ("VGG16 inference, data-parallel 1 img/GPU, bf16 convs / fp32 RoI + head "
+                                       "(BASELINE.json configs[2])"),
+                          "image": "1x3x600x1000", "global_batch": world, "launch": "hipGraph replay" if use_graph else "eager", "parallelism": "dp%d (images sharded, no collective)" % world,
                           "n_rois_last_step": n_rois}}
         if timer:
             avg = timer.averages_ms()
             flops, (fh, fw) = conv_flops(LAYERS, IM_H, IM_W)
             conv_ms = sum(avg[k] for k in flops)
             conv_tf = sum(flops.values()) / (conv_ms * 1e-3) / 1e12
-            res["roofline"] = {"bound": "mfma", "achieved": conv_tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": conv_tf / PEAK_F32_MFMA_TFLOPS, "traffic": None,
-                               "kernel": "conv3x3_mfma_f32_kernel (14 launches/image: 13 VGG-16 convs + rpn_conv_3x3)",
+            peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+            res["roofline"] = {"bound": "mfma", "achieved": conv_tf, "peak": peak, "unit": "TFLOP/s",
+                               "frac": conv_tf / peak, "traffic": None,
+                               "kernel": "conv_mfma_%s_kernel (14 launches/image: 13 VGG-16 convs + rpn_conv_3x3)" % args.dtype,
                                "algorithmic_gflop_per_image": sum(flops.values()) / 1e9, "conv_ms_per_image": conv_ms}
             roi_bytes = (512 * fh * fw + 300 * 512 * 49) * 4 + 300 * 16
             res["stages_ms"] = {k: round(v, 4) for k, v in avg.items()}

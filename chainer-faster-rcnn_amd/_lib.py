@@ -46,6 +46,13 @@ SIGNATURES = {
     "frcnn_clip_boxes": (_I, [_P, _I, _I, _I, _P]),
     "frcnn_softmax_rows": (_I, [_P, _I, _I, _P, _P]),
     "frcnn_conv_f32_ex": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
+    "frcnn_bf16_padded_channels": (_I, [_I]),
+    "frcnn_bf16_pack_conv_w": (_I, [_P, _I, _I, _I, _P, _P]),
+    "frcnn_bf16_from_nchw_f32": (_I, [_P, _I, _I, _I, _P, _P]),
+    "frcnn_bf16_to_nchw_f32": (_I, [_P, _I, _I, _I, _P, _P]),
+    "frcnn_conv_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "frcnn_maxpool2x2_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "frcnn_softmax_channels_f32": (_I, [_P, _I, _I, _P, _P]),
     "frcnn_im2col7x7s2_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "frcnn_maxpool3x3s2_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "frcnn_subsample2_f32": (_I, [_P, _P, _I, _I, _I, _P]),

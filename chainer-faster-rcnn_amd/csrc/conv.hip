@@ -581,6 +581,12 @@ int frcnn_rpn_heads_pack(const float *w_cls, const float *b_cls, const float *w_
     return frcnn_launch_status();
 }
 
+int frcnn_softmax_channels_f32(const float *score, int n_ch, int HW, float *prob, void *stream) {
+    if (!score || !prob || n_ch < 1 || HW < 1) return FRCNN_ERR_INVALID;
+    hipLaunchKernelGGL(softmax_channels_kernel, dim3(frcnn_cdiv(HW, 256)), dim3(256), 0, (hipStream_t)stream, score, n_ch, HW, prob);
+    return frcnn_launch_status();
+}
+
 int frcnn_rpn_heads_f32(const float *h, int Cmid, int H, int W, int A, const float *w_packed, const float *b_packed, float *raw,
                         float *cls_prob, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;

@@ -1,0 +1,287 @@
+// conv_bf16.hip -- the convolution stack in bf16 on the matrix cores (BASELINE config 3: "bf16 convs / fp32 RoI").
+//
+// Same reference interface as conv.hip (L.Convolution2D(ci, co, 3, 1, 1) + F.relu, /root/reference/models/vgg16.py:39-68;
+// rpn_conv_3x3 and the two 1x1 heads, region_proposal_network.py:53-57), different arithmetic: operands rounded to bf16
+// (round to nearest even), products accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).
+//
+// Layout.  A bf16 MFMA lane supplies EIGHT consecutive k-values of one row/column, so the contraction index must be
+// contiguous in memory: activations are channel-last (H, W, C) bf16 and the weights are packed [tap][cout][cin] bf16,
+// with channel counts padded to a multiple of 16; k = (tap, cin).  MFMA A = weights (row = cout), B = activations
+// (column = pixel): lane l of a B fragment reads 16 contiguous bytes -- channels 8*(l>>5)..+7 of pixel l&31 -- and
+// register r of the D fragment holds cout (r&3)+8*(r>>2)+4*(l>>5) of pixel l&31, i.e. four consecutive couts of one pixel:
+// one 8-byte channel-last store per register quad.  The last layer of a bf16 chain can instead write fp32 NCHW
+// (out_mode 1), which is what RoI pooling, the 18-way softmax and the proposal kernels consume.
+//
+// A workgroup (4 waves = 2 cout blocks x 2 row pairs) owns 64 couts x 4 rows x 32 px.  Per 16-channel K-chunk it stages the
+// 6 x 34 pixel halo (32 B per pixel) and the 9 x 64 weight rows (32 B per row) in LDS -- pitch 48 B, so the
+// ds_read_b128 fragment reads of any 16-lane group fall on 16 distinct 16-byte bank slots (conflict-free) -- register
+// staged and double buffered exactly like the fp32 kernel, global reads through buffer descriptors (padding = out of
+// range = 0).  At bf16 rates this kernel is bound by LDS and L2 traffic, not by the matrix cores: 3 fragment reads feed 2
+// MFMAs (32 cycles each).
+#include "frcnn_common.h"
+#include <frcnn_buffer.h>   // angle brackets: shadowed by the test emulator
+#include <frcnn_intrin.h>
+
+namespace {
+
+constexpr int kCK = 16;                 // channels per K-chunk = the MFMA's k extent
+constexpr int kPitchB = 48;             // LDS bytes per (pixel | weight row): 32 B of data + 16 B pad
+
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);        // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                                  // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+
+template <int KS>
+__global__ void __launch_bounds__(256)
+conv_mfma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
+                      int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles) {
+    constexpr int TAPS = KS * KS, PAD = KS / 2;
+    constexpr int BROWS = 4, BCO = 64;
+    constexpr int HR = BROWS + KS - 1, HPX = 32 + KS - 1;
+    constexpr int HALO_V = HR * HPX * 2;            // 16-byte vectors of activations per chunk (2 per pixel)
+    constexpr int W_V = TAPS * BCO * 2;             // 16-byte vectors of weights per chunk (2 per row)
+    constexpr int HIT = (HALO_V + 255) / 256, WIT = (W_V + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char in_lds[2][HR * HPX * kPitchB];
+    __shared__ __attribute__((aligned(16))) unsigned char w_lds[2][TAPS * BCO * kPitchB];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave & 1, wrow = wave >> 1;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int tile = blockIdx.x;
+    const int tx = tile % xtiles, ty = (tile / xtiles) % ytiles, cot = tile / (xtiles * ytiles);
+    const int x0 = tx * 32, y0 = ty * BROWS, co0 = cot * BCO;
+    const int nchunks = CinP / kCK;
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)H * W * CinP * 2));
+    const frcnn_buf_t wbuf = frcnn_make_buf(wp, (uint32_t)((size_t)TAPS * CoutP * CinP * 2));
+
+    // byte offsets (chunk 0) of this thread's staging vectors; chunk c adds c * 32 bytes to both
+    uint32_t hoff[HIT], woff[WIT];
+#pragma unroll
+    for (int q = 0; q < HIT; ++q) {
+        const int v = tid + q * 256;
+        const int pix = v >> 1, half = v & 1;
+        const int hr = pix / HPX, hx = pix - hr * HPX;
+        const int gy = y0 - PAD + hr, gx = x0 - PAD + hx;
+        const bool inside = v < HALO_V && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        hoff[q] = inside ? (uint32_t)(((size_t)gy * W + gx) * CinP * 2 + half * 16) : kBufOob;
+    }
+#pragma unroll
+    for (int q = 0; q < WIT; ++q) {
+        const int v = tid + q * 256;
+        const int row = v >> 1, half = v & 1;                    // row = tap * BCO + co_local
+        const int tap = row / BCO, col = row - tap * BCO;
+        woff[q] = (v < W_V && co0 + col < CoutP) ? (uint32_t)((((size_t)tap * CoutP + co0 + col) * CinP) * 2 + half * 16) : kBufOob;
+    }
+    float4 hreg[HIT], wreg[WIT];
+    auto fetch = [&](int chunk) {
+        const uint32_t cb = (uint32_t)chunk * (kCK * 2);
+#pragma unroll
+        for (int q = 0; q < HIT; ++q) hreg[q] = frcnn_buf_load_f32x4(xbuf, hoff[q] + cb);
+#pragma unroll
+        for (int q = 0; q < WIT; ++q) wreg[q] = frcnn_buf_load_f32x4(wbuf, woff[q] + cb);
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < HIT; ++q) {
+            const int v = tid + q * 256;
+            if (v < HALO_V) *reinterpret_cast<float4 *>(&in_lds[buf][(v >> 1) * kPitchB + (v & 1) * 16]) = hreg[q];
+        }
+#pragma unroll
+        for (int q = 0; q < WIT; ++q) {
+            const int v = tid + q * 256;
+            if (v < W_V) *reinterpret_cast<float4 *>(&w_lds[buf][(v >> 1) * kPitchB + (v & 1) * 16]) = wreg[q];
+        }
+    };
+
+    frcnn_f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    fetch(0);
+    stage(0);
+    __syncthreads();
+    int cur = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        if (more) fetch(chunk + 1);
+        const unsigned char *wl = &w_lds[cur][(wco * 32 + l31) * kPitchB + khalf * 16];
+        const unsigned char *il = &in_lds[cur][((wrow * 2) * HPX + l31) * kPitchB + khalf * 16];
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / KS, kx = tap % KS;
+            const uint4 a = *reinterpret_cast<const uint4 *>(wl + tap * BCO * kPitchB);
+            const uint4 b0 = *reinterpret_cast<const uint4 *>(il + ((ky)*HPX + kx) * kPitchB);
+            const uint4 b1 = *reinterpret_cast<const uint4 *>(il + ((ky + 1) * HPX + kx) * kPitchB);
+            acc[0] = frcnn_mfma_32x32x16_bf16(a, b0, acc[0]);
+            acc[1] = frcnn_mfma_32x32x16_bf16(a, b1, acc[1]);
+        }
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // epilogue: register r of lane l = cout (r&3) + 8*(r>>2) + 4*khalf of pixel l31
+    const int px = x0 + l31;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int py = y0 + wrow * 2 + j;
+        if (px >= W || py >= H) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int co = co0 + wco * 32 + 8 * g + 4 * khalf;       // first of four consecutive couts
+            float v[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                v[t] = acc[j][4 * g + t] + (co + t < Cout ? bias[co + t] : 0.0f);
+                if (relu) v[t] = fmaxf(v[t], 0.0f);
+            }
+            if (out_mode == 0) {                                     // bf16 channel-last, CoutP channels per pixel
+                if (co < CoutP) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(y) + ((size_t)py * W + px) * CoutP + co) = pk;
+                }
+            } else {                                                 // fp32 NCHW
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (co + t < Cout) reinterpret_cast<float *>(y)[(size_t)(co + t) * H * W + (size_t)py * W + px] = v[t];
+            }
+        }
+    }
+}
+
+// (Cout, Cin, k, k) fp32 -> [tap][CoutP][CinP] bf16, zero padded
+__global__ void __launch_bounds__(256)
+pack_w_bf16_kernel(const float *__restrict__ w, int Cout, int Cin, int taps, int CoutP, int CinP, uint16_t *__restrict__ wp) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)taps * CoutP * CinP;
+    if (i >= total) return;
+    const int ci = (int)(i % CinP), co = (int)((i / CinP) % CoutP), tap = (int)(i / ((size_t)CinP * CoutP));
+    wp[i] = (co < Cout && ci < Cin) ? f32_to_bf16(w[((size_t)co * Cin + ci) * taps + tap]) : (uint16_t)0;
+}
+
+// (C,H,W) fp32 -> (H,W,CP) bf16, channels C..CP-1 zero
+__global__ void __launch_bounds__(256)
+nchw_to_nhwc_bf16_kernel(const float *__restrict__ x, int C, int HW, int CP, uint16_t *__restrict__ y) {
+    const size_t total = (size_t)HW * CP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % CP);
+        const size_t p = i / CP;
+        y[i] = c < C ? f32_to_bf16(x[(size_t)c * HW + p]) : (uint16_t)0;
+    }
+}
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// F.MaxPooling2D(2, 2), cover_all, channel-last bf16: one thread = one output pixel x 8 channels (16-byte vectors)
+__global__ void __launch_bounds__(256)
+maxpool2x2_bf16_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ y, int C, int H, int W, int OH, int OW) {
+    const int cv = C / 8;
+    const size_t total = (size_t)OH * OW * cv;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c8 = (int)(i % cv), ow = (int)((i / cv) % OW), oh = (int)(i / ((size_t)cv * OW));
+        const bool hasx = 2 * ow + 1 < W, hasy = 2 * oh + 1 < H;
+        const uint16_t *p = x + (((size_t)(2 * oh) * W + 2 * ow) * C + c8 * 8);
+        uint4 q[4];
+        q[0] = *reinterpret_cast<const uint4 *>(p);
+        q[1] = hasx ? *reinterpret_cast<const uint4 *>(p + C) : q[0];
+        q[2] = hasy ? *reinterpret_cast<const uint4 *>(p + (size_t)W * C) : q[0];
+        q[3] = (hasx && hasy) ? *reinterpret_cast<const uint4 *>(p + (size_t)W * C + C) : q[0];
+        uint32_t out[4];
+        const uint32_t *w0 = reinterpret_cast<const uint32_t *>(&q[0]), *w1 = reinterpret_cast<const uint32_t *>(&q[1]);
+        const uint32_t *w2 = reinterpret_cast<const uint32_t *>(&q[2]), *w3 = reinterpret_cast<const uint32_t *>(&q[3]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            uint32_t r = 0;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int sh = 16 * hh;
+                const float a = bf16_to_f32((uint16_t)(w0[t] >> sh)), b = bf16_to_f32((uint16_t)(w1[t] >> sh));
+                const float c = bf16_to_f32((uint16_t)(w2[t] >> sh)), d = bf16_to_f32((uint16_t)(w3[t] >> sh));
+                const float m = fmaxf(fmaxf(a, b), fmaxf(c, d));
+                r |= ((__float_as_uint(m) >> 16) & 0xffffu) << sh;          // a maximum of bf16 values is a bf16 value: exact
+            }
+            out[t] = r;
+        }
+        *reinterpret_cast<uint4 *>(y + (((size_t)oh * OW + ow) * C + c8 * 8)) = make_uint4(out[0], out[1], out[2], out[3]);
+    }
+}
+
+// (H,W,CP) bf16 -> (C,H,W) fp32 through a 64x65 LDS tile (both sides coalesced)
+__global__ void __launch_bounds__(256)
+nhwc_bf16_to_nchw_kernel(const uint16_t *__restrict__ x, int C, int HW, int CP, float *__restrict__ y) {
+    __shared__ float tile[64][65];
+    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int p = p0 + i, c = c0 + tx;
+        tile[i][tx] = (p < HW && c < C) ? bf16_to_f32(x[(size_t)p * CP + c]) : 0.0f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, p = p0 + tx;
+        if (c < C && p < HW) y[(size_t)c * HW + p] = tile[tx][i];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int frcnn_bf16_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, void *stream) {
+    if (!x || !y || C < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    const int CP = (C + 15) / 16 * 16;
+    hipLaunchKernelGGL(nhwc_bf16_to_nchw_kernel, dim3(frcnn_cdiv(H * W, 64), frcnn_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, C, H * W, CP, y);
+    return frcnn_launch_status();
+}
+
+int frcnn_bf16_padded_channels(int c) { return (c + 15) / 16 * 16; }
+
+int frcnn_bf16_pack_conv_w(const float *w, int Cout, int Cin, int ksize, uint16_t *w_packed, void *stream) {
+    if (!w || !w_packed || Cout < 1 || Cin < 1 || (ksize != 1 && ksize != 3)) return FRCNN_ERR_INVALID;
+    const int CoutP = frcnn_bf16_padded_channels(Cout), CinP = frcnn_bf16_padded_channels(Cin), taps = ksize * ksize;
+    const size_t total = (size_t)taps * CoutP * CinP;
+    hipLaunchKernelGGL(pack_w_bf16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, taps, CoutP,
+                       CinP, w_packed);
+    return frcnn_launch_status();
+}
+
+int frcnn_bf16_from_nchw_f32(const float *x, int C, int H, int W, uint16_t *y, void *stream) {
+    if (!x || !y || C < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    const int CP = frcnn_bf16_padded_channels(C);
+    const size_t total = (size_t)H * W * CP;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(nchw_to_nhwc_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, C, H * W, CP, y);
+    return frcnn_launch_status();
+}
+
+int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H, int W, int ksize, int relu,
+                    int out_mode, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    if ((ksize != 1 && ksize != 3) || (out_mode != 0 && out_mode != 1)) return FRCNN_ERR_INVALID;
+    const int CinP = frcnn_bf16_padded_channels(Cin), CoutP = frcnn_bf16_padded_channels(Cout);
+    if ((size_t)H * W * CinP * 2 >= (1ull << 31) || (size_t)ksize * ksize * CoutP * CinP * 2 >= (1ull << 31)) return FRCNN_ERR_INVALID;
+    const int xtiles = frcnn_cdiv(W, 32), ytiles = frcnn_cdiv(H, 4), cotiles = frcnn_cdiv(CoutP, 64);
+    const dim3 grid(xtiles * ytiles * cotiles), blk(256);
+    if (ksize == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3>), grid, blk, 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<1>), grid, blk, 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
+    return frcnn_launch_status();
+}
+
+int frcnn_maxpool2x2_bf16(const uint16_t *x, uint16_t *y, int C, int H, int W, void *stream) {
+    if (!x || !y || C < 16 || (C % 16) != 0 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+    const size_t total = (size_t)OH * OW * (C / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(maxpool2x2_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, C, H, W, OH, OW);
+    return frcnn_launch_status();
+}
+
+}  // extern "C"

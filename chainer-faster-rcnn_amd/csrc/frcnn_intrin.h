@@ -10,3 +10,12 @@ __device__ __forceinline__ float frcnn_max_f32(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+
+// v_mfma_f32_32x32x16_bf16: D(32x32 f32) += A(32x16 bf16) * B(16x32 bf16).  Lane l supplies A[i = l&31][k = 8*(l>>5) .. +7] and
+// B[k = 8*(l>>5) .. +7][j = l&31], eight bf16 each = one uint4 (element t in the low/high half of word t/2); D uses the standard
+// 32x32 map (register r of lane l = row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31).
+typedef float frcnn_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ frcnn_f32x16 frcnn_mfma_32x32x16_bf16(uint4 a, uint4 b, frcnn_f32x16 c) {
+    typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+}

@@ -36,11 +36,15 @@ class FasterRCNN(object):
     type_check_enable = int(os.environ.get('CHAINER_TYPE_CHECK', '1')) != 0
 
     def __init__(self, trunk_class=VGG16Prev, rpn_in_ch=512, rpn_mid_ch=512, feat_stride=16, anchor_ratios=(0.5, 1, 2),
-                 anchor_scales=(8, 16, 32), num_classes=21, loss_lambda=1, rpn_delta=3, rcnn_delta=1, runtime=None):
+                 anchor_scales=(8, 16, 32), num_classes=21, loss_lambda=1, rpn_delta=3, rcnn_delta=1, runtime=None,
+                 conv_dtype="f32"):
+        """conv_dtype: "f32" = BASELINE config 2 (fp32 everywhere); "bf16" = config 3 (trunk + RPN convolutions in bf16 on
+        v_mfma_f32_32x32x16_bf16, RoI pooling / proposals / head in fp32)."""
         self.rt = runtime or default_runtime()
-        self.trunk = trunk_class(runtime=self.rt)
+        self.conv_dtype = conv_dtype
+        self.trunk = trunk_class(runtime=self.rt, conv_dtype=conv_dtype) if conv_dtype != "f32" else trunk_class(runtime=self.rt)
         self.RPN = RegionProposalNetwork(rpn_in_ch, rpn_mid_ch, feat_stride, anchor_ratios, anchor_scales, num_classes,
-                                         loss_lambda, rpn_delta, runtime=self.rt)
+                                         loss_lambda, rpn_delta, runtime=self.rt, conv_dtype=conv_dtype)
         self.fc6, self.fc7 = Linear(self.rt), Linear(self.rt)
         self.cls_score, self.bbox_pred = Linear(self.rt), Linear(self.rt)
         self._feat_stride = feat_stride

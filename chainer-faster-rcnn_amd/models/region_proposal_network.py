@@ -15,11 +15,12 @@ class RegionProposalNetwork(object):
     type_check_enable = int(os.environ.get('CHAINER_TYPE_CHECK', '1')) != 0
 
     def __init__(self, in_ch=512, mid_ch=512, feat_stride=16, anchor_ratios=(0.5, 1, 2), anchor_scales=(8, 16, 32),
-                 num_classes=21, loss_lambda=1., delta=3, runtime=None):
+                 num_classes=21, loss_lambda=1., delta=3, runtime=None, conv_dtype="f32"):
         self.rt = runtime or default_runtime()
+        self.conv_dtype = conv_dtype
         self.n_anchors = len(anchor_ratios) * len(anchor_scales)
         self.mid_ch = mid_ch
-        self.rpn_conv_3x3 = Conv3x3(self.rt, in_ch, mid_ch)
+        self.rpn_conv_3x3 = Conv3x3(self.rt, in_ch, mid_ch, conv_dtype)
         self.rpn_cls_score = dict(W=None, b=None)       # (2A, mid, 1, 1)
         self.rpn_bbox_pred = dict(W=None, b=None)       # (4A, mid, 1, 1)
         self.proposal_layer = ProposalLayer(feat_stride, anchor_ratios, anchor_scales, runtime=self.rt)
@@ -47,6 +48,11 @@ class RegionProposalNetwork(object):
             store["b"] = rt.asarray(np.ascontiguousarray(params[prefix + name + "/b"], dtype=np.float32), "f32")
         self._heads_packed = rt.rpn_heads_pack(self.rpn_cls_score["W"], self.rpn_cls_score["b"],
                                                self.rpn_bbox_pred["W"], self.rpn_bbox_pred["b"])
+        if self.conv_dtype == "bf16":                   # the two 1x1 heads as ONE bf16 1x1 convolution: cls (2A) rows then bbox (4A) rows
+            W = np.concatenate([np.asarray(params[prefix + n + "/W"], dtype=np.float32).reshape(-1, self.mid_ch)
+                                for n in ("rpn_cls_score", "rpn_bbox_pred")], 0)
+            b = np.concatenate([np.asarray(params[prefix + n + "/b"], dtype=np.float32) for n in ("rpn_cls_score", "rpn_bbox_pred")], 0)
+            self._heads_bf16 = (rt.bf16_pack_conv_w(rt.asarray(np.ascontiguousarray(W[:, :, None, None]), "f32"), 1), rt.asarray(b, "f32"))
 
     def _check_data_type_forward(self, x, img_info, gt_boxes):
         assert x.shape[0] == 1
@@ -59,10 +65,27 @@ class RegionProposalNetwork(object):
 
     def heads(self, x, want_score=True, timer=None):
         """(h, rpn_cls_score, rpn_cls_prob, rpn_bbox_pred) -- region_proposal_network.py:117-120."""
+        if self.conv_dtype == "bf16":
+            return self._heads_bf16_path(self.rt.asarray(unwrap(x), "f32"), timer)
         h = self.rpn_conv_3x3(self.rt.asarray(unwrap(x), "f32"), relu=True)
         if timer:
             timer.mark("rpn_conv_3x3")
         score, prob, bbox = self.rt.rpn_heads(h, self._heads_packed)
+        if timer:
+            timer.mark("rpn_heads")
+        return h, score, prob, bbox
+
+    def _heads_bf16_path(self, x, timer):
+        """x = fp32 NCHW feature map whose values are bf16-representable (it came out of the bf16 trunk): back to channel-last
+        bf16 (exact), rpn_conv_3x3 in bf16, both heads as one bf16 1x1 convolution writing fp32 NCHW, softmax in fp32."""
+        rt, A = self.rt, self.n_anchors
+        h = self.rpn_conv_3x3.bf16(rt.bf16_from_nchw(x), relu=True)
+        if timer:
+            timer.mark("rpn_conv_3x3")
+        wb, bb = self._heads_bf16
+        raw = rt.conv_bf16(h, wb, bb, self.mid_ch, 6 * A, 1, relu=False, out_f32_nchw=True)       # (1, 6A, H, W) fp32
+        score, bbox = raw[:, :2 * A], raw[:, 2 * A:]
+        prob = rt.softmax_channels(score[0])
         if timer:
             timer.mark("rpn_heads")
         return h, score, prob, bbox

@@ -18,9 +18,9 @@ LAYERS = [
 class Conv3x3(object):
     """L.Convolution2D(ci, co, 3, 1, 1): holds W (co,ci,3,3) + b on device and the kernel's packed copy."""
 
-    def __init__(self, rt, cin, cout):
-        self.rt, self.cin, self.cout = rt, cin, cout
-        self.W = self.b = self.Wp = None
+    def __init__(self, rt, cin, cout, conv_dtype="f32"):
+        self.rt, self.cin, self.cout, self.conv_dtype = rt, cin, cout, conv_dtype
+        self.W = self.b = self.Wp = self.Wb = None
 
     def set(self, W, b):
         rt = self.rt
@@ -29,20 +29,27 @@ class Conv3x3(object):
         self.W = rt.asarray(W, "f32")
         self.b = rt.asarray(np.ascontiguousarray(b, dtype=np.float32) if isinstance(b, np.ndarray) else b, "f32")
         self.Wp = rt.pack_conv3x3_w(self.W)
+        if self.conv_dtype == "bf16":
+            self.Wb = rt.bf16_pack_conv_w(self.W, 3)          # [tap][CoutP][CinP] bf16 (csrc/conv_bf16.hip)
 
     def __call__(self, x, relu=True, out=None, cfg=-1):
         return self.rt.conv3x3(x, self.Wp, self.b, relu=relu, out=out, cfg=cfg)
 
+    def bf16(self, x_nhwc, relu=True, out_f32_nchw=False):
+        """x (H,W,CinP) bf16 channel-last -> (H,W,CoutP) bf16 (or fp32 NCHW)."""
+        return self.rt.conv_bf16(x_nhwc, self.Wb, self.b, self.cin, self.cout, 3, relu=relu, out_f32_nchw=out_f32_nchw)
+
 
 class VGG16Prev(object):
-    def __init__(self, train=False, runtime=None, layers=None):
+    def __init__(self, train=False, runtime=None, layers=None, conv_dtype="f32"):
         self.rt = runtime or default_runtime()
         self.train = train
+        self.conv_dtype = conv_dtype                                      # "f32" (BASELINE config 2) or "bf16" (config 3)
         self.layers = list(layers) if layers is not None else LAYERS     # (tests build narrow / shallow variants)
         self.links = {}
         for l in self.layers:
             if l != "pool":
-                self.links[l[0]] = Conv3x3(self.rt, l[1], l[2])
+                self.links[l[0]] = Conv3x3(self.rt, l[1], l[2], conv_dtype)
                 setattr(self, l[0], self.links[l[0]])
 
     def load_params(self, params, prefix="trunk/"):
@@ -58,6 +65,8 @@ class VGG16Prev(object):
         rt = self.rt
         h = rt.asarray(unwrap(x), "f32")
         assert h.ndim == 4 and int(h.shape[0]) == 1, "batch size 1 (models/faster_rcnn.py:77)"
+        if self.conv_dtype == "bf16":
+            return self._call_bf16(h, timer)
         n_pool = 0
         for l in self.layers:
             if l == "pool":
@@ -70,6 +79,28 @@ class VGG16Prev(object):
                 if timer:
                     timer.mark(l[0])
         return h
+
+
+    def _call_bf16(self, x, timer):
+        """bf16 chain: fp32 NCHW image -> channel-last bf16 -> 13 bf16 convs / 4 pools -> conv5_3 back as fp32 NCHW."""
+        rt = self.rt
+        h = rt.bf16_from_nchw(x)
+        n_pool, cout = 0, int(x.shape[1])
+        for l in self.layers:
+            if l == "pool":
+                h = rt.maxpool2x2_bf16(h)
+                n_pool += 1
+                if timer:
+                    timer.mark("pool%d" % n_pool)
+            else:
+                h = self.links[l[0]].bf16(h, relu=True)
+                cout = l[2]
+                if timer:
+                    timer.mark(l[0])
+        feat = rt.bf16_to_nchw(h, cout)
+        if timer:
+            timer.mark("to_nchw")
+        return feat
 
 
 VGG16 = VGG16Prev   # the reference's default trunk_class needs a caffemodel download; same network (SURVEY 8a-2)

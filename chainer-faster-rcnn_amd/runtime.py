@@ -9,7 +9,7 @@ import numpy as np
 
 from . import _lib
 
-_NP = {"f32": np.float32, "i32": np.int32, "u8": np.uint8, "f64": np.float64, "i64": np.int64}
+_NP = {"f32": np.float32, "i32": np.int32, "u8": np.uint8, "f64": np.float64, "i64": np.int64, "i16": np.int16}
 
 
 class TorchDeviceMemory(object):
@@ -22,7 +22,7 @@ class TorchDeviceMemory(object):
         self.torch = torch
         self.device = torch.device(device)
         self._dt = {"f32": torch.float32, "i32": torch.int32, "u8": torch.uint8, "f64": torch.float64,
-                    "i64": torch.int64}
+                    "i64": torch.int64, "i16": torch.int16}
 
     def empty(self, shape, dtype="f32"):
         return self.torch.empty(shape, dtype=self._dt[dtype], device=self.device)
@@ -293,6 +293,56 @@ class Runtime(object):
         _lib.check(L.frcnn_conv_f32_ex(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(mask), m.ptr(y), ci, co, H, W, int(ksize),
                                        int(act), m.ptr(ws), ws.shape[0], m.stream()), "frcnn_conv_f32_ex")
         return y
+
+    # ------------------------------------------------------------------ bf16 convolution stack (raw bf16 bits live in int16 arrays)
+    def bf16_pad(self, c):
+        return (int(c) + 15) // 16 * 16
+
+    def bf16_pack_conv_w(self, w, ksize=3):
+        m, L = self.mem, self.lib
+        co, ci = int(w.shape[0]), int(w.shape[1])
+        wp = m.empty((ksize * ksize, self.bf16_pad(co), self.bf16_pad(ci)), "i16")
+        _lib.check(L.frcnn_bf16_pack_conv_w(m.ptr(w), co, ci, int(ksize), m.ptr(wp), m.stream()), "frcnn_bf16_pack_conv_w")
+        return wp
+
+    def bf16_from_nchw(self, x):
+        m, L = self.mem, self.lib
+        C, H, W = [int(v) for v in x.shape[-3:]]
+        y = m.empty((H, W, self.bf16_pad(C)), "i16")
+        _lib.check(L.frcnn_bf16_from_nchw_f32(m.ptr(x), C, H, W, m.ptr(y), m.stream()), "frcnn_bf16_from_nchw_f32")
+        return y
+
+    def bf16_to_nchw(self, x, C):
+        m, L = self.mem, self.lib
+        H, W = int(x.shape[0]), int(x.shape[1])
+        y = m.empty((1, int(C), H, W), "f32")
+        _lib.check(L.frcnn_bf16_to_nchw_f32(m.ptr(x), int(C), H, W, m.ptr(y), m.stream()), "frcnn_bf16_to_nchw_f32")
+        return y
+
+    def conv_bf16(self, x, w_packed, bias, cin, cout, ksize=3, relu=True, out_f32_nchw=False):
+        """x (H,W,CinP) bf16 -> (H,W,CoutP) bf16, or (1,Cout,H,W) fp32 when out_f32_nchw."""
+        m, L = self.mem, self.lib
+        H, W = int(x.shape[0]), int(x.shape[1])
+        assert int(x.shape[2]) == self.bf16_pad(cin) and int(w_packed.shape[2]) == self.bf16_pad(cin)
+        y = m.empty((1, int(cout), H, W), "f32") if out_f32_nchw else m.empty((H, W, self.bf16_pad(cout)), "i16")
+        _lib.check(L.frcnn_conv_bf16(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(y), int(cin), int(cout), H, W, int(ksize),
+                                     int(bool(relu)), int(bool(out_f32_nchw)), m.stream()), "frcnn_conv_bf16")
+        return y
+
+    def maxpool2x2_bf16(self, x):
+        m, L = self.mem, self.lib
+        H, W, C = [int(v) for v in x.shape]
+        y = m.empty(((H + 1) // 2, (W + 1) // 2, C), "i16")
+        _lib.check(L.frcnn_maxpool2x2_bf16(m.ptr(x), m.ptr(y), C, H, W, m.stream()), "frcnn_maxpool2x2_bf16")
+        return y
+
+    def softmax_channels(self, score):
+        """(n_ch, H, W) fp32 -> softmax over the channel axis."""
+        m, L = self.mem, self.lib
+        n_ch, H, W = [int(v) for v in score.shape[-3:]]
+        prob = m.empty((1, n_ch, H, W), "f32")
+        _lib.check(L.frcnn_softmax_channels_f32(m.ptr(score), n_ch, H * W, m.ptr(prob), m.stream()), "frcnn_softmax_channels_f32")
+        return prob
 
     # ------------------------------------------------------------------ ResNet trunk pieces
     def im2col7x7s2(self, x, Kp):

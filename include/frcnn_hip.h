@@ -164,6 +164,23 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
                       int Cout, int H, int W, int ksize, int act, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* ---- bf16 convolution stack (BASELINE config 3: bf16 convs / fp32 RoI) -----------------------------------
+ * Same reference interface as the fp32 stack (L.Convolution2D + F.relu, F.MaxPooling2D: models/vgg16.py:39-68,
+ * region_proposal_network.py:53-57); operands rounded to bf16 (nearest even), fp32 accumulation on
+ * v_mfma_f32_32x32x16_bf16.  Activations are channel-last (H,W,CP) bf16, CP = frcnn_bf16_padded_channels(C) (multiple
+ * of 16, padding channels zero); weights packed [tap][CoutP][CinP] bf16 by frcnn_bf16_pack_conv_w from Chainer's
+ * (Cout,Cin,k,k) fp32.  out_mode 0: y = (H,W,CoutP) bf16; out_mode 1: y = (Cout,H,W) fp32 NCHW (what RoI pooling, the
+ * 18-way softmax and the proposal kernels consume).  uint16_t = raw bf16 bits. */
+int frcnn_bf16_padded_channels(int c);
+int frcnn_bf16_pack_conv_w(const float *w, int Cout, int Cin, int ksize, uint16_t *w_packed, void *stream);
+int frcnn_bf16_from_nchw_f32(const float *x, int C, int H, int W, uint16_t *y, void *stream);
+int frcnn_bf16_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, void *stream);
+int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
+                    int W, int ksize, int relu, int out_mode, void *stream);
+int frcnn_maxpool2x2_bf16(const uint16_t *x, uint16_t *y, int C, int H, int W, void *stream);
+/* softmax over the channel axis of a (n_ch, H*W) fp32 map: the reference's F.softmax(rpn_cls_score) (region_proposal_network.py:119) */
+int frcnn_softmax_channels_f32(const float *score, int n_ch, int HW, float *prob, void *stream);
+
 /* ---- ResNet trunk pieces (models/resnet.py -> chainer ResNetLayers) ------------------
  * frcnn_conv_f32_ex with act = 3 is the bottleneck tail: y = relu(conv + bias + residual), residual passed as `mask`.
  * frcnn_im2col7x7s2_f32: the 7x7 / stride 2 / pad 3 stem as an explicit im2col (Kp >= Cin*49 rows, zero padded) so that

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 
-_NP = {"f32": np.float32, "i32": np.int32, "u8": np.uint8, "f64": np.float64, "i64": np.int64}
+_NP = {"f32": np.float32, "i32": np.int32, "u8": np.uint8, "f64": np.float64, "i64": np.int64, "i16": np.int16}
 
 
 class HostMemory(object):

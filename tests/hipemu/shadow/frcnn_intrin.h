@@ -2,3 +2,26 @@
 #pragma once
 #include <hip/hip_runtime.h>
 static inline float frcnn_max_f32(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+
+typedef float frcnn_f32x16 __attribute__((ext_vector_type(16)));
+static inline float hipemu_bf16_to_f32(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+__attribute__((noinline)) static frcnn_f32x16 frcnn_mfma_32x32x16_bf16(uint4 a, uint4 b, frcnn_f32x16 c) {
+    unsigned short ab[16];
+    memcpy(ab, &a, 16);
+    memcpy(ab + 8, &b, 16);
+    auto e = hipemu::wave_exchange(ab, sizeof(ab), HIPEMU_SITE());
+    if (e.present != ~0ull) { fprintf(stderr, "hipemu: MFMA with a partial wave\n"); abort(); }
+    const int l = hipemu::G().cur->lane, j = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 16; ++k) {
+            unsigned short av, bv;
+            memcpy(&av, e.vals[i + 32 * (k >> 3)] + 2 * (k & 7), 2);
+            memcpy(&bv, e.vals[j + 32 * (k >> 3)] + 16 + 2 * (k & 7), 2);
+            acc += hipemu_bf16_to_f32(av) * hipemu_bf16_to_f32(bv);
+        }
+        c[r] = acc;
+    }
+    return c;
+}

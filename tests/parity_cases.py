@@ -338,3 +338,74 @@ def check_resnet_pieces(rt, seed=0):
     cols = host(rt, rt.im2col7x7s2(dev(rt, x3), 152))
     want = torch.nn.functional.unfold(torch.from_numpy(x3), 7, padding=3, stride=2).numpy().reshape(1, 147, 11, 15)
     assert np.array_equal(cols[:, :147], want) and not cols[:, 147:].any()
+
+
+# ------------------------------------------------------------------------------------------- bf16 convolution stack
+def to_bf16(a):
+    """float32 -> (the float32 value of its bf16 rounding [nearest even], raw int16 bits)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = ((u + 0x7fff + ((u >> 16) & 1)) >> 16).astype(np.uint32)
+    return (r << 16).view(np.float32), r.astype(np.uint16).view(np.int16)
+
+
+def from_bf16_bits(b):
+    return (b.view(np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def check_conv_bf16(rt, Cin, Cout, H, W, ksize=3, relu=True, seed=0):
+    rs = np.random.RandomState(seed)
+    x = rs.randn(1, Cin, H, W).astype(np.float32)
+    w = (rs.randn(Cout, Cin, ksize, ksize) * np.sqrt(2.0 / (Cin * ksize * ksize))).astype(np.float32)
+    b = (rs.randn(Cout) * 0.1).astype(np.float32)
+    xb, xbits = to_bf16(x)
+    wb, _ = to_bf16(w)
+    xd = rt.bf16_from_nchw(dev(rt, x))
+    cp = rt.bf16_pad(Cin)
+    got_bits = host(rt, xd)
+    assert np.array_equal(got_bits[:, :, :Cin], xbits[0].transpose(1, 2, 0)) and not got_bits[:, :, Cin:].any()    # conversion: exact
+    want = O.conv2d(xb, wb, b, ksize // 2)                       # the kernel's operands exactly; fp32 accumulation
+    if relu:
+        want = O.relu(want)
+    wpk = rt.bf16_pack_conv_w(dev(rt, w), ksize)
+    y32 = host(rt, rt.conv_bf16(xd, wpk, dev(rt, b), Cin, Cout, ksize, relu=relu, out_f32_nchw=True))
+    scale = max(np.abs(want).max(), 1e-6)
+    assert np.abs(y32 - want).max() <= 2e-5 * scale, np.abs(y32 - want).max() / scale           # accumulation order only
+    y16 = host(rt, rt.conv_bf16(xd, wpk, dev(rt, b), Cin, Cout, ksize, relu=relu))
+    got = from_bf16_bits(y16)
+    assert got.shape == (H, W, rt.bf16_pad(Cout)) and not got[:, :, Cout:].any()
+    want_hwc = want[0].transpose(1, 2, 0)
+    assert np.all(np.abs(got[:, :, :Cout] - want_hwc) <= np.abs(want_hwc) * 2.0 ** -8 + 1e-5 * scale)     # one bf16 rounding of the output
+    back = host(rt, rt.bf16_to_nchw(rt.conv_bf16(xd, wpk, dev(rt, b), Cin, Cout, ksize, relu=relu), Cout))
+    assert np.array_equal(back[0], got[:, :, :Cout].transpose(2, 0, 1))
+
+
+def check_maxpool_bf16(rt, C, H, W, seed=0):
+    rs = np.random.RandomState(seed)
+    x = rs.randn(1, C, H, W).astype(np.float32)
+    xb, _ = to_bf16(x)
+    y = host(rt, rt.maxpool2x2_bf16(rt.bf16_from_nchw(dev(rt, x))))
+    want = O.max_pool_2x2(xb)[0].transpose(1, 2, 0)
+    assert np.array_equal(from_bf16_bits(y)[:, :, :C], want)
+
+
+def check_vgg_bf16_forward(rt, im_h, im_w, seed=5):
+    """Config 3 numerics: the bf16-conv pipeline vs the fp32 oracle; bf16 has 8 mantissa bits, so 14 stacked convolutions
+    are compared at 3e-2 of the feature scale, and the downstream fp32 stages exactly given the device's own maps."""
+    from chainer_faster_rcnn_amd import synthetic
+    from chainer_faster_rcnn_amd.models import FasterRCNN
+    params = synthetic.params(seed=1)
+    x = synthetic.image(seed=seed, h=im_h, w=im_w)
+    info = np.array([[im_h, im_w]], dtype=np.int32)
+    model = FasterRCNN(runtime=rt, conv_dtype="bf16")
+    model.load_params(params)
+    out = model.forward_device(rt.mem.from_numpy(x), im_h, im_w, keep=True)
+    feat = host(rt, out["feat"])
+    want = O.vgg16_trunk(params, x)
+    err = np.abs(feat - want).max() / np.abs(want).max()
+    assert err < 3e-2, err
+    n = int(host(rt, out["n_out"])[0])
+    p2, s2 = O.proposal_layer(host(rt, out["rpn_cls_prob"]), host(rt, out["rpn_bbox_pred"]), info, train=False)
+    assert n == len(p2) and np.allclose(host(rt, out["rois"])[:n], p2, rtol=5e-7, atol=1e-4)
+    rois = host(rt, out["rois"])[:n]
+    assert np.array_equal(host(rt, out["pool5"])[:n], O.roi_pooling_2d(feat, np.concatenate([np.zeros((n, 1), np.float32), rois], 1), 7, 7, 1 / 16.))
+    return err

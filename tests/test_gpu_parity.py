@@ -15,7 +15,7 @@ def rt():
 
 
 def test_library_is_the_device_build(rt):
-    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 4
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 5
 
 
 def test_nms_golden(rt):
@@ -231,3 +231,20 @@ def test_faster_rcnn_resnet101_config4(rt):
     cp, pb, _ = O.rcnn_head(params, pool5, rois, info)
     assert np.allclose(rt.mem.to_numpy(out["cls_prob"])[:n], cp, rtol=1e-3, atol=1e-5)
     assert np.allclose(rt.mem.to_numpy(out["pred_boxes"])[:n], pb, rtol=1e-3, atol=1e-2)
+
+
+# ---- bf16 convolution stack (BASELINE config 3: bf16 convs / fp32 RoI)
+@pytest.mark.parametrize("cin,cout,h,w,ks", [(3, 64, 120, 200, 3), (64, 64, 60, 100, 3), (128, 256, 75, 125, 3), (512, 512, 38, 63, 3),
+                                             (512, 54, 38, 63, 1)])
+def test_conv_bf16(rt, cin, cout, h, w, ks):
+    P.check_conv_bf16(rt, cin, cout, h, w, ksize=ks, relu=(ks == 3))
+
+
+def test_maxpool_bf16(rt):
+    P.check_maxpool_bf16(rt, 64, 75, 125)
+    P.check_maxpool_bf16(rt, 128, 300, 500)
+
+
+def test_vgg16_bf16_forward(rt):
+    err = P.check_vgg_bf16_forward(rt, 224, 320)
+    assert err < 3e-2

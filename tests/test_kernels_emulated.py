@@ -124,3 +124,15 @@ def test_resnet_pieces(rt):
 
 def test_resnet_tiny(rt):
     P.check_resnet(rt, blocks=(2, 1, 1, 1), im_h=40, im_w=70)     # one `a` + one `b` block, all four stages, odd sizes
+
+
+# ---- bf16 convolution stack (BASELINE config 3)
+def test_conv_bf16(rt):
+    P.check_conv_bf16(rt, 16, 64, 9, 37)
+    P.check_conv_bf16(rt, 3, 64, 7, 33, seed=1)                    # conv1_1: channels padded 3 -> 16
+    P.check_conv_bf16(rt, 32, 54, 5, 40, ksize=1, relu=False, seed=2)   # the stacked RPN heads: 54 real couts of 64
+
+
+def test_maxpool_bf16(rt):
+    P.check_maxpool_bf16(rt, 16, 7, 9)
+    P.check_maxpool_bf16(rt, 32, 8, 6, seed=1)
