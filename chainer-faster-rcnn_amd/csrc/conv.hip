@@ -209,19 +209,22 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
             const int P = (int)(g_last - g_first + 1), p = (int)(g - g_first);
             // slot 0 = the piece a workgroup starts with, slot 1 = the piece it ends with
             const int my_slot = (it == it_begin) ? 0 : 1;
-            float *mine = partial_ws + ((size_t)g * 2 + my_slot) * ((size_t)NT * FRAG);
+            // Partial accumulators travel as 16-byte vectors: slot layout [FRAG/4][NT] float4, every store / load
+            // instruction of a wave covers 1 KB.  Stores are write-through (sc1), so publishing needs no release fence:
+            // drain, barrier, ticket (cdna_hip_programming.md G16 R1); the last arriver acquires once and reads plainly.
+            const size_t slot_floats = (size_t)NT * FRAG;
+            const frcnn_buf_t pbuf = frcnn_make_buf(partial_ws + ((size_t)g * 2 + my_slot) * slot_floats, (uint32_t)(slot_floats * sizeof(float)));
 #pragma unroll
             for (int i = 0; i < ACO; ++i)
 #pragma unroll
                 for (int j = 0; j < APX; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) mine[(size_t)((i * APX + j) * 16 + r) * NT + tid] = acc[i][j][r];
+                    for (int r4 = 0; r4 < 4; ++r4)
+                        frcnn_buf_store_f32x4_wt(pbuf, (uint32_t)((((i * APX + j) * 4 + r4) * NT + tid) * 16),
+                                                 make_float4(acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]));
             frcnn_drain_vmem();
             __syncthreads();
-            if (tid == 0) {
-                frcnn_release_agent();
-                s_ticket = frcnn_ticket(&tile_counters[tile]);
-            }
+            if (tid == 0) s_ticket = frcnn_ticket(&tile_counters[tile]);
             __syncthreads();
             finish = (s_ticket == P - 1);
             if (finish) {
@@ -239,13 +242,19 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
                 for (int q = 0; q < P; ++q) {
                     const long long b = g_first + q;
                     const int slot = (q == 0 && start_of(b) != t_first) ? 1 : 0;
-                    const float *piece = partial_ws + ((size_t)b * 2 + slot) * ((size_t)NT * FRAG);
+                    const float4 *piece = reinterpret_cast<const float4 *>(partial_ws + ((size_t)b * 2 + slot) * slot_floats);
+                    float4 v[ACO * APX * 4];
+#pragma unroll
+                    for (int e = 0; e < ACO * APX * 4; ++e) v[e] = piece[(size_t)e * NT + tid];       // all loads of a piece in flight
 #pragma unroll
                     for (int i = 0; i < ACO; ++i)
 #pragma unroll
                         for (int j = 0; j < APX; ++j)
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) acc[i][j][r] += piece[(size_t)((i * APX + j) * 16 + r) * NT + tid];
+                            for (int r4 = 0; r4 < 4; ++r4) {
+                                const float4 t = v[(i * APX + j) * 4 + r4];
+                                acc[i][j][4 * r4] += t.x; acc[i][j][4 * r4 + 1] += t.y; acc[i][j][4 * r4 + 2] += t.z; acc[i][j][4 * r4 + 3] += t.w;
+                            }
                 }
             }
         }
@@ -438,15 +447,15 @@ static int launch_conv(const float *x, const float *wp, const float *bias, float
 
 // Chosen from scripts/conv_sweep.py on MI355X (profiles/r01_conv_sweep*.json).  Returns decomposition id + 100 * mode.
 //   conv1_1 (Cin = 3): 4-channel chunks (K = 27 padded to 36, not 72), four workgroups per CU -- output-write bound.
-//   Everything else 64 couts x 32 px wide: 4 rows per workgroup (wave = 32co x 2 rows) as whole tiles while the
-//   layer has at least one full round of them; stream-K once the tile count drops below the number of
-//   workgroup slots (75x125 maps), and stream-K over 2-row tiles for the 38x63 maps, where whole tiles would
-//   leave 20-80 % of the SIMDs idle.
+//   Everything else 64 couts x 32 px wide, wave = 32co x 2 rows (4-row tiles) or 32co x 1 row (2-row tiles for the
+//   38x63 maps).  Whole tiles only while a layer has many rounds of them (conv1_2: 6.25 rounds of the 768 workgroup
+//   slots); otherwise stream-K: with write-through partial tiles the fix-up costs less than the ragged last round
+//   (20 % at 3.1 rounds, 80 % of the SIMDs idle at 0.2 rounds).
 static int pick_conv_config(int Cin, int Cout, int H, int W) {
     if (Cin < 8) return 14;
     const long ntiles = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4) * (Cout / 64);
     const long slots = (long)frcnn_cu_count() * 3;
-    if (ntiles >= slots) return 10;
+    if (ntiles >= 4 * slots) return 10;
     if (2 * ntiles >= slots) return 210;
     return 205;
 }

@@ -23,3 +23,13 @@ __device__ __forceinline__ float4 frcnn_buf_load_f32x4(frcnn_buf_t b, uint32_t b
     const frcnn_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)byte_off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+
+// Write-through (sc1) 16-byte store: the bytes leave this XCD's L2 for memory at once, so another workgroup -- on any
+// XCD -- that acquires AFTER the store has drained (s_waitcnt vmcnt(0)) reads them without the producer running an
+// agent-scope release fence (buffer_wbl2 writes back EVERY dirty line of the XCD's L2: ~3x the cost for tens of KB per
+// workgroup; cdna_hip_programming.md Guideline 16 form R1, MI355X_MICROARCH.md row "publish-large").
+__device__ __forceinline__ void frcnn_buf_store_f32x4_wt(frcnn_buf_t b, uint32_t byte_off, float4 v) {
+    frcnn_u32x4 u;
+    u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(u, b, (int)byte_off, 0, /*aux: sc1*/ 16);
+}

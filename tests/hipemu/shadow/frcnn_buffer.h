@@ -14,3 +14,6 @@ static inline float frcnn_buf_load_f32(frcnn_buf_t b, uint32_t off) {
 static inline float4 frcnn_buf_load_f32x4(frcnn_buf_t b, uint32_t off) {
     return make_float4(frcnn_buf_load_f32(b, off), frcnn_buf_load_f32(b, off + 4), frcnn_buf_load_f32(b, off + 8), frcnn_buf_load_f32(b, off + 12));
 }
+static inline void frcnn_buf_store_f32x4_wt(frcnn_buf_t b, uint32_t off, float4 v) {
+    if ((uint64_t)off + 16 <= b.bytes) memcpy(const_cast<char *>(b.base) + off, &v, 16);
+}
