@@ -53,9 +53,30 @@ row_softmax_kernel(const float *__restrict__ s, int R, int n, float *__restrict_
     for (int c = 0; c < n; ++c) p[(size_t)r * n + c] = expf(row[c] - m) / sum;
 }
 
+// forward.py:50-53: for cls_id in 1..ncls-1: dets = hstack(bbox[:, 4*cls_id:4*cls_id+4], clss[:, cls_id]) -> (ncls-1, R, 5)
+__global__ void __launch_bounds__(256)
+class_dets_kernel(const float *__restrict__ cls_prob, const float *__restrict__ pred_boxes, int R, int ncls, float *__restrict__ dets) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (ncls - 1) * R) return;
+    const int c = i / R + 1, r = i - (c - 1) * R;
+    const float4 b = reinterpret_cast<const float4 *>(pred_boxes)[(size_t)r * ncls + c];
+    float *d = dets + (size_t)i * 5;
+    d[0] = b.x; d[1] = b.y; d[2] = b.z; d[3] = b.w;
+    d[4] = cls_prob[(size_t)r * ncls + c];
+}
+
 }  // namespace
 
 extern "C" {
+
+int frcnn_class_dets(const float *cls_prob, const float *pred_boxes, int R, int ncls, float *dets, void *stream) {
+    if (!cls_prob || !pred_boxes || !dets || R < 0 || ncls < 2) return FRCNN_ERR_INVALID;
+    if (R == 0) return FRCNN_OK;
+    hipLaunchKernelGGL(class_dets_kernel, dim3(frcnn_cdiv((ncls - 1) * R, 256)), dim3(256), 0, (hipStream_t)stream, cls_prob, pred_boxes, R, ncls,
+                       dets);
+    return frcnn_launch_status();
+}
+
 
 int frcnn_bbox_transform_inv(const float *boxes, const float *deltas, int R, int ncls, float *pred_boxes, void *stream) {
     if (!boxes || !deltas || !pred_boxes || R < 0 || ncls < 1) return FRCNN_ERR_INVALID;

@@ -259,6 +259,14 @@ class Runtime(object):
         return pred, prob
 
 
+    def class_dets(self, cls_prob, pred_boxes):
+        """(R,ncls), (R,4*ncls) -> (ncls-1, R, 5) per-class [x1,y1,x2,y2,score] rows (forward.py:50-53)."""
+        m, L = self.mem, self.lib
+        R, ncls = int(cls_prob.shape[0]), int(cls_prob.shape[1])
+        dets = m.empty((ncls - 1, max(R, 1), 5), "f32")
+        _lib.check(L.frcnn_class_dets(m.ptr(cls_prob), m.ptr(pred_boxes), R, ncls, m.ptr(dets), m.stream()), "frcnn_class_dets")
+        return dets[:, :R]
+
     def bbox_transform_inv(self, boxes, deltas):
         m, L = self.mem, self.lib
         R, c4 = int(deltas.shape[0]), int(deltas.shape[1])

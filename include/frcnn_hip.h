@@ -150,6 +150,9 @@ int frcnn_linear_f32(const float *x, const float *w, const float *bias, float *y
  * boxes (R,4), deltas (R,4*ncls) -> pred_boxes (R,4*ncls); cls_score (R,ncls) -> cls_prob (R,ncls). */
 int frcnn_head_decode(const float *boxes, const float *deltas, const float *cls_score, int R, int ncls,
                       int im_h, int im_w, float *pred_boxes, float *cls_prob, void *stream);
+/* forward.py:50-53: per-class detection rows for the 20 per-class NMS problems --
+ * dets (ncls-1, R, 5) = [pred_boxes[:, 4c:4c+4], cls_prob[:, c]] for c = 1..ncls-1; feed frcnn_nms_batched(thresh 0.3). */
+int frcnn_class_dets(const float *cls_prob, const float *pred_boxes, int R, int ncls, float *dets, void *stream);
 /* the three pieces on their own: bbox_transform_inv (bbox_transform.py:41-76), clip_boxes (:79-99, in
  * place on n_boxes x 4 floats), and a row-wise softmax (F.softmax on (R,n)) */
 int frcnn_bbox_transform_inv(const float *boxes, const float *deltas, int R, int ncls, float *pred_boxes,

@@ -409,3 +409,22 @@ def check_vgg_bf16_forward(rt, im_h, im_w, seed=5):
     rois = host(rt, out["rois"])[:n]
     assert np.array_equal(host(rt, out["pool5"])[:n], O.roi_pooling_2d(feat, np.concatenate([np.zeros((n, 1), np.float32), rois], 1), 7, 7, 1 / 16.))
     return err
+
+
+def check_detections(rt, R=300, ncls=21, seed=0):
+    """forward.py:48-58 post-processing: 20 per-class NMS problems (thresh 0.3) + conf cut, batched on the device."""
+    from chainer_faster_rcnn_amd.postprocess import detections
+    rs = np.random.RandomState(seed)
+    xy = rs.uniform(0, 700, (R, 1, 2)) + rs.uniform(-20, 20, (R, ncls, 2))
+    boxes = np.concatenate([xy, xy + rs.uniform(30, 300, (R, ncls, 2))], axis=2).reshape(R, 4 * ncls).astype(np.float32)
+    prob = O.softmax((rs.randn(R, ncls) * 4).astype(np.float32), axis=1)
+    got = detections(dev(rt, prob), dev(rt, boxes), 0.3, 0.5, im_scale=1.6, runtime=rt)
+    total = 0
+    for c in range(1, ncls):
+        d = np.hstack((boxes[:, 4 * c:4 * c + 4], prob[:, c:c + 1])).astype(np.float32)       # forward.py:50-53
+        d = d[O.cpu_nms(d, 0.3)]
+        d = d[d[:, -1] >= 0.5].copy()
+        d[:, :4] /= 1.6
+        assert np.array_equal(got[c], d), c
+        total += len(d)
+    assert total > 0

@@ -15,7 +15,7 @@ def rt():
 
 
 def test_library_is_the_device_build(rt):
-    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 5
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 6
 
 
 def test_nms_golden(rt):
@@ -248,3 +248,7 @@ def test_maxpool_bf16(rt):
 def test_vgg16_bf16_forward(rt):
     err = P.check_vgg_bf16_forward(rt, 224, 320)
     assert err < 3e-2
+
+
+def test_detections_postprocess(rt):
+    P.check_detections(rt, R=300)

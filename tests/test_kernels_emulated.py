@@ -136,3 +136,7 @@ def test_conv_bf16(rt):
 def test_maxpool_bf16(rt):
     P.check_maxpool_bf16(rt, 16, 7, 9)
     P.check_maxpool_bf16(rt, 32, 8, 6, seed=1)
+
+
+def test_detections_postprocess(rt):
+    P.check_detections(rt, R=60)
