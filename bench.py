@@ -197,7 +197,7 @@ def main():
     from chainer_faster_rcnn_amd.models.vgg16 import LAYERS
     rt = pkg.runtime.Runtime(pkg._lib.load(), pkg.runtime.TorchDeviceMemory("cuda:%d" % local_rank))
     params = synthetic.params(seed=1)
-    model = FasterRCNN(runtime=rt, conv_dtype=args.dtype)
+    model = FasterRCNN(runtime=rt, conv_dtype=args.dtype, head_dtype=args.dtype)
     model.load_params(params)
     x_host = synthetic.image(seed=rank, h=IM_H, w=IM_W)          # every rank its own image (1 img / GPU)
     x = rt.mem.from_numpy(x_host)
@@ -259,8 +259,8 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": ("VGG16 inference, 1xMI355X per image, batch 1, 300 proposals post-NMS, fp32 "
                                        "(BASELINE.json configs[1]); 1 image per GPU per step") if args.dtype == "f32" else
-                                      ("VGG16 inference, data-parallel 1 img/GPU, bf16 convs / fp32 RoI + head "
-                                       "(BASELINE.json configs[2])"),
+                                      ("VGG16 inference, data-parallel 1 img/GPU, bf16 convs + bf16 FC head (fp32 accumulate) / fp32 proposals, "
+                                       "RoI pooling, decode (BASELINE.json configs[2])"),
                           "image": "1x3x600x1000", "global_batch": world, "launch": "hipGraph replay" if use_graph else "eager", "parallelism": "dp%d (images sharded, no collective)" % world,
                           "n_rois_last_step": n_rois}}
         if timer:

@@ -285,3 +285,182 @@ int frcnn_maxpool2x2_bf16(const uint16_t *x, uint16_t *y, int C, int H, int W, v
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// Fully connected head in bf16: y(M,N) = act(x(M,K) @ W(N,K)^T + b), operands bf16 (nearest even), fp32 accumulation.
+// Replaces L.Linear + F.relu (/root/reference/models/faster_rcnn.py:33-36,127-134) on the config-3 path: fc6's 411 MB of
+// fp32 weights become 205 MB and the 72 GFLOP of the head run at the bf16 MFMA rate.
+// Both operands are K-contiguous, so a lane's eight consecutive k-values are one 16-byte read: A = x rows, B = W rows,
+// D[m][n] with n on the lanes.  Workgroup = 4 waves along N: tile (32*AM) x 128, K panels of 64 through LDS (pitch 144 B:
+// conflict-free ds_read_b128), register-staged double buffer, split-K partial slabs + the fp32 reduce/bias/ReLU pass.
+namespace {
+
+constexpr int kLBK = 64;            // k per panel
+constexpr int kLPitch = 144;        // bytes per LDS row: 128 B of bf16 + 16 B pad
+
+template <int AM>
+__global__ void __launch_bounds__(256)
+linear_mfma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w, float *__restrict__ part, int M, int N, int K, int k_per_split) {
+    constexpr int BM = 32 * AM, BN = 128;
+    constexpr int XV = BM * (kLBK / 8), WV = BN * (kLBK / 8);          // 16-byte vectors per panel
+    constexpr int XIT = (XV + 255) / 256, WIT = (WV + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char xs[2][BM * kLPitch];
+    __shared__ __attribute__((aligned(16))) unsigned char ws[2][BN * kLPitch];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * k_per_split, k_end = min(K, k_begin + k_per_split);
+    const int nchunks = (k_end - k_begin + kLBK - 1) / kLBK;
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)M * K * 2));
+    const frcnn_buf_t wbuf = frcnn_make_buf(w, (uint32_t)((size_t)N * K * 2));
+    uint32_t xoff[XIT], woff[WIT];
+#pragma unroll
+    for (int q = 0; q < XIT; ++q) {
+        const int v = tid + q * 256, row = v / (kLBK / 8), k8 = v % (kLBK / 8);
+        xoff[q] = (v < XV && m0 + row < M) ? (uint32_t)(((size_t)(m0 + row) * K + k_begin + k8 * 8) * 2) : kBufOob;
+    }
+#pragma unroll
+    for (int q = 0; q < WIT; ++q) {
+        const int v = tid + q * 256, row = v / (kLBK / 8), k8 = v % (kLBK / 8);
+        woff[q] = (v < WV && n0 + row < N) ? (uint32_t)(((size_t)(n0 + row) * K + k_begin + k8 * 8) * 2) : kBufOob;
+    }
+    float4 xreg[XIT], wreg[WIT];
+    auto fetch = [&](int chunk) {
+        // K % 8 == 0 and the split boundaries are multiples of kLBK, so a 16-byte vector is entirely inside or outside [k_begin, k_end)
+        const uint32_t cb = (uint32_t)chunk * (kLBK * 2);
+        const int kb = k_begin + chunk * kLBK;
+#pragma unroll
+        for (int q = 0; q < XIT; ++q) {
+            const int k8 = (tid + q * 256) % (kLBK / 8);
+            xreg[q] = frcnn_buf_load_f32x4(xbuf, (kb + k8 * 8 < k_end) ? xoff[q] + cb : kBufOob);
+        }
+#pragma unroll
+        for (int q = 0; q < WIT; ++q) {
+            const int k8 = (tid + q * 256) % (kLBK / 8);
+            wreg[q] = frcnn_buf_load_f32x4(wbuf, (kb + k8 * 8 < k_end) ? woff[q] + cb : kBufOob);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < XIT; ++q) {
+            const int v = tid + q * 256;
+            if (v < XV) *reinterpret_cast<float4 *>(&xs[buf][(v / (kLBK / 8)) * kLPitch + (v % (kLBK / 8)) * 16]) = xreg[q];
+        }
+#pragma unroll
+        for (int q = 0; q < WIT; ++q) {
+            const int v = tid + q * 256;
+            if (v < WV) *reinterpret_cast<float4 *>(&ws[buf][(v / (kLBK / 8)) * kLPitch + (v % (kLBK / 8)) * 16]) = wreg[q];
+        }
+    };
+    frcnn_f32x16 acc[AM];
+#pragma unroll
+    for (int i = 0; i < AM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    if (nchunks > 0) { fetch(0); stage(0); }
+    __syncthreads();
+    const int l31 = lane & 31, khalf = lane >> 5;
+    int cur = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        const bool more = chunk + 1 < nchunks;
+        if (more) fetch(chunk + 1);
+        const unsigned char *wl = &ws[cur][(wave * 32 + l31) * kLPitch + khalf * 16];
+        const unsigned char *xl = &xs[cur][l31 * kLPitch + khalf * 16];
+#pragma unroll
+        for (int ks = 0; ks < kLBK / 16; ++ks) {
+            const uint4 b = *reinterpret_cast<const uint4 *>(wl + ks * 32);
+#pragma unroll
+            for (int i = 0; i < AM; ++i) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(xl + i * 32 * kLPitch + ks * 32);
+                acc[i] = frcnn_mfma_32x32x16_bf16(a, b, acc[i]);
+            }
+        }
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    float *out = part + (size_t)blockIdx.z * M * N;
+    const int n = n0 + wave * 32 + l31;
+    if (n < N) {
+#pragma unroll
+        for (int i = 0; i < AM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (m < M) out[(size_t)m * N + n] = acc[i][r];
+            }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+linear_reduce_bf16_kernel(const float *__restrict__ part, const float *__restrict__ bias, void *__restrict__ y, int M, int N, int splits, int relu,
+                          int out_bf16) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        for (int s = 0; s < splits; ++s) v += part[(size_t)s * total + i];
+        v += bias[i % N];
+        if (relu) v = fmaxf(v, 0.0f);
+        if (out_bf16) reinterpret_cast<uint16_t *>(y)[i] = f32_to_bf16(v);
+        else reinterpret_cast<float *>(y)[i] = v;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+f32_to_bf16_kernel(const float *__restrict__ x, size_t n, uint16_t *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = f32_to_bf16(x[i]);
+}
+
+struct LinPlan { int am, mblocks, nblocks, splits, k_per_split; };
+static LinPlan plan_linear_bf16(int M, int N, int K) {
+    LinPlan p;
+    p.am = (M > 96) ? 5 : (M > 32 ? 3 : 1);
+    p.mblocks = frcnn_cdiv(M, 32 * p.am);
+    p.nblocks = frcnn_cdiv(N, 128);
+    const int tiles = p.mblocks * p.nblocks, kchunks = frcnn_cdiv(K, kLBK);
+    int splits = frcnn_cdiv(512, tiles);
+    if (splits > kchunks / 4) splits = kchunks / 4;
+    if (splits < 1) splits = 1;
+    if (splits > 64) splits = 64;
+    p.k_per_split = frcnn_cdiv(kchunks, splits) * kLBK;
+    p.splits = frcnn_cdiv(K, p.k_per_split);
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int frcnn_f32_to_bf16(const float *x, size_t n, uint16_t *y, void *stream) {
+    if (n == 0) return FRCNN_OK;
+    if (!x || !y) return FRCNN_ERR_INVALID;
+    const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(f32_to_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, y);
+    return frcnn_launch_status();
+}
+
+size_t frcnn_linear_bf16_workspace_bytes(int M, int N, int K) {
+    if (M < 1 || N < 1 || K < 1) return 0;
+    const LinPlan p = plan_linear_bf16(M, N, K);
+    return frcnn_align256((size_t)p.splits * M * N * sizeof(float));
+}
+
+int frcnn_linear_bf16(const uint16_t *x, const uint16_t *w, const float *bias, void *y, int M, int N, int K, int relu, int out_bf16, void *workspace,
+                      size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !w || !bias || !y || M < 1 || N < 1 || K < 1 || (K % 8) != 0) return FRCNN_ERR_INVALID;
+    if ((size_t)M * K * 2 >= (1ull << 31) || (size_t)N * K * 2 >= (1ull << 31)) return FRCNN_ERR_INVALID;
+    const LinPlan p = plan_linear_bf16(M, N, K);
+    if (!workspace || workspace_bytes < (size_t)p.splits * M * N * sizeof(float)) return FRCNN_ERR_INVALID;
+    float *part = (float *)workspace;
+    const dim3 grid(p.nblocks, p.mblocks, p.splits);
+    if (p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_bf16_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    else if (p.am == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_bf16_kernel<3>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_bf16_kernel<1>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    const size_t total = (size_t)M * N;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(linear_reduce_bf16_kernel, dim3(blocks), dim3(256), 0, stream, part, bias, y, M, N, p.splits, relu, out_bf16);
+    return frcnn_launch_status();
+}
+
+}  // extern "C"

@@ -20,16 +20,21 @@ from .vgg16 import VGG16Prev
 class Linear(object):
     """L.Linear: W (out, in), b (out)."""
 
-    def __init__(self, rt):
-        self.rt = rt
-        self.W = self.b = None
+    def __init__(self, rt, dtype="f32"):
+        self.rt, self.dtype = rt, dtype
+        self.W = self.b = self.Wb = None
 
     def set(self, W, b):
         self.W = self.rt.asarray(np.ascontiguousarray(W, dtype=np.float32) if isinstance(W, np.ndarray) else W, "f32")
         self.b = self.rt.asarray(np.ascontiguousarray(b, dtype=np.float32) if isinstance(b, np.ndarray) else b, "f32")
+        if self.dtype == "bf16":
+            self.Wb = self.rt.to_bf16(self.W)              # raw bf16 bits, (out, in): K-contiguous for the MFMA B operand
 
     def __call__(self, x, relu=False):
         return self.rt.linear(x, self.W, self.b, relu=relu)
+
+    def bf16(self, x_bits, relu=False, out_bf16=False):
+        return self.rt.linear_bf16(x_bits, self.Wb, self.b, relu=relu, out_bf16=out_bf16)
 
 
 class FasterRCNN(object):
@@ -37,16 +42,17 @@ class FasterRCNN(object):
 
     def __init__(self, trunk_class=VGG16Prev, rpn_in_ch=512, rpn_mid_ch=512, feat_stride=16, anchor_ratios=(0.5, 1, 2),
                  anchor_scales=(8, 16, 32), num_classes=21, loss_lambda=1, rpn_delta=3, rcnn_delta=1, runtime=None,
-                 conv_dtype="f32"):
+                 conv_dtype="f32", head_dtype="f32"):
         """conv_dtype: "f32" = BASELINE config 2 (fp32 everywhere); "bf16" = config 3 (trunk + RPN convolutions in bf16 on
-        v_mfma_f32_32x32x16_bf16, RoI pooling / proposals / head in fp32)."""
+        v_mfma_f32_32x32x16_bf16; proposals and RoI pooling in fp32).  head_dtype: the four L.Linear layers of the RCNN
+        head, "f32" or "bf16" (bf16 operands, fp32 accumulation; box decoding and the class softmax stay fp32)."""
         self.rt = runtime or default_runtime()
-        self.conv_dtype = conv_dtype
+        self.conv_dtype, self.head_dtype = conv_dtype, head_dtype
         self.trunk = trunk_class(runtime=self.rt, conv_dtype=conv_dtype) if conv_dtype != "f32" else trunk_class(runtime=self.rt)
         self.RPN = RegionProposalNetwork(rpn_in_ch, rpn_mid_ch, feat_stride, anchor_ratios, anchor_scales, num_classes,
                                          loss_lambda, rpn_delta, runtime=self.rt, conv_dtype=conv_dtype)
-        self.fc6, self.fc7 = Linear(self.rt), Linear(self.rt)
-        self.cls_score, self.bbox_pred = Linear(self.rt), Linear(self.rt)
+        self.fc6, self.fc7 = Linear(self.rt, head_dtype), Linear(self.rt, head_dtype)
+        self.cls_score, self.bbox_pred = Linear(self.rt, head_dtype), Linear(self.rt, head_dtype)
         self._feat_stride = feat_stride
         self._num_classes = num_classes
         self.RPN.train = False                               # faster_rcnn.py:42
@@ -109,12 +115,20 @@ class FasterRCNN(object):
         mark("proposals")
         pool5 = rt.roi_pool_fwd_chw(feat, rois, 7, 7, self._spatial_scale)    # rois (R,4): concat (:123-124) folded in
         mark("roi_pool")
-        fc6 = self.fc6(pool5, relu=True)        # dropout is the identity in inference (faster_rcnn.py:127-128)
-        mark("fc6")
-        fc7 = self.fc7(fc6, relu=True)
-        mark("fc7")
-        cls_score = self.cls_score(fc7)
-        bbox_pred = self.bbox_pred(fc7)
+        if self.head_dtype == "bf16":
+            fc6 = self.fc6.bf16(rt.to_bf16(pool5.reshape(int(pool5.shape[0]), -1)), relu=True, out_bf16=True)
+            mark("fc6")
+            fc7 = self.fc7.bf16(fc6, relu=True, out_bf16=True)
+            mark("fc7")
+            cls_score = self.cls_score.bf16(fc7)
+            bbox_pred = self.bbox_pred.bf16(fc7)
+        else:
+            fc6 = self.fc6(pool5, relu=True)        # dropout is the identity in inference (faster_rcnn.py:127-128)
+            mark("fc6")
+            fc7 = self.fc7(fc6, relu=True)
+            mark("fc7")
+            cls_score = self.cls_score(fc7)
+            bbox_pred = self.bbox_pred(fc7)
         pred_boxes, cls_prob = rt.head_decode(rois, bbox_pred, cls_score, im_h, im_w)
         mark("head_out")
         out = dict(cls_prob=cls_prob, pred_boxes=pred_boxes, rois=rois, probs=probs, n_out=n_out)

@@ -344,6 +344,25 @@ class Runtime(object):
         _lib.check(L.frcnn_maxpool2x2_bf16(m.ptr(x), m.ptr(y), C, H, W, m.stream()), "frcnn_maxpool2x2_bf16")
         return y
 
+    def to_bf16(self, x):
+        """fp32 array -> raw bf16 bits (int16 array of the same shape), round to nearest even."""
+        m, L = self.mem, self.lib
+        y = m.empty(tuple(int(v) for v in x.shape), "i16")
+        _lib.check(L.frcnn_f32_to_bf16(m.ptr(x), int(np.prod(x.shape)), m.ptr(y), m.stream()), "frcnn_f32_to_bf16")
+        return y
+
+    def linear_bf16(self, x, w, bias, relu=False, out_bf16=False):
+        """x (M,K) bf16 bits, w (N,K) bf16 bits, bias (N,) fp32 -> (M,N) fp32 (or bf16 bits)."""
+        m, L = self.mem, self.lib
+        M, K = int(x.shape[0]), int(np.prod(x.shape[1:]))
+        N = int(w.shape[0])
+        assert int(np.prod(w.shape[1:])) == K
+        y = m.empty((M, N), "i16" if out_bf16 else "f32")
+        ws = self.workspace("linear", L.frcnn_linear_bf16_workspace_bytes(M, N, K))
+        _lib.check(L.frcnn_linear_bf16(m.ptr(x), m.ptr(w), m.ptr(bias), m.ptr(y), M, N, K, int(bool(relu)), int(bool(out_bf16)), m.ptr(ws),
+                                       ws.shape[0], m.stream()), "frcnn_linear_bf16")
+        return y
+
     def softmax_channels(self, score):
         """(n_ch, H, W) fp32 -> softmax over the channel axis."""
         m, L = self.mem, self.lib

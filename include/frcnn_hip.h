@@ -181,6 +181,13 @@ int frcnn_bf16_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, voi
 int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
                     int W, int ksize, int relu, int out_mode, void *stream);
 int frcnn_maxpool2x2_bf16(const uint16_t *x, uint16_t *y, int C, int H, int W, void *stream);
+/* bf16 fully connected layer (config-3 head): y(M,N) = act(x(M,K) @ W(N,K)^T + b); x, W raw bf16 bits (frcnn_f32_to_bf16
+ * converts fp32 arrays: weights once at load, activations per call), fp32 accumulation and bias; y fp32, or bf16 when
+ * out_bf16 (feeding the next bf16 layer).  K % 8 == 0. */
+int frcnn_f32_to_bf16(const float *x, size_t n, uint16_t *y, void *stream);
+size_t frcnn_linear_bf16_workspace_bytes(int M, int N, int K);
+int frcnn_linear_bf16(const uint16_t *x, const uint16_t *w, const float *bias, void *y, int M, int N, int K, int relu,
+                      int out_bf16, void *workspace, size_t workspace_bytes, void *stream);
 /* softmax over the channel axis of a (n_ch, H*W) fp32 map: the reference's F.softmax(rpn_cls_score) (region_proposal_network.py:119) */
 int frcnn_softmax_channels_f32(const float *score, int n_ch, int HW, float *prob, void *stream);
 

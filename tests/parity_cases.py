@@ -396,7 +396,7 @@ def check_vgg_bf16_forward(rt, im_h, im_w, seed=5):
     params = synthetic.params(seed=1)
     x = synthetic.image(seed=seed, h=im_h, w=im_w)
     info = np.array([[im_h, im_w]], dtype=np.int32)
-    model = FasterRCNN(runtime=rt, conv_dtype="bf16")
+    model = FasterRCNN(runtime=rt, conv_dtype="bf16", head_dtype="bf16")
     model.load_params(params)
     out = model.forward_device(rt.mem.from_numpy(x), im_h, im_w, keep=True)
     feat = host(rt, out["feat"])
@@ -407,7 +407,11 @@ def check_vgg_bf16_forward(rt, im_h, im_w, seed=5):
     p2, s2 = O.proposal_layer(host(rt, out["rpn_cls_prob"]), host(rt, out["rpn_bbox_pred"]), info, train=False)
     assert n == len(p2) and np.allclose(host(rt, out["rois"])[:n], p2, rtol=5e-7, atol=1e-4)
     rois = host(rt, out["rois"])[:n]
-    assert np.array_equal(host(rt, out["pool5"])[:n], O.roi_pooling_2d(feat, np.concatenate([np.zeros((n, 1), np.float32), rois], 1), 7, 7, 1 / 16.))
+    pool5 = O.roi_pooling_2d(feat, np.concatenate([np.zeros((n, 1), np.float32), rois], 1), 7, 7, 1 / 16.)
+    assert np.array_equal(host(rt, out["pool5"])[:n], pool5)
+    cp, pb, _ = O.rcnn_head(params, pool5, rois, info)                       # bf16 head vs the fp32 oracle on the same pool5
+    assert np.abs(host(rt, out["cls_prob"])[:n] - cp).max() < 2e-2
+    assert np.abs(host(rt, out["pred_boxes"])[:n] - pb).max() < 2e-2 * max(im_h, im_w)
     return err
 
 
@@ -428,3 +432,20 @@ def check_detections(rt, R=300, ncls=21, seed=0):
         assert np.array_equal(got[c], d), c
         total += len(d)
     assert total > 0
+
+
+def check_linear_bf16(rt, M, N, K, relu, seed=0):
+    rs = np.random.RandomState(seed)
+    x = rs.randn(M, K).astype(np.float32)
+    w = (rs.randn(N, K) / np.sqrt(K)).astype(np.float32)
+    b = rs.randn(N).astype(np.float32) * 0.1
+    xb, xbits = to_bf16(x)
+    wb, wbits = to_bf16(w)
+    assert np.array_equal(host(rt, rt.to_bf16(dev(rt, x))), xbits)
+    want = O.linear(xb, wb, b)
+    if relu:
+        want = O.relu(want)
+    y = host(rt, rt.linear_bf16(rt.to_bf16(dev(rt, x)), rt.to_bf16(dev(rt, w)), dev(rt, b), relu=relu))
+    assert np.abs(y - want).max() <= 3e-5 * max(np.abs(want).max(), 1e-6), np.abs(y - want).max()
+    y16 = from_bf16_bits(host(rt, rt.linear_bf16(rt.to_bf16(dev(rt, x)), rt.to_bf16(dev(rt, w)), dev(rt, b), relu=relu, out_bf16=True)))
+    assert np.all(np.abs(y16 - want) <= np.abs(want) * 2.0 ** -8 + 3e-5 * np.abs(want).max())

@@ -15,7 +15,7 @@ def rt():
 
 
 def test_library_is_the_device_build(rt):
-    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 6
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 7
 
 
 def test_nms_golden(rt):
@@ -252,3 +252,10 @@ def test_vgg16_bf16_forward(rt):
 
 def test_detections_postprocess(rt):
     P.check_detections(rt, R=300)
+
+
+def test_linear_bf16(rt):
+    P.check_linear_bf16(rt, 300, 4096, 25088, True)      # fc6
+    P.check_linear_bf16(rt, 300, 4096, 4096, True)       # fc7
+    P.check_linear_bf16(rt, 300, 84, 4096, False)        # bbox_pred
+    P.check_linear_bf16(rt, 17, 33, 104, False)

@@ -140,3 +140,8 @@ def test_maxpool_bf16(rt):
 
 def test_detections_postprocess(rt):
     P.check_detections(rt, R=60)
+
+
+def test_linear_bf16(rt):
+    P.check_linear_bf16(rt, 70, 140, 256, True)
+    P.check_linear_bf16(rt, 9, 21, 72, False)
