@@ -259,7 +259,28 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
             }
         }
 
-        if (finish) {
+        if (finish && relu == 4) {
+            // epilogue with F.MaxPooling2D(2, 2) (cover_all) fused behind the ReLU: the wave's two rows are one window row
+            // pair (tile rows start at multiples of 4), the horizontal neighbour is the next lane.  y is (Cout, ceil(H/2), ceil(W/2)).
+            if constexpr (APX == 2) {
+                const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+                const int px = x0 + l31, py = y0 + b_row;
+                const bool has_row1 = py + 1 < H, has_right = px + 1 < W;
+#pragma unroll
+                for (int i = 0; i < ACO; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float m = has_row1 ? fmaxf(acc[i][0][r], acc[i][1][r]) : acc[i][0][r];
+                        const float right = __shfl_xor(m, 1);
+                        if (has_right) m = fmaxf(m, right);
+                        if ((l31 & 1) == 0 && px < W && py < H) {
+                            const int co = co0 + wco * (32 * ACO) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                            y[(size_t)co * OH * OW + (size_t)(py >> 1) * OW + (px >> 1)] = fmaxf(m + bias[co], 0.0f);   // max, +bias, ReLU commute
+                        }
+                    }
+                }
+            }
+        } else if (finish) {
             // epilogue: D register r of lane l = cout (r&3) + 8*(r>>2) + 4*(l>>5), pixel l&31
             const int px = x0 + l31;
 #pragma unroll
@@ -487,7 +508,10 @@ int frcnn_pack_conv3x3_w(const float *w, int Cout, int Cin, float *w_packed, voi
     X(12, 2, 2, 1, 4, 8, true, 2)                             \
     X(14, 2, 2, 1, 2, 4, true, 4)                             \
     X(15, 2, 4, 1, 2, 8, true, 2)                             \
-    X(16, 4, 2, 1, 2, 8, true, 1)
+    X(16, 4, 2, 1, 2, 8, true, 1)                             \
+    X(17, 1, 4, 2, 2, 8, true, 2)                             \
+    X(18, 1, 2, 2, 2, 8, true, 3)                             \
+    X(19, 1, 4, 2, 1, 8, true, 3)
 
 size_t frcnn_conv3x3_workspace_bytes(int Cin, int Cout, int H, int W) {
     if (Cin < 1 || Cout < 1 || H < 1 || W < 1) return 0;
@@ -528,10 +552,11 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
                       int H, int W, int ksize, int act, void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (Cout % 64) != 0) return FRCNN_ERR_INVALID;
-    if (act < 0 || act > 3 || (act >= 2 && !mask) || (ksize != 1 && ksize != 3)) return FRCNN_ERR_INVALID;
+    if (act < 0 || act > 4 || ((act == 2 || act == 3) && !mask) || (ksize != 1 && ksize != 3) || (act == 4 && ksize != 3)) return FRCNN_ERR_INVALID;
     if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cin * ksize * ksize * Cout * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;
     if (ksize == 1) return launch_conv<1, 2, 2, 1, 1, 8, true, 3>(x, w_packed, bias, y, Cin, Cout, H, W, act, 0, nullptr, 0, stream, mask);
-    const int cfg = pick_conv_config(Cin, Cout, H, W);
+    int cfg = pick_conv_config(Cin, Cout, H, W);
+    if (act == 4 && cfg % 100 == 5) cfg = 210;                 // the fused pool needs the two-rows-per-wave decomposition
     const int streamk = cfg / 100;
     switch (cfg % 100) {
         case 14: return launch_conv<3, 2, 2, 1, 2, 4, true, 4>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);

@@ -35,6 +35,10 @@ class Conv3x3(object):
     def __call__(self, x, relu=True, out=None, cfg=-1):
         return self.rt.conv3x3(x, self.Wp, self.b, relu=relu, out=out, cfg=cfg)
 
+    def relu_pool(self, x):
+        """conv + ReLU + the following F.MaxPooling2D(2,2) in one launch (the pool lives in the conv kernel's epilogue)."""
+        return self.rt.conv_ex(x, self.Wp, self.b, 3, act=4)
+
     def bf16(self, x_nhwc, relu=True, out_f32_nchw=False):
         """x (H,W,CinP) bf16 channel-last -> (H,W,CoutP) bf16 (or fp32 NCHW)."""
         return self.rt.conv_bf16(x_nhwc, self.Wb, self.b, self.cin, self.cout, 3, relu=relu, out_f32_nchw=out_f32_nchw)
@@ -45,6 +49,7 @@ class VGG16Prev(object):
         self.rt = runtime or default_runtime()
         self.train = train
         self.conv_dtype = conv_dtype                                      # "f32" (BASELINE config 2) or "bf16" (config 3)
+        self.fuse_pool = True        # inference: conv -> ReLU -> pool as one launch (the trainer keeps the pre-pool maps instead)
         self.layers = list(layers) if layers is not None else LAYERS     # (tests build narrow / shallow variants)
         self.links = {}
         for l in self.layers:
@@ -67,15 +72,20 @@ class VGG16Prev(object):
         assert h.ndim == 4 and int(h.shape[0]) == 1, "batch size 1 (models/faster_rcnn.py:77)"
         if self.conv_dtype == "bf16":
             return self._call_bf16(h, timer)
-        n_pool = 0
-        for l in self.layers:
+        n_pool, skip = 0, False
+        for idx, l in enumerate(self.layers):
             if l == "pool":
-                h = rt.maxpool2x2(h)
                 n_pool += 1
+                if skip:                                                  # already applied inside the previous conv
+                    skip = False
+                    continue
+                h = rt.maxpool2x2(h)
                 if timer:
                     timer.mark("pool%d" % n_pool)
             else:
-                h = self.links[l[0]](h, relu=True)
+                fuse = self.fuse_pool and idx + 1 < len(self.layers) and self.layers[idx + 1] == "pool" and l[2] % 64 == 0
+                h = self.links[l[0]].relu_pool(h) if fuse else self.links[l[0]](h, relu=True)
+                skip = fuse
                 if timer:
                     timer.mark(l[0])
         return h

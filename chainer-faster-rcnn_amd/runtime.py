@@ -296,7 +296,8 @@ class Runtime(object):
         ci, H, W = [int(v) for v in x.shape[-3:]]
         co = int(w_packed.shape[1])
         assert int(w_packed.shape[0]) == ci * ksize * ksize
-        y = out if out is not None else m.empty((1, co, H, W), "f32")
+        oh, ow = ((H + 1) // 2, (W + 1) // 2) if act == 4 else (H, W)      # act 4: ReLU + 2x2 max-pool fused
+        y = out if out is not None else m.empty((1, co, oh, ow), "f32")
         ws = self.workspace("conv3x3", L.frcnn_conv3x3_workspace_bytes(ci, co, H, W))
         _lib.check(L.frcnn_conv_f32_ex(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(mask), m.ptr(y), ci, co, H, W, int(ksize),
                                        int(act), m.ptr(ws), ws.shape[0], m.stream()), "frcnn_conv_f32_ex")

@@ -161,6 +161,7 @@ int frcnn_clip_boxes(float *boxes, int n_boxes, int im_h, int im_w, void *stream
 int frcnn_softmax_rows(const float *scores, int R, int n, float *probs, void *stream);
 
 /* generic form of the convolution entry: ksize 1 or 3 (stride 1, pad ksize/2), act 0 = none, 1 = ReLU,
+ * 4 = ReLU then F.MaxPooling2D(2,2) (cover_all) fused into the epilogue: y is (Cout, ceil(H/2), ceil(W/2)) (ksize 3),
  * 3 = y = relu(conv + bias + mask) (residual add), 2 = y = (mask > 0) ? conv + bias : 0  -- the input-gradient convolution of the backward pass with the producing
  * ReLU's mask fused in (mask has y's shape).  Cout % 64 == 0. */
 int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, const float *mask, float *y, int Cin,

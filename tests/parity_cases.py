@@ -449,3 +449,18 @@ def check_linear_bf16(rt, M, N, K, relu, seed=0):
     assert np.abs(y - want).max() <= 3e-5 * max(np.abs(want).max(), 1e-6), np.abs(y - want).max()
     y16 = from_bf16_bits(host(rt, rt.linear_bf16(rt.to_bf16(dev(rt, x)), rt.to_bf16(dev(rt, w)), dev(rt, b), relu=relu, out_bf16=True)))
     assert np.all(np.abs(y16 - want) <= np.abs(want) * 2.0 ** -8 + 3e-5 * np.abs(want).max())
+
+
+def check_conv_relu_pool(rt, Cin, Cout, H, W, seed=0):
+    """act = 4: conv + bias + ReLU + F.MaxPooling2D(2,2) (cover_all) in one launch, vs the three separate oracle steps."""
+    rs = np.random.RandomState(seed)
+    x = rs.randn(1, Cin, H, W).astype(np.float32)
+    w = (rs.randn(Cout, Cin, 3, 3) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    b = rs.randn(Cout).astype(np.float32) * 0.1
+    want = O.max_pool_2x2(O.relu(O.conv2d(x, w, b, 1)))
+    wp = rt.pack_conv3x3_w(dev(rt, w))
+    got = host(rt, rt.conv_ex(dev(rt, x), wp, dev(rt, b), 3, act=4))
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6)
+    sep = host(rt, rt.maxpool2x2(rt.conv3x3(dev(rt, x), wp, dev(rt, b), relu=True, cfg=10)))
+    assert np.array_equal(got, sep) or np.abs(got - sep).max() <= 1e-5 * np.abs(sep).max()

@@ -259,3 +259,8 @@ def test_linear_bf16(rt):
     P.check_linear_bf16(rt, 300, 4096, 4096, True)       # fc7
     P.check_linear_bf16(rt, 300, 84, 4096, False)        # bbox_pred
     P.check_linear_bf16(rt, 17, 33, 104, False)
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 120, 200), (128, 128, 60, 100), (256, 256, 150, 250), (512, 512, 75, 125)])
+def test_conv_relu_pool_fused(rt, cin, cout, h, w):
+    P.check_conv_relu_pool(rt, cin, cout, h, w)

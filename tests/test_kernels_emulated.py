@@ -145,3 +145,8 @@ def test_detections_postprocess(rt):
 def test_linear_bf16(rt):
     P.check_linear_bf16(rt, 70, 140, 256, True)
     P.check_linear_bf16(rt, 9, 21, 72, False)
+
+
+def test_conv_relu_pool_fused(rt):
+    P.check_conv_relu_pool(rt, 8, 64, 9, 37)          # odd H and W: clipped windows on both edges
+    P.check_conv_relu_pool(rt, 16, 128, 8, 64, seed=1)
