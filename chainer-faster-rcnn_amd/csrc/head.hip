@@ -65,9 +65,47 @@ class_dets_kernel(const float *__restrict__ cls_prob, const float *__restrict__ 
     d[4] = cls_prob[(size_t)r * ncls + c];
 }
 
+// forward.py:33-45 img_preprocessing on the device: uint8 HWC (BGR, as cv.imread returns) -> float32 mean-subtracted,
+// bilinearly resized (cv.resize(..., fx=fy=im_scale, INTER_LINEAR) on the float image: half-pixel centres, edge clamp,
+// horizontal then vertical blend in float), transposed to CHW.  One thread per output pixel.
+struct PixelMeans { double m[4]; };
+__global__ void __launch_bounds__(256)
+preprocess_kernel(const uint8_t *__restrict__ img, int H, int W, int C, PixelMeans means, int OH, int OW, double inv_scale_x, double inv_scale_y,
+                  float *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= OH * OW) return;
+    const int oy = i / OW, ox = i - oy * OW;
+    float fx = (float)(((double)ox + 0.5) * inv_scale_x - 0.5), fy = (float)(((double)oy + 0.5) * inv_scale_y - 0.5);
+    int sx = (int)floorf(fx), sy = (int)floorf(fy);
+    fx -= (float)sx; fy -= (float)sy;
+    if (sx < 0) { fx = 0.0f; sx = 0; }
+    if (sx >= W - 1) { fx = 0.0f; sx = W - 1; }
+    if (sy < 0) { fy = 0.0f; sy = 0; }
+    if (sy >= H - 1) { fy = 0.0f; sy = H - 1; }
+    const int sx1 = min(sx + 1, W - 1), sy1 = min(sy + 1, H - 1);
+    for (int c = 0; c < C; ++c) {
+        const double mean = means.m[c];
+        const float p00 = (float)((double)img[((size_t)sy * W + sx) * C + c] - mean), p01 = (float)((double)img[((size_t)sy * W + sx1) * C + c] - mean);
+        const float p10 = (float)((double)img[((size_t)sy1 * W + sx) * C + c] - mean), p11 = (float)((double)img[((size_t)sy1 * W + sx1) * C + c] - mean);
+        const float r0 = p00 * (1.0f - fx) + p01 * fx, r1 = p10 * (1.0f - fx) + p11 * fx;
+        out[((size_t)c * OH + oy) * OW + ox] = r0 * (1.0f - fy) + r1 * fy;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int frcnn_preprocess_u8(const uint8_t *img, int H, int W, int C, const double *means_host, double im_scale, int OH, int OW, float *out,
+                        void *stream) {
+    if (!img || !means_host || !out || H < 1 || W < 1 || C < 1 || C > 4 || OH < 1 || OW < 1 || !(im_scale > 0.0)) return FRCNN_ERR_INVALID;
+    PixelMeans pm;
+    for (int c = 0; c < 4; ++c) pm.m[c] = c < C ? means_host[c] : 0.0;
+    hipLaunchKernelGGL(preprocess_kernel, dim3(frcnn_cdiv(OH * OW, 256)), dim3(256), 0, (hipStream_t)stream, img, H, W, C, pm, OH, OW,
+                       1.0 / im_scale, 1.0 / im_scale, out);
+    return frcnn_launch_status();
+}
+
 
 int frcnn_class_dets(const float *cls_prob, const float *pred_boxes, int R, int ncls, float *dets, void *stream) {
     if (!cls_prob || !pred_boxes || !dets || R < 0 || ncls < 2) return FRCNN_ERR_INVALID;

@@ -30,3 +30,22 @@ def detections(cls_prob, pred_boxes, nms_thresh=0.3, conf=0.8, im_scale=1.0, run
         d[:, :4] /= im_scale
         out[c] = d
     return out
+
+
+PIXEL_MEANS = np.array([[[102.9801, 115.9465, 122.7717]]])        # forward.py:22 (BGR)
+
+
+def img_preprocessing(orig_img, pixel_means=PIXEL_MEANS, max_size=1000, scale=600, runtime=None):
+    """forward.py:33-45 with the reference's signature: uint8 HWC image -> ((1? no: C,H,W) float32 device array, im_scale).
+    The scale rule is the reference's host arithmetic; mean subtraction, the bilinear resize and the HWC->CHW transpose
+    run in one device kernel on the uint8 upload.  Returns (img (C,OH,OW) device f32, im_scale)."""
+    rt = runtime or default_runtime()
+    h, w = orig_img.shape[0], orig_img.shape[1]
+    im_size_min, im_size_max = min(h, w), max(h, w)
+    im_scale = float(scale) / float(im_size_min)
+    if np.round(im_scale * im_size_max) > max_size:
+        im_scale = float(max_size) / float(im_size_max)
+    oh, ow = int(np.rint(h * im_scale)), int(np.rint(w * im_scale))           # cv.resize: dsize = round(size * f), ties to even
+    dev = rt.asarray(np.ascontiguousarray(orig_img, dtype=np.uint8), "u8") if isinstance(orig_img, np.ndarray) else orig_img
+    out = rt.preprocess_u8(dev, np.asarray(pixel_means, dtype=np.float64).ravel(), im_scale, (oh, ow))
+    return out[0], im_scale

@@ -259,6 +259,17 @@ class Runtime(object):
         return pred, prob
 
 
+    def preprocess_u8(self, img, means, im_scale, out_hw):
+        """img (H,W,C) uint8 device array -> (1,C,OH,OW) float32 (forward.py:33-45 on the device)."""
+        m, L = self.mem, self.lib
+        H, W, C = [int(v) for v in img.shape]
+        OH, OW = int(out_hw[0]), int(out_hw[1])
+        out = m.empty((1, C, OH, OW), "f32")
+        mh = np.ascontiguousarray(means, dtype=np.float64).ravel()
+        _lib.check(L.frcnn_preprocess_u8(m.ptr(img), H, W, C, mh.ctypes.data_as(ctypes.c_void_p), float(im_scale), OH, OW, m.ptr(out),
+                                         m.stream()), "frcnn_preprocess_u8")
+        return out
+
     def class_dets(self, cls_prob, pred_boxes):
         """(R,ncls), (R,4*ncls) -> (ncls-1, R, 5) per-class [x1,y1,x2,y2,score] rows (forward.py:50-53)."""
         m, L = self.mem, self.lib

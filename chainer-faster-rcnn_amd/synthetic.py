@@ -51,9 +51,9 @@ def params(seed=1, num_classes=21, n_anchors=9, rpn_ch=512, roi_feat=512 * 7 * 7
 
 
 def load_npz(path, model):
-    """serializers.load_npz(path, model) for the reference's snapshot format (forward.py:29)."""
-    with np.load(path) as f:
-        model.load_params({k: f[k] for k in f.files})
+    """serializers.load_npz(path, model) for the reference's snapshot format (forward.py:29); see serializers.py."""
+    from .serializers import load_npz as _load
+    return _load(path, model)
 
 
 def resnet_params(n_layers=101, seed=2, blocks=None, prefix="trunk/"):

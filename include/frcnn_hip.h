@@ -153,6 +153,11 @@ int frcnn_head_decode(const float *boxes, const float *deltas, const float *cls_
 /* forward.py:50-53: per-class detection rows for the 20 per-class NMS problems --
  * dets (ncls-1, R, 5) = [pred_boxes[:, 4c:4c+4], cls_prob[:, c]] for c = 1..ncls-1; feed frcnn_nms_batched(thresh 0.3). */
 int frcnn_class_dets(const float *cls_prob, const float *pred_boxes, int R, int ncls, float *dets, void *stream);
+/* forward.py:33-45 img_preprocessing: img (H,W,C) uint8 as cv.imread returns it -> out (C,OH,OW) f32 =
+ * cv.resize(float32(img) - means, fx=fy=im_scale, INTER_LINEAR) transposed to CHW; OH = round(H*im_scale), OW = round(W*im_scale)
+ * are computed by the caller (the upload is 1.8 MB of uint8 instead of 7.2 MB of float32). */
+int frcnn_preprocess_u8(const uint8_t *img, int H, int W, int C, const double *means_host, double im_scale, int OH, int OW,
+                        float *out, void *stream);
 /* the three pieces on their own: bbox_transform_inv (bbox_transform.py:41-76), clip_boxes (:79-99, in
  * place on n_boxes x 4 floats), and a row-wise softmax (F.softmax on (R,n)) */
 int frcnn_bbox_transform_inv(const float *boxes, const float *deltas, int R, int ncls, float *pred_boxes,

@@ -600,3 +600,32 @@ def resnet_forward(p, x, blocks=(3, 4, 23, 3), prefix="trunk/", eps=2e-5):
                 t = F.relu(bn(conv(t, q + "conv2", 1, 1), q + "bn2"))
                 h = F.relu(bn(conv(t, q + "conv3"), q + "bn3") + sc)
         return h.numpy()
+
+
+# --------------------------------------------------------------------------- image preprocessing (cv2-ext)
+def img_preprocessing(orig_img, pixel_means, max_size=1000, scale=600):
+    """forward.py:33-45.  cv.resize(INTER_LINEAR) is OpenCV (absent here: parity unpinned); restated from its documented
+    float path: dsize = round(size*f); source coordinate (d + 0.5)/f - 0.5, floor, clamp with zero weight at the edges,
+    horizontal blend then vertical blend in float32."""
+    img = orig_img.astype(np.float32, copy=True)
+    img -= pixel_means
+    h, w = img.shape[:2]
+    im_scale = float(scale) / float(min(h, w))
+    if np.round(im_scale * max(h, w)) > max_size:
+        im_scale = float(max_size) / float(max(h, w))
+    oh, ow = int(np.rint(h * im_scale)), int(np.rint(w * im_scale))
+
+    def taps(n_out, n_in):
+        f = ((np.arange(n_out, dtype=np.float64) + 0.5) * (1.0 / im_scale) - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        a = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        a[lo] = 0; s[lo] = 0
+        hi = s >= n_in - 1
+        a[hi] = 0; s[hi] = n_in - 1
+        return s, np.minimum(s + 1, n_in - 1), a
+    sx, sx1, ax = taps(ow, w)
+    sy, sy1, ay = taps(oh, h)
+    rows = img[:, sx] * (np.float32(1) - ax)[None, :, None] + img[:, sx1] * ax[None, :, None]
+    out = rows[sy] * (np.float32(1) - ay)[:, None, None] + rows[sy1] * ay[:, None, None]
+    return out.transpose(2, 0, 1).astype(np.float32), im_scale

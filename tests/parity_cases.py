@@ -464,3 +464,13 @@ def check_conv_relu_pool(rt, Cin, Cout, H, W, seed=0):
     assert np.abs(got - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6)
     sep = host(rt, rt.maxpool2x2(rt.conv3x3(dev(rt, x), wp, dev(rt, b), relu=True, cfg=10)))
     assert np.array_equal(got, sep) or np.abs(got - sep).max() <= 1e-5 * np.abs(sep).max()
+
+
+def check_preprocess(rt, h, w, seed=0):
+    from chainer_faster_rcnn_amd.postprocess import PIXEL_MEANS, img_preprocessing
+    rs = np.random.RandomState(seed)
+    img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    want, want_scale = O.img_preprocessing(img, PIXEL_MEANS)
+    got, scale = img_preprocessing(img, runtime=rt)
+    assert scale == want_scale and tuple(got.shape) == want.shape, (tuple(got.shape), want.shape)
+    assert np.allclose(host(rt, got), want, rtol=0, atol=2e-4)          # float32 blends of values up to 255: a few ulps

@@ -15,7 +15,7 @@ def rt():
 
 
 def test_library_is_the_device_build(rt):
-    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 7
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 8
 
 
 def test_nms_golden(rt):
@@ -264,3 +264,8 @@ def test_linear_bf16(rt):
 @pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 120, 200), (128, 128, 60, 100), (256, 256, 150, 250), (512, 512, 75, 125)])
 def test_conv_relu_pool_fused(rt, cin, cout, h, w):
     P.check_conv_relu_pool(rt, cin, cout, h, w)
+
+
+def test_img_preprocessing(rt):
+    P.check_preprocess(rt, 375, 500)          # a VOC-sized image -> 600 x 800
+    P.check_preprocess(rt, 333, 1000, seed=1)

@@ -150,3 +150,8 @@ def test_linear_bf16(rt):
 def test_conv_relu_pool_fused(rt):
     P.check_conv_relu_pool(rt, 8, 64, 9, 37)          # odd H and W: clipped windows on both edges
     P.check_conv_relu_pool(rt, 16, 128, 8, 64, seed=1)
+
+
+def test_img_preprocessing(rt):
+    P.check_preprocess(rt, 37, 50)            # scale 600/37: upsampling, both clamps
+    P.check_preprocess(rt, 60, 200, seed=1)   # max_size rule: scale 1000/200

@@ -108,3 +108,36 @@ def test_data_parallel_step_gloo_world2():
         p.join(timeout=60)
     assert all(ok for _, ok, _ in res), res
     assert res[0][2] == res[1][2]
+
+
+def test_snapshot_roundtrip_after_training(rt, tmp_path):
+    """save_npz / load_npz in chainer's link-path key scheme (forward.py:29): after one training step the packed weights are
+    synced back, written, and a fresh model loaded from the file reproduces the trained model's RPN outputs bit for bit."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.serializers import load_npz, save_npz
+    from chainer_faster_rcnn_amd.train import RPNTrainer
+    import parity_cases as P
+    rs = np.random.RandomState(0)
+    params = T.small_params()
+    model = T.build_small(rt, params)
+    tr = RPNTrainer(model)
+    x = rs.randn(1, 3, 40, 56).astype(np.float32)
+    gt = P.gt_case(rs, 2, 40, 56)
+    gt[0, :, 2] = np.minimum(gt[0, :, 0] + 20, 55); gt[0, :, 3] = np.minimum(gt[0, :, 1] + 20, 39)
+    info = np.array([[40, 56]], dtype=np.int32)
+    np.random.seed(0)
+    tr.step(Variable(x), Variable(info), Variable(gt))
+    path = str(tmp_path / "rpn_model_snapshot_1.npz")
+    save_npz(path, model, trainer=tr)
+    with np.load(path) as f:
+        keys = set(f.files)
+        assert {"trunk/conv1_1/W", "trunk/conv2_2/b", "RPN/rpn_conv_3x3/W", "RPN/rpn_cls_score/W", "RPN/rpn_bbox_pred/b"} <= keys
+        assert f["trunk/conv2_1/W"].shape == (64, 64, 3, 3) and f["RPN/rpn_cls_score/W"].shape == (18, 64, 1, 1)
+        assert not np.array_equal(f["trunk/conv2_1/W"], params["trunk/conv2_1/W"])          # the step did change the weights
+    fresh = load_npz(path, T.build_small(rt, params))
+    model.rpn_train = False
+    fresh.rpn_train = False
+    a = model.RPN.heads(model.trunk(Variable(x)))
+    b = fresh.RPN.heads(fresh.trunk(Variable(x)))
+    for u, v in zip(a[1:], b[1:]):
+        assert np.array_equal(rt.mem.to_numpy(u), rt.mem.to_numpy(v))
