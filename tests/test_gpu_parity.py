@@ -269,3 +269,51 @@ def test_conv_relu_pool_fused(rt, cin, cout, h, w):
 def test_img_preprocessing(rt):
     P.check_preprocess(rt, 375, 500)          # a VOC-sized image -> 600 x 800
     P.check_preprocess(rt, 333, 1000, seed=1)
+
+
+# ---- BASELINE.json full sizes through size-independent properties (the oracle is not needed at these sizes)
+def test_conv_full_size_linearity_and_spot_values(rt):
+    """conv1_2 at 600x1000 (153.6 MB per tensor): conv is linear in x without bias/ReLU, and individual output pixels equal
+    the direct 576-term dot product (float64) at image corners, edges and the interior."""
+    rs = np.random.RandomState(0)
+    x1 = rs.randn(1, 64, 600, 1000).astype(np.float32)
+    x2 = rs.randn(1, 64, 600, 1000).astype(np.float32)
+    w = (rs.randn(64, 64, 3, 3) * 0.06).astype(np.float32)
+    zero = P.dev(rt, np.zeros(64, np.float32))
+    wp = rt.pack_conv3x3_w(P.dev(rt, w))
+    y1 = P.host(rt, rt.conv3x3(P.dev(rt, x1), wp, zero, relu=False))
+    y2 = P.host(rt, rt.conv3x3(P.dev(rt, x2), wp, zero, relu=False))
+    y3 = P.host(rt, rt.conv3x3(P.dev(rt, (2 * x1 - x2)), wp, zero, relu=False))
+    assert np.abs(y3 - (2 * y1 - y2)).max() <= 2e-5 * np.abs(y1).max() * 4
+    xp = np.pad(x1[0], ((0, 0), (1, 1), (1, 1))).astype(np.float64)
+    for (co, py, px) in [(0, 0, 0), (63, 599, 999), (17, 0, 999), (40, 599, 0), (5, 300, 31), (5, 300, 32), (33, 3, 4), (62, 597, 993)]:
+        want = float((xp[:, py:py + 3, px:px + 3] * w[co].astype(np.float64)).sum())
+        assert abs(y1[0, co, py, px] - want) <= 1e-4 * max(abs(want), 1.0), (co, py, px)
+
+
+def test_nms_train_size_properties(rt):
+    """12000 boxes (ProposalLayer train mode): greedy-NMS invariants checked on the host from the result alone -- survivors
+    are in descending score order, no two survivors overlap >= thresh, every dropped box overlaps an earlier-scored survivor."""
+    rs = np.random.RandomState(1)
+    n = 12000
+    xy = rs.uniform(0, 900, (n, 2))
+    wh = rs.uniform(16, 300, (n, 2))
+    scores = rs.permutation(n).astype(np.float32) / n
+    dets = np.hstack([xy, xy + wh, scores[:, None]]).astype(np.float32)
+    keep, n_keep = rt.nms(P.dev(rt, dets), 0.7)
+    k = P.host(rt, keep)[:int(P.host(rt, n_keep)[0])]
+    assert len(k) > 100 and np.all(np.diff(dets[k, 4]) < 0)
+
+    def iou(a, b):
+        iw = np.maximum(0, np.minimum(a[:, None, 2], b[None, :, 2]) - np.maximum(a[:, None, 0], b[None, :, 0]) + 1)
+        ih = np.maximum(0, np.minimum(a[:, None, 3], b[None, :, 3]) - np.maximum(a[:, None, 1], b[None, :, 1]) + 1)
+        inter = (iw * ih).astype(np.float32)
+        area = lambda z: (z[:, 2] - z[:, 0] + 1) * (z[:, 3] - z[:, 1] + 1)
+        return inter / (area(a)[:, None] + area(b)[None, :] - inter)
+    K = dets[k]
+    m = iou(K, K)
+    np.fill_diagonal(m, 0)
+    assert (m.astype(np.float64) >= 0.7).sum() == 0
+    dropped = np.setdiff1d(np.arange(n), k)
+    sup = (iou(dets[dropped], K).astype(np.float64) >= 0.7) & (K[None, :, 4] > dets[dropped, 4][:, None])
+    assert sup.any(axis=1).all()
