@@ -323,25 +323,52 @@ conv_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    for (int b = b_begin; b < b_end; ++b) {
-        const int tx = b % xtiles, ty = b / xtiles;
+    // Staging elements of this thread: fixed (channel, halo row, halo column) / (channel, row, pixel) slots, so only the
+    // image-border test and one add depend on the tile.  Register-staged double buffer: tile b+1 is fetched while tile b
+    // feeds the MFMAs and written to LDS after the barrier.
+    constexpr int XN = 64 * HR * HP, DN = 64 * WG_ROWS * 32;
+    constexpr int XIT = (XN + 255) / 256, DIT = (DN + 255) / 256;
+    float xreg[XIT], dreg[DIT];
+    auto fetch = [&](int blk) {
+        const int tx = blk % xtiles, ty = blk / xtiles;
         const int x0 = tx * 32, y0 = ty * WG_ROWS;
-        // ---- stage: 64 input channels' halo and 64 output-gradient channels' tile
-        for (int e = tid; e < 64 * HR * HP; e += 256) {
+#pragma unroll
+        for (int q = 0; q < XIT; ++q) {
+            const int e = tid + q * 256;
             const int c = e / (HR * HP), rem = e - c * (HR * HP);
             const int hr = rem / HP, hx = rem - hr * HP;
             const int gy = y0 - PAD + hr, gx = x0 - PAD + hx, gc = ci0 + c;
-            const bool inside = gc < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W;
-            x_lds[c * CHP + hr * HP + hx] = frcnn_buf_load_f32(xbuf, inside ? (uint32_t)(gc * HWs + gy * W + gx) * 4u : kBufOob);
+            const bool inside = e < XN && gc < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            xreg[q] = frcnn_buf_load_f32(xbuf, inside ? (uint32_t)(gc * HWs + gy * W + gx) * 4u : kBufOob);
         }
-        for (int e = tid; e < 64 * WG_ROWS * 32; e += 256) {
+#pragma unroll
+        for (int q = 0; q < DIT; ++q) {
+            const int e = tid + q * 256;
             const int c = e / (WG_ROWS * 32), rem = e - c * (WG_ROWS * 32);
-            const int r = rem >> 5, px = rem & 31;
-            const int gy = y0 + r, gx = x0 + px, gc = co0 + c;
+            const int gy = y0 + (rem >> 5), gx = x0 + (rem & 31), gc = co0 + c;
             const bool inside = gc < Cout && gy < H && gx < W;
-            dy_lds[c * DP + rem] = frcnn_buf_load_f32(dbuf, inside ? (uint32_t)(gc * HWs + gy * W + gx) * 4u : kBufOob);
+            dreg[q] = frcnn_buf_load_f32(dbuf, inside ? (uint32_t)(gc * HWs + gy * W + gx) * 4u : kBufOob);
         }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < XIT; ++q) {
+            const int e = tid + q * 256;
+            if (e < XN) { const int c = e / (HR * HP); x_lds[c * CHP + (e - c * (HR * HP))] = xreg[q]; }
+        }
+#pragma unroll
+        for (int q = 0; q < DIT; ++q) {
+            const int e = tid + q * 256;
+            const int c = e / (WG_ROWS * 32);
+            dy_lds[c * DP + (e - c * (WG_ROWS * 32))] = dreg[q];
+        }
+    };
+    if (b_begin < b_end) fetch(b_begin);
+    for (int b = b_begin; b < b_end; ++b) {
+        __syncthreads();                       // every wave is done reading the previous tile
+        stage();
         __syncthreads();
+        if (b + 1 < b_end) fetch(b + 1);       // in flight during the MFMAs below
         const float *xa = x_lds + (wci * 32 + l31) * CHP + khalf;
         const float *db = dy_lds + (wco * 32 + l31) * DP + khalf;
 #pragma unroll 1
@@ -357,7 +384,6 @@ conv_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy
                 }
             }
         }
-        __syncthreads();
     }
     // ---- partial tile -> slab `split`, in dWp's own layout: row (ci*T + tap), column co
     float *slab = slabs + (size_t)split * ((size_t)Cin * T * Cout);
