@@ -5,8 +5,11 @@
 // (round to nearest even), products accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).
 //
 // Layout.  A bf16 MFMA lane supplies EIGHT consecutive k-values of one row/column, so the contraction index must be
-// contiguous in memory: activations are channel-last (H, W, C) bf16 and the weights are packed [tap][cout][cin] bf16,
-// with channel counts padded to a multiple of 16; k = (tap, cin).  MFMA A = weights (row = cout), B = activations
+// contiguous in memory -- and a K-chunk of 16 channels should still be whole cache lines.  Activations are therefore
+// channel-BLOCKED, [C/16][H][W][16] bf16 (a chunk's halo row is one contiguous run of 34 x 32 B), and the weights are packed
+// [C/16][tap][cout][16] bf16 (a chunk's panel for 64 couts is 9 contiguous runs of 2 KB), channel counts padded to a multiple
+// of 16; k = (tap, cin).  [With plain channel-last tensors every 16-byte staging load touched its own 128-byte line and the
+// kernel sat on the CU's global-load rate: ~10 B/clk.]  MFMA A = weights (row = cout), B = activations
 // (column = pixel): lane l of a B fragment reads 16 contiguous bytes -- channels 8*(l>>5)..+7 of pixel l&31 -- and
 // register r of the D fragment holds cout (r&3)+8*(r>>2)+4*(l>>5) of pixel l&31, i.e. four consecutive couts of one pixel:
 // one 8-byte channel-last store per register quad.  The last layer of a bf16 chain can instead write fp32 NCHW
@@ -19,6 +22,7 @@
 // range = 0).  At bf16 rates this kernel is bound by LDS and L2 traffic, not by the matrix cores: 3 fragment reads feed 2
 // MFMAs (32 cycles each).
 #include "frcnn_common.h"
+#include <stdlib.h>
 #include <frcnn_buffer.h>   // angle brackets: shadowed by the test emulator
 #include <frcnn_intrin.h>
 
@@ -34,18 +38,20 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     return (uint16_t)(u >> 16);
 }
 
-template <int KS>
-__global__ void __launch_bounds__(256)
+template <int KS, int RP>           // RP = row pairs per workgroup: 2 -> 4 waves, 64co x 4 rows; 4 -> 8 waves, 64co x 8 rows
+__global__ void __launch_bounds__(128 * RP)
 conv_mfma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
                       int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles) {
     constexpr int TAPS = KS * KS, PAD = KS / 2;
-    constexpr int BROWS = 4, BCO = 64;
+    constexpr int BROWS = 2 * RP, BCO = 64, NT = 128 * RP;
     constexpr int HR = BROWS + KS - 1, HPX = 32 + KS - 1;
     constexpr int HALO_V = HR * HPX * 2;            // 16-byte vectors of activations per chunk (2 per pixel)
     constexpr int W_V = TAPS * BCO * 2;             // 16-byte vectors of weights per chunk (2 per row)
-    constexpr int HIT = (HALO_V + 255) / 256, WIT = (W_V + 255) / 256;
+    constexpr int HIT = (HALO_V + NT - 1) / NT, WIT = (W_V + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) unsigned char in_lds[2][HR * HPX * kPitchB];
-    __shared__ __attribute__((aligned(16))) unsigned char w_lds[2][TAPS * BCO * kPitchB];
+    constexpr int OP = BCO * 2 + 16;                                     // epilogue tile: LDS bytes per pixel (128 B + pad)
+    constexpr int W_BYTES = TAPS * BCO * kPitchB > BROWS * 32 * OP / 2 ? TAPS * BCO * kPitchB : BROWS * 32 * OP / 2;
+    __shared__ __attribute__((aligned(16))) unsigned char w_lds[2][W_BYTES];       // weights; re-used by the epilogue transpose
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave & 1, wrow = wave >> 1;
@@ -56,42 +62,45 @@ conv_mfma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict
     const int nchunks = CinP / kCK;
     const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)H * W * CinP * 2));
     const frcnn_buf_t wbuf = frcnn_make_buf(wp, (uint32_t)((size_t)TAPS * CoutP * CinP * 2));
+    const uint32_t x_chunk_bytes = (uint32_t)(H * W) * 32u, w_chunk_bytes = (uint32_t)(TAPS * CoutP) * 32u;
 
-    // byte offsets (chunk 0) of this thread's staging vectors; chunk c adds c * 32 bytes to both
+    // byte offsets (chunk 0) of this thread's staging vectors; chunk c adds c channel blocks
     uint32_t hoff[HIT], woff[WIT];
 #pragma unroll
     for (int q = 0; q < HIT; ++q) {
-        const int v = tid + q * 256;
+        const int v = tid + q * NT;
         const int pix = v >> 1, half = v & 1;
         const int hr = pix / HPX, hx = pix - hr * HPX;
         const int gy = y0 - PAD + hr, gx = x0 - PAD + hx;
         const bool inside = v < HALO_V && gy >= 0 && gy < H && gx >= 0 && gx < W;
-        hoff[q] = inside ? (uint32_t)(((size_t)gy * W + gx) * CinP * 2 + half * 16) : kBufOob;
+        hoff[q] = inside ? (uint32_t)((gy * W + gx) * 32 + half * 16) : kBufOob;
     }
 #pragma unroll
     for (int q = 0; q < WIT; ++q) {
-        const int v = tid + q * 256;
+        const int v = tid + q * NT;
         const int row = v >> 1, half = v & 1;                    // row = tap * BCO + co_local
         const int tap = row / BCO, col = row - tap * BCO;
-        woff[q] = (v < W_V && co0 + col < CoutP) ? (uint32_t)((((size_t)tap * CoutP + co0 + col) * CinP) * 2 + half * 16) : kBufOob;
+        woff[q] = (v < W_V && co0 + col < CoutP) ? (uint32_t)((tap * CoutP + co0 + col) * 32 + half * 16) : kBufOob;
     }
-    float4 hreg[HIT], wreg[WIT];
-    auto fetch = [&](int chunk) {
-        const uint32_t cb = (uint32_t)chunk * (kCK * 2);
+    // Two register sets: chunk t+2 is fetched while chunk t feeds the MFMAs and chunk t+1 waits in the other set, so a load has
+    // two chunk times (plus the co-resident workgroup's) to land -- one chunk of 18 MFMAs is shorter than an L2 round trip.
+    float4 hregA[HIT], wregA[WIT], hregB[HIT], wregB[WIT];
+    auto fetch = [&](int chunk, float4 (&hreg)[HIT], float4 (&wreg)[WIT]) {
+        const uint32_t xb = (uint32_t)chunk * x_chunk_bytes, wb = (uint32_t)chunk * w_chunk_bytes;
 #pragma unroll
-        for (int q = 0; q < HIT; ++q) hreg[q] = frcnn_buf_load_f32x4(xbuf, hoff[q] + cb);
+        for (int q = 0; q < HIT; ++q) hreg[q] = frcnn_buf_load_f32x4(xbuf, hoff[q] + xb);
 #pragma unroll
-        for (int q = 0; q < WIT; ++q) wreg[q] = frcnn_buf_load_f32x4(wbuf, woff[q] + cb);
+        for (int q = 0; q < WIT; ++q) wreg[q] = frcnn_buf_load_f32x4(wbuf, woff[q] + wb);
     };
-    auto stage = [&](int buf) {
+    auto stage = [&](int buf, const float4 (&hreg)[HIT], const float4 (&wreg)[WIT]) {
 #pragma unroll
         for (int q = 0; q < HIT; ++q) {
-            const int v = tid + q * 256;
+            const int v = tid + q * NT;
             if (v < HALO_V) *reinterpret_cast<float4 *>(&in_lds[buf][(v >> 1) * kPitchB + (v & 1) * 16]) = hreg[q];
         }
 #pragma unroll
         for (int q = 0; q < WIT; ++q) {
-            const int v = tid + q * 256;
+            const int v = tid + q * NT;
             if (v < W_V) *reinterpret_cast<float4 *>(&w_lds[buf][(v >> 1) * kPitchB + (v & 1) * 16]) = wreg[q];
         }
     };
@@ -102,97 +111,171 @@ conv_mfma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
-    fetch(0);
-    stage(0);
-    __syncthreads();
-    int cur = 0;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        const bool more = chunk + 1 < nchunks;
-        if (more) fetch(chunk + 1);
-        const unsigned char *wl = &w_lds[cur][(wco * 32 + l31) * kPitchB + khalf * 16];
-        const unsigned char *il = &in_lds[cur][((wrow * 2) * HPX + l31) * kPitchB + khalf * 16];
+    // all fragments of a chunk are read before its MFMAs: one LDS round trip per chunk, and the wave's two output rows share
+    // the halo rows between them (KS+1 distinct rows of B fragments instead of 2*KS)
+    auto compute = [&](int buf) {
+        const unsigned char *wl = &w_lds[buf][(wco * 32 + l31) * kPitchB + khalf * 16];
+        const unsigned char *il = &in_lds[buf][((wrow * 2) * HPX + l31) * kPitchB + khalf * 16];
+        uint4 a[TAPS], b[KS + 1][KS];
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) a[tap] = *reinterpret_cast<const uint4 *>(wl + tap * BCO * kPitchB);
+#pragma unroll
+        for (int r = 0; r < KS + 1; ++r)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) b[r][kx] = *reinterpret_cast<const uint4 *>(il + (r * HPX + kx) * kPitchB);
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int ky = tap / KS, kx = tap % KS;
-            const uint4 a = *reinterpret_cast<const uint4 *>(wl + tap * BCO * kPitchB);
-            const uint4 b0 = *reinterpret_cast<const uint4 *>(il + ((ky)*HPX + kx) * kPitchB);
-            const uint4 b1 = *reinterpret_cast<const uint4 *>(il + ((ky + 1) * HPX + kx) * kPitchB);
-            acc[0] = frcnn_mfma_32x32x16_bf16(a, b0, acc[0]);
-            acc[1] = frcnn_mfma_32x32x16_bf16(a, b1, acc[1]);
+            acc[0] = frcnn_mfma_32x32x16_bf16(a[tap], b[ky][kx], acc[0]);
+            acc[1] = frcnn_mfma_32x32x16_bf16(a[tap], b[ky + 1][kx], acc[1]);
         }
-        if (more) stage(cur ^ 1);
+    };
+
+    fetch(0, hregA, wregA);
+    if (nchunks > 1) fetch(1, hregB, wregB);
+    stage(0, hregA, wregA);
+    __syncthreads();
+    for (int chunk = 0; chunk < nchunks; chunk += 2) {
+        // even chunk: LDS buffer 0 holds it, set B holds chunk+1
+        if (chunk + 2 < nchunks) fetch(chunk + 2, hregA, wregA);
+        compute(0);
+        if (chunk + 1 < nchunks) stage(1, hregB, wregB);
         __syncthreads();
-        cur ^= 1;
+        if (chunk + 1 >= nchunks) break;
+        // odd chunk: LDS buffer 1 holds it, set A holds chunk+2
+        if (chunk + 3 < nchunks) fetch(chunk + 3, hregB, wregB);
+        compute(1);
+        if (chunk + 2 < nchunks) stage(0, hregA, wregA);
+        __syncthreads();
     }
 
     // epilogue: register r of lane l = cout (r&3) + 8*(r>>2) + 4*khalf of pixel l31
     const int px = x0 + l31;
+    if (out_mode == 0 || out_mode == 2) {
+        // bf16 channel-blocked output: transpose through LDS so that each 16-cout block of a tile row leaves as one contiguous
+        // run of 32 px x 32 B (16-byte stores, consecutive lanes consecutive addresses)
+        unsigned char *ot = &w_lds[0][0];                             // the K loop is over: all waves passed its last barrier
+        static_assert(BROWS * 32 * OP <= (int)sizeof(w_lds), "epilogue tile must fit in the weight buffers");
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int py = y0 + wrow * 2 + j;
-        if (px >= W || py >= H) continue;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int co = co0 + wco * 32 + 8 * g + 4 * khalf;       // first of four consecutive couts
-            float v[4];
+            for (int g = 0; g < 4; ++g) {
+                const int col = wco * 32 + 8 * g + 4 * khalf;             // first of four consecutive couts (within the tile)
+                float v[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                v[t] = acc[j][4 * g + t] + (co + t < Cout ? bias[co + t] : 0.0f);
-                if (relu) v[t] = fmaxf(v[t], 0.0f);
-            }
-            if (out_mode == 0) {                                     // bf16 channel-last, CoutP channels per pixel
-                if (co < CoutP) {
-                    uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(y) + ((size_t)py * W + px) * CoutP + co) = pk;
+                for (int t = 0; t < 4; ++t) {
+                    v[t] = acc[j][4 * g + t] + (co0 + col + t < Cout ? bias[co0 + col + t] : 0.0f);
+                    if (relu) v[t] = fmaxf(v[t], 0.0f);
                 }
-            } else {                                                 // fp32 NCHW
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                *reinterpret_cast<uint2 *>(ot + ((wrow * 2 + j) * 32 + l31) * OP + col * 2) = pk;
+            }
+        __syncthreads();
+        if (out_mode == 2) {
+            // F.MaxPooling2D(2, 2) (cover_all) fused: tiles start at even rows / columns, so every 2x2 window lies inside the tile;
+            // y is [CoutP/16][ceil(H/2)][ceil(W/2)][16].  A maximum of bf16 values is a bf16 value: exact.
+            const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+            for (int v = tid; v < (BROWS / 2) * 16 * 8; v += NT) {
+                const int cbl = v / ((BROWS / 2) * 16 * 2), rem = v - cbl * ((BROWS / 2) * 16 * 2);
+                const int opix = rem >> 1, half = rem & 1;
+                const int orow = opix >> 4, ocol = opix & 15;
+                const int py = y0 + 2 * orow, qx = x0 + 2 * ocol, co = co0 + cbl * 16;
+                if (py >= H || qx >= W || co >= CoutP) continue;
+                const bool hasx = qx + 1 < W, hasy = py + 1 < H;
+                const unsigned char *t0 = ot + ((2 * orow) * 32 + 2 * ocol) * OP + (cbl * 2 + half) * 16;
+                uint4 q[4];
+                q[0] = *reinterpret_cast<const uint4 *>(t0);
+                q[1] = hasx ? *reinterpret_cast<const uint4 *>(t0 + OP) : q[0];
+                q[2] = hasy ? *reinterpret_cast<const uint4 *>(t0 + 32 * OP) : q[0];
+                q[3] = (hasx && hasy) ? *reinterpret_cast<const uint4 *>(t0 + 33 * OP) : q[0];
+                uint32_t o4[4];
+                const uint32_t *w0 = reinterpret_cast<const uint32_t *>(&q[0]), *w1 = reinterpret_cast<const uint32_t *>(&q[1]);
+                const uint32_t *w2 = reinterpret_cast<const uint32_t *>(&q[2]), *w3 = reinterpret_cast<const uint32_t *>(&q[3]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    uint32_t r = 0;
+#pragma unroll
+                    for (int hh = 0; hh < 2; ++hh) {
+                        const int sh = 16 * hh;
+                        const float a = __uint_as_float((w0[t] >> sh) << 16), b = __uint_as_float((w1[t] >> sh) << 16);
+                        const float c = __uint_as_float((w2[t] >> sh) << 16), d = __uint_as_float((w3[t] >> sh) << 16);
+                        r |= ((__float_as_uint(fmaxf(fmaxf(a, b), fmaxf(c, d))) >> 16) & 0xffffu) << sh;
+                    }
+                    o4[t] = r;
+                }
+                *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(y) + (((size_t)(co >> 4) * OH + (py >> 1)) * OW + (qx >> 1)) * 16 + half * 8) =
+                    make_uint4(o4[0], o4[1], o4[2], o4[3]);
+            }
+            return;
+        }
+        for (int v = tid; v < BROWS * 32 * 8; v += NT) {                  // 16-byte vectors: (cout block of 16, pixel, half)
+            const int cbl = v / (BROWS * 32 * 2), rem = v - cbl * (BROWS * 32 * 2);
+            const int pix = rem >> 1, half = rem & 1;
+            const int py = y0 + (pix >> 5), qx = x0 + (pix & 31), co = co0 + cbl * 16;
+            if (py < H && qx < W && co < CoutP)
+                *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(y) + (((size_t)(co >> 4) * H + py) * W + qx) * 16 + half * 8) =
+                    *reinterpret_cast<const uint4 *>(ot + pix * OP + (cbl * 2 + half) * 16);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int py = y0 + wrow * 2 + j;
+            if (px >= W || py >= H) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = co0 + wco * 32 + 8 * g + 4 * khalf;
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    if (co + t < Cout) reinterpret_cast<float *>(y)[(size_t)(co + t) * H * W + (size_t)py * W + px] = v[t];
+                    if (co + t < Cout) {
+                        float v = acc[j][4 * g + t] + bias[co + t];
+                        if (relu) v = fmaxf(v, 0.0f);
+                        reinterpret_cast<float *>(y)[(size_t)(co + t) * H * W + (size_t)py * W + px] = v;      // fp32 NCHW
+                    }
             }
         }
     }
 }
 
-// (Cout, Cin, k, k) fp32 -> [tap][CoutP][CinP] bf16, zero padded
+// (Cout, Cin, k, k) fp32 -> [CinP/16][tap][CoutP][16] bf16, zero padded
 __global__ void __launch_bounds__(256)
 pack_w_bf16_kernel(const float *__restrict__ w, int Cout, int Cin, int taps, int CoutP, int CinP, uint16_t *__restrict__ wp) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)taps * CoutP * CinP;
     if (i >= total) return;
-    const int ci = (int)(i % CinP), co = (int)((i / CinP) % CoutP), tap = (int)(i / ((size_t)CinP * CoutP));
+    const int c16 = (int)(i % 16), co = (int)((i / 16) % CoutP), tap = (int)((i / (16 * (size_t)CoutP)) % taps);
+    const int ci = (int)(i / (16 * (size_t)CoutP * taps)) * 16 + c16;
     wp[i] = (co < Cout && ci < Cin) ? f32_to_bf16(w[((size_t)co * Cin + ci) * taps + tap]) : (uint16_t)0;
 }
 
-// (C,H,W) fp32 -> (H,W,CP) bf16, channels C..CP-1 zero
+// (C,H,W) fp32 -> [CP/16][H*W][16] bf16, channels C..CP-1 zero
 __global__ void __launch_bounds__(256)
 nchw_to_nhwc_bf16_kernel(const float *__restrict__ x, int C, int HW, int CP, uint16_t *__restrict__ y) {
     const size_t total = (size_t)HW * CP;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % CP);
-        const size_t p = i / CP;
+        const int c16 = (int)(i % 16);
+        const size_t p = (i / 16) % HW;
+        const int c = (int)(i / (16 * (size_t)HW)) * 16 + c16;
         y[i] = c < C ? f32_to_bf16(x[(size_t)c * HW + p]) : (uint16_t)0;
     }
 }
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
-// F.MaxPooling2D(2, 2), cover_all, channel-last bf16: one thread = one output pixel x 8 channels (16-byte vectors)
+// F.MaxPooling2D(2, 2), cover_all, channel-blocked bf16 [C/16][H][W][16]: one thread = one output pixel x 8 channels (16 bytes)
 __global__ void __launch_bounds__(256)
 maxpool2x2_bf16_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ y, int C, int H, int W, int OH, int OW) {
-    const int cv = C / 8;
-    const size_t total = (size_t)OH * OW * cv;
+    const size_t total = (size_t)(C / 16) * OH * OW * 2;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int c8 = (int)(i % cv), ow = (int)((i / cv) % OW), oh = (int)(i / ((size_t)cv * OW));
+        const int half = (int)(i & 1), ow = (int)((i >> 1) % OW), oh = (int)(((i >> 1) / OW) % OH), cb = (int)((i >> 1) / ((size_t)OW * OH));
         const bool hasx = 2 * ow + 1 < W, hasy = 2 * oh + 1 < H;
-        const uint16_t *p = x + (((size_t)(2 * oh) * W + 2 * ow) * C + c8 * 8);
+        const uint16_t *p = x + ((((size_t)cb * H + 2 * oh) * W + 2 * ow) * 16 + half * 8);
         uint4 q[4];
         q[0] = *reinterpret_cast<const uint4 *>(p);
-        q[1] = hasx ? *reinterpret_cast<const uint4 *>(p + C) : q[0];
-        q[2] = hasy ? *reinterpret_cast<const uint4 *>(p + (size_t)W * C) : q[0];
-        q[3] = (hasx && hasy) ? *reinterpret_cast<const uint4 *>(p + (size_t)W * C + C) : q[0];
+        q[1] = hasx ? *reinterpret_cast<const uint4 *>(p + 16) : q[0];
+        q[2] = hasy ? *reinterpret_cast<const uint4 *>(p + (size_t)W * 16) : q[0];
+        q[3] = (hasx && hasy) ? *reinterpret_cast<const uint4 *>(p + (size_t)W * 16 + 16) : q[0];
         uint32_t out[4];
         const uint32_t *w0 = reinterpret_cast<const uint32_t *>(&q[0]), *w1 = reinterpret_cast<const uint32_t *>(&q[1]);
         const uint32_t *w2 = reinterpret_cast<const uint32_t *>(&q[2]), *w3 = reinterpret_cast<const uint32_t *>(&q[3]);
@@ -209,11 +292,11 @@ maxpool2x2_bf16_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ y,
             }
             out[t] = r;
         }
-        *reinterpret_cast<uint4 *>(y + (((size_t)oh * OW + ow) * C + c8 * 8)) = make_uint4(out[0], out[1], out[2], out[3]);
+        *reinterpret_cast<uint4 *>(y + ((((size_t)cb * OH + oh) * OW + ow) * 16 + half * 8)) = make_uint4(out[0], out[1], out[2], out[3]);
     }
 }
 
-// (H,W,CP) bf16 -> (C,H,W) fp32 through a 64x65 LDS tile (both sides coalesced)
+// [CP/16][H*W][16] bf16 -> (C,H,W) fp32 through a 64x65 LDS tile
 __global__ void __launch_bounds__(256)
 nhwc_bf16_to_nchw_kernel(const uint16_t *__restrict__ x, int C, int HW, int CP, float *__restrict__ y) {
     __shared__ float tile[64][65];
@@ -221,7 +304,7 @@ nhwc_bf16_to_nchw_kernel(const uint16_t *__restrict__ x, int C, int HW, int CP, 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     for (int i = ty; i < 64; i += 4) {
         const int p = p0 + i, c = c0 + tx;
-        tile[i][tx] = (p < HW && c < C) ? bf16_to_f32(x[(size_t)p * CP + c]) : 0.0f;
+        tile[i][tx] = (p < HW && c < C) ? bf16_to_f32(x[((size_t)(c >> 4) * HW + p) * 16 + (c & 15)]) : 0.0f;
     }
     __syncthreads();
     for (int i = ty; i < 64; i += 4) {
@@ -265,13 +348,19 @@ int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bi
                     int out_mode, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
-    if ((ksize != 1 && ksize != 3) || (out_mode != 0 && out_mode != 1)) return FRCNN_ERR_INVALID;
+    if ((ksize != 1 && ksize != 3) || out_mode < 0 || out_mode > 2 || (out_mode == 2 && !relu)) return FRCNN_ERR_INVALID;
     const int CinP = frcnn_bf16_padded_channels(Cin), CoutP = frcnn_bf16_padded_channels(Cout);
     if ((size_t)H * W * CinP * 2 >= (1ull << 31) || (size_t)ksize * ksize * CoutP * CinP * 2 >= (1ull << 31)) return FRCNN_ERR_INVALID;
-    const int xtiles = frcnn_cdiv(W, 32), ytiles = frcnn_cdiv(H, 4), cotiles = frcnn_cdiv(CoutP, 64);
-    const dim3 grid(xtiles * ytiles * cotiles), blk(256);
-    if (ksize == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3>), grid, blk, 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<1>), grid, blk, 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
+    const int xtiles = frcnn_cdiv(W, 32), cotiles = frcnn_cdiv(CoutP, 64);
+    // 8-row tiles (8 waves) carry 1.7x the MFMA work per staged byte but measured no faster than 4-row tiles on any VGG layer
+    // (scripts/conv_bf16_sweep.py, r01); kept as a tuning hook: FRCNN_BF16_RP=4 selects them.
+    const char *rp_env = getenv("FRCNN_BF16_RP");
+    const bool big = rp_env && atoi(rp_env) == 4;
+    const int ytiles = frcnn_cdiv(H, big ? 8 : 4);
+    const dim3 grid(xtiles * ytiles * cotiles);
+    if (ksize == 3 && big) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3, 4>), grid, dim3(512), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
+    else if (ksize == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3, 2>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<1, 2>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
     return frcnn_launch_status();
 }
 
@@ -279,7 +368,7 @@ int frcnn_maxpool2x2_bf16(const uint16_t *x, uint16_t *y, int C, int H, int W, v
     if (!x || !y || C < 16 || (C % 16) != 0 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;
     const size_t total = (size_t)OH * OW * (C / 8);
-    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(maxpool2x2_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, y, C, H, W, OH, OW);
     return frcnn_launch_status();
 }

@@ -39,9 +39,9 @@ class Conv3x3(object):
         """conv + ReLU + the following F.MaxPooling2D(2,2) in one launch (the pool lives in the conv kernel's epilogue)."""
         return self.rt.conv_ex(x, self.Wp, self.b, 3, act=4)
 
-    def bf16(self, x_nhwc, relu=True, out_f32_nchw=False):
-        """x (H,W,CinP) bf16 channel-last -> (H,W,CoutP) bf16 (or fp32 NCHW)."""
-        return self.rt.conv_bf16(x_nhwc, self.Wb, self.b, self.cin, self.cout, 3, relu=relu, out_f32_nchw=out_f32_nchw)
+    def bf16(self, x_blk, relu=True, out_f32_nchw=False, pool=False):
+        """x [CinP/16][H][W][16] bf16 (channel-blocked) -> [CoutP/16][H][W][16] bf16 (or fp32 NCHW)."""
+        return self.rt.conv_bf16(x_blk, self.Wb, self.b, self.cin, self.cout, 3, relu=relu, out_f32_nchw=out_f32_nchw, pool=pool)
 
 
 class VGG16Prev(object):
@@ -92,18 +92,23 @@ class VGG16Prev(object):
 
 
     def _call_bf16(self, x, timer):
-        """bf16 chain: fp32 NCHW image -> channel-last bf16 -> 13 bf16 convs / 4 pools -> conv5_3 back as fp32 NCHW."""
+        """bf16 chain: fp32 NCHW image -> channel-blocked bf16 -> 13 bf16 convs / 4 pools -> conv5_3 back as fp32 NCHW."""
         rt = self.rt
         h = rt.bf16_from_nchw(x)
-        n_pool, cout = 0, int(x.shape[1])
-        for l in self.layers:
+        n_pool, cout, skip = 0, int(x.shape[1]), False
+        for idx, l in enumerate(self.layers):
             if l == "pool":
-                h = rt.maxpool2x2_bf16(h)
                 n_pool += 1
+                if skip:
+                    skip = False
+                    continue
+                h = rt.maxpool2x2_bf16(h)
                 if timer:
                     timer.mark("pool%d" % n_pool)
             else:
-                h = self.links[l[0]].bf16(h, relu=True)
+                fuse = self.fuse_pool and idx + 1 < len(self.layers) and self.layers[idx + 1] == "pool"
+                h = self.links[l[0]].bf16(h, relu=True, pool=fuse)
+                skip = fuse
                 cout = l[2]
                 if timer:
                     timer.mark(l[0])

@@ -321,38 +321,43 @@ class Runtime(object):
     def bf16_pack_conv_w(self, w, ksize=3):
         m, L = self.mem, self.lib
         co, ci = int(w.shape[0]), int(w.shape[1])
-        wp = m.empty((ksize * ksize, self.bf16_pad(co), self.bf16_pad(ci)), "i16")
+        wp = m.empty((self.bf16_pad(ci) // 16, ksize * ksize, self.bf16_pad(co), 16), "i16")
         _lib.check(L.frcnn_bf16_pack_conv_w(m.ptr(w), co, ci, int(ksize), m.ptr(wp), m.stream()), "frcnn_bf16_pack_conv_w")
         return wp
 
     def bf16_from_nchw(self, x):
         m, L = self.mem, self.lib
         C, H, W = [int(v) for v in x.shape[-3:]]
-        y = m.empty((H, W, self.bf16_pad(C)), "i16")
+        y = m.empty((self.bf16_pad(C) // 16, H, W, 16), "i16")          # channel-blocked: [C/16][H][W][16]
         _lib.check(L.frcnn_bf16_from_nchw_f32(m.ptr(x), C, H, W, m.ptr(y), m.stream()), "frcnn_bf16_from_nchw_f32")
         return y
 
     def bf16_to_nchw(self, x, C):
         m, L = self.mem, self.lib
-        H, W = int(x.shape[0]), int(x.shape[1])
+        H, W = int(x.shape[1]), int(x.shape[2])
         y = m.empty((1, int(C), H, W), "f32")
         _lib.check(L.frcnn_bf16_to_nchw_f32(m.ptr(x), int(C), H, W, m.ptr(y), m.stream()), "frcnn_bf16_to_nchw_f32")
         return y
 
-    def conv_bf16(self, x, w_packed, bias, cin, cout, ksize=3, relu=True, out_f32_nchw=False):
-        """x (H,W,CinP) bf16 -> (H,W,CoutP) bf16, or (1,Cout,H,W) fp32 when out_f32_nchw."""
+    def conv_bf16(self, x, w_packed, bias, cin, cout, ksize=3, relu=True, out_f32_nchw=False, pool=False):
+        """x [CinP/16][H][W][16] bf16 -> [CoutP/16][H][W][16] bf16, or (1,Cout,H,W) fp32 when out_f32_nchw."""
         m, L = self.mem, self.lib
-        H, W = int(x.shape[0]), int(x.shape[1])
-        assert int(x.shape[2]) == self.bf16_pad(cin) and int(w_packed.shape[2]) == self.bf16_pad(cin)
-        y = m.empty((1, int(cout), H, W), "f32") if out_f32_nchw else m.empty((H, W, self.bf16_pad(cout)), "i16")
+        H, W = int(x.shape[1]), int(x.shape[2])
+        assert int(x.shape[0]) * 16 == self.bf16_pad(cin) and int(w_packed.shape[0]) * 16 == self.bf16_pad(cin)
+        if pool:                                         # ReLU + 2x2 ceil-mode max-pool fused into the epilogue (out_mode 2)
+            y = m.empty((self.bf16_pad(cout) // 16, (H + 1) // 2, (W + 1) // 2, 16), "i16")
+        else:
+            y = m.empty((1, int(cout), H, W), "f32") if out_f32_nchw else m.empty((self.bf16_pad(cout) // 16, H, W, 16), "i16")
+        mode = 2 if pool else int(bool(out_f32_nchw))
         _lib.check(L.frcnn_conv_bf16(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(y), int(cin), int(cout), H, W, int(ksize),
-                                     int(bool(relu)), int(bool(out_f32_nchw)), m.stream()), "frcnn_conv_bf16")
+                                     int(bool(relu)), mode, m.stream()), "frcnn_conv_bf16")
         return y
 
     def maxpool2x2_bf16(self, x):
         m, L = self.mem, self.lib
-        H, W, C = [int(v) for v in x.shape]
-        y = m.empty(((H + 1) // 2, (W + 1) // 2, C), "i16")
+        CB, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
+        C = CB * 16
+        y = m.empty((CB, (H + 1) // 2, (W + 1) // 2, 16), "i16")
         _lib.check(L.frcnn_maxpool2x2_bf16(m.ptr(x), m.ptr(y), C, H, W, m.stream()), "frcnn_maxpool2x2_bf16")
         return y
 

@@ -176,9 +176,10 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
 /* ---- bf16 convolution stack (BASELINE config 3: bf16 convs / fp32 RoI) -----------------------------------
  * Same reference interface as the fp32 stack (L.Convolution2D + F.relu, F.MaxPooling2D: models/vgg16.py:39-68,
  * region_proposal_network.py:53-57); operands rounded to bf16 (nearest even), fp32 accumulation on
- * v_mfma_f32_32x32x16_bf16.  Activations are channel-last (H,W,CP) bf16, CP = frcnn_bf16_padded_channels(C) (multiple
- * of 16, padding channels zero); weights packed [tap][CoutP][CinP] bf16 by frcnn_bf16_pack_conv_w from Chainer's
- * (Cout,Cin,k,k) fp32.  out_mode 0: y = (H,W,CoutP) bf16; out_mode 1: y = (Cout,H,W) fp32 NCHW (what RoI pooling, the
+ * v_mfma_f32_32x32x16_bf16.  Activations are channel-blocked [CP/16][H][W][16] bf16, CP = frcnn_bf16_padded_channels(C)
+ * (multiple of 16, padding channels zero); weights packed [CinP/16][tap][CoutP][16] bf16 by frcnn_bf16_pack_conv_w from
+ * Chainer's (Cout,Cin,k,k) fp32.  out_mode 0: y = [CoutP/16][H][W][16] bf16; out_mode 2: the same with
+ * F.MaxPooling2D(2,2) (cover_all) fused behind the ReLU, y = [CoutP/16][ceil(H/2)][ceil(W/2)][16]; out_mode 1: y = (Cout,H,W) fp32 NCHW (what RoI pooling, the
  * 18-way softmax and the proposal kernels consume).  uint16_t = raw bf16 bits. */
 int frcnn_bf16_padded_channels(int c);
 int frcnn_bf16_pack_conv_w(const float *w, int Cout, int Cin, int ksize, uint16_t *w_packed, void *stream);

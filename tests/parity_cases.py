@@ -352,6 +352,12 @@ def from_bf16_bits(b):
     return (b.view(np.uint16).astype(np.uint32) << 16).view(np.float32)
 
 
+def blocked_to_hwc(a):
+    """[C/16][H][W][16] -> (H, W, C): the channel-blocked layout of the bf16 kernels, flattened for comparisons."""
+    cb, h, w, _ = a.shape
+    return np.ascontiguousarray(a.transpose(1, 2, 0, 3)).reshape(h, w, cb * 16)
+
+
 def check_conv_bf16(rt, Cin, Cout, H, W, ksize=3, relu=True, seed=0):
     rs = np.random.RandomState(seed)
     x = rs.randn(1, Cin, H, W).astype(np.float32)
@@ -361,7 +367,7 @@ def check_conv_bf16(rt, Cin, Cout, H, W, ksize=3, relu=True, seed=0):
     wb, _ = to_bf16(w)
     xd = rt.bf16_from_nchw(dev(rt, x))
     cp = rt.bf16_pad(Cin)
-    got_bits = host(rt, xd)
+    got_bits = blocked_to_hwc(host(rt, xd))
     assert np.array_equal(got_bits[:, :, :Cin], xbits[0].transpose(1, 2, 0)) and not got_bits[:, :, Cin:].any()    # conversion: exact
     want = O.conv2d(xb, wb, b, ksize // 2)                       # the kernel's operands exactly; fp32 accumulation
     if relu:
@@ -370,7 +376,7 @@ def check_conv_bf16(rt, Cin, Cout, H, W, ksize=3, relu=True, seed=0):
     y32 = host(rt, rt.conv_bf16(xd, wpk, dev(rt, b), Cin, Cout, ksize, relu=relu, out_f32_nchw=True))
     scale = max(np.abs(want).max(), 1e-6)
     assert np.abs(y32 - want).max() <= 2e-5 * scale, np.abs(y32 - want).max() / scale           # accumulation order only
-    y16 = host(rt, rt.conv_bf16(xd, wpk, dev(rt, b), Cin, Cout, ksize, relu=relu))
+    y16 = blocked_to_hwc(host(rt, rt.conv_bf16(xd, wpk, dev(rt, b), Cin, Cout, ksize, relu=relu)))
     got = from_bf16_bits(y16)
     assert got.shape == (H, W, rt.bf16_pad(Cout)) and not got[:, :, Cout:].any()
     want_hwc = want[0].transpose(1, 2, 0)
@@ -379,11 +385,24 @@ def check_conv_bf16(rt, Cin, Cout, H, W, ksize=3, relu=True, seed=0):
     assert np.array_equal(back[0], got[:, :, :Cout].transpose(2, 0, 1))
 
 
+def check_conv_bf16_pool(rt, Cin, Cout, H, W, seed=0):
+    """out_mode 2: bf16 conv + ReLU + 2x2 ceil-mode pool in one launch == the two separate bf16 launches, bit for bit."""
+    rs = np.random.RandomState(seed)
+    x = rs.randn(1, Cin, H, W).astype(np.float32)
+    w = (rs.randn(Cout, Cin, 3, 3) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    b = dev(rt, (rs.randn(Cout) * 0.1).astype(np.float32))
+    xd = rt.bf16_from_nchw(dev(rt, x))
+    wpk = rt.bf16_pack_conv_w(dev(rt, w), 3)
+    fused = host(rt, rt.conv_bf16(xd, wpk, b, Cin, Cout, 3, relu=True, pool=True))
+    sep = host(rt, rt.maxpool2x2_bf16(rt.conv_bf16(xd, wpk, b, Cin, Cout, 3, relu=True)))
+    assert fused.shape == sep.shape and np.array_equal(fused, sep)
+
+
 def check_maxpool_bf16(rt, C, H, W, seed=0):
     rs = np.random.RandomState(seed)
     x = rs.randn(1, C, H, W).astype(np.float32)
     xb, _ = to_bf16(x)
-    y = host(rt, rt.maxpool2x2_bf16(rt.bf16_from_nchw(dev(rt, x))))
+    y = blocked_to_hwc(host(rt, rt.maxpool2x2_bf16(rt.bf16_from_nchw(dev(rt, x)))))
     want = O.max_pool_2x2(xb)[0].transpose(1, 2, 0)
     assert np.array_equal(from_bf16_bits(y)[:, :, :C], want)
 

@@ -240,6 +240,11 @@ def test_conv_bf16(rt, cin, cout, h, w, ks):
     P.check_conv_bf16(rt, cin, cout, h, w, ksize=ks, relu=(ks == 3))
 
 
+def test_conv_bf16_pool_fused(rt):
+    P.check_conv_bf16_pool(rt, 64, 64, 120, 200)
+    P.check_conv_bf16_pool(rt, 256, 512, 75, 125, seed=1)
+
+
 def test_maxpool_bf16(rt):
     P.check_maxpool_bf16(rt, 64, 75, 125)
     P.check_maxpool_bf16(rt, 128, 300, 500)

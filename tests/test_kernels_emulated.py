@@ -133,6 +133,11 @@ def test_conv_bf16(rt):
     P.check_conv_bf16(rt, 32, 54, 5, 40, ksize=1, relu=False, seed=2)   # the stacked RPN heads: 54 real couts of 64
 
 
+def test_conv_bf16_pool_fused(rt):
+    P.check_conv_bf16_pool(rt, 16, 64, 9, 37)            # odd H, W: clipped windows
+    P.check_conv_bf16_pool(rt, 16, 128, 8, 64, seed=1)
+
+
 def test_maxpool_bf16(rt):
     P.check_maxpool_bf16(rt, 16, 7, 9)
     P.check_maxpool_bf16(rt, 32, 8, 6, seed=1)
@@ -155,3 +160,9 @@ def test_conv_relu_pool_fused(rt):
 def test_img_preprocessing(rt):
     P.check_preprocess(rt, 37, 50)            # scale 600/37: upsampling, both clamps
     P.check_preprocess(rt, 60, 200, seed=1)   # max_size rule: scale 1000/200
+
+
+def test_conv_bf16_eight_row_tiles(rt, monkeypatch):
+    monkeypatch.setenv("FRCNN_BF16_RP", "4")                        # force the 8-wave / 8-row decomposition
+    P.check_conv_bf16(rt, 16, 64, 13, 37, seed=3)
+    P.check_conv_bf16(rt, 32, 128, 8, 33, seed=4)
