@@ -25,6 +25,7 @@
 // with -ffp-contract=off), IEEE division, exp evaluated in double and rounded to fp32, IoU threshold test
 // `(double)iou >= thresh` (cpu_nms.pyx:18,66).
 #include "frcnn_common.h"
+#include <frcnn_sync.h>     // angle brackets: shadowed by the test emulator
 
 namespace {
 
@@ -350,6 +351,109 @@ nms_scan_kernel(const unsigned long long *__restrict__ mask, int pitch, const in
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same sequential pass on ONE wave, for up to kWaveChunks chunks (16384 boxes: both ProposalLayer modes).  The
+// `removed` bitmap lives in registers (lane l holds words l, l+64, l+128, l+192), the word of the current chunk is fetched with
+// v_readlane, kept rows are OR-ed in four at a time (their loads are independent and in flight together) and the next chunk's
+// diagonal word is prefetched -- no LDS, no atomics, no barriers (76 -> 54 us for 6000 boxes; what remains is the dependent
+// instruction chain of a lone wave, ~1200 cycles per chunk: taking the next chunk's word off the memory path as well -- from
+// prefetched super-diagonal words -- measured no faster).
+constexpr int kWaveChunks = 256;
+
+template <int NJ>                          // bitmap words per lane: chunks <= 64 * NJ
+__global__ void __launch_bounds__(64)
+nms_scan_wave_kernel(const unsigned long long *__restrict__ mask, int pitch, const int *__restrict__ counters_in, int top_k,
+                     int max_out, const int32_t *__restrict__ order, const float *__restrict__ sorted_boxes,
+                     const float *__restrict__ sorted_scores, int32_t *__restrict__ keep_pos, int32_t *__restrict__ out_index,
+                     float *__restrict__ out_boxes, float *__restrict__ out_scores, int32_t *__restrict__ n_out,
+                     int out_capacity, size_t slab, size_t out_gs) {
+    const int gz = blockIdx.z;
+    counters_in = slab_ptr(counters_in, slab); mask = slab_ptr(mask, slab); order = slab_ptr(order, slab);
+    sorted_boxes = slab_ptr(sorted_boxes, slab); sorted_scores = slab_ptr(sorted_scores, slab); keep_pos = slab_ptr(keep_pos, slab);
+    if (out_index) out_index += gz * out_gs;
+    if (out_boxes) out_boxes += gz * out_gs * 4;
+    if (out_scores) out_scores += gz * out_gs;
+    n_out += gz;
+    int m = counters_in[0];
+    if (top_k > 0 && top_k < m) m = top_k;
+    const int limit = (max_out > 0 && max_out < m) ? max_out : m;
+    const int n_chunks = (m + kChunk - 1) / kChunk;
+    const int lane = threadIdx.x;
+    unsigned long long rem[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) rem[j] = 0ull;
+    int n_kept = 0;
+    unsigned long long diag_next = (lane < m) ? mask[(size_t)lane * pitch] : 0ull;
+    for (int c = 0; c < n_chunks && n_kept < limit; ++c) {
+        const unsigned long long diag = diag_next;
+        if (c + 1 < n_chunks) {
+            const int r1 = (c + 1) * kChunk + lane;
+            diag_next = (r1 < m) ? mask[(size_t)r1 * pitch + c + 1] : 0ull;          // lands while this chunk is resolved
+        }
+        unsigned long long sel = rem[0];
+#pragma unroll
+        for (int j = 1; j < NJ; ++j) sel = ((c >> 6) == j) ? rem[j] : sel;
+        const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sel, c & 63);
+        const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sel >> 32), c & 63);
+        const int in_chunk = min(kChunk, m - c * kChunk);
+        const unsigned long long valid = in_chunk == 64 ? ~0ull : ((1ull << in_chunk) - 1ull);
+        unsigned long long alive = ~(((unsigned long long)rhi << 32) | rlo) & valid;
+        const int dlo = (int)(uint32_t)diag, dhi = (int)(uint32_t)(diag >> 32);
+        unsigned long long kept = 0ull;
+        int budget = limit - n_kept;
+        while (alive != 0ull && budget > 0) {
+            const int i = __ffsll((long long)alive) - 1;
+            kept |= 1ull << i;
+            --budget;
+            const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane(dlo, i);
+            const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane(dhi, i);
+            alive &= ~(((unsigned long long)shi << 32) | slo);
+            alive &= ~(1ull << i);
+        }
+        if ((kept >> lane) & 1ull) keep_pos[n_kept + __popcll(kept & ((1ull << lane) - 1ull))] = c * kChunk + lane;
+        n_kept += __popcll(kept);
+        if (n_kept < limit) {
+            unsigned long long kk = kept;
+            while (kk != 0ull) {                      // four kept rows per round; a short round repeats its first row (OR is idempotent)
+                int idx[4];
+                idx[0] = __ffsll((long long)kk) - 1;
+                kk &= kk - 1ull;
+#pragma unroll
+                for (int q = 1; q < 4; ++q) {
+                    idx[q] = kk != 0ull ? __ffsll((long long)kk) - 1 : idx[0];
+                    kk &= kk - 1ull;               // 0 stays 0
+                }
+                unsigned long long v[4][NJ];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned long long *row = mask + (size_t)(c * kChunk + idx[q]) * pitch;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int w = lane + 64 * j;
+                        v[q][j] = (w > c && w < n_chunks) ? row[w] : 0ull;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) rem[j] |= (v[0][j] | v[1][j]) | (v[2][j] | v[3][j]);
+            }
+        }
+    }
+    if (lane == 0) n_out[0] = n_kept;
+    frcnn_drain_vmem();                               // keep_pos was written by other lanes of this wave
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < n_kept; k += 64) {
+        const int pos = keep_pos[k];
+        if (out_index) out_index[k] = order[pos];
+        if (out_boxes) reinterpret_cast<float4 *>(out_boxes)[k] = reinterpret_cast<const float4 *>(sorted_boxes)[pos];
+        if (out_scores) out_scores[k] = sorted_scores[pos];
+    }
+    for (int k = n_kept + lane; k < out_capacity; k += 64) {
+        if (out_index) out_index[k] = -1;
+        if (out_boxes) reinterpret_cast<float4 *>(out_boxes)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (out_scores) out_scores[k] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 struct Layout {   // carve-up of the caller's workspace (per group)
     size_t counters, keys, boxes, scores, order, sboxes, sscores, keep_pos, mask, total;
     int n_pad, n_tiles, m_max, pitch;
@@ -411,9 +515,18 @@ int frcnn_nms_batched(const float *dets, int groups, int n, double thresh, int m
                        dets + 4, 5, 0, counters, order, sboxes, sscores, (size_t)n * 5, gs);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(frcnn_cdiv(L.pitch, 4), L.pitch, groups), blk, 0, stream, sboxes, counters, 0, thresh,
                        mask, L.pitch, gs);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1, 1, groups), blk, 0, stream, mask, L.pitch, counters, 0, max_out, order, sboxes,
-                       sscores, keep_pos, keep, (float *)nullptr, (float *)nullptr, n_keep,
-                       (max_out > 0 && max_out < n) ? max_out : n, gs, (size_t)n);
+    if (L.pitch <= 128)
+        hipLaunchKernelGGL(nms_scan_wave_kernel<2>, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, 0, max_out, order, sboxes,
+                           sscores, keep_pos, keep, (float *)nullptr, (float *)nullptr, n_keep,
+                           (max_out > 0 && max_out < n) ? max_out : n, gs, (size_t)n);
+    else if (L.pitch <= kWaveChunks)
+        hipLaunchKernelGGL(nms_scan_wave_kernel<4>, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, 0, max_out, order, sboxes,
+                           sscores, keep_pos, keep, (float *)nullptr, (float *)nullptr, n_keep,
+                           (max_out > 0 && max_out < n) ? max_out : n, gs, (size_t)n);
+    else
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(1, 1, groups), blk, 0, stream, mask, L.pitch, counters, 0, max_out, order, sboxes,
+                           sscores, keep_pos, keep, (float *)nullptr, (float *)nullptr, n_keep,
+                           (max_out > 0 && max_out < n) ? max_out : n, gs, (size_t)n);
     return frcnn_launch_status();
 }
 
@@ -460,9 +573,18 @@ int frcnn_proposals(const float *rpn_cls_prob, const float *rpn_bbox_pred, int A
                        pre_nms_top_n, counters, order, sboxes, sscores, (size_t)0, (size_t)0);
     hipLaunchKernelGGL(nms_mask_kernel, dim3(frcnn_cdiv(L.pitch, 4), L.pitch), blk, 0, stream, sboxes, counters, pre_nms_top_n,
                        nms_thresh, mask, L.pitch, (size_t)0);
-    hipLaunchKernelGGL(nms_scan_kernel, dim3(1), blk, 0, stream, mask, L.pitch, counters, pre_nms_top_n, post_nms_top_n, order,
-                       sboxes, sscores, keep_pos, src_index, rois, probs, n_out,
-                       (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
+    if (L.pitch <= 128)
+        hipLaunchKernelGGL(nms_scan_wave_kernel<2>, dim3(1), dim3(64), 0, stream, mask, L.pitch, counters, pre_nms_top_n, post_nms_top_n, order,
+                           sboxes, sscores, keep_pos, src_index, rois, probs, n_out,
+                           (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
+    else if (L.pitch <= kWaveChunks)
+        hipLaunchKernelGGL(nms_scan_wave_kernel<4>, dim3(1), dim3(64), 0, stream, mask, L.pitch, counters, pre_nms_top_n, post_nms_top_n, order,
+                           sboxes, sscores, keep_pos, src_index, rois, probs, n_out,
+                           (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
+    else
+        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), blk, 0, stream, mask, L.pitch, counters, pre_nms_top_n, post_nms_top_n, order,
+                           sboxes, sscores, keep_pos, src_index, rois, probs, n_out,
+                           (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
     return frcnn_launch_status();
 }
 

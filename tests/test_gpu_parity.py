@@ -30,6 +30,11 @@ def test_nms_random(rt):
     P.check_nms_random(rt, n=3000, seeds=(0, 1, 2))
 
 
+def test_nms_above_single_wave_capacity(rt):
+    """> 16384 boxes: the multi-wave scan kernel (LDS bitmap) instead of the register-resident single-wave one."""
+    P.check_nms_random(rt, n=17000, seeds=(0,), thrs=(0.5,))
+
+
 def test_nms_batched(rt):
     P.check_nms_batched(rt, groups=20, n=300)
 
