@@ -65,6 +65,12 @@ SIGNATURES = {
     "frcnn_anchor_target_workspace_bytes": (_S, [_I, _I, _I, _I]),
     "frcnn_anchor_target": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _I, _P, _P, _P, _P, _P, _P, _S, _P]),
     "frcnn_rpn_loss": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _P, _P, _P, _P]),
+    "frcnn_rcnn_loss": (_I, [_P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
+    "frcnn_mul_f32": (_I, [_P, _P, _S, _P, _P]),
+    "frcnn_add_f32": (_I, [_P, _P, _S, _P, _P]),
+    "frcnn_relu_bwd_f32": (_I, [_P, _P, _S, _P]),
+    "frcnn_gather_rows_f32": (_I, [_P, _P, _I, _I, _P, _P]),
+    "frcnn_scatter_rows_f32": (_I, [_P, _P, _I, _I, _P, _I, _P]),
     "frcnn_maxpool2x2_bwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "frcnn_bias_grad_workspace_bytes": (_S, [_I, _I]),
     "frcnn_bias_grad_f32": (_I, [_P, _I, _I, _P, _P, _S, _P]),

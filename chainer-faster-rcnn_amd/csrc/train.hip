@@ -429,6 +429,83 @@ transpose_kernel(const float *__restrict__ src, int R, int Cc, float *__restrict
         if (c0 + i < Cc && r0 + tx < R) dst[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// Stage-2 (rcnn_train) losses and gradients, models/faster_rcnn.py:152-164: F.softmax_cross_entropy(cls_score, labels) (mean over
+// the R sampled RoIs), F.accuracy, F.huber_loss(bbox_pred, targets, delta) summed per RoI and divided by R; gradients of
+// loss_cls + loss_bbox.  One workgroup, fixed reduction tree.  out[0..2] = loss_cls, loss_bbox, cls_accuracy.
+__global__ void __launch_bounds__(256)
+rcnn_loss_kernel(const float *__restrict__ cls_score, const float *__restrict__ bbox_pred, const int32_t *__restrict__ labels,
+                 const float *__restrict__ targets, int R, int ncls, float delta, float *__restrict__ out, float *__restrict__ dcls,
+                 float *__restrict__ dbbox) {
+    __shared__ double red[3][256];
+    const int tid = threadIdx.x;
+    double s_cls = 0.0, s_box = 0.0, s_acc = 0.0;
+    const float inv_r = 1.0f / (float)(R > 0 ? R : 1);
+    for (int r = tid; r < R; r += 256) {
+        const float *s = cls_score + (size_t)r * ncls;
+        const int lab = labels[r];
+        float m = s[0];
+        int arg = 0;
+        for (int c = 1; c < ncls; ++c) if (s[c] > m) { m = s[c]; arg = c; }
+        float z = 0.0f;
+        for (int c = 0; c < ncls; ++c) z += expf(s[c] - m);
+        const float logz = m + logf(z);
+        s_cls += (double)(logz - s[lab]);
+        s_acc += arg == lab ? 1.0 : 0.0;
+        if (dcls)
+            for (int c = 0; c < ncls; ++c) dcls[(size_t)r * ncls + c] = (expf(s[c] - m) / z - (c == lab ? 1.0f : 0.0f)) * inv_r;
+        for (int c = 0; c < 4 * ncls; ++c) {
+            const float d = bbox_pred[(size_t)r * 4 * ncls + c] - targets[(size_t)r * 4 * ncls + c];
+            const float ad = fabsf(d);
+            s_box += (double)(ad < delta ? 0.5f * d * d : delta * (ad - 0.5f * delta));
+            if (dbbox) dbbox[(size_t)r * 4 * ncls + c] = (ad < delta ? d : (d > 0.0f ? delta : -delta)) * inv_r;
+        }
+    }
+    red[0][tid] = s_cls; red[1][tid] = s_box; red[2][tid] = s_acc;
+    __syncthreads();
+    for (int q = 128; q > 0; q >>= 1) {
+        if (tid < q) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) red[k][tid] += red[k][tid + q];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double n = R > 0 ? (double)R : 1.0;
+        out[0] = (float)(red[0][0] / n);
+        out[1] = (float)(red[1][0] / n);
+        out[2] = (float)(red[2][0] / n);
+    }
+}
+
+// y = a * b (F.dropout forward with b = the 0 / 1/(1-ratio) mask, and its backward); y may alias a
+__global__ void __launch_bounds__(256)
+mul_kernel(const float *__restrict__ a, const float *__restrict__ b, size_t n, float *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = a[i] * b[i];
+}
+
+__global__ void __launch_bounds__(256)
+add_kernel(const float *__restrict__ a, const float *__restrict__ b, size_t n, float *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = a[i] + b[i];
+}
+
+// F.relu backward: g = (out > 0) ? g : 0, in place
+__global__ void __launch_bounds__(256)
+relu_bwd_kernel(float *__restrict__ g, const float *__restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) g[i] = out[i] > 0.0f ? g[i] : 0.0f;
+}
+
+// dst[i][:] = src[idx[i]][:]  (x[keep_inds]) and its adjoint dst[idx[i]][:] = src[i][:] into a zero-filled dst (indices unique)
+__global__ void __launch_bounds__(256)
+gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ idx, int n, int cols, float *__restrict__ dst, int scatter) {
+    const size_t total = (size_t)n * cols;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int r = (int)(i / cols), c = (int)(i - (size_t)r * cols);
+        if (scatter) dst[(size_t)idx[r] * cols + c] = src[i];
+        else dst[i] = src[(size_t)idx[r] * cols + c];
+    }
+}
+
 struct WgradPlan { int xtiles, nblocks, splits, ci_tiles, co_tiles; size_t slab_floats; };
 
 static WgradPlan plan_wgrad(int Cin, int Cout, int H, int W, int ks) {
@@ -517,6 +594,54 @@ int frcnn_rpn_loss(const float *rpn_cls_score, const float *rpn_bbox_pred, const
     }
     hipLaunchKernelGGL(rpn_loss_kernel, dim3(1), dim3(1024), 0, stream, rpn_cls_score, rpn_bbox_pred, labels, targets, inds_inside, n_inside, A,
                        (int)HW, delta, loss_lambda, losses, d_cls_score, d_bbox_pred);
+    return frcnn_launch_status();
+}
+
+int frcnn_rcnn_loss(const float *cls_score, const float *bbox_pred, const int32_t *labels, const float *targets, int R, int ncls, float delta,
+                    float *losses, float *d_cls_score, float *d_bbox_pred, void *stream) {
+    if (!cls_score || !bbox_pred || !labels || !targets || !losses || R < 1 || ncls < 2) return FRCNN_ERR_INVALID;
+    if ((d_cls_score == nullptr) != (d_bbox_pred == nullptr)) return FRCNN_ERR_INVALID;
+    hipLaunchKernelGGL(rcnn_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, cls_score, bbox_pred, labels, targets, R, ncls, delta, losses,
+                       d_cls_score, d_bbox_pred);
+    return frcnn_launch_status();
+}
+
+static int grid_for(size_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
+
+int frcnn_mul_f32(const float *a, const float *b, size_t n, float *y, void *stream) {
+    if (n == 0) return FRCNN_OK;
+    if (!a || !b || !y) return FRCNN_ERR_INVALID;
+    hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, y);
+    return frcnn_launch_status();
+}
+
+int frcnn_add_f32(const float *a, const float *b, size_t n, float *y, void *stream) {
+    if (n == 0) return FRCNN_OK;
+    if (!a || !b || !y) return FRCNN_ERR_INVALID;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, y);
+    return frcnn_launch_status();
+}
+
+int frcnn_relu_bwd_f32(float *g, const float *out, size_t n, void *stream) {
+    if (n == 0) return FRCNN_OK;
+    if (!g || !out) return FRCNN_ERR_INVALID;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, g, out, n);
+    return frcnn_launch_status();
+}
+
+int frcnn_gather_rows_f32(const float *src, const int32_t *idx, int n, int cols, float *dst, void *stream) {
+    if (n == 0) return FRCNN_OK;
+    if (!src || !idx || !dst || n < 0 || cols < 1) return FRCNN_ERR_INVALID;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)n * cols)), dim3(256), 0, (hipStream_t)stream, src, idx, n, cols, dst, 0);
+    return frcnn_launch_status();
+}
+
+int frcnn_scatter_rows_f32(const float *src, const int32_t *idx, int n, int cols, float *dst, int dst_rows, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!dst || dst_rows < 1 || cols < 1 || n < 0 || (n > 0 && (!src || !idx))) return FRCNN_ERR_INVALID;
+    FRCNN_HIP_TRY(hipMemsetAsync(dst, 0, sizeof(float) * (size_t)dst_rows * cols, stream));
+    if (n == 0) return FRCNN_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((size_t)n * cols)), dim3(256), 0, stream, src, idx, n, cols, dst, 1);
     return frcnn_launch_status();
 }
 

@@ -8,6 +8,7 @@ from .cpu_nms import cpu_nms, gpu_nms  # noqa: F401
 from .faster_rcnn import FasterRCNN  # noqa: F401
 from .generate_anchors import generate_anchors  # noqa: F401
 from .proposal_layer import ProposalLayer  # noqa: F401
+from .proposal_target_layer import ProposalTargetLayer  # noqa: F401
 from .region_proposal_network import RegionProposalNetwork  # noqa: F401
 from .resnet import ResNet, ResNet50, ResNet101, ResNet152  # noqa: F401
 from .roi_pooling_2d import ROIPooling2D, roi_pooling_2d  # noqa: F401

@@ -55,6 +55,7 @@ class FasterRCNN(object):
         self.cls_score, self.bbox_pred = Linear(self.rt, head_dtype), Linear(self.rt, head_dtype)
         self._feat_stride = feat_stride
         self._num_classes = num_classes
+        self._rcnn_delta = rcnn_delta
         self.RPN.train = False                               # faster_rcnn.py:42
         self._rcnn_train = False
         self._spatial_scale = 1. / feat_stride
@@ -142,8 +143,14 @@ class FasterRCNN(object):
             self._check_data_type_forward(x, img_info, gt_boxes)
         if self.rpn_train and gt_boxes is not None:                  # faster_rcnn.py:115-116: RPN training mode returns rpn_loss
             return self.RPN(Variable(self.trunk(x)), img_info, gt_boxes)
-        if self.rcnn_train and gt_boxes is not None:
-            raise NotImplementedError("stage-2 (rcnn_train) losses: SURVEY.md 8(f) rank 2, not on this round's path")
+        if self.rcnn_train and gt_boxes is not None:                 # faster_rcnn.py:136-166: returns loss_rcnn
+            from ..train import RCNNTrainer                          # the forward half of the stage-2 step (dropout, ProposalTargetLayer, losses)
+            if getattr(self, "_rcnn_stepper", None) is None:
+                self._rcnn_stepper = RCNNTrainer(self)
+            out = self._rcnn_stepper.forward_backward(x, img_info, gt_boxes)
+            l = self._rcnn_stepper.losses_host(out)
+            self.loss_cls, self.loss_bbox, self.cls_accuracy = l["loss_cls"], l["loss_bbox"], l["cls_accuracy"]
+            return Variable(np.float32(l["loss_rcnn"]), name='loss_rcnn')
         im_h, im_w = self.RPN.proposal_layer._img_hw(img_info)
         out = self.forward_device(x, im_h, im_w)
         n = int(self.rt.mem.to_numpy(out["n_out"])[0])

@@ -238,12 +238,12 @@ class Runtime(object):
         return raw[:2 * A].reshape(1, 2 * A, H, W), prob, raw[2 * A:6 * A].reshape(1, 4 * A, H, W)
 
     # ------------------------------------------------------------------ head
-    def linear(self, x, w, bias, relu=False):
+    def linear(self, x, w, bias, relu=False, out=None):
         m, L = self.mem, self.lib
         M, K = int(x.shape[0]), int(np.prod(x.shape[1:]))
         N = int(w.shape[0])
         assert int(w.shape[1]) == K
-        y = m.empty((M, N), "f32")
+        y = out if out is not None else m.empty((M, N), "f32")
         ws = self.workspace("linear", L.frcnn_linear_workspace_bytes(M, N, K))
         _lib.check(L.frcnn_linear_f32(m.ptr(x), m.ptr(w), m.ptr(bias), m.ptr(y), M, N, K, int(bool(relu)), m.ptr(ws),
                                       ws.shape[0], m.stream()), "frcnn_linear_f32")
@@ -445,6 +445,48 @@ class Runtime(object):
                                     float(delta), float(loss_lambda), m.ptr(losses), m.ptr(d_score) if want_grad else None,
                                     m.ptr(d_bbox) if want_grad else None, m.stream()), "frcnn_rpn_loss")
         return (losses, d_score, d_bbox) if want_grad else losses
+
+    def rcnn_loss(self, cls_score, bbox_pred, labels, targets, delta=1.0, want_grad=True):
+        """(R,ncls), (R,4ncls), labels (R,) i32, targets (R,4ncls) -> losses (3,) [, d_cls_score, d_bbox_pred]."""
+        m, L = self.mem, self.lib
+        R, ncls = int(cls_score.shape[0]), int(cls_score.shape[1])
+        losses = m.empty((3,), "f32")
+        ds = m.empty((R, ncls), "f32") if want_grad else None
+        db = m.empty((R, 4 * ncls), "f32") if want_grad else None
+        _lib.check(L.frcnn_rcnn_loss(m.ptr(cls_score), m.ptr(bbox_pred), m.ptr(labels), m.ptr(targets), R, ncls, float(delta), m.ptr(losses),
+                                     m.ptr(ds), m.ptr(db), m.stream()), "frcnn_rcnn_loss")
+        return (losses, ds, db) if want_grad else losses
+
+    def mul(self, a, b, out=None):
+        m, L = self.mem, self.lib
+        y = out if out is not None else m.empty(tuple(int(v) for v in a.shape), "f32")
+        _lib.check(L.frcnn_mul_f32(m.ptr(a), m.ptr(b), int(np.prod(a.shape)), m.ptr(y), m.stream()), "frcnn_mul_f32")
+        return y
+
+    def add(self, a, b, out=None):
+        m, L = self.mem, self.lib
+        y = out if out is not None else m.empty(tuple(int(v) for v in a.shape), "f32")
+        _lib.check(L.frcnn_add_f32(m.ptr(a), m.ptr(b), int(np.prod(a.shape)), m.ptr(y), m.stream()), "frcnn_add_f32")
+        return y
+
+    def relu_bwd_(self, g, out):
+        m, L = self.mem, self.lib
+        _lib.check(L.frcnn_relu_bwd_f32(m.ptr(g), m.ptr(out), int(np.prod(g.shape)), m.stream()), "frcnn_relu_bwd_f32")
+        return g
+
+    def gather_rows(self, src, idx):
+        m, L = self.mem, self.lib
+        n, cols = int(idx.shape[0]), int(np.prod(src.shape[1:]))
+        dst = m.empty((n,) + tuple(int(v) for v in src.shape[1:]), "f32")
+        _lib.check(L.frcnn_gather_rows_f32(m.ptr(src), m.ptr(idx), n, cols, m.ptr(dst), m.stream()), "frcnn_gather_rows_f32")
+        return dst
+
+    def scatter_rows(self, src, idx, dst_rows):
+        m, L = self.mem, self.lib
+        n, cols = int(idx.shape[0]), int(np.prod(src.shape[1:]))
+        dst = m.empty((int(dst_rows),) + tuple(int(v) for v in src.shape[1:]), "f32")
+        _lib.check(L.frcnn_scatter_rows_f32(m.ptr(src), m.ptr(idx), n, cols, m.ptr(dst), int(dst_rows), m.stream()), "frcnn_scatter_rows_f32")
+        return dst
 
     def maxpool2x2_bwd(self, x, dy, out=None):
         m, L = self.mem, self.lib

@@ -27,6 +27,35 @@ from .chainer_compat import unwrap
 from .models.anchor_target_layer import AnchorTargetLayer
 
 
+def trunk_forward(model, x):
+    """Trunk forward keeping every layer's input (the backward pass needs them) -> (feat, inputs)."""
+    rt = model.rt
+    inputs, h = [], x
+    for l in model.trunk.layers:
+        inputs.append(h)
+        h = rt.maxpool2x2(h) if l == "pool" else model.trunk.links[l[0]](h, relu=True)
+    return h, inputs
+
+
+def trunk_backward(trainer, layer_inputs, g):
+    """Backward through [(layer, input)] in reverse, starting from g = dL/d(output of the last layer) ALREADY masked by that
+    layer's ReLU.  Writes weight / bias gradients into trainer.grad and re-packs the input-gradient weights."""
+    rt = trainer.rt
+    first = trainer.convs[0][0]
+    links = dict(trainer.convs)
+    for l, xin in reversed(layer_inputs):
+        if l == "pool":
+            g = rt.maxpool2x2_bwd(xin, g)
+            continue
+        name = l[0]
+        rt.conv_wgrad(xin, g, 3, out=trainer.grad[name + "/W"])
+        rt.bias_grad(g, out=trainer.grad[name + "/b"])
+        if name != first:                                         # the image needs no gradient
+            rt.pack_conv_dgrad_w(links[name].Wp, 3, out=trainer.wd[name])
+            g = rt.conv_ex(g, trainer.wd[name], trainer.zero_bias, 3, act=2, mask=xin)
+    return g
+
+
 class _Seg(object):
     def __init__(self, name, shape, offset):
         self.name, self.shape, self.offset = name, tuple(shape), offset
@@ -86,12 +115,7 @@ class RPNTrainer(object):
         rt, model, rpn = self.rt, self.model, self.model.RPN
         x = rt.asarray(unwrap(x), "f32")
         im_h, im_w = rpn.proposal_layer._img_hw(img_info)
-        # ---- forward, keeping every layer's input
-        inputs, h = [], x
-        for l in self.layers:
-            inputs.append(h)
-            h = rt.maxpool2x2(h) if l == "pool" else model.trunk.links[l[0]](h, relu=True)
-        feat = h
+        feat, inputs = trunk_forward(model, x)                     # keeps every layer's input
         mid = rpn.rpn_conv_3x3(feat, relu=True)
         score, _, bbox = rt.rpn_heads(mid, rpn._heads_packed)
         A = self.A
@@ -110,18 +134,7 @@ class RPNTrainer(object):
         rt.pack_conv_dgrad_w(rpn._heads_packed[0], 1, out=self.wd_heads)
         g = rt.conv_ex(draw.reshape(1, NP, H, W), self.wd_heads, self.zero_bias, 1, act=2, mask=mid)
         # ---- rpn_conv_3x3, then the trunk in reverse
-        layer_inputs = list(zip(self.layers, inputs)) + [(("rpn_conv_3x3", 0, 0), feat)]
-        for l, xin in reversed(layer_inputs):
-            if l == "pool":
-                g = rt.maxpool2x2_bwd(xin, g)
-                continue
-            name = l[0]
-            link = dict(self.convs)[name]
-            rt.conv_wgrad(xin, g, 3, out=self.grad[name + "/W"])
-            rt.bias_grad(g, out=self.grad[name + "/b"])
-            if name != self.convs[0][0]:                                # the image needs no gradient
-                rt.pack_conv_dgrad_w(link.Wp, 3, out=self.wd[name])
-                g = rt.conv_ex(g, self.wd[name], self.zero_bias, 3, act=2, mask=xin)
+        trunk_backward(self, list(zip(self.layers, inputs)) + [(("rpn_conv_3x3", 0, 0), feat)], g)
         return dict(losses=losses)
 
     def all_reduce(self):
@@ -170,6 +183,155 @@ class RPNTrainer(object):
         out["RPN/rpn_cls_score/W"], out["RPN/rpn_cls_score/b"] = gw[:2 * A].reshape(2 * A, -1, 1, 1), gb[:2 * A]
         out["RPN/rpn_bbox_pred/W"], out["RPN/rpn_bbox_pred/b"] = gw[2 * A:6 * A].reshape(4 * A, -1, 1, 1), gb[2 * A:6 * A]
         return out
+
+
+class RCNNTrainer(object):
+    """Stage-2 step of train_rcnn.py (train_rcnn.py:35-78; models/faster_rcnn.py:110-173 with rcnn_train = True): trunk -> RPN
+    proposals (test-mode ProposalLayer, no gradient) -> RoI pooling -> fc6/fc7 with dropout -> cls_score / bbox_pred ->
+    ProposalTargetLayer sampling -> softmax-CE + Huber(1) on the sampled rows -> backward through the head (the four L.Linear
+    as GEMMs on transposed operands), RoI pooling (arg-max scatter), the trunk -> MomentumSGD + WeightDecay over trunk + head.
+
+    Dropout masks are drawn on the host from NumPy's global RNG in the order chainer's CPU path draws them (fc6's mask, fc7's
+    mask, then ProposalTargetLayer's two np.random.choice calls), so a seeded run follows the reference's random stream.
+    """
+
+    HEAD = ("fc6", "fc7", "cls_score", "bbox_pred")
+
+    def __init__(self, model, lr=0.001, momentum=0.9, weight_decay=0.0005, dropout_ratio=0.5, comm=None):
+        from .models.proposal_target_layer import ProposalTargetLayer
+        self.model, self.rt = model, model.rt
+        self.lr, self.momentum, self.weight_decay, self.dropout_ratio, self.comm = lr, momentum, weight_decay, dropout_ratio, comm
+        rt = self.rt
+        self.ptl = ProposalTargetLayer(model._feat_stride, num_classes=model._num_classes, runtime=rt)
+        self.layers = model.trunk.layers
+        self.convs = [(l[0], model.trunk.links[l[0]]) for l in self.layers if l != "pool"]
+        segs, off = {}, 0
+        def add(name, shape):
+            nonlocal off
+            segs[name] = _Seg(name, shape, off)
+            off += (segs[name].size + 63) // 64 * 64
+        for name, link in self.convs:
+            add(name + "/W", link.Wp.shape)
+            add(name + "/b", link.b.shape)
+        for n in self.HEAD:
+            lin = getattr(model, n)
+            add(n + "/W", lin.W.shape)
+            add(n + "/b", lin.b.shape)
+        self.seg, self.n_flat = segs, off
+        self.W, self.G, self.V = rt.mem.zeros((off,), "f32"), rt.mem.zeros((off,), "f32"), rt.mem.zeros((off,), "f32")
+        def adopt(seg, src):
+            v = rt.mem.view(self.W, seg.offset, seg.shape)
+            v[...] = src
+            return v
+        for name, link in self.convs:
+            link.Wp = adopt(segs[name + "/W"], link.Wp)
+            link.b = adopt(segs[name + "/b"], link.b)
+        for n in self.HEAD:
+            lin = getattr(model, n)
+            lin.W = adopt(segs[n + "/W"], lin.W)
+            lin.b = adopt(segs[n + "/b"], lin.b)
+        self.grad = {k: rt.mem.view(self.G, sg.offset, sg.shape) for k, sg in segs.items()}
+        self.wd = {name: rt.mem.empty((int(link.Wp.shape[1]) * 9, int(link.Wp.shape[0]) // 9), "f32") for name, link in self.convs[1:]}
+        self.zero_bias = rt.mem.zeros((max(512, max(int(getattr(model, n).W.shape[1]) for n in self.HEAD)),), "f32")
+        self.iteration = 0
+
+    # ------------------------------------------------------------------ one L.Linear backward: GEMMs on transposed operands
+    def _linear_backward(self, name, x, dy, need_dx=True):
+        """x (M,K) the layer's input, dy (M,N): fills grad[name/W] (N,K), grad[name/b]; returns dx (M,K) or None."""
+        rt = self.rt
+        lin = getattr(self.model, name)
+        M, K = int(x.shape[0]), int(np.prod(x.shape[1:]))
+        N = int(dy.shape[1])
+        Mp = (M + 3) // 4 * 4                                        # the GEMM contracts over M here: pad it to a multiple of 4
+        xpad, dpad = rt.mem.zeros((Mp, K), "f32"), rt.mem.zeros((Mp, N), "f32")
+        xpad[:M] = x.reshape(M, K)
+        dpad[:M] = dy
+        dyT, xT = rt.transpose(dpad), rt.transpose(xpad)             # (N, Mp), (K, Mp)
+        rt.linear(dyT, xT, self.zero_bias[:K], out=self.grad[name + "/W"])          # dW = dy^T x
+        rt.bias_grad(dyT.reshape(1, N, 1, Mp), out=self.grad[name + "/b"])          # db = column sums of dy
+        if not need_dx:
+            return None
+        Np = (N + 3) // 4 * 4                                        # dx = dy W contracts over N: pad it to a multiple of 4 as well
+        if Np != N:
+            dyn, wn = rt.mem.zeros((M, Np), "f32"), rt.mem.zeros((Np, K), "f32")
+            dyn[:, :N] = dy
+            wn[:N] = lin.W
+        else:
+            dyn, wn = dy, lin.W
+        return rt.linear(dyn, rt.transpose(wn), self.zero_bias[:K])                 # W^T is (K, Np)
+
+    def forward_backward(self, x, img_info, gt_boxes, masks=None):
+        """Fills self.G; returns dict(losses (3,) device [loss_cls, loss_bbox, cls_accuracy], n_rois, keep_inds)."""
+        rt, model = self.rt, self.model
+        x = rt.asarray(unwrap(x), "f32")
+        im_h, im_w = model.RPN.proposal_layer._img_hw(img_info)
+        feat, inputs = trunk_forward(model, x)
+        C, H, W = [int(v) for v in feat.shape[1:]]
+        _, _, prob, bbox = model.RPN.heads(feat, want_score=False)
+        rois, _, n_out = model.RPN.proposal_layer.forward_device(prob, bbox, im_h, im_w)      # RPN.train is False in rcnn_train mode
+        n = int(rt.mem.to_numpy(n_out)[0])
+        rois = rois[:n]
+        pool5, argmax = rt.roi_pool_fwd_chw(feat, rois, 7, 7, model._spatial_scale, want_argmax=True)
+        pool5 = pool5.reshape(n, -1)
+        scale = 1.0 / (1.0 - self.dropout_ratio)
+        a6 = model.fc6(pool5, relu=True)
+        if masks is None:                                            # F.dropout [chainer-ext]: mask = (rand >= ratio) * 1/(1-ratio)
+            m6 = ((np.random.rand(*a6.shape) >= self.dropout_ratio) * scale).astype(np.float32)
+        else:
+            m6 = masks[0]
+        m6 = rt.asarray(m6, "f32")
+        d6 = rt.mul(a6, m6)
+        a7 = model.fc7(d6, relu=True)
+        m7 = ((np.random.rand(*a7.shape) >= self.dropout_ratio) * scale).astype(np.float32) if masks is None else masks[1]
+        m7 = rt.asarray(m7, "f32")
+        d7 = rt.mul(a7, m7)
+        cls_score, bbox_pred = model.cls_score(d7), model.bbox_pred(d7)
+        use_gt, ext, keep = self.ptl(rois, gt_boxes)
+        labels = rt.mem.from_numpy(rt.mem.to_numpy(use_gt)[:, -1].astype(np.int32))        # faster_rcnn.py:153
+        losses, dcs, dbp = rt.rcnn_loss(rt.gather_rows(cls_score, keep), rt.gather_rows(bbox_pred, keep), labels, ext, model._rcnn_delta)
+        # ---- backward: head
+        dcls, dbb = rt.scatter_rows(dcs, keep, n), rt.scatter_rows(dbp, keep, n)
+        g7 = rt.add(self._linear_backward("cls_score", d7, dcls), self._linear_backward("bbox_pred", d7, dbb))
+        g7 = rt.relu_bwd_(rt.mul(g7, m7, out=g7), a7)
+        g6 = self._linear_backward("fc7", d6, g7)
+        g6 = rt.relu_bwd_(rt.mul(g6, m6, out=g6), a6)
+        gp = self._linear_backward("fc6", pool5, g6)
+        # ---- RoI pooling (arg-max scatter) and the trunk; feat = relu(conv5_3): mask before entering conv5_3's backward
+        gfeat = rt.relu_bwd_(rt.roi_pool_bwd(gp.reshape(n, C, 7, 7), argmax, C, H, W), feat)
+        trunk_backward(self, list(zip(self.layers, inputs)), gfeat)
+        return dict(losses=losses, n_rois=n, keep_inds=keep)
+
+    def all_reduce(self):
+        if self.comm is not None and self.comm.world_size > 1:
+            self.comm.all_reduce_sum(self.G)
+
+    def update(self):
+        self.rt.sgd_momentum_wd(self.W, self.G, self.V, self.lr, self.momentum, self.weight_decay)
+        self.iteration += 1
+
+    def step(self, x, img_info, gt_boxes, masks=None):
+        out = self.forward_backward(x, img_info, gt_boxes, masks)
+        self.all_reduce()
+        self.update()
+        return out
+
+    def losses_host(self, out):
+        l = self.rt.mem.to_numpy(out["losses"])
+        return dict(loss_cls=float(l[0]), loss_bbox=float(l[1]), cls_accuracy=float(l[2]), loss_rcnn=float(l[0] + l[1]))
+
+    def grads_chainer_layout(self):
+        rt, out = self.rt, {}
+        for name, link in self.convs:
+            g = rt.mem.to_numpy(self.grad[name + "/W"])
+            out["trunk/" + name + "/W"] = np.ascontiguousarray(g.T).reshape(link.cout, link.cin, 3, 3)
+            out["trunk/" + name + "/b"] = rt.mem.to_numpy(self.grad[name + "/b"])
+        for n in self.HEAD:
+            out[n + "/W"], out[n + "/b"] = rt.mem.to_numpy(self.grad[n + "/W"]), rt.mem.to_numpy(self.grad[n + "/b"])
+        return out
+
+    def sync_params(self):
+        for name, link in self.convs:
+            link.W = self.rt.transpose(link.Wp).reshape(link.cout, link.cin, 3, 3)
 
 
 class TorchComm(object):

@@ -237,6 +237,19 @@ int frcnn_anchor_target(const double *anchors_host, int A, int H, int W, int fea
 int frcnn_rpn_loss(const float *rpn_cls_score, const float *rpn_bbox_pred, const int32_t *labels,
                    const float *targets, const int32_t *inds_inside, int n_inside, int A, int H, int W, float delta,
                    float loss_lambda, float *losses, float *d_cls_score, float *d_bbox_pred, void *stream);
+/* Stage-2 (rcnn_train) pieces, models/faster_rcnn.py:136-173: frcnn_rcnn_loss = softmax-CE (mean over the R
+ * sampled RoIs) + Huber(delta) summed per RoI / R, and the gradients of their sum; losses (3) = [loss_cls, loss_bbox,
+ * cls_accuracy]; labels int32 (R), targets (R,4*ncls).  frcnn_mul_f32: F.dropout forward/backward with the 0 | 1/(1-ratio)
+ * mask; frcnn_relu_bwd_f32: g = (out > 0) ? g : 0 in place; frcnn_gather_rows_f32 / frcnn_scatter_rows_f32: x[keep_inds] and
+ * its adjoint (dst zero-filled, dst_rows rows).  The head's L.Linear gradients are frcnn_linear_f32 calls on transposed
+ * operands (frcnn_transpose_f32); RoI pooling backward is frcnn_roi_pool_bwd. */
+int frcnn_rcnn_loss(const float *cls_score, const float *bbox_pred, const int32_t *labels, const float *targets, int R,
+                    int ncls, float delta, float *losses, float *d_cls_score, float *d_bbox_pred, void *stream);
+int frcnn_mul_f32(const float *a, const float *b, size_t n, float *y, void *stream);
+int frcnn_add_f32(const float *a, const float *b, size_t n, float *y, void *stream);      /* y = a + b (y may alias a or b) */
+int frcnn_relu_bwd_f32(float *g, const float *out, size_t n, void *stream);
+int frcnn_gather_rows_f32(const float *src, const int32_t *idx, int n, int cols, float *dst, void *stream);
+int frcnn_scatter_rows_f32(const float *src, const int32_t *idx, int n, int cols, float *dst, int dst_rows, void *stream);
 int frcnn_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int C, int H, int W, void *stream);
 size_t frcnn_bias_grad_workspace_bytes(int C, int HW);
 int frcnn_bias_grad_f32(const float *dy, int C, int HW, float *db, void *workspace, size_t workspace_bytes, void *stream);

@@ -629,3 +629,97 @@ def img_preprocessing(orig_img, pixel_means, max_size=1000, scale=600):
     rows = img[:, sx] * (np.float32(1) - ax)[None, :, None] + img[:, sx1] * ax[None, :, None]
     out = rows[sy] * (np.float32(1) - ay)[:, None, None] + rows[sy1] * ay[:, None, None]
     return out.transpose(2, 0, 1).astype(np.float32), im_scale
+
+
+# --------------------------------------------------------------------------- ProposalTargetLayer + stage-2 losses
+def proposal_target_layer(proposals, gt_boxes, num_classes=21, rng=np.random):
+    """models/proposal_target_layer.py:84-150.  proposals (n,4) f32, gt_boxes (1,G,5) f32.
+    Returns (use_gt_boxes (k,5) f32, ext_bbox_reg_targets (k,4*num_classes) f32, keep_inds (k,) int32), k <= 128.
+    `rng.choice` is drawn exactly as the reference draws np.random.choice (:107-108, :121-122)."""
+    FG_THRESH, BG_HI, BG_LO, ROIS, FG_FRAC = 0.5, 0.5, 0.1, 128, 0.25            # :46-50
+    n_fg_rois = int(FG_FRAC * ROIS)
+    gt = gt_boxes[0]
+    overlaps = bbox_overlaps(np.ascontiguousarray(proposals, dtype=np.float64),
+                             np.ascontiguousarray(gt[:, :4], dtype=np.float64))   # anchor_target_layer.py:183-185
+    argmax = overlaps.argmax(axis=1)
+    max_ov = overlaps[np.arange(len(proposals)), argmax]
+    cls_labels = gt[argmax, 4]                                                     # :92
+    fg_inds = np.where(max_ov >= FG_THRESH)[0]                                     # :95
+    n_fg = min(n_fg_rois, fg_inds.size)                                            # :99
+    if fg_inds.size > 0:
+        fg_inds = rng.choice(fg_inds, size=n_fg, replace=False)                    # :105-108
+    bg_inds = np.where((max_ov < BG_HI) & (max_ov >= BG_LO))[0]                    # :111-112
+    n_bg = min(ROIS - n_fg, bg_inds.size)                                          # :114-115
+    if bg_inds.size > 0:
+        bg_inds = rng.choice(bg_inds, size=n_bg, replace=False)                    # :119-122
+    keep = np.concatenate([fg_inds, bg_inds]).astype(np.int32)                     # :126
+    cls_labels = cls_labels[keep]
+    cls_labels[n_fg:] = 0                                                          # :130 (a local copy: use_gt_boxes keeps the gt's label)
+    props = proposals[keep]
+    use_gt = gt[argmax[keep]]                                                      # :134
+    targets = bbox_transform(props, use_gt)                                        # :135 (float32 in, float32 out)
+    ext = np.zeros((len(keep), 4 * num_classes), dtype=np.float32)                 # :138-139
+    for ind in np.where(use_gt[:, 4] > 0)[0]:                                      # :140-143
+        pos = int(4 * use_gt[ind, -1])
+        ext[ind, pos:pos + 4] = targets[ind]
+    return use_gt, ext, keep
+
+
+def _torch_rcnn_losses(cls_score, bbox_pred, labels, targets, delta):
+    """models/faster_rcnn.py:152-164: softmax CE (mean over the sampled RoIs) + huber_loss(delta) summed per RoI, divided by
+    the number of RoIs (F.huber_loss returns one value per row [chainer-ext]; loss_bbox.size is the row count)."""
+    import torch
+    loss_cls = torch.nn.functional.cross_entropy(cls_score, torch.from_numpy(np.asarray(labels, dtype=np.int64)))
+    d = bbox_pred - torch.from_numpy(np.ascontiguousarray(targets, dtype=np.float32))
+    a = d.abs()
+    loss_bbox = torch.where(a < delta, 0.5 * d * d, delta * (a - 0.5 * delta)).sum() / bbox_pred.shape[0]
+    return loss_cls, loss_bbox
+
+
+def rcnn_loss_grads(cls_score, bbox_pred, labels, targets, delta=1.0):
+    """-> (loss_cls, loss_bbox, accuracy, d cls_score, d bbox_pred) of loss_rcnn = loss_cls + loss_bbox (faster_rcnn.py:164)."""
+    s = _t(cls_score).clone().requires_grad_(True)
+    b = _t(bbox_pred).clone().requires_grad_(True)
+    lc, lb = _torch_rcnn_losses(s, b, labels, targets, delta)
+    (lc + lb).backward()
+    acc = float((np.asarray(cls_score).argmax(axis=1) == np.asarray(labels)).mean())
+    return np.float32(lc.item()), np.float32(lb.item()), np.float32(acc), s.grad.numpy(), b.grad.numpy()
+
+
+def rcnn_train_grads(p, x, rois, keep_inds, labels, targets, mask6, mask7, layers=None, spatial_scale=1.0 / 16, delta=1.0):
+    """One rcnn_train-mode forward/backward of FasterRCNN (faster_rcnn.py:110-173) given the proposals (rois (R,4)), the
+    ProposalTargetLayer output (keep_inds, labels = use_gt_boxes[:, -1], class-wise targets) and the two dropout masks
+    (values 0 or 1/(1-ratio) [chainer-ext F.dropout]).  RoI pooling is a custom autograd function over the C oracle.
+    -> (loss_rcnn, {link path: gradient}) for the trunk and the four head layers (the RPN receives no gradient)."""
+    import torch
+    F = torch.nn.functional
+
+    class RoiPool(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, feat, brois):
+            y, am = roi_pooling_2d(feat.detach().numpy(), brois, 7, 7, spatial_scale, return_argmax=True)
+            ctx.am, ctx.shape, ctx.brois = am, tuple(feat.shape), brois
+            return torch.from_numpy(y)
+
+        @staticmethod
+        def backward(ctx, gy):
+            return torch.from_numpy(roi_pooling_2d_backward(np.ascontiguousarray(gy.numpy()), ctx.am, ctx.brois, ctx.shape)), None
+
+    names = [k for k in p if k.startswith("trunk/") or k.split("/")[0] in ("fc6", "fc7", "cls_score", "bbox_pred")]
+    tp = {k: _t(p[k]).clone().requires_grad_(True) for k in names}
+    h = _t(x)
+    layers = layers or ["conv1_1", "conv1_2", "pool", "conv2_1", "conv2_2", "pool", "conv3_1", "conv3_2", "conv3_3", "pool",
+                        "conv4_1", "conv4_2", "conv4_3", "pool", "conv5_1", "conv5_2", "conv5_3"]
+    for l in layers:
+        h = F.max_pool2d(h, 2, 2, ceil_mode=True) if l == "pool" else F.relu(F.conv2d(h, tp["trunk/%s/W" % l], tp["trunk/%s/b" % l], padding=1))
+    brois = np.concatenate([np.zeros((len(rois), 1), np.float32), np.asarray(rois, np.float32)], axis=1)
+    pool5 = RoiPool.apply(h, brois)
+    fc6 = F.relu(F.linear(pool5.reshape(len(rois), -1), tp["fc6/W"], tp["fc6/b"])) * _t(mask6)
+    fc7 = F.relu(F.linear(fc6, tp["fc7/W"], tp["fc7/b"])) * _t(mask7)
+    cls_score = F.linear(fc7, tp["cls_score/W"], tp["cls_score/b"])
+    bbox_pred = F.linear(fc7, tp["bbox_pred/W"], tp["bbox_pred/b"])
+    idx = torch.from_numpy(np.asarray(keep_inds, dtype=np.int64))
+    lc, lb = _torch_rcnn_losses(cls_score[idx], bbox_pred[idx], labels, targets, delta)
+    total = lc + lb
+    total.backward()
+    return np.float32(total.item()), {k: v.grad.numpy() for k, v in tp.items()}

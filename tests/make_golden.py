@@ -155,5 +155,33 @@ def main():
           (at["b_labels"] == 1).sum(), (at["b_labels"] == 0).sum())
 
 
+def proposal_target_cases(ns):
+    """ProposalTargetLayer (proposal_target_layer.py:84-150): three proposal sets built around the gt boxes (fg / bg / far)."""
+    from oracle import frcnn_oracle as O
+    out = {}
+    for tag, n, G, seed in (("a", 300, 4, 31), ("b", 300, 1, 32), ("c", 40, 6, 33)):
+        rs = np.random.RandomState(seed)
+        x1 = rs.uniform(0, 800, G); y1 = rs.uniform(0, 400, G)
+        gt = np.stack([x1, y1, x1 + rs.uniform(40, 190, G), y1 + rs.uniform(40, 190, G), rs.randint(1, 21, G)], 1)[None].astype(np.float32)
+        k = n // 3
+        base = gt[0, rs.randint(0, G, k), :4]
+        fg = base + rs.uniform(-8, 8, (k, 4))
+        bg = base + rs.uniform(-60, 60, (k, 4)) + np.array([40, 40, 40, 40])
+        xy = rs.uniform(0, 900, (n - 2 * k, 2))
+        far = np.hstack([xy, xy + rs.uniform(20, 100, (n - 2 * k, 2))])
+        props = np.vstack([fg, bg, far]).astype(np.float32)
+        props[:, 2:] = np.maximum(props[:, 2:], props[:, :2] + 1)
+        props = props[rs.permutation(n)]
+        layer = ns.ProposalTargetLayer(16, [0.5, 1, 2], [8, 16, 32], 21)
+        np.random.seed(seed + 100)
+        ug, ext, keep = layer(props, ns.Variable(gt))
+        ug2, ext2, keep2 = O.proposal_target_layer(props, gt, rng=np.random.RandomState(seed + 100))
+        assert np.array_equal(ug, ug2) and np.array_equal(ext, ext2) and np.array_equal(keep, keep2), tag
+        out.update({tag + "_props": props, tag + "_gt": gt, tag + "_seed": np.array(seed + 100), tag + "_use_gt": ug, tag + "_ext": ext,
+                    tag + "_keep": keep})
+    np.savez_compressed(os.path.join(OUT, "proposal_target.npz"), **out)
+
+
 if __name__ == "__main__":
     main()
+    proposal_target_cases(rh.load())

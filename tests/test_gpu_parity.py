@@ -15,7 +15,7 @@ def rt():
 
 
 def test_library_is_the_device_build(rt):
-    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 8
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 9
 
 
 def test_nms_golden(rt):
@@ -327,3 +327,15 @@ def test_nms_train_size_properties(rt):
     dropped = np.setdiff1d(np.arange(n), k)
     sup = (iou(dets[dropped], K).astype(np.float64) >= 0.7) & (K[None, :, 4] > dets[dropped, 4][:, None])
     assert sup.any(axis=1).all()
+
+
+# ---- stage-2 (rcnn_train) step: SURVEY.md 8f rank 2
+def test_rcnn_train_step_small(rt):
+    import train_cases as T
+    T.check_small_rcnn_step(rt)
+
+
+def test_rcnn_train_step_vgg16(rt):
+    import train_cases as T
+    losses, worst = T.check_vgg_rcnn_step(rt)
+    assert losses["loss_rcnn"] > 0 and worst <= 1e-3

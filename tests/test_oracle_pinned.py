@@ -152,3 +152,13 @@ def test_ref_native_so_travels():
         pytest.skip("oracle/_ref not built")
     g = np.load(__import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "cpu_nms.npz"))
     assert rh.native("cpu_nms").cpu_nms(g["n300_t03_dets"], 0.3) == g["n300_t03_keep"].tolist()
+
+
+def test_proposal_target_layer(golden):
+    """oracle restatement of models/proposal_target_layer.py:84-150 vs vectors produced by the reference's own class."""
+    g = golden("proposal_target")
+    for tag in "abc":
+        rng = np.random.RandomState(int(g[tag + "_seed"]))
+        ug, ext, keep = O.proposal_target_layer(g[tag + "_props"], g[tag + "_gt"], rng=rng)
+        assert keep.dtype == np.int32 and np.array_equal(keep, g[tag + "_keep"])
+        assert np.array_equal(ug, g[tag + "_use_gt"]) and np.array_equal(ext, g[tag + "_ext"])

@@ -141,3 +141,22 @@ def test_snapshot_roundtrip_after_training(rt, tmp_path):
     b = fresh.RPN.heads(fresh.trunk(Variable(x)))
     for u, v in zip(a[1:], b[1:]):
         assert np.array_equal(rt.mem.to_numpy(u), rt.mem.to_numpy(v))
+
+
+def test_proposal_target_layer_mirror(rt):
+    """ProposalTargetLayer(...)(proposals, Variable(gt)) vs the golden vectors the reference itself produced (tests/make_golden.py)."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.models import ProposalTargetLayer
+    g = np.load(os.path.join(HERE, "golden", "proposal_target.npz"))
+    layer = ProposalTargetLayer(16, [0.5, 1, 2], [8, 16, 32], 21, runtime=rt)
+    for tag in "abc":
+        np.random.seed(int(g[tag + "_seed"]))
+        ug, ext, keep = layer(g[tag + "_props"], Variable(g[tag + "_gt"]))
+        assert np.array_equal(rt.mem.to_numpy(keep), g[tag + "_keep"])
+        assert np.array_equal(rt.mem.to_numpy(ug), g[tag + "_use_gt"])
+        assert np.allclose(rt.mem.to_numpy(ext), g[tag + "_ext"], rtol=1e-6, atol=1e-7)
+        assert len(g[tag + "_keep"]) <= 128
+
+
+def test_rcnn_train_step_small(rt):
+    T.check_small_rcnn_step(rt)

@@ -119,3 +119,99 @@ def check_vgg_step(rt, im_h=160, im_w=224, seed=0):
         worst = max(worst, err)
         assert err <= 1e-3, (k, err)
     return l, worst
+
+
+def small_head_params(rs, ch=64, hidden=128, ncls=21):
+    p = {}
+    p["fc6/W"] = (rs.randn(hidden, ch * 49) * np.sqrt(2.0 / (ch * 49))).astype(np.float32)
+    p["fc6/b"] = (rs.randn(hidden) * 0.01).astype(np.float32)
+    p["fc7/W"] = (rs.randn(hidden, hidden) * np.sqrt(2.0 / hidden)).astype(np.float32)
+    p["fc7/b"] = (rs.randn(hidden) * 0.01).astype(np.float32)
+    p["cls_score/W"] = (rs.randn(ncls, hidden) * 0.05).astype(np.float32)
+    p["cls_score/b"] = (rs.randn(ncls) * 0.01).astype(np.float32)
+    p["bbox_pred/W"] = (rs.randn(4 * ncls, hidden) * 0.02).astype(np.float32)
+    p["bbox_pred/b"] = (rs.randn(4 * ncls) * 0.01).astype(np.float32)
+    return p
+
+
+def check_rcnn_step(rt, model, params, layers, x, gt, info, feat_stride, seed=0):
+    """Stage-2 step vs the oracle: the device's own proposals, ProposalTargetLayer sample and dropout masks are handed to the
+    oracle's autograd restatement; loss and every trunk / head gradient within 1e-3 relative."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.train import RCNNTrainer
+    model.rcnn_train = True
+    tr = RCNNTrainer(model)
+    # dropout masks fixed up front (the proposal count is not known before the forward: draw for the capacity, slice below)
+    rs = np.random.RandomState(seed)
+    cap = model.RPN.proposal_layer.TEST_RPN_POST_NMS_TOP_N
+    h6, h7 = int(model.fc6.W.shape[0]), int(model.fc7.W.shape[0])
+    m6 = ((rs.rand(cap, h6) >= 0.5) * 2.0).astype(np.float32)
+    m7 = ((rs.rand(cap, h7) >= 0.5) * 2.0).astype(np.float32)
+
+    class Masks(object):                      # sliced to the actual RoI count on first use
+        def __getitem__(self, i):
+            return (m6, m7)[i][:self.n]
+    # one un-timed forward to learn n (proposals are deterministic)
+    feat = model.trunk(Variable(x))
+    _, _, prob, bbox = model.RPN.heads(feat, want_score=False)
+    n = int(rt.mem.to_numpy(model.RPN.proposal_layer.forward_device(prob, bbox, int(info[0][0]), int(info[0][1]))[2])[0])
+    assert n >= 8, n
+    masks = (m6[:n], m7[:n])
+    np.random.seed(seed + 1)
+    out = tr.forward_backward(Variable(x), Variable(info), Variable(gt), masks=masks)
+    assert out["n_rois"] == n
+    keep = rt.mem.to_numpy(out["keep_inds"])
+    rois = rt.mem.to_numpy(model.RPN.proposal_layer.forward_device(prob, bbox, int(info[0][0]), int(info[0][1]))[0])[:n]
+    np.random.seed(seed + 1)
+    use_gt, ext, keep2 = O.proposal_target_layer(rois, gt)
+    assert np.array_equal(keep, keep2)
+    names = [l if l == "pool" else l[0] for l in layers]
+    want_loss, want = O.rcnn_train_grads(params, x, rois, keep, use_gt[:, -1].astype(np.int64), ext, masks[0], masks[1], layers=names,
+                                         spatial_scale=1.0 / feat_stride)
+    l = tr.losses_host(out)
+    assert abs(l["loss_rcnn"] - want_loss) <= 1e-4 * abs(want_loss), (l, want_loss)
+    got = tr.grads_chainer_layout()
+    worst = 0.0
+    for k in sorted(want):
+        scale = max(np.abs(want[k]).max(), 1e-8)
+        err = np.abs(got[k] - want[k]).max() / scale
+        worst = max(worst, err)
+        assert err <= 1e-3, (k, err, scale)
+    # update: same arithmetic as the oracle's MomentumSGD + WeightDecay
+    w0, g = rt.mem.to_numpy(tr.W), rt.mem.to_numpy(tr.G)
+    tr.update()
+    w1, _ = O.momentum_sgd_wd(w0, g, np.zeros_like(w0))
+    assert np.array_equal(rt.mem.to_numpy(tr.W), w1)
+    return l, worst
+
+
+def check_small_rcnn_step(rt, seed=0, im_h=48, im_w=64):
+    rs = np.random.RandomState(seed)
+    params = small_params()
+    params.update(small_head_params(rs))
+    x = rs.randn(1, 3, im_h, im_w).astype(np.float32)
+    gt = P.gt_case(rs, 3, im_h, im_w)
+    gt[0, :, 2] = np.minimum(gt[0, :, 0] + rs.uniform(10, 30, 3), im_w - 1)
+    gt[0, :, 3] = np.minimum(gt[0, :, 1] + rs.uniform(10, 30, 3), im_h - 1)
+    info = np.array([[im_h, im_w]], dtype=np.int32)
+    model = build_small(rt, params)
+    for n in ("fc6", "fc7", "cls_score", "bbox_pred"):
+        getattr(model, n).set(params[n + "/W"], params[n + "/b"])
+    model.RPN.proposal_layer.RPN_MIN_SIZE = 4
+    model.RPN.proposal_layer._min_size = 4
+    return check_rcnn_step(rt, model, params, SMALL_LAYERS, x, gt, info, 4, seed)
+
+
+def check_vgg_rcnn_step(rt, im_h=160, im_w=224, seed=0):
+    """Stage-2 step of the real VGG-16 FasterRCNN (GPU suite)."""
+    from chainer_faster_rcnn_amd import synthetic
+    from chainer_faster_rcnn_amd.models import FasterRCNN
+    from chainer_faster_rcnn_amd.models.vgg16 import LAYERS
+    rs = np.random.RandomState(seed)
+    params = synthetic.params(seed=1)
+    x = synthetic.image(seed=4, h=im_h, w=im_w)
+    gt = P.gt_case(rs, 4, im_h, im_w)
+    info = np.array([[im_h, im_w]], dtype=np.int32)
+    model = FasterRCNN(runtime=rt)
+    model.load_params(params)
+    return check_rcnn_step(rt, model, params, LAYERS, x, gt, info, 16, seed)
