@@ -63,6 +63,37 @@ class EventTimer(object):
         return {k: float(np.mean(v)) for k, v in acc.items()}
 
 
+def pmc_traffic(dtype):
+    """HBM bytes per conv launch from the committed PMC passes of this same command (scripts/gpu_traffic.sh: FETCH_SIZE and
+    WRITE_SIZE in separate rocprofv3 --pmc runs); counters cannot be read from inside the process, so the bench line carries
+    the last measured figure and names its source, or null when no PMC pass exists for this dtype."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic_pmc.json")
+    if dtype != "f32" or not os.path.exists(path):
+        return None, None
+    try:
+        s = json.load(open(path))["_summary"]["conv_mfma_f32_kernel"]
+        return s["hbm_bytes_per_launch"], "profiles/r01_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
+    except (KeyError, ValueError):
+        return None, None
+
+
+def conv_algorithmic_bytes(model_layers, h, w, esize=4):
+    """Bytes each 3x3 conv launch must move once: input + output (after a fused pool where there is one) + weights + bias."""
+    out, prev = {}, None
+    for l in model_layers:
+        if l == "pool":
+            h2, w2 = (h + 1) // 2, (w + 1) // 2
+            if prev is not None:        # VGG16Prev.fuse_pool: the pooled map is what the conv launch writes
+                out[prev[0]] -= esize * prev[2] * (h * w - h2 * w2)
+            h, w = h2, w2
+        else:
+            name, ci, co = l
+            out[name] = esize * (ci * h * w + co * h * w) + 4 * (9 * ci * co + co)
+            prev = l
+    out["rpn_conv_3x3"] = esize * (512 * h * w * 2) + 4 * (9 * 512 * 512 + 512)
+    return out
+
+
 def conv_flops(model_layers, h, w):
     """Algorithmic FLOPs (2*MAC) of every 3x3 conv at a h x w input; bias/ReLU/pool excluded."""
     out = {}
@@ -269,10 +300,12 @@ def main():
             conv_ms = sum(avg[k] for k in flops)
             conv_tf = sum(flops.values()) / (conv_ms * 1e-3) / 1e12
             peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+            traffic, traffic_src = pmc_traffic(args.dtype)
             res["roofline"] = {"bound": "mfma", "achieved": conv_tf, "peak": peak, "unit": "TFLOP/s",
-                               "frac": conv_tf / peak, "traffic": None,
+                               "frac": conv_tf / peak, "traffic": traffic, "traffic_source": traffic_src,
                                "kernel": "conv_mfma_%s_kernel (14 launches/image: 13 VGG-16 convs + rpn_conv_3x3)" % args.dtype,
-                               "algorithmic_gflop_per_image": sum(flops.values()) / 1e9, "conv_ms_per_image": conv_ms}
+                               "algorithmic_gflop_per_image": sum(flops.values()) / 1e9, "conv_ms_per_image": conv_ms,
+                               "algorithmic_bytes_per_launch": sum(conv_algorithmic_bytes(LAYERS, IM_H, IM_W, 4 if args.dtype == "f32" else 2).values()) / 14.0}
             roi_bytes = (512 * fh * fw + 300 * 512 * 49) * 4 + 300 * 16
             res["stages_ms"] = {k: round(v, 4) for k, v in avg.items()}
             res["per_layer_tflops"] = {k: round(flops[k] / (avg[k] * 1e-3) / 1e12, 2) for k in flops}
