@@ -33,6 +33,7 @@ SIGNATURES = {
     "frcnn_roi_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "frcnn_pack_conv3x3_w": (_I, [_P, _I, _I, _P, _P]),
     "frcnn_conv3x3_workspace_bytes": (_S, [_I, _I, _I, _I]),
+    "frcnn_conv3x3_workspace_init": (_I, [_P, _S, _P]),
     "frcnn_conv3x3_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_conv3x3_f32_cfg": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_maxpool2x2_f32": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -75,7 +75,19 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
     const int l31 = lane & 31, khalf = lane >> 5;
     const int a_col = wco * (32 * ACO) + l31;
     const int b_row = wpx * APX;
-    const long long G = gridDim.x, g = blockIdx.x;
+    // XCD-aware placement: workgroups are dealt to the 8 XCDs round-robin, so XCD x is given the x-th contiguous eighth of
+    // the work and what that eighth shares meets in ONE 4 MB L2 instead of eight.  Two work orders (host picks per layer):
+    //   relu bit 8: [cout block][pixel tile] -- an XCD keeps one weight slab resident and streams the map (weights >> map);
+    //   relu bit 9: [row band][cout block][pixel tile of the band] -- an XCD keeps its band of the map resident across the
+    //               cout blocks and streams the weights (map >> weights).
+    const long long G = gridDim.x;
+    long long g = blockIdx.x;
+    const bool banded = (relu & 512) != 0;
+    if (relu & (256 | 512)) {
+        const long long xcd = g & 7, q = G >> 3, r = G & 7;
+        g = xcd * q + (xcd < r ? xcd : r) + (g >> 3);
+    }
+    relu &= 255;
     const long long it_begin = g * total / G, it_end = (g + 1) * total / G;
 
     float4 wreg[WIT];
@@ -90,7 +102,19 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
         const int tile = (int)(it / nchunks);
         const int c_begin = (int)(it - (long long)tile * nchunks);
         const int c_end = (int)((long long)nchunks < c_begin + (it_end - it) ? (long long)nchunks : c_begin + (it_end - it));
-        const int tx = tile % xtiles, ty = (tile / xtiles) % ytiles, cot = tile / (xtiles * ytiles);
+        int pxt = tile % (xtiles * ytiles), cot = tile / (xtiles * ytiles);
+        if (banded) {
+            const int npx = xtiles * ytiles, ncot = Cout / BCO;
+            int b = (int)(((long long)tile * 8) / ((long long)npx * ncot));             // band guess, then settle
+            b = b > 7 ? 7 : b;
+            while (b > 0 && (long long)ncot * ((long long)b * npx / 8) > tile) --b;
+            while (b < 7 && (long long)ncot * ((long long)(b + 1) * npx / 8) <= tile) ++b;
+            const int p0 = (int)((long long)b * npx / 8), nb = (int)((long long)(b + 1) * npx / 8) - p0;
+            const int rem = tile - ncot * p0;
+            cot = rem / nb;
+            pxt = p0 + rem % nb;
+        }
+        const int tx = pxt % xtiles, ty = pxt / xtiles;
         const int x0 = tx * 32, y0 = ty * BROWS, co0 = cot * BCO;
 
         // byte offsets of this thread's staging elements within chunk 0 of the tile (chunk c adds c * chunk_bytes)
@@ -228,7 +252,10 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
             __syncthreads();
             finish = (s_ticket == P - 1);
             if (finish) {
-                if (tid == 0) frcnn_acquire_agent();
+                if (tid == 0) {
+                    frcnn_acquire_agent();
+                    frcnn_counter_reset(&tile_counters[tile]);      // all P tickets are drawn: leave the page zeroed for the next launch
+                }
                 __syncthreads();
                 // re-accumulate ALL P pieces (this workgroup's own one included, read back from its slot) in
                 // piece order: the sum is then independent of which piece happened to arrive last, and no
@@ -415,7 +442,8 @@ subsample2_kernel(const float *__restrict__ x, float *__restrict__ y, int C, int
 // cfg 3: 64co x (2 rows x 32 px), 4 waves 2x2, wave 32co x 1 row    -- 38x63 / 75x125 maps
 // Workspace of the stream-K distribution: tile counters (one int per tile) followed by two partial-tile slots
 // per workgroup.  Sized for the worst case over all decompositions; owned by the caller.
-struct ConvPlan { int xtiles, ytiles, cotiles, nchunks, ntiles, G; long long total; size_t counters_bytes, ws_bytes; };
+constexpr size_t kCounterPageBytes = 64 * 1024;
+struct ConvPlan { int xtiles, ytiles, cotiles, nchunks, ntiles, G; long long total; size_t counters_bytes, ws_bytes; bool self_cleaning; };
 
 static int frcnn_cu_count() {
     static int cus = 0;
@@ -439,7 +467,12 @@ static ConvPlan plan_conv(int Cin, int Cout, int H, int W, int blocks_per_cu, in
     // stream-K only pays when whole-tile scheduling would leave a ragged last round
     p.G = (streamk && p.ntiles > slots && p.total >= slots) ? slots : p.ntiles;
     if (streamk == 2 && p.total >= slots) p.G = slots;          // forced (tests / tuning)
-    p.counters_bytes = frcnn_align256((size_t)p.ntiles * sizeof(int));
+    // tile counters live in a fixed 64 KB page at the head of the workspace (zeroed once by frcnn_conv3x3_workspace_init;
+    // the last arriver of every split tile puts its counter back to 0, so no launch needs a memset); only a forced stream-K
+    // decomposition with more than 16384 tiles outgrows the page and is zeroed per launch
+    const size_t need = frcnn_align256((size_t)p.ntiles * sizeof(int));
+    p.counters_bytes = need > kCounterPageBytes ? need : kCounterPageBytes;
+    p.self_cleaning = need <= kCounterPageBytes;
     p.ws_bytes = p.counters_bytes + (p.G == p.ntiles ? 0 : (size_t)p.G * 2 * NT * FRAG * sizeof(float));
     return p;
 }
@@ -454,12 +487,23 @@ static int launch_conv(const float *x, const float *wp, const float *bias, float
     if (p.G != p.ntiles && (!workspace || workspace_bytes < p.ws_bytes)) {     // no workspace: fall back to whole tiles
         p.G = p.ntiles;
     }
+    // XCD-aware work order (see the kernel), picked from the PMC traffic passes (profiles/r01_hbm_traffic_pmc.json; no order
+    // changes the run time, the kernel is MFMA-bound): an eighth of the work per XCD halves the fetches of whole-tile launches
+    // (neighbouring tiles share halos in one L2) and of layers whose weights outweigh the map (conv5_x: 111 -> 53 MB);
+    // stream-K layers with a large map fetch least with round-robin placement (161 MB vs 185 / 224 banded).
+    // FRCNN_CONV_XCD=0/1/2 overrides.
+    static const int xcd_env = getenv("FRCNN_CONV_XCD") ? atoi(getenv("FRCNN_CONV_XCD")) : -1;
+    if (!(relu & 768)) {
+        const double map_bytes = 4.0 * Cin * H * W, w_bytes = 4.0 * KS * KS * Cin * Cout;
+        const int order = xcd_env >= 0 ? xcd_env : ((p.G == p.ntiles || w_bytes >= map_bytes) ? 1 : 0);
+        relu |= 256 * order;
+    }
     int *counters = nullptr;
     float *partials = nullptr;
     if (p.G != p.ntiles) {
         counters = (int *)workspace;
         partials = (float *)((char *)workspace + p.counters_bytes);
-        FRCNN_HIP_TRY(hipMemsetAsync(counters, 0, p.counters_bytes, stream));
+        if (!p.self_cleaning) FRCNN_HIP_TRY(hipMemsetAsync(counters, 0, p.counters_bytes, stream));
     }
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_f32_kernel<KS, WCO, WPX, ACO, APX, CK, PIPE, BPC, ABL>), dim3(p.G), dim3(64 * WCO * WPX), 0,
                        stream, x, wp, bias, y, Cin, Cout, H, W, relu, p.xtiles, p.ytiles, p.nchunks, p.total, partials, counters, mask);
@@ -513,9 +557,15 @@ int frcnn_pack_conv3x3_w(const float *w, int Cout, int Cin, float *w_packed, voi
     X(18, 1, 2, 2, 2, 8, true, 3)                             \
     X(19, 1, 4, 2, 1, 8, true, 3)
 
+int frcnn_conv3x3_workspace_init(void *workspace, size_t workspace_bytes, void *stream) {
+    if (!workspace || workspace_bytes < kCounterPageBytes) return FRCNN_ERR_INVALID;
+    FRCNN_HIP_TRY(hipMemsetAsync(workspace, 0, kCounterPageBytes, (hipStream_t)stream));
+    return FRCNN_OK;
+}
+
 size_t frcnn_conv3x3_workspace_bytes(int Cin, int Cout, int H, int W) {
     if (Cin < 1 || Cout < 1 || H < 1 || W < 1) return 0;
-    size_t best = 256;
+    size_t best = kCounterPageBytes;
 #define X(id, wco, wpx, aco, apx, ck, pipe, bpc)                                                        \
     if (Cout % (32 * aco * wco) == 0) {                                                                 \
         const ConvPlan p = plan_conv<wco, wpx, aco, apx, ck>(Cin, Cout, H, W, bpc, 2);                   \
@@ -532,6 +582,7 @@ int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bi
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (Cout % 4) != 0) return FRCNN_ERR_INVALID;
     if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cin * 9 * Cout * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;   // 32-bit buffer offsets
     if (cfg < 0) cfg = pick_conv_config(Cin, Cout, H, W);
+    if (cfg >= 1000) { relu |= 256 * (cfg / 1000); cfg %= 1000; }     // + 1000 / + 2000: force an XCD-aware work order (tuning)
     const int streamk = cfg / 100;
     cfg %= 100;
     switch (cfg) {

@@ -18,3 +18,6 @@ __device__ __forceinline__ void frcnn_acquire_agent() { __builtin_amdgcn_fence(_
 __device__ __forceinline__ int frcnn_ticket(int *counter) {
     return __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+__device__ __forceinline__ void frcnn_counter_reset(int *counter) {
+    __hip_atomic_exchange(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // same path as the tickets
+}

@@ -71,12 +71,21 @@ class Runtime(object):
         self._ws = {}
 
     # ------------------------------------------------------------------ helpers
-    def workspace(self, tag, nbytes):
+    def workspace(self, tag, nbytes, init=None):
+        """Caller-owned scratch, grown on demand; `init(ws)` runs once per (re)allocation (the conv workspace's counter page)."""
         w = self._ws.get(tag)
         if w is None or w.shape[0] < nbytes:
             w = self.mem.empty((max(int(nbytes), 256),), "u8")
             self._ws[tag] = w
+            if init is not None:
+                init(w)
         return w
+
+    def _conv_workspace(self, ci, co, H, W):
+        m, L = self.mem, self.lib
+        return self.workspace("conv3x3", L.frcnn_conv3x3_workspace_bytes(ci, co, H, W),
+                              init=lambda w: _lib.check(L.frcnn_conv3x3_workspace_init(m.ptr(w), w.shape[0], m.stream()),
+                                                        "frcnn_conv3x3_workspace_init"))
 
     def asarray(self, a, dtype="f32"):
         """Accept device arrays, NumPy arrays or anything with `.data` (chainer.Variable-like)."""
@@ -202,7 +211,7 @@ class Runtime(object):
         co = int(w_packed.shape[1])
         assert int(w_packed.shape[0]) == ci * 9
         y = out if out is not None else m.empty((1, co, H, W), "f32")
-        ws = self.workspace("conv3x3", L.frcnn_conv3x3_workspace_bytes(ci, co, H, W))
+        ws = self._conv_workspace(ci, co, H, W)
         _lib.check(L.frcnn_conv3x3_f32_cfg(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(y), ci, co, H, W,
                                            int(bool(relu)), int(cfg), m.ptr(ws), ws.shape[0], m.stream()),
                    "frcnn_conv3x3_f32")
@@ -309,7 +318,7 @@ class Runtime(object):
         assert int(w_packed.shape[0]) == ci * ksize * ksize
         oh, ow = ((H + 1) // 2, (W + 1) // 2) if act == 4 else (H, W)      # act 4: ReLU + 2x2 max-pool fused
         y = out if out is not None else m.empty((1, co, oh, ow), "f32")
-        ws = self.workspace("conv3x3", L.frcnn_conv3x3_workspace_bytes(ci, co, H, W))
+        ws = self._conv_workspace(ci, co, H, W)
         _lib.check(L.frcnn_conv_f32_ex(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(mask), m.ptr(y), ci, co, H, W, int(ksize),
                                        int(act), m.ptr(ws), ws.shape[0], m.stream()), "frcnn_conv_f32_ex")
         return y

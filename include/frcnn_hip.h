@@ -113,7 +113,14 @@ int frcnn_roi_pool_bwd(const float *dy, const int32_t *argmax, int R, int C, int
  *   frcnn_maxpool2x2_f32: (C,H,W) -> (C,ceil(H/2),ceil(W/2))
  */
 int frcnn_pack_conv3x3_w(const float *w, int Cout, int Cin, float *w_packed, void *stream);
+/*   workspace contract:   the first 64 KB of the conv workspace are the tile counters of the stream-K
+ *                         distribution.  Zero them ONCE after allocating the workspace
+ *                         (frcnn_conv3x3_workspace_init); every launch leaves them zeroed again (the last
+ *                         arriver of a split tile resets its counter), so no launch pays a memset.  Do not
+ *                         hand the same scratch to other entry points, and do not share it between streams.
+ */
 size_t frcnn_conv3x3_workspace_bytes(int Cin, int Cout, int H, int W);
+int frcnn_conv3x3_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
 int frcnn_conv3x3_f32(const float *x, const float *w_packed, const float *bias, float *y, int Cin,
                       int Cout, int H, int W, int relu, void *workspace, size_t workspace_bytes,
                       void *stream);

@@ -56,7 +56,7 @@ def test_conv3x3_cfg(rt, cfg):
     P.check_conv3x3(rt, 8, 128, 9, 37, cfg=cfg)
 
 
-@pytest.mark.parametrize("cfg", [201, 205, 210, 104, 110])
+@pytest.mark.parametrize("cfg", [201, 205, 210, 104, 110, 1205, 2205, 2210, 1010, 2010])
 def test_conv3x3_streamk(rt, cfg):
     """stream-K work distribution: the emulated chip has 3 CUs, so tiles split unevenly into 2..4 pieces and the
     last-arriver fix-up (partial slots, tickets, piece-ordered sum) is exercised."""
