@@ -445,15 +445,6 @@ subsample2_kernel(const float *__restrict__ x, float *__restrict__ y, int C, int
 constexpr size_t kCounterPageBytes = 64 * 1024;
 struct ConvPlan { int xtiles, ytiles, cotiles, nchunks, ntiles, G; long long total; size_t counters_bytes, ws_bytes; bool self_cleaning; };
 
-static int frcnn_cu_count() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
-        else cus = 256;
-    }
-    return cus;
-}
 
 template <int WCO, int WPX, int ACO, int APX, int CK>
 static ConvPlan plan_conv(int Cin, int Cout, int H, int W, int blocks_per_cu, int streamk) {

@@ -38,7 +38,106 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
     return (uint16_t)(u >> 16);
 }
 
-template <int KS, int RP>           // RP = row pairs per workgroup: 2 -> 4 waves, 64co x 4 rows; 4 -> 8 waves, 64co x 8 rows
+// maximum of four packed bf16 pairs, lane-wise per 16-bit half (a maximum of bf16 values is a bf16 value: exact)
+__device__ __forceinline__ uint32_t bf16x2_max4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        const int sh = 16 * hh;
+        const float fa = __uint_as_float((a >> sh) << 16), fb = __uint_as_float((b >> sh) << 16);
+        const float fc = __uint_as_float((c >> sh) << 16), fd = __uint_as_float((d >> sh) << 16);
+        r |= ((__float_as_uint(fmaxf(fmaxf(fa, fb), fmaxf(fc, fd))) >> 16) & 0xffffu) << sh;
+    }
+    return r;
+}
+__device__ __forceinline__ uint4 bf16x8_max4(uint4 a, uint4 b, uint4 c, uint4 d) {
+    return make_uint4(bf16x2_max4(a.x, b.x, c.x, d.x), bf16x2_max4(a.y, b.y, c.y, d.y), bf16x2_max4(a.z, b.z, c.z, d.z), bf16x2_max4(a.w, b.w, c.w, d.w));
+}
+
+// Epilogue shared by the bf16 conv kernels: bias, ReLU, and one of three output forms.  `ot` is LDS scratch of at least
+// BROWS * 32 * (BCO * 2 + 16) bytes that no wave reads any more (the caller has passed a barrier after its last fragment read).
+template <int BROWS, int NT, int RW>       // tile rows, threads, rows per wave (wave w owns rows (w >> 1) * RW ..)
+__device__ __forceinline__ void conv_bf16_epilogue(frcnn_f32x16 (&acc)[RW], unsigned char *ot, const float *__restrict__ bias, void *__restrict__ y,
+                                                   int Cout, int CoutP, int H, int W, int relu, int out_mode, int x0, int y0, int co0) {
+    constexpr int BCO = 64;
+    constexpr int OP = BCO * 2 + 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave & 1, wrow = wave >> 1;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    // epilogue: register r of lane l = cout (r&3) + 8*(r>>2) + 4*khalf of pixel l31
+    const int px = x0 + l31;
+    if (out_mode == 0 || out_mode == 2) {
+        // bf16 channel-blocked output: transpose through LDS so that each 16-cout block of a tile row leaves as one contiguous
+        // run of 32 px x 32 B (16-byte stores, consecutive lanes consecutive addresses)
+#pragma unroll
+        for (int j = 0; j < RW; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = wco * 32 + 8 * g + 4 * khalf;             // first of four consecutive couts (within the tile)
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    v[t] = acc[j][4 * g + t] + (co0 + col + t < Cout ? bias[co0 + col + t] : 0.0f);
+                    if (relu) v[t] = fmaxf(v[t], 0.0f);
+                }
+                uint2 pk;
+                pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                *reinterpret_cast<uint2 *>(ot + ((wrow * RW + j) * 32 + l31) * OP + col * 2) = pk;
+            }
+        __syncthreads();
+        if (out_mode == 2) {
+            // F.MaxPooling2D(2, 2) (cover_all) fused: tiles start at even rows / columns, so every 2x2 window lies inside the tile;
+            // y is [CoutP/16][ceil(H/2)][ceil(W/2)][16].  A maximum of bf16 values is a bf16 value: exact.
+            const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+            for (int v = tid; v < (BROWS / 2) * 16 * 8; v += NT) {
+                const int cbl = v / ((BROWS / 2) * 16 * 2), rem = v - cbl * ((BROWS / 2) * 16 * 2);
+                const int opix = rem >> 1, half = rem & 1;
+                const int orow = opix >> 4, ocol = opix & 15;
+                const int py = y0 + 2 * orow, qx = x0 + 2 * ocol, co = co0 + cbl * 16;
+                if (py >= H || qx >= W || co >= CoutP) continue;
+                const bool hasx = qx + 1 < W, hasy = py + 1 < H;
+                const unsigned char *t0 = ot + ((2 * orow) * 32 + 2 * ocol) * OP + (cbl * 2 + half) * 16;
+                const uint4 q0 = *reinterpret_cast<const uint4 *>(t0);
+                const uint4 q1 = hasx ? *reinterpret_cast<const uint4 *>(t0 + OP) : q0;
+                const uint4 q2 = hasy ? *reinterpret_cast<const uint4 *>(t0 + 32 * OP) : q0;
+                const uint4 q3 = (hasx && hasy) ? *reinterpret_cast<const uint4 *>(t0 + 33 * OP) : q0;
+                *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(y) + (((size_t)(co >> 4) * OH + (py >> 1)) * OW + (qx >> 1)) * 16 + half * 8) =
+                    bf16x8_max4(q0, q1, q2, q3);
+            }
+            return;
+        }
+        for (int v = tid; v < BROWS * 32 * 8; v += NT) {                  // 16-byte vectors: (cout block of 16, pixel, half)
+            const int cbl = v / (BROWS * 32 * 2), rem = v - cbl * (BROWS * 32 * 2);
+            const int pix = rem >> 1, half = rem & 1;
+            const int py = y0 + (pix >> 5), qx = x0 + (pix & 31), co = co0 + cbl * 16;
+            if (py < H && qx < W && co < CoutP)
+                *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(y) + (((size_t)(co >> 4) * H + py) * W + qx) * 16 + half * 8) =
+                    *reinterpret_cast<const uint4 *>(ot + pix * OP + (cbl * 2 + half) * 16);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const int py = y0 + wrow * RW + j;
+            if (px >= W || py >= H) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = co0 + wco * 32 + 8 * g + 4 * khalf;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (co + t < Cout) {
+                        float v = acc[j][4 * g + t] + bias[co + t];
+                        if (relu) v = fmaxf(v, 0.0f);
+                        reinterpret_cast<float *>(y)[(size_t)(co + t) * H * W + (size_t)py * W + px] = v;      // fp32 NCHW
+                    }
+            }
+        }
+    }
+}
+
+// ABL = timing ablations (WRONG results; scripts/conv_bf16_sweep.py only): 1 no global loads, 2 no LDS stores, 4 no fragment reads
+template <int KS, int RP, int ABL = 0>   // RP = row pairs per workgroup: 2 -> 4 waves, 64co x 4 rows; 4 -> 8 waves, 64co x 8 rows
 __global__ void __launch_bounds__(128 * RP)
 conv_mfma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
                       int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles) {
@@ -85,7 +184,14 @@ conv_mfma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict
     // Two register sets: chunk t+2 is fetched while chunk t feeds the MFMAs and chunk t+1 waits in the other set, so a load has
     // two chunk times (plus the co-resident workgroup's) to land -- one chunk of 18 MFMAs is shorter than an L2 round trip.
     float4 hregA[HIT], wregA[WIT], hregB[HIT], wregB[WIT];
+    if constexpr ((ABL & 1) != 0) {
+#pragma unroll
+        for (int q = 0; q < HIT; ++q) hregA[q] = hregB[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < WIT; ++q) wregA[q] = wregB[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     auto fetch = [&](int chunk, float4 (&hreg)[HIT], float4 (&wreg)[WIT]) {
+        if constexpr ((ABL & 1) != 0) return;
         const uint32_t xb = (uint32_t)chunk * x_chunk_bytes, wb = (uint32_t)chunk * w_chunk_bytes;
 #pragma unroll
         for (int q = 0; q < HIT; ++q) hreg[q] = frcnn_buf_load_f32x4(xbuf, hoff[q] + xb);
@@ -93,6 +199,13 @@ conv_mfma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict
         for (int q = 0; q < WIT; ++q) wreg[q] = frcnn_buf_load_f32x4(wbuf, woff[q] + wb);
     };
     auto stage = [&](int buf, const float4 (&hreg)[HIT], const float4 (&wreg)[WIT]) {
+        if constexpr ((ABL & 2) != 0) {
+#pragma unroll
+            for (int q = 0; q < HIT; ++q) asm volatile("" ::"v"(hreg[q].x), "v"(hreg[q].y), "v"(hreg[q].z), "v"(hreg[q].w));
+#pragma unroll
+            for (int q = 0; q < WIT; ++q) asm volatile("" ::"v"(wreg[q].x), "v"(wreg[q].y), "v"(wreg[q].z), "v"(wreg[q].w));
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < HIT; ++q) {
             const int v = tid + q * NT;
@@ -117,12 +230,21 @@ conv_mfma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict
         const unsigned char *wl = &w_lds[buf][(wco * 32 + l31) * kPitchB + khalf * 16];
         const unsigned char *il = &in_lds[buf][((wrow * 2) * HPX + l31) * kPitchB + khalf * 16];
         uint4 a[TAPS], b[KS + 1][KS];
+        if constexpr ((ABL & 4) != 0) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) a[tap] = make_uint4(lane + tap, buf, lane, tap);
+#pragma unroll
+            for (int r = 0; r < KS + 1; ++r)
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) b[r][kx] = make_uint4(lane + r, kx, buf, lane);
+        } else {
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) a[tap] = *reinterpret_cast<const uint4 *>(wl + tap * BCO * kPitchB);
 #pragma unroll
         for (int r = 0; r < KS + 1; ++r)
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) b[r][kx] = *reinterpret_cast<const uint4 *>(il + (r * HPX + kx) * kPitchB);
+        }
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
             const int ky = tap / KS, kx = tap % KS;
@@ -149,93 +271,155 @@ conv_mfma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict
         __syncthreads();
     }
 
-    // epilogue: register r of lane l = cout (r&3) + 8*(r>>2) + 4*khalf of pixel l31
-    const int px = x0 + l31;
-    if (out_mode == 0 || out_mode == 2) {
-        // bf16 channel-blocked output: transpose through LDS so that each 16-cout block of a tile row leaves as one contiguous
-        // run of 32 px x 32 B (16-byte stores, consecutive lanes consecutive addresses)
-        unsigned char *ot = &w_lds[0][0];                             // the K loop is over: all waves passed its last barrier
-        static_assert(BROWS * 32 * OP <= (int)sizeof(w_lds), "epilogue tile must fit in the weight buffers");
+    static_assert(BROWS * 32 * OP <= (int)sizeof(w_lds), "epilogue tile must fit in the weight buffers");
+    // the K loop is over and all waves passed its last barrier: the weight buffers are free to carry the output tile
+    conv_bf16_epilogue<2 * RP, 128 * RP, 2>(acc, &w_lds[0][0], bias, y, Cout, CoutP, H, W, relu, out_mode, x0, y0, co0);
+}
+
+// The same 3x3 convolution with LDS-DMA staging (buffer_load_dwordx4 ... lds): a chunk's halo and weight panel go from L2 straight into
+// LDS, 1 KB per wave-instruction -- no staging VGPRs, no ds_write_b128 (13 LDS cycles per KB through the VGPR->LDS path, which with
+// the fragment reads made the register-staged kernel LDS-bound), no wait on a load result inside the K loop.  The destination of
+// a piece is lane-linear, so the LDS image has pitch 32 B (no pad) and is kept conflict-free by an XOR swizzle applied on both
+// sides (rule 21): 16-byte slot of (row P, half h) = 2P + (h ^ ((P >> 3) & 1)) -- every 16-lane group of a ds_read_b128 whose
+// lanes read consecutive rows at any base offset then covers 16 distinct bank slots.  NS ring stages: chunk c+NS-1 is in flight
+// while chunk c feeds the MFMAs; per chunk one counted s_waitcnt vmcnt(N) + one fence-less barrier.
+template <int NS, int WPS, int RPW = 1, int ABL = 0>   // RPW = row pairs per wave: the tile is 64 couts x 4*RPW rows x 32 px; ABL: 1 no DMA, 4 no compute
+__global__ void __launch_bounds__(256, WPS)
+conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
+                     int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles) {
+    constexpr int KS = 3, TAPS = 9, PAD = 1;
+    constexpr int RW = 2 * RPW, BROWS = 2 * RW, BCO = 64;
+    constexpr int HR = BROWS + KS - 1, HPX = 32 + KS - 1;
+    constexpr int IN_ROWS = HR * HPX;                         // 204 halo pixels, 32 B each
+    constexpr int IN_PIECES = (IN_ROWS * 2 + 63) / 64;        // 1 KB pieces (64 lanes x 16 B): 7, the last one partly out of range
+    constexpr int W_PIECES = TAPS * BCO * 2 / 64;             // 18
+    constexpr int PIECES = IN_PIECES + W_PIECES;
+    constexpr int IN_BYTES = IN_PIECES * 1024, STAGE_BYTES = PIECES * 1024;
+    constexpr int PPW = (PIECES + 3) / 4;                     // pieces per wave (wave w moves pieces w, w+4, ...)
+    constexpr int OP = BCO * 2 + 16;
+    constexpr int RING_BYTES = NS * STAGE_BYTES > BROWS * 32 * OP ? NS * STAGE_BYTES : BROWS * 32 * OP;
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[RING_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave & 1, wrow = wave >> 1;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int tile = blockIdx.x;
+    const int tx = tile % xtiles, ty = (tile / xtiles) % ytiles, cot = tile / (xtiles * ytiles);
+    const int x0 = tx * 32, y0 = ty * BROWS, co0 = cot * BCO;
+    const int nchunks = CinP / kCK;
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)H * W * CinP * 2));
+    const frcnn_buf_t wbuf = frcnn_make_buf(wp, (uint32_t)((size_t)TAPS * CoutP * CinP * 2));
+    const uint32_t x_chunk_bytes = (uint32_t)(H * W) * 32u, w_chunk_bytes = (uint32_t)(TAPS * CoutP) * 32u;
+
+    // source offset (chunk 0) of the 16 bytes this lane contributes to each of its wave's pieces: slot s of a region holds
+    // (row P = s >> 1, half (s & 1) ^ ((P >> 3) & 1))
+    uint32_t poff[PPW];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col = wco * 32 + 8 * g + 4 * khalf;             // first of four consecutive couts (within the tile)
-                float v[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    v[t] = acc[j][4 * g + t] + (co0 + col + t < Cout ? bias[co0 + col + t] : 0.0f);
-                    if (relu) v[t] = fmaxf(v[t], 0.0f);
-                }
-                uint2 pk;
-                pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                *reinterpret_cast<uint2 *>(ot + ((wrow * 2 + j) * 32 + l31) * OP + col * 2) = pk;
-            }
-        __syncthreads();
-        if (out_mode == 2) {
-            // F.MaxPooling2D(2, 2) (cover_all) fused: tiles start at even rows / columns, so every 2x2 window lies inside the tile;
-            // y is [CoutP/16][ceil(H/2)][ceil(W/2)][16].  A maximum of bf16 values is a bf16 value: exact.
-            const int OH = (H + 1) / 2, OW = (W + 1) / 2;
-            for (int v = tid; v < (BROWS / 2) * 16 * 8; v += NT) {
-                const int cbl = v / ((BROWS / 2) * 16 * 2), rem = v - cbl * ((BROWS / 2) * 16 * 2);
-                const int opix = rem >> 1, half = rem & 1;
-                const int orow = opix >> 4, ocol = opix & 15;
-                const int py = y0 + 2 * orow, qx = x0 + 2 * ocol, co = co0 + cbl * 16;
-                if (py >= H || qx >= W || co >= CoutP) continue;
-                const bool hasx = qx + 1 < W, hasy = py + 1 < H;
-                const unsigned char *t0 = ot + ((2 * orow) * 32 + 2 * ocol) * OP + (cbl * 2 + half) * 16;
-                uint4 q[4];
-                q[0] = *reinterpret_cast<const uint4 *>(t0);
-                q[1] = hasx ? *reinterpret_cast<const uint4 *>(t0 + OP) : q[0];
-                q[2] = hasy ? *reinterpret_cast<const uint4 *>(t0 + 32 * OP) : q[0];
-                q[3] = (hasx && hasy) ? *reinterpret_cast<const uint4 *>(t0 + 33 * OP) : q[0];
-                uint32_t o4[4];
-                const uint32_t *w0 = reinterpret_cast<const uint32_t *>(&q[0]), *w1 = reinterpret_cast<const uint32_t *>(&q[1]);
-                const uint32_t *w2 = reinterpret_cast<const uint32_t *>(&q[2]), *w3 = reinterpret_cast<const uint32_t *>(&q[3]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    uint32_t r = 0;
-#pragma unroll
-                    for (int hh = 0; hh < 2; ++hh) {
-                        const int sh = 16 * hh;
-                        const float a = __uint_as_float((w0[t] >> sh) << 16), b = __uint_as_float((w1[t] >> sh) << 16);
-                        const float c = __uint_as_float((w2[t] >> sh) << 16), d = __uint_as_float((w3[t] >> sh) << 16);
-                        r |= ((__float_as_uint(fmaxf(fmaxf(a, b), fmaxf(c, d))) >> 16) & 0xffffu) << sh;
-                    }
-                    o4[t] = r;
-                }
-                *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(y) + (((size_t)(co >> 4) * OH + (py >> 1)) * OW + (qx >> 1)) * 16 + half * 8) =
-                    make_uint4(o4[0], o4[1], o4[2], o4[3]);
-            }
-            return;
-        }
-        for (int v = tid; v < BROWS * 32 * 8; v += NT) {                  // 16-byte vectors: (cout block of 16, pixel, half)
-            const int cbl = v / (BROWS * 32 * 2), rem = v - cbl * (BROWS * 32 * 2);
-            const int pix = rem >> 1, half = rem & 1;
-            const int py = y0 + (pix >> 5), qx = x0 + (pix & 31), co = co0 + cbl * 16;
-            if (py < H && qx < W && co < CoutP)
-                *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(y) + (((size_t)(co >> 4) * H + py) * W + qx) * 16 + half * 8) =
-                    *reinterpret_cast<const uint4 *>(ot + pix * OP + (cbl * 2 + half) * 16);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int py = y0 + wrow * 2 + j;
-            if (px >= W || py >= H) continue;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = co0 + wco * 32 + 8 * g + 4 * khalf;
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (co + t < Cout) {
-                        float v = acc[j][4 * g + t] + bias[co + t];
-                        if (relu) v = fmaxf(v, 0.0f);
-                        reinterpret_cast<float *>(y)[(size_t)(co + t) * H * W + (size_t)py * W + px] = v;      // fp32 NCHW
-                    }
-            }
+    for (int q = 0; q < PPW; ++q) {
+        const int pid = wave + 4 * q;
+        if (pid < IN_PIECES) {
+            const int sl = pid * 64 + lane, P = sl >> 1, half = (sl & 1) ^ ((P >> 3) & 1);
+            const int hr = P / HPX, hx = P - hr * HPX;
+            const int gy = y0 - PAD + hr, gx = x0 - PAD + hx;
+            const bool inside = P < IN_ROWS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            poff[q] = inside ? (uint32_t)((gy * W + gx) * 32 + half * 16) : kBufOob;
+        } else {
+            const int sl = (pid - IN_PIECES) * 64 + lane, P = sl >> 1, half = (sl & 1) ^ ((P >> 3) & 1);
+            const int tap = P / BCO, col = P - tap * BCO;
+            poff[q] = (pid < PIECES && co0 + col < CoutP) ? (uint32_t)((tap * CoutP + co0 + col) * 32 + half * 16) : kBufOob;
         }
     }
+    auto issue = [&](int chunk, int stage) {
+        if constexpr ((ABL & 1) != 0) return;
+        unsigned char *dst = ring + stage * STAGE_BYTES + wave * 1024;
+        const uint32_t xs = (uint32_t)chunk * x_chunk_bytes, ws = (uint32_t)chunk * w_chunk_bytes;
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            // pieces 4q .. 4q+3 belong to waves 0..3: which tensor they come from is a compile-time fact except where the halo
+            // region ends inside the group (then: a wave-uniform select), and only the last group can run past the end
+            if (4 * q + 3 < IN_PIECES) frcnn_buf_load_lds_b128(xbuf, dst + q * 4096, poff[q], xs);
+            else if (4 * q >= IN_PIECES) {
+                if (4 * q + 3 < PIECES || wave + 4 * q < PIECES) frcnn_buf_load_lds_b128(wbuf, dst + q * 4096, poff[q], ws);
+            } else {
+                const bool in = wave + 4 * q < IN_PIECES;
+                frcnn_buf_load_lds_b128(in ? xbuf : wbuf, dst + q * 4096, poff[q], in ? xs : ws);
+            }
+        }
+    };
+    // this wave's loads per chunk: the N of "all but the newest chunk have landed"
+    const bool seven = wave < PIECES - 4 * (PPW - 1);
+    auto wait_all_but_newest = [&]() {
+        if (seven) frcnn_wait_vmcnt<PPW>(); else frcnn_wait_vmcnt<PPW - 1>();
+    };
+
+    // fragment byte offsets inside a stage (swizzled): A = weight row tap*64 + wco*32 + l31, B = halo pixel (RW*wrow + r)*34 + l31 + kx
+    const uint32_t a_off = (uint32_t)(IN_BYTES + (wco * 32 + l31) * 32 + ((khalf ^ ((l31 >> 3) & 1)) << 4));
+    uint32_t b_off[RW + KS - 1][KS];
+#pragma unroll
+    for (int r = 0; r < RW + KS - 1; ++r)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const int P = (wrow * RW + r) * HPX + l31 + kx;
+            b_off[r][kx] = (uint32_t)(P * 32 + ((khalf ^ ((P >> 3) & 1)) << 4));
+        }
+
+    frcnn_f32x16 acc[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    auto compute = [&](int stage) {
+        if constexpr ((ABL & 4) != 0) return;
+        const unsigned char *st = ring + stage * STAGE_BYTES;
+        uint4 a[TAPS], b[RW + KS - 1][KS];
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) a[tap] = *reinterpret_cast<const uint4 *>(st + a_off + tap * BCO * 32);
+#pragma unroll
+        for (int r = 0; r < RW + KS - 1; ++r)
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) b[r][kx] = *reinterpret_cast<const uint4 *>(st + b_off[r][kx]);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+            for (int j = 0; j < RW; ++j) acc[j] = frcnn_mfma_32x32x16_bf16(a[tap], b[ky + j][kx], acc[j]);
+        }
+    };
+
+    if constexpr (NS == 1) {
+        // single stage: no overlap inside the workgroup -- the other (up to five) workgroups of the CU run their MFMAs while this
+        // one waits for its chunk; the small LDS footprint is what buys that occupancy
+        for (int c = 0; c < nchunks; ++c) {
+            issue(c, 0);
+            frcnn_wait_vmcnt<0>();
+            frcnn_barrier_nofence();
+            compute(0);
+            if (c + 1 < nchunks) frcnn_barrier_nofence();       // everybody is done reading before the stage is refilled
+        }
+    } else {
+    // prologue: NS-1 chunks in flight, chunk 0 landed
+#pragma unroll
+    for (int c = 0; c < NS - 1; ++c)
+        if (c < nchunks) issue(c, c);
+    if (NS == 3 && nchunks > 1) wait_all_but_newest(); else frcnn_wait_vmcnt<0>();
+    frcnn_barrier_nofence();
+    int s_cur = 0, s_new = NS - 1;                               // stage of chunk c, stage chunk c+NS-1 goes to
+    for (int c = 0; c < nchunks; ++c) {
+        const bool more = c + NS - 1 < nchunks;
+        if (more) issue(c + NS - 1, s_new);
+        compute(s_cur);
+        if (c + 1 < nchunks) {
+            // chunk c+1 must have landed for everybody, and everybody must be done reading stage s_cur before it is refilled
+            if (NS == 3 && more) wait_all_but_newest(); else frcnn_wait_vmcnt<0>();
+            frcnn_barrier_nofence();
+        }
+        s_cur = s_cur + 1 == NS ? 0 : s_cur + 1;
+        s_new = s_new + 1 == NS ? 0 : s_new + 1;
+    }
+    }
+    __syncthreads();                                            // the ring becomes the epilogue's output tile
+    conv_bf16_epilogue<BROWS, 256, RW>(acc, ring, bias, y, Cout, CoutP, H, W, relu, out_mode, x0, y0, co0);
 }
 
 // (Cout, Cin, k, k) fp32 -> [CinP/16][tap][CoutP][16] bf16, zero padded
@@ -271,28 +455,11 @@ maxpool2x2_bf16_kernel(const uint16_t *__restrict__ x, uint16_t *__restrict__ y,
         const int half = (int)(i & 1), ow = (int)((i >> 1) % OW), oh = (int)(((i >> 1) / OW) % OH), cb = (int)((i >> 1) / ((size_t)OW * OH));
         const bool hasx = 2 * ow + 1 < W, hasy = 2 * oh + 1 < H;
         const uint16_t *p = x + ((((size_t)cb * H + 2 * oh) * W + 2 * ow) * 16 + half * 8);
-        uint4 q[4];
-        q[0] = *reinterpret_cast<const uint4 *>(p);
-        q[1] = hasx ? *reinterpret_cast<const uint4 *>(p + 16) : q[0];
-        q[2] = hasy ? *reinterpret_cast<const uint4 *>(p + (size_t)W * 16) : q[0];
-        q[3] = (hasx && hasy) ? *reinterpret_cast<const uint4 *>(p + (size_t)W * 16 + 16) : q[0];
-        uint32_t out[4];
-        const uint32_t *w0 = reinterpret_cast<const uint32_t *>(&q[0]), *w1 = reinterpret_cast<const uint32_t *>(&q[1]);
-        const uint32_t *w2 = reinterpret_cast<const uint32_t *>(&q[2]), *w3 = reinterpret_cast<const uint32_t *>(&q[3]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            uint32_t r = 0;
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int sh = 16 * hh;
-                const float a = bf16_to_f32((uint16_t)(w0[t] >> sh)), b = bf16_to_f32((uint16_t)(w1[t] >> sh));
-                const float c = bf16_to_f32((uint16_t)(w2[t] >> sh)), d = bf16_to_f32((uint16_t)(w3[t] >> sh));
-                const float m = fmaxf(fmaxf(a, b), fmaxf(c, d));
-                r |= ((__float_as_uint(m) >> 16) & 0xffffu) << sh;          // a maximum of bf16 values is a bf16 value: exact
-            }
-            out[t] = r;
-        }
-        *reinterpret_cast<uint4 *>(y + ((((size_t)cb * OH + oh) * OW + ow) * 16 + half * 8)) = make_uint4(out[0], out[1], out[2], out[3]);
+        const uint4 q0 = *reinterpret_cast<const uint4 *>(p);
+        const uint4 q1 = hasx ? *reinterpret_cast<const uint4 *>(p + 16) : q0;
+        const uint4 q2 = hasy ? *reinterpret_cast<const uint4 *>(p + (size_t)W * 16) : q0;
+        const uint4 q3 = (hasx && hasy) ? *reinterpret_cast<const uint4 *>(p + (size_t)W * 16 + 16) : q0;
+        *reinterpret_cast<uint4 *>(y + ((((size_t)cb * OH + oh) * OW + ow) * 16 + half * 8)) = bf16x8_max4(q0, q1, q2, q3);
     }
 }
 
@@ -358,8 +525,46 @@ int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bi
     const bool big = rp_env && atoi(rp_env) == 4;
     const int ytiles = frcnn_cdiv(H, big ? 8 : 4);
     const dim3 grid(xtiles * ytiles * cotiles);
+    // 3x3: LDS-DMA staging.  Launches with at least four tiles per CU run single-stage rings -- 25 KB of LDS per workgroup, up to six
+    // workgroups per CU, the other workgroups' MFMAs cover a workgroup's wait -- smaller launches (the 75x125 and 38x63 maps: 0.6-2.4
+    // tiles per CU) get the two-stage ring that overlaps the next chunk's DMA with the MFMAs inside the workgroup
+    // (scripts/conv_bf16_sweep.py, r01: +20...45 % over register staging on every VGG layer).  FRCNN_BF16_DMA overrides
+    // (digits = ring stages, waves/SIMD budget, row pairs per wave; 0 = the register-staged kernel; 4-digit values = timing ablations).
+    const char *dma_env = getenv("FRCNN_BF16_DMA");
+    int mode = dma_env ? atoi(dma_env) : -1;
+    if (mode < 0) mode = (long)grid.x >= 4L * frcnn_cu_count() ? 141 : 231;
     if (ksize == 3 && big) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3, 4>), grid, dim3(512), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
-    else if (ksize == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3, 2>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
+    else if (ksize == 3 && mode > 0) {
+        const int yt8 = frcnn_cdiv(H, 8);
+        const dim3 grid8(xtiles * yt8 * cotiles);
+#define FRCNN_DMA_CASE(NS, WPS, RPW)                                                                                                     \
+    case NS * 100 + WPS * 10 + RPW:                                                                                                      \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dma_bf16_kernel<NS, WPS, RPW>), RPW == 2 ? grid8 : grid, dim3(256), 0, stream, x, w_packed, \
+                           bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, RPW == 2 ? yt8 : ytiles);                               \
+        break;
+#define FRCNN_DMA_ABL(NS, WPS, A)                                                                                                        \
+    case NS * 1000 + WPS * 100 + 10 + A:                                                                                                 \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dma_bf16_kernel<NS, WPS, 1, A>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP,   \
+                           Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);                                                            \
+        break;
+        switch (mode) {
+            FRCNN_DMA_CASE(3, 2, 1) FRCNN_DMA_CASE(2, 3, 1) FRCNN_DMA_CASE(1, 4, 1) FRCNN_DMA_CASE(1, 3, 2) FRCNN_DMA_CASE(2, 2, 2)
+            FRCNN_DMA_ABL(1, 4, 1) FRCNN_DMA_ABL(1, 4, 4) FRCNN_DMA_ABL(2, 3, 1) FRCNN_DMA_ABL(2, 3, 4)      // WRONG results: sweeps only
+            default: return FRCNN_ERR_INVALID;
+        }
+#undef FRCNN_DMA_CASE
+#undef FRCNN_DMA_ABL
+    }
+    else if (ksize == 3) {
+        const char *abl_env = getenv("FRCNN_BF16_ABL");
+        const int abl = abl_env ? atoi(abl_env) : 0;
+#define FRCNN_ABL_CASE(A) case A: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3, 2, A>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles); break;
+        switch (abl) {
+            FRCNN_ABL_CASE(1) FRCNN_ABL_CASE(2) FRCNN_ABL_CASE(3)
+            default: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3, 2>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
+        }
+#undef FRCNN_ABL_CASE
+    }
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<1, 2>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
     return frcnn_launch_status();
 }

@@ -33,3 +33,24 @@ __device__ __forceinline__ void frcnn_buf_store_f32x4_wt(frcnn_buf_t b, uint32_t
     u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
     __builtin_amdgcn_raw_buffer_store_b128(u, b, (int)byte_off, 0, /*aux: sc1*/ 16);
 }
+
+// LDS-DMA: one wave-instruction moves 64 x 16 bytes from the buffer straight into LDS at lds_wave_base + 16 * lane -- no staging
+// VGPRs, no ds_write.  The destination is lane-linear by construction (any swizzle goes on the per-lane SOURCE offset and on the
+// reader, cdna_hip_programming.md rule 21); out-of-range lanes deposit zeros; `soff` is a wave-uniform byte offset added after the
+// range check.  Completion is counted by vmcnt: the caller waits with frcnn_wait_vmcnt<N>() -- the compiler does not see these loads,
+// which is the point (it would drain vmcnt(0) at the next barrier and serialise the prefetch with the MFMAs).
+__device__ __forceinline__ void frcnn_buf_load_lds_b128(frcnn_buf_t b, void *lds_wave_base, uint32_t byte_off, uint32_t soff) {
+    const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_wave_base;
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(la), "v"(byte_off), "s"(b), "s"(soff)
+                 : "memory");
+}
+template <int N>
+__device__ __forceinline__ void frcnn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// workgroup barrier WITHOUT the fences of __syncthreads() (which would drain every outstanding LDS-DMA): the caller has already
+// waited for exactly the loads it needs; the "memory" clobbers keep the compiler from moving LDS accesses across it.
+__device__ __forceinline__ void frcnn_barrier_nofence() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}

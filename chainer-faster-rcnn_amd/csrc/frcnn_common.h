@@ -21,3 +21,15 @@ static inline int frcnn_launch_status() {
 
 static inline size_t frcnn_align256(size_t v) { return (v + 255) & ~(size_t)255; }
 static inline int frcnn_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// compute units of the current device (256 on MI355X; the test emulator reports its own count)
+static inline int frcnn_cu_count() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+        else cus = 256;
+    }
+    return cus;
+}
+

@@ -15,6 +15,16 @@ SHAPES = [("conv1_1", 3, 64, 600, 1000), ("conv1_2", 64, 64, 600, 1000), ("conv2
 
 
 def main():
+    """FRCNN_BF16_ABLS="0 1 2 3 4 7": repeat the sweep with each timing ablation of the 3x3 kernel (see conv_bf16.hip)."""
+    for abl in os.environ.get("FRCNN_BF16_ABLS", "0").split():
+        for dma in os.environ.get("FRCNN_BF16_DMAS", "").split() or [os.environ.get("FRCNN_BF16_DMA", "0")]:
+            os.environ["FRCNN_BF16_ABL"] = abl
+            os.environ["FRCNN_BF16_DMA"] = dma
+            print("abl", abl, "dma", dma, end="  ")
+            sweep()
+
+
+def sweep():
     rt = pkg.runtime.default_runtime()
     blk_a = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     blk_b = torch.empty_like(blk_a)

@@ -17,3 +17,11 @@ static inline float4 frcnn_buf_load_f32x4(frcnn_buf_t b, uint32_t off) {
 static inline void frcnn_buf_store_f32x4_wt(frcnn_buf_t b, uint32_t off, float4 v) {
     if ((uint64_t)off + 16 <= b.bytes) memcpy(const_cast<char *>(b.base) + off, &v, 16);
 }
+static inline void frcnn_buf_load_lds_b128(frcnn_buf_t b, void *lds_wave_base, uint32_t off, uint32_t soff) {
+    // lane-linear destination; the range check sees the per-lane offset only (soff is added after it), as on the hardware
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((uint64_t)off + 16 <= b.bytes) memcpy(&v, b.base + off + soff, 16);
+    memcpy((char *)lds_wave_base + 16 * (threadIdx.x & 63), &v, 16);
+}
+template <int N> static inline void frcnn_wait_vmcnt() {}
+static inline void frcnn_barrier_nofence() { __syncthreads(); }

@@ -166,3 +166,15 @@ def test_conv_bf16_eight_row_tiles(rt, monkeypatch):
     monkeypatch.setenv("FRCNN_BF16_RP", "4")                        # force the 8-wave / 8-row decomposition
     P.check_conv_bf16(rt, 16, 64, 13, 37, seed=3)
     P.check_conv_bf16(rt, 32, 128, 8, 33, seed=4)
+
+
+@pytest.mark.parametrize("mode", ["321", "231", "141", "132", "222", "0"])
+def test_conv_bf16_lds_dma(rt, monkeypatch, mode):
+    """Every LDS-DMA staging variant of the 3x3 bf16 kernel (lane-linear swizzled LDS image, NS-stage ring) and the
+    register-staged kernel ("0"): same results.  The default picks 141 / 231 by launch size."""
+    monkeypatch.setenv("FRCNN_BF16_DMA", mode)
+    P.check_conv_bf16(rt, 16, 64, 9, 37)                  # one chunk
+    P.check_conv_bf16(rt, 3, 64, 7, 33, seed=1)
+    P.check_conv_bf16(rt, 80, 128, 13, 70, seed=2)        # five chunks: the ring wraps; three x tiles, ragged rows
+    P.check_conv_bf16_pool(rt, 48, 64, 9, 37, seed=3)
+
