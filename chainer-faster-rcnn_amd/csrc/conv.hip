@@ -45,7 +45,9 @@ namespace {
 // and runs the bias/ReLU epilogue.  Nobody ever waits, so residency is irrelevant to correctness.
 // BPC = workgroups meant to be co-resident per CU; it is the register budget handed to the compiler
 // (__launch_bounds__'s second argument is waves per SIMD = BPC * threads / 256).
-template <int KS, int WCO, int WPX, int ACO, int APX, int CK, bool PIPE, int BPC, int ABL = 0>
+// DMA = stage through LDS-DMA (buffer_load ... lds: no staging VGPRs, no ds_write pass, counted vmcnt wait + fence-less barrier);
+// the LDS images are the same -- they were lane-linear per 64-thread slice already.
+template <int KS, int WCO, int WPX, int ACO, int APX, int CK, bool PIPE, int BPC, int ABL = 0, bool DMA = false>
 __global__ void __launch_bounds__(64 * WCO * WPX, (BPC * 64 * WCO * WPX) / 256)
 conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
                      float *__restrict__ y, int Cin, int Cout, int H, int W, int relu, int xtiles, int ytiles, int nchunks,
@@ -64,7 +66,8 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
     constexpr int HIT = (HV + NT - 1) / NT;
     constexpr int FRAG = ACO * APX * 16;             // accumulator floats per thread
     __shared__ __attribute__((aligned(16))) float w_lds[2][KR][BCO];
-    __shared__ __attribute__((aligned(16))) float in_lds[2][CK][HR][kHaloPitch];
+    constexpr int HVP = (HV + 63) / 64 * 64;          // a buffer holds whole 64-float DMA pieces (the tail lanes deposit zeros)
+    __shared__ __attribute__((aligned(16))) float in_lds[2][HVP];
     __shared__ int s_ticket;
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -150,8 +153,21 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
 #pragma unroll
             for (int q = 0; q < HIT; ++q) {
                 const int e = tid + q * NT;
-                if (e < HV) (&in_lds[buf][0][0][0])[e] = hreg[q];
+                if (e < HV) in_lds[buf][e] = hreg[q];
             }
+        };
+
+        // LDS-DMA form of fetch + stage: slice q of the register path (threads tid + q*NT) is, per wave, one lane-linear piece
+        auto issue = [&](int chunk, int buf) {
+            const uint32_t wb = (uint32_t)chunk * w_chunk_bytes, xb = (uint32_t)chunk * x_chunk_bytes;
+#pragma unroll
+            for (int q = 0; q < WIT; ++q)
+                if ((q + 1) * NT <= WV || wave * 64 + q * NT < WV)
+                    frcnn_buf_load_lds_b128(wbuf, reinterpret_cast<float4 *>(&w_lds[buf][0][0]) + q * NT + wave * 64, woff[q], wb);
+#pragma unroll
+            for (int q = 0; q < HIT; ++q)
+                if ((q + 1) * NT <= HVP || wave * 64 + q * NT < HVP)
+                    frcnn_buf_load_lds_b32(xbuf, &in_lds[buf][q * NT + wave * 64], hoff[q], xb);
         };
 
         f32x16 acc[ACO][APX];
@@ -162,13 +178,22 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-        fetch(c_begin);
-        stage(0);
-        __syncthreads();
+        if constexpr (DMA) {
+            issue(c_begin, 0);
+            frcnn_wait_vmcnt<0>();
+            frcnn_barrier_nofence();
+        } else {
+            fetch(c_begin);
+            stage(0);
+            __syncthreads();
+        }
         int cur = 0;
         for (int chunk = c_begin; chunk < c_end; ++chunk) {
             const bool more = chunk + 1 < c_end;
-            if (more && ABL == 0) fetch(chunk + 1);
+            if constexpr (DMA) {
+                if (more) issue(chunk + 1, cur ^ 1);
+            }
+            if (!DMA && more && ABL == 0) fetch(chunk + 1);
             constexpr int NSTEP = TAPS * (CK / 2);       // k-steps per chunk: step s = (tap, channel pair)
             auto frag = [&](int s, float *a, float *b) {
                 const int tap = s / (CK / 2), cp = s % (CK / 2);
@@ -184,7 +209,7 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
 #pragma unroll
                 for (int i = 0; i < ACO; ++i) a[i] = w_lds[cur][c * TAPS + tap][a_col + 32 * i];
 #pragma unroll
-                for (int j = 0; j < APX; ++j) b[j] = in_lds[cur][c][b_row + j + ky][l31 + kx];
+                for (int j = 0; j < APX; ++j) b[j] = in_lds[cur][(c * HR + b_row + j + ky) * kHaloPitch + l31 + kx];
             };
             if constexpr (PIPE) {
                 // fragments of step s+1 are read before the MFMAs of step s are issued (register double
@@ -213,8 +238,13 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
                 }
             }
-            if (more && ABL == 0) stage(cur ^ 1);
-            if (ABL < 2) __syncthreads();
+            if constexpr (DMA) {
+                frcnn_wait_vmcnt<0>();           // chunk + 1 has landed (nothing else is in flight)
+                frcnn_barrier_nofence();         // ... for everybody, and everybody is done reading buffer `cur`
+            } else {
+                if (more && ABL == 0) stage(cur ^ 1);
+                if (ABL < 2) __syncthreads();
+            }
             cur ^= 1;
         }
 
@@ -468,7 +498,7 @@ static ConvPlan plan_conv(int Cin, int Cout, int H, int W, int blocks_per_cu, in
     return p;
 }
 
-template <int KS, int WCO, int WPX, int ACO, int APX, int CK, bool PIPE, int BPC, int ABL = 0>
+template <int KS, int WCO, int WPX, int ACO, int APX, int CK, bool PIPE, int BPC, int ABL = 0, bool DMA = false>
 static int launch_conv(const float *x, const float *wp, const float *bias, float *y, int Cin, int Cout, int H, int W, int relu,
                        int streamk, void *workspace, size_t workspace_bytes, hipStream_t stream, const float *mask = nullptr) {
     constexpr int blocks_per_cu = BPC;
@@ -496,24 +526,26 @@ static int launch_conv(const float *x, const float *wp, const float *bias, float
         partials = (float *)((char *)workspace + p.counters_bytes);
         if (!p.self_cleaning) FRCNN_HIP_TRY(hipMemsetAsync(counters, 0, p.counters_bytes, stream));
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_f32_kernel<KS, WCO, WPX, ACO, APX, CK, PIPE, BPC, ABL>), dim3(p.G), dim3(64 * WCO * WPX), 0,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_f32_kernel<KS, WCO, WPX, ACO, APX, CK, PIPE, BPC, ABL, DMA>), dim3(p.G), dim3(64 * WCO * WPX), 0,
                        stream, x, wp, bias, y, Cin, Cout, H, W, relu, p.xtiles, p.ytiles, p.nchunks, p.total, partials, counters, mask);
     return frcnn_launch_status();
 }
 
 // Chosen from scripts/conv_sweep.py on MI355X (profiles/r01_conv_sweep*.json).  Returns decomposition id + 100 * mode.
-//   conv1_1 (Cin = 3): 4-channel chunks (K = 27 padded to 36, not 72), four workgroups per CU -- output-write bound.
-//   Everything else 64 couts x 32 px wide, wave = 32co x 2 rows (4-row tiles) or 32co x 1 row (2-row tiles for the
-//   38x63 maps).  Whole tiles only while a layer has many rounds of them (conv1_2: 6.25 rounds of the 768 workgroup
-//   slots); otherwise stream-K: with write-through partial tiles the fix-up costs less than the ragged last round
-//   (20 % at 3.1 rounds, 80 % of the SIMDs idle at 0.2 rounds).
-static int pick_conv_config(int Cin, int Cout, int H, int W) {
-    if (Cin < 8) return 14;
+// All picks stage through LDS-DMA (+3.5 ... 5 % over register staging on every layer) with 4-channel chunks: 25 KB of LDS per
+// workgroup instead of 50, four workgroups per CU instead of three.
+//   34: 64 couts x 4 rows x 32 px, wave = 32co x 2 rows.  Whole tiles while a layer has >= 4 rounds of them (conv1_1, conv1_2).
+//   36: 2-row tiles, wave = 32co x 1 row: whole tiles at 2-4 rounds of the 4-row tiling (the 300x500 maps), stream-K (236) below
+//       that (150x250, 75x125, 38x63: the fix-up costs less than a ragged last round; 80 % of the SIMDs would idle at 0.2 rounds).
+//   `two_rows` (the fused ReLU + pool epilogue needs a wave to own a window row pair): 34 / stream-K 230 (8-channel chunks).
+static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows) {
+    if (Cin < 8) return 34;
     const long ntiles = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4) * (Cout / 64);
     const long slots = (long)frcnn_cu_count() * 3;
-    if (ntiles >= 4 * slots) return 10;
-    if (2 * ntiles >= slots) return 210;
-    return 205;
+    if (ntiles >= 4 * slots) return 34;
+    if (two_rows) return 230;
+    if (ntiles >= 2 * slots) return 36;
+    return 236;
 }
 
 }  // namespace
@@ -537,6 +569,7 @@ int frcnn_pack_conv3x3_w(const float *w, int Cout, int Cin, float *w_packed, voi
     X(3, 2, 2, 1, 1, 8, false, 3)                             \
     X(4, 2, 2, 2, 2, 4, true, 2)                              \
     X(5, 2, 2, 1, 1, 8, true, 3)                              \
+    X(6, 2, 2, 1, 1, 4, true, 4)                              \
     X(8, 1, 4, 2, 2, 4, true, 2)                              \
     X(10, 2, 2, 1, 2, 8, true, 3)                             \
     X(11, 1, 4, 2, 1, 8, true, 3)                             \
@@ -572,7 +605,7 @@ int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bi
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (Cout % 4) != 0) return FRCNN_ERR_INVALID;
     if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cin * 9 * Cout * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;   // 32-bit buffer offsets
-    if (cfg < 0) cfg = pick_conv_config(Cin, Cout, H, W);
+    if (cfg < 0) cfg = pick_conv_config(Cin, Cout, H, W, false);
     if (cfg >= 1000) { relu |= 256 * (cfg / 1000); cfg %= 1000; }     // + 1000 / + 2000: force an XCD-aware work order (tuning)
     const int streamk = cfg / 100;
     cfg %= 100;
@@ -586,6 +619,11 @@ int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bi
         case 51: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 1>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 52: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 2>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 53: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 3>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        // LDS-DMA staging forms of decompositions 10 / 5 / 14 
+        case 30: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 35: return launch_conv<3, 2, 2, 1, 1, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 34: return launch_conv<3, 2, 2, 1, 2, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 36: return launch_conv<3, 2, 2, 1, 1, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         default: return FRCNN_ERR_INVALID;
     }
 }
@@ -596,14 +634,13 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (Cout % 64) != 0) return FRCNN_ERR_INVALID;
     if (act < 0 || act > 4 || ((act == 2 || act == 3) && !mask) || (ksize != 1 && ksize != 3) || (act == 4 && ksize != 3)) return FRCNN_ERR_INVALID;
     if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cin * ksize * ksize * Cout * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;
-    if (ksize == 1) return launch_conv<1, 2, 2, 1, 1, 8, true, 3>(x, w_packed, bias, y, Cin, Cout, H, W, act, 0, nullptr, 0, stream, mask);
-    int cfg = pick_conv_config(Cin, Cout, H, W);
-    if (act == 4 && cfg % 100 == 5) cfg = 210;                 // the fused pool needs the two-rows-per-wave decomposition
+    if (ksize == 1) return launch_conv<1, 2, 2, 1, 1, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, 0, nullptr, 0, stream, mask);
+    const int cfg = pick_conv_config(Cin, Cout, H, W, act == 4);
     const int streamk = cfg / 100;
     switch (cfg % 100) {
-        case 14: return launch_conv<3, 2, 2, 1, 2, 4, true, 4>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
-        case 5: return launch_conv<3, 2, 2, 1, 1, 8, true, 3>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
-        default: return launch_conv<3, 2, 2, 1, 2, 8, true, 3>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
+        case 34: return launch_conv<3, 2, 2, 1, 2, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
+        case 36: return launch_conv<3, 2, 2, 1, 1, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
+        default: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
     }
 }
 
@@ -668,7 +705,7 @@ int frcnn_rpn_heads_f32(const float *h, int Cmid, int H, int W, int A, const flo
     hipStream_t stream = (hipStream_t)stream_;
     if (!h || !w_packed || !b_packed || !raw || !cls_prob || Cmid < 1 || H < 1 || W < 1 || A < 1) return FRCNN_ERR_INVALID;
     const int NP = frcnn_rpn_heads_padded_channels(A);
-    const int st = launch_conv<1, 2, 2, 1, 1, 8, true, 3>(h, w_packed, b_packed, raw, Cmid, NP, H, W, 0, 0, nullptr, 0, stream);
+    const int st = launch_conv<1, 2, 2, 1, 1, 8, true, 3, 0, true>(h, w_packed, b_packed, raw, Cmid, NP, H, W, 0, 0, nullptr, 0, stream);
     if (st != FRCNN_OK) return st;
     hipLaunchKernelGGL(softmax_channels_kernel, dim3(frcnn_cdiv(H * W, 256)), dim3(256), 0, stream, raw, 2 * A, H * W, cls_prob);
     return frcnn_launch_status();

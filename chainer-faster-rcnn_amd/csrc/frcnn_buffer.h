@@ -47,6 +47,15 @@ __device__ __forceinline__ void frcnn_buf_load_lds_b128(frcnn_buf_t b, void *lds
                  : "s"(la), "v"(byte_off), "s"(b), "s"(soff)
                  : "memory");
 }
+// same, 4 bytes per lane: 256 B per wave-instruction at lds_wave_base + 4 * lane
+__device__ __forceinline__ void frcnn_buf_load_lds_b32(frcnn_buf_t b, void *lds_wave_base, uint32_t byte_off, uint32_t soff) {
+    const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_wave_base;
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(la), "v"(byte_off), "s"(b), "s"(soff)
+                 : "memory");
+}
 template <int N>
 __device__ __forceinline__ void frcnn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 // workgroup barrier WITHOUT the fences of __syncthreads() (which would drain every outstanding LDS-DMA): the caller has already

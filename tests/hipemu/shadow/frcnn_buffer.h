@@ -23,5 +23,10 @@ static inline void frcnn_buf_load_lds_b128(frcnn_buf_t b, void *lds_wave_base, u
     if ((uint64_t)off + 16 <= b.bytes) memcpy(&v, b.base + off + soff, 16);
     memcpy((char *)lds_wave_base + 16 * (threadIdx.x & 63), &v, 16);
 }
+static inline void frcnn_buf_load_lds_b32(frcnn_buf_t b, void *lds_wave_base, uint32_t off, uint32_t soff) {
+    float v = 0.0f;
+    if ((uint64_t)off + 4 <= b.bytes) memcpy(&v, b.base + off + soff, 4);
+    memcpy((char *)lds_wave_base + 4 * (threadIdx.x & 63), &v, 4);
+}
 template <int N> static inline void frcnn_wait_vmcnt() {}
 static inline void frcnn_barrier_nofence() { __syncthreads(); }
