@@ -12,6 +12,8 @@ OBJ = os.path.join(HERE, "_obj")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-I", os.path.join(ROOT, "include"), "-I", HERE]
+if os.environ.get("FRCNN_TIMING_ABLATIONS") == "1":      # tuning builds only: adds kernels that skip work (wrong results) for the sweeps
+    FLAGS.append("-DFRCNN_TIMING_ABLATIONS")
 
 
 def build(force=False, verbose=False):

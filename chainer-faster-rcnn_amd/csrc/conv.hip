@@ -615,10 +615,13 @@ int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bi
                                                                       workspace, workspace_bytes, stream);
         FRCNN_CONV_CASES(X)
 #undef X
-        // timing ablations of decomposition 10 (WRONG results by construction; scripts/conv_sweep.py only)
+#ifdef FRCNN_TIMING_ABLATIONS
+        // timing ablations of decomposition 10 (WRONG results by construction; scripts/conv_sweep.py only; built only when
+        // FRCNN_TIMING_ABLATIONS=1 is in the environment of csrc/build.py -- never in the shipped library)
         case 51: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 1>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 52: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 2>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 53: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 3>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+#endif
         // LDS-DMA staging forms of decompositions 10 / 5 / 14 
         case 30: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 35: return launch_conv<3, 2, 2, 1, 1, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);

@@ -529,7 +529,8 @@ int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bi
     // workgroups per CU, the other workgroups' MFMAs cover a workgroup's wait -- smaller launches (the 75x125 and 38x63 maps: 0.6-2.4
     // tiles per CU) get the two-stage ring that overlaps the next chunk's DMA with the MFMAs inside the workgroup
     // (scripts/conv_bf16_sweep.py, r01: +20...45 % over register staging on every VGG layer).  FRCNN_BF16_DMA overrides
-    // (digits = ring stages, waves/SIMD budget, row pairs per wave; 0 = the register-staged kernel; 4-digit values = timing ablations).
+    // (digits = ring stages, waves/SIMD budget, row pairs per wave; 0 = the register-staged kernel; 4-digit values = timing ablations,
+    // compiled only with FRCNN_TIMING_ABLATIONS).
     const char *dma_env = getenv("FRCNN_BF16_DMA");
     int mode = dma_env ? atoi(dma_env) : -1;
     if (mode < 0) mode = (long)grid.x >= 4L * frcnn_cu_count() ? 141 : 231;
@@ -549,7 +550,9 @@ int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bi
         break;
         switch (mode) {
             FRCNN_DMA_CASE(3, 2, 1) FRCNN_DMA_CASE(2, 3, 1) FRCNN_DMA_CASE(1, 4, 1) FRCNN_DMA_CASE(1, 3, 2) FRCNN_DMA_CASE(2, 2, 2)
-            FRCNN_DMA_ABL(1, 4, 1) FRCNN_DMA_ABL(1, 4, 4) FRCNN_DMA_ABL(2, 3, 1) FRCNN_DMA_ABL(2, 3, 4)      // WRONG results: sweeps only
+#ifdef FRCNN_TIMING_ABLATIONS                                                                       // WRONG results: sweeps only, never shipped
+            FRCNN_DMA_ABL(1, 4, 1) FRCNN_DMA_ABL(1, 4, 4) FRCNN_DMA_ABL(2, 3, 1) FRCNN_DMA_ABL(2, 3, 4)
+#endif
             default: return FRCNN_ERR_INVALID;
         }
 #undef FRCNN_DMA_CASE
@@ -560,7 +563,9 @@ int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bi
         const int abl = abl_env ? atoi(abl_env) : 0;
 #define FRCNN_ABL_CASE(A) case A: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3, 2, A>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles); break;
         switch (abl) {
+#ifdef FRCNN_TIMING_ABLATIONS
             FRCNN_ABL_CASE(1) FRCNN_ABL_CASE(2) FRCNN_ABL_CASE(3)
+#endif
             default: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3, 2>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
         }
 #undef FRCNN_ABL_CASE
