@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <frcnn_buffer.h>   // angle brackets: shadowed by the test emulator
 #include <frcnn_intrin.h>
+#include <frcnn_sync.h>
 
 namespace {
 
@@ -286,7 +287,8 @@ conv_mfma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict
 template <int NS, int WPS, int RPW = 1, int ABL = 0>   // RPW = row pairs per wave: the tile is 64 couts x 4*RPW rows x 32 px; ABL: 1 no DMA, 4 no compute
 __global__ void __launch_bounds__(256, WPS)
 conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
-                     int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles) {
+                     int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles, int nsplit,
+                     float *__restrict__ partial_ws, int *__restrict__ tile_counters) {
     constexpr int KS = 3, TAPS = 9, PAD = 1;
     constexpr int RW = 2 * RPW, BROWS = 2 * RW, BCO = 64;
     constexpr int HR = BROWS + KS - 1, HPX = 32 + KS - 1;
@@ -299,14 +301,19 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
     constexpr int OP = BCO * 2 + 16;
     constexpr int RING_BYTES = NS * STAGE_BYTES > BROWS * 32 * OP ? NS * STAGE_BYTES : BROWS * 32 * OP;
     __shared__ __attribute__((aligned(1024))) unsigned char ring[RING_BYTES];
+    __shared__ int s_ticket;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave & 1, wrow = wave >> 1;
     const int l31 = lane & 31, khalf = lane >> 5;
-    const int tile = blockIdx.x;
+    // split-K for launches with fewer tiles than the chip has room for (the 38x63 maps: 160 tiles on 256 CUs): `nsplit`
+    // consecutive workgroups share a tile, each takes a contiguous range of the K-chunks, the last to finish sums the
+    // pieces in split order (deterministic) and runs the epilogue -- the stream-K fix-up of conv.hip, with fixed ranges
+    const int tile = blockIdx.x / nsplit, split = blockIdx.x - tile * nsplit;
     const int tx = tile % xtiles, ty = (tile / xtiles) % ytiles, cot = tile / (xtiles * ytiles);
     const int x0 = tx * 32, y0 = ty * BROWS, co0 = cot * BCO;
-    const int nchunks = CinP / kCK;
+    const int all_chunks = CinP / kCK;
+    const int c_first = split * all_chunks / nsplit, nchunks = (split + 1) * all_chunks / nsplit - c_first;
     const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)H * W * CinP * 2));
     const frcnn_buf_t wbuf = frcnn_make_buf(wp, (uint32_t)((size_t)TAPS * CoutP * CinP * 2));
     const uint32_t x_chunk_bytes = (uint32_t)(H * W) * 32u, w_chunk_bytes = (uint32_t)(TAPS * CoutP) * 32u;
@@ -332,7 +339,7 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
     auto issue = [&](int chunk, int stage) {
         if constexpr ((ABL & 1) != 0) return;
         unsigned char *dst = ring + stage * STAGE_BYTES + wave * 1024;
-        const uint32_t xs = (uint32_t)chunk * x_chunk_bytes, ws = (uint32_t)chunk * w_chunk_bytes;
+        const uint32_t xs = (uint32_t)(c_first + chunk) * x_chunk_bytes, ws = (uint32_t)(c_first + chunk) * w_chunk_bytes;
 #pragma unroll
         for (int q = 0; q < PPW; ++q) {
             // pieces 4q .. 4q+3 belong to waves 0..3: which tensor they come from is a compile-time fact except where the halo
@@ -417,6 +424,45 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
         s_cur = s_cur + 1 == NS ? 0 : s_cur + 1;
         s_new = s_new + 1 == NS ? 0 : s_new + 1;
     }
+    }
+    if (nsplit > 1) {
+        // publish this split's accumulators (fragment-linear float4s, write-through: no release fence needed), take a ticket
+        constexpr int NV = RW * 4;                                // float4s per thread
+        const size_t slot_floats = (size_t)256 * RW * 16;
+        const frcnn_buf_t pbuf = frcnn_make_buf(partial_ws + ((size_t)tile * nsplit + split) * slot_floats, (uint32_t)(slot_floats * sizeof(float)));
+#pragma unroll
+        for (int j = 0; j < RW; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                frcnn_buf_store_f32x4_wt(pbuf, (uint32_t)(((j * 4 + r4) * 256 + tid) * 16),
+                                         make_float4(acc[j][4 * r4], acc[j][4 * r4 + 1], acc[j][4 * r4 + 2], acc[j][4 * r4 + 3]));
+        frcnn_drain_vmem();
+        __syncthreads();
+        if (tid == 0) s_ticket = frcnn_ticket(&tile_counters[tile]);
+        __syncthreads();
+        if (s_ticket != nsplit - 1) return;                       // workgroup-uniform
+        if (tid == 0) {
+            frcnn_acquire_agent();
+            frcnn_counter_reset(&tile_counters[tile]);            // leave the counter page zeroed for the next launch
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        for (int q = 0; q < nsplit; ++q) {
+            const float4 *piece = reinterpret_cast<const float4 *>(partial_ws + ((size_t)tile * nsplit + q) * slot_floats);
+            float4 v[NV];
+#pragma unroll
+            for (int e = 0; e < NV; ++e) v[e] = piece[(size_t)e * 256 + tid];
+#pragma unroll
+            for (int j = 0; j < RW; ++j)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 t = v[j * 4 + r4];
+                    acc[j][4 * r4] += t.x; acc[j][4 * r4 + 1] += t.y; acc[j][4 * r4 + 2] += t.z; acc[j][4 * r4 + 3] += t.w;
+                }
+        }
     }
     __syncthreads();                                            // the ring becomes the epilogue's output tile
     conv_bf16_epilogue<BROWS, 256, RW>(acc, ring, bias, y, Cout, CoutP, H, W, relu, out_mode, x0, y0, co0);
@@ -511,8 +557,34 @@ int frcnn_bf16_from_nchw_f32(const float *x, int C, int H, int W, uint16_t *y, v
     return frcnn_launch_status();
 }
 
-int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H, int W, int ksize, int relu,
-                    int out_mode, void *stream_) {
+// split-K factor for a 3x3 launch.  Measured on MI355X (r01, scripts/conv_bf16_sweep.py with FRCNN_BF16_SPLIT=1/2/4): splitting does
+// not pay on any VGG layer -- conv5_x (160 tiles on 256 CUs) 27 / 26 / 30 us, conv4_2 53 / 62 / 79 us -- the per-CU LDS-DMA rate,
+// not the length of a workgroup's chunk chain, is what bounds the small launches.  So the default is 1; FRCNN_BF16_SPLIT=2/4
+// keeps the path reachable for other shapes (it is exercised by the emulator and GPU tests).
+static int conv_bf16_pick_split(long tiles, int chunks) {
+    (void)tiles;
+    const char *e = getenv("FRCNN_BF16_SPLIT");
+    int s = e ? atoi(e) : 1;
+    if (s != 2 && s != 4) s = 1;
+    while (s > 1 && chunks / s < 4) s >>= 1;                      // a split should still carry a few chunks
+    return s;
+}
+constexpr size_t kBf16CounterPageBytes = 64 * 1024;
+
+size_t frcnn_conv_bf16_workspace_bytes(int Cin, int Cout, int H, int W) {
+    if (Cin < 1 || Cout < 1 || H < 1 || W < 1) return 0;
+    const long tiles = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4) * frcnn_cdiv(frcnn_bf16_padded_channels(Cout), 64);
+    return kBf16CounterPageBytes + (size_t)tiles * 4 * 256 * 32 * sizeof(float);      // up to 4 splits x 32 KB of accumulators per tile
+}
+
+int frcnn_conv_bf16_workspace_init(void *workspace, size_t workspace_bytes, void *stream) {
+    if (!workspace || workspace_bytes < kBf16CounterPageBytes) return FRCNN_ERR_INVALID;
+    FRCNN_HIP_TRY(hipMemsetAsync(workspace, 0, kBf16CounterPageBytes, (hipStream_t)stream));
+    return FRCNN_OK;
+}
+
+int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H, int W, int ksize, int relu,
+                       int out_mode, void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
     if ((ksize != 1 && ksize != 3) || out_mode < 0 || out_mode > 2 || (out_mode == 2 && !relu)) return FRCNN_ERR_INVALID;
@@ -533,20 +605,29 @@ int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bi
     // compiled only with FRCNN_TIMING_ABLATIONS).
     const char *dma_env = getenv("FRCNN_BF16_DMA");
     int mode = dma_env ? atoi(dma_env) : -1;
-    if (mode < 0) mode = (long)grid.x >= 4L * frcnn_cu_count() ? 141 : 231;
+    // split-K needs the workspace (partial tiles + the zeroed counter page); without one every tile is whole
+    int nsplit = 1;
+    if (ksize == 3 && !big && workspace && (long)grid.x * 4 <= 16384) {
+        nsplit = conv_bf16_pick_split((long)grid.x, CinP / kCK);
+        if (workspace_bytes < kBf16CounterPageBytes + (size_t)grid.x * nsplit * 256 * 32 * sizeof(float)) nsplit = 1;
+    }
+    float *partials = nsplit > 1 ? (float *)((char *)workspace + kBf16CounterPageBytes) : nullptr;
+    int *counters = nsplit > 1 ? (int *)workspace : nullptr;
+    if (mode < 0) mode = (long)grid.x * nsplit >= 4L * frcnn_cu_count() ? 141 : 231;
     if (ksize == 3 && big) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3, 4>), grid, dim3(512), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
     else if (ksize == 3 && mode > 0) {
         const int yt8 = frcnn_cdiv(H, 8);
         const dim3 grid8(xtiles * yt8 * cotiles);
 #define FRCNN_DMA_CASE(NS, WPS, RPW)                                                                                                     \
     case NS * 100 + WPS * 10 + RPW:                                                                                                      \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dma_bf16_kernel<NS, WPS, RPW>), RPW == 2 ? grid8 : grid, dim3(256), 0, stream, x, w_packed, \
-                           bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, RPW == 2 ? yt8 : ytiles);                               \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dma_bf16_kernel<NS, WPS, RPW>), RPW == 2 ? grid8 : dim3(grid.x * nsplit), dim3(256), 0,  \
+                           stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, RPW == 2 ? yt8 : ytiles,          \
+                           RPW == 2 ? 1 : nsplit, partials, counters);                                                                    \
         break;
 #define FRCNN_DMA_ABL(NS, WPS, A)                                                                                                        \
     case NS * 1000 + WPS * 100 + 10 + A:                                                                                                 \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dma_bf16_kernel<NS, WPS, 1, A>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP,   \
-                           Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);                                                            \
+                           Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, 1, nullptr, nullptr);                                       \
         break;
         switch (mode) {
             FRCNN_DMA_CASE(3, 2, 1) FRCNN_DMA_CASE(2, 3, 1) FRCNN_DMA_CASE(1, 4, 1) FRCNN_DMA_CASE(1, 3, 2) FRCNN_DMA_CASE(2, 2, 2)
@@ -572,6 +653,11 @@ int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bi
     }
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<1, 2>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
     return frcnn_launch_status();
+}
+
+int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H, int W, int ksize, int relu,
+                    int out_mode, void *stream) {
+    return frcnn_conv_bf16_ws(x, w_packed, bias, y, Cin, Cout, H, W, ksize, relu, out_mode, nullptr, 0, stream);
 }
 
 int frcnn_maxpool2x2_bf16(const uint16_t *x, uint16_t *y, int C, int H, int W, void *stream) {

@@ -358,8 +358,11 @@ class Runtime(object):
         else:
             y = m.empty((1, int(cout), H, W), "f32") if out_f32_nchw else m.empty((self.bf16_pad(cout) // 16, H, W, 16), "i16")
         mode = 2 if pool else int(bool(out_f32_nchw))
-        _lib.check(L.frcnn_conv_bf16(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(y), int(cin), int(cout), H, W, int(ksize),
-                                     int(bool(relu)), mode, m.stream()), "frcnn_conv_bf16")
+        ws = self.workspace("conv_bf16", L.frcnn_conv_bf16_workspace_bytes(int(cin), int(cout), H, W),
+                            init=lambda w: _lib.check(L.frcnn_conv_bf16_workspace_init(m.ptr(w), w.shape[0], m.stream()),
+                                                      "frcnn_conv_bf16_workspace_init"))
+        _lib.check(L.frcnn_conv_bf16_ws(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(y), int(cin), int(cout), H, W, int(ksize),
+                                        int(bool(relu)), mode, m.ptr(ws), ws.shape[0], m.stream()), "frcnn_conv_bf16_ws")
         return y
 
     def maxpool2x2_bf16(self, x):

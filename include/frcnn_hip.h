@@ -194,6 +194,14 @@ int frcnn_bf16_from_nchw_f32(const float *x, int C, int H, int W, uint16_t *y, v
 int frcnn_bf16_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, void *stream);
 int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
                     int W, int ksize, int relu, int out_mode, void *stream);
+/* the same with a workspace, which lets launches with fewer tiles than the chip has room for (the 38x63 maps) split K
+ * across workgroups (deterministic: partial tiles are summed in split order by the last arriver).  Same contract as the
+ * fp32 conv workspace: its first 64 KB are tile counters -- zero them once (frcnn_conv_bf16_workspace_init), every
+ * launch leaves them zeroed; convolutions only, one workspace per stream.  workspace NULL = frcnn_conv_bf16. */
+size_t frcnn_conv_bf16_workspace_bytes(int Cin, int Cout, int H, int W);
+int frcnn_conv_bf16_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
+int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
+                       int W, int ksize, int relu, int out_mode, void *workspace, size_t workspace_bytes, void *stream);
 int frcnn_maxpool2x2_bf16(const uint16_t *x, uint16_t *y, int C, int H, int W, void *stream);
 /* bf16 fully connected layer (config-3 head): y(M,N) = act(x(M,K) @ W(N,K)^T + b); x, W raw bf16 bits (frcnn_f32_to_bf16
  * converts fp32 arrays: weights once at load, activations per call), fp32 accumulation and bias; y fp32, or bf16 when

@@ -17,7 +17,7 @@ SHAPES = [("conv1_1", 3, 64, 600, 1000), ("conv1_2", 64, 64, 600, 1000), ("conv2
 def main():
     """FRCNN_BF16_ABLS="0 1 2 3 4 7": repeat the sweep with each timing ablation of the 3x3 kernel (see conv_bf16.hip)."""
     for abl in os.environ.get("FRCNN_BF16_ABLS", "0").split():
-        for dma in os.environ.get("FRCNN_BF16_DMAS", "").split() or [os.environ.get("FRCNN_BF16_DMA", "0")]:
+        for dma in os.environ.get("FRCNN_BF16_DMAS", "").split() or [os.environ.get("FRCNN_BF16_DMA", "-1")]:
             os.environ["FRCNN_BF16_ABL"] = abl
             os.environ["FRCNN_BF16_DMA"] = dma
             print("abl", abl, "dma", dma, end="  ")

@@ -15,7 +15,7 @@ def rt():
 
 
 def test_library_is_the_device_build(rt):
-    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 10
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 11
 
 
 def test_nms_golden(rt):
@@ -247,6 +247,30 @@ def test_conv_bf16(rt, cin, cout, h, w, ks):
 
 def test_conv_bf16_pool_fused(rt):
     P.check_conv_bf16_pool(rt, 64, 64, 120, 200)
+    P.check_conv_bf16_pool(rt, 256, 512, 75, 125, seed=1)
+
+
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 600, 1000), (256, 256, 150, 250), (512, 512, 38, 63), (3, 64, 600, 1000)])
+def test_conv_bf16_staging_variants_bit_identical(rt, monkeypatch, cin, cout, h, w):
+    """Full-size property: the LDS-DMA kernels (every ring depth / tile shape) accumulate in the register-staged kernel's
+    order, so all outputs -- plain and pool-fused -- are bit-identical to it at the real VGG layer sizes."""
+    rs = np.random.RandomState(11)
+    x = rt.bf16_from_nchw(rt.mem.from_numpy(rs.randn(1, cin, h, w).astype(np.float32)))
+    wt = rt.bf16_pack_conv_w(rt.mem.from_numpy((rs.randn(cout, cin, 3, 3) * 0.05).astype(np.float32)), 3)
+    b = rt.mem.from_numpy(rs.randn(cout).astype(np.float32))
+    outs = {}
+    for mode in ["0", "-1", "141", "231", "321", "132", "222"]:
+        monkeypatch.setenv("FRCNN_BF16_DMA", mode)
+        outs[mode] = (rt.mem.to_numpy(rt.conv_bf16(x, wt, b, cin, cout, 3, relu=True)),
+                      rt.mem.to_numpy(rt.conv_bf16(x, wt, b, cin, cout, 3, relu=True, pool=True)))
+    for mode, (full, pooled) in outs.items():
+        assert np.array_equal(full, outs["0"][0]) and np.array_equal(pooled, outs["0"][1]), mode
+
+
+@pytest.mark.parametrize("split", ["2", "4"])
+def test_conv_bf16_split_k(rt, monkeypatch, split):
+    monkeypatch.setenv("FRCNN_BF16_SPLIT", split)
+    P.check_conv_bf16(rt, 512, 512, 38, 63)              # the shape split-K exists for: 160 tiles, 32 chunks
     P.check_conv_bf16_pool(rt, 256, 512, 75, 125, seed=1)
 
 

@@ -178,3 +178,12 @@ def test_conv_bf16_lds_dma(rt, monkeypatch, mode):
     P.check_conv_bf16(rt, 80, 128, 13, 70, seed=2)        # five chunks: the ring wraps; three x tiles, ragged rows
     P.check_conv_bf16_pool(rt, 48, 64, 9, 37, seed=3)
 
+
+@pytest.mark.parametrize("split", ["2", "4"])
+def test_conv_bf16_split_k(rt, monkeypatch, split):
+    """Split-K form of the bf16 3x3 kernel: partial tiles through the workspace, last arriver sums in split order."""
+    monkeypatch.setenv("FRCNN_BF16_SPLIT", split)
+    P.check_conv_bf16(rt, 128, 64, 9, 37, seed=5)         # 8 chunks: 2 or 4 splits of >= 2 chunks ... (the picker wants >= 4 per split)
+    P.check_conv_bf16(rt, 256, 128, 6, 40, seed=6)        # 16 chunks
+    P.check_conv_bf16_pool(rt, 256, 64, 8, 33, seed=7)
+
