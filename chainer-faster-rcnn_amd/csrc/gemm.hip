@@ -11,6 +11,8 @@
 // caller's workspace, combined by linear_reduce_kernel together with bias + ReLU): the decomposition
 // yields 2048 equal wave-level work units for fc6 = exactly two per SIMD.
 #include "frcnn_common.h"
+#include <stdlib.h>
+#include <frcnn_buffer.h>   // angle brackets: shadowed by the test emulator
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -123,6 +125,107 @@ linear_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ w,
     }
 }
 
+// LDS-DMA form (K a multiple of 32).  A 32-k panel row is 128 B = eight 16-byte groups; pieces of 64 groups (8 rows) go from L2
+// straight into LDS (buffer_load_dwordx4 ... lds: no staging registers, no ds_write pass -- the register-staged kernel above spends
+// 36 ds_write_b32 per thread per panel on its odd-pitch image).  The image is lane-linear with an XOR swizzle on both sides:
+// group g of row r sits in slot 8r + (g ^ ((r >> 1) & 7)), which puts the ds_read_b128 of any 16-lane group (16 different rows, one
+// g) on 16 distinct bank slots.  A lane reads ONE float4 per operand for FOUR MFMA k-steps: lanes 0-31 take group 2j, lanes 32-63
+// group 2j+1, and k-step t of the quad contracts element t of both -- i.e. k = 8j+t and 8j+4+t; A and B use the same map, so the
+// product is the same sum in a different (fixed) order.  4x fewer LDS instructions per MFMA than the b32 fragment reads.
+template <int AM>
+__global__ void __launch_bounds__(256, 2)
+linear_dma_f32_kernel(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ part, int M, int N, int K,
+                      int k_per_split) {
+    constexpr int BM = 32 * AM, BN = 128;
+    constexpr int XP = BM / 8, WP = BN / 8;                  // 1 KB pieces per panel (8 rows each)
+    constexpr int PPW = (XP + WP) / 4;                       // pieces per wave: (4*AM + 16) / 4
+    constexpr int STAGE = (BM + BN) * 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * k_per_split;
+    const int k_end = min(K, k_begin + k_per_split);
+    const int nchunks = (k_end - k_begin) / kBK;             // whole panels only: the host guarantees K % 32 == 0
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)M * K * sizeof(float)));
+    const frcnn_buf_t wbuf = frcnn_make_buf(w, (uint32_t)((size_t)N * K * sizeof(float)));
+
+    // source offset (panel 0 of this split) of the 16 bytes this lane contributes to each of its wave's pieces
+    uint32_t poff[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int pid = wave + 4 * q;                        // pieces 0 .. XP-1: x rows, then W rows
+        const bool isx = pid < XP;
+        const int sl = (isx ? pid : pid - XP) * 64 + lane, row = sl >> 3, g = (sl & 7) ^ ((row >> 1) & 7);
+        const int gr = (isx ? m0 : n0) + row;
+        poff[q] = gr < (isx ? M : N) ? (uint32_t)(((size_t)gr * K + k_begin + 4 * g) * sizeof(float)) : kBufOob;
+    }
+    auto issue = [&](int chunk, int stage) {
+        unsigned char *dst = lds + stage * STAGE + wave * 1024;
+        const uint32_t so = (uint32_t)chunk * (kBK * sizeof(float));
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            if (4 * q + 3 < XP) frcnn_buf_load_lds_b128(xbuf, dst + q * 4096, poff[q], so);
+            else if (4 * q >= XP) frcnn_buf_load_lds_b128(wbuf, dst + q * 4096, poff[q], so);
+            else frcnn_buf_load_lds_b128(wave + 4 * q < XP ? xbuf : wbuf, dst + q * 4096, poff[q], so);
+        }
+    };
+
+    f32x16 acc[AM];
+#pragma unroll
+    for (int i = 0; i < AM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    const int l31 = lane & 31, khalf = lane >> 5;
+    // byte offset of (row, group 2j + khalf) inside a stage: row * 128 + ((2j + khalf) ^ ((row >> 1) & 7)) * 16
+    auto frag_off = [&](int row, int j) { return (uint32_t)(row * 128 + (((2 * j + khalf) ^ ((row >> 1) & 7)) << 4)); };
+
+    if (nchunks > 0) issue(0, 0);
+    frcnn_wait_vmcnt<0>();
+    frcnn_barrier_nofence();
+    int cur = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        if (chunk + 1 < nchunks) issue(chunk + 1, cur ^ 1);
+        const unsigned char *xs = lds + cur * STAGE, *wsm = xs + BM * 128;
+        float4 a[2][AM], b[2];
+        auto frag = [&](int j, float4 (&aa)[AM], float4 &bb) {
+            bb = *reinterpret_cast<const float4 *>(wsm + frag_off(wave * 32 + l31, j));
+#pragma unroll
+            for (int i = 0; i < AM; ++i) aa[i] = *reinterpret_cast<const float4 *>(xs + frag_off(32 * i + l31, j));
+        };
+        frag(0, a[0], b[0]);
+#pragma unroll
+        for (int j = 0; j < kBK / 8; ++j) {
+            if (j + 1 < kBK / 8) frag(j + 1, a[(j + 1) & 1], b[(j + 1) & 1]);       // next quad's fragments land under this quad's MFMAs
+            const float4 bq = b[j & 1];
+            const float bv[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < AM; ++i) {
+                    const float4 aq = a[j & 1][i];
+                    const float av = t == 0 ? aq.x : (t == 1 ? aq.y : (t == 2 ? aq.z : aq.w));
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[i], 0, 0, 0);
+                }
+        }
+        frcnn_wait_vmcnt<0>();
+        frcnn_barrier_nofence();
+        cur ^= 1;
+    }
+    float *out = part + (size_t)blockIdx.z * M * N;
+    const int n = n0 + wave * 32 + l31;
+    if (n < N) {
+#pragma unroll
+        for (int i = 0; i < AM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (m < M) out[(size_t)m * N + n] = acc[i][r];
+            }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 linear_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias, float *__restrict__ y, int M, int N, int splits,
                      int relu) {
@@ -173,7 +276,11 @@ int frcnn_linear_f32(const float *x, const float *w, const float *bias, float *y
     if (!workspace || workspace_bytes < (size_t)p.splits * M * N * sizeof(float)) return FRCNN_ERR_INVALID;
     float *part = (float *)workspace;
     const dim3 grid(p.nblocks, p.mblocks, p.splits);
-    if (p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_f32_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    const bool dma = (K % kBK) == 0 && (size_t)M * K * 4 < (1ull << 31) && (size_t)N * K * 4 < (1ull << 31) && !getenv("FRCNN_LINEAR_NODMA");
+    if (dma && p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_f32_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    else if (dma && p.am == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_f32_kernel<3>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    else if (dma) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_f32_kernel<1>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    else if (p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_f32_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     else if (p.am == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_f32_kernel<3>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_f32_kernel<1>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     const size_t total = (size_t)M * N;

@@ -82,6 +82,8 @@ def test_linear(rt):
     P.check_linear(rt, 70, 140, 256, True)
     P.check_linear(rt, 9, 21, 64, False)
     P.check_linear(rt, 130, 84, 128, False)
+    P.check_linear(rt, 9, 21, 72, False, seed=3)          # K % 32 != 0: the register-staged kernel (odd-pitch LDS image)
+    P.check_linear(rt, 100, 130, 96, True, seed=4)        # AM = 5, ragged M and N, three panels
 
 
 def test_head_decode(rt):
