@@ -408,15 +408,39 @@ rpn_heads_pack_kernel(const float *__restrict__ w_cls, const float *__restrict__
     if (i < NP) bp[i] = (i < 2 * A) ? b_cls[i] : (i < 6 * A ? b_bbox[i - 2 * A] : 0.0f);
 }
 
-__global__ void __launch_bounds__(256)
+// One thread per pixel, 64-thread workgroups (a 38x63 map is 2394 pixels: small blocks put it on 38 CUs instead of 10); the scores
+// are loaded once, all loads in flight together, and every exponential is evaluated once -- same operations in the same order as
+// the three-pass form (max, sum of expf(s - m) in channel order, expf(s - m) / sum), so the probabilities are unchanged.
+template <int MAXC>
+__global__ void __launch_bounds__(64)
 softmax_channels_kernel(const float *__restrict__ score, int n_ch, int HW, float *__restrict__ prob) {
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= HW) return;
-    float m = score[p];
-    for (int c = 1; c < n_ch; ++c) m = fmaxf(m, score[(size_t)c * HW + p]);
-    float sum = 0.0f;
-    for (int c = 0; c < n_ch; ++c) sum += expf(score[(size_t)c * HW + p] - m);
-    for (int c = 0; c < n_ch; ++c) prob[(size_t)c * HW + p] = expf(score[(size_t)c * HW + p] - m) / sum;
+    if constexpr (MAXC > 0) {
+        float v[MAXC];
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) v[c] = c < n_ch ? score[(size_t)c * HW + p] : 0.0f;
+        float m = v[0];
+#pragma unroll
+        for (int c = 1; c < MAXC; ++c) if (c < n_ch) m = fmaxf(m, v[c]);
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) if (c < n_ch) { v[c] = expf(v[c] - m); sum += v[c]; }
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) if (c < n_ch) prob[(size_t)c * HW + p] = v[c] / sum;
+    } else {
+        float m = score[p];
+        for (int c = 1; c < n_ch; ++c) m = fmaxf(m, score[(size_t)c * HW + p]);
+        float sum = 0.0f;
+        for (int c = 0; c < n_ch; ++c) sum += expf(score[(size_t)c * HW + p] - m);
+        for (int c = 0; c < n_ch; ++c) prob[(size_t)c * HW + p] = expf(score[(size_t)c * HW + p] - m) / sum;
+    }
+}
+
+static void launch_softmax_channels(const float *score, int n_ch, int HW, float *prob, hipStream_t stream) {
+    const dim3 grid(frcnn_cdiv(HW, 64)), blk(64);
+    if (n_ch <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(softmax_channels_kernel<32>), grid, blk, 0, stream, score, n_ch, HW, prob);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(softmax_channels_kernel<0>), grid, blk, 0, stream, score, n_ch, HW, prob);
 }
 
 // ---- ResNet stem / stride helpers (models/resnet.py -> chainer ResNetLayers: conv1 7x7/2 pad 3, max-pool 3x3/2, stride-2 1x1) ----
@@ -699,7 +723,7 @@ int frcnn_rpn_heads_pack(const float *w_cls, const float *b_cls, const float *w_
 
 int frcnn_softmax_channels_f32(const float *score, int n_ch, int HW, float *prob, void *stream) {
     if (!score || !prob || n_ch < 1 || HW < 1) return FRCNN_ERR_INVALID;
-    hipLaunchKernelGGL(softmax_channels_kernel, dim3(frcnn_cdiv(HW, 256)), dim3(256), 0, (hipStream_t)stream, score, n_ch, HW, prob);
+    launch_softmax_channels(score, n_ch, HW, prob, (hipStream_t)stream);
     return frcnn_launch_status();
 }
 
@@ -710,7 +734,7 @@ int frcnn_rpn_heads_f32(const float *h, int Cmid, int H, int W, int A, const flo
     const int NP = frcnn_rpn_heads_padded_channels(A);
     const int st = launch_conv<1, 2, 2, 1, 1, 8, true, 3, 0, true>(h, w_packed, b_packed, raw, Cmid, NP, H, W, 0, 0, nullptr, 0, stream);
     if (st != FRCNN_OK) return st;
-    hipLaunchKernelGGL(softmax_channels_kernel, dim3(frcnn_cdiv(H * W, 256)), dim3(256), 0, stream, raw, 2 * A, H * W, cls_prob);
+    launch_softmax_channels(raw, 2 * A, H * W, cls_prob, stream);
     return frcnn_launch_status();
 }
 
