@@ -413,18 +413,21 @@ nms_scan_wave_kernel(const unsigned long long *__restrict__ mask, int pitch, con
         n_kept += __popcll(kept);
         if (n_kept < limit) {
             unsigned long long kk = kept;
-            while (kk != 0ull) {                      // four kept rows per round; a short round repeats its first row (OR is idempotent)
-                int idx[4];
+            // RB kept rows per round, all their loads in flight together: a round costs one L2 round trip whatever RB is, and a
+            // chunk of well-separated boxes keeps up to 64 of them.  A short round repeats its first row (OR is idempotent).
+            constexpr int RB = NJ <= 2 ? 16 : 8;
+            while (kk != 0ull) {
+                int idx[RB];
                 idx[0] = __ffsll((long long)kk) - 1;
                 kk &= kk - 1ull;
 #pragma unroll
-                for (int q = 1; q < 4; ++q) {
+                for (int q = 1; q < RB; ++q) {
                     idx[q] = kk != 0ull ? __ffsll((long long)kk) - 1 : idx[0];
                     kk &= kk - 1ull;               // 0 stays 0
                 }
-                unsigned long long v[4][NJ];
+                unsigned long long v[RB][NJ];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                for (int q = 0; q < RB; ++q) {
                     const unsigned long long *row = mask + (size_t)(c * kChunk + idx[q]) * pitch;
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
@@ -433,7 +436,12 @@ nms_scan_wave_kernel(const unsigned long long *__restrict__ mask, int pitch, con
                     }
                 }
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) rem[j] |= (v[0][j] | v[1][j]) | (v[2][j] | v[3][j]);
+                for (int j = 0; j < NJ; ++j) {
+                    unsigned long long acc = 0ull;
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) acc |= v[q][j];
+                    rem[j] |= acc;
+                }
             }
         }
     }
