@@ -86,6 +86,7 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
     const long long G = gridDim.x;
     long long g = blockIdx.x;
     const bool banded = (relu & 512) != 0;
+    const bool soff_mode = (relu & 1024) != 0;
     if (relu & (256 | 512)) {
         const long long xcd = g & 7, q = G >> 3, r = G & 7;
         g = xcd * q + (xcd < r ? xcd : r) + (g >> 3);
@@ -157,17 +158,35 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
             }
         };
 
-        // LDS-DMA form of fetch + stage: slice q of the register path (threads tid + q*NT) is, per wave, one lane-linear piece
+        // LDS-DMA form of fetch + stage: slice q of the register path (threads tid + q*NT) is, per wave, one lane-linear piece.
+        // With a ragged last chunk (Cin % CK != 0, past chunk 0) the range check must see the true end of the tensor so that the
+        // channels past Cin deposit zeros: that launch gives each chunk its own descriptors (base advanced, size shrunk; ~3 % slower
+        // than the scalar-offset form, which every VGG layer uses).  Adding the chunk offset to the per-lane offsets instead puts a
+        // VALU write in front of every DMA: -4 %.
         auto issue = [&](int chunk, int buf) {
-            const uint32_t wb = (uint32_t)chunk * w_chunk_bytes, xb = (uint32_t)chunk * x_chunk_bytes;
+            if (soff_mode) {                 // Cin is a whole number of chunks: the chunk offset rides in the scalar offset (3 % faster)
+                const uint32_t wb = (uint32_t)chunk * w_chunk_bytes, xb = (uint32_t)chunk * x_chunk_bytes;
+#pragma unroll
+                for (int q = 0; q < WIT; ++q)
+                    if ((q + 1) * NT <= WV || wave * 64 + q * NT < WV)
+                        frcnn_buf_load_lds_b128(wbuf, reinterpret_cast<float4 *>(&w_lds[buf][0][0]) + q * NT + wave * 64, woff[q], wb);
+#pragma unroll
+                for (int q = 0; q < HIT; ++q)
+                    if ((q + 1) * NT <= HVP || wave * 64 + q * NT < HVP)
+                        frcnn_buf_load_lds_b32(xbuf, &in_lds[buf][q * NT + wave * 64], hoff[q], xb);
+                return;
+            }
+            const long long wrem = (long long)(K - chunk * KR) * Cout, xrem = (long long)(Cin - chunk * CK) * HW;
+            const frcnn_buf_t wb_c = frcnn_make_buf(wp + (size_t)chunk * KR * Cout, (uint32_t)((wrem > 0 ? wrem : 0) * sizeof(float)));
+            const frcnn_buf_t xb_c = frcnn_make_buf(x + (size_t)chunk * CK * HW, (uint32_t)((xrem > 0 ? xrem : 0) * sizeof(float)));
 #pragma unroll
             for (int q = 0; q < WIT; ++q)
                 if ((q + 1) * NT <= WV || wave * 64 + q * NT < WV)
-                    frcnn_buf_load_lds_b128(wbuf, reinterpret_cast<float4 *>(&w_lds[buf][0][0]) + q * NT + wave * 64, woff[q], wb);
+                    frcnn_buf_load_lds_b128(wb_c, reinterpret_cast<float4 *>(&w_lds[buf][0][0]) + q * NT + wave * 64, woff[q], 0);
 #pragma unroll
             for (int q = 0; q < HIT; ++q)
                 if ((q + 1) * NT <= HVP || wave * 64 + q * NT < HVP)
-                    frcnn_buf_load_lds_b32(xbuf, &in_lds[buf][q * NT + wave * 64], hoff[q], xb);
+                    frcnn_buf_load_lds_b32(xb_c, &in_lds[buf][q * NT + wave * 64], hoff[q], 0);
         };
 
         f32x16 acc[ACO][APX];
@@ -543,6 +562,7 @@ static int launch_conv(const float *x, const float *wp, const float *bias, float
         const int order = xcd_env >= 0 ? xcd_env : ((p.G == p.ntiles || w_bytes >= map_bytes) ? 1 : 0);
         relu |= 256 * order;
     }
+    if (DMA && (Cin % CK == 0 || Cin <= CK)) relu |= 1024;        // no ragged chunk past chunk 0: scalar-offset DMA form
     int *counters = nullptr;
     float *partials = nullptr;
     if (p.G != p.ntiles) {
@@ -661,7 +681,7 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (Cout % 64) != 0) return FRCNN_ERR_INVALID;
     if (act < 0 || act > 4 || ((act == 2 || act == 3) && !mask) || (ksize != 1 && ksize != 3) || (act == 4 && ksize != 3)) return FRCNN_ERR_INVALID;
     if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cin * ksize * ksize * Cout * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;
-    if (ksize == 1) return launch_conv<1, 2, 2, 1, 1, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, 0, nullptr, 0, stream, mask);
+    if (ksize == 1) return launch_conv<1, 2, 2, 1, 1, 32, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, 0, nullptr, 0, stream, mask);
     const int cfg = pick_conv_config(Cin, Cout, H, W, act == 4);
     const int streamk = cfg / 100;
     switch (cfg % 100) {
@@ -732,7 +752,7 @@ int frcnn_rpn_heads_f32(const float *h, int Cmid, int H, int W, int A, const flo
     hipStream_t stream = (hipStream_t)stream_;
     if (!h || !w_packed || !b_packed || !raw || !cls_prob || Cmid < 1 || H < 1 || W < 1 || A < 1) return FRCNN_ERR_INVALID;
     const int NP = frcnn_rpn_heads_padded_channels(A);
-    const int st = launch_conv<1, 2, 2, 1, 1, 8, true, 3, 0, true>(h, w_packed, b_packed, raw, Cmid, NP, H, W, 0, 0, nullptr, 0, stream);
+    const int st = launch_conv<1, 2, 2, 1, 1, 32, true, 3, 0, true>(h, w_packed, b_packed, raw, Cmid, NP, H, W, 0, 0, nullptr, 0, stream);
     if (st != FRCNN_OK) return st;
     launch_softmax_channels(raw, 2 * A, H * W, cls_prob, stream);
     return frcnn_launch_status();

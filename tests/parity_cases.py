@@ -493,3 +493,22 @@ def check_preprocess(rt, h, w, seed=0):
     got, scale = img_preprocessing(img, runtime=rt)
     assert scale == want_scale and tuple(got.shape) == want.shape, (tuple(got.shape), want.shape)
     assert np.allclose(host(rt, got), want, rtol=0, atol=2e-4)          # float32 blends of values up to 255: a few ulps
+
+
+def check_conv_workspace_self_cleaning(rt):
+    """The stream-K / split-K tile counters live in the first 64 KB of the conv workspaces, are zeroed ONCE
+    (frcnn_conv3x3_workspace_init / frcnn_conv_bf16_workspace_init) and must be back to zero after every launch
+    (the last arriver of a split tile resets its counter) -- the invariant that lets launches skip the memset."""
+    import os
+    check_conv3x3(rt, 24, 128, 9, 70, cfg=236)                  # stream-K, LDS-DMA decomposition
+    check_conv3x3(rt, 24, 128, 9, 70, cfg=210, seed=1)          # stream-K, register-staged decomposition
+    page = host(rt, rt._ws["conv3x3"])[:65536]
+    assert not page.any()
+    os.environ["FRCNN_BF16_SPLIT"] = "2"
+    try:
+        check_conv_bf16(rt, 128, 64, 9, 37, seed=5)
+    finally:
+        del os.environ["FRCNN_BF16_SPLIT"]
+    page = host(rt, rt._ws["conv_bf16"])[:65536]
+    assert not page.any()
+

@@ -363,3 +363,8 @@ def test_rcnn_train_step_vgg16(rt):
     import train_cases as T
     losses, worst = T.check_vgg_rcnn_step(rt)
     assert losses["loss_rcnn"] > 0 and worst <= 1e-3
+
+
+def test_conv_workspace_self_cleaning(rt):
+    P.check_conv_workspace_self_cleaning(rt)
+

@@ -189,3 +189,7 @@ def test_conv_bf16_split_k(rt, monkeypatch, split):
     P.check_conv_bf16(rt, 256, 128, 6, 40, seed=6)        # 16 chunks
     P.check_conv_bf16_pool(rt, 256, 64, 8, 33, seed=7)
 
+
+def test_conv_workspace_self_cleaning(rt):
+    P.check_conv_workspace_self_cleaning(rt)
+
