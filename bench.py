@@ -321,6 +321,10 @@ def main():
                                "algorithmic_bytes_per_launch": sum(conv_algorithmic_bytes(LAYERS, IM_H, IM_W, 4 if args.dtype == "f32" else 2).values()) / 14.0}
             roi_bytes = (512 * fh * fw + 300 * 512 * 49) * 4 + 300 * 16
             res["stages_ms"] = {k: round(v, 4) for k, v in avg.items()}
+            res["stage_events"] = {"where": ("HIP events on the launch stream around every stage of %d eager forwards run immediately before the "
+                                             "timed graph replays (events cannot be read out of a replayed graph)" % max(3, args.steps // 3)) if use_graph
+                                   else "HIP events on the launch stream inside the timed region",
+                                   "sum_of_stages_ms": round(sum(avg.values()), 4), "timed_ms_per_step": round(ms_per_step, 4)}
             res["per_layer_tflops"] = {k: round(flops[k] / (avg[k] * 1e-3) / 1e12, 2) for k in flops}
             res["nms_roi"] = {"proposals_nms_us": avg["proposals"] * 1e3, "roi_pool_us": avg["roi_pool"] * 1e3,
                               "roi_pool_algorithmic_mb": roi_bytes / 1e6,

@@ -1,0 +1,44 @@
+"""bench.py pieces that do not need a GPU: the algorithmic work the roofline is priced on, and the loud failure without a device."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("frcnn_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_algorithmic_work_matches_design():
+    b = _bench()
+    from chainer_faster_rcnn_amd.models.vgg16 import LAYERS
+    flops, (fh, fw) = b.conv_flops(LAYERS, b.IM_H, b.IM_W)
+    assert (b.IM_H, b.IM_W) == (600, 1000) and (fh, fw) == (38, 63) and len(flops) == 14
+    assert abs(sum(flops.values()) / 1e9 - 379.03) < 0.01                        # 13 VGG convs + rpn_conv_3x3
+    nbytes = b.conv_algorithmic_bytes(LAYERS, b.IM_H, b.IM_W)
+    assert set(nbytes) == set(flops) and abs(sum(nbytes.values()) / 14e6 - 67.5) < 0.1
+    assert b.PEAK_F32_MFMA_TFLOPS == 157.3 and b.PEAK_HBM_GBPS == 8000.0
+
+
+def test_pmc_traffic_comes_from_the_committed_profile():
+    b = _bench()
+    traffic, src = b.pmc_traffic("f32")
+    summary = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")))["_summary"]
+    assert traffic == summary["conv_mfma_f32_kernel"]["hbm_bytes_per_launch"] and "profiles/r01_hbm_traffic_pmc.json" in src
+    assert b.pmc_traffic("bf16") == (None, None)
+
+
+def test_bench_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and not r.stdout.strip().startswith("{")            # no number is better than a CPU-fallback number
