@@ -43,6 +43,7 @@ SIGNATURES = {
     "frcnn_linear_workspace_bytes": (_S, [_I, _I, _I]),
     "frcnn_linear_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_head_decode": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P]),
+    "frcnn_head_decode_stacked": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _P]),
     "frcnn_preprocess_u8": (_I, [_P, _I, _I, _I, _P, _D, _I, _I, _P, _P]),
     "frcnn_class_dets": (_I, [_P, _P, _I, _I, _P, _P]),
     "frcnn_bbox_transform_inv": (_I, [_P, _P, _I, _I, _P, _P]),

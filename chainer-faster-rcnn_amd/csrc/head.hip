@@ -92,6 +92,35 @@ preprocess_kernel(const uint8_t *__restrict__ img, int H, int W, int C, PixelMea
     }
 }
 
+// cls_score and bbox_pred of the stacked head GEMM (one launch instead of two: `out` is (R, ld) with the class scores in columns
+// [0, ncls) and the 4*ncls deltas from column `dcol`, 16-byte aligned), decoded in one kernel: thread (r, c) decodes + clips class c's
+// box of RoI r and writes softmax(score[r])[c].  The softmax is evaluated per thread exactly as row_softmax_kernel does per row
+// (max, sum of expf(s - m) in class order, expf(s - m) / sum), so the probabilities are the same bits.
+__global__ void __launch_bounds__(256)
+head_decode_softmax_kernel(const float *__restrict__ boxes, const float *__restrict__ out, int ld, int dcol, int R, int ncls, int im_h,
+                           int im_w, float *__restrict__ pred, float *__restrict__ prob) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * ncls) return;
+    const int r = i / ncls, c = i - r * ncls;
+    const float *row = out + (size_t)r * ld;
+    const float4 b = reinterpret_cast<const float4 *>(boxes)[r];
+    const float4 d = *reinterpret_cast<const float4 *>(row + dcol + 4 * c);
+    const float widths = b.z - b.x + 1.0f, heights = b.w - b.y + 1.0f;
+    const float ctr_x = b.x + 0.5f * widths, ctr_y = b.y + 0.5f * heights;
+    const float pcx = d.x * widths + ctr_x, pcy = d.y * heights + ctr_y;
+    const float pw = (float)exp((double)d.z) * widths, ph = (float)exp((double)d.w) * heights;
+    const float mx = (float)(im_w - 1), my = (float)(im_h - 1);
+    float4 o = make_float4(pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph);
+    o.x = clip_like_numpy(o.x, mx); o.y = clip_like_numpy(o.y, my);
+    o.z = clip_like_numpy(o.z, mx); o.w = clip_like_numpy(o.w, my);
+    reinterpret_cast<float4 *>(pred)[i] = o;
+    float m = row[0];
+    for (int k = 1; k < ncls; ++k) m = fmaxf(m, row[k]);
+    float sum = 0.0f;
+    for (int k = 0; k < ncls; ++k) sum += expf(row[k] - m);
+    prob[i] = expf(row[c] - m) / sum;
+}
+
 }  // namespace
 
 extern "C" {
@@ -146,6 +175,19 @@ int frcnn_head_decode(const float *boxes, const float *deltas, const float *cls_
     hipLaunchKernelGGL(head_decode_kernel, dim3(frcnn_cdiv(R * ncls, 256)), dim3(256), 0, stream, boxes, deltas, R, ncls, 1, im_h, im_w,
                        pred_boxes);
     hipLaunchKernelGGL(row_softmax_kernel, dim3(frcnn_cdiv(R, 256)), dim3(256), 0, stream, cls_score, R, ncls, cls_prob);
+    return frcnn_launch_status();
+}
+
+/* stacked form: `out` (R, ld) holds cls_score in columns [0, ncls) and bbox_pred from column dcol (dcol % 4 == 0, ld % 4 == 0) */
+int frcnn_head_decode_stacked(const float *boxes, const float *out, int ld, int dcol, int R, int ncls, int im_h, int im_w,
+                              float *pred_boxes, float *cls_prob, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!boxes || !out || !pred_boxes || !cls_prob || R < 0 || ncls < 1 || (ld % 4) != 0 || (dcol % 4) != 0 || dcol < ncls ||
+        dcol + 4 * ncls > ld)
+        return FRCNN_ERR_INVALID;
+    if (R == 0) return FRCNN_OK;
+    hipLaunchKernelGGL(head_decode_softmax_kernel, dim3(frcnn_cdiv(R * ncls, 256)), dim3(256), 0, stream, boxes, out, ld, dcol, R, ncls, im_h,
+                       im_w, pred_boxes, cls_prob);
     return frcnn_launch_status();
 }
 

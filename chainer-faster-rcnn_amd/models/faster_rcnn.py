@@ -91,6 +91,28 @@ class FasterRCNN(object):
         self.RPN.load_params(params, "RPN/")
         for name in ("fc6", "fc7", "cls_score", "bbox_pred"):
             getattr(self, name).set(params[name + "/W"], params[name + "/b"])
+        self._stack_head()
+
+    def _stack_head(self):
+        """Inference runs cls_score and bbox_pred (faster_rcnn.py:35-36) as ONE L.Linear: weight rows [cls_score.W; zero rows up to
+        the next multiple of 32; bbox_pred.W], so a row of the output is [scores | pad | deltas] and one GEMM launch replaces two
+        (every output column is still its own dot product over fc7).  The trainers keep using the two separate layers."""
+        rt, ncls = self.rt, self._num_classes
+        Wc, bc = rt.mem.to_numpy(self.cls_score.W), rt.mem.to_numpy(self.cls_score.b)
+        Wb, bb = rt.mem.to_numpy(self.bbox_pred.W), rt.mem.to_numpy(self.bbox_pred.b)
+        self._head_dcol = (ncls + 31) // 32 * 32
+        n = self._head_dcol + 4 * ncls
+        W = np.zeros((n, Wc.shape[1]), np.float32)
+        b = np.zeros((n,), np.float32)
+        W[:ncls], b[:ncls] = Wc, bc
+        W[self._head_dcol:], b[self._head_dcol:] = Wb, bb
+        self.head_out = Linear(rt, self.head_dtype)
+        self.head_out.set(W, b)
+        self._head_dirty = False
+
+    def mark_params_updated(self):
+        """The trainers call this after an optimizer update: the stacked inference head is rebuilt on the next inference."""
+        self._head_dirty = True
 
     def _check_data_type_forward(self, x, img_info, gt_boxes):
         assert x.shape[0] == 1
@@ -108,6 +130,8 @@ class FasterRCNN(object):
         n_out (1,) int32) -- all device arrays, R = post_nms_top_n; rows >= n_out are padding.
         `timer.mark(name)` (optional) is called after every stage: bench.py records a HIP event there."""
         rt = self.rt
+        if getattr(self, "_head_dirty", True):
+            self._stack_head()
         mark = timer.mark if timer else (lambda name: None)
         feat = self.trunk(x, timer=timer)
         C, H, W = [int(v) for v in feat.shape[1:]]
@@ -121,21 +145,21 @@ class FasterRCNN(object):
             mark("fc6")
             fc7 = self.fc7.bf16(fc6, relu=True, out_bf16=True)
             mark("fc7")
-            cls_score = self.cls_score.bf16(fc7)
-            bbox_pred = self.bbox_pred.bf16(fc7)
+            head = self.head_out.bf16(fc7)
         else:
             fc6 = self.fc6(pool5, relu=True)        # dropout is the identity in inference (faster_rcnn.py:127-128)
             mark("fc6")
             fc7 = self.fc7(fc6, relu=True)
             mark("fc7")
-            cls_score = self.cls_score(fc7)
-            bbox_pred = self.bbox_pred(fc7)
-        pred_boxes, cls_prob = rt.head_decode(rois, bbox_pred, cls_score, im_h, im_w)
+            head = self.head_out(fc7)
+        pred_boxes, cls_prob = rt.head_decode_stacked(rois, head, self._num_classes, self._head_dcol, im_h, im_w)
         mark("head_out")
         out = dict(cls_prob=cls_prob, pred_boxes=pred_boxes, rois=rois, probs=probs, n_out=n_out)
         if keep:
+            ncls, d0 = self._num_classes, self._head_dcol
             out.update(feat=feat, rpn_cls_prob=prob, rpn_bbox_pred=bbox, pool5=pool5, fc6=fc6, fc7=fc7,
-                       cls_score=cls_score, bbox_pred=bbox_pred)
+                       cls_score=rt.mem.from_numpy(np.ascontiguousarray(rt.mem.to_numpy(head)[:, :ncls])),
+                       bbox_pred=rt.mem.from_numpy(np.ascontiguousarray(rt.mem.to_numpy(head)[:, d0:d0 + 4 * ncls])))
         return out
 
     def __call__(self, x, img_info, gt_boxes=None):

@@ -268,6 +268,16 @@ class Runtime(object):
         return pred, prob
 
 
+    def head_decode_stacked(self, boxes, out, ncls, dcol, im_h, im_w):
+        """`out` (R, ld): class scores in columns [0, ncls), deltas from column dcol -- the stacked cls_score/bbox_pred GEMM."""
+        m, L = self.mem, self.lib
+        R, ld = int(out.shape[0]), int(out.shape[1])
+        pred = m.empty((R, 4 * ncls), "f32")
+        prob = m.empty((R, ncls), "f32")
+        _lib.check(L.frcnn_head_decode_stacked(m.ptr(boxes), m.ptr(out), ld, int(dcol), R, int(ncls), int(im_h), int(im_w),
+                                               m.ptr(pred), m.ptr(prob), m.stream()), "frcnn_head_decode_stacked")
+        return pred, prob
+
     def preprocess_u8(self, img, means, im_scale, out_hw):
         """img (H,W,C) uint8 device array -> (1,C,OH,OW) float32 (forward.py:33-45 on the device)."""
         m, L = self.mem, self.lib

@@ -144,6 +144,8 @@ class RPNTrainer(object):
 
     def update(self):
         self.rt.sgd_momentum_wd(self.W, self.G, self.V, self.lr, self.momentum, self.weight_decay)
+        if hasattr(self.model, "mark_params_updated"):
+            self.model.mark_params_updated()
         self.iteration += 1
 
     def step(self, x, img_info, gt_boxes):
@@ -307,6 +309,8 @@ class RCNNTrainer(object):
 
     def update(self):
         self.rt.sgd_momentum_wd(self.W, self.G, self.V, self.lr, self.momentum, self.weight_decay)
+        if hasattr(self.model, "mark_params_updated"):
+            self.model.mark_params_updated()
         self.iteration += 1
 
     def step(self, x, img_info, gt_boxes, masks=None):

@@ -157,6 +157,10 @@ int frcnn_linear_f32(const float *x, const float *w, const float *bias, float *y
  * boxes (R,4), deltas (R,4*ncls) -> pred_boxes (R,4*ncls); cls_score (R,ncls) -> cls_prob (R,ncls). */
 int frcnn_head_decode(const float *boxes, const float *deltas, const float *cls_score, int R, int ncls,
                       int im_h, int im_w, float *pred_boxes, float *cls_prob, void *stream);
+/* the same for the stacked head GEMM (cls_score and bbox_pred as ONE L.Linear whose weight rows are [cls_score.W; 0...; bbox_pred.W]):
+ * out (R, ld) holds the class scores in columns [0, ncls) and the 4*ncls deltas from column dcol; ld % 4 == dcol % 4 == 0 */
+int frcnn_head_decode_stacked(const float *boxes, const float *out, int ld, int dcol, int R, int ncls, int im_h, int im_w,
+                              float *pred_boxes, float *cls_prob, void *stream);
 /* forward.py:50-53: per-class detection rows for the 20 per-class NMS problems --
  * dets (ncls-1, R, 5) = [pred_boxes[:, 4c:4c+4], cls_prob[:, c]] for c = 1..ncls-1; feed frcnn_nms_batched(thresh 0.3). */
 int frcnn_class_dets(const float *cls_prob, const float *pred_boxes, int R, int ncls, float *dets, void *stream);
