@@ -399,7 +399,29 @@ conv_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy
 
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float *__restrict__ slabs, size_t n, int splits, float *__restrict__ dwp) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    // slabs are added in split order (deterministic); four slabs' loads are in flight at a time and each thread owns four
+    // consecutive weights (n is a multiple of 4: Cout % 4 == 0), so the pass streams at the memory rate instead of one 4-byte
+    // load per thread per round trip
+    const size_t n4 = n / 4;
+    const bool out_aligned = (reinterpret_cast<uintptr_t>(dwp) & 15) == 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int q = 0;
+        for (; q + 4 <= splits; q += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4 *>(slabs + (size_t)(q + u) * n)[i];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+        }
+        for (; q < splits; ++q) {
+            const float4 v = reinterpret_cast<const float4 *>(slabs + (size_t)q * n)[i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (out_aligned) reinterpret_cast<float4 *>(dwp)[i] = s;
+        else { dwp[4 * i] = s.x; dwp[4 * i + 1] = s.y; dwp[4 * i + 2] = s.z; dwp[4 * i + 3] = s.w; }   // a view at an odd offset of the flat gradient buffer
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         float s = 0.0f;
         for (int q = 0; q < splits; ++q) s += slabs[(size_t)q * n + i];
         dwp[i] = s;
@@ -702,7 +724,8 @@ int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int 
     if (ksize == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<3>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<1>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
     const size_t n = p.slab_floats;
-    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    const size_t work = (n / 4 + 255) / 256 + 1;
+    const int blocks = (int)(work < 4096 ? work : 4096);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, n, p.splits, dw_packed);
     return frcnn_launch_status();
 }
