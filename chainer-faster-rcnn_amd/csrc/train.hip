@@ -15,6 +15,7 @@
 // Arithmetic parity: float64 where the reference is float64 (anchors, IoU, targets), float32 where it is float32
 // (the ground-truth side of bbox_transform), no FMA contraction (built with -ffp-contract=off).
 #include "frcnn_common.h"
+#include <stdlib.h>
 #include <frcnn_buffer.h>   // angle brackets: shadowed by the test emulator
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -397,6 +398,106 @@ conv_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy
         }
 }
 
+// LDS-DMA form of the same kernel.  The register-staged kernel above holds 144 accumulator registers AND a 50-register staging set
+// AND its address arithmetic: 384 VGPRs, ONE wave per SIMD, nothing to hide a load or an LDS round trip behind.  Here a tile's
+// rows go from L2 straight into the same padded LDS images (buffer_load_dword ... lds), one DMA per (channel, halo row): the row
+// base is a scalar offset, the per-lane offset (column, or out-of-range for padding / beyond the image) is fixed for the tile, so a
+// DMA costs a handful of SALU operations and no VALU -- and no staging registers: two workgroups per CU, one's MFMAs over the
+// other's loads, plus fragment reads software-pipelined one step ahead of the MFMAs.
+template <int KS>
+__global__ void __launch_bounds__(256, 2)
+conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slabs, int Cin, int Cout, int H, int W,
+                      int xtiles, int nblocks, int splits) {
+    constexpr int T = KS * KS, PAD = KS / 2;
+    constexpr int HP = 32 + KS - 1;
+    constexpr int HR = WG_ROWS + KS - 1;
+    constexpr int CHP = HR * HP + ((HR * HP) % 2 == 0 ? 1 : 0);
+    constexpr int DP = WG_ROWS * 32 + 1;
+    __shared__ float x_lds[64 * CHP];
+    __shared__ float dy_lds[64 * DP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wci = wave & 1, wco = wave >> 1;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int HWs = H * W;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
+    const int b_begin = (int)((long long)split * nblocks / splits), b_end = (int)((long long)(split + 1) * nblocks / splits);
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)Cin * HWs * sizeof(float)));
+    const frcnn_buf_t dbuf = frcnn_make_buf(dy, (uint32_t)((size_t)Cout * HWs * sizeof(float)));
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    static_assert(WG_ROWS == 2, "a dy piece is the two 32-pixel rows of one channel");
+    for (int b = b_begin; b < b_end; ++b) {
+        const int tx = b % xtiles, ty = b / xtiles;
+        const int x0 = tx * 32, y0 = ty * WG_ROWS;
+        // per-lane parts, fixed for the tile.  x piece = one halo row of one channel (HP floats: lanes >= HP sit it out), columns
+        // x0-PAD .. x0+32+PAD-1; the scalar row base points at column xs = max(x0-PAD, 0) so no offset is ever negative.
+        const int xs = x0 - PAD > 0 ? x0 - PAD : 0;
+        const int gx = x0 - PAD + lane;
+        const uint32_t vx = (lane < HP && gx >= 0 && gx < W) ? (uint32_t)(gx - xs) * 4u : kBufOob;
+        // dy piece = both rows of one channel (64 floats): lane -> (row lane>>5, column lane&31)
+        const int dgy = y0 + (lane >> 5), dgx = x0 + (lane & 31);
+        const uint32_t vd = (dgy < H && dgx < W) ? (uint32_t)((lane >> 5) * W + (lane & 31)) * 4u : kBufOob;
+        if (b != b_begin) frcnn_barrier_nofence();            // every wave is done reading the previous tile
+        // wave w moves channels w, w+4, ... (16 channels: HR x rows + 1 dy piece each)
+#pragma unroll 1
+        for (int q = 0; q < 16; ++q) {
+            const int c = wave + 4 * q;
+            const int gc = ci0 + c, gco = co0 + c;
+#pragma unroll
+            for (int hr = 0; hr < HR; ++hr) {
+                const int gy = y0 - PAD + hr;
+                const bool row_ok = gc < Cin && gy >= 0 && gy < H;              // wave-uniform
+                const uint32_t so = row_ok ? (uint32_t)(((size_t)gc * H + gy) * W + xs) * 4u : 0u;
+                if (lane < HP) frcnn_buf_load_lds_b32(xbuf, &x_lds[c * CHP + hr * HP], row_ok ? vx : kBufOob, so);
+            }
+            const bool ch_ok = gco < Cout && y0 < H;
+            const uint32_t so = ch_ok ? (uint32_t)(((size_t)gco * H + y0) * W + x0) * 4u : 0u;
+            frcnn_buf_load_lds_b32(dbuf, &dy_lds[c * DP], ch_ok ? vd : kBufOob, so);
+        }
+        frcnn_wait_vmcnt<0>();
+        frcnn_barrier_nofence();
+        const float *xa = x_lds + (wci * 32 + l31) * CHP + khalf;
+        const float *db = dy_lds + (wco * 32 + l31) * DP + khalf;
+        // step s = (row r, pixel pair pp): one dy value and the T shifted x values feed T MFMAs; the fragments of step s+1 are
+        // read before the MFMAs of step s are issued (register double buffer, two steps per trip so it is indexed statically)
+        constexpr int NSTEP = WG_ROWS * 16;
+        float av[2][T], bv[2];
+        auto frag = [&](int s, float (&a)[T], float &bb) {
+            const int r = s >> 4, pp = s & 15;
+            bb = db[r * 32 + 2 * pp];
+#pragma unroll
+            for (int t = 0; t < T; ++t) a[t] = xa[(r + t / KS) * HP + 2 * pp + t % KS];
+        };
+        frag(0, av[0], bv[0]);
+#pragma unroll 1
+        for (int s = 0; s < NSTEP; s += 2) {
+            frag(s + 1, av[1], bv[1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][t], bv[0], acc[t], 0, 0, 0);
+            if (s + 2 < NSTEP) frag(s + 2, av[0], bv[0]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][t], bv[1], acc[t], 0, 0, 0);
+        }
+    }
+    float *slab = slabs + (size_t)split * ((size_t)Cin * T * Cout);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            const int co = co0 + wco * 32 + l31;
+            if (ci < Cin && co < Cout) slab[((size_t)ci * T + t) * Cout + co] = acc[t][r];
+        }
+}
+
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float *__restrict__ slabs, size_t n, int splits, float *__restrict__ dwp) {
     // slabs are added in split order (deterministic); four slabs' loads are in flight at a time and each thread owns four
@@ -721,7 +822,10 @@ int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int 
     if (!workspace || workspace_bytes < p.slab_floats * p.splits * sizeof(float)) return FRCNN_ERR_INVALID;
     float *slabs = (float *)workspace;
     const dim3 grid(p.ci_tiles, p.co_tiles, p.splits);
-    if (ksize == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<3>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
+    const bool reg = getenv("FRCNN_WGRAD_REG") != nullptr;        // A/B hook: the register-staged kernel
+    if (ksize == 3 && !reg) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
+    else if (ksize == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<3>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
+    else if (!reg) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<1>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<1>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
     const size_t n = p.slab_floats;
     const size_t work = (n / 4 + 255) / 256 + 1;
