@@ -269,9 +269,16 @@ def main():
                 timer.end()
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = model.forward_device(x, IM_H, IM_W)
-        graph.replay()
+        try:
+            # thread_local: with N > 1 the process group's watchdog thread polls events while this thread captures
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                out = model.forward_device(x, IM_H, IM_W)
+            graph.replay()
+        except Exception as e:                                    # never lose the run to the capture: time eager launches instead
+            print("hipGraph capture failed (%s): timing eager launches" % (e,), file=sys.stderr)
+            torch.cuda.synchronize()
+            use_graph, graph = False, None
+    if use_graph:
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -279,14 +286,15 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
     else:
+        eager_timer = timer if args.graph == "off" else None      # after a failed capture the stage events already exist
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            if timer:
-                timer.begin()
-            out = model.forward_device(x, IM_H, IM_W, timer=timer)
-            if timer:
-                timer.end()
+            if eager_timer:
+                eager_timer.begin()
+            out = model.forward_device(x, IM_H, IM_W, timer=eager_timer)
+            if eager_timer:
+                eager_timer.end()
         barrier()
         dt = time.perf_counter() - t0
     n_rois = int(out["n_out"].cpu()[0])
@@ -322,7 +330,7 @@ def main():
             roi_bytes = (512 * fh * fw + 300 * 512 * 49) * 4 + 300 * 16
             res["stages_ms"] = {k: round(v, 4) for k, v in avg.items()}
             res["stage_events"] = {"where": ("HIP events on the launch stream around every stage of %d eager forwards run immediately before the "
-                                             "timed graph replays (events cannot be read out of a replayed graph)" % max(3, args.steps // 3)) if use_graph
+                                             "timed graph replays (events cannot be read out of a replayed graph)" % max(3, args.steps // 3)) if args.graph != "off"
                                    else "HIP events on the launch stream inside the timed region",
                                    "sum_of_stages_ms": round(sum(avg.values()), 4), "timed_ms_per_step": round(ms_per_step, 4)}
             res["per_layer_tflops"] = {k: round(flops[k] / (avg[k] * 1e-3) / 1e12, 2) for k in flops}
