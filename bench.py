@@ -268,12 +268,10 @@ def main():
                 model.forward_device(x, IM_H, IM_W, timer=timer)
                 timer.end()
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
         try:
-            # thread_local: with N > 1 the process group's watchdog thread polls events while this thread captures
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
-                out = model.forward_device(x, IM_H, IM_W)
-            graph.replay()
+            from chainer_faster_rcnn_amd.graph import CapturedForward
+            graph = CapturedForward(model, x, IM_H, IM_W, warmup=1)
+            out = graph.replay()
         except Exception as e:                                    # never lose the run to the capture: time eager launches instead
             print("hipGraph capture failed (%s): timing eager launches" % (e,), file=sys.stderr)
             torch.cuda.synchronize()

@@ -3,6 +3,7 @@
   csrc/      hand-written HIP kernels for gfx950 + the C ABI (include/frcnn_hip.h) -> libfrcnn_hip.so
   _lib.py    ctypes binding of that ABI (no fallback: raises if the library or the GPU is missing)
   runtime.py device memory / stream plumbing (PyTorch-ROCm) + typed wrappers over each entry point
+  graph.py   hipGraph capture / replay of the inference forward (CapturedForward)
   train.py   the RPN training step (forward, anchor targets, losses, backward, one all-reduce, fused SGD update)
   models/    host-side mirror of the reference's models/ package (ProposalLayer, AnchorTargetLayer,
              cpu_nms, bbox, roi_pooling_2d, VGG16Prev, RegionProposalNetwork, FasterRCNN)

@@ -368,3 +368,20 @@ def test_rcnn_train_step_vgg16(rt):
 def test_conv_workspace_self_cleaning(rt):
     P.check_conv_workspace_self_cleaning(rt)
 
+
+def test_captured_forward_matches_eager(rt):
+    """hipGraph replay (graph.CapturedForward) == eager launches, bit for bit, also after the input buffer is replaced."""
+    from chainer_faster_rcnn_amd import synthetic
+    from chainer_faster_rcnn_amd.graph import CapturedForward
+    from chainer_faster_rcnn_amd.models import FasterRCNN
+    model = FasterRCNN(runtime=rt)
+    model.load_params(synthetic.params(seed=1))
+    h, w = 224, 320
+    x0, x1 = [rt.mem.from_numpy(synthetic.image(seed=s, h=h, w=w)) for s in (3, 4)]
+    cap = CapturedForward(model, x0, h, w)
+    for x in (x0, x1, x0):
+        want = {k: rt.mem.to_numpy(v).copy() for k, v in model.forward_device(x, h, w).items()}
+        got = {k: rt.mem.to_numpy(v).copy() for k, v in cap.replay(x).items()}
+        for k in want:
+            assert np.array_equal(want[k], got[k]), k
+
