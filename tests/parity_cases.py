@@ -512,3 +512,21 @@ def check_conv_workspace_self_cleaning(rt):
     page = host(rt, rt._ws["conv_bf16"])[:65536]
     assert not page.any()
 
+
+def check_empty_proposals_pipeline(rt):
+    """Nothing survives the min-size filter (ProposalLayer with a huge min_size): zero proposals out, padding rows zeroed, and the
+    downstream stages accept the all-padding RoI block (degenerate RoIs at the origin) without faulting -- the reference would
+    hand F.roi_pooling_2d an empty array here; the fixed-capacity device path hands it zero rows that n_out tells the caller to drop."""
+    G = g("proposal_14x14_train_rand")
+    anchors = O.generate_anchors()
+    im_h, im_w = [int(v) for v in G["img_info"][0]]
+    rois, probs, n_out, src = rt.proposals(dev(rt, G["rpn_cls_prob"][0]), dev(rt, G["rpn_bbox_pred"][0]), anchors, 16,
+                                           im_h, im_w, 1.0e6, 200, 50, 0.7, want_index=True)
+    assert int(host(rt, n_out)[0]) == 0
+    assert not host(rt, rois).any() and not host(rt, probs).any() and (host(rt, src) == -1).all()
+    C, H, W = 16, 14, 14
+    x = np.abs(np.random.RandomState(0).randn(1, C, H, W)).astype(np.float32)
+    y = host(rt, rt.roi_pool_fwd_chw(dev(rt, x[0]), rois, 7, 7, 0.0625))
+    want, _ = O.roi_pooling_2d(x, np.zeros((rois.shape[0], 5), np.float32), 7, 7, 0.0625, return_argmax=True)
+    assert np.array_equal(y, want)                        # a (0,0,0,0) RoI is the 1x1 window at the origin in every bin it covers
+

@@ -385,3 +385,7 @@ def test_captured_forward_matches_eager(rt):
         for k in want:
             assert np.array_equal(want[k], got[k]), k
 
+
+def test_empty_proposals_pipeline(rt):
+    P.check_empty_proposals_pipeline(rt)
+

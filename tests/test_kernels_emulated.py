@@ -193,3 +193,7 @@ def test_conv_bf16_split_k(rt, monkeypatch, split):
 def test_conv_workspace_self_cleaning(rt):
     P.check_conv_workspace_self_cleaning(rt)
 
+
+def test_empty_proposals_pipeline(rt):
+    P.check_empty_proposals_pipeline(rt)
+
