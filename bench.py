@@ -139,7 +139,7 @@ def cpu_baseline(params, x, samples):
 
 
 def train_mode(args, torch, dist, rt, model, x, rank, world, barrier):
-    """BASELINE.json configs[4]: train_rpn.py's step -- forward, anchor targets, losses, backward, ONE all-reduce of the
+    """BASELINE.json configs[4]: train_rpn.py's step -- forward, anchor targets, losses, backward, the all-reduce of the
     flat gradient buffer (RCCL), fused MomentumSGD+WD -- one synthetic VOC-shaped image per GPU per step."""
     from chainer_faster_rcnn_amd.train import RPNTrainer, TorchComm
     model.rpn_train = True
@@ -187,8 +187,8 @@ def train_mode(args, torch, dist, rt, model, x, rank, world, barrier):
         print(json.dumps({"metric": "images/sec RPN training step VGG16 600x1000", "value": world * args.steps / dt, "unit": "img/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "train_rpn.py end-to-end RPN training step, 1 image per GPU, one all-reduce of the "
-                                                 "flat fp32 gradient buffer per step (BASELINE.json configs[4])",
+                          "config": {"workload": "train_rpn.py end-to-end RPN training step, 1 image per GPU, all-reduce of the flat fp32 gradient "
+                                                 "buffer in 3 buckets overlapped with the backward pass (BASELINE.json configs[4])",
                                      "grad_buffer_mb": tr.n_flat * 4 / 1e6, "global_batch": world},
                           "stages_ms": st, "losses": tr.losses_host(out)}))
     if dist is not None:
@@ -221,12 +221,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # one rank per GPU; FRCNN_DIST_BACKEND=gloo + fewer GPUs than ranks is the functional smoke test of the N > 1 path on a 1-GPU box
+    backend = os.environ.get("FRCNN_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import chainer_faster_rcnn_amd as pkg
     from chainer_faster_rcnn_amd import synthetic

@@ -10,7 +10,8 @@ What runs where:
   losses          frcnn_rpn_loss: softmax-CE + Huber and their gradients w.r.t. the two head outputs
   backward        per conv: weight gradient (MFMA, pixels as the reduction axis), bias gradient, input gradient = the forward
                   kernel on 180-degree-rotated weights with the ReLU mask fused into the epilogue; max-pool: gather
-  data parallel   ONE all_reduce(SUM) of the flat fp32 gradient buffer per step (RCCL over xGMI; gloo on CPU), i.e. the
+  data parallel   all_reduce(SUM) of the flat fp32 gradient buffer (RCCL over xGMI; gloo on CPU), launched per bucket (three
+                  contiguous tail ranges) while the backward pass is still running -- see RPNTrainer._plan_buckets; i.e. the
                   gradients are summed over replicas exactly as ParallelUpdater's addgrads does, then every rank applies
                   the identical update (replaces gather-to-main + copyparams broadcast)
   update          one fused MomentumSGD + WeightDecay launch over the flat parameter / gradient / velocity buffers
@@ -50,6 +51,8 @@ def trunk_backward(trainer, layer_inputs, g):
         name = l[0]
         rt.conv_wgrad(xin, g, 3, out=trainer.grad[name + "/W"])
         rt.bias_grad(g, out=trainer.grad[name + "/b"])
+        if hasattr(trainer, "_grads_ready"):
+            trainer._grads_ready(name)                            # data parallel: a finished bucket starts its all-reduce now
         if name != first:                                         # the image needs no gradient
             rt.pack_conv_dgrad_w(links[name].Wp, 3, out=trainer.wd[name])
             g = rt.conv_ex(g, trainer.wd[name], trainer.zero_bias, 3, act=2, mask=xin)
@@ -108,11 +111,43 @@ class RPNTrainer(object):
         self.zero_bias = rt.mem.zeros((512,), "f32")
         self._draw = None
         self.iteration = 0
+        self._plan_buckets()
+
+    # ------------------------------------------------------------------ data parallel: bucketed, overlapped all-reduce
+    def _plan_buckets(self, n_buckets=3):
+        """The flat gradient buffer is laid out in FORWARD order, the backward pass fills it from the END: [heads, rpn_conv,
+        conv5_3, ...] first, conv1_1 last.  So a bucket is a contiguous tail range, closed by the layer whose gradients complete
+        it; its all-reduce is launched (async, on the collective's own stream) the moment that layer's kernels are enqueued and
+        runs under the rest of the backward pass.  The 68 MB of VGG-16 gradients split into [heads..conv5_2 | conv5_1..conv4_2 |
+        conv4_1..conv1_1] = 28.5 / 28.3 / 11.7 MB; the first is complete after ~1 ms of an 8 ms backward, only the last and smallest
+        is exposed.  Same sums as one all-reduce (element-wise over ranks); xGMI rings are per-link bound, so a few large buckets,
+        not many small ones."""
+        names = [n for n, _ in self.convs]                          # forward order; heads come after them in the buffer
+        total = self.n_flat
+        self.buckets, end = [], total                               # (closing layer, start, end), in backward order
+        target = total / float(n_buckets)
+        for i in range(len(names) - 1, -1, -1):
+            start = self.seg[names[i] + "/W"].offset
+            if end - start >= target or i == 0:
+                self.buckets.append((names[i], start, end))
+                end = start
+        self._closing = {b[0]: k for k, b in enumerate(self.buckets)}
+        self._works = []
+
+    def _grads_ready(self, name):
+        k = self._closing.get(name)
+        if k is None or self.comm is None or self.comm.world_size <= 1:
+            return
+        _, start, end = self.buckets[k]
+        self._works.append(self.comm.all_reduce_sum_async(self.G[start:end]))
 
     # ------------------------------------------------------------------
     def forward_backward(self, x, img_info, gt_boxes):
         """Fills self.G with this replica's gradients; returns dict(loss, loss_cls, loss_bbox, accuracy) (device scalars)."""
         rt, model, rpn = self.rt, self.model, self.model.RPN
+        for w in self._works:                                      # a previous backward whose sums were never consumed
+            self.comm.wait(w)
+        self._works = []
         x = rt.asarray(unwrap(x), "f32")
         im_h, im_w = rpn.proposal_layer._img_hw(img_info)
         feat, inputs = trunk_forward(model, x)                     # keeps every layer's input
@@ -138,9 +173,19 @@ class RPNTrainer(object):
         return dict(losses=losses)
 
     def all_reduce(self):
-        """Sum the gradient buffer over the replicas (ParallelUpdater: grads are added, not averaged)."""
-        if self.comm is not None and self.comm.world_size > 1:
+        """Sum the gradient buffer over the replicas (ParallelUpdater: grads are added, not averaged).  The buckets were launched
+        during the backward pass (_grads_ready); this waits for them -- the update must see every sum."""
+        if self.comm is None or self.comm.world_size <= 1:
+            return
+        if len(self._works) != len(self.buckets):                 # forward_backward was not the producer (e.g. a hand-filled G)
+            for w in self._works:
+                self.comm.wait(w)
+            self._works = []
             self.comm.all_reduce_sum(self.G)
+            return
+        for w in self._works:
+            self.comm.wait(w)
+        self._works = []
 
     def update(self):
         self.rt.sgd_momentum_wd(self.W, self.G, self.V, self.lr, self.momentum, self.weight_decay)
@@ -351,3 +396,12 @@ class TorchComm(object):
     def all_reduce_sum(self, buf):
         t = buf if isinstance(buf, self.torch.Tensor) else self.torch.from_numpy(buf)      # NumPy buffers are reduced in place
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+    def all_reduce_sum_async(self, buf):
+        """Launch the all-reduce of a (contiguous) slice now and return a handle: with RCCL it is enqueued behind the kernels
+        already on the current stream and runs on the collective's stream, under whatever the caller launches next."""
+        t = buf if isinstance(buf, self.torch.Tensor) else self.torch.from_numpy(buf)
+        return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=True)
+
+    def wait(self, work):
+        work.wait()                                # RCCL: the current stream waits for the collective (no host block); gloo: blocks

@@ -160,3 +160,20 @@ def test_proposal_target_layer_mirror(rt):
 
 def test_rcnn_train_step_small(rt):
     T.check_small_rcnn_step(rt)
+
+
+def test_gradient_buckets_tile_the_flat_buffer(rt):
+    """Data-parallel buckets: contiguous tail ranges of the flat gradient buffer in backward order, together covering it exactly
+    once, each closed by a layer whose gradients are the last of the bucket to be produced."""
+    from chainer_faster_rcnn_amd.train import RPNTrainer
+    tr = RPNTrainer(T.build_small(rt, T.small_params()))
+    assert 1 <= len(tr.buckets) <= 3
+    end = tr.n_flat
+    order = [n for n, _ in tr.convs]
+    last_idx = len(order)
+    for name, start, stop in tr.buckets:                      # backward order
+        assert stop == end and start < stop and start == tr.seg[name + "/W"].offset
+        assert order.index(name) < last_idx                   # closing layers come earlier and earlier in the network
+        last_idx, end = order.index(name), start
+    assert end == 0 and tr.buckets[-1][0] == order[0]
+
