@@ -65,7 +65,51 @@ class _Seg(object):
         self.size = int(np.prod(shape))
 
 
-class RPNTrainer(object):
+class _BucketedAllReduce(object):
+    """Data parallel: the gradient all-reduce as a few contiguous TAIL buckets of the flat buffer, each launched asynchronously
+    the moment the layer that completes it has its gradient kernels enqueued (the buffer is laid out in forward order and the
+    backward pass fills it from the end), so the exchange runs under the rest of the backward pass.  Same element-wise sums over
+    ranks as one all-reduce.  Few large buckets, not many small ones: xGMI is point-to-point, a ring collective is per-link bound,
+    and every extra collective adds its latency."""
+
+    def _plan_buckets(self, names, n_buckets=3):
+        """names: parameter groups in FORWARD (= buffer) order; every group's gradients precede, in time, those of the groups
+        before it.  Buckets are (closing group, start, end) in backward order and tile [0, n_flat)."""
+        total, end = self.n_flat, self.n_flat
+        target = total / float(n_buckets)
+        self.buckets = []
+        for i in range(len(names) - 1, -1, -1):
+            start = self.seg[names[i] + "/W"].offset
+            if end - start >= target or i == 0:
+                self.buckets.append((names[i], start if i else 0, end))
+                end = start
+        self._closing = {b[0]: k for k, b in enumerate(self.buckets)}
+        self._works = []
+
+    def _grads_ready(self, name):
+        k = self._closing.get(name)
+        if k is None or self.comm is None or self.comm.world_size <= 1:
+            return
+        _, start, end = self.buckets[k]
+        self._works.append(self.comm.all_reduce_sum_async(self.G[start:end]))
+
+    def _drain(self):
+        for w in self._works:
+            self.comm.wait(w)
+        self._works = []
+
+    def all_reduce(self):
+        """Sum the gradient buffer over the replicas (ParallelUpdater: grads are added, not averaged).  The buckets were launched
+        during the backward pass (_grads_ready); this waits for them -- the update must see every sum."""
+        if self.comm is None or self.comm.world_size <= 1:
+            return
+        complete = len(self._works) == len(self.buckets)
+        self._drain()
+        if not complete:                                          # forward_backward was not the producer (e.g. a hand-filled G)
+            self.comm.all_reduce_sum(self.G)
+
+
+class RPNTrainer(_BucketedAllReduce):
     def __init__(self, model, lr=0.001, momentum=0.9, weight_decay=0.0005, comm=None):
         self.model, self.rt = model, model.rt
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
@@ -111,43 +155,13 @@ class RPNTrainer(object):
         self.zero_bias = rt.mem.zeros((512,), "f32")
         self._draw = None
         self.iteration = 0
-        self._plan_buckets()
-
-    # ------------------------------------------------------------------ data parallel: bucketed, overlapped all-reduce
-    def _plan_buckets(self, n_buckets=3):
-        """The flat gradient buffer is laid out in FORWARD order, the backward pass fills it from the END: [heads, rpn_conv,
-        conv5_3, ...] first, conv1_1 last.  So a bucket is a contiguous tail range, closed by the layer whose gradients complete
-        it; its all-reduce is launched (async, on the collective's own stream) the moment that layer's kernels are enqueued and
-        runs under the rest of the backward pass.  The 68 MB of VGG-16 gradients split into [heads..conv5_2 | conv5_1..conv4_2 |
-        conv4_1..conv1_1] = 28.5 / 28.3 / 11.7 MB; the first is complete after ~1 ms of an 8 ms backward, only the last and smallest
-        is exposed.  Same sums as one all-reduce (element-wise over ranks); xGMI rings are per-link bound, so a few large buckets,
-        not many small ones."""
-        names = [n for n, _ in self.convs]                          # forward order; heads come after them in the buffer
-        total = self.n_flat
-        self.buckets, end = [], total                               # (closing layer, start, end), in backward order
-        target = total / float(n_buckets)
-        for i in range(len(names) - 1, -1, -1):
-            start = self.seg[names[i] + "/W"].offset
-            if end - start >= target or i == 0:
-                self.buckets.append((names[i], start, end))
-                end = start
-        self._closing = {b[0]: k for k, b in enumerate(self.buckets)}
-        self._works = []
-
-    def _grads_ready(self, name):
-        k = self._closing.get(name)
-        if k is None or self.comm is None or self.comm.world_size <= 1:
-            return
-        _, start, end = self.buckets[k]
-        self._works.append(self.comm.all_reduce_sum_async(self.G[start:end]))
+        self._plan_buckets([n for n, _ in self.convs])       # heads follow rpn_conv_3x3 in the buffer and precede it in time
 
     # ------------------------------------------------------------------
     def forward_backward(self, x, img_info, gt_boxes):
         """Fills self.G with this replica's gradients; returns dict(loss, loss_cls, loss_bbox, accuracy) (device scalars)."""
         rt, model, rpn = self.rt, self.model, self.model.RPN
-        for w in self._works:                                      # a previous backward whose sums were never consumed
-            self.comm.wait(w)
-        self._works = []
+        self._drain()                                              # a previous backward whose sums were never consumed
         x = rt.asarray(unwrap(x), "f32")
         im_h, im_w = rpn.proposal_layer._img_hw(img_info)
         feat, inputs = trunk_forward(model, x)                     # keeps every layer's input
@@ -171,21 +185,6 @@ class RPNTrainer(object):
         # ---- rpn_conv_3x3, then the trunk in reverse
         trunk_backward(self, list(zip(self.layers, inputs)) + [(("rpn_conv_3x3", 0, 0), feat)], g)
         return dict(losses=losses)
-
-    def all_reduce(self):
-        """Sum the gradient buffer over the replicas (ParallelUpdater: grads are added, not averaged).  The buckets were launched
-        during the backward pass (_grads_ready); this waits for them -- the update must see every sum."""
-        if self.comm is None or self.comm.world_size <= 1:
-            return
-        if len(self._works) != len(self.buckets):                 # forward_backward was not the producer (e.g. a hand-filled G)
-            for w in self._works:
-                self.comm.wait(w)
-            self._works = []
-            self.comm.all_reduce_sum(self.G)
-            return
-        for w in self._works:
-            self.comm.wait(w)
-        self._works = []
 
     def update(self):
         self.rt.sgd_momentum_wd(self.W, self.G, self.V, self.lr, self.momentum, self.weight_decay)
@@ -232,7 +231,7 @@ class RPNTrainer(object):
         return out
 
 
-class RCNNTrainer(object):
+class RCNNTrainer(_BucketedAllReduce):
     """Stage-2 step of train_rcnn.py (train_rcnn.py:35-78; models/faster_rcnn.py:110-173 with rcnn_train = True): trunk -> RPN
     proposals (test-mode ProposalLayer, no gradient) -> RoI pooling -> fc6/fc7 with dropout -> cls_score / bbox_pred ->
     ProposalTargetLayer sampling -> softmax-CE + Huber(1) on the sampled rows -> backward through the head (the four L.Linear
@@ -281,6 +280,8 @@ class RCNNTrainer(object):
         self.wd = {name: rt.mem.empty((int(link.Wp.shape[1]) * 9, int(link.Wp.shape[0]) // 9), "f32") for name, link in self.convs[1:]}
         self.zero_bias = rt.mem.zeros((max(512, max(int(getattr(model, n).W.shape[1]) for n in self.HEAD)),), "f32")
         self.iteration = 0
+        # the head (fc6: 411 MB of gradients) is complete before the trunk's backward starts: its bucket rides under all of it
+        self._plan_buckets([n for n, _ in self.convs] + list(self.HEAD))
 
     # ------------------------------------------------------------------ one L.Linear backward: GEMMs on transposed operands
     def _linear_backward(self, name, x, dy, need_dx=True):
@@ -310,6 +311,7 @@ class RCNNTrainer(object):
     def forward_backward(self, x, img_info, gt_boxes, masks=None):
         """Fills self.G; returns dict(losses (3,) device [loss_cls, loss_bbox, cls_accuracy], n_rois, keep_inds)."""
         rt, model = self.rt, self.model
+        self._drain()                                              # a previous backward whose sums were never consumed
         x = rt.asarray(unwrap(x), "f32")
         im_h, im_w = model.RPN.proposal_layer._img_hw(img_info)
         feat, inputs = trunk_forward(model, x)
@@ -343,14 +345,12 @@ class RCNNTrainer(object):
         g6 = self._linear_backward("fc7", d6, g7)
         g6 = rt.relu_bwd_(rt.mul(g6, m6, out=g6), a6)
         gp = self._linear_backward("fc6", pool5, g6)
+        for n_ in reversed(self.HEAD):                             # every head gradient is enqueued: a bucket closed by a head layer starts now
+            self._grads_ready(n_)
         # ---- RoI pooling (arg-max scatter) and the trunk; feat = relu(conv5_3): mask before entering conv5_3's backward
         gfeat = rt.relu_bwd_(rt.roi_pool_bwd(gp.reshape(n, C, 7, 7), argmax, C, H, W), feat)
         trunk_backward(self, list(zip(self.layers, inputs)), gfeat)
         return dict(losses=losses, n_rois=n, keep_inds=keep)
-
-    def all_reduce(self):
-        if self.comm is not None and self.comm.world_size > 1:
-            self.comm.all_reduce_sum(self.G)
 
     def update(self):
         self.rt.sgd_momentum_wd(self.W, self.G, self.V, self.lr, self.momentum, self.weight_decay)

@@ -177,3 +177,21 @@ def test_gradient_buckets_tile_the_flat_buffer(rt):
         last_idx, end = order.index(name), start
     assert end == 0 and tr.buckets[-1][0] == order[0]
 
+
+def test_rcnn_gradient_buckets_put_the_head_first(rt):
+    """Stage 2: the head's gradients (fc6 alone is most of the buffer) are complete before the trunk's backward starts, so the
+    first bucket is closed by a head layer and the buckets still tile the buffer."""
+    from chainer_faster_rcnn_amd.train import RCNNTrainer
+    params = T.small_params()
+    params.update(T.small_head_params(np.random.RandomState(0)))
+    model = T.build_small(rt, params)
+    for n in RCNNTrainer.HEAD:
+        getattr(model, n).set(params[n + "/W"], params[n + "/b"])
+    tr = RCNNTrainer(model)
+    assert tr.buckets[0][0] in RCNNTrainer.HEAD and tr.buckets[0][2] == tr.n_flat
+    end = tr.n_flat
+    for _, start, stop in tr.buckets:
+        assert stop == end and start < stop
+        end = start
+    assert end == 0
+
