@@ -159,10 +159,11 @@ def train_mode(args, torch, dist, rt, model, x, rank, world, barrier):
         e.record()
         ev.setdefault(name, []).append(e)
 
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < args.ramp_seconds:          # untimed clock-ramp preamble (see the inference mode)
+    # untimed clock-ramp preamble (see the inference mode) -- a FIXED number of steps: every step holds collectives, so all ranks
+    # must run the same count (a wall-clock loop would let them diverge and deadlock the first all-reduce)
+    for _ in range(max(1, int(round(args.ramp_seconds / 0.0125)))):
         out = tr.step(x, info, gt_dev)
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = tr.step(x, info, gt_dev)
     barrier()
