@@ -579,7 +579,8 @@ static int launch_conv(const float *x, const float *wp, const float *bias, float
 // All picks stage through LDS-DMA (+3.5 ... 5 % over register staging on every layer) with 4-channel chunks: 25 KB of LDS per
 // workgroup instead of 50, four workgroups per CU instead of three.
 //   34: 64 couts x 4 rows x 32 px, wave = 32co x 2 rows.  Whole tiles while a layer has >= 4 rounds of them (conv1_1, conv1_2).
-//   36: 2-row tiles, wave = 32co x 1 row: whole tiles at 2-4 rounds of the 4-row tiling (the 300x500 maps), stream-K (236) below
+//   36 / 46: 2-row tiles, wave = 32co x 1 row: whole tiles at 2-4 rounds of the 4-row tiling (the 300x500 maps; 46 = a
+//       six-workgroup register budget), stream-K (236) below
 //       that (150x250, 75x125, 38x63: the fix-up costs less than a ragged last round; 80 % of the SIMDs would idle at 0.2 rounds).
 //   `two_rows` (the fused ReLU + pool epilogue needs a wave to own a window row pair): 34 / stream-K 230 (8-channel chunks).
 static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows) {
@@ -588,7 +589,7 @@ static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows) {
     const long slots = (long)frcnn_cu_count() * 3;
     if (ntiles >= 4 * slots) return 34;
     if (two_rows) return 230;
-    if (ntiles >= 2 * slots) return 36;
+    if (ntiles >= 2 * slots) return 46;            // same decomposition, 72 VGPRs: six workgroups per CU (+3 % on the 300x500 maps)
     return 236;
 }
 
@@ -640,6 +641,7 @@ size_t frcnn_conv3x3_workspace_bytes(int Cin, int Cout, int H, int W) {
         if (p.ws_bytes > best) best = p.ws_bytes;                                                       \
     }
     FRCNN_CONV_CASES(X)
+    X(46, 2, 2, 1, 1, 4, true, 6)
 #undef X
     return best;
 }
@@ -671,6 +673,7 @@ int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bi
         case 35: return launch_conv<3, 2, 2, 1, 1, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 34: return launch_conv<3, 2, 2, 1, 2, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 36: return launch_conv<3, 2, 2, 1, 1, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 46: return launch_conv<3, 2, 2, 1, 1, 4, true, 6, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         default: return FRCNN_ERR_INVALID;
     }
 }
@@ -687,6 +690,7 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
     switch (cfg % 100) {
         case 34: return launch_conv<3, 2, 2, 1, 2, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
         case 36: return launch_conv<3, 2, 2, 1, 1, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
+        case 46: return launch_conv<3, 2, 2, 1, 1, 4, true, 6, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
         default: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
     }
 }

@@ -51,12 +51,12 @@ def test_roi_pool(rt):
     P.check_roi_pool(rt, R=6, C=6, H=70, W=90, seed=3)      # 3 planes per group (odd sizes: scalar copies)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 8, 10, 11, 30, 35, 34, 36])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 8, 10, 11, 30, 35, 34, 36, 46])
 def test_conv3x3_cfg(rt, cfg):
     P.check_conv3x3(rt, 8, 128, 9, 37, cfg=cfg)
 
 
-@pytest.mark.parametrize("cfg", [201, 205, 210, 104, 110, 1205, 2205, 2210, 1010, 2010, 230, 235, 1235, 236, 234, 206])
+@pytest.mark.parametrize("cfg", [201, 205, 210, 104, 110, 1205, 2205, 2210, 1010, 2010, 230, 235, 1235, 236, 234, 206, 246])
 def test_conv3x3_streamk(rt, cfg):
     """stream-K work distribution: the emulated chip has 3 CUs, so tiles split unevenly into 2..4 pieces and the
     last-arriver fix-up (partial slots, tickets, piece-ordered sum) is exercised."""
