@@ -777,6 +777,84 @@ linear_mfma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restri
     }
 }
 
+// LDS-DMA form of the bf16 FC kernel (K a multiple of 64): a 64-k panel row is 128 B = eight 16-byte groups (8 bf16 each), staged as
+// 1 KB pieces of 8 rows into a lane-linear image with the XOR swizzle of the fp32 FC kernel (gemm.hip): group g of row r in slot
+// 8r + (g ^ ((r >> 1) & 7)).  k-step ks of a panel reads group 2ks + (lane >> 5) of the lane's row -- one conflict-free ds_read_b128
+// per operand per MFMA, no staging registers, no ds_write_b128 pass (this kernel is staging-bound: 460 B staged per MFMA).
+template <int AM>
+__global__ void __launch_bounds__(256, 2)
+linear_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w, float *__restrict__ part, int M, int N, int K, int k_per_split) {
+    constexpr int BM = 32 * AM, BN = 128;
+    constexpr int XP = BM / 8, WP = BN / 8;                  // 1 KB pieces per panel (8 rows each)
+    constexpr int PPW = (XP + WP) / 4;
+    constexpr int STAGE = (BM + BN) * 128;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * k_per_split, k_end = min(K, k_begin + k_per_split);
+    const int nchunks = (k_end - k_begin) / kLBK;            // whole panels: the host guarantees K % 64 == 0
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)M * K * 2));
+    const frcnn_buf_t wbuf = frcnn_make_buf(w, (uint32_t)((size_t)N * K * 2));
+    uint32_t poff[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int pid = wave + 4 * q;
+        const bool isx = pid < XP;
+        const int sl = (isx ? pid : pid - XP) * 64 + lane, row = sl >> 3, g = (sl & 7) ^ ((row >> 1) & 7);
+        const int gr = (isx ? m0 : n0) + row;
+        poff[q] = gr < (isx ? M : N) ? (uint32_t)(((size_t)gr * K + k_begin + 8 * g) * 2) : kBufOob;
+    }
+    auto issue = [&](int chunk, int stage) {
+        unsigned char *dst = lds + stage * STAGE + wave * 1024;
+        const uint32_t so = (uint32_t)chunk * (kLBK * 2);
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            if (4 * q + 3 < XP) frcnn_buf_load_lds_b128(xbuf, dst + q * 4096, poff[q], so);
+            else if (4 * q >= XP) frcnn_buf_load_lds_b128(wbuf, dst + q * 4096, poff[q], so);
+            else frcnn_buf_load_lds_b128(wave + 4 * q < XP ? xbuf : wbuf, dst + q * 4096, poff[q], so);
+        }
+    };
+    frcnn_f32x16 acc[AM];
+#pragma unroll
+    for (int i = 0; i < AM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    auto frag_off = [&](int row, int ks) { return (uint32_t)(row * 128 + (((2 * ks + khalf) ^ ((row >> 1) & 7)) << 4)); };
+    if (nchunks > 0) issue(0, 0);
+    frcnn_wait_vmcnt<0>();
+    frcnn_barrier_nofence();
+    int cur = 0;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        if (chunk + 1 < nchunks) issue(chunk + 1, cur ^ 1);
+        const unsigned char *xs = lds + cur * STAGE, *wsm = xs + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < kLBK / 16; ++ks) {
+            const uint4 b = *reinterpret_cast<const uint4 *>(wsm + frag_off(wave * 32 + l31, ks));
+#pragma unroll
+            for (int i = 0; i < AM; ++i) {
+                const uint4 a = *reinterpret_cast<const uint4 *>(xs + frag_off(32 * i + l31, ks));
+                acc[i] = frcnn_mfma_32x32x16_bf16(a, b, acc[i]);
+            }
+        }
+        frcnn_wait_vmcnt<0>();
+        frcnn_barrier_nofence();
+        cur ^= 1;
+    }
+    float *out = part + (size_t)blockIdx.z * M * N;
+    const int n = n0 + wave * 32 + l31;
+    if (n < N) {
+#pragma unroll
+        for (int i = 0; i < AM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (m < M) out[(size_t)m * N + n] = acc[i][r];
+            }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 linear_reduce_bf16_kernel(const float *__restrict__ part, const float *__restrict__ bias, void *__restrict__ y, int M, int N, int splits, int relu,
                           int out_bf16) {
@@ -839,7 +917,11 @@ int frcnn_linear_bf16(const uint16_t *x, const uint16_t *w, const float *bias, v
     if (!workspace || workspace_bytes < (size_t)p.splits * M * N * sizeof(float)) return FRCNN_ERR_INVALID;
     float *part = (float *)workspace;
     const dim3 grid(p.nblocks, p.mblocks, p.splits);
-    if (p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_bf16_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    const bool dma = (K % kLBK) == 0 && (p.k_per_split % kLBK) == 0 && !getenv("FRCNN_LINEAR_NODMA");
+    if (dma && p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_bf16_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    else if (dma && p.am == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_bf16_kernel<3>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    else if (dma) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_bf16_kernel<1>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    else if (p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_bf16_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     else if (p.am == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_bf16_kernel<3>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_bf16_kernel<1>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     const size_t total = (size_t)M * N;

@@ -151,7 +151,9 @@ def test_detections_postprocess(rt):
 
 def test_linear_bf16(rt):
     P.check_linear_bf16(rt, 70, 140, 256, True)
-    P.check_linear_bf16(rt, 9, 21, 72, False)
+    P.check_linear_bf16(rt, 9, 21, 72, False)              # K % 64 != 0: the register-staged kernel
+    P.check_linear_bf16(rt, 100, 130, 128, True, seed=2)   # LDS-DMA kernel, AM = 5, ragged M and N, two panels
+    P.check_linear_bf16(rt, 20, 40, 64, False, seed=3)     # AM = 1, one panel
 
 
 def test_conv_relu_pool_fused(rt):
