@@ -135,7 +135,8 @@ class FasterRCNN(object):
         mark = timer.mark if timer else (lambda name: None)
         feat = self.trunk(x, timer=timer)
         C, H, W = [int(v) for v in feat.shape[1:]]
-        _, score, prob, bbox = self.RPN.heads(feat, want_score=False, timer=timer)
+        x_bf16 = getattr(self.trunk, "feat_bf16", None) if self.conv_dtype == "bf16" else None
+        _, score, prob, bbox = self.RPN.heads(feat, want_score=False, timer=timer, x_bf16=x_bf16)
         rois, probs, n_out = self.RPN.proposal_layer.forward_device(prob, bbox, im_h, im_w)
         mark("proposals")
         pool5 = rt.roi_pool_fwd_chw(feat, rois, 7, 7, self._spatial_scale)    # rois (R,4): concat (:123-124) folded in

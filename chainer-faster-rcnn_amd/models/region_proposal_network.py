@@ -63,10 +63,11 @@ class RegionProposalNetwork(object):
         if gt_boxes is not None:
             assert gt_boxes.shape[0] == 1 and gt_boxes.shape[2] == 5 and kind(gt_boxes) == 'f'
 
-    def heads(self, x, want_score=True, timer=None):
-        """(h, rpn_cls_score, rpn_cls_prob, rpn_bbox_pred) -- region_proposal_network.py:117-120."""
+    def heads(self, x, want_score=True, timer=None, x_bf16=None):
+        """(h, rpn_cls_score, rpn_cls_prob, rpn_bbox_pred) -- region_proposal_network.py:117-120.  x_bf16: the same map as the
+        channel-blocked bf16 array the bf16 trunk produced (skips re-converting the fp32 copy)."""
         if self.conv_dtype == "bf16":
-            return self._heads_bf16_path(self.rt.asarray(unwrap(x), "f32"), timer)
+            return self._heads_bf16_path(self.rt.asarray(unwrap(x), "f32"), timer, x_bf16)
         h = self.rpn_conv_3x3(self.rt.asarray(unwrap(x), "f32"), relu=True)
         if timer:
             timer.mark("rpn_conv_3x3")
@@ -75,11 +76,11 @@ class RegionProposalNetwork(object):
             timer.mark("rpn_heads")
         return h, score, prob, bbox
 
-    def _heads_bf16_path(self, x, timer):
+    def _heads_bf16_path(self, x, timer, x_bf16=None):
         """x = fp32 NCHW feature map whose values are bf16-representable (it came out of the bf16 trunk): back to channel-last
         bf16 (exact), rpn_conv_3x3 in bf16, both heads as one bf16 1x1 convolution writing fp32 NCHW, softmax in fp32."""
         rt, A = self.rt, self.n_anchors
-        h = self.rpn_conv_3x3.bf16(rt.bf16_from_nchw(x), relu=True)
+        h = self.rpn_conv_3x3.bf16(x_bf16 if x_bf16 is not None else rt.bf16_from_nchw(x), relu=True)
         if timer:
             timer.mark("rpn_conv_3x3")
         wb, bb = self._heads_bf16

@@ -112,6 +112,7 @@ class VGG16Prev(object):
                 cout = l[2]
                 if timer:
                     timer.mark(l[0])
+        self.feat_bf16 = h                   # the channel-blocked bf16 map itself: the RPN's bf16 conv takes it as is
         feat = rt.bf16_to_nchw(h, cout)
         if timer:
             timer.mark("to_nchw")
