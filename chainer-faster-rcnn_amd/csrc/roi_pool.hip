@@ -242,7 +242,16 @@ __device__ __forceinline__ void roi_scan_lane(const float *pc, int ws, int bw, i
     }
 }
 
-template <bool ARGMAX>
+__device__ __forceinline__ uint32_t roi_f32_to_bf16(float f) {          // round to nearest even, the bf16 stack's conversion
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+
+// OUT16: y is raw bf16 (uint16) -- what the bf16 FC head consumes; pooling itself stays fp32 (a max of fp32 values, then ONE rounding:
+// the same bits as pooling to fp32 and converting afterwards, without the 30 MB fp32 round trip)
+template <bool ARGMAX, bool OUT16 = false>
 __global__ void __launch_bounds__(64 * kPlaneWaves)
 roi_pool_planes_kernel(const float *__restrict__ x, int C, int H, int W, const float *__restrict__ rois, int roi_cols, int R,
                        int outh, int outw, float scale, float *__restrict__ y, int32_t *__restrict__ argmax, int CG,
@@ -337,7 +346,20 @@ roi_pool_planes_kernel(const float *__restrict__ x, int C, int H, int W, const f
         frcnn_wave_sync();     // the wave's own LDS writes above are read by other lanes below (DS ops of a wave are in order)
         // ---- (r, c0 .. c0 + cg, :, :) is one contiguous run of cg*bins floats of y
         const size_t dst = ((size_t)(g0 + rl * ng) * C + c0) * bins;
-        if ((run & 3) == 0 && (dst & 3) == 0) {
+        if constexpr (OUT16) {
+            uint16_t *y16 = reinterpret_cast<uint16_t *>(y);
+            if ((run & 3) == 0 && (dst & 3) == 0) {
+                for (int i = lane; i < run / 4; i += 64) {
+                    const float4 v = reinterpret_cast<const float4 *>(sv)[i];
+                    uint2 pk;
+                    pk.x = roi_f32_to_bf16(v.x) | (roi_f32_to_bf16(v.y) << 16);
+                    pk.y = roi_f32_to_bf16(v.z) | (roi_f32_to_bf16(v.w) << 16);
+                    reinterpret_cast<uint2 *>(y16 + dst)[i] = pk;
+                }
+            } else {
+                for (int i = lane; i < run; i += 64) y16[dst + i] = (uint16_t)roi_f32_to_bf16(sv[i]);
+            }
+        } else if ((run & 3) == 0 && (dst & 3) == 0) {
             for (int i = lane; i < run / 4; i += 64) {
                 reinterpret_cast<float4 *>(y + dst)[i] = reinterpret_cast<const float4 *>(sv)[i];
                 if (ARGMAX) reinterpret_cast<int4 *>(argmax + dst)[i] = reinterpret_cast<const int4 *>(si)[i];
@@ -443,6 +465,28 @@ int frcnn_roi_pool_fwd_chw(const float *x, int C, int H, int W, const float *roi
     const dim3 grid(cgroups, rgroups), blk(64 * kPlaneWaves);
     if (argmax) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_planes_kernel<true>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, spatial_scale, y, argmax, cg, per_block);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_planes_kernel<false>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, spatial_scale, y, argmax, cg, per_block);
+    return frcnn_launch_status();
+}
+
+int frcnn_roi_pool_fwd_chw_bf16(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
+                                float spatial_scale, uint16_t *y, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !rois || !y || C < 1 || H < 1 || W < 1 || R < 0) return FRCNN_ERR_INVALID;
+    if (outh < 1 || outw < 1 || outh > 7 || outw > 7 || (roi_cols != 4 && roi_cols != 5)) return FRCNN_ERR_INVALID;
+    if (R == 0) return FRCNN_OK;
+    const int cg = roi_planes_per_group(C, H, W, outh, outw);
+    if (cg == 0) return FRCNN_ERR_INVALID;          // plane-resident kernel only: convert an fp32 result with frcnn_f32_to_bf16 instead
+    const int cgroups = frcnn_cdiv(C, cg);
+    int rgroups = frcnn_cdiv(frcnn_roi_cu_count(), cgroups);
+    const int max_rgroups = frcnn_cdiv(R, kPlaneWaves);
+    if (rgroups > max_rgroups) rgroups = max_rgroups;
+    if (rgroups < frcnn_cdiv(R, kMaxRoisPerBlock)) rgroups = frcnn_cdiv(R, kMaxRoisPerBlock);
+    if (rgroups < 1) rgroups = 1;
+    if (rgroups > R) rgroups = R;
+    const int per_block = frcnn_cdiv(R, rgroups);
+    const dim3 grid(cgroups, rgroups), blk(64 * kPlaneWaves);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_planes_kernel<false, true>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw,
+                       spatial_scale, reinterpret_cast<float *>(y), (int32_t *)nullptr, cg, per_block);
     return frcnn_launch_status();
 }
 

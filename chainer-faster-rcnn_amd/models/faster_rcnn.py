@@ -139,10 +139,17 @@ class FasterRCNN(object):
         _, score, prob, bbox = self.RPN.heads(feat, want_score=False, timer=timer, x_bf16=x_bf16)
         rois, probs, n_out = self.RPN.proposal_layer.forward_device(prob, bbox, im_h, im_w)
         mark("proposals")
-        pool5 = rt.roi_pool_fwd_chw(feat, rois, 7, 7, self._spatial_scale)    # rois (R,4): concat (:123-124) folded in
+        if self.head_dtype == "bf16" and not keep:
+            pool5 = rt.roi_pool_fwd_chw_bf16(feat, rois, 7, 7, self._spatial_scale)       # pooled in fp32, stored as bf16 bits
+            pool5_bits = pool5
+        else:
+            pool5 = rt.roi_pool_fwd_chw(feat, rois, 7, 7, self._spatial_scale)    # rois (R,4): concat (:123-124) folded in
+            pool5_bits = None
         mark("roi_pool")
         if self.head_dtype == "bf16":
-            fc6 = self.fc6.bf16(rt.to_bf16(pool5.reshape(int(pool5.shape[0]), -1)), relu=True, out_bf16=True)
+            if pool5_bits is None:
+                pool5_bits = rt.to_bf16(pool5.reshape(int(pool5.shape[0]), -1))
+            fc6 = self.fc6.bf16(pool5_bits, relu=True, out_bf16=True)
             mark("fc6")
             fc7 = self.fc7.bf16(fc6, relu=True, out_bf16=True)
             mark("fc7")

@@ -173,6 +173,16 @@ class Runtime(object):
                                             m.ptr(y), m.ptr(am), m.ptr(ws), ws.shape[0], m.stream()), "frcnn_roi_pool_fwd_chw")
         return (y, am) if want_argmax else y
 
+    def roi_pool_fwd_chw_bf16(self, x, rois, outh, outw, scale):
+        """The same pooling with the result written as raw bf16 bits, flattened (R, C*outh*outw): the bf16 FC head's input."""
+        m, L = self.mem, self.lib
+        C, H, W = [int(v) for v in x.shape[-3:]]
+        R = int(rois.shape[0])
+        y = m.empty((R, C * outh * outw), "i16")
+        _lib.check(L.frcnn_roi_pool_fwd_chw_bf16(m.ptr(x), C, H, W, m.ptr(rois), R, int(rois.shape[1]), outh, outw, float(scale),
+                                                 m.ptr(y), m.stream()), "frcnn_roi_pool_fwd_chw_bf16")
+        return y
+
     def chw_to_hwc(self, x):
         m, L = self.mem, self.lib
         C, H, W = [int(v) for v in x.shape[-3:]]

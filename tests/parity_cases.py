@@ -136,6 +136,10 @@ def check_roi_pool(rt, R=12, C=128, H=38, W=63, seed=0):
     assert np.array_equal(host(rt, y2), want_y)
     y3 = rt.roi_pool_fwd_chw(dev(rt, x[0]), dev(rt, np.ascontiguousarray(rois[:, 1:])), 7, 7, 0.0625)   # bare (R,4) rois
     assert np.array_equal(host(rt, y3), want_y)
+    if hasattr(rt, "roi_pool_fwd_chw_bf16") and C >= 8 and W <= 64:                # bf16-output form: ONE rounding of the fp32 maximum
+        _, want_bits = to_bf16(want_y.reshape(R, -1))
+        y5 = host(rt, rt.roi_pool_fwd_chw_bf16(dev(rt, x[0]), dev(rt, np.ascontiguousarray(rois[:, 1:])), 7, 7, 0.0625))
+        assert np.array_equal(y5.view(np.uint16), want_bits.view(np.uint16).reshape(y5.shape))
     xt = rt.chw_to_hwc(dev(rt, x[0]))                                          # channel-last gather kernel (any map size)
     y4, am4 = rt.roi_pool_fwd_hwc(xt, C, H, W, dev(rt, rois), 7, 7, 0.0625, want_argmax=True)
     assert np.array_equal(host(rt, y4), want_y) and np.array_equal(host(rt, am4), want_am)
