@@ -125,7 +125,7 @@ class FasterRCNN(object):
             assert gt_boxes.shape[0] == 1 and gt_boxes.shape[1] > 0 and gt_boxes.shape[2] == 5
             assert kind(gt_boxes) == 'f' and is_variable(gt_boxes)
 
-    def forward_device(self, x, im_h, im_w, keep=False, timer=None):
+    def forward_device(self, x, im_h, im_w, keep=False, timer=None, collect=None):
         """Sync-free inference.  Returns dict(cls_prob (R,ncls), pred_boxes (R,4*ncls), rois (R,4), probs (R,),
         n_out (1,) int32) -- all device arrays, R = post_nms_top_n; rows >= n_out are padding.
         `timer.mark(name)` (optional) is called after every stage: bench.py records a HIP event there."""
@@ -133,11 +133,14 @@ class FasterRCNN(object):
         if getattr(self, "_head_dirty", True):
             self._stack_head()
         mark = timer.mark if timer else (lambda name: None)
-        feat = self.trunk(x, timer=timer)
+        feat = self.trunk(x, timer=timer, collect=collect) if collect is not None else self.trunk(x, timer=timer)
         C, H, W = [int(v) for v in feat.shape[1:]]
         x_bf16 = getattr(self.trunk, "feat_bf16", None) if self.conv_dtype == "bf16" else None
-        _, score, prob, bbox = self.RPN.heads(feat, want_score=False, timer=timer, x_bf16=x_bf16)
-        rois, probs, n_out = self.RPN.proposal_layer.forward_device(prob, bbox, im_h, im_w)
+        rpn_h, score, prob, bbox = self.RPN.heads(feat, want_score=False, timer=timer, x_bf16=x_bf16)
+        if keep:
+            rois, probs, n_out, src_index = self.RPN.proposal_layer.forward_device(prob, bbox, im_h, im_w, want_index=True)
+        else:
+            rois, probs, n_out = self.RPN.proposal_layer.forward_device(prob, bbox, im_h, im_w)
         mark("proposals")
         if self.head_dtype == "bf16" and not keep:
             pool5 = rt.roi_pool_fwd_chw_bf16(feat, rois, 7, 7, self._spatial_scale)       # pooled in fp32, stored as bf16 bits
@@ -165,7 +168,7 @@ class FasterRCNN(object):
         out = dict(cls_prob=cls_prob, pred_boxes=pred_boxes, rois=rois, probs=probs, n_out=n_out)
         if keep:
             ncls, d0 = self._num_classes, self._head_dcol
-            out.update(feat=feat, rpn_cls_prob=prob, rpn_bbox_pred=bbox, pool5=pool5, fc6=fc6, fc7=fc7,
+            out.update(feat=feat, rpn_h=rpn_h, rpn_cls_prob=prob, rpn_bbox_pred=bbox, src_index=src_index, pool5=pool5, fc6=fc6, fc7=fc7,
                        cls_score=rt.mem.from_numpy(np.ascontiguousarray(rt.mem.to_numpy(head)[:, :ncls])),
                        bbox_pred=rt.mem.from_numpy(np.ascontiguousarray(rt.mem.to_numpy(head)[:, d0:d0 + 4 * ncls])))
         return out

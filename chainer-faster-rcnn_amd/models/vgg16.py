@@ -66,12 +66,14 @@ class VGG16Prev(object):
             yield prefix + name + "/W", link.W
             yield prefix + name + "/b", link.b
 
-    def __call__(self, x, timer=None):
+    def __call__(self, x, timer=None, collect=None):
+        """`collect` (a dict, optional) receives every launch's output under the layer's name -- `pool<n>` for a convolution
+        whose ReLU + max-pool ran fused (the pre-pool map never exists then); the full-size parity tests read it."""
         rt = self.rt
         h = rt.asarray(unwrap(x), "f32")
         assert h.ndim == 4 and int(h.shape[0]) == 1, "batch size 1 (models/faster_rcnn.py:77)"
         if self.conv_dtype == "bf16":
-            return self._call_bf16(h, timer)
+            return self._call_bf16(h, timer, collect)
         n_pool, skip = 0, False
         for idx, l in enumerate(self.layers):
             if l == "pool":
@@ -82,16 +84,20 @@ class VGG16Prev(object):
                 h = rt.maxpool2x2(h)
                 if timer:
                     timer.mark("pool%d" % n_pool)
+                if collect is not None:
+                    collect["pool%d" % n_pool] = h
             else:
                 fuse = self.fuse_pool and idx + 1 < len(self.layers) and self.layers[idx + 1] == "pool" and l[2] % 64 == 0
                 h = self.links[l[0]].relu_pool(h) if fuse else self.links[l[0]](h, relu=True)
                 skip = fuse
                 if timer:
                     timer.mark(l[0])
+                if collect is not None:
+                    collect["pool%d" % (n_pool + 1) if fuse else l[0]] = h
         return h
 
 
-    def _call_bf16(self, x, timer):
+    def _call_bf16(self, x, timer, collect=None):
         """bf16 chain: fp32 NCHW image -> channel-blocked bf16 -> 13 bf16 convs / 4 pools -> conv5_3 back as fp32 NCHW."""
         rt = self.rt
         h = rt.bf16_from_nchw(x)
@@ -105,6 +111,8 @@ class VGG16Prev(object):
                 h = rt.maxpool2x2_bf16(h)
                 if timer:
                     timer.mark("pool%d" % n_pool)
+                if collect is not None:
+                    collect["pool%d" % n_pool] = (h, cout)
             else:
                 fuse = self.fuse_pool and idx + 1 < len(self.layers) and self.layers[idx + 1] == "pool"
                 h = self.links[l[0]].bf16(h, relu=True, pool=fuse)
@@ -112,6 +120,8 @@ class VGG16Prev(object):
                 cout = l[2]
                 if timer:
                     timer.mark(l[0])
+                if collect is not None:                      # channel-blocked bf16 arrays: (array, channels)
+                    collect["pool%d" % (n_pool + 1) if fuse else l[0]] = (h, cout)
         self.feat_bf16 = h                   # the channel-blocked bf16 map itself: the RPN's bf16 conv takes it as is
         feat = rt.bf16_to_nchw(h, cout)
         if timer:

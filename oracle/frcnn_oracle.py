@@ -105,6 +105,9 @@ def bbox_transform(ex_rois, gt_rois):
     return np.stack([(gcx - ecx) / ew, (gcy - ecy) / eh, np.log(gw / ew), np.log(gh / eh)], axis=1)
 
 
+EXP = np.exp      # tests/test_coord_margins.py swaps this for an exp perturbed by +-k ulp (how far are the decisions from flipping?)
+
+
 def bbox_transform_inv(boxes, trans):
     """models/bbox_transform.py:41-76.  Separate multiply and add (no FMA), np.exp in the input dtype,
     no clamp on dw/dh; generic over trans (N, 4*C)."""
@@ -117,8 +120,8 @@ def bbox_transform_inv(boxes, trans):
     dx, dy, dw, dh = trans[:, 0::4], trans[:, 1::4], trans[:, 2::4], trans[:, 3::4]
     pcx = dx * widths[:, None] + ctr_x[:, None]
     pcy = dy * heights[:, None] + ctr_y[:, None]
-    pw = np.exp(dw) * widths[:, None]
-    ph = np.exp(dh) * heights[:, None]
+    pw = EXP(dw) * widths[:, None]
+    ph = EXP(dh) * heights[:, None]
     out = np.zeros(trans.shape, dtype=trans.dtype)
     out[:, 0::4] = pcx - 0.5 * pw
     out[:, 1::4] = pcy - 0.5 * ph
@@ -411,13 +414,20 @@ def softmax(x, axis=1):
     return (e / e.sum(axis=axis, keepdims=True)).astype(x.dtype)
 
 
-def vgg16_trunk(p, x, upto=None):
-    """models/vgg16.py:74-82 (VGG16Prev): conv1_1 ... relu5_3, no pool5."""
+def vgg16_trunk(p, x, upto=None, collect=None):
+    """models/vgg16.py:74-82 (VGG16Prev): conv1_1 ... relu5_3, no pool5.  `collect` (a dict) receives every layer's output:
+    collect["conv3_2"] = relu3_2, collect["pool3"] = the map after the third F.MaxPooling2D."""
+    n_pool = 0
     for l in VGG16_LAYERS:
         if l == "pool":
             x = max_pool_2x2(x)
+            n_pool += 1
+            if collect is not None:
+                collect["pool%d" % n_pool] = x
         else:
             x = relu(conv2d(x, p["trunk/%s/W" % l[0]], p["trunk/%s/b" % l[0]], 1))
+            if collect is not None:
+                collect[l[0]] = x
             if upto == l[0]:
                 break
     return x
@@ -450,15 +460,18 @@ def rcnn_head(p, pool5, proposals, img_info):
 
 def faster_rcnn_forward(p, x, img_info, return_debug=False):
     """models/faster_rcnn.py:111-134,175-178 inference path end to end."""
-    feat = vgg16_trunk(p, x)
+    layers = {} if return_debug == "layers" else None
+    feat = vgg16_trunk(p, x, collect=layers)
     h, score, prob, bbox = rpn_head(p, feat)
-    proposals, probs = proposal_layer(prob, bbox, img_info, train=False)
+    proposals, probs, pdbg = proposal_layer(prob, bbox, img_info, train=False, return_debug=True)
     brois = np.concatenate((np.zeros((len(proposals), 1), np.float32), proposals), axis=1)  # :123-124
     pool5 = roi_pooling_2d(feat, brois, 7, 7, 1.0 / 16)
     cls_prob, pred_boxes, dbg = rcnn_head(p, pool5, proposals, img_info)
     if return_debug:
         dbg.update(feat=feat, rpn_h=h, rpn_cls_score=score, rpn_cls_prob=prob, rpn_bbox_pred=bbox,
-                   proposals=proposals, probs=probs, pool5=pool5)
+                   proposals=proposals, probs=probs, pool5=pool5, proposal_debug=pdbg)
+        if layers is not None:
+            dbg["layers"] = layers
         return cls_prob, pred_boxes, dbg
     return cls_prob, pred_boxes
 
