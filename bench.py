@@ -2,18 +2,22 @@
 """Benchmark of the Faster R-CNN hot path on MI355X (BASELINE.json metric: images/sec, VGG16, 600x1000).
 
   python bench.py --gpus N --steps K --warmup W
-N>1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`.
+N>1: the driver launches `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`; a plain
+`python bench.py --gpus N` re-launches itself that way (one rank per GPU; with fewer GPUs than ranks the ranks share GPUs over
+gloo -- a functional smoke of the N>1 path, said so in the line).
 
 A "step" = one full inference forward of one synthetic 600x1000 image per GPU (trunk -> RPN -> proposals ->
 NMS -> RoI pooling -> FC head -> decode), inputs and weights resident in HBM before the timed region.
 Workload = BASELINE.json configs[1]: "VGG16 inference, 1xMI355X, batch 1, 300 proposals post-NMS, fp32".
 Images shard one per GPU with no collective on the data path (weak scaling).
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel family (the fp32 MFMA conv3x3: 14
-launches per image) -- algorithmic FLOPs / HIP-event time measured inside the timed region on the launch
-stream -- against the dense fp32 MFMA peak (157.3 TFLOP/s, MI355X_MICROARCH.md).  `cpu_baseline` times the
-CPU oracle (oracle/frcnn_oracle.py: torch-CPU convs + the reference's proposal/NMS/RoI arithmetic) on this
-box's host cores on a bounded sample of the same workload.
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel family (the MFMA conv3x3: 14 launches per image) --
+algorithmic FLOPs / HIP-event time of a hipGraph holding exactly those launches, on the launch stream -- against the dense MFMA
+peak of the dtype (MI355X_MICROARCH.md).  `nms_roi` prices RoI pooling against the HBM peak and reports proposals+NMS us/img, both
+from hipGraphs of back-to-back launches (kernel time only) next to the in-pipeline stage events.  `cpu_baseline` times the CPU
+path of forward.py on this box's host cores per SURVEY 8(d): torch-CPU fp32 convs/linears (stand-in for Chainer's CPU im2col+GEMM),
+the reference's own compiled cpu_nms (oracle/_ref) inside the pinned NumPy restatement of proposal_layer.py, the C restatement of
+Chainer's RoI pooling; per-stage ms, median of >= 5 images.  `parity` compares the device forward with that very oracle forward.
 """
 import argparse
 import json
@@ -30,6 +34,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: Peak BF16 MFMA, dense
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak BW (spec)
 IM_H, IM_W = 600, 1000
+DEFAULT_STEPS = 250               # ~1 s of timed region at 3.9 ms / step: long enough for an outside observer (rocm-smi) to see it
 
 
 class EventTimer(object):
@@ -67,14 +72,19 @@ def pmc_traffic(dtype):
     """HBM bytes per conv launch from the committed PMC passes of this same command (scripts/gpu_traffic.sh: FETCH_SIZE and
     WRITE_SIZE in separate rocprofv3 --pmc runs); counters cannot be read from inside the process, so the bench line carries
     the last measured figure and names its source, or null when no PMC pass exists for this dtype."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_hbm_traffic_pmc.json")
-    if dtype != "f32" or not os.path.exists(path):
-        return None, None
-    try:
-        s = json.load(open(path))["_summary"]["conv_mfma_f32_kernel"]
-        return s["hbm_bytes_per_launch"], "profiles/r01_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)"
-    except (KeyError, ValueError):
-        return None, None
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    cands = (["r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"] if dtype == "f32" else ["r02_hbm_traffic_pmc_bf16.json"])
+    kernel = "conv_mfma_f32_kernel" if dtype == "f32" else "conv_bf16_kernel"
+    for name in cands:
+        path = os.path.join(prof, name)
+        if not os.path.exists(path):
+            continue
+        try:
+            s = json.load(open(path))["_summary"][kernel]
+            return s["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % name
+        except (KeyError, ValueError):
+            continue
+    return None, None
 
 
 def conv_algorithmic_bytes(model_layers, h, w, esize=4):
@@ -108,10 +118,19 @@ def conv_flops(model_layers, h, w):
 
 
 def cpu_baseline(params, x, samples):
+    """forward.py's CPU path on this box (SURVEY 8(d) / BASELINE.md 4): warm-up 2, then `samples` (>= 5) full 600x1000 images,
+    per-stage medians.  Returns (the bench-line object, the oracle's debug dict of the LAST image for the parity block)."""
     import torch
     from oracle import frcnn_oracle as O
     info = np.array([[IM_H, IM_W]], dtype=np.int32)
     O.build_c()
+    nms_fn, nms_kind = None, "C restatement of models/cpu_nms.pyx (oracle/c/frcnn_oracle.c)"
+    try:
+        from oracle import ref_harness
+        nms_fn = ref_harness.native("cpu_nms").cpu_nms
+        nms_kind = "the reference's own models/cpu_nms.pyx, compiled in place into oracle/_ref (single-threaded, as in the reference)"
+    except Exception as e:                                          # oracle/_ref absent: the restatement is the baseline, and says so
+        print("oracle/_ref cpu_nms not loadable (%s): timing the C restatement" % (e,), file=sys.stderr)
     # batch-1 convs do not scale to hundreds of threads: pick the thread count that is fastest on one mid-size
     # layer (conv3_2 at 150x250) and report it as `cores`
     xs = np.random.RandomState(0).randn(1, 256, 150, 250).astype(np.float32)
@@ -127,23 +146,84 @@ def cpu_baseline(params, x, samples):
         if best is None or dt < best[0]:
             best = (dt, nt)
     torch.set_num_threads(best[1])
-    O.faster_rcnn_forward(params, x, info)                      # warm-up (thread pools, page faults)
-    t0 = time.perf_counter()
-    for _ in range(samples):
-        O.faster_rcnn_forward(params, x, info)
-    dt = (time.perf_counter() - t0) / samples
-    return {"value": 1.0 / dt, "unit": "img/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d full 600x1000 forwards after 1 warm-up (oracle: torch-CPU fp32 convs/linears on all cores, "
-                      "single-threaded C restatement of the reference's proposal/NMS/RoI code)" % samples,
-            "ms_per_image": dt * 1e3}
+    samples = max(int(samples), 5)
+    stages, totals, dbg = {}, [], None
+    for it in range(2 + samples):
+        st = {}
+        t0 = time.perf_counter()
+        layers = {}
+        feat = O.vgg16_trunk(params, x, collect=layers)
+        t1 = time.perf_counter()
+        h, score, prob, bbox = O.rpn_head(params, feat)
+        t2 = time.perf_counter()
+        pt = {}
+        proposals, probs, pdbg = O.proposal_layer(prob, bbox, info, train=False, return_debug=True, nms_fn=nms_fn, stage_times=pt)
+        t3 = time.perf_counter()
+        brois = np.concatenate((np.zeros((len(proposals), 1), np.float32), proposals), axis=1)
+        pool5 = O.roi_pooling_2d(feat, brois, 7, 7, 1.0 / 16)
+        t4 = time.perf_counter()
+        cls_prob, pred_boxes, hd = O.rcnn_head(params, pool5, proposals, info)
+        t5 = time.perf_counter()
+        if it < 2:
+            continue
+        st = {"trunk": t1 - t0, "rpn_head": t2 - t1, "proposals_decode_sort": pt["decode_sort"], "nms": pt["nms"],
+              "roi_pool": t4 - t3, "head": t5 - t4}
+        for k, v in st.items():
+            stages.setdefault(k, []).append(v * 1e3)
+        totals.append(t5 - t0)
+        dbg = dict(hd, feat=feat, rpn_h=h, rpn_cls_score=score, rpn_cls_prob=prob, rpn_bbox_pred=bbox, proposals=proposals, probs=probs,
+                   pool5=pool5, proposal_debug=pdbg, layers=layers)
+    med = float(np.median(totals))
+    res = {"value": 1.0 / med, "unit": "img/s", "cores": torch.get_num_threads(),
+           "kind": "reference-native" if nms_fn is not None else "port",
+           "sample": "%d full 600x1000 forwards after 2 warm-ups, median; torch-CPU fp32 convs/linears on `cores` threads (stand-in for Chainer's "
+                     "CPU im2col+GEMM), the pinned NumPy restatement of proposal_layer.py, NMS = %s, C restatement of Chainer's RoI pooling"
+                     % (samples, nms_kind),
+           "ms_per_image": med * 1e3, "stages_ms": {k: round(float(np.median(v)), 3) for k, v in stages.items()}}
+    return res, dbg
 
 
-def train_mode(args, torch, dist, rt, model, x, rank, world, barrier):
-    """BASELINE.json configs[4]: train_rpn.py's step -- forward, anchor targets, losses, backward, the all-reduce of the
-    flat gradient buffer (RCCL), fused MomentumSGD+WD -- one synthetic VOC-shaped image per GPU per step."""
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: become `torch.distributed.run --nproc-per-node N bench.py ...`."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def graph_time_us(torch, fn, launches_per_replay, replays):
+    """Average duration of ONE launch sequence `fn` (it must enqueue `launches_per_replay` repetitions): HIP events on the launch
+    stream around `replays` replays of a hipGraph holding them -- kernel time only, no host in the interval."""
+    fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        fn()
+    for _ in range(2):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(replays):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (replays * launches_per_replay)
+
+
+def train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note):
+    """BASELINE.json configs[4]: train_rpn.py's step -- forward, ProposalLayer (train top-N, discarded, as the reference runs it),
+    anchor targets, losses, backward, the all-reduce of the flat gradient buffer (RCCL), fused MomentumSGD+WD -- one synthetic
+    VOC-shaped image per GPU per step."""
     from chainer_faster_rcnn_amd.train import RPNTrainer, TorchComm
     model.rpn_train = True
-    tr = RPNTrainer(model, comm=TorchComm() if dist is not None else None)
+    tr = RPNTrainer(model, comm=TorchComm() if dist is not None else None, run_proposal_layer=not args.no_train_proposals)
     rs = np.random.RandomState(rank)
     G = 4
     w, h = rs.uniform(32, 400, G), rs.uniform(32, 400, G)
@@ -178,6 +258,18 @@ def train_mode(args, torch, dist, rt, model, x, rank, world, barrier):
         mark("update")
     barrier()
     dt = time.perf_counter() - t0
+    # the same K steps without the (discarded) ProposalLayer launch sequence, for the record
+    other_ms = None
+    if not args.no_train_proposals:
+        tr.run_proposal_layer = False
+        for _ in range(2):
+            tr.step(x, info, gt_dev)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            tr.step(x, info, gt_dev)
+        barrier()
+        other_ms = (time.perf_counter() - t1) / args.steps * 1e3
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -190,7 +282,9 @@ def train_mode(args, torch, dist, rt, model, x, rank, world, barrier):
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": "train_rpn.py end-to-end RPN training step, 1 image per GPU, all-reduce of the flat fp32 gradient "
                                                  "buffer in 3 buckets overlapped with the backward pass (BASELINE.json configs[4])",
-                                     "grad_buffer_mb": tr.n_flat * 4 / 1e6, "global_batch": world},
+                                     "proposal_layer_in_step": (not args.no_train_proposals),
+                                     "grad_buffer_mb": tr.n_flat * 4 / 1e6, "global_batch": world, "ranks_share_gpus": shared_note},
+                          "ms_per_step_without_proposal_layer": other_ms,
                           "stages_ms": st, "losses": tr.losses_host(out)}))
     if dist is not None:
         dist.barrier()
@@ -200,12 +294,14 @@ def train_mode(args, torch, dist, rt, model, x, rank, world, barrier):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default %d for inference, 40 for --mode train)" % DEFAULT_STEPS)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--ramp-seconds", type=float, default=1.0, help="untimed clock-ramp preamble before the warm-up steps")
-    ap.add_argument("--cpu-samples", type=int, default=3)
+    ap.add_argument("--cpu-samples", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true")
+    ap.add_argument("--no-train-proposals", action="store_true",
+                    help="--mode train: skip the ProposalLayer(12000/2000) launch sequence the reference runs and discards in every RPN step")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the forward as ONE captured hipGraph in the timed region (auto = on: the ~45 launches of a bf16 step are "
                          "shorter than the host can issue them, and the f32 step, GPU-bound in eager mode on a quiet host, lost up to "
@@ -215,17 +311,27 @@ def main():
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = BASELINE.json configs[1] (the contract line); train = configs[4], the RPN training step")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = DEFAULT_STEPS if args.mode == "infer" else 40
 
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        self_launch(args)
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    # one rank per GPU; FRCNN_DIST_BACKEND=gloo + fewer GPUs than ranks is the functional smoke test of the N > 1 path on a 1-GPU box
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # one rank per GPU.  Fewer GPUs than ranks (a 1-GPU box): the ranks share GPUs and talk over gloo -- RCCL refuses two ranks on one
+    # device -- which exercises the N>1 code path (sharding, barriers, bucketed all-reduce) but is NOT a scaling measurement.
     backend = os.environ.get("FRCNN_DIST_BACKEND", "nccl")
+    n_dev = max(torch.cuda.device_count(), 1)
+    shared_note = None
+    if world > n_dev:
+        backend = "gloo"
+        shared_note = "%d ranks on %d GPU(s), gloo: functional smoke of the N>1 path, not a scaling number" % (world, n_dev)
     if backend != "nccl":
-        local_rank %= max(torch.cuda.device_count(), 1)
+        local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -254,7 +360,7 @@ def main():
         torch.cuda.synchronize()
 
     if args.mode == "train":
-        return train_mode(args, torch, dist, rt, model, x, rank, world, barrier)
+        return train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note)
 
     use_graph = args.graph in ("on", "auto")
     # Untimed preamble before the W warm-up steps: the first forwards of a process run at idle clocks (DVFS needs a few hundred
@@ -271,7 +377,7 @@ def main():
         # Stage events come from an eager pass (they cannot be read out of a replayed graph); the TIMED region below is
         # K replays of one captured hipGraph of the whole forward: no Python, no per-launch host cost inside it.
         if timer:
-            for _ in range(max(3, args.steps // 3)):
+            for _ in range(min(20, max(3, args.steps // 3))):
                 timer.begin()
                 model.forward_device(x, IM_H, IM_W, timer=timer)
                 timer.end()
@@ -305,28 +411,51 @@ def main():
         dt = time.perf_counter() - t0
     n_rois = int(out["n_out"].cpu()[0])
     # roofline of the dominant kernel: the 14 conv launches (13 trunk convs with their fused pools + rpn_conv_3x3) as their own
-    # hipGraph, K replays bracketed by HIP events on the launch stream -- kernel time only, whatever the host is doing
-    conv_chain_ms = None
-    if rank == 0 and args.dtype == "f32" and args.graph != "off" and not args.no_stage_events:
+    # hipGraph, replays bracketed by HIP events on the launch stream -- kernel time only, whatever the host is doing
+    conv_chain_ms, iso = None, {}
+    iso_replays = max(args.steps, 100)
+    if rank == 0 and args.graph != "off" and not args.no_stage_events:
         try:
-            def conv_chain():
-                return model.RPN.rpn_conv_3x3(model.trunk(x), relu=True)
-            conv_chain()
-            torch.cuda.synchronize()
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2, capture_error_mode="thread_local"):
-                conv_chain()
-            for _ in range(3):
-                g2.replay()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(args.steps):
-                g2.replay()
-            e1.record()
-            torch.cuda.synchronize()
-            conv_chain_ms = e0.elapsed_time(e1) / args.steps
+            if args.dtype == "f32":
+                def conv_chain():
+                    return model.RPN.rpn_conv_3x3(model.trunk(x), relu=True)
+            else:
+                xb = rt.bf16_from_nchw(x)                      # the fp32 -> bf16 image conversion and the final bf16 -> fp32 copy are not convs
+
+                def conv_chain():
+                    tr_ = model.trunk
+                    h, n_l = xb, len(tr_.layers)
+                    for idx, l in enumerate(tr_.layers):
+                        if l == "pool":
+                            continue
+                        h = tr_.links[l[0]].bf16(h, relu=True, pool=(idx + 1 < n_l and tr_.layers[idx + 1] == "pool"))
+                    return model.RPN.rpn_conv_3x3.bf16(h, relu=True)
+            conv_chain_ms = graph_time_us(torch, conv_chain, 1, iso_replays) / 1e3
         except Exception as e:
             print("conv-chain graph failed (%s): roofline from the per-stage events" % (e,), file=sys.stderr)
+            torch.cuda.synchronize()
+        # RoI pooling and the proposal pipeline in isolation: 8 back-to-back launches per replay, the RoI outputs rotating over 10 buffers
+        # (301 MB > the 256 MB Infinity Cache, so the writes cannot all be absorbed on-die)
+        try:
+            feat = model.trunk(x)
+            _, _, prob, bbox = model.RPN.heads(feat, want_score=False, x_bf16=getattr(model.trunk, "feat_bf16", None) if args.dtype == "bf16" else None)
+            rois, _, _ = model.RPN.proposal_layer.forward_device(prob, bbox, IM_H, IM_W)
+            outs = [rt.mem.empty((int(rois.shape[0]), 512, 7, 7), "f32") for _ in range(10)]
+            state = {"i": 0}
+
+            def roi_seq():
+                for _ in range(8):
+                    rt.roi_pool_fwd_chw(feat, rois, 7, 7, 1.0 / 16, out=outs[state["i"] % 10])
+                    state["i"] += 1
+            iso["roi_pool_us"] = graph_time_us(torch, roi_seq, 8, max(iso_replays // 4, 25))
+            del outs
+
+            def prop_seq():
+                for _ in range(8):
+                    model.RPN.proposal_layer.forward_device(prob, bbox, IM_H, IM_W)
+            iso["proposals_nms_us"] = graph_time_us(torch, prop_seq, 8, max(iso_replays // 4, 25))
+        except Exception as e:
+            print("isolated RoI / proposal graphs failed (%s)" % (e,), file=sys.stderr)
             torch.cuda.synchronize()
     if dist is not None:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -344,7 +473,7 @@ def main():
                                       ("VGG16 inference, data-parallel 1 img/GPU, bf16 convs + bf16 FC head (fp32 accumulate) / fp32 proposals, "
                                        "RoI pooling, decode (BASELINE.json configs[2])"),
                           "image": "1x3x600x1000", "global_batch": world, "launch": "hipGraph replay" if use_graph else "eager", "parallelism": "dp%d (images sharded, no collective)" % world,
-                          "n_rois_last_step": n_rois}}
+                          "n_rois_last_step": n_rois, "ranks_share_gpus": shared_note}}
         if timer:
             avg = timer.averages_ms()
             flops, (fh, fw) = conv_flops(LAYERS, IM_H, IM_W)
@@ -352,7 +481,7 @@ def main():
             conv_src = "sum of the 14 per-stage HIP-event intervals"
             if conv_chain_ms is not None:
                 conv_ms, conv_src = conv_chain_ms, ("HIP events around %d replays of a hipGraph holding exactly the 14 conv launches (no host "
-                                                    "gaps inside the interval; the per-stage figures below come from eager launches)" % args.steps)
+                                                    "gaps inside the interval; the per-stage figures below come from eager launches)" % iso_replays)
             conv_tf = sum(flops.values()) / (conv_ms * 1e-3) / 1e12
             peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
             traffic, traffic_src = pmc_traffic(args.dtype)
@@ -364,16 +493,30 @@ def main():
             roi_bytes = (512 * fh * fw + 300 * 512 * 49) * 4 + 300 * 16
             res["stages_ms"] = {k: round(v, 4) for k, v in avg.items()}
             res["stage_events"] = {"where": ("HIP events on the launch stream around every stage of %d eager forwards run immediately before the "
-                                             "timed graph replays (events cannot be read out of a replayed graph)" % max(3, args.steps // 3)) if args.graph != "off"
+                                             "timed graph replays (events cannot be read out of a replayed graph)" % len(timer.steps)) if args.graph != "off"
                                    else "HIP events on the launch stream inside the timed region",
                                    "sum_of_stages_ms": round(sum(avg.values()), 4), "timed_ms_per_step": round(ms_per_step, 4)}
             res["per_layer_tflops"] = {k: round(flops[k] / (avg[k] * 1e-3) / 1e12, 2) for k in flops}
-            res["nms_roi"] = {"proposals_nms_us": avg["proposals"] * 1e3, "roi_pool_us": avg["roi_pool"] * 1e3,
+            roi_us = iso.get("roi_pool_us", avg["roi_pool"] * 1e3)
+            res["nms_roi"] = {"proposals_nms_us": iso.get("proposals_nms_us", avg["proposals"] * 1e3), "roi_pool_us": roi_us,
+                              "source": ("HIP events around hipGraphs of 8 back-to-back launches (kernel time; RoI outputs rotate over 10 buffers = 301 MB)"
+                                         if "roi_pool_us" in iso else "per-stage HIP events of eager launches"),
+                              "proposals_nms_us_in_pipeline_stage_event": avg["proposals"] * 1e3,
+                              "roi_pool_us_in_pipeline_stage_event": avg["roi_pool"] * 1e3,
                               "roi_pool_algorithmic_mb": roi_bytes / 1e6,
-                              "roi_pool_gbps": roi_bytes / (avg["roi_pool"] * 1e-3) / 1e9,
-                              "roi_pool_frac_of_hbm_peak": roi_bytes / (avg["roi_pool"] * 1e-3) / 1e9 / PEAK_HBM_GBPS}
+                              "roi_pool_gbps": roi_bytes / (roi_us * 1e-6) / 1e9,
+                              "roi_pool_frac_of_hbm_peak": roi_bytes / (roi_us * 1e-6) / 1e9 / PEAK_HBM_GBPS}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(params, x_host, args.cpu_samples)
+            res["cpu_baseline"], dbg = cpu_baseline(params, x_host, args.cpu_samples)
+            try:
+                from oracle import parity
+                info = np.array([[IM_H, IM_W]], dtype=np.int32)
+                tol = 1e-3 if args.dtype == "f32" else 3e-2
+                rep = parity.compare_forward(params, info, dbg, parity.device_forward_host(rt, model, x, IM_H, IM_W), layer_tol=tol, head_tol=tol)
+                rep["against"] = "the cpu_baseline forward of this run (same image, same weights); /root/reference/forward.py:92-94"
+                res["parity"] = rep
+            except Exception as e:
+                res["parity"] = {"ok": False, "error": repr(e)}
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

@@ -23,6 +23,11 @@ class CapturedForward(object):
         # thread_local: other threads (e.g. a process group's watchdog) may touch the runtime while this one captures
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.out = model.forward_device(self.x, self.im_h, self.im_w)
+        # The graph holds RAW pointers into the runtime's workspaces (conv stream-K counter page and partials, proposal / NMS /
+        # linear scratch).  Runtime.workspace() drops a workspace when a larger one is requested (a bigger image, a training step):
+        # keep every array that existed at capture time alive for the lifetime of this object, so replays never write into
+        # memory the allocator has handed to someone else.
+        self._pinned_workspaces = dict(model.rt._ws)
 
     def replay(self, x=None):
         """Run the captured forward; `x` (same shape) replaces the input first.  Returns the dict of captured output arrays

@@ -25,8 +25,16 @@ class Linear(object):
         self.W = self.b = self.Wb = None
 
     def set(self, W, b):
-        self.W = self.rt.asarray(np.ascontiguousarray(W, dtype=np.float32) if isinstance(W, np.ndarray) else W, "f32")
-        self.b = self.rt.asarray(np.ascontiguousarray(b, dtype=np.float32) if isinstance(b, np.ndarray) else b, "f32")
+        W = self.rt.asarray(np.ascontiguousarray(W, dtype=np.float32) if isinstance(W, np.ndarray) else W, "f32")
+        b = self.rt.asarray(np.ascontiguousarray(b, dtype=np.float32) if isinstance(b, np.ndarray) else b, "f32")
+        if getattr(self, "_adopted", False) and self.W is not None and tuple(self.W.shape) == tuple(W.shape):
+            self.W[...] = W                                # windows of a trainer's flat buffer: write through them (see Conv3x3.set)
+            self.b[...] = b
+        else:
+            self.W, self.b = W, b
+        self.refresh_bf16()
+
+    def refresh_bf16(self):
         if self.dtype == "bf16":
             self.Wb = self.rt.to_bf16(self.W)              # raw bf16 bits, (out, in): K-contiguous for the MFMA B operand
 
@@ -110,9 +118,28 @@ class FasterRCNN(object):
         self.head_out.set(W, b)
         self._head_dirty = False
 
-    def mark_params_updated(self):
-        """The trainers call this after an optimizer update: the stacked inference head is rebuilt on the next inference."""
+    def mark_params_updated(self, trainer=None):
+        """The trainers call this after an optimizer update (and serializers.load_npz after a load): everything DERIVED from the
+        parameters -- the stacked inference head, the bf16 copies of the convolution / RPN-head / FC weights -- is rebuilt on the
+        next inference.  `trainer`: the trainer holding the live packed weights (its sync_params() writes them back to Chainer's
+        layout first)."""
         self._head_dirty = True
+        self._derived_dirty = True
+        if trainer is not None:
+            self._last_trainer = trainer
+
+    def _refresh_derived(self):
+        tr = getattr(self, "_last_trainer", None)
+        if tr is not None:
+            tr.sync_params()                                 # packed training weights -> (co,ci,3,3) / (out,in) arrays on the links
+        if self.conv_dtype == "bf16":
+            for link in getattr(self.trunk, "links", {}).values():
+                link.refresh_bf16()
+            self.RPN.rpn_conv_3x3.refresh_bf16()
+            self.RPN.refresh_heads_bf16()
+        for name in ("fc6", "fc7", "cls_score", "bbox_pred"):
+            getattr(self, name).refresh_bf16()
+        self._derived_dirty = False
 
     def _check_data_type_forward(self, x, img_info, gt_boxes):
         assert x.shape[0] == 1
@@ -130,6 +157,8 @@ class FasterRCNN(object):
         n_out (1,) int32) -- all device arrays, R = post_nms_top_n; rows >= n_out are padding.
         `timer.mark(name)` (optional) is called after every stage: bench.py records a HIP event there."""
         rt = self.rt
+        if getattr(self, "_derived_dirty", False):
+            self._refresh_derived()
         if getattr(self, "_head_dirty", True):
             self._stack_head()
         mark = timer.mark if timer else (lambda name: None)

@@ -46,13 +46,23 @@ class RegionProposalNetwork(object):
             W = np.ascontiguousarray(params[prefix + name + "/W"], dtype=np.float32)
             store["W"] = rt.asarray(W.reshape(W.shape[0], -1), "f32")
             store["b"] = rt.asarray(np.ascontiguousarray(params[prefix + name + "/b"], dtype=np.float32), "f32")
-        self._heads_packed = rt.rpn_heads_pack(self.rpn_cls_score["W"], self.rpn_cls_score["b"],
-                                               self.rpn_bbox_pred["W"], self.rpn_bbox_pred["b"])
-        if self.conv_dtype == "bf16":                   # the two 1x1 heads as ONE bf16 1x1 convolution: cls (2A) rows then bbox (4A) rows
-            W = np.concatenate([np.asarray(params[prefix + n + "/W"], dtype=np.float32).reshape(-1, self.mid_ch)
-                                for n in ("rpn_cls_score", "rpn_bbox_pred")], 0)
-            b = np.concatenate([np.asarray(params[prefix + n + "/b"], dtype=np.float32) for n in ("rpn_cls_score", "rpn_bbox_pred")], 0)
-            self._heads_bf16 = (rt.bf16_pack_conv_w(rt.asarray(np.ascontiguousarray(W[:, :, None, None]), "f32"), 1), rt.asarray(b, "f32"))
+        packed = rt.rpn_heads_pack(self.rpn_cls_score["W"], self.rpn_cls_score["b"], self.rpn_bbox_pred["W"], self.rpn_bbox_pred["b"])
+        if getattr(self, "_heads_adopted", False):      # windows of a trainer's flat parameter buffer: write through them
+            self._heads_packed[0][...] = packed[0]
+            self._heads_packed[1][...] = packed[1]
+        else:
+            self._heads_packed = packed
+        self.refresh_heads_bf16()
+
+    def refresh_heads_bf16(self):
+        """The two 1x1 heads as ONE bf16 1x1 convolution: cls (2A) rows then bbox (4A) rows -- re-derived from the fp32 head weights."""
+        if self.conv_dtype != "bf16":
+            return
+        rt = self.rt
+        W = np.concatenate([rt.mem.to_numpy(self.rpn_cls_score["W"]).reshape(-1, self.mid_ch),
+                            rt.mem.to_numpy(self.rpn_bbox_pred["W"]).reshape(-1, self.mid_ch)], 0).astype(np.float32)
+        b = np.concatenate([rt.mem.to_numpy(self.rpn_cls_score["b"]), rt.mem.to_numpy(self.rpn_bbox_pred["b"])], 0).astype(np.float32)
+        self._heads_bf16 = (rt.bf16_pack_conv_w(rt.asarray(np.ascontiguousarray(W[:, :, None, None]), "f32"), 1), rt.asarray(b, "f32"))
 
     def _check_data_type_forward(self, x, img_info, gt_boxes):
         assert x.shape[0] == 1

@@ -40,10 +40,13 @@ def conv_specs(blocks):
 
 
 class _FoldedConv(object):
-    def __init__(self, rt, W, bn, ksize):
-        """W (co,ci,k,k) without bias + its BN statistics -> packed (ci*k*k [padded], co) weights and a (co,) bias on device."""
+    def __init__(self, rt, W, bn, ksize, conv_bias=None):
+        """W (co,ci,k,k) [+ an optional convolution bias: chainer's ResNetLayers creates conv1 WITH one] + its BN statistics ->
+        packed (ci*k*k [padded], co) weights and a (co,) bias on device:  bn(conv(x) + b) = s*conv(x) + beta + (b - mean)*s."""
         gamma, beta, mean, var = [np.asarray(v, dtype=np.float64) for v in bn]
         s = gamma / np.sqrt(var + BN_EPS)
+        if conv_bias is not None:
+            mean = mean - np.asarray(conv_bias, dtype=np.float64)
         Wf = (np.asarray(W, dtype=np.float64) * s[:, None, None, None]).astype(np.float32)
         co = Wf.shape[0]
         packed = np.ascontiguousarray(Wf.reshape(co, -1).T)                 # (ci*k*k, co): the kernels' layout
@@ -67,7 +70,7 @@ class ResNet(object):
             W = params[prefix + conv + "/W"]
             assert tuple(W.shape) == (co, ci, k, k), (conv, tuple(W.shape))
             stats = [params[prefix + bn + "/" + n] for n in ("gamma", "beta", "avg_mean", "avg_var")]
-            self.convs[conv] = _FoldedConv(self.rt, W, stats, k)
+            self.convs[conv] = _FoldedConv(self.rt, W, stats, k, conv_bias=params.get(prefix + conv + "/b"))
 
     def _conv(self, name, x, act=1, residual=None):
         c = self.convs[name]

@@ -27,10 +27,18 @@ class Conv3x3(object):
         W = np.ascontiguousarray(W, dtype=np.float32) if isinstance(W, np.ndarray) else W
         assert tuple(W.shape) == (self.cout, self.cin, 3, 3), (tuple(W.shape), self.cout, self.cin)
         self.W = rt.asarray(W, "f32")
-        self.b = rt.asarray(np.ascontiguousarray(b, dtype=np.float32) if isinstance(b, np.ndarray) else b, "f32")
-        self.Wp = rt.pack_conv3x3_w(self.W)
+        b = rt.asarray(np.ascontiguousarray(b, dtype=np.float32) if isinstance(b, np.ndarray) else b, "f32")
+        Wp = rt.pack_conv3x3_w(self.W)
+        if getattr(self, "_adopted", False):                  # Wp / b are windows of a trainer's flat parameter buffer: write THROUGH them,
+            self.Wp[...] = Wp                                 # or the trainer would keep updating an orphaned copy (load_npz after training)
+            self.b[...] = b
+        else:
+            self.Wp, self.b = Wp, b
+        self.refresh_bf16()
+
+    def refresh_bf16(self):
         if self.conv_dtype == "bf16":
-            self.Wb = rt.bf16_pack_conv_w(self.W, 3)          # [tap][CoutP][CinP] bf16 (csrc/conv_bf16.hip)
+            self.Wb = self.rt.bf16_pack_conv_w(self.W, 3)     # [tap][CoutP][CinP] bf16 (csrc/conv_bf16.hip)
 
     def __call__(self, x, relu=True, out=None, cfg=-1):
         return self.rt.conv3x3(x, self.Wp, self.b, relu=relu, out=out, cfg=cfg)

@@ -47,6 +47,11 @@ class TorchDeviceMemory(object):
         n = int(np.prod(shape))
         return flat[offset:offset + n].view(*shape)
 
+    def within(self, a, flat):
+        """True when array `a` is a window of the flat buffer `flat` (the trainers' parameter arenas)."""
+        lo = flat.data_ptr()
+        return lo <= a.data_ptr() and a.data_ptr() + a.numel() * a.element_size() <= lo + flat.numel() * flat.element_size()
+
     def ptr(self, t):
         if t is None:
             return None

@@ -42,4 +42,9 @@ def load_npz(path, model):
     for n in ("fc6", "fc7", "cls_score", "bbox_pred"):
         if n + "/W" in params:
             getattr(model, n).set(params[n + "/W"], params[n + "/b"])
+    # everything derived from the parameters (the stacked inference head above all: forward_device() would otherwise keep the OLD
+    # cls_score / bbox_pred rows next to the new trunk) is rebuilt now; links adopted by a trainer were written through in place
+    model._last_trainer = None
+    if hasattr(model, "_stack_head") and all(getattr(model, n).W is not None for n in ("cls_score", "bbox_pred")):
+        model._stack_head()
     return model

@@ -19,8 +19,8 @@ What runs where:
 Trained parameters are the trunk and the RPN (in rpn_train mode FasterRCNN.__call__ returns before the head:
 models/faster_rcnn.py:115-116).  Convolution weights live in the kernels' packed layout (Cin*9, Cout) while training;
 `sync_params()` writes them back to Chainer's (Cout, Cin, 3, 3) arrays for snapshots.
-ProposalLayer is NOT run in the training step (the reference runs it and discards the result:
-region_proposal_network.py:123-126).
+ProposalLayer runs inside the training step exactly where the reference runs it (train-mode top-N 12000 / 2000,
+region_proposal_network.py:123-126) and its result is discarded, as there; `run_proposal_layer=False` skips it (same gradients).
 """
 import numpy as np
 
@@ -65,7 +65,24 @@ class _Seg(object):
         self.size = int(np.prod(shape))
 
 
-class _BucketedAllReduce(object):
+class _ParamArena(object):
+    """A trainer keeps its parameters in ONE flat buffer (self.W) and re-points the links' arrays at windows of it, so a single
+    fused launch updates everything.  Two trainers on one model (the reference's rpn -> rcnn -> rpn alternation, train.py; the
+    hidden RCNNTrainer of FasterRCNN.__call__) would orphan each other's windows: before every step a trainer therefore checks
+    that each link still points INTO its buffer and re-adopts the link's current values if not (velocities are kept)."""
+
+    def _adopt(self, key, current):
+        seg = self.seg[key]
+        v = self.rt.mem.view(self.W, seg.offset, seg.shape)
+        if not self.rt.mem.within(current, self.W):
+            v[...] = current
+        return v
+
+    def _ensure_adopted(self):
+        raise NotImplementedError
+
+
+class _BucketedAllReduce(_ParamArena):
     """Data parallel: the gradient all-reduce as a few contiguous TAIL buckets of the flat buffer, each launched asynchronously
     the moment the layer that completes it has its gradient kernels enqueued (the buffer is laid out in forward order and the
     backward pass fills it from the end), so the exchange runs under the rest of the backward pass.  Same element-wise sums over
@@ -110,10 +127,12 @@ class _BucketedAllReduce(object):
 
 
 class RPNTrainer(_BucketedAllReduce):
-    def __init__(self, model, lr=0.001, momentum=0.9, weight_decay=0.0005, comm=None):
+    def __init__(self, model, lr=0.001, momentum=0.9, weight_decay=0.0005, comm=None, run_proposal_layer=True):
         self.model, self.rt = model, model.rt
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.comm = comm
+        self.run_proposal_layer = run_proposal_layer
+        self.proposals = None
         rt = self.rt
         rpn = model.RPN
         self.atl = AnchorTargetLayer(rpn.proposal_layer._feat_stride, runtime=rt)
@@ -140,14 +159,7 @@ class RPNTrainer(_BucketedAllReduce):
         self.W = rt.mem.zeros((off,), "f32")
         self.G = rt.mem.zeros((off,), "f32")
         self.V = rt.mem.zeros((off,), "f32")
-        def adopt(seg, src):
-            v = rt.mem.view(self.W, seg.offset, seg.shape)
-            v[...] = src
-            return v
-        for name, link in self.convs:
-            link.Wp = adopt(self.seg[name + "/W"], link.Wp)
-            link.b = adopt(self.seg[name + "/b"], link.b)
-        rpn._heads_packed = (adopt(self.seg["heads/W"], wp), adopt(self.seg["heads/b"], bp), self.A)
+        self._ensure_adopted()
         self.grad = {k: rt.mem.view(self.G, s.offset, s.shape) for k, s in self.seg.items()}
         # weights of the input-gradient convolutions (re-packed from the current weights every step)
         self.wd = {name: rt.mem.empty((int(link.Wp.shape[1]) * 9, int(link.Wp.shape[0]) // 9), "f32") for name, link in self.convs[1:]}
@@ -157,16 +169,31 @@ class RPNTrainer(_BucketedAllReduce):
         self.iteration = 0
         self._plan_buckets([n for n, _ in self.convs])       # heads follow rpn_conv_3x3 in the buffer and precede it in time
 
+    def _ensure_adopted(self):
+        rpn = self.model.RPN
+        for name, link in self.convs:
+            link.Wp = self._adopt(name + "/W", link.Wp)
+            link.b = self._adopt(name + "/b", link.b)
+            link._adopted = True
+        wp, bp, A = rpn._heads_packed
+        rpn._heads_packed = (self._adopt("heads/W", wp), self._adopt("heads/b", bp), A)
+        rpn._heads_adopted = True
+
     # ------------------------------------------------------------------
     def forward_backward(self, x, img_info, gt_boxes):
         """Fills self.G with this replica's gradients; returns dict(loss, loss_cls, loss_bbox, accuracy) (device scalars)."""
         rt, model, rpn = self.rt, self.model, self.model.RPN
         self._drain()                                              # a previous backward whose sums were never consumed
+        self._ensure_adopted()
         x = rt.asarray(unwrap(x), "f32")
         im_h, im_w = rpn.proposal_layer._img_hw(img_info)
         feat, inputs = trunk_forward(model, x)                     # keeps every layer's input
         mid = rpn.rpn_conv_3x3(feat, relu=True)
-        score, _, bbox = rt.rpn_heads(mid, rpn._heads_packed)
+        score, prob, bbox = rt.rpn_heads(mid, rpn._heads_packed)
+        if self.run_proposal_layer:
+            # region_proposal_network.py:123-126: `proposals, probs = self.proposal_layer(...)` in train mode (12000 -> NMS -> 2000);
+            # nothing downstream consumes it in rpn_train mode (faster_rcnn.py:115-116 returns the loss) -- kept for inspection
+            self.proposals = rpn.proposal_layer.forward_device(prob, bbox, im_h, im_w)
         A = self.A
         H, W = int(feat.shape[2]), int(feat.shape[3])
         NP = int(rpn._heads_packed[0].shape[1])
@@ -187,9 +214,10 @@ class RPNTrainer(_BucketedAllReduce):
         return dict(losses=losses)
 
     def update(self):
+        self._ensure_adopted()
         self.rt.sgd_momentum_wd(self.W, self.G, self.V, self.lr, self.momentum, self.weight_decay)
         if hasattr(self.model, "mark_params_updated"):
-            self.model.mark_params_updated()
+            self.model.mark_params_updated(self)
         self.iteration += 1
 
     def step(self, x, img_info, gt_boxes):
@@ -265,23 +293,24 @@ class RCNNTrainer(_BucketedAllReduce):
             add(n + "/b", lin.b.shape)
         self.seg, self.n_flat = segs, off
         self.W, self.G, self.V = rt.mem.zeros((off,), "f32"), rt.mem.zeros((off,), "f32"), rt.mem.zeros((off,), "f32")
-        def adopt(seg, src):
-            v = rt.mem.view(self.W, seg.offset, seg.shape)
-            v[...] = src
-            return v
-        for name, link in self.convs:
-            link.Wp = adopt(segs[name + "/W"], link.Wp)
-            link.b = adopt(segs[name + "/b"], link.b)
-        for n in self.HEAD:
-            lin = getattr(model, n)
-            lin.W = adopt(segs[n + "/W"], lin.W)
-            lin.b = adopt(segs[n + "/b"], lin.b)
+        self._ensure_adopted()
         self.grad = {k: rt.mem.view(self.G, sg.offset, sg.shape) for k, sg in segs.items()}
         self.wd = {name: rt.mem.empty((int(link.Wp.shape[1]) * 9, int(link.Wp.shape[0]) // 9), "f32") for name, link in self.convs[1:]}
         self.zero_bias = rt.mem.zeros((max(512, max(int(getattr(model, n).W.shape[1]) for n in self.HEAD)),), "f32")
         self.iteration = 0
         # the head (fc6: 411 MB of gradients) is complete before the trunk's backward starts: its bucket rides under all of it
         self._plan_buckets([n for n, _ in self.convs] + list(self.HEAD))
+
+    def _ensure_adopted(self):
+        for name, link in self.convs:
+            link.Wp = self._adopt(name + "/W", link.Wp)
+            link.b = self._adopt(name + "/b", link.b)
+            link._adopted = True
+        for n in self.HEAD:
+            lin = getattr(self.model, n)
+            lin.W = self._adopt(n + "/W", lin.W)
+            lin.b = self._adopt(n + "/b", lin.b)
+            lin._adopted = True
 
     # ------------------------------------------------------------------ one L.Linear backward: GEMMs on transposed operands
     def _linear_backward(self, name, x, dy, need_dx=True):
@@ -312,6 +341,7 @@ class RCNNTrainer(_BucketedAllReduce):
         """Fills self.G; returns dict(losses (3,) device [loss_cls, loss_bbox, cls_accuracy], n_rois, keep_inds)."""
         rt, model = self.rt, self.model
         self._drain()                                              # a previous backward whose sums were never consumed
+        self._ensure_adopted()
         x = rt.asarray(unwrap(x), "f32")
         im_h, im_w = model.RPN.proposal_layer._img_hw(img_info)
         feat, inputs = trunk_forward(model, x)
@@ -353,9 +383,10 @@ class RCNNTrainer(_BucketedAllReduce):
         return dict(losses=losses, n_rois=n, keep_inds=keep)
 
     def update(self):
+        self._ensure_adopted()
         self.rt.sgd_momentum_wd(self.W, self.G, self.V, self.lr, self.momentum, self.weight_decay)
         if hasattr(self.model, "mark_params_updated"):
-            self.model.mark_params_updated()
+            self.model.mark_params_updated(self)
         self.iteration += 1
 
     def step(self, x, img_info, gt_boxes, masks=None):

@@ -215,11 +215,15 @@ class ProposalParams(object):
 def proposal_layer(rpn_cls_prob, rpn_bbox_pred, img_info, train=False, feat_stride=16,
                    anchor_ratios=(0.5, 1, 2), anchor_scales=(8, 16, 32),
                    pre_nms_top_n=None, post_nms_top_n=None, nms_thresh=0.7, min_size=16,
-                   return_debug=False):
+                   return_debug=False, nms_fn=None, stage_times=None):
     """models/proposal_layer.py:102-198.  Inputs (1,2A,H,W), (1,4A,H,W) float32, img_info (1,2) int.
 
     Returns (proposals (n,4) f32, fg_probs (n,1) f32) [+ a dict of intermediates].
+    nms_fn: a cpu_nms(dets, thresh) callable to use instead of the C restatement (bench.py passes the reference's own
+    compiled models/cpu_nms.pyx from oracle/_ref); stage_times: dict receiving seconds spent before / inside NMS.
     """
+    import time as _time
+    _t0 = _time.perf_counter()
     anchors = generate_anchors(ratios=anchor_ratios, scales=anchor_scales)      # :63-64
     A = len(anchors)
     pre, post = ProposalParams.TRAIN if train else ProposalParams.TEST            # :75-83
@@ -241,7 +245,12 @@ def proposal_layer(rpn_cls_prob, rpn_bbox_pred, img_info, train=False, feat_stri
         order = order[:pre]                                                        # :167-168
     proposals = proposals[order]
     fg = fg[order]
-    keep = cpu_nms(np.hstack((proposals, fg)), float(nms_thresh))                  # :178
+    dets = np.hstack((proposals, fg))
+    _t1 = _time.perf_counter()
+    keep = (nms_fn or cpu_nms)(dets, float(nms_thresh))                            # :178
+    if stage_times is not None:
+        stage_times["decode_sort"] = stage_times.get("decode_sort", 0.0) + (_t1 - _t0)
+        stage_times["nms"] = stage_times.get("nms", 0.0) + (_time.perf_counter() - _t1)
     if post > 0:
         keep = keep[:post]                                                         # :189-190
     out_p, out_s = proposals[keep], fg[keep]

@@ -38,6 +38,10 @@ class HostMemory(object):
         n = int(np.prod(shape))
         return flat[offset:offset + n].reshape(shape)
 
+    def within(self, a, flat):
+        lo = flat.ctypes.data
+        return lo <= a.ctypes.data and a.ctypes.data + a.nbytes <= lo + flat.nbytes
+
     def ptr(self, a):
         if a is None:
             return None

@@ -195,3 +195,118 @@ def test_rcnn_gradient_buckets_put_the_head_first(rt):
         end = start
     assert end == 0
 
+
+
+# ---- derived state and parameter arenas
+def _small_full_model(rt, conv_dtype="f32", head_dtype="f32", seed=0):
+    import functools
+    from chainer_faster_rcnn_amd.models import FasterRCNN, VGG16Prev
+    params = T.small_params()
+    params.update(T.small_head_params(np.random.RandomState(seed)))
+    model = FasterRCNN(trunk_class=functools.partial(VGG16Prev, layers=T.SMALL_LAYERS), rpn_in_ch=64, rpn_mid_ch=64, feat_stride=4,
+                       anchor_scales=(2, 4, 8), runtime=rt, conv_dtype=conv_dtype, head_dtype=head_dtype)
+    model.load_params(params)
+    model.RPN.proposal_layer.RPN_MIN_SIZE = 4
+    model.RPN.proposal_layer._min_size = 4
+    return model, params
+
+
+def _step_inputs(seed=0, h=40, w=56):
+    import parity_cases as P
+    rs = np.random.RandomState(seed)
+    x = rs.randn(1, 3, h, w).astype(np.float32)
+    gt = P.gt_case(rs, 2, h, w)
+    gt[0, :, 2] = np.minimum(gt[0, :, 0] + 20, w - 1); gt[0, :, 3] = np.minimum(gt[0, :, 1] + 20, h - 1)
+    return x, gt, np.array([[h, w]], dtype=np.int32)
+
+
+def test_load_npz_rebuilds_the_stacked_inference_head(rt, tmp_path):
+    """load_npz() on a model that already ran inference: the stacked cls_score|bbox_pred GEMM must carry the LOADED rows
+    (it kept the old ones: detections silently wrong)."""
+    from chainer_faster_rcnn_amd.serializers import load_npz, save_npz
+    a, pa = _small_full_model(rt, seed=0)
+    b, pb = _small_full_model(rt, seed=7)                     # different head weights
+    x, _, _ = _step_inputs()
+    xd = rt.mem.from_numpy(x)
+    want = {k: rt.mem.to_numpy(v) for k, v in b.forward_device(xd, 40, 56).items()}
+    a.forward_device(xd, 40, 56)                              # a's stacked head exists now
+    path = str(tmp_path / "b.npz")
+    save_npz(path, b)
+    load_npz(path, a)
+    got = {k: rt.mem.to_numpy(v) for k, v in a.forward_device(xd, 40, 56).items()}
+    assert not np.array_equal(pa["cls_score/W"], pb["cls_score/W"])
+    for k in want:
+        assert np.array_equal(want[k], got[k]), k
+
+
+def test_two_trainers_on_one_model_keep_training_it(rt):
+    """rpn -> rcnn -> rpn on ONE model (the reference's alternation): the second trainer re-points the links at its own buffer; the
+    first must notice, re-adopt the current values and keep updating the LIVE weights (it trained an orphaned copy)."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.train import RCNNTrainer, RPNTrainer
+    model, _ = _small_full_model(rt)
+    x, gt, info = _step_inputs()
+    model.rpn_train = True
+    t1 = RPNTrainer(model)
+    np.random.seed(0)
+    t1.step(Variable(x), Variable(info), Variable(gt))
+    model.rcnn_train = True
+    t2 = RCNNTrainer(model)                                   # adopts trunk convs (and the head) into ITS buffer
+    np.random.seed(1)
+    t2.step(Variable(x), Variable(info), Variable(gt))
+    link = model.trunk.links["conv2_1"]
+    after_t2 = rt.mem.to_numpy(link.Wp).copy()
+    assert rt.mem.within(link.Wp, t2.W) and not rt.mem.within(link.Wp, t1.W)
+    model.rpn_train = True
+    np.random.seed(2)
+    t1.step(Variable(x), Variable(info), Variable(gt))
+    assert rt.mem.within(link.Wp, t1.W)                       # re-adopted ...
+    live = rt.mem.to_numpy(link.Wp)
+    assert not np.array_equal(live, after_t2)                 # ... and the live weights moved
+    # the step started from t2's result, not from t1's stale copy: one SGD step changes a weight by at most lr * (|g| + wd |w|) + momentum * |v|
+    assert np.abs(live - after_t2).max() < 0.05
+    # inference sees the trained weights: the link's arrays ARE the windows
+    seg = t1.seg["conv2_1/W"]
+    assert np.array_equal(live.ravel(), rt.mem.to_numpy(t1.W)[seg.offset:seg.offset + seg.size])
+
+
+def test_load_npz_writes_through_adopted_links(rt, tmp_path):
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.serializers import load_npz, save_npz
+    from chainer_faster_rcnn_amd.train import RPNTrainer
+    model, params = _small_full_model(rt)
+    other, _ = _small_full_model(rt)
+    other.trunk.links["conv2_1"].set(params["trunk/conv2_1/W"] * 2.0, params["trunk/conv2_1/b"])
+    path = str(tmp_path / "o.npz")
+    save_npz(path, other)
+    model.rpn_train = True
+    tr = RPNTrainer(model)
+    load_npz(path, model)
+    link = model.trunk.links["conv2_1"]
+    assert rt.mem.within(link.Wp, tr.W)                       # still the trainer's window, now holding the loaded values
+    assert np.array_equal(rt.mem.to_numpy(link.Wp), rt.mem.to_numpy(other.trunk.links["conv2_1"].Wp))
+
+
+def test_bf16_copies_follow_the_optimizer(rt):
+    """A bf16 model infers with the TRAINED weights after trainer.step(): Conv3x3.Wb, the stacked RPN heads and Linear.Wb are
+    re-derived from the updated fp32 parameters (they stayed at their load-time values)."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.train import RPNTrainer
+    model, params = _small_full_model(rt, conv_dtype="bf16", head_dtype="bf16")
+    x, gt, info = _step_inputs()
+    xd = rt.mem.from_numpy(x)
+    before = rt.mem.to_numpy(model.forward_device(xd, 40, 56, keep=True)["feat"]).copy()
+    model.rpn_train = True
+    tr = RPNTrainer(model, lr=0.05)                           # a large step so bf16 rounding cannot hide the change
+    np.random.seed(0)
+    tr.step(Variable(x), Variable(info), Variable(gt))
+    model.rpn_train = False
+    after = rt.mem.to_numpy(model.forward_device(xd, 40, 56, keep=True)["feat"])
+    assert not np.array_equal(before, after)
+    # reference: a FRESH bf16 model loaded with the trained fp32 weights
+    from chainer_faster_rcnn_amd.serializers import namedparams
+    trained = {k: rt.mem.to_numpy(rt.mem.contiguous(v)) for k, v in namedparams(model)}
+    fresh, _ = _small_full_model(rt, conv_dtype="bf16", head_dtype="bf16")
+    fresh.load_params(trained)
+    want = rt.mem.to_numpy(fresh.forward_device(xd, 40, 56, keep=True)["feat"])
+    assert np.array_equal(after, want)
