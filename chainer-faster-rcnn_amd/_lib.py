@@ -108,6 +108,9 @@ def bind(path):
         fn = getattr(lib, name)      # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
+    # the reference's own C FFI (models/gpu_nms.hpp:9-10): void _nms(int*, int*, const float*, int, int, float, int)
+    lib._nms.restype = None
+    lib._nms.argtypes = [_P, ctypes.POINTER(ctypes.c_int), _P, _I, _I, _F, _I]
     return lib
 
 

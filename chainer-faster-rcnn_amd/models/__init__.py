@@ -4,7 +4,8 @@ the HIP kernels in libfrcnn_hip.so."""
 from .anchor_target_layer import AnchorTargetLayer  # noqa: F401
 from .bbox import bbox_overlaps  # noqa: F401
 from .bbox_transform import bbox_transform_inv, clip_boxes  # noqa: F401
-from .cpu_nms import cpu_nms, gpu_nms  # noqa: F401
+from .cpu_nms import cpu_nms  # noqa: F401
+from .gpu_nms import gpu_nms  # noqa: F401
 from .faster_rcnn import FasterRCNN  # noqa: F401
 from .generate_anchors import generate_anchors  # noqa: F401
 from .proposal_layer import ProposalLayer  # noqa: F401

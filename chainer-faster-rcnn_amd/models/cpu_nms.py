@@ -25,9 +25,3 @@ def cpu_nms(dets, thresh, max_out=0, runtime=None):
     keep, n_keep = rt.nms(d, thresh, max_out)
     n = int(rt.mem.to_numpy(n_keep)[0])
     return [int(v) for v in rt.mem.to_numpy(keep)[:n]]
-
-
-def gpu_nms(dets, thresh, device_id=0):
-    """models/gpu_nms.pyx:16 signature (dead code in the reference, proposal_layer.py:180-187).  Same device
-    kernel; note it therefore keeps cpu_nms's `>=`-in-double rule, not nms_kernel.cu:71's `>`."""
-    return cpu_nms(dets, float(thresh))

@@ -1,6 +1,12 @@
 """`load_npz(path, model)` / `save_npz(path, model)` for the reference's snapshot format (forward.py:29
 `serializers.load_npz('data/VGG16_faster_rcnn_final.model', model)`, train_rpn.py:101-109 snapshot_object): a NumPy .npz whose
 keys are chainer link paths -- `trunk/conv1_1/W` (co,ci,3,3), `RPN/rpn_cls_score/b`, `fc6/W` (out,in), ....
+
+`save_trainer_npz` / `load_trainer_npz` cover train_rpn.py:101-105 `extensions.snapshot()`: chainer v1 serialises the trainer as
+`updater/model:main/<link path>` (the parameters), `updater/optimizer:main/<link path>/v` (MomentumSGD's velocity, in the
+parameter's shape), `updater/optimizer:main/t`, `updater/optimizer:main/epoch`, `updater/iteration` [chainer-ext: Trainer.serialize
+-> StandardUpdater.serialize -> Optimizer.serialize].  Iterator / extension / trigger entries of such a file are the reference's
+control plane (out of scope): ignored on load, not written on save.
 """
 import numpy as np
 
@@ -31,7 +37,8 @@ def save_npz(path, model, trainer=None):
     if trainer is not None:
         trainer.sync_params()
     rt = model.rt
-    np.savez(path, **{k: rt.mem.to_numpy(rt.mem.contiguous(v)) for k, v in namedparams(model)})
+    with open(path, "wb") as f:        # chainer's save_npz writes through a file object: the name is kept as given (`..._final.model`)
+        np.savez(f, **{k: rt.mem.to_numpy(rt.mem.contiguous(v)) for k, v in namedparams(model)})
 
 
 def load_npz(path, model):
@@ -48,3 +55,43 @@ def load_npz(path, model):
     if hasattr(model, "_stack_head") and all(getattr(model, n).W is not None for n in ("cls_score", "bbox_pred")):
         model._stack_head()
     return model
+
+
+TRAINER_MODEL = "updater/model:main/"
+TRAINER_OPT = "updater/optimizer:main/"
+
+
+def save_trainer_npz(path, trainer):
+    """Resumable snapshot of a training run (train_rpn.py:101-105): parameters + momentum velocities + iteration count."""
+    model, rt = trainer.model, trainer.rt
+    trainer.sync_params()
+    d = {TRAINER_MODEL + k: rt.mem.to_numpy(rt.mem.contiguous(v)) for k, v in namedparams(model)}
+    for k, v in trainer.flat_to_chainer_layout(trainer.V).items():
+        d[TRAINER_OPT + k + "/v"] = v
+    d[TRAINER_OPT + "t"] = np.asarray(trainer.iteration, dtype=np.int32)
+    d[TRAINER_OPT + "epoch"] = np.asarray(0, dtype=np.int32)
+    d["updater/iteration"] = np.asarray(trainer.iteration, dtype=np.int32)
+    with open(path, "wb") as f:
+        np.savez(f, **d)
+
+
+def load_trainer_npz(path, trainer):
+    """Resume: parameters into the model (written THROUGH the trainer's windows), velocities into trainer.V, iteration count."""
+    import os
+    import tempfile
+    with np.load(path) as f:
+        arrays = {k: f[k] for k in f.files}
+    params = {k[len(TRAINER_MODEL):]: v for k, v in arrays.items() if k.startswith(TRAINER_MODEL)}
+    fd, tmp = tempfile.mkstemp(suffix=".npz")
+    os.close(fd)
+    try:
+        np.savez(tmp, **params)
+        load_npz(tmp, trainer.model)
+    finally:
+        os.remove(tmp)
+    trainer._ensure_adopted()
+    vel = {k[len(TRAINER_OPT):-2]: v for k, v in arrays.items() if k.startswith(TRAINER_OPT) and k.endswith("/v")}
+    trainer.chainer_layout_to_flat(vel, trainer.V)
+    if "updater/iteration" in arrays:
+        trainer.iteration = int(arrays["updater/iteration"])
+    return trainer

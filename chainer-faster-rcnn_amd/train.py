@@ -244,19 +244,52 @@ class RPNTrainer(_BucketedAllReduce):
         rpn.rpn_cls_score["W"], rpn.rpn_cls_score["b"] = wt[:2 * A], bp[:2 * A]
         rpn.rpn_bbox_pred["W"], rpn.rpn_bbox_pred["b"] = wt[2 * A:6 * A], bp[2 * A:6 * A]
 
-    def grads_chainer_layout(self):
-        """{link path: gradient in Chainer's layout} (host arrays) -- for tests and inspection."""
+    def flat_to_chainer_layout(self, flat):
+        """A flat buffer in this trainer's segment layout (gradients, velocities, parameters) -> {link path: host array in
+        Chainer's layout}: packed (Cin*9, Cout) -> (Cout, Cin, 3, 3); the stacked heads -> rpn_cls_score / rpn_bbox_pred."""
         rt, out = self.rt, {}
+        host = rt.mem.to_numpy(flat)
+        def seg(key):
+            sg = self.seg[key]
+            return host[sg.offset:sg.offset + sg.size].reshape(sg.shape)
         for name, link in self.convs:
             prefix = "RPN/" if name == "rpn_conv_3x3" else "trunk/"
-            g = rt.mem.to_numpy(self.grad[name + "/W"])
-            out[prefix + name + "/W"] = np.ascontiguousarray(g.T).reshape(link.cout, link.cin, 3, 3)
-            out[prefix + name + "/b"] = rt.mem.to_numpy(self.grad[name + "/b"])
+            out[prefix + name + "/W"] = np.ascontiguousarray(seg(name + "/W").T).reshape(link.cout, link.cin, 3, 3)
+            out[prefix + name + "/b"] = seg(name + "/b").copy()
         A = self.A
-        gw, gb = rt.mem.to_numpy(self.grad["heads/W"]).T, rt.mem.to_numpy(self.grad["heads/b"])
-        out["RPN/rpn_cls_score/W"], out["RPN/rpn_cls_score/b"] = gw[:2 * A].reshape(2 * A, -1, 1, 1), gb[:2 * A]
-        out["RPN/rpn_bbox_pred/W"], out["RPN/rpn_bbox_pred/b"] = gw[2 * A:6 * A].reshape(4 * A, -1, 1, 1), gb[2 * A:6 * A]
+        gw, gb = seg("heads/W").T, seg("heads/b")
+        out["RPN/rpn_cls_score/W"], out["RPN/rpn_cls_score/b"] = np.ascontiguousarray(gw[:2 * A]).reshape(2 * A, -1, 1, 1), gb[:2 * A].copy()
+        out["RPN/rpn_bbox_pred/W"], out["RPN/rpn_bbox_pred/b"] = np.ascontiguousarray(gw[2 * A:6 * A]).reshape(4 * A, -1, 1, 1), gb[2 * A:6 * A].copy()
         return out
+
+    def chainer_layout_to_flat(self, arrays, flat):
+        """Inverse of flat_to_chainer_layout: write {link path: array} into `flat` (missing keys leave their segment untouched)."""
+        rt = self.rt
+        host = rt.mem.to_numpy(flat).copy()
+        def put(key, val):
+            sg = self.seg[key]
+            host[sg.offset:sg.offset + sg.size] = np.asarray(val, dtype=np.float32).reshape(-1)
+        for name, link in self.convs:
+            prefix = "RPN/" if name == "rpn_conv_3x3" else "trunk/"
+            if prefix + name + "/W" in arrays:
+                put(name + "/W", np.asarray(arrays[prefix + name + "/W"], dtype=np.float32).reshape(link.cout, -1).T)
+            if prefix + name + "/b" in arrays:
+                put(name + "/b", arrays[prefix + name + "/b"])
+        A = self.A
+        sw, sb = self.seg["heads/W"], self.seg["heads/b"]
+        if "RPN/rpn_cls_score/W" in arrays and "RPN/rpn_bbox_pred/W" in arrays:
+            w = np.zeros((sw.shape[1], sw.shape[0]), np.float32)                       # (NP, Cmid): rows past 6A are channel padding
+            w[:2 * A] = np.asarray(arrays["RPN/rpn_cls_score/W"], dtype=np.float32).reshape(2 * A, -1)
+            w[2 * A:6 * A] = np.asarray(arrays["RPN/rpn_bbox_pred/W"], dtype=np.float32).reshape(4 * A, -1)
+            put("heads/W", w.T)
+            b = np.zeros((sb.shape[0],), np.float32)
+            b[:2 * A], b[2 * A:6 * A] = arrays["RPN/rpn_cls_score/b"], arrays["RPN/rpn_bbox_pred/b"]
+            put("heads/b", b)
+        flat[...] = rt.mem.from_numpy(host)
+
+    def grads_chainer_layout(self):
+        """{link path: gradient in Chainer's layout} (host arrays) -- for tests and inspection."""
+        return self.flat_to_chainer_layout(self.G)
 
 
 class RCNNTrainer(_BucketedAllReduce):
@@ -399,15 +432,38 @@ class RCNNTrainer(_BucketedAllReduce):
         l = self.rt.mem.to_numpy(out["losses"])
         return dict(loss_cls=float(l[0]), loss_bbox=float(l[1]), cls_accuracy=float(l[2]), loss_rcnn=float(l[0] + l[1]))
 
-    def grads_chainer_layout(self):
+    def flat_to_chainer_layout(self, flat):
         rt, out = self.rt, {}
+        host = rt.mem.to_numpy(flat)
+        def seg(key):
+            sg = self.seg[key]
+            return host[sg.offset:sg.offset + sg.size].reshape(sg.shape)
         for name, link in self.convs:
-            g = rt.mem.to_numpy(self.grad[name + "/W"])
-            out["trunk/" + name + "/W"] = np.ascontiguousarray(g.T).reshape(link.cout, link.cin, 3, 3)
-            out["trunk/" + name + "/b"] = rt.mem.to_numpy(self.grad[name + "/b"])
+            out["trunk/" + name + "/W"] = np.ascontiguousarray(seg(name + "/W").T).reshape(link.cout, link.cin, 3, 3)
+            out["trunk/" + name + "/b"] = seg(name + "/b").copy()
         for n in self.HEAD:
-            out[n + "/W"], out[n + "/b"] = rt.mem.to_numpy(self.grad[n + "/W"]), rt.mem.to_numpy(self.grad[n + "/b"])
+            out[n + "/W"], out[n + "/b"] = seg(n + "/W").copy(), seg(n + "/b").copy()
         return out
+
+    def chainer_layout_to_flat(self, arrays, flat):
+        rt = self.rt
+        host = rt.mem.to_numpy(flat).copy()
+        def put(key, val):
+            sg = self.seg[key]
+            host[sg.offset:sg.offset + sg.size] = np.asarray(val, dtype=np.float32).reshape(-1)
+        for name, link in self.convs:
+            if "trunk/" + name + "/W" in arrays:
+                put(name + "/W", np.asarray(arrays["trunk/" + name + "/W"], dtype=np.float32).reshape(link.cout, -1).T)
+            if "trunk/" + name + "/b" in arrays:
+                put(name + "/b", arrays["trunk/" + name + "/b"])
+        for n in self.HEAD:
+            for sfx in ("/W", "/b"):
+                if n + sfx in arrays:
+                    put(n + sfx, arrays[n + sfx])
+        flat[...] = rt.mem.from_numpy(host)
+
+    def grads_chainer_layout(self):
+        return self.flat_to_chainer_layout(self.G)
 
     def sync_params(self):
         for name, link in self.convs:

@@ -58,6 +58,15 @@ size_t frcnn_nms_batched_workspace_bytes(int groups, int n);
 int frcnn_nms_batched(const float *dets, int groups, int n, double thresh, int max_out, int32_t *keep,
                       int32_t *n_keep, void *workspace, size_t workspace_bytes, void *stream);
 
+/* The reference's own C FFI, signature unchanged (models/gpu_nms.hpp:9-10; bound by models/gpu_nms.pyx:16-31, which links against
+ * this symbol as is): HOST pointers, synchronous, device memory allocated and freed inside the call, `device_id` selected for the
+ * duration of the call only (the caller's current device is restored).  boxes_host: boxes_num rows of boxes_dim >= 5 floats
+ * [x1,y1,x2,y2,score,..] pre-sorted by descending score (gpu_nms.pyx:25-28); keep_out (capacity boxes_num): surviving row indices.
+ * Errors are reported as *num_out = -1 (never printed and swallowed).  Suppression rule = cpu_nms.pyx's `(double)iou >= thresh`
+ * with thresh recovered as the shortest decimal that rounds to the float passed in (0.7f -> 0.7): see csrc/nms_host.hip. */
+void _nms(int *keep_out, int *num_out, const float *boxes_host, int boxes_num, int boxes_dim,
+          float nms_overlap_thresh, int device_id);
+
 /* ---- ProposalLayer ---------------------------------------------------------------------------------
  * Replaces ProposalLayer.__call__ (models/proposal_layer.py:102-198): anchor enumeration (:200-221),
  * bbox_transform_inv (bbox_transform.py:41-76), clip_boxes (:79-99), filter_boxes (:102-109), fg-score

@@ -60,6 +60,29 @@ def check_nms_edges(rt):
     assert O.cpu_nms(d, 0.0) == host(rt, rt.nms(dev(rt, d), 0.0)[0])[:1].tolist() == [2]
 
 
+def check_gpu_nms_ffi(rt, tags=("n6000_t07", "n300_t03", "n65_t05", "n1_t07")):
+    """`_nms` with the reference's exact C signature (models/gpu_nms.hpp:9-10) through the gpu_nms.pyx-shaped binding: host arrays
+    in, list out, equal to the reference's cpu_nms on the reference-generated golden vectors -- including threshold 0.3, where
+    nms_kernel.cu's fp32 `>` and cpu_nms's double `>=` differ (the threshold is narrowed to a C float by the FFI and recovered)."""
+    from chainer_faster_rcnn_amd.models import gpu_nms
+    from chainer_faster_rcnn_amd._lib import FrcnnError
+    G = g("cpu_nms")
+    for tag in tags:
+        dets, thr, want = G[tag + "_dets"], float(G[tag + "_thresh"]), G[tag + "_keep"]
+        assert [int(v) for v in gpu_nms(dets, thr, 0, lib=rt.lib)] == want.tolist(), tag
+    for thr in (0.7, 0.5, 0.3):          # boxes whose IoU sits exactly on the float32 neighbours of the threshold
+        assert [int(v) for v in gpu_nms(G["edge_dets"], thr, 0, lib=rt.lib)] == G["edge_keep_%02d" % int(thr * 10)].tolist(), thr
+    wide = np.hstack([G["n65_t05_dets"], np.full((65, 2), 7.0, np.float32)])          # boxes_dim = 7: only the first five columns count
+    assert [int(v) for v in gpu_nms(wide, 0.5, 0, lib=rt.lib)] == G["n65_t05_keep"].tolist()
+    assert gpu_nms(np.zeros((0, 5), np.float32), 0.7, 0, lib=rt.lib) == []
+    try:                                  # errors are reported (num_out = -1), not printed and swallowed
+        gpu_nms(G["n65_t05_dets"], 0.5, 4096, lib=rt.lib)
+        raise AssertionError("an invalid device id must fail")
+    except FrcnnError:
+        pass
+    assert [int(v) for v in gpu_nms(G["n65_t05_dets"], 0.5, 0, lib=rt.lib)] == G["n65_t05_keep"].tolist()   # and the library still works
+
+
 def check_nms_random(rt, n=700, seeds=(0, 1), thrs=(0.3, 0.5, 0.7)):
     for seed in seeds:
         rs = np.random.RandomState(seed)

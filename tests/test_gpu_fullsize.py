@@ -133,3 +133,61 @@ def test_resnet101_config4_600x1000(rt):
     _report("resnet101_cfg4_600x1000", rep)
     assert rep["res5_rel_err"] <= 1e-3 and rep["proposals_index_exact_given_device_maps"] and rep["pool5_exact"]
     assert rep["cls_prob_rel_err"] <= 1e-3 and rep["pred_boxes_rel_err"] <= 1e-3
+
+
+def test_checkpoint_io_vgg16(rt, tmp_path):
+    """f-4 at the boundary it exists for, on the real VGG-16 (548 MB of parameters):
+      * forward.py:29  serializers.load_npz('data/VGG16_faster_rcnn_final.model', model): a file in chainer's key / layout scheme,
+        written here with plain numpy.savez (what chainer's save_npz does), loaded into a model that ALREADY ran inference with other
+        weights -> same outputs as a fresh model given the arrays directly (the stacked head is rebuilt);
+      * train_rpn.py:106-109 snapshot_object: save_npz round-trips every array bit for bit;
+      * train_rpn.py:101-105 snapshot(): parameters + velocities + iteration; a resumed run continues bit-identically."""
+    from chainer_faster_rcnn_amd import synthetic
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.models import FasterRCNN
+    from chainer_faster_rcnn_amd.serializers import load_npz, load_trainer_npz, save_npz, save_trainer_npz
+    from chainer_faster_rcnn_amd.train import RPNTrainer
+    import parity_cases as P
+    params = synthetic.params(seed=1)
+    path = str(tmp_path / "VGG16_faster_rcnn_final.model")
+    with open(path, "wb") as f:
+        np.savez(f, **params)
+    h, w = 224, 320
+    x = rt.mem.from_numpy(synthetic.image(seed=3, h=h, w=w))
+    fresh = FasterRCNN(runtime=rt)
+    fresh.load_params(params)
+    want = {k: rt.mem.to_numpy(v) for k, v in fresh.forward_device(x, h, w).items()}
+    model = FasterRCNN(runtime=rt)
+    model.load_params(synthetic.params(seed=2))
+    model.forward_device(x, h, w)
+    load_npz(path, model)
+    got = {k: rt.mem.to_numpy(v) for k, v in model.forward_device(x, h, w).items()}
+    for k in want:
+        assert np.array_equal(want[k], got[k]), k
+    out = str(tmp_path / "rpn_model_snapshot_1")
+    save_npz(out, model)
+    with np.load(out) as f:
+        assert sorted(f.files) == sorted(params)
+        for k in params:
+            assert f[k].shape == params[k].shape and np.array_equal(f[k], params[k]), k
+    # trainer snapshot / resume
+    rs = np.random.RandomState(0)
+    gt = P.gt_case(rs, 3, h, w)
+    info = np.array([[h, w]], dtype=np.int32)
+    xi = synthetic.image(seed=3, h=h, w=w)
+    model.rpn_train = True
+    tr = RPNTrainer(model)
+    for s in (0, 1):
+        np.random.seed(s)
+        tr.step(Variable(xi), Variable(info), Variable(gt))
+    snap = str(tmp_path / "rpn_trainer_snapshot_2")
+    save_trainer_npz(snap, tr)
+    model2 = FasterRCNN(runtime=rt)
+    model2.load_params(synthetic.params(seed=2))
+    model2.rpn_train = True
+    tr2 = load_trainer_npz(snap, RPNTrainer(model2))
+    assert tr2.iteration == 2
+    for t in (tr, tr2):
+        np.random.seed(5)
+        t.step(Variable(xi), Variable(info), Variable(gt))
+    assert np.array_equal(rt.mem.to_numpy(tr.W), rt.mem.to_numpy(tr2.W)) and np.array_equal(rt.mem.to_numpy(tr.V), rt.mem.to_numpy(tr2.V))

@@ -26,6 +26,14 @@ def test_nms_edges(rt):
     P.check_nms_edges(rt)
 
 
+def test_gpu_nms_reference_ffi(rt):
+    """The reference's one C FFI, `_nms` (models/gpu_nms.hpp:9-10), exported with its exact signature."""
+    import torch
+    before = torch.cuda.current_device()
+    P.check_gpu_nms_ffi(rt)
+    assert torch.cuda.current_device() == before
+
+
 def test_nms_random(rt):
     P.check_nms_random(rt, n=3000, seeds=(0, 1, 2))
 

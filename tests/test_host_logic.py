@@ -23,6 +23,11 @@ def test_device_library_builds_and_exports_every_declared_symbol():
     lib = ctypes.CDLL(so)
     for name in _declared():
         assert hasattr(lib, name), name
+    assert hasattr(lib, "_nms")                         # the reference's own C FFI (models/gpu_nms.hpp:9-10), same name and signature
+    hdr = open(os.path.join(ROOT, "include", "frcnn_hip.h")).read()
+    ref = "void _nms(int* keep_out, int* num_out, const float* boxes_host, int boxes_num, int boxes_dim, float nms_overlap_thresh, int device_id);"
+    norm = lambda t: re.sub(r"\s+", "", t.replace("* ", "*").replace(" *", "*"))
+    assert norm(ref) in norm(hdr)
     import chainer_faster_rcnn_amd as pkg
     assert sorted(pkg._lib.SIGNATURES) == _declared()   # the binding table mirrors the header one to one
     assert lib.frcnn_abi_version() == 13

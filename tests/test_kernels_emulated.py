@@ -36,6 +36,11 @@ def test_nms_random(rt):
     P.check_nms_random(rt, n=700, seeds=(0,), thrs=(0.3, 0.7))
 
 
+def test_gpu_nms_reference_ffi(rt):
+    """`_nms` (models/gpu_nms.hpp:9-10) host-pointer wrapper: H2D, frcnn_nms, D2H, threshold recovery, error reporting."""
+    P.check_gpu_nms_ffi(rt, tags=("n300_t03", "n65_t05", "n1_t07"))
+
+
 def test_nms_batched(rt):
     P.check_nms_batched(rt, groups=3, n=150)
 

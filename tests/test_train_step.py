@@ -310,3 +310,84 @@ def test_bf16_copies_follow_the_optimizer(rt):
     fresh.load_params(trained)
     want = rt.mem.to_numpy(fresh.forward_device(xd, 40, 56, keep=True)["feat"])
     assert np.array_equal(after, want)
+
+
+# ---- snapshots in chainer's on-disk scheme (fixtures hand-built by tests/make_chainer_snapshot.py)
+def _fixture_model(rt):
+    import functools
+    from chainer_faster_rcnn_amd.models import FasterRCNN, VGG16Prev
+    model = FasterRCNN(trunk_class=functools.partial(VGG16Prev, layers=T.SMALL_LAYERS), rpn_in_ch=64, rpn_mid_ch=64, feat_stride=4,
+                       anchor_scales=(2, 4, 8), runtime=rt)
+    model.RPN.proposal_layer.RPN_MIN_SIZE = 4
+    model.RPN.proposal_layer._min_size = 4
+    return model
+
+
+def test_load_chainer_model_snapshot_fixture(rt, tmp_path):
+    """forward.py:29 `serializers.load_npz('data/VGG16_faster_rcnn_final.model', model)`: a file in chainer's key / layout scheme
+    (no .npz suffix, link-path keys, (out,in,kh,kw) / (out,in) arrays) drives inference; save_npz writes the same scheme back."""
+    import shutil
+    from chainer_faster_rcnn_amd.serializers import load_npz, namedparams, save_npz
+    src = os.path.join(HERE, "golden", "chainer_model_snapshot_small.npz")
+    path = str(tmp_path / "small_faster_rcnn_final.model")           # the reference's files carry no .npz suffix
+    shutil.copy(src, path)
+    with np.load(src) as f:
+        want = {k: f[k] for k in f.files}
+    model = load_npz(path, _fixture_model(rt))
+    got = {k: rt.mem.to_numpy(rt.mem.contiguous(v)) for k, v in namedparams(model)}
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k].shape == want[k].shape and np.array_equal(got[k], want[k]), k
+    ref = _fixture_model(rt)
+    ref.load_params(want)
+    x, _, _ = _step_inputs()
+    xd = rt.mem.from_numpy(x)
+    a, b = model.forward_device(xd, 40, 56), ref.forward_device(xd, 40, 56)
+    for k in a:
+        assert np.array_equal(rt.mem.to_numpy(a[k]), rt.mem.to_numpy(b[k])), k
+    out = str(tmp_path / "resaved.model")
+    save_npz(out, model)
+    assert os.path.exists(out) and not os.path.exists(out + ".npz")
+    with np.load(out) as f:
+        assert sorted(f.files) == sorted(want) and all(np.array_equal(f[k], want[k]) for k in want)
+
+
+def test_trainer_snapshot_fixture_and_resume(rt, tmp_path):
+    """train_rpn.py:101-105 `extensions.snapshot()`: parameters + MomentumSGD velocities + iteration in chainer's trainer tree; the
+    iterator / extension entries of such a file are ignored.  A run resumed from a snapshot continues bit-identically."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.serializers import load_trainer_npz, save_trainer_npz
+    from chainer_faster_rcnn_amd.train import RPNTrainer
+    src = os.path.join(HERE, "golden", "chainer_trainer_snapshot_small.npz")
+    with np.load(src) as f:
+        want = {k: f[k] for k in f.files}
+    model = _fixture_model(rt)
+    with np.load(os.path.join(HERE, "golden", "chainer_model_snapshot_small.npz")) as f:
+        model.load_params({k: f[k] for k in f.files})                # some other weights first
+    model.rpn_train = True
+    tr = load_trainer_npz(src, RPNTrainer(model))
+    assert tr.iteration == 37
+    w = tr.flat_to_chainer_layout(tr.W)
+    v = tr.flat_to_chainer_layout(tr.V)
+    for k in w:
+        assert np.array_equal(w[k], want["updater/model:main/" + k]), k
+        assert np.array_equal(v[k], want["updater/optimizer:main/" + k + "/v"]), k
+    # resume == continue: step the loaded trainer, snapshot, load into a second trainer, step both once more
+    x, gt, info = _step_inputs()
+    np.random.seed(3)
+    tr.step(Variable(x), Variable(info), Variable(gt))
+    path = str(tmp_path / "rpn_trainer_snapshot_38")
+    save_trainer_npz(path, tr)
+    with np.load(path) as f:
+        assert "updater/optimizer:main/trunk/conv2_1/W/v" in f.files and int(f["updater/iteration"]) == 38
+        assert f["updater/optimizer:main/RPN/rpn_cls_score/W/v"].shape == (18, 64, 1, 1)
+    model2 = _fixture_model(rt)
+    with np.load(os.path.join(HERE, "golden", "chainer_model_snapshot_small.npz")) as f:
+        model2.load_params({k: f[k] for k in f.files})
+    model2.rpn_train = True
+    tr2 = load_trainer_npz(path, RPNTrainer(model2))
+    for t in (tr, tr2):
+        np.random.seed(4)
+        t.step(Variable(x), Variable(info), Variable(gt))
+    assert tr2.iteration == tr.iteration == 39
+    assert np.array_equal(rt.mem.to_numpy(tr.W), rt.mem.to_numpy(tr2.W)) and np.array_equal(rt.mem.to_numpy(tr.V), rt.mem.to_numpy(tr2.V))
