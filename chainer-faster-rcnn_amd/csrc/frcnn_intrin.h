@@ -11,6 +11,13 @@ __device__ __forceinline__ float frcnn_max_f32(float a, float b) {
     return r;
 }
 
+// v_max3_f32: max(max(a, b), c) with the same NaN rule, one instruction for two updates of a running maximum
+__device__ __forceinline__ float frcnn_max3_f32(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // v_mfma_f32_32x32x16_bf16: D(32x32 f32) += A(32x16 bf16) * B(16x32 bf16).  Lane l supplies A[i = l&31][k = 8*(l>>5) .. +7] and
 // B[k = 8*(l>>5) .. +7][j = l&31], eight bf16 each = one uint4 (element t in the low/high half of word t/2); D uses the standard
 // 32x32 map (register r of lane l = row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31).

@@ -19,6 +19,7 @@
 // tests/test_oracle_pinned.py::test_roi_bin_edges_need_double_arithmetic).  Empty bins give 0 / argmax -1.
 #include "frcnn_common.h"
 #include <frcnn_intrin.h>   // angle brackets: shadowed by the test emulator
+#include <stdlib.h>
 
 namespace {
 
@@ -374,6 +375,244 @@ roi_pool_planes_kernel(const float *__restrict__ x, int C, int H, int W, const f
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cell-major forward (inference; the default when the map fits): the same LDS-resident idea with the data laid out for the
+// LDS itself.  The plane kernel above reads one float per lane (ds_read_b32: 128 B/clk per CU) from addresses that collide at
+// random across its (channel, pw) lanes -- PMC: ~45 % of its LDS cycles are bank conflicts, and the LDS array is what it waits
+// for.  Here a workgroup holds EIGHT channels of the whole map as 32-byte cells, cells[h][swz(w)] = {c0 .. c0+7}:
+//   * a lane reads 16 B = four channels of one cell (ds_read_b128: 256 B/clk per CU, 4x fewer LDS instructions per value, one
+//     address computation for four maxima);
+//   * lane = (pg, cq, pw): pg = which pair of output rows (ph = 2 pg, 2 pg + 1), cq = channel quad, pw = output column.  The
+//     hardware serves a ds_read_b128 in four fixed 16-lane groups; pg is exactly that group, so the lanes that share an LDS cycle
+//     read the two quads of SEVEN cells of one map row -- conflict-free when the seven columns differ mod 8 (a 256-byte bank row
+//     holds 8 cells), which the column swizzle swz(w) = (w & ~7) | ((w + (w >> 3)) & 7) arranges for every regular bin spacing
+//     (1, 2, 4, 8 cells: the spacings that alias without it);
+//   * every lane owns its bins outright (no cross-lane reduction, no staging pass, no wave barrier): it walks the wave's largest
+//     bin shape with clamped rows / columns -- a duplicate read cannot displace the first maximum -- so all loops are
+//     wave-uniform, and stores its 2 x 4 results straight to y;
+//   * bin edges come from two 72-entry tables the workgroup builds while its plane loads are in flight, with the oracle's double
+//     arithmetic (floor(p * (e / out)), ceil((p + 1) * (e / out))): a lookup per RoI instead of fourteen double divisions
+//     (extents >= 72 cells take the arithmetic path);
+//   * 78 KB of LDS and 512 threads per workgroup: TWO workgroups per CU, one loads its planes while the other scans.
+// Scan order = the oracle's: the bin's first cell, then NaN-ignoring maxima; a NaN first cell is restored at the end.
+constexpr int kCellPitch = 64;           // cells per LDS row
+constexpr int kCellWaves = 8;
+constexpr int kTabExt = 72;              // the bin tables cover extents 1 .. kTabExt-1
+
+__device__ __forceinline__ int cell_swz(int col) { return (col & ~7) | ((col + (col >> 3)) & 7); }
+
+__device__ __forceinline__ float4 max4(float4 a, float4 b) {
+    return make_float4(frcnn_max_f32(a.x, b.x), frcnn_max_f32(a.y, b.y), frcnn_max_f32(a.z, b.z), frcnn_max_f32(a.w, b.w));
+}
+__device__ __forceinline__ float4 max4_3(float4 a, float4 b, float4 c) {
+    return make_float4(frcnn_max3_f32(a.x, b.x, c.x), frcnn_max3_f32(a.y, b.y, c.y), frcnn_max3_f32(a.z, b.z, c.z), frcnn_max3_f32(a.w, b.w, c.w));
+}
+
+// One chunk of NC bin columns starting at k0: both of the lane's bins walk the rows of the wave's tallest bin together (8 reads
+// in flight per step), row addresses advance by one pitch and saturate at the bin's last row (a duplicate read cannot displace a
+// maximum), and the next step's cells are fetched before the current step's maxima are taken.
+template <int NC>
+__device__ __forceinline__ void cells_scan_chunk(const float4 *__restrict__ cells, int k0, int ws, int we, int cq, int W,
+                                                 const int (&r0)[2], const int (&r1)[2], int mbh, float4 (&acc)[2]) {
+    int ca[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) {
+        int col = min(ws + k0 + q, we - 1);
+        col = min(max(col, 0), W - 1);
+        ca[q] = cell_swz(col) * 2 + cq;
+    }
+    int row[2] = {r0[0], r0[1]};                    // float4 index of the current map row of each bin
+    auto fetch = [&](float4 (&buf)[2][NC]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int q = 0; q < NC; ++q) buf[s][q] = cells[row[s] + ca[q]];
+    };
+    auto advance = [&]() {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) row[s] = min(row[s] + kCellPitch * 2, r1[s]);
+    };
+    auto take = [&](const float4 (&buf)[2][NC]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            if constexpr (NC == 1) acc[s] = max4(acc[s], buf[s][0]);
+            else if constexpr (NC == 2) acc[s] = max4_3(acc[s], buf[s][0], buf[s][1]);
+            else if constexpr (NC == 3) acc[s] = max4(max4_3(acc[s], buf[s][0], buf[s][1]), buf[s][2]);
+            else acc[s] = max4_3(max4_3(acc[s], buf[s][0], buf[s][1]), buf[s][2], buf[s][3]);
+        }
+    };
+    // two register buffers in ping-pong: the row after next is in flight while the maxima of the current row are taken
+    float4 a[2][NC], b[2][NC];
+    fetch(a);
+    int left = mbh - 1;                             // rows still to fetch (wave-uniform)
+#pragma unroll 1
+    while (left >= 2) {
+        advance(); fetch(b);
+        __builtin_amdgcn_sched_barrier(0);          // keep the fetches ABOVE the maxima: they fly while the VALU works
+        take(a);
+        advance(); fetch(a);
+        __builtin_amdgcn_sched_barrier(0);
+        take(b);
+        left -= 2;
+    }
+    if (left == 1) {
+        advance(); fetch(b);
+        __builtin_amdgcn_sched_barrier(0);
+        take(a);
+        take(b);
+    } else {
+        take(a);
+    }
+}
+
+template <int kRows, bool OUT16>
+__global__ void __launch_bounds__(64 * kCellWaves)
+roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const float *__restrict__ rois, int roi_cols, int R,
+                      int outh, int outw, float scale, float *__restrict__ y, int rsplit) {
+    __shared__ __attribute__((aligned(16))) float4 cells[kRows * kCellPitch * 2];
+    __shared__ uint16_t tab[2][kTabExt][8];            // [0] rows (outh), [1] columns (outw): lo | hi << 8, relative to the RoI origin
+    __shared__ uint8_t tabmax[2][kTabExt];             // tallest / widest bin of an extent
+    __shared__ int next_roi;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = H * W, bins = outh * outw;
+    const int c0 = blockIdx.x * 8;
+    const int g0 = blockIdx.y;
+
+    // ---- 8 channel planes -> cells: one map row per wave and step (coalesced NCHW rows), all loads issued before the table
+    //      arithmetic below and landing during it
+    constexpr int kRowsPerWave = (kRows + kCellWaves - 1) / kCellWaves;
+    float v[kRowsPerWave][8];
+#pragma unroll
+    for (int i = 0; i < kRowsPerWave; ++i) {
+        const int h = wave + i * kCellWaves;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            v[i][c] = (h < H && lane < W && c0 + c < C) ? x[(size_t)(c0 + c) * HW + h * W + lane] : 0.0f;
+    }
+    if (tid == 0) next_roi = 0;
+    for (int e = tid; e < 2 * kTabExt * 8; e += 64 * kCellWaves) {
+        const int t = e / (kTabExt * 8), ext = (e >> 3) % kTabExt, p = e & 7;
+        const int out = t ? outw : outh;
+        int lo = 0, hi = 0;
+        if (p < out && ext > 0) {
+            const double stride = (double)ext / (double)out;            // bin_range()'s arithmetic, offset and clamp applied per RoI
+            lo = (int)floor((double)p * stride);
+            hi = (int)ceil((double)(p + 1) * stride);
+        }
+        tab[t][ext][p] = (uint16_t)(lo | (hi << 8));
+    }
+#pragma unroll
+    for (int i = 0; i < kRowsPerWave; ++i) {
+        const int h = wave + i * kCellWaves;
+        if (h < H && lane < W) {
+            float4 *dst = cells + (h * kCellPitch + cell_swz(lane)) * 2;
+            dst[0] = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+            dst[1] = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
+        }
+    }
+    __syncthreads();
+    if (tid < 2 * kTabExt) {
+        const int t = tid / kTabExt, ext = tid % kTabExt;
+        int m = 0;
+        for (int p = 0; p < 8; ++p) { const int u = tab[t][ext][p]; m = max(m, (u >> 8) - (u & 255)); }
+        tabmax[t][ext] = (uint8_t)m;
+    }
+    __syncthreads();
+
+    // ---- lane -> (pg, cq, pw): pg = the hardware's ds_read_b128 lane group ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32)
+    const int l5 = lane & 31;
+    const bool in_a = (l5 < 4) || (l5 >= 12 && l5 < 16) || (l5 >= 20 && l5 < 28);
+    const int j = in_a ? (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12)) : (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16));
+    const int pg = (lane >> 5) * 2 + (in_a ? 0 : 1);
+    const int cq = j & 1, pw = j >> 1;
+    const bool pw_on = pw < outw;
+
+    for (;;) {
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&next_roi, 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        const int r = g0 + slot * rsplit;
+        if (r >= R) break;
+        const RoiGeom g = roi_geometry(rois + (size_t)roi_cols * r + (roi_cols - 5), scale);
+        int ws, we, hs[2], he[2], mbw, mbh;
+        if (g.rw < kTabExt && g.rh < kTabExt) {                         // wave-uniform
+            const int tw = tab[1][g.rw][min(pw, 7)];
+            ws = min(max((tw & 255) + g.xs, 0), W);
+            we = min(max((tw >> 8) + g.xs, 0), W);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int th = tab[0][g.rh][min(2 * pg + s, 7)];
+                hs[s] = min(max((th & 255) + g.ys, 0), H);
+                he[s] = min(max((th >> 8) + g.ys, 0), H);
+            }
+            mbw = tabmax[1][g.rw];
+            mbh = tabmax[0][g.rh];
+        } else {                                                        // huge RoI: the arithmetic itself, trip counts = the map
+            bin_range(min(pw, outw - 1), g.rw, outw, g.xs, W, ws, we);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) bin_range(min(2 * pg + s, outh - 1), g.rh, outh, g.ys, H, hs[s], he[s]);
+            mbw = W;
+            mbh = H;
+        }
+        mbw = min(__builtin_amdgcn_readfirstlane(mbw), W);
+        mbh = min(__builtin_amdgcn_readfirstlane(mbh), H);
+        // per bin: first / last map row as float4 indices (clamped into the map so an empty bin still reads valid cells); the bin's
+        // first cell seeds the maximum (the oracle's scan order)
+        int r0[2], r1[2];
+        float4 first[2], acc[2];
+        const int c_first = cell_swz(min(max(ws, 0), W - 1)) * 2 + cq;
+        bool any_empty = we <= ws;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int h0 = min(max(hs[s], 0), H - 1);
+            r0[s] = h0 * (kCellPitch * 2);
+            r1[s] = min(max(he[s] - 1, h0), H - 1) * (kCellPitch * 2);
+            first[s] = cells[r0[s] + c_first];
+            acc[s] = first[s];
+            any_empty = any_empty || (he[s] <= hs[s]);
+        }
+#pragma unroll 1
+        for (int k0 = 0; k0 < mbw; k0 += 4) {
+            const int nc = min(mbw - k0, 4);                            // wave-uniform
+            if (nc >= 4) cells_scan_chunk<4>(cells, k0, ws, we, cq, W, r0, r1, mbh, acc);
+            else if (nc == 3) cells_scan_chunk<3>(cells, k0, ws, we, cq, W, r0, r1, mbh, acc);
+            else if (nc == 2) cells_scan_chunk<2>(cells, k0, ws, we, cq, W, r0, r1, mbh, acc);
+            else cells_scan_chunk<1>(cells, k0, ws, we, cq, W, r0, r1, mbh, acc);
+        }
+        // rare fix-ups behind ONE wave-level test: a NaN first cell stays (`>` never replaces it: x + y + z + w is NaN iff one of them
+        // is), an empty bin is 0
+        const float nan_probe = (first[0].x + first[0].y) + (first[0].z + first[0].w) + (first[1].x + first[1].y) + (first[1].z + first[1].w);
+        if (__any((nan_probe != nan_probe) || any_empty)) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bool empty = (he[s] <= hs[s]) || (we <= ws);
+                if (first[s].x != first[s].x) acc[s].x = first[s].x;
+                if (first[s].y != first[s].y) acc[s].y = first[s].y;
+                if (first[s].z != first[s].z) acc[s].z = first[s].z;
+                if (first[s].w != first[s].w) acc[s].w = first[s].w;
+                if (empty) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int ph = 2 * pg + s;
+            const float o[4] = {acc[s].x, acc[s].y, acc[s].z, acc[s].w};
+            if (pw_on && ph < outh) {
+                const int cbase = c0 + 4 * cq;
+                const size_t dst = ((size_t)r * C + cbase) * bins + ph * outw + pw;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (cbase + q < C) {
+                        if constexpr (OUT16) reinterpret_cast<uint16_t *>(y)[dst + (size_t)q * bins] = (uint16_t)roi_f32_to_bf16(o[q]);
+                        else y[dst + (size_t)q * bins] = o[q];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // dx[c, argmax] += dy for every (roi, c, bin) with argmax >= 0 (Chainer backward_cpu).  fp32 atomics:
 // the accumulation order differs from the reference's roi-major loop only in rounding.
 __global__ void __launch_bounds__(256)
@@ -386,6 +625,28 @@ roi_pool_bwd_kernel(const float *__restrict__ dy, const int32_t *__restrict__ ar
             atomicAdd(&dx[(size_t)c * HW + a], dy[i]);
         }
     }
+}
+
+static int frcnn_roi_cu_count();
+
+// Launch the cell-major kernel when the map fits its LDS image (W <= 64 cells per row; H <= 38: two workgroups per CU,
+// H <= 76: one).  FRCNN_ROI_KERNEL=planes keeps the plane kernel (A/B measurements).  Returns false when it does not apply.
+template <bool OUT16>
+static bool roi_cells_launch(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
+                             float scale, float *y, hipStream_t stream) {
+    const char *sel = getenv("FRCNN_ROI_KERNEL");
+    if (sel && sel[0] == 'p') return false;
+    if (W > kCellPitch || H > 76) return false;
+    const int cgroups = frcnn_cdiv(C, 8);
+    const int per_cu = H <= 38 ? 2 : 1;
+    int rsplit = frcnn_cdiv(per_cu * frcnn_roi_cu_count(), cgroups);       // about `per_cu` resident workgroups per CU
+    const int max_split = frcnn_cdiv(R, kCellWaves);                         // at least one RoI per wave
+    if (rsplit > max_split) rsplit = max_split;
+    if (rsplit < 1) rsplit = 1;
+    const dim3 grid(cgroups, rsplit), blk(64 * kCellWaves);
+    if (H <= 38) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<38, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<76, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit);
+    return true;
 }
 
 static int frcnn_roi_cu_count() {
@@ -447,6 +708,7 @@ int frcnn_roi_pool_fwd_chw(const float *x, int C, int H, int W, const float *roi
     if (!x || !rois || !y || C < 1 || H < 1 || W < 1 || R < 0) return FRCNN_ERR_INVALID;
     if (outh < 1 || outw < 1 || outh > 7 || outw > 7 || (roi_cols != 4 && roi_cols != 5)) return FRCNN_ERR_INVALID;
     if (R == 0) return FRCNN_OK;
+    if (!argmax && roi_cells_launch<false>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, y, stream)) return frcnn_launch_status();
     const int cg = roi_planes_per_group(C, H, W, outh, outw);
     if (cg == 0) {     // map too large for LDS-resident planes: channel-last gather kernel
         if (!workspace || workspace_bytes < frcnn_roi_pool_workspace_bytes(C, H, W)) return FRCNN_ERR_INVALID;
@@ -474,6 +736,7 @@ int frcnn_roi_pool_fwd_chw_bf16(const float *x, int C, int H, int W, const float
     if (!x || !rois || !y || C < 1 || H < 1 || W < 1 || R < 0) return FRCNN_ERR_INVALID;
     if (outh < 1 || outw < 1 || outh > 7 || outw > 7 || (roi_cols != 4 && roi_cols != 5)) return FRCNN_ERR_INVALID;
     if (R == 0) return FRCNN_OK;
+    if (roi_cells_launch<true>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, reinterpret_cast<float *>(y), stream)) return frcnn_launch_status();
     const int cg = roi_planes_per_group(C, H, W, outh, outw);
     if (cg == 0) return FRCNN_ERR_INVALID;          // plane-resident kernel only: convert an fp32 result with frcnn_f32_to_bf16 instead
     const int cgroups = frcnn_cdiv(C, cg);

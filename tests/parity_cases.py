@@ -172,6 +172,33 @@ def check_roi_pool(rt, R=12, C=128, H=38, W=63, seed=0):
     assert np.allclose(host(rt, dx), want_dx, rtol=1e-4, atol=1e-4)    # atomics: summation order differs
 
 
+def check_roi_pool_cells(rt):
+    """The cell-major inference kernel (maps up to 76 x 64): ragged channel counts, non-7x7 outputs, the tall-map instantiation,
+    RoIs larger than the bin tables, and the oracle's NaN rule -- a NaN in a bin's FIRST cell stays, NaNs elsewhere never win."""
+    for (R, C, H, W, oh, ow, seed) in [(23, 16, 38, 63, 7, 7, 0), (9, 11, 19, 32, 7, 7, 1), (11, 8, 50, 40, 7, 7, 2), (7, 24, 12, 17, 3, 5, 3),
+                                        (5, 8, 38, 63, 1, 1, 4), (6, 8, 76, 64, 6, 7, 5)]:
+        rs = np.random.RandomState(seed)
+        x, rois = roi_case(rs, R, C, H, W)
+        if seed == 0:                                   # NaNs: top-left cell of some bins, and interior cells
+            x[0, 3, 5, 7] = np.nan
+            x[0, 3, 6, 9] = np.nan
+            x[0, 12, 0, 0] = np.nan
+            x[0, 5, 20, 30:34] = np.nan
+            rois[0] = [0, 7 * 16, 5 * 16, 30 * 16, 20 * 16]        # bin (0,0) starts exactly at the NaN cell (5,7)
+            rois[1] = [0, 0, 0, 40 * 16, 30 * 16]
+            rois[2] = [0, 30 * 16, 20 * 16, 33 * 16, 20 * 16]      # a one-row RoI made of NaNs
+        if seed == 2:
+            rois[0] = [0, -3000, -2000, 9000, 7000]                 # extent >= 72 cells: the arithmetic path
+        want = O.roi_pooling_2d(x, rois, oh, ow, 0.0625)
+        got = host(rt, rt.roi_pool_fwd(dev(rt, x[0]), dev(rt, rois), oh, ow, 0.0625))
+        assert np.array_equal(np.isnan(got), np.isnan(want)), (R, C, H, W)
+        assert np.array_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(want, nan=-1.0)), (R, C, H, W, oh, ow)
+        if W <= 64 and hasattr(rt, "roi_pool_fwd_chw_bf16") and seed in (1, 3):
+            _, want_bits = to_bf16(want.reshape(R, -1))
+            y5 = host(rt, rt.roi_pool_fwd_chw_bf16(dev(rt, x[0]), dev(rt, np.ascontiguousarray(rois[:, 1:])), oh, ow, 0.0625))
+            assert np.array_equal(y5.view(np.uint16), want_bits.view(np.uint16).reshape(y5.shape))
+
+
 # ------------------------------------------------------------------------------------------- conv stack
 def check_conv3x3(rt, Cin, Cout, H, W, cfg=-1, seed=0, relu=True):
     rs = np.random.RandomState(seed)

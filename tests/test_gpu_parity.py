@@ -65,6 +65,20 @@ def test_proposals_repeatable(rt):
         assert all(np.array_equal(u, v) for u, v in zip(a, b))
 
 
+def test_roi_pool_cells_kernel(rt):
+    P.check_roi_pool_cells(rt)
+
+
+def test_roi_pool_kernels_agree_at_full_size(rt, monkeypatch):
+    """The cell-major kernel (default) and the plane kernel (FRCNN_ROI_KERNEL=planes) give the same 300 x 512 x 7 x 7 bits."""
+    rs = np.random.RandomState(3)
+    x, rois = P.roi_case(rs, 300, 512, 38, 63)
+    a = P.host(rt, rt.roi_pool_fwd(P.dev(rt, x[0]), P.dev(rt, rois), 7, 7, 0.0625))
+    monkeypatch.setenv("FRCNN_ROI_KERNEL", "planes")
+    b = P.host(rt, rt.roi_pool_fwd(P.dev(rt, x[0]), P.dev(rt, rois), 7, 7, 0.0625))
+    assert np.array_equal(a, b)
+
+
 def test_roi_pool_full_size(rt):
     P.check_roi_pool(rt, R=300, C=512, H=38, W=63)        # BASELINE config: 300 x 512 x 7 x 7
     P.check_roi_pool(rt, R=7, C=64, H=19, W=32, seed=2)   # VEC=1 path
