@@ -25,11 +25,13 @@
 // with -ffp-contract=off), IEEE division, exp evaluated in double and rounded to fp32, IoU threshold test
 // `(double)iou >= thresh` (cpu_nms.pyx:18,66).
 #include "frcnn_common.h"
+#include <stdlib.h>
 #include <frcnn_sync.h>     // angle brackets: shadowed by the test emulator
 
 namespace {
 
-constexpr int kSortTile = 1024;   // keys per bitonic tile
+constexpr int kSortTile = 4096;   // keys per bitonic tile (one 1024-thread workgroup, 4 keys per thread)
+constexpr int kSortThreads = 1024;
 constexpr int kChunk = 64;        // NMS chunk = wave width
 
 __device__ __forceinline__ uint32_t ordered_bits(float f) {
@@ -99,9 +101,13 @@ proposal_decode_kernel(const float *__restrict__ cls_prob, const float *__restri
     } else if (t < n_pad) {
         keys[t] = 0ull;   // padding of the last sort tile
     }
-    // n_valid: one atomic per wave
+    // n_valid: every block leaves ITS count in counters[1 + blockIdx.x] (plain stores: no zeroed counter, no memset launch, no
+    // atomics); rank_scatter_kernel's first block adds them up into counters[0] for the NMS kernels
+    __shared__ int wave_count[4];
     const unsigned long long bal = __ballot(valid);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&counters[0], (int)__popcll(bal));
+    if ((threadIdx.x & 63) == 0) wave_count[threadIdx.x >> 6] = (int)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) counters[1 + blockIdx.x] = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
 }
 
 // keys for frcnn_nms(): every row of the (n,5) dets array takes part.
@@ -118,27 +124,61 @@ dets_keys_kernel(const float *__restrict__ dets, int n, int n_pad, unsigned long
 }
 
 // ------------------------------------------------------------------------------------------------
-// Bitonic sort (descending) of one 1024-key tile in LDS.
-__global__ void __launch_bounds__(256)
+// Bitonic sort (descending) of one 4096-key tile by one 1024-thread workgroup.  Thread t holds elements t, t + 1024, t + 2048,
+// t + 3072 in registers, so a compare-exchange at distance j is
+//   j >= 1024   between two of the thread's own registers          (no communication)
+//   j <  64     with lane ^ j of the same wave                      (__shfl_xor: no LDS image, no barrier)
+//   otherwise   with another wave                                   (through LDS, two barriers)
+// 78 network steps, of which only 18 touch LDS (the all-LDS version of round 1 ran 55 barrier-separated passes per 1024 keys).
+// Element i keeps the larger key of the pair (i, i ^ j) iff (i & j) == 0 is equal to ((i & k) == 0): the usual bitonic rule, descending.
+__global__ void __launch_bounds__(kSortThreads)
 tile_sort_kernel(unsigned long long *__restrict__ keys, size_t slab) {
     __shared__ unsigned long long s[kSortTile];
     keys = slab_ptr(keys, slab);
     unsigned long long *g = keys + (size_t)blockIdx.x * kSortTile;
-    for (int t = threadIdx.x; t < kSortTile; t += 256) s[t] = g[t];
-    __syncthreads();
+    const int tid = threadIdx.x;
+    unsigned long long key[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) key[r] = g[r * kSortThreads + tid];
     for (int k = 2; k <= kSortTile; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int q = threadIdx.x; q < kSortTile / 2; q += 256) {
-                const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1));
-                const int l = i | j;
-                const unsigned long long x = s[i], y = s[l];
-                const bool desc = (i & k) == 0;
-                if (desc ? (x < y) : (x > y)) { s[i] = y; s[l] = x; }
+            if (j >= kSortThreads) {
+                const int dr = j / kSortThreads;                   // 1 or 2
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if ((r & dr) == 0) {
+                        const int i = r * kSortThreads + tid;
+                        const bool desc = (i & k) == 0;
+                        const unsigned long long a = key[r], b = key[r | dr];
+                        const bool swap = desc ? (a < b) : (a > b);
+                        if (swap) { key[r] = b; key[r | dr] = a; }
+                    }
+                }
+            } else {
+                unsigned long long other[4];
+                if (j >= 64) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s[r * kSortThreads + tid] = key[r];
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) other[r] = s[r * kSortThreads + (tid ^ j)];
+                    __syncthreads();
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) other[r] = __shfl_xor(key[r], j);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = r * kSortThreads + tid;
+                    const bool keep_max = ((i & j) == 0) == ((i & k) == 0);
+                    const bool gt = other[r] > key[r];
+                    key[r] = (keep_max == gt) ? other[r] : key[r];
+                }
             }
-            __syncthreads();
         }
     }
-    for (int t = threadIdx.x; t < kSortTile; t += 256) g[t] = s[t];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g[r * kSortThreads + tid] = key[r];
 }
 
 // number of elements of the descending-sorted tile (in LDS) that are > key
@@ -158,15 +198,26 @@ __device__ __forceinline__ int count_greater(const unsigned long long *tile, uns
 // Ranks below limit = min(n_valid, top_k) are gathered into score order.
 __global__ void __launch_bounds__(256)
 rank_scatter_kernel(const unsigned long long *__restrict__ keys, int n_tiles, const float *__restrict__ boxes_in, int box_stride,
-                    const float *__restrict__ scores_in, int score_stride, int top_k, const int *__restrict__ counters,
+                    const float *__restrict__ scores_in, int score_stride, int top_k, int *__restrict__ counters_rw, int n_count_blocks,
                     int32_t *__restrict__ order, float *__restrict__ sorted_boxes, float *__restrict__ sorted_scores,
                     size_t in_gs, size_t slab) {
     __shared__ unsigned long long tile[2][kSortTile];
     boxes_in += blockIdx.z * in_gs; scores_in += blockIdx.z * in_gs;
-    keys = slab_ptr(keys, slab); counters = slab_ptr(counters, slab);
+    keys = slab_ptr(keys, slab);
     order = slab_ptr(order, slab); sorted_boxes = slab_ptr(sorted_boxes, slab); sorted_scores = slab_ptr(sorted_scores, slab);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;       // position in the tile-sorted key array (< n_tiles*1024)
     const unsigned long long key = keys[t];
+    // n_valid = the decode blocks' counts, summed once (ProposalLayer path; frcnn_nms sets counters[0] itself: n_count_blocks = 0)
+    if (blockIdx.x == 0 && n_count_blocks > 0) {
+        __shared__ int partial[4];
+        int *cw = slab_ptr(counters_rw, slab);
+        int acc = 0;
+        for (int b = threadIdx.x; b < n_count_blocks; b += 256) acc += cw[1 + b];
+        for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+        if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) cw[0] = partial[0] + partial[1] + partial[2] + partial[3];
+    }
     unsigned long long stage[kSortTile / 256];
 #pragma unroll
     for (int q = 0; q < kSortTile / 256; ++q) tile[0][threadIdx.x + 256 * q] = keys[threadIdx.x + 256 * q];
@@ -187,9 +238,8 @@ rank_scatter_kernel(const unsigned long long *__restrict__ keys, int n_tiles, co
         cur ^= 1;
     }
     if (key == 0ull) return;                                   // filtered-out / padding element
-    int limit = counters[0];
-    if (top_k > 0 && top_k < limit) limit = top_k;
-    if (rank < limit) {
+    // a valid key's rank (the number of larger keys) is below n_valid by construction: only the top-K cut needs testing
+    if (top_k <= 0 || rank < top_k) {
         const uint32_t idx = key_index(key);
         order[rank] = (int32_t)idx;
         const float *b = boxes_in + (size_t)idx * box_stride;
@@ -199,57 +249,65 @@ rank_scatter_kernel(const unsigned long long *__restrict__ keys, int n_tiles, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// Suppression bitmask.  Block = 4 waves; wave w of block (bx,by) handles row chunk by against column
-// chunk 4*bx+w.  Lane = row box.  mask[row*pitch + colchunk] bit t  <=>  box (colchunk*64+t) comes later
-// in score order than `row` and IoU(row, it) >= thresh in the reference's arithmetic.
+// Suppression bitmask, wave-ballot form.  mask[row*pitch + colchunk] bit t  <=>  box (colchunk*64+t) comes later in score
+// order than `row` and IoU(row, it) >= thresh in the reference's arithmetic.
+// One wave = one 64 x 64 tile of the UPPER triangle only (tiles are enumerated linearly: no launched-and-idle lower half).
+// Lane = COLUMN box (its coordinates and area live in registers for the whole tile); the 64 row boxes are walked one per step,
+// each broadcast from the lane that loaded it (v_readlane -> scalar operands), so the suppression test of a step is one
+// wave-wide compare whose 64-bit result IS the row's mask word -- no per-lane bit loop, no LDS, no barrier.  Lane t keeps the
+// word of row t and the tile leaves as 64 eight-byte stores.
 __device__ __forceinline__ float ref_max(float a, float b) { return a >= b ? a : b; }   // cpu_nms.pyx:12-13
 __device__ __forceinline__ float ref_min(float a, float b) { return a <= b ? a : b; }   // cpu_nms.pyx:15-16
+__device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 
 __global__ void __launch_bounds__(256)
 nms_mask_kernel(const float *__restrict__ sorted_boxes, const int *__restrict__ counters, int top_k, double thresh,
                 unsigned long long *__restrict__ mask, int pitch, size_t slab) {
-    __shared__ float cbox[4][kChunk][5];
     sorted_boxes = slab_ptr(sorted_boxes, slab); counters = slab_ptr(counters, slab); mask = slab_ptr(mask, slab);
     int m = counters[0];
     if (top_k > 0 && top_k < m) m = top_k;
     const int n_chunks = (m + kChunk - 1) / kChunk;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int rc = blockIdx.y, cc = blockIdx.x * 4 + wave;
-    const bool active = (rc < n_chunks) && (cc < n_chunks) && (cc >= rc);
-    if (active) {
-        const int c = cc * kChunk + lane;
-        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < m) b = reinterpret_cast<const float4 *>(sorted_boxes)[c];
-        cbox[wave][lane][0] = b.x; cbox[wave][lane][1] = b.y; cbox[wave][lane][2] = b.z; cbox[wave][lane][3] = b.w;
-        cbox[wave][lane][4] = (b.z - b.x + 1.0f) * (b.w - b.y + 1.0f);     // areas, cpu_nms.pyx:25
-    }
-    __syncthreads();
-    if (!active) return;
-    const int r = rc * kChunk + lane;
-    if (r >= m) return;
-    const float4 rb = reinterpret_cast<const float4 *>(sorted_boxes)[r];
-    const float rarea = (rb.z - rb.x + 1.0f) * (rb.w - rb.y + 1.0f);
+    // linear upper-triangle tile index -> (rc, cc), rows enumerated over the STATIC pitch (the launch is sized before m is known)
+    const long long T = (long long)blockIdx.x * 4 + wave;
+    const long long total = (long long)pitch * (pitch + 1) / 2;
+    if (T >= total) return;
+    // row rc starts at S(rc) = rc * pitch - rc (rc - 1) / 2; invert with a float estimate and fix up
+    int rc = (int)((2.0 * pitch + 1.0 - sqrt((2.0 * pitch + 1.0) * (2.0 * pitch + 1.0) - 8.0 * (double)T)) * 0.5);
+    rc = min(max(rc, 0), pitch - 1);
+    while (rc > 0 && (long long)rc * pitch - (long long)rc * (rc - 1) / 2 > T) --rc;
+    while (rc + 1 < pitch && (long long)(rc + 1) * pitch - (long long)(rc + 1) * rc / 2 <= T) ++rc;
+    const int cc = rc + (int)(T - ((long long)rc * pitch - (long long)rc * (rc - 1) / 2));
+    if (rc >= n_chunks || cc >= n_chunks) return;                      // wave-uniform
+    const int c = cc * kChunk + lane, r = rc * kChunk + lane;
+    float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), rb = cb;
+    if (c < m) cb = reinterpret_cast<const float4 *>(sorted_boxes)[c];
+    if (r < m) rb = reinterpret_cast<const float4 *>(sorted_boxes)[r];
+    const float carea = (cb.z - cb.x + 1.0f) * (cb.w - cb.y + 1.0f);  // areas, cpu_nms.pyx:25
+    const float rarea_l = (rb.z - rb.x + 1.0f) * (rb.w - rb.y + 1.0f);
     const float thr_f = (float)thresh;
-    const bool fast_ok = (thresh > 1e-6) && (rarea > 0.0f);
-    unsigned long long bits = 0ull;
-    const int t_end = min(kChunk, m - cc * kChunk);
-    const int t_begin = (cc == rc) ? lane + 1 : 0;        // only later boxes can be suppressed by `r`
-    for (int t = 0; t < t_end; ++t) {
-        const float cx1 = cbox[wave][t][0], cy1 = cbox[wave][t][1], cx2 = cbox[wave][t][2], cy2 = cbox[wave][t][3];
-        const float carea = cbox[wave][t][4];
-        const float xx1 = ref_max(rb.x, cx1), yy1 = ref_max(rb.y, cy1);          // cpu_nms.pyx:58-61
-        const float xx2 = ref_min(rb.z, cx2), yy2 = ref_min(rb.w, cy2);
+    const bool col_ok = c < m;
+    const int t_rows = min(kChunk, m - rc * kChunk);
+    unsigned long long word = 0ull;
+    for (int t = 0; t < t_rows; ++t) {
+        const float rx1 = lane_bcast(rb.x, t), ry1 = lane_bcast(rb.y, t), rx2 = lane_bcast(rb.z, t), ry2 = lane_bcast(rb.w, t);
+        const float rarea = lane_bcast(rarea_l, t);
+        const float xx1 = ref_max(rx1, cb.x), yy1 = ref_max(ry1, cb.y);          // cpu_nms.pyx:58-61 (i = the row box, j = the column box)
+        const float xx2 = ref_min(rx2, cb.z), yy2 = ref_min(ry2, cb.w);
         const float w = ref_max(0.0f, xx2 - xx1 + 1.0f), h = ref_max(0.0f, yy2 - yy1 + 1.0f);   // :62-63
         const float inter = w * h;                                               // :64
         const float uni = rarea + carea - inter;                                 // :65
-        bool sup;
         const float tt = thr_f * uni;
-        if (fast_ok && carea > 0.0f && inter >= tt * 1.0001f) sup = true;         // clear of the rounding band
-        else if (fast_ok && carea > 0.0f && inter <= tt * 0.9999f) sup = false;
+        const bool fast_ok = (thresh > 1e-6) && (rarea > 0.0f) && (carea > 0.0f);
+        bool sup;
+        if (fast_ok && inter >= tt * 1.0001f) sup = true;                        // clear of the rounding band
+        else if (fast_ok && inter <= tt * 0.9999f) sup = false;
         else sup = (double)(inter / uni) >= thresh;                              // exact: IEEE divide, double compare (:65-66)
-        if (sup && t >= t_begin) bits |= 1ull << t;
+        unsigned long long bal = __ballot(sup && col_ok);
+        if (cc == rc) bal &= (t == 63) ? 0ull : (~0ull << (t + 1));              // only later boxes can be suppressed by row t
+        if (lane == t) word = bal;
     }
-    mask[(size_t)r * pitch + cc] = bits;
+    if (r < m) mask[(size_t)r * pitch + cc] = word;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -462,10 +520,158 @@ nms_scan_wave_kernel(const unsigned long long *__restrict__ mask, int pitch, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// The single-wave pass, FOUR chunks per memory round trip.  The chain of the kernel above is one dependent trip to the mask per
+// 64-box chunk (the rows of the boxes it keeps must be OR-ed in before the next chunk can be resolved): 94 trips for 6000 boxes,
+// ~0.45 us each -- the mask was written by other XCDs, so every trip goes to the Infinity Cache.  Here a "super-chunk" of 256 boxes
+// is resolved from registers: its 4 x 4 block of diagonal words (the upper 10; lane l holds row l of each sub-chunk) is prefetched
+// one super-chunk ahead, suppression INSIDE the super-chunk is propagated with v_readlane as boxes are kept, and the rows of all
+// boxes kept in the super-chunk are fetched together (up to 16 in flight) for the chunks after it: one exposed trip per 256 boxes.
+template <int NJ>
+__global__ void __launch_bounds__(64)
+nms_scan_wave4_kernel(const unsigned long long *__restrict__ mask, int pitch, const int *__restrict__ counters_in, int top_k,
+                      int max_out, const int32_t *__restrict__ order, const float *__restrict__ sorted_boxes,
+                      const float *__restrict__ sorted_scores, int32_t *__restrict__ keep_pos, int32_t *__restrict__ out_index,
+                      float *__restrict__ out_boxes, float *__restrict__ out_scores, int32_t *__restrict__ n_out,
+                      int out_capacity, size_t slab, size_t out_gs) {
+    const int gz = blockIdx.z;
+    counters_in = slab_ptr(counters_in, slab); mask = slab_ptr(mask, slab); order = slab_ptr(order, slab);
+    sorted_boxes = slab_ptr(sorted_boxes, slab); sorted_scores = slab_ptr(sorted_scores, slab); keep_pos = slab_ptr(keep_pos, slab);
+    if (out_index) out_index += gz * out_gs;
+    if (out_boxes) out_boxes += gz * out_gs * 4;
+    if (out_scores) out_scores += gz * out_gs;
+    n_out += gz;
+    int m = counters_in[0];
+    if (top_k > 0 && top_k < m) m = top_k;
+    const int limit = (max_out > 0 && max_out < m) ? max_out : m;
+    const int n_chunks = (m + kChunk - 1) / kChunk;
+    const int n_super = (n_chunks + 3) / 4;
+    const int lane = threadIdx.x;
+    unsigned long long rem[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) rem[j] = 0ull;
+    int n_kept = 0;
+    unsigned long long dnext[4][4];
+    auto load_diag = [&](int S, unsigned long long (&D)[4][4]) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = a; b < 4; ++b) {
+                const int row = (4 * S + a) * kChunk + lane, col = 4 * S + b;
+                D[a][b] = (row < m && col < n_chunks) ? mask[(size_t)row * pitch + col] : 0ull;
+            }
+    };
+    load_diag(0, dnext);
+    for (int S = 0; S < n_super && n_kept < limit; ++S) {
+        unsigned long long D[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = a; b < 4; ++b) D[a][b] = dnext[a][b];
+        if (S + 1 < n_super) load_diag(S + 1, dnext);              // lands while this super-chunk is resolved
+        unsigned long long local[4] = {0ull, 0ull, 0ull, 0ull};    // bits removed by boxes kept INSIDE this super-chunk (wave-uniform)
+        unsigned long long keptw[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int c = 4 * S + a;
+            if (c < n_chunks && n_kept < limit) {                   // wave-uniform
+                unsigned long long sel = rem[0];
+#pragma unroll
+                for (int j = 1; j < NJ; ++j) sel = ((c >> 6) == j) ? rem[j] : sel;
+                const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sel, c & 63);
+                const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sel >> 32), c & 63);
+                const int in_chunk = min(kChunk, m - c * kChunk);
+                const unsigned long long valid = in_chunk == 64 ? ~0ull : ((1ull << in_chunk) - 1ull);
+                unsigned long long alive = ~((((unsigned long long)rhi << 32) | rlo) | local[a]) & valid;
+                unsigned long long kept = 0ull;
+                int budget = limit - n_kept;
+                while (alive != 0ull && budget > 0) {
+                    const int i = __ffsll((long long)alive) - 1;
+                    kept |= 1ull << i;
+                    --budget;
+#pragma unroll
+                    for (int b = a; b < 4; ++b) {
+                        const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)D[a][b], i);
+                        const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(D[a][b] >> 32), i);
+                        const unsigned long long w = ((unsigned long long)shi << 32) | slo;
+                        if (b == a) alive &= ~w;
+                        else local[b] |= w;
+                    }
+                    alive &= ~(1ull << i);
+                }
+                if ((kept >> lane) & 1ull) keep_pos[n_kept + __popcll(kept & ((1ull << lane) - 1ull))] = c * kChunk + lane;
+                n_kept += __popcll(kept);
+                keptw[a] = kept;
+            }
+        }
+        if (n_kept < limit && 4 * S + 4 < n_chunks) {
+            // rows of every box kept in this super-chunk, RB at a time with all their loads in flight (a short round repeats its
+            // first row: OR is idempotent); only the words of chunks AFTER the super-chunk are needed
+            constexpr int RB = NJ <= 2 ? 16 : 8;
+            const int c_last = 4 * S + 3;
+            int a_cur = 0;
+            unsigned long long kk = keptw[0];
+            auto next_row = [&]() -> int {                           // next kept row of the super-chunk, or -1
+                while (kk == 0ull && a_cur < 3) { ++a_cur; kk = keptw[a_cur]; }
+                if (kk == 0ull) return -1;
+                const int i = __ffsll((long long)kk) - 1;
+                kk &= kk - 1ull;
+                return (4 * S + a_cur) * kChunk + i;
+            };
+            for (;;) {
+                int rows[RB];
+                rows[0] = next_row();
+                if (rows[0] < 0) break;
+#pragma unroll
+                for (int q = 1; q < RB; ++q) { const int rr = next_row(); rows[q] = rr >= 0 ? rr : rows[0]; }
+                unsigned long long v[RB][NJ];
+#pragma unroll
+                for (int q = 0; q < RB; ++q) {
+                    const unsigned long long *row = mask + (size_t)rows[q] * pitch;
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int w = lane + 64 * j;
+                        v[q][j] = (w > c_last && w < n_chunks) ? row[w] : 0ull;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    unsigned long long acc = 0ull;
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) acc |= v[q][j];
+                    rem[j] |= acc;
+                }
+            }
+        }
+    }
+    if (lane == 0) n_out[0] = n_kept;
+    frcnn_drain_vmem();                               // keep_pos was written by other lanes of this wave
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < n_kept; k += 64) {
+        const int pos = keep_pos[k];
+        if (out_index) out_index[k] = order[pos];
+        if (out_boxes) reinterpret_cast<float4 *>(out_boxes)[k] = reinterpret_cast<const float4 *>(sorted_boxes)[pos];
+        if (out_scores) out_scores[k] = sorted_scores[pos];
+    }
+    for (int k = n_kept + lane; k < out_capacity; k += 64) {
+        if (out_index) out_index[k] = -1;
+        if (out_boxes) reinterpret_cast<float4 *>(out_boxes)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (out_scores) out_scores[k] = 0.0f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 struct Layout {   // carve-up of the caller's workspace (per group)
     size_t counters, keys, boxes, scores, order, sboxes, sscores, keep_pos, mask, total;
     int n_pad, n_tiles, m_max, pitch;
 };
+
+// FRCNN_NMS_SCAN=1: the one-chunk-per-trip single-wave scan of round 1 (A/B measurements); default: four chunks per trip
+static bool scan_one_chunk_per_trip() {
+    const char *e = getenv("FRCNN_NMS_SCAN");
+    return e && e[0] == '1';
+}
+
+static int mask_blocks(int pitch) { return (int)(((long long)pitch * (pitch + 1) / 2 + 3) / 4); }   // 4 upper-triangle tiles per block
 
 static Layout make_layout(int n_total, int top_k, bool own_boxes) {
     Layout L;
@@ -475,7 +681,7 @@ static Layout make_layout(int n_total, int top_k, bool own_boxes) {
     if (L.m_max < 1) L.m_max = 1;
     L.pitch = frcnn_cdiv(L.m_max, kChunk);
     size_t o = 0;
-    L.counters = o; o += 256;
+    L.counters = o; o += frcnn_align256((size_t)(1 + L.n_pad / 256) * sizeof(int));   // [0] n_valid, [1 + b] decode block b's count
     L.keys = o; o += frcnn_align256((size_t)L.n_pad * 8);
     L.boxes = o; o += own_boxes ? frcnn_align256((size_t)(n_total > 0 ? n_total : 1) * 16) : 0;
     L.scores = o; o += own_boxes ? frcnn_align256((size_t)(n_total > 0 ? n_total : 1) * 4) : 0;
@@ -518,12 +724,21 @@ int frcnn_nms_batched(const float *dets, int groups, int n, double thresh, int m
     const dim3 blk(256);
     hipLaunchKernelGGL(dets_keys_kernel, dim3(frcnn_cdiv(L.n_pad, 256), 1, groups), blk, 0, stream, dets, n, L.n_pad, keys,
                        counters, (size_t)n * 5, gs);
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(L.n_tiles, 1, groups), blk, 0, stream, keys, gs);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(L.n_tiles, 1, groups), dim3(kSortThreads), 0, stream, keys, gs);
     hipLaunchKernelGGL(rank_scatter_kernel, dim3(frcnn_cdiv(L.n_pad, 256), 1, groups), blk, 0, stream, keys, L.n_tiles, dets, 5,
-                       dets + 4, 5, 0, counters, order, sboxes, sscores, (size_t)n * 5, gs);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(frcnn_cdiv(L.pitch, 4), L.pitch, groups), blk, 0, stream, sboxes, counters, 0, thresh,
+                       dets + 4, 5, 0, counters, 0, order, sboxes, sscores, (size_t)n * 5, gs);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_blocks(L.pitch), 1, groups), blk, 0, stream, sboxes, counters, 0, thresh,
                        mask, L.pitch, gs);
-    if (L.pitch <= 128)
+    const bool scan1 = scan_one_chunk_per_trip();
+    if (L.pitch <= 128 && !scan1)
+        hipLaunchKernelGGL(nms_scan_wave4_kernel<2>, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, 0, max_out, order, sboxes,
+                           sscores, keep_pos, keep, (float *)nullptr, (float *)nullptr, n_keep,
+                           (max_out > 0 && max_out < n) ? max_out : n, gs, (size_t)n);
+    else if (L.pitch <= kWaveChunks && !scan1)
+        hipLaunchKernelGGL(nms_scan_wave4_kernel<4>, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, 0, max_out, order, sboxes,
+                           sscores, keep_pos, keep, (float *)nullptr, (float *)nullptr, n_keep,
+                           (max_out > 0 && max_out < n) ? max_out : n, gs, (size_t)n);
+    else if (L.pitch <= 128)
         hipLaunchKernelGGL(nms_scan_wave_kernel<2>, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, 0, max_out, order, sboxes,
                            sscores, keep_pos, keep, (float *)nullptr, (float *)nullptr, n_keep,
                            (max_out > 0 && max_out < n) ? max_out : n, gs, (size_t)n);
@@ -572,16 +787,24 @@ int frcnn_proposals(const float *rpn_cls_prob, const float *rpn_bbox_pred, int A
     Anchors anc;
     for (int a = 0; a < A; ++a)
         for (int c = 0; c < 4; ++c) anc.a[a][c] = anchors_host[a * 4 + c];
-    FRCNN_HIP_TRY(hipMemsetAsync(counters, 0, 256, stream));
     const dim3 blk(256);
     hipLaunchKernelGGL(proposal_decode_kernel, dim3(frcnn_cdiv(L.n_pad, 256)), blk, 0, stream, rpn_cls_prob, rpn_bbox_pred, A, H, W,
                        anc, feat_stride, im_h, im_w, min_size, boxes, scores, keys, L.n_pad, counters);
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(L.n_tiles), blk, 0, stream, keys, (size_t)0);
+    hipLaunchKernelGGL(tile_sort_kernel, dim3(L.n_tiles), dim3(kSortThreads), 0, stream, keys, (size_t)0);
     hipLaunchKernelGGL(rank_scatter_kernel, dim3(frcnn_cdiv(L.n_pad, 256)), blk, 0, stream, keys, L.n_tiles, boxes, 4, scores, 1,
-                       pre_nms_top_n, counters, order, sboxes, sscores, (size_t)0, (size_t)0);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(frcnn_cdiv(L.pitch, 4), L.pitch), blk, 0, stream, sboxes, counters, pre_nms_top_n,
+                       pre_nms_top_n, counters, L.n_pad / 256, order, sboxes, sscores, (size_t)0, (size_t)0);
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_blocks(L.pitch)), blk, 0, stream, sboxes, counters, pre_nms_top_n,
                        nms_thresh, mask, L.pitch, (size_t)0);
-    if (L.pitch <= 128)
+    const bool scan1 = scan_one_chunk_per_trip();
+    if (L.pitch <= 128 && !scan1)
+        hipLaunchKernelGGL(nms_scan_wave4_kernel<2>, dim3(1), dim3(64), 0, stream, mask, L.pitch, counters, pre_nms_top_n, post_nms_top_n, order,
+                           sboxes, sscores, keep_pos, src_index, rois, probs, n_out,
+                           (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
+    else if (L.pitch <= kWaveChunks && !scan1)
+        hipLaunchKernelGGL(nms_scan_wave4_kernel<4>, dim3(1), dim3(64), 0, stream, mask, L.pitch, counters, pre_nms_top_n, post_nms_top_n, order,
+                           sboxes, sscores, keep_pos, src_index, rois, probs, n_out,
+                           (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
+    else if (L.pitch <= 128)
         hipLaunchKernelGGL(nms_scan_wave_kernel<2>, dim3(1), dim3(64), 0, stream, mask, L.pitch, counters, pre_nms_top_n, post_nms_top_n, order,
                            sboxes, sscores, keep_pos, src_index, rois, probs, n_out,
                            (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
