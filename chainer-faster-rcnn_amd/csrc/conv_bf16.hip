@@ -23,6 +23,7 @@
 // MFMAs (32 cycles each).
 #include "frcnn_common.h"
 #include <stdlib.h>
+#include <string.h>
 #include <frcnn_buffer.h>   // angle brackets: shadowed by the test emulator
 #include <frcnn_intrin.h>
 #include <frcnn_sync.h>
@@ -57,14 +58,16 @@ __device__ __forceinline__ uint4 bf16x8_max4(uint4 a, uint4 b, uint4 c, uint4 d)
 
 // Epilogue shared by the bf16 conv kernels: bias, ReLU, and one of three output forms.  `ot` is LDS scratch of at least
 // BROWS * 32 * (BCO * 2 + 16) bytes that no wave reads any more (the caller has passed a barrier after its last fragment read).
-template <int BROWS, int NT, int RW>       // tile rows, threads, rows per wave (wave w owns rows (w >> 1) * RW ..)
-__device__ __forceinline__ void conv_bf16_epilogue(frcnn_f32x16 (&acc)[RW], unsigned char *ot, const float *__restrict__ bias, void *__restrict__ y,
+// COB = cout blocks (of 32) per wave: 1 -> wave w owns couts (w & 1) * 32 .., rows (w >> 1) * RW ..; 2 -> wave w owns all 64
+// couts of rows w * RW .. (acc is indexed [cob * RW + j])
+template <int BROWS, int NT, int RW, int COB = 1>       // tile rows, threads, rows per wave
+__device__ __forceinline__ void conv_bf16_epilogue(frcnn_f32x16 (&acc)[RW * COB], unsigned char *ot, const float *__restrict__ bias, void *__restrict__ y,
                                                    int Cout, int CoutP, int H, int W, int relu, int out_mode, int x0, int y0, int co0) {
     constexpr int BCO = 64;
     constexpr int OP = BCO * 2 + 16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = wave & 1, wrow = wave >> 1;
+    const int wco0 = COB == 2 ? 0 : (wave & 1), wrow = COB == 2 ? wave : (wave >> 1);
     const int l31 = lane & 31, khalf = lane >> 5;
     // epilogue: register r of lane l = cout (r&3) + 8*(r>>2) + 4*khalf of pixel l31
     const int px = x0 + l31;
@@ -72,14 +75,16 @@ __device__ __forceinline__ void conv_bf16_epilogue(frcnn_f32x16 (&acc)[RW], unsi
         // bf16 channel-blocked output: transpose through LDS so that each 16-cout block of a tile row leaves as one contiguous
         // run of 32 px x 32 B (16-byte stores, consecutive lanes consecutive addresses)
 #pragma unroll
+        for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
         for (int j = 0; j < RW; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int col = wco * 32 + 8 * g + 4 * khalf;             // first of four consecutive couts (within the tile)
+                const int col = (wco0 + cb) * 32 + 8 * g + 4 * khalf;     // first of four consecutive couts (within the tile)
                 float v[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    v[t] = acc[j][4 * g + t] + (co0 + col + t < Cout ? bias[co0 + col + t] : 0.0f);
+                    v[t] = acc[cb * RW + j][4 * g + t] + (co0 + col + t < Cout ? bias[co0 + col + t] : 0.0f);
                     if (relu) v[t] = fmaxf(v[t], 0.0f);
                 }
                 uint2 pk;
@@ -119,16 +124,18 @@ __device__ __forceinline__ void conv_bf16_epilogue(frcnn_f32x16 (&acc)[RW], unsi
         }
     } else {
 #pragma unroll
+        for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
         for (int j = 0; j < RW; ++j) {
             const int py = y0 + wrow * RW + j;
             if (px >= W || py >= H) continue;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int co = co0 + wco * 32 + 8 * g + 4 * khalf;
+                const int co = co0 + (wco0 + cb) * 32 + 8 * g + 4 * khalf;
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     if (co + t < Cout) {
-                        float v = acc[j][4 * g + t] + bias[co + t];
+                        float v = acc[cb * RW + j][4 * g + t] + bias[co + t];
                         if (relu) v = fmaxf(v, 0.0f);
                         reinterpret_cast<float *>(y)[(size_t)(co + t) * H * W + (size_t)py * W + px] = v;      // fp32 NCHW
                     }
@@ -284,13 +291,23 @@ conv_mfma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict
 // sides (rule 21): 16-byte slot of (row P, half h) = 2P + (h ^ ((P >> 3) & 1)) -- every 16-lane group of a ds_read_b128 whose
 // lanes read consecutive rows at any base offset then covers 16 distinct bank slots.  NS ring stages: chunk c+NS-1 is in flight
 // while chunk c feeds the MFMAs; per chunk one counted s_waitcnt vmcnt(N) + one fence-less barrier.
-template <int NS, int WPS, int RPW = 1, int ABL = 0>   // RPW = row pairs per wave: the tile is 64 couts x 4*RPW rows x 32 px; ABL: 1 no DMA, 4 no compute
+// Tile shapes (RPW selects one; all 64 couts x 32 px wide, 4 waves):
+//   RPW 1, 2  a wave owns 32 couts x 2*RPW rows (two cout blocks x two row groups across the waves): 4 / 8 tile rows
+//   RPW 3, 4  a wave owns ALL 64 couts x 2 / 4 rows (four row groups across the waves): 8 / 16 tile rows.  Every B fragment feeds two
+//             MFMAs and every A fragment RW of them: 0.83 / 0.5 LDS fragment reads per MFMA instead of 1.17 / 0.75, and 1.7x / 2.6x the
+//             MFMA work per staged byte -- the fragment reads (84 KB per chunk for 576 MFMA cycles in the RPW 1 form) were co-limiting
+//             the matrix pipe.
+template <int NS, int WPS, int RPW = 1, int ABL = 0>   // ABL: 1 no DMA, 4 no compute
 __global__ void __launch_bounds__(256, WPS)
 conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
                      int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles, int nsplit,
                      float *__restrict__ partial_ws, int *__restrict__ tile_counters) {
     constexpr int KS = 3, TAPS = 9, PAD = 1;
-    constexpr int RW = 2 * RPW, BROWS = 2 * RW, BCO = 64;
+    constexpr int COB = RPW >= 3 ? 2 : 1;                       // cout blocks per wave
+    constexpr int RW = RPW == 1 ? 2 : (RPW == 2 ? 4 : (RPW == 3 ? 2 : 4));
+    constexpr int ROWG = COB == 2 ? 4 : 2;                      // row groups across the four waves
+    constexpr int NACC = RW * COB;
+    constexpr int BROWS = ROWG * RW, BCO = 64;
     constexpr int HR = BROWS + KS - 1, HPX = 32 + KS - 1;
     constexpr int IN_ROWS = HR * HPX;                         // 204 halo pixels, 32 B each
     constexpr int IN_PIECES = (IN_ROWS * 2 + 63) / 64;        // 1 KB pieces (64 lanes x 16 B): 7, the last one partly out of range
@@ -304,7 +321,7 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
     __shared__ int s_ticket;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wco = wave & 1, wrow = wave >> 1;
+    const int wco = COB == 2 ? 0 : (wave & 1), wrow = COB == 2 ? wave : (wave >> 1);
     const int l31 = lane & 31, khalf = lane >> 5;
     // split-K for launches with fewer tiles than the chip has room for (the 38x63 maps: 160 tiles on 256 CUs): `nsplit`
     // consecutive workgroups share a tile, each takes a contiguous range of the K-chunks, the last to finish sums the
@@ -370,27 +387,52 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
             b_off[r][kx] = (uint32_t)(P * 32 + ((khalf ^ ((P >> 3) & 1)) << 4));
         }
 
-    frcnn_f32x16 acc[RW];
+    frcnn_f32x16 acc[NACC];
 #pragma unroll
-    for (int j = 0; j < RW; ++j)
+    for (int j = 0; j < NACC; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
 
     auto compute = [&](int stage) {
         if constexpr ((ABL & 4) != 0) return;
         const unsigned char *st = ring + stage * STAGE_BYTES;
-        uint4 a[TAPS], b[RW + KS - 1][KS];
+        if constexpr (COB == 1) {
+            uint4 a[TAPS], b[RW + KS - 1][KS];
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) a[tap] = *reinterpret_cast<const uint4 *>(st + a_off + tap * BCO * 32);
+            for (int tap = 0; tap < TAPS; ++tap) a[tap] = *reinterpret_cast<const uint4 *>(st + a_off + tap * BCO * 32);
 #pragma unroll
-        for (int r = 0; r < RW + KS - 1; ++r)
+            for (int r = 0; r < RW + KS - 1; ++r)
 #pragma unroll
-            for (int kx = 0; kx < KS; ++kx) b[r][kx] = *reinterpret_cast<const uint4 *>(st + b_off[r][kx]);
+                for (int kx = 0; kx < KS; ++kx) b[r][kx] = *reinterpret_cast<const uint4 *>(st + b_off[r][kx]);
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int ky = tap / KS, kx = tap % KS;
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int ky = tap / KS, kx = tap % KS;
 #pragma unroll
-            for (int j = 0; j < RW; ++j) acc[j] = frcnn_mfma_32x32x16_bf16(a[tap], b[ky + j][kx], acc[j]);
+                for (int j = 0; j < RW; ++j) acc[j] = frcnn_mfma_32x32x16_bf16(a[tap], b[ky + j][kx], acc[j]);
+            }
+        } else {
+            // both cout blocks in one wave: the halo fragments are read once per chunk and stay in registers, the weight fragments
+            // stream through one tap row at a time (same (chunk, tap) accumulation order per output as every other variant:
+            // bit-identical results); the second cout block's weight rows sit 32 rows (1 KB, same swizzle phase) further on
+            uint4 b[RW + KS - 1][KS];
+#pragma unroll
+            for (int r = 0; r < RW + KS - 1; ++r)
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) b[r][kx] = *reinterpret_cast<const uint4 *>(st + b_off[r][kx]);
+#pragma unroll
+            for (int ky = 0; ky < KS; ++ky) {
+                uint4 a[2][KS];
+#pragma unroll
+                for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                    for (int kx = 0; kx < KS; ++kx) a[cb][kx] = *reinterpret_cast<const uint4 *>(st + a_off + ((ky * KS + kx) * BCO + cb * 32) * 32);
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int j = 0; j < RW; ++j) acc[cb * RW + j] = frcnn_mfma_32x32x16_bf16(a[cb][kx], b[ky + j][kx], acc[cb * RW + j]);
+            }
         }
     };
 
@@ -427,11 +469,11 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
     }
     if (nsplit > 1) {
         // publish this split's accumulators (fragment-linear float4s, write-through: no release fence needed), take a ticket
-        constexpr int NV = RW * 4;                                // float4s per thread
-        const size_t slot_floats = (size_t)256 * RW * 16;
+        constexpr int NV = NACC * 4;                              // float4s per thread
+        const size_t slot_floats = (size_t)256 * NACC * 16;
         const frcnn_buf_t pbuf = frcnn_make_buf(partial_ws + ((size_t)tile * nsplit + split) * slot_floats, (uint32_t)(slot_floats * sizeof(float)));
 #pragma unroll
-        for (int j = 0; j < RW; ++j)
+        for (int j = 0; j < NACC; ++j)
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4)
                 frcnn_buf_store_f32x4_wt(pbuf, (uint32_t)(((j * 4 + r4) * 256 + tid) * 16),
@@ -447,7 +489,7 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < RW; ++j)
+        for (int j = 0; j < NACC; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
         for (int q = 0; q < nsplit; ++q) {
@@ -456,7 +498,7 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
 #pragma unroll
             for (int e = 0; e < NV; ++e) v[e] = piece[(size_t)e * 256 + tid];
 #pragma unroll
-            for (int j = 0; j < RW; ++j)
+            for (int j = 0; j < NACC; ++j)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const float4 t = v[j * 4 + r4];
@@ -465,7 +507,7 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
         }
     }
     __syncthreads();                                            // the ring becomes the epilogue's output tile
-    conv_bf16_epilogue<BROWS, 256, RW>(acc, ring, bias, y, Cout, CoutP, H, W, relu, out_mode, x0, y0, co0);
+    conv_bf16_epilogue<BROWS, 256, RW, COB>(acc, ring, bias, y, Cout, CoutP, H, W, relu, out_mode, x0, y0, co0);
 }
 
 // (Cout, Cin, k, k) fp32 -> [CinP/16][tap][CoutP][16] bf16, zero padded
@@ -605,24 +647,38 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
     // compiled only with FRCNN_TIMING_ABLATIONS).
     const char *dma_env = getenv("FRCNN_BF16_DMA");
     int mode = dma_env ? atoi(dma_env) : -1;
+    // tile rows / accumulators per thread of the DMA kernel's shapes (RPW = last digit of the mode): 64 couts x {4, 8, 8, 16} rows x 32 px
+    static const int kRowsOf[5] = {0, 4, 8, 8, 16}, kAccOf[5] = {0, 2, 4, 4, 8};
+    if (mode < 0) {
+        const char *def_env = getenv("FRCNN_BF16_DMA_DEFAULT");       // "<big launches>,<small launches>", e.g. 224,223 (tuning hook)
+        int big_mode = 141, small_mode = 231;
+        if (def_env) {
+            big_mode = atoi(def_env);
+            const char *comma = strchr(def_env, ',');
+            small_mode = comma ? atoi(comma + 1) : big_mode;
+        }
+        mode = (long)grid.x >= 4L * frcnn_cu_count() ? big_mode : small_mode;
+    }
+    const int rpw = (mode > 0 && mode < 1000) ? mode % 10 : 1;
+    if (mode > 0 && (rpw < 1 || rpw > 4)) return FRCNN_ERR_INVALID;
+    const int trows = kRowsOf[rpw], nacc = kAccOf[rpw];
+    const int yt = frcnn_cdiv(H, trows);
+    const long dma_tiles = (long)xtiles * yt * cotiles;
     // split-K needs the workspace (partial tiles + the zeroed counter page); without one every tile is whole
     int nsplit = 1;
-    if (ksize == 3 && !big && workspace && (long)grid.x * 4 <= 16384) {
-        nsplit = conv_bf16_pick_split((long)grid.x, CinP / kCK);
-        if (workspace_bytes < kBf16CounterPageBytes + (size_t)grid.x * nsplit * 256 * 32 * sizeof(float)) nsplit = 1;
+    if (ksize == 3 && !big && mode > 0 && workspace && dma_tiles * 4 <= 16384) {
+        nsplit = conv_bf16_pick_split(dma_tiles, CinP / kCK);
+        if (workspace_bytes < kBf16CounterPageBytes + (size_t)dma_tiles * nsplit * 256 * nacc * 16 * sizeof(float)) nsplit = 1;
     }
     float *partials = nsplit > 1 ? (float *)((char *)workspace + kBf16CounterPageBytes) : nullptr;
     int *counters = nsplit > 1 ? (int *)workspace : nullptr;
-    if (mode < 0) mode = (long)grid.x * nsplit >= 4L * frcnn_cu_count() ? 141 : 231;
     if (ksize == 3 && big) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3, 4>), grid, dim3(512), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
     else if (ksize == 3 && mode > 0) {
-        const int yt8 = frcnn_cdiv(H, 8);
-        const dim3 grid8(xtiles * yt8 * cotiles);
+        const dim3 dgrid((unsigned)(dma_tiles * nsplit));
 #define FRCNN_DMA_CASE(NS, WPS, RPW)                                                                                                     \
     case NS * 100 + WPS * 10 + RPW:                                                                                                      \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dma_bf16_kernel<NS, WPS, RPW>), RPW == 2 ? grid8 : dim3(grid.x * nsplit), dim3(256), 0,  \
-                           stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, RPW == 2 ? yt8 : ytiles,          \
-                           RPW == 2 ? 1 : nsplit, partials, counters);                                                                    \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dma_bf16_kernel<NS, WPS, RPW>), dgrid, dim3(256), 0, stream, x, w_packed, bias, y, CinP,  \
+                           Cout, CoutP, H, W, relu, out_mode, xtiles, yt, nsplit, partials, counters);                                    \
         break;
 #define FRCNN_DMA_ABL(NS, WPS, A)                                                                                                        \
     case NS * 1000 + WPS * 100 + 10 + A:                                                                                                 \
@@ -631,6 +687,8 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
         break;
         switch (mode) {
             FRCNN_DMA_CASE(3, 2, 1) FRCNN_DMA_CASE(2, 3, 1) FRCNN_DMA_CASE(1, 4, 1) FRCNN_DMA_CASE(1, 3, 2) FRCNN_DMA_CASE(2, 2, 2)
+            FRCNN_DMA_CASE(2, 2, 3) FRCNN_DMA_CASE(2, 3, 3) FRCNN_DMA_CASE(3, 2, 3) FRCNN_DMA_CASE(2, 2, 4) FRCNN_DMA_CASE(3, 2, 4)
+            FRCNN_DMA_CASE(1, 2, 4) FRCNN_DMA_CASE(1, 3, 3)
 #ifdef FRCNN_TIMING_ABLATIONS                                                                       // WRONG results: sweeps only, never shipped
             FRCNN_DMA_ABL(1, 4, 1) FRCNN_DMA_ABL(1, 4, 4) FRCNN_DMA_ABL(2, 3, 1) FRCNN_DMA_ABL(2, 3, 4)
 #endif

@@ -26,12 +26,14 @@
 // `(double)iou >= thresh` (cpu_nms.pyx:18,66).
 #include "frcnn_common.h"
 #include <stdlib.h>
+#include <frcnn_intrin.h>
 #include <frcnn_sync.h>     // angle brackets: shadowed by the test emulator
 
 namespace {
 
-constexpr int kSortTile = 4096;   // keys per bitonic tile (one 1024-thread workgroup, 4 keys per thread)
-constexpr int kSortThreads = 1024;
+constexpr int kSortTile = 1024;   // keys per bitonic tile (one 256-thread workgroup, 4 keys per thread)
+constexpr int kSortThreads = 256;
+constexpr int kRankTiles = 4;     // tiles searched together by rank_scatter_kernel (independent binary searches in flight)
 constexpr int kChunk = 64;        // NMS chunk = wave width
 
 __device__ __forceinline__ uint32_t ordered_bits(float f) {
@@ -124,12 +126,13 @@ dets_keys_kernel(const float *__restrict__ dets, int n, int n_pad, unsigned long
 }
 
 // ------------------------------------------------------------------------------------------------
-// Bitonic sort (descending) of one 4096-key tile by one 1024-thread workgroup.  Thread t holds elements t, t + 1024, t + 2048,
-// t + 3072 in registers, so a compare-exchange at distance j is
-//   j >= 1024   between two of the thread's own registers          (no communication)
+// Bitonic sort (descending) of one 1024-key tile by one 256-thread workgroup (one wave per SIMD of a CU; the 22 tiles of a
+// 600 x 1000 image run on 22 CUs -- the network is VALU-issue-bound, so 4096-key tiles on 6 CUs were 1.5x slower: r02 measurement).
+// Thread t holds elements t, t + 256, t + 512, t + 768 in registers, so a compare-exchange at distance j is
+//   j >= 256    between two of the thread's own registers          (no communication)
 //   j <  64     with lane ^ j of the same wave                      (__shfl_xor: no LDS image, no barrier)
 //   otherwise   with another wave                                   (through LDS, two barriers)
-// 78 network steps, of which only 18 touch LDS (the all-LDS version of round 1 ran 55 barrier-separated passes per 1024 keys).
+// 55 network steps, of which only 7 touch LDS (the all-LDS version of round 1 ran 55 barrier-separated passes).
 // Element i keeps the larger key of the pair (i, i ^ j) iff (i & j) == 0 is equal to ((i & k) == 0): the usual bitonic rule, descending.
 __global__ void __launch_bounds__(kSortThreads)
 tile_sort_kernel(unsigned long long *__restrict__ keys, size_t slab) {
@@ -181,32 +184,25 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, size_t slab) {
     for (int r = 0; r < 4; ++r) g[r * kSortThreads + tid] = key[r];
 }
 
-// number of elements of the descending-sorted tile (in LDS) that are > key
-__device__ __forceinline__ int count_greater(const unsigned long long *tile, unsigned long long key) {
-    int pos = 0;
-#pragma unroll
-    for (int s = kSortTile / 2; s >= 1; s >>= 1)
-        if (tile[pos + s - 1] > key) pos += s;
-    if (tile[pos] > key) pos += 1;
-    return pos;
-}
-
-// Global rank by merging: rank(key) = sum over all sorted tiles of count_greater(tile, key) (keys are unique,
-// so in the key's own tile that count is just its position there).  A workgroup owns 256 consecutive keys and
-// streams every tile through LDS (register-staged double buffer: the next tile's 8 KB is in flight while the
-// current one is binary-searched -- 11 dependent LDS reads per key per tile instead of 11 dependent L2 trips).
-// Ranks below limit = min(n_valid, top_k) are gathered into score order.
+// Global rank by merging: rank(key) = sum over all sorted tiles of (number of elements > key) (keys are unique, so in the key's
+// own tile that count is just its position there).  A workgroup owns 256 consecutive keys and streams the tiles through LDS
+// kRankTiles at a time (register-staged double buffer: the next group's 32 KB is in flight while the current one is searched); the
+// kRankTiles branch-free binary searches of a thread are independent, so their 11 dependent LDS reads each overlap (one search at
+// a time was a chain of 242 dependent reads for 22 tiles).  Ranks below top_k are gathered into score order.
 __global__ void __launch_bounds__(256)
 rank_scatter_kernel(const unsigned long long *__restrict__ keys, int n_tiles, const float *__restrict__ boxes_in, int box_stride,
                     const float *__restrict__ scores_in, int score_stride, int top_k, int *__restrict__ counters_rw, int n_count_blocks,
                     int32_t *__restrict__ order, float *__restrict__ sorted_boxes, float *__restrict__ sorted_scores,
                     size_t in_gs, size_t slab) {
-    __shared__ unsigned long long tile[2][kSortTile];
+    constexpr int GK = kRankTiles * kSortTile;                 // keys per group
+    constexpr int SQ = GK / 256;                               // staged keys per thread
+    __shared__ unsigned long long tile[2][GK];
     boxes_in += blockIdx.z * in_gs; scores_in += blockIdx.z * in_gs;
     keys = slab_ptr(keys, slab);
     order = slab_ptr(order, slab); sorted_boxes = slab_ptr(sorted_boxes, slab); sorted_scores = slab_ptr(sorted_scores, slab);
     const int t = blockIdx.x * blockDim.x + threadIdx.x;       // position in the tile-sorted key array (< n_tiles*1024)
     const unsigned long long key = keys[t];
+    const int n_keys = n_tiles * kSortTile;
     // n_valid = the decode blocks' counts, summed once (ProposalLayer path; frcnn_nms sets counters[0] itself: n_count_blocks = 0)
     if (blockIdx.x == 0 && n_count_blocks > 0) {
         __shared__ int partial[4];
@@ -218,21 +214,31 @@ rank_scatter_kernel(const unsigned long long *__restrict__ keys, int n_tiles, co
         __syncthreads();
         if (threadIdx.x == 0) cw[0] = partial[0] + partial[1] + partial[2] + partial[3];
     }
-    unsigned long long stage[kSortTile / 256];
+    const int n_groups = (n_tiles + kRankTiles - 1) / kRankTiles;
+    unsigned long long stage[SQ];
 #pragma unroll
-    for (int q = 0; q < kSortTile / 256; ++q) tile[0][threadIdx.x + 256 * q] = keys[threadIdx.x + 256 * q];
+    for (int q = 0; q < SQ; ++q) { const int i = threadIdx.x + 256 * q; tile[0][i] = i < n_keys ? keys[i] : 0ull; }   // a missing tile is all zeros: nothing in it is > key
     __syncthreads();
     int rank = 0, cur = 0;
-    for (int o = 0; o < n_tiles; ++o) {
-        const bool more = o + 1 < n_tiles;
+    for (int o = 0; o < n_groups; ++o) {
+        const bool more = o + 1 < n_groups;
         if (more) {
 #pragma unroll
-            for (int q = 0; q < kSortTile / 256; ++q) stage[q] = keys[(size_t)(o + 1) * kSortTile + threadIdx.x + 256 * q];
+            for (int q = 0; q < SQ; ++q) { const int i = (o + 1) * GK + threadIdx.x + 256 * q; stage[q] = i < n_keys ? keys[i] : 0ull; }
         }
-        rank += count_greater(tile[cur], key);
+        int pos[kRankTiles];
+#pragma unroll
+        for (int g = 0; g < kRankTiles; ++g) pos[g] = 0;
+#pragma unroll
+        for (int st = kSortTile / 2; st >= 1; st >>= 1)
+#pragma unroll
+            for (int g = 0; g < kRankTiles; ++g)
+                if (tile[cur][g * kSortTile + pos[g] + st - 1] > key) pos[g] += st;
+#pragma unroll
+        for (int g = 0; g < kRankTiles; ++g) rank += pos[g] + (tile[cur][g * kSortTile + pos[g]] > key ? 1 : 0);
         if (more) {
 #pragma unroll
-            for (int q = 0; q < kSortTile / 256; ++q) tile[cur ^ 1][threadIdx.x + 256 * q] = stage[q];
+            for (int q = 0; q < SQ; ++q) tile[cur ^ 1][threadIdx.x + 256 * q] = stage[q];
         }
         __syncthreads();
         cur ^= 1;
@@ -260,6 +266,45 @@ __device__ __forceinline__ float ref_max(float a, float b) { return a >= b ? a :
 __device__ __forceinline__ float ref_min(float a, float b) { return a <= b ? a : b; }   // cpu_nms.pyx:15-16
 __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
 
+// The 64 steps of one tile.  FASTMM: coordinates are known NaN-free, so cpu_nms.pyx's max / min helpers (a >= b ? a : b) are one
+// v_max_f32 / v_min_f32 each instead of compare + select -- identical values (only the sign of a zero can differ, and xx2 - xx1 does
+// not see it).  The threshold test avoids the division: |inter - thr * uni| outside a 1e-4 relative band decides at once; inside it
+// (or for degenerate areas) the reference's own expression is evaluated.
+template <bool FASTMM>
+__device__ __forceinline__ unsigned long long nms_tile_words(const float4 rb, const float rarea_l, const float4 cb, const float carea,
+                                                             int t_rows, bool diag, bool col_ok, int lane, double thresh) {
+    const float thr_f = (float)thresh;
+    const bool lane_fast = (thresh > 1e-6) && (carea > 0.0f);
+    unsigned long long word = 0ull;
+    for (int t = 0; t < t_rows; ++t) {
+        const float rx1 = lane_bcast(rb.x, t), ry1 = lane_bcast(rb.y, t), rx2 = lane_bcast(rb.z, t), ry2 = lane_bcast(rb.w, t);
+        const float rarea = lane_bcast(rarea_l, t);
+        float xx1, yy1, xx2, yy2, w, h;
+        if constexpr (FASTMM) {
+            xx1 = frcnn_max_f32(rx1, cb.x); yy1 = frcnn_max_f32(ry1, cb.y);      // cpu_nms.pyx:58-61 (i = the row box, j = the column box)
+            xx2 = frcnn_min_f32(rx2, cb.z); yy2 = frcnn_min_f32(ry2, cb.w);
+            w = frcnn_max_f32(0.0f, xx2 - xx1 + 1.0f); h = frcnn_max_f32(0.0f, yy2 - yy1 + 1.0f);   // :62-63
+        } else {
+            xx1 = ref_max(rx1, cb.x); yy1 = ref_max(ry1, cb.y);
+            xx2 = ref_min(rx2, cb.z); yy2 = ref_min(ry2, cb.w);
+            w = ref_max(0.0f, xx2 - xx1 + 1.0f); h = ref_max(0.0f, yy2 - yy1 + 1.0f);
+        }
+        const float inter = w * h;                                               // :64
+        const float uni = rarea + carea - inter;                                 // :65
+        const float tt = thr_f * uni;
+        const float d = inter - tt;
+        bool sup = d > 0.0f;
+        const bool in_band = !(fabsf(d) > 1e-4f * fabsf(tt)) || !lane_fast || !(rarea > 0.0f);     // NaNs land here too
+        if (__any(in_band)) {
+            if (in_band) sup = (double)(inter / uni) >= thresh;                  // exact: IEEE divide, double compare (:65-66)
+        }
+        unsigned long long bal = __ballot(sup && col_ok);
+        if (diag) bal &= (t == 63) ? 0ull : (~0ull << (t + 1));                  // only later boxes can be suppressed by row t
+        if (lane == t) word = bal;
+    }
+    return word;
+}
+
 __global__ void __launch_bounds__(256)
 nms_mask_kernel(const float *__restrict__ sorted_boxes, const int *__restrict__ counters, int top_k, double thresh,
                 unsigned long long *__restrict__ mask, int pitch, size_t slab) {
@@ -267,17 +312,19 @@ nms_mask_kernel(const float *__restrict__ sorted_boxes, const int *__restrict__ 
     int m = counters[0];
     if (top_k > 0 && top_k < m) m = top_k;
     const int n_chunks = (m + kChunk - 1) / kChunk;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // linear upper-triangle tile index -> (rc, cc), rows enumerated over the STATIC pitch (the launch is sized before m is known)
     const long long T = (long long)blockIdx.x * 4 + wave;
     const long long total = (long long)pitch * (pitch + 1) / 2;
     if (T >= total) return;
-    // row rc starts at S(rc) = rc * pitch - rc (rc - 1) / 2; invert with a float estimate and fix up
+    // row rc starts at S(rc) = rc * pitch - rc (rc - 1) / 2; invert with a floating-point estimate and fix up
     int rc = (int)((2.0 * pitch + 1.0 - sqrt((2.0 * pitch + 1.0) * (2.0 * pitch + 1.0) - 8.0 * (double)T)) * 0.5);
     rc = min(max(rc, 0), pitch - 1);
     while (rc > 0 && (long long)rc * pitch - (long long)rc * (rc - 1) / 2 > T) --rc;
     while (rc + 1 < pitch && (long long)(rc + 1) * pitch - (long long)(rc + 1) * rc / 2 <= T) ++rc;
-    const int cc = rc + (int)(T - ((long long)rc * pitch - (long long)rc * (rc - 1) / 2));
+    rc = __builtin_amdgcn_readfirstlane(rc);
+    const int cc = __builtin_amdgcn_readfirstlane(rc + (int)(T - ((long long)rc * pitch - (long long)rc * (rc - 1) / 2)));
     if (rc >= n_chunks || cc >= n_chunks) return;                      // wave-uniform
     const int c = cc * kChunk + lane, r = rc * kChunk + lane;
     float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), rb = cb;
@@ -285,28 +332,11 @@ nms_mask_kernel(const float *__restrict__ sorted_boxes, const int *__restrict__ 
     if (r < m) rb = reinterpret_cast<const float4 *>(sorted_boxes)[r];
     const float carea = (cb.z - cb.x + 1.0f) * (cb.w - cb.y + 1.0f);  // areas, cpu_nms.pyx:25
     const float rarea_l = (rb.z - rb.x + 1.0f) * (rb.w - rb.y + 1.0f);
-    const float thr_f = (float)thresh;
-    const bool col_ok = c < m;
     const int t_rows = min(kChunk, m - rc * kChunk);
-    unsigned long long word = 0ull;
-    for (int t = 0; t < t_rows; ++t) {
-        const float rx1 = lane_bcast(rb.x, t), ry1 = lane_bcast(rb.y, t), rx2 = lane_bcast(rb.z, t), ry2 = lane_bcast(rb.w, t);
-        const float rarea = lane_bcast(rarea_l, t);
-        const float xx1 = ref_max(rx1, cb.x), yy1 = ref_max(ry1, cb.y);          // cpu_nms.pyx:58-61 (i = the row box, j = the column box)
-        const float xx2 = ref_min(rx2, cb.z), yy2 = ref_min(ry2, cb.w);
-        const float w = ref_max(0.0f, xx2 - xx1 + 1.0f), h = ref_max(0.0f, yy2 - yy1 + 1.0f);   // :62-63
-        const float inter = w * h;                                               // :64
-        const float uni = rarea + carea - inter;                                 // :65
-        const float tt = thr_f * uni;
-        const bool fast_ok = (thresh > 1e-6) && (rarea > 0.0f) && (carea > 0.0f);
-        bool sup;
-        if (fast_ok && inter >= tt * 1.0001f) sup = true;                        // clear of the rounding band
-        else if (fast_ok && inter <= tt * 0.9999f) sup = false;
-        else sup = (double)(inter / uni) >= thresh;                              // exact: IEEE divide, double compare (:65-66)
-        unsigned long long bal = __ballot(sup && col_ok);
-        if (cc == rc) bal &= (t == 63) ? 0ull : (~0ull << (t + 1));              // only later boxes can be suppressed by row t
-        if (lane == t) word = bal;
-    }
+    const float probe = (cb.x + cb.y) + (cb.z + cb.w) + (rb.x + rb.y) + (rb.z + rb.w);       // NaN iff any coordinate of the tile is
+    unsigned long long word;
+    if (__any(probe != probe)) word = nms_tile_words<false>(rb, rarea_l, cb, carea, t_rows, cc == rc, c < m, lane, thresh);
+    else word = nms_tile_words<true>(rb, rarea_l, cb, carea, t_rows, cc == rc, c < m, lane, thresh);
     if (r < m) mask[(size_t)r * pitch + cc] = word;
 }
 

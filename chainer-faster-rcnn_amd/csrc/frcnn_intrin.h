@@ -11,6 +11,11 @@ __device__ __forceinline__ float frcnn_max_f32(float a, float b) {
     return r;
 }
 
+__device__ __forceinline__ float frcnn_min_f32(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // v_max3_f32: max(max(a, b), c) with the same NaN rule, one instruction for two updates of a running maximum
 __device__ __forceinline__ float frcnn_max3_f32(float a, float b, float c) {
     float r;

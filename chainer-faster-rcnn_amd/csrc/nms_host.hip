@@ -34,9 +34,12 @@ struct DeviceScope {      // hipSetDevice for the call only
     int prev = -1;
     bool ok = false;
     explicit DeviceScope(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) return;
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); return; }
         ok = (prev == dev) || (hipSetDevice(dev) == hipSuccess);
-        if (!ok) prev = -1;
+        if (!ok) {
+            prev = -1;
+            (void)hipGetLastError();          // a refused device id must not linger as the "last error" of the caller's next launch
+        }
     }
     ~DeviceScope() {
         int cur = -1;
@@ -58,6 +61,7 @@ extern "C" void _nms(int *keep_out, int *num_out, const float *boxes_host, int b
     *num_out = -1;
     if (boxes_num < 0 || boxes_dim < 5 || (boxes_num > 0 && (!keep_out || !boxes_host))) return;
     if (boxes_num == 0) { *num_out = 0; return; }
+    (void)hipGetLastError();                  // start from a clean slate: frcnn_nms reports hipGetLastError() after its launches
     DeviceScope scope(device_id);
     if (!scope.ok) return;
     const size_t n = (size_t)boxes_num;

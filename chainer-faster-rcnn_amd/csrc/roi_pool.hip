@@ -19,7 +19,10 @@
 // tests/test_oracle_pinned.py::test_roi_bin_edges_need_double_arithmetic).  Empty bins give 0 / argmax -1.
 #include "frcnn_common.h"
 #include <frcnn_intrin.h>   // angle brackets: shadowed by the test emulator
+#include <frcnn_buffer.h>
+#include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -384,22 +387,28 @@ roi_pool_planes_kernel(const float *__restrict__ x, int C, int H, int W, const f
 //     address computation for four maxima);
 //   * lane = (pg, cq, pw): pg = which pair of output rows (ph = 2 pg, 2 pg + 1), cq = channel quad, pw = output column.  The
 //     hardware serves a ds_read_b128 in four fixed 16-lane groups; pg is exactly that group, so the lanes that share an LDS cycle
-//     read the two quads of SEVEN cells of one map row -- conflict-free when the seven columns differ mod 8 (a 256-byte bank row
-//     holds 8 cells), which the column swizzle swz(w) = (w & ~7) | ((w + (w >> 3)) & 7) arranges for every regular bin spacing
-//     (1, 2, 4, 8 cells: the spacings that alias without it);
+//     read the two quads of SEVEN cells of one map row (the idle eighth lane pair shadows the seventh: a broadcast).  Seven cells
+//     in the eight 32-byte slots of a bank row still collide two-way more often than not (measured: half of the LDS-active cycles;
+//     a column swizzle made no difference and was dropped) -- but the kernel is bound by VALU issue, not by the LDS (r02 counters);
 //   * every lane owns its bins outright (no cross-lane reduction, no staging pass, no wave barrier): it walks the wave's largest
-//     bin shape with clamped rows / columns -- a duplicate read cannot displace the first maximum -- so all loops are
+//     bin shape with saturating rows / columns -- a duplicate read cannot displace the first maximum -- so all loops are
 //     wave-uniform, and stores its 2 x 4 results straight to y;
-//   * bin edges come from two 72-entry tables the workgroup builds while its plane loads are in flight, with the oracle's double
-//     arithmetic (floor(p * (e / out)), ceil((p + 1) * (e / out))): a lookup per RoI instead of fourteen double divisions
+//   * bin edges come from two 72-entry tables built on the host with the oracle's double arithmetic (floor(p * (e / out)),
+//     ceil((p + 1) * (e / out))), passed by value and copied to LDS: a lookup per RoI instead of fourteen double divisions
 //     (extents >= 72 cells take the arithmetic path);
-//   * 78 KB of LDS and 512 threads per workgroup: TWO workgroups per CU, one loads its planes while the other scans.
+//   * 78 KB of LDS and 512 threads per workgroup: TWO workgroups per CU.
 // Scan order = the oracle's: the bin's first cell, then NaN-ignoring maxima; a NaN first cell is restored at the end.
 constexpr int kCellPitch = 64;           // cells per LDS row
 constexpr int kCellWaves = 8;
 constexpr int kTabExt = 72;              // the bin tables cover extents 1 .. kTabExt-1
 
-__device__ __forceinline__ int cell_swz(int col) { return (col & ~7) | ((col + (col >> 3)) & 7); }
+// Bin-edge tables (relative to the RoI origin) for every extent below kTabExt, built ON THE HOST with the oracle's double arithmetic
+// -- floor(p * (e / out)), ceil((p + 1) * (e / out)): IEEE double division / multiplication / floor / ceil are correctly rounded, so
+// the host's values are the device's -- and handed to the kernel by value; a workgroup copies them into LDS (2.4 KB) on entry.
+struct RoiBinTables {
+    uint16_t tab[2][kTabExt][8];        // [0] rows (outh), [1] columns (outw): lo | hi << 8
+    uint8_t tabmax[2][kTabExt];         // tallest / widest bin of an extent
+};
 
 __device__ __forceinline__ float4 max4(float4 a, float4 b) {
     return make_float4(frcnn_max_f32(a.x, b.x), frcnn_max_f32(a.y, b.y), frcnn_max_f32(a.z, b.z), frcnn_max_f32(a.w, b.w));
@@ -412,15 +421,11 @@ __device__ __forceinline__ float4 max4_3(float4 a, float4 b, float4 c) {
 // in flight per step), row addresses advance by one pitch and saturate at the bin's last row (a duplicate read cannot displace a
 // maximum), and the next step's cells are fetched before the current step's maxima are taken.
 template <int NC>
-__device__ __forceinline__ void cells_scan_chunk(const float4 *__restrict__ cells, int k0, int ws, int we, int cq, int W,
+__device__ __forceinline__ void cells_scan_chunk(const float4 *__restrict__ cells, int k0, int c_lo, int c_hi, int cq,
                                                  const int (&r0)[2], const int (&r1)[2], int mbh, float4 (&acc)[2]) {
-    int ca[NC];
+    int ca[NC];                                     // float4 index of column k0 + q of the lane's bin, saturating at its last column
 #pragma unroll
-    for (int q = 0; q < NC; ++q) {
-        int col = min(ws + k0 + q, we - 1);
-        col = min(max(col, 0), W - 1);
-        ca[q] = cell_swz(col) * 2 + cq;
-    }
+    for (int q = 0; q < NC; ++q) ca[q] = min(c_lo + k0 + q, c_hi) * 2 + cq;
     int row[2] = {r0[0], r0[1]};                    // float4 index of the current map row of each bin
     auto fetch = [&](float4 (&buf)[2][NC]) {
 #pragma unroll
@@ -468,10 +473,9 @@ __device__ __forceinline__ void cells_scan_chunk(const float4 *__restrict__ cell
 template <int kRows, bool OUT16>
 __global__ void __launch_bounds__(64 * kCellWaves)
 roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const float *__restrict__ rois, int roi_cols, int R,
-                      int outh, int outw, float scale, float *__restrict__ y, int rsplit) {
+                      int outh, int outw, float scale, float *__restrict__ y, int rsplit, const RoiBinTables tables) {
     __shared__ __attribute__((aligned(16))) float4 cells[kRows * kCellPitch * 2];
-    __shared__ uint16_t tab[2][kTabExt][8];            // [0] rows (outh), [1] columns (outw): lo | hi << 8, relative to the RoI origin
-    __shared__ uint8_t tabmax[2][kTabExt];             // tallest / widest bin of an extent
+    __shared__ __attribute__((aligned(16))) RoiBinTables tb;
     __shared__ int next_roi;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -479,44 +483,33 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
     const int c0 = blockIdx.x * 8;
     const int g0 = blockIdx.y;
 
-    // ---- 8 channel planes -> cells: one map row per wave and step (coalesced NCHW rows), all loads issued before the table
-    //      arithmetic below and landing during it
+    // ---- 8 channel planes -> cells: one map row per wave and step (coalesced NCHW rows) through a buffer descriptor -- rows past
+    //      H, columns past W and channels past C are out-of-range offsets that load 0: no branches; all loads are issued before the
+    //      table copy below and land during it
     constexpr int kRowsPerWave = (kRows + kCellWaves - 1) / kCellWaves;
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)C * HW * sizeof(float)));
     float v[kRowsPerWave][8];
 #pragma unroll
     for (int i = 0; i < kRowsPerWave; ++i) {
         const int h = wave + i * kCellWaves;
+        const uint32_t base = (h < H && lane < W) ? (uint32_t)((c0 * HW + h * W + lane) * 4) : kBufOob;
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-            v[i][c] = (h < H && lane < W && c0 + c < C) ? x[(size_t)(c0 + c) * HW + h * W + lane] : 0.0f;
+        for (int c = 0; c < 8; ++c) v[i][c] = frcnn_buf_load_f32(xbuf, base + (uint32_t)(c * HW * 4));   // c0 + c >= C: past the end -> 0
     }
     if (tid == 0) next_roi = 0;
-    for (int e = tid; e < 2 * kTabExt * 8; e += 64 * kCellWaves) {
-        const int t = e / (kTabExt * 8), ext = (e >> 3) % kTabExt, p = e & 7;
-        const int out = t ? outw : outh;
-        int lo = 0, hi = 0;
-        if (p < out && ext > 0) {
-            const double stride = (double)ext / (double)out;            // bin_range()'s arithmetic, offset and clamp applied per RoI
-            lo = (int)floor((double)p * stride);
-            hi = (int)ceil((double)(p + 1) * stride);
-        }
-        tab[t][ext][p] = (uint16_t)(lo | (hi << 8));
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(&tables);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&tb);
+        for (int e = tid; e < (int)(sizeof(RoiBinTables) / 4); e += 64 * kCellWaves) dst[e] = src[e];
     }
 #pragma unroll
     for (int i = 0; i < kRowsPerWave; ++i) {
         const int h = wave + i * kCellWaves;
         if (h < H && lane < W) {
-            float4 *dst = cells + (h * kCellPitch + cell_swz(lane)) * 2;
+            float4 *dst = cells + (h * kCellPitch + lane) * 2;
             dst[0] = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
             dst[1] = make_float4(v[i][4], v[i][5], v[i][6], v[i][7]);
         }
-    }
-    __syncthreads();
-    if (tid < 2 * kTabExt) {
-        const int t = tid / kTabExt, ext = tid % kTabExt;
-        int m = 0;
-        for (int p = 0; p < 8; ++p) { const int u = tab[t][ext][p]; m = max(m, (u >> 8) - (u & 255)); }
-        tabmax[t][ext] = (uint8_t)m;
     }
     __syncthreads();
 
@@ -525,8 +518,9 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
     const bool in_a = (l5 < 4) || (l5 >= 12 && l5 < 16) || (l5 >= 20 && l5 < 28);
     const int j = in_a ? (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12)) : (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16));
     const int pg = (lane >> 5) * 2 + (in_a ? 0 : 1);
-    const int cq = j & 1, pw = j >> 1;
-    const bool pw_on = pw < outw;
+    const int cq = j & 1;
+    const bool pw_on = (j >> 1) < outw;
+    const int pw = min(j >> 1, outw - 1);           // an idle lane shadows the last column bin: same addresses -> LDS broadcast, no conflict
 
     for (;;) {
         int slot = 0;
@@ -537,17 +531,17 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
         const RoiGeom g = roi_geometry(rois + (size_t)roi_cols * r + (roi_cols - 5), scale);
         int ws, we, hs[2], he[2], mbw, mbh;
         if (g.rw < kTabExt && g.rh < kTabExt) {                         // wave-uniform
-            const int tw = tab[1][g.rw][min(pw, 7)];
+            const int tw = tb.tab[1][g.rw][pw];
             ws = min(max((tw & 255) + g.xs, 0), W);
             we = min(max((tw >> 8) + g.xs, 0), W);
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const int th = tab[0][g.rh][min(2 * pg + s, 7)];
+                const int th = tb.tab[0][g.rh][min(2 * pg + s, 7)];
                 hs[s] = min(max((th & 255) + g.ys, 0), H);
                 he[s] = min(max((th >> 8) + g.ys, 0), H);
             }
-            mbw = tabmax[1][g.rw];
-            mbh = tabmax[0][g.rh];
+            mbw = tb.tabmax[1][g.rw];
+            mbh = tb.tabmax[0][g.rh];
         } else {                                                        // huge RoI: the arithmetic itself, trip counts = the map
             bin_range(min(pw, outw - 1), g.rw, outw, g.xs, W, ws, we);
 #pragma unroll
@@ -561,7 +555,8 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
         // first cell seeds the maximum (the oracle's scan order)
         int r0[2], r1[2];
         float4 first[2], acc[2];
-        const int c_first = cell_swz(min(max(ws, 0), W - 1)) * 2 + cq;
+        const int c_lo = min(ws, W - 1), c_hi = min(max(we - 1, c_lo), W - 1);      // first / last column of the bin, inside the map
+        const int c_first = c_lo * 2 + cq;
         bool any_empty = we <= ws;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -575,10 +570,10 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
 #pragma unroll 1
         for (int k0 = 0; k0 < mbw; k0 += 4) {
             const int nc = min(mbw - k0, 4);                            // wave-uniform
-            if (nc >= 4) cells_scan_chunk<4>(cells, k0, ws, we, cq, W, r0, r1, mbh, acc);
-            else if (nc == 3) cells_scan_chunk<3>(cells, k0, ws, we, cq, W, r0, r1, mbh, acc);
-            else if (nc == 2) cells_scan_chunk<2>(cells, k0, ws, we, cq, W, r0, r1, mbh, acc);
-            else cells_scan_chunk<1>(cells, k0, ws, we, cq, W, r0, r1, mbh, acc);
+            if (nc >= 4) cells_scan_chunk<4>(cells, k0, c_lo, c_hi, cq, r0, r1, mbh, acc);
+            else if (nc == 3) cells_scan_chunk<3>(cells, k0, c_lo, c_hi, cq, r0, r1, mbh, acc);
+            else if (nc == 2) cells_scan_chunk<2>(cells, k0, c_lo, c_hi, cq, r0, r1, mbh, acc);
+            else cells_scan_chunk<1>(cells, k0, c_lo, c_hi, cq, r0, r1, mbh, acc);
         }
         // rare fix-ups behind ONE wave-level test: a NaN first cell stays (`>` never replaces it: x + y + z + w is NaN iff one of them
         // is), an empty bin is 0
@@ -637,15 +632,33 @@ static bool roi_cells_launch(const float *x, int C, int H, int W, const float *r
     const char *sel = getenv("FRCNN_ROI_KERNEL");
     if (sel && sel[0] == 'p') return false;
     if (W > kCellPitch || H > 76) return false;
+    if ((size_t)C * H * W * sizeof(float) >= (1ull << 31)) return false;      // the map is read through a 32-bit buffer descriptor
     const int cgroups = frcnn_cdiv(C, 8);
     const int per_cu = H <= 38 ? 2 : 1;
-    int rsplit = frcnn_cdiv(per_cu * frcnn_roi_cu_count(), cgroups);       // about `per_cu` resident workgroups per CU
+    const char *mul = getenv("FRCNN_ROI_SPLIT_MUL");                         // tuning hook: workgroups per resident slot (default 1)
+    const int rounds = mul && atoi(mul) > 0 ? atoi(mul) : 1;
+    int rsplit = frcnn_cdiv(rounds * per_cu * frcnn_roi_cu_count(), cgroups);  // about `per_cu` resident workgroups per CU
     const int max_split = frcnn_cdiv(R, kCellWaves);                         // at least one RoI per wave
     if (rsplit > max_split) rsplit = max_split;
     if (rsplit < 1) rsplit = 1;
+    RoiBinTables tables;
+    memset(&tables, 0, sizeof(tables));
+    for (int t = 0; t < 2; ++t) {
+        const int out = t ? outw : outh;
+        for (int ext = 1; ext < kTabExt; ++ext) {
+            int m = 0;
+            for (int p = 0; p < out; ++p) {
+                const double stride = (double)ext / (double)out;                // bin_range()'s arithmetic; offset and clamp are applied per RoI
+                const int lo = (int)floor((double)p * stride), hi = (int)ceil((double)(p + 1) * stride);
+                tables.tab[t][ext][p] = (uint16_t)(lo | (hi << 8));
+                if (hi - lo > m) m = hi - lo;
+            }
+            tables.tabmax[t][ext] = (uint8_t)m;
+        }
+    }
     const dim3 grid(cgroups, rsplit), blk(64 * kCellWaves);
-    if (H <= 38) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<38, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<76, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit);
+    if (H <= 38) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<38, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, tables);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<76, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, tables);
     return true;
 }
 

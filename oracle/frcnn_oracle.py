@@ -570,9 +570,12 @@ def rpn_loss_grads(rpn_cls_score, rpn_bbox_pred, labels, targets, inds_inside, n
     return np.float32(lc.item()), np.float32(lb.item()), s.grad.numpy(), p.grad.numpy()
 
 
-def rpn_train_grads(p, x, labels, targets, inds_inside, n_all, delta=3.0, lam=1.0, layers=None):
+def rpn_train_grads(p, x, labels, targets, inds_inside, n_all, delta=3.0, lam=1.0, layers=None, f64_wgrad=()):
     """One RPN-mode forward/backward of FasterRCNN (faster_rcnn.py:110-116 -> region_proposal_network.py:116-145):
-    -> (rpn_loss, {chainer link path: gradient}) for the trunk and RPN parameters, given the anchor targets."""
+    -> (rpn_loss, {chainer link path: gradient}) for the trunk and RPN parameters, given the anchor targets.
+    f64_wgrad: trunk layer names whose WEIGHT gradient is additionally accumulated in float64 from the same fp32 upstream gradient
+    (returned under "<path>/W@f64"): at 600 x 1000 a conv1_x weight gradient is a 600 000-term fp32 sum, and two correct fp32
+    implementations differ by more than the sum's own rounding -- the float64 value is the arbiter."""
     import torch
     F = torch.nn.functional
     from_names = [k for k in p if k.startswith("trunk/") or k.startswith("RPN/")]
@@ -580,8 +583,16 @@ def rpn_train_grads(p, x, labels, targets, inds_inside, n_all, delta=3.0, lam=1.
     h = _t(x)
     layers = layers or ["conv1_1", "conv1_2", "pool", "conv2_1", "conv2_2", "pool", "conv3_1", "conv3_2", "conv3_3", "pool",
                         "conv4_1", "conv4_2", "conv4_3", "pool", "conv5_1", "conv5_2", "conv5_3"]
+    taps = {}
     for l in layers:
-        h = F.max_pool2d(h, 2, 2, ceil_mode=True) if l == "pool" else F.relu(F.conv2d(h, tp["trunk/%s/W" % l], tp["trunk/%s/b" % l], padding=1))
+        if l == "pool":
+            h = F.max_pool2d(h, 2, 2, ceil_mode=True)
+            continue
+        pre = F.conv2d(h, tp["trunk/%s/W" % l], tp["trunk/%s/b" % l], padding=1)
+        if l in f64_wgrad:
+            pre.retain_grad()
+            taps[l] = (h.detach(), pre)
+        h = F.relu(pre)
     hh = F.relu(F.conv2d(h, tp["RPN/rpn_conv_3x3/W"], tp["RPN/rpn_conv_3x3/b"], padding=1))
     score = F.conv2d(hh, tp["RPN/rpn_cls_score/W"], tp["RPN/rpn_cls_score/b"])
     bbox = F.conv2d(hh, tp["RPN/rpn_bbox_pred/W"], tp["RPN/rpn_bbox_pred/b"])
@@ -589,7 +600,11 @@ def rpn_train_grads(p, x, labels, targets, inds_inside, n_all, delta=3.0, lam=1.
     A = int(score.shape[1]) // 2
     lc, lb, total = _torch_rpn_losses(score, bbox, labels, targets, inds_inside, n_all, fh, fw, A, delta, lam)
     total.backward()
-    return np.float32(total.item()), {k: v.grad.numpy() for k, v in tp.items()}
+    grads = {k: v.grad.numpy() for k, v in tp.items()}
+    for l, (xin, pre) in taps.items():
+        W = tp["trunk/%s/W" % l]
+        grads["trunk/%s/W@f64" % l] = torch.nn.grad.conv2d_weight(xin.double(), tuple(W.shape), pre.grad.double(), padding=1).numpy()
+    return np.float32(total.item()), grads
 
 
 # --------------------------------------------------------------------------- ResNet trunk (chainer-ext)

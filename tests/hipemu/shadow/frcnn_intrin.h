@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 static inline float frcnn_max_f32(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+static inline float frcnn_min_f32(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
 static inline float frcnn_max3_f32(float a, float b, float c) { return frcnn_max_f32(frcnn_max_f32(a, b), c); }
 
 typedef float frcnn_f32x16 __attribute__((ext_vector_type(16)));

@@ -281,7 +281,7 @@ def test_conv_bf16_staging_variants_bit_identical(rt, monkeypatch, cin, cout, h,
     wt = rt.bf16_pack_conv_w(rt.mem.from_numpy((rs.randn(cout, cin, 3, 3) * 0.05).astype(np.float32)), 3)
     b = rt.mem.from_numpy(rs.randn(cout).astype(np.float32))
     outs = {}
-    for mode in ["0", "-1", "141", "231", "321", "132", "222"]:
+    for mode in ["0", "-1", "141", "231", "321", "132", "222", "223", "233", "224", "324", "124", "133"]:
         monkeypatch.setenv("FRCNN_BF16_DMA", mode)
         outs[mode] = (rt.mem.to_numpy(rt.conv_bf16(x, wt, b, cin, cout, 3, relu=True)),
                       rt.mem.to_numpy(rt.conv_bf16(x, wt, b, cin, cout, 3, relu=True, pool=True)))
@@ -289,9 +289,11 @@ def test_conv_bf16_staging_variants_bit_identical(rt, monkeypatch, cin, cout, h,
         assert np.array_equal(full, outs["0"][0]) and np.array_equal(pooled, outs["0"][1]), mode
 
 
-@pytest.mark.parametrize("split", ["2", "4"])
-def test_conv_bf16_split_k(rt, monkeypatch, split):
+@pytest.mark.parametrize("split,mode", [("2", None), ("4", None), ("2", "224"), ("4", "223")])
+def test_conv_bf16_split_k(rt, monkeypatch, split, mode):
     monkeypatch.setenv("FRCNN_BF16_SPLIT", split)
+    if mode:
+        monkeypatch.setenv("FRCNN_BF16_DMA", mode)
     P.check_conv_bf16(rt, 512, 512, 38, 63)              # the shape split-K exists for: 160 tiles, 32 chunks
     P.check_conv_bf16_pool(rt, 256, 512, 75, 125, seed=1)
 

@@ -181,7 +181,7 @@ def test_conv_bf16_eight_row_tiles(rt, monkeypatch):
     P.check_conv_bf16(rt, 32, 128, 8, 33, seed=4)
 
 
-@pytest.mark.parametrize("mode", ["321", "231", "141", "132", "222", "0"])
+@pytest.mark.parametrize("mode", ["321", "231", "141", "132", "222", "0", "223", "233", "323", "224", "324", "124", "133"])
 def test_conv_bf16_lds_dma(rt, monkeypatch, mode):
     """Every LDS-DMA staging variant of the 3x3 bf16 kernel (lane-linear swizzled LDS image, NS-stage ring) and the
     register-staged kernel ("0"): same results.  The default picks 141 / 231 by launch size."""
@@ -192,10 +192,12 @@ def test_conv_bf16_lds_dma(rt, monkeypatch, mode):
     P.check_conv_bf16_pool(rt, 48, 64, 9, 37, seed=3)
 
 
-@pytest.mark.parametrize("split", ["2", "4"])
-def test_conv_bf16_split_k(rt, monkeypatch, split):
+@pytest.mark.parametrize("split,mode", [("2", None), ("4", None), ("2", "224"), ("4", "223")])
+def test_conv_bf16_split_k(rt, monkeypatch, split, mode):
     """Split-K form of the bf16 3x3 kernel: partial tiles through the workspace, last arriver sums in split order."""
     monkeypatch.setenv("FRCNN_BF16_SPLIT", split)
+    if mode:
+        monkeypatch.setenv("FRCNN_BF16_DMA", mode)
     P.check_conv_bf16(rt, 128, 64, 9, 37, seed=5)         # 8 chunks: 2 or 4 splits of >= 2 chunks ... (the picker wants >= 4 per split)
     P.check_conv_bf16(rt, 256, 128, 6, 40, seed=6)        # 16 chunks
     P.check_conv_bf16_pool(rt, 256, 64, 8, 33, seed=7)

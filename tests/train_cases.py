@@ -37,7 +37,7 @@ def build_small(rt, params):
     return model
 
 
-def oracle_step(params, x, gt, info, layers, feat_stride, scales, seed):
+def oracle_step(params, x, gt, info, layers, feat_stride, scales, seed, f64_wgrad=()):
     """The oracle's forward/backward for one image: anchor targets with the SAME NumPy RNG state, then autograd."""
     names = [l if l == "pool" else l[0] for l in layers]
     h, w = x.shape[2], x.shape[3]
@@ -46,7 +46,7 @@ def oracle_step(params, x, gt, info, layers, feat_stride, scales, seed):
             h, w = (h + 1) // 2, (w + 1) // 2
     np.random.seed(seed)
     labels, targets, inds, n_all = O.anchor_target_layer(h, w, gt, info, feat_stride=feat_stride, anchor_scales=scales)
-    loss, grads = O.rpn_train_grads(params, x, labels, targets, inds, n_all, layers=names)
+    loss, grads = O.rpn_train_grads(params, x, labels, targets, inds, n_all, layers=names, f64_wgrad=f64_wgrad)
     return loss, grads
 
 
@@ -108,16 +108,26 @@ def check_vgg_step(rt, im_h=160, im_w=224, seed=0):
     tr = RPNTrainer(model)
     np.random.seed(11)
     out = tr.forward_backward(Variable(x), Variable(info), Variable(gt))
-    want_loss, want = oracle_step(params, x, gt, info, LAYERS, 16, (8, 16, 32), 11)
+    # the weight gradients of the 600 x 1000 / 300 x 500 layers are 150 000 ... 600 000-term fp32 sums: judged against a float64
+    # accumulation of the same fp32 upstream gradient (the fp32 autograd value's own distance from it is reported)
+    big = ("conv1_1", "conv1_2", "conv2_1", "conv2_2") if im_h * im_w >= 300000 else ()
+    want_loss, want = oracle_step(params, x, gt, info, LAYERS, 16, (8, 16, 32), 11, f64_wgrad=big)
     l = tr.losses_host(out)
     assert abs(l["rpn_loss"] - want_loss) <= 1e-4 * abs(want_loss), (l, want_loss)
     got = tr.grads_chainer_layout()
-    worst = 0.0
+    worst, notes = 0.0, {}
     for k in sorted(want):
-        scale = max(np.abs(want[k]).max(), 1e-8)
-        err = np.abs(got[k] - want[k]).max() / scale
+        if k.endswith("@f64"):
+            continue
+        ref = want.get(k + "@f64", want[k])
+        scale = max(np.abs(ref).max(), 1e-8)
+        err = np.abs(got[k] - ref).max() / scale
+        if k + "@f64" in want:
+            notes[k] = {"device_vs_f64": float(err), "torch_fp32_vs_f64": float(np.abs(want[k] - ref).max() / scale)}
         worst = max(worst, err)
         assert err <= 1e-3, (k, err)
+    if notes:
+        print("\nwgrad vs float64 accumulation: %s" % notes)
     return l, worst
 
 
