@@ -307,24 +307,27 @@ __device__ __forceinline__ unsigned long long nms_tile_words(const float4 rb, co
 
 __global__ void __launch_bounds__(256)
 nms_mask_kernel(const float *__restrict__ sorted_boxes, const int *__restrict__ counters, int top_k, double thresh,
-                unsigned long long *__restrict__ mask, int pitch, size_t slab) {
+                unsigned long long *__restrict__ mask, int pitch, size_t slab, int cc_lo, int cc_hi, const int32_t *__restrict__ n_done,
+                int max_out) {
     sorted_boxes = slab_ptr(sorted_boxes, slab); counters = slab_ptr(counters, slab); mask = slab_ptr(mask, slab);
     int m = counters[0];
     if (top_k > 0 && top_k < m) m = top_k;
     const int n_chunks = (m + kChunk - 1) / kChunk;
+    // second stage of a staged launch: nothing to do when the first stage's scan already kept `limit` boxes
+    if (n_done && n_done[blockIdx.z] >= ((max_out > 0 && max_out < m) ? max_out : m)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // linear upper-triangle tile index -> (rc, cc), rows enumerated over the STATIC pitch (the launch is sized before m is known)
-    const long long T = (long long)blockIdx.x * 4 + wave;
-    const long long total = (long long)pitch * (pitch + 1) / 2;
-    if (T >= total) return;
-    // row rc starts at S(rc) = rc * pitch - rc (rc - 1) / 2; invert with a floating-point estimate and fix up
-    int rc = (int)((2.0 * pitch + 1.0 - sqrt((2.0 * pitch + 1.0) * (2.0 * pitch + 1.0) - 8.0 * (double)T)) * 0.5);
-    rc = min(max(rc, 0), pitch - 1);
-    while (rc > 0 && (long long)rc * pitch - (long long)rc * (rc - 1) / 2 > T) --rc;
-    while (rc + 1 < pitch && (long long)(rc + 1) * pitch - (long long)(rc + 1) * rc / 2 <= T) ++rc;
-    rc = __builtin_amdgcn_readfirstlane(rc);
-    const int cc = __builtin_amdgcn_readfirstlane(rc + (int)(T - ((long long)rc * pitch - (long long)rc * (rc - 1) / 2)));
+    // tiles of the upper triangle, enumerated column by column (column cc holds rows 0 .. cc); this launch covers columns
+    // [cc_lo, cc_hi) of the STATIC pitch (it is sized before m is known): tile T' = T + tri(cc_lo), tri(k) = k (k + 1) / 2
+    const long long tri_lo = (long long)cc_lo * (cc_lo + 1) / 2;
+    const long long Tp = (long long)blockIdx.x * 4 + wave + tri_lo;
+    if (Tp >= (long long)cc_hi * (cc_hi + 1) / 2) return;
+    int cc = (int)((sqrt(8.0 * (double)Tp + 1.0) - 1.0) * 0.5);
+    cc = min(max(cc, 0), pitch - 1);
+    while (cc > 0 && (long long)cc * (cc + 1) / 2 > Tp) --cc;
+    while ((long long)(cc + 1) * (cc + 2) / 2 <= Tp) ++cc;
+    cc = __builtin_amdgcn_readfirstlane(cc);
+    const int rc = __builtin_amdgcn_readfirstlane((int)(Tp - (long long)cc * (cc + 1) / 2));
     if (rc >= n_chunks || cc >= n_chunks) return;                      // wave-uniform
     const int c = cc * kChunk + lane, r = rc * kChunk + lane;
     float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), rb = cb;
@@ -550,19 +553,35 @@ nms_scan_wave_kernel(const unsigned long long *__restrict__ mask, int pitch, con
 }
 
 // ------------------------------------------------------------------------------------------------
-// The single-wave pass, FOUR chunks per memory round trip.  The chain of the kernel above is one dependent trip to the mask per
-// 64-box chunk (the rows of the boxes it keeps must be OR-ed in before the next chunk can be resolved): 94 trips for 6000 boxes,
-// ~0.45 us each -- the mask was written by other XCDs, so every trip goes to the Infinity Cache.  Here a "super-chunk" of 256 boxes
-// is resolved from registers: its 4 x 4 block of diagonal words (the upper 10; lane l holds row l of each sub-chunk) is prefetched
-// one super-chunk ahead, suppression INSIDE the super-chunk is propagated with v_readlane as boxes are kept, and the rows of all
-// boxes kept in the super-chunk are fetched together (up to 16 in flight) for the chunks after it: one exposed trip per 256 boxes.
-template <int NJ>
+// The sequential pass in COLUMN form, one wave, any number of chunks.  The row form above ORs the whole mask row of every box it
+// keeps into a bitmap: one dependent trip to memory per 16 kept rows, ~0.45 us each (the mask was written by other XCDs) -- with
+// 300 survivors among the first 600 boxes, as on the benchmark image, 19 such trips are most of its 41 us.  Here the removed-word of
+// chunk c+1 is gathered directly, and one chunk AHEAD of its use:
+//     removed(c+1) = OR { mask[i][c+1] : i kept in chunks < c }        <- one 8-byte load per kept box, issued BEFORE chunk c is resolved
+//                  | OR { mask[c*64+l][c+1] : lane l kept in chunk c }  <- the super-diagonal word of every row of chunk c, prefetched
+// so no load sits on the dependent chain; only words that are actually needed are ever read (kept boxes x visited chunks).  The list
+// of kept rows lives in LDS (first 2048; beyond that it is read back from keep_pos).
+// Stages: the host may split the chunk range in two launches ([0, S) and [S, end)) with the mask of the second computed in
+// between; a later stage finds n_out[0] >= limit (or no chunks left) and exits at once -- see frcnn_proposals.
+constexpr int kKeptLds = 2048;
+
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        lo |= (uint32_t)__shfl_xor((int)lo, d);
+        hi |= (uint32_t)__shfl_xor((int)hi, d);
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+
 __global__ void __launch_bounds__(64)
-nms_scan_wave4_kernel(const unsigned long long *__restrict__ mask, int pitch, const int *__restrict__ counters_in, int top_k,
-                      int max_out, const int32_t *__restrict__ order, const float *__restrict__ sorted_boxes,
-                      const float *__restrict__ sorted_scores, int32_t *__restrict__ keep_pos, int32_t *__restrict__ out_index,
-                      float *__restrict__ out_boxes, float *__restrict__ out_scores, int32_t *__restrict__ n_out,
-                      int out_capacity, size_t slab, size_t out_gs) {
+nms_scan_col_kernel(const unsigned long long *__restrict__ mask, int pitch, const int *__restrict__ counters_in, int top_k,
+                    int max_out, const int32_t *__restrict__ order, const float *__restrict__ sorted_boxes,
+                    const float *__restrict__ sorted_scores, int32_t *__restrict__ keep_pos, int32_t *__restrict__ out_index,
+                    float *__restrict__ out_boxes, float *__restrict__ out_scores, int32_t *__restrict__ n_out,
+                    int out_capacity, size_t slab, size_t out_gs, int c_begin, int c_end, int first_stage, int last_stage) {
+    __shared__ int kept_list[kKeptLds];
     const int gz = blockIdx.z;
     counters_in = slab_ptr(counters_in, slab); mask = slab_ptr(mask, slab); order = slab_ptr(order, slab);
     sorted_boxes = slab_ptr(sorted_boxes, slab); sorted_scores = slab_ptr(sorted_scores, slab); keep_pos = slab_ptr(keep_pos, slab);
@@ -574,106 +593,63 @@ nms_scan_wave4_kernel(const unsigned long long *__restrict__ mask, int pitch, co
     if (top_k > 0 && top_k < m) m = top_k;
     const int limit = (max_out > 0 && max_out < m) ? max_out : m;
     const int n_chunks = (m + kChunk - 1) / kChunk;
-    const int n_super = (n_chunks + 3) / 4;
     const int lane = threadIdx.x;
-    unsigned long long rem[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) rem[j] = 0ull;
     int n_kept = 0;
-    unsigned long long dnext[4][4];
-    auto load_diag = [&](int S, unsigned long long (&D)[4][4]) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = a; b < 4; ++b) {
-                const int row = (4 * S + a) * kChunk + lane, col = 4 * S + b;
-                D[a][b] = (row < m && col < n_chunks) ? mask[(size_t)row * pitch + col] : 0ull;
+    if (!first_stage) {
+        n_kept = n_out[0];
+        if (n_kept >= limit || c_begin >= n_chunks) return;        // an earlier stage finished the job and wrote the outputs
+        for (int k = lane; k < min(n_kept, kKeptLds); k += 64) kept_list[k] = keep_pos[k];
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int c_stop = min(c_end, n_chunks);
+    auto gather = [&](int col, int upto) -> unsigned long long {   // this lane's share of OR { mask[kept row][col] }
+        unsigned long long acc = 0ull;
+        if (col < n_chunks)
+            for (int k = lane; k < upto; k += 64) {
+                const int row = k < kKeptLds ? kept_list[k] : keep_pos[k];
+                acc |= mask[(size_t)row * pitch + col];
             }
+        return acc;
     };
-    load_diag(0, dnext);
-    for (int S = 0; S < n_super && n_kept < limit; ++S) {
-        unsigned long long D[4][4];
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = a; b < 4; ++b) D[a][b] = dnext[a][b];
-        if (S + 1 < n_super) load_diag(S + 1, dnext);              // lands while this super-chunk is resolved
-        unsigned long long local[4] = {0ull, 0ull, 0ull, 0ull};    // bits removed by boxes kept INSIDE this super-chunk (wave-uniform)
-        unsigned long long keptw[4] = {0ull, 0ull, 0ull, 0ull};
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int c = 4 * S + a;
-            if (c < n_chunks && n_kept < limit) {                   // wave-uniform
-                unsigned long long sel = rem[0];
-#pragma unroll
-                for (int j = 1; j < NJ; ++j) sel = ((c >> 6) == j) ? rem[j] : sel;
-                const uint32_t rlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)sel, c & 63);
-                const uint32_t rhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(sel >> 32), c & 63);
-                const int in_chunk = min(kChunk, m - c * kChunk);
-                const unsigned long long valid = in_chunk == 64 ? ~0ull : ((1ull << in_chunk) - 1ull);
-                unsigned long long alive = ~((((unsigned long long)rhi << 32) | rlo) | local[a]) & valid;
-                unsigned long long kept = 0ull;
-                int budget = limit - n_kept;
-                while (alive != 0ull && budget > 0) {
-                    const int i = __ffsll((long long)alive) - 1;
-                    kept |= 1ull << i;
-                    --budget;
-#pragma unroll
-                    for (int b = a; b < 4; ++b) {
-                        const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)D[a][b], i);
-                        const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(D[a][b] >> 32), i);
-                        const unsigned long long w = ((unsigned long long)shi << 32) | slo;
-                        if (b == a) alive &= ~w;
-                        else local[b] |= w;
-                    }
-                    alive &= ~(1ull << i);
-                }
-                if ((kept >> lane) & 1ull) keep_pos[n_kept + __popcll(kept & ((1ull << lane) - 1ull))] = c * kChunk + lane;
-                n_kept += __popcll(kept);
-                keptw[a] = kept;
-            }
+    auto load_word = [&](int c, int col) -> unsigned long long {
+        const int row = c * kChunk + lane;
+        return (c < n_chunks && col < n_chunks && row < m) ? mask[(size_t)row * pitch + col] : 0ull;
+    };
+    unsigned long long removed = first_stage ? 0ull : wave_or_u64(gather(c_begin, n_kept));
+    unsigned long long diag = load_word(c_begin, c_begin), sup = load_word(c_begin, c_begin + 1);
+    for (int c = c_begin; c < c_stop && n_kept < limit; ++c) {
+        if (n_kept > kKeptLds) frcnn_drain_vmem();                  // rows past the LDS list are read back from keep_pos: written by this wave
+        const unsigned long long part_next = gather(c + 1, n_kept); // in flight while the chunk is resolved
+        const unsigned long long diag_n = load_word(c + 1, c + 1), sup_n = load_word(c + 1, c + 2);
+        const int in_chunk = min(kChunk, m - c * kChunk);
+        const unsigned long long valid = in_chunk == 64 ? ~0ull : ((1ull << in_chunk) - 1ull);
+        unsigned long long alive = ~removed & valid;
+        const int dlo = (int)(uint32_t)diag, dhi = (int)(uint32_t)(diag >> 32);
+        unsigned long long kept = 0ull;
+        int budget = limit - n_kept;
+        while (alive != 0ull && budget > 0) {
+            const int i = __ffsll((long long)alive) - 1;
+            kept |= 1ull << i;
+            --budget;
+            const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane(dlo, i);
+            const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane(dhi, i);
+            alive &= ~(((unsigned long long)shi << 32) | slo);
+            alive &= ~(1ull << i);
         }
-        if (n_kept < limit && 4 * S + 4 < n_chunks) {
-            // rows of every box kept in this super-chunk, RB at a time with all their loads in flight (a short round repeats its
-            // first row: OR is idempotent); only the words of chunks AFTER the super-chunk are needed
-            constexpr int RB = NJ <= 2 ? 16 : 8;
-            const int c_last = 4 * S + 3;
-            int a_cur = 0;
-            unsigned long long kk = keptw[0];
-            auto next_row = [&]() -> int {                           // next kept row of the super-chunk, or -1
-                while (kk == 0ull && a_cur < 3) { ++a_cur; kk = keptw[a_cur]; }
-                if (kk == 0ull) return -1;
-                const int i = __ffsll((long long)kk) - 1;
-                kk &= kk - 1ull;
-                return (4 * S + a_cur) * kChunk + i;
-            };
-            for (;;) {
-                int rows[RB];
-                rows[0] = next_row();
-                if (rows[0] < 0) break;
-#pragma unroll
-                for (int q = 1; q < RB; ++q) { const int rr = next_row(); rows[q] = rr >= 0 ? rr : rows[0]; }
-                unsigned long long v[RB][NJ];
-#pragma unroll
-                for (int q = 0; q < RB; ++q) {
-                    const unsigned long long *row = mask + (size_t)rows[q] * pitch;
-#pragma unroll
-                    for (int j = 0; j < NJ; ++j) {
-                        const int w = lane + 64 * j;
-                        v[q][j] = (w > c_last && w < n_chunks) ? row[w] : 0ull;
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) {
-                    unsigned long long acc = 0ull;
-#pragma unroll
-                    for (int q = 0; q < RB; ++q) acc |= v[q][j];
-                    rem[j] |= acc;
-                }
-            }
+        const bool mine = (kept >> lane) & 1ull;
+        if (mine) {
+            const int idx = n_kept + __popcll(kept & ((1ull << lane) - 1ull));
+            keep_pos[idx] = c * kChunk + lane;
+            if (idx < kKeptLds) kept_list[idx] = c * kChunk + lane;
         }
+        n_kept += __popcll(kept);
+        removed = wave_or_u64(part_next | (mine ? sup : 0ull));
+        diag = diag_n;
+        sup = sup_n;
+        __builtin_amdgcn_wave_barrier();                            // kept_list: written above, read by other lanes in the next gather
     }
     if (lane == 0) n_out[0] = n_kept;
+    if (!(n_kept >= limit || c_stop >= n_chunks || last_stage)) return;   // a later stage continues (and writes the outputs)
     frcnn_drain_vmem();                               // keep_pos was written by other lanes of this wave
     __builtin_amdgcn_wave_barrier();
     for (int k = lane; k < n_kept; k += 64) {
@@ -701,7 +677,17 @@ static bool scan_one_chunk_per_trip() {
     return e && e[0] == '1';
 }
 
-static int mask_blocks(int pitch) { return (int)(((long long)pitch * (pitch + 1) / 2 + 3) / 4); }   // 4 upper-triangle tiles per block
+// blocks (4 tiles each) of a mask launch over columns [lo, hi) of the upper triangle
+static int mask_blocks(int lo, int hi) { return (int)((((long long)hi * (hi + 1) - (long long)lo * (lo + 1)) / 2 + 3) / 4); }
+// first-stage width of a staged NMS: 4 x post_nms_top_n boxes (a greedy NMS that keeps `limit` boxes has usually done so long before
+// it has looked at 4 x limit of them: 610 of 6000 on the benchmark image); 0 = one stage
+static int nms_stage_chunks(int pitch, int max_out) {
+    const char *e = getenv("FRCNN_NMS_STAGE");
+    if (e && e[0] == '0') return 0;
+    if (max_out <= 0) return 0;
+    const int s = (4 * max_out + kChunk - 1) / kChunk;
+    return (s + 8 <= pitch) ? s : 0;                                   // not worth two launches for the last few columns
+}
 
 static Layout make_layout(int n_total, int top_k, bool own_boxes) {
     Layout L;
@@ -722,6 +708,40 @@ static Layout make_layout(int n_total, int top_k, bool own_boxes) {
     L.mask = o; o += frcnn_align256((size_t)L.m_max * L.pitch * 8);
     L.total = o;
     return L;
+}
+
+// Mask + sequential pass of one (possibly batched) NMS problem, in one or two stages (see nms_scan_col_kernel).
+static void launch_mask_and_scan(hipStream_t stream, int groups, const Layout &L, const float *sboxes, const int *counters, int top_k,
+                                 double thresh, int max_out, unsigned long long *mask, const int32_t *order, const float *sscores,
+                                 int32_t *keep_pos, int32_t *out_index, float *out_boxes, float *out_scores, int32_t *n_out,
+                                 int out_capacity, size_t slab, size_t out_gs) {
+    const dim3 blk(256);
+    if (scan_one_chunk_per_trip()) {                       // round-1 row-form scan (A/B measurements)
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_blocks(0, L.pitch), 1, groups), blk, 0, stream, sboxes, counters, top_k, thresh, mask,
+                           L.pitch, slab, 0, L.pitch, (const int32_t *)nullptr, max_out);
+        if (L.pitch <= 128)
+            hipLaunchKernelGGL(nms_scan_wave_kernel<2>, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, top_k, max_out, order,
+                               sboxes, sscores, keep_pos, out_index, out_boxes, out_scores, n_out, out_capacity, slab, out_gs);
+        else if (L.pitch <= kWaveChunks)
+            hipLaunchKernelGGL(nms_scan_wave_kernel<4>, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, top_k, max_out, order,
+                               sboxes, sscores, keep_pos, out_index, out_boxes, out_scores, n_out, out_capacity, slab, out_gs);
+        else
+            hipLaunchKernelGGL(nms_scan_kernel, dim3(1, 1, groups), blk, 0, stream, mask, L.pitch, counters, top_k, max_out, order, sboxes,
+                               sscores, keep_pos, out_index, out_boxes, out_scores, n_out, out_capacity, slab, out_gs);
+        return;
+    }
+    const int S = nms_stage_chunks(L.pitch, max_out);
+    const int hi0 = S > 0 ? S : L.pitch;
+    hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_blocks(0, hi0), 1, groups), blk, 0, stream, sboxes, counters, top_k, thresh, mask, L.pitch,
+                       slab, 0, hi0, (const int32_t *)nullptr, max_out);
+    hipLaunchKernelGGL(nms_scan_col_kernel, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, top_k, max_out, order, sboxes,
+                       sscores, keep_pos, out_index, out_boxes, out_scores, n_out, out_capacity, slab, out_gs, 0, hi0, 1, S > 0 ? 0 : 1);
+    if (S > 0) {
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_blocks(S, L.pitch), 1, groups), blk, 0, stream, sboxes, counters, top_k, thresh, mask,
+                           L.pitch, slab, S, L.pitch, (const int32_t *)n_out, max_out);
+        hipLaunchKernelGGL(nms_scan_col_kernel, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, top_k, max_out, order, sboxes,
+                           sscores, keep_pos, out_index, out_boxes, out_scores, n_out, out_capacity, slab, out_gs, S, L.pitch, 0, 1);
+    }
 }
 
 }  // namespace
@@ -757,29 +777,8 @@ int frcnn_nms_batched(const float *dets, int groups, int n, double thresh, int m
     hipLaunchKernelGGL(tile_sort_kernel, dim3(L.n_tiles, 1, groups), dim3(kSortThreads), 0, stream, keys, gs);
     hipLaunchKernelGGL(rank_scatter_kernel, dim3(frcnn_cdiv(L.n_pad, 256), 1, groups), blk, 0, stream, keys, L.n_tiles, dets, 5,
                        dets + 4, 5, 0, counters, 0, order, sboxes, sscores, (size_t)n * 5, gs);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_blocks(L.pitch), 1, groups), blk, 0, stream, sboxes, counters, 0, thresh,
-                       mask, L.pitch, gs);
-    const bool scan1 = scan_one_chunk_per_trip();
-    if (L.pitch <= 128 && !scan1)
-        hipLaunchKernelGGL(nms_scan_wave4_kernel<2>, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, 0, max_out, order, sboxes,
-                           sscores, keep_pos, keep, (float *)nullptr, (float *)nullptr, n_keep,
-                           (max_out > 0 && max_out < n) ? max_out : n, gs, (size_t)n);
-    else if (L.pitch <= kWaveChunks && !scan1)
-        hipLaunchKernelGGL(nms_scan_wave4_kernel<4>, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, 0, max_out, order, sboxes,
-                           sscores, keep_pos, keep, (float *)nullptr, (float *)nullptr, n_keep,
-                           (max_out > 0 && max_out < n) ? max_out : n, gs, (size_t)n);
-    else if (L.pitch <= 128)
-        hipLaunchKernelGGL(nms_scan_wave_kernel<2>, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, 0, max_out, order, sboxes,
-                           sscores, keep_pos, keep, (float *)nullptr, (float *)nullptr, n_keep,
-                           (max_out > 0 && max_out < n) ? max_out : n, gs, (size_t)n);
-    else if (L.pitch <= kWaveChunks)
-        hipLaunchKernelGGL(nms_scan_wave_kernel<4>, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, 0, max_out, order, sboxes,
-                           sscores, keep_pos, keep, (float *)nullptr, (float *)nullptr, n_keep,
-                           (max_out > 0 && max_out < n) ? max_out : n, gs, (size_t)n);
-    else
-        hipLaunchKernelGGL(nms_scan_kernel, dim3(1, 1, groups), blk, 0, stream, mask, L.pitch, counters, 0, max_out, order, sboxes,
-                           sscores, keep_pos, keep, (float *)nullptr, (float *)nullptr, n_keep,
-                           (max_out > 0 && max_out < n) ? max_out : n, gs, (size_t)n);
+    launch_mask_and_scan(stream, groups, L, sboxes, counters, 0, thresh, max_out, mask, order, sscores, keep_pos, keep, (float *)nullptr,
+                         (float *)nullptr, n_keep, (max_out > 0 && max_out < n) ? max_out : n, gs, (size_t)n);
     return frcnn_launch_status();
 }
 
@@ -823,29 +822,8 @@ int frcnn_proposals(const float *rpn_cls_prob, const float *rpn_bbox_pred, int A
     hipLaunchKernelGGL(tile_sort_kernel, dim3(L.n_tiles), dim3(kSortThreads), 0, stream, keys, (size_t)0);
     hipLaunchKernelGGL(rank_scatter_kernel, dim3(frcnn_cdiv(L.n_pad, 256)), blk, 0, stream, keys, L.n_tiles, boxes, 4, scores, 1,
                        pre_nms_top_n, counters, L.n_pad / 256, order, sboxes, sscores, (size_t)0, (size_t)0);
-    hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_blocks(L.pitch)), blk, 0, stream, sboxes, counters, pre_nms_top_n,
-                       nms_thresh, mask, L.pitch, (size_t)0);
-    const bool scan1 = scan_one_chunk_per_trip();
-    if (L.pitch <= 128 && !scan1)
-        hipLaunchKernelGGL(nms_scan_wave4_kernel<2>, dim3(1), dim3(64), 0, stream, mask, L.pitch, counters, pre_nms_top_n, post_nms_top_n, order,
-                           sboxes, sscores, keep_pos, src_index, rois, probs, n_out,
-                           (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
-    else if (L.pitch <= kWaveChunks && !scan1)
-        hipLaunchKernelGGL(nms_scan_wave4_kernel<4>, dim3(1), dim3(64), 0, stream, mask, L.pitch, counters, pre_nms_top_n, post_nms_top_n, order,
-                           sboxes, sscores, keep_pos, src_index, rois, probs, n_out,
-                           (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
-    else if (L.pitch <= 128)
-        hipLaunchKernelGGL(nms_scan_wave_kernel<2>, dim3(1), dim3(64), 0, stream, mask, L.pitch, counters, pre_nms_top_n, post_nms_top_n, order,
-                           sboxes, sscores, keep_pos, src_index, rois, probs, n_out,
-                           (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
-    else if (L.pitch <= kWaveChunks)
-        hipLaunchKernelGGL(nms_scan_wave_kernel<4>, dim3(1), dim3(64), 0, stream, mask, L.pitch, counters, pre_nms_top_n, post_nms_top_n, order,
-                           sboxes, sscores, keep_pos, src_index, rois, probs, n_out,
-                           (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
-    else
-        hipLaunchKernelGGL(nms_scan_kernel, dim3(1), blk, 0, stream, mask, L.pitch, counters, pre_nms_top_n, post_nms_top_n, order,
-                           sboxes, sscores, keep_pos, src_index, rois, probs, n_out,
-                           (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
+    launch_mask_and_scan(stream, 1, L, sboxes, counters, pre_nms_top_n, nms_thresh, post_nms_top_n, mask, order, sscores, keep_pos, src_index,
+                         rois, probs, n_out, (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
     return frcnn_launch_status();
 }
 

@@ -399,7 +399,6 @@ roi_pool_planes_kernel(const float *__restrict__ x, int C, int H, int W, const f
 //   * 78 KB of LDS and 512 threads per workgroup: TWO workgroups per CU.
 // Scan order = the oracle's: the bin's first cell, then NaN-ignoring maxima; a NaN first cell is restored at the end.
 constexpr int kCellPitch = 64;           // cells per LDS row
-constexpr int kCellWaves = 8;
 constexpr int kTabExt = 72;              // the bin tables cover extents 1 .. kTabExt-1
 
 // Bin-edge tables (relative to the RoI origin) for every extent below kTabExt, built ON THE HOST with the oracle's double arithmetic
@@ -427,55 +426,49 @@ __device__ __forceinline__ void cells_scan_chunk(const float4 *__restrict__ cell
 #pragma unroll
     for (int q = 0; q < NC; ++q) ca[q] = min(c_lo + k0 + q, c_hi) * 2 + cq;
     int row[2] = {r0[0], r0[1]};                    // float4 index of the current map row of each bin
-    auto fetch = [&](float4 (&buf)[2][NC]) {
+    float4 buf[2][NC];                              // one register buffer per bin: bin 1's cells are in flight while bin 0's maxima are
+                                                    // taken and vice versa (two buffers per bin did not fit the 128-register budget of
+                                                    // a 16-wave workgroup)
+    auto fetch = [&](int s) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
-#pragma unroll
-            for (int q = 0; q < NC; ++q) buf[s][q] = cells[row[s] + ca[q]];
+        for (int q = 0; q < NC; ++q) buf[s][q] = cells[row[s] + ca[q]];
     };
-    auto advance = [&]() {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) row[s] = min(row[s] + kCellPitch * 2, r1[s]);
+    auto take = [&](int s) {
+        if constexpr (NC == 1) acc[s] = max4(acc[s], buf[s][0]);
+        else if constexpr (NC == 2) acc[s] = max4_3(acc[s], buf[s][0], buf[s][1]);
+        else if constexpr (NC == 3) acc[s] = max4(max4_3(acc[s], buf[s][0], buf[s][1]), buf[s][2]);
+        else acc[s] = max4_3(max4_3(acc[s], buf[s][0], buf[s][1]), buf[s][2], buf[s][3]);
     };
-    auto take = [&](const float4 (&buf)[2][NC]) {
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if constexpr (NC == 1) acc[s] = max4(acc[s], buf[s][0]);
-            else if constexpr (NC == 2) acc[s] = max4_3(acc[s], buf[s][0], buf[s][1]);
-            else if constexpr (NC == 3) acc[s] = max4(max4_3(acc[s], buf[s][0], buf[s][1]), buf[s][2]);
-            else acc[s] = max4_3(max4_3(acc[s], buf[s][0], buf[s][1]), buf[s][2], buf[s][3]);
-        }
-    };
-    // two register buffers in ping-pong: the row after next is in flight while the maxima of the current row are taken
-    float4 a[2][NC], b[2][NC];
-    fetch(a);
-    int left = mbh - 1;                             // rows still to fetch (wave-uniform)
+    fetch(0);
+    fetch(1);
 #pragma unroll 1
-    while (left >= 2) {
-        advance(); fetch(b);
-        __builtin_amdgcn_sched_barrier(0);          // keep the fetches ABOVE the maxima: they fly while the VALU works
-        take(a);
-        advance(); fetch(a);
+    for (int left = mbh - 1; left > 0; --left) {
+        take(0);
+        row[0] = min(row[0] + kCellPitch * 2, r1[0]);
+        fetch(0);
+        __builtin_amdgcn_sched_barrier(0);          // bin 0's next row is requested BEFORE bin 1's maxima are taken
+        take(1);
+        row[1] = min(row[1] + kCellPitch * 2, r1[1]);
+        fetch(1);
         __builtin_amdgcn_sched_barrier(0);
-        take(b);
-        left -= 2;
     }
-    if (left == 1) {
-        advance(); fetch(b);
-        __builtin_amdgcn_sched_barrier(0);
-        take(a);
-        take(b);
-    } else {
-        take(a);
-    }
+    take(0);
+    take(1);
 }
 
+// kRows = 38: one 1024-thread workgroup per CU (16 waves share one 78 KB image of the eight planes; each wave has a 1.5 KB LDS slot
+// in which a RoI's [8][7][7] block is assembled, so it leaves as ONE contiguous float4-coalesced run: full 128-byte lines, 2 store
+// instructions per RoI instead of 8 scattered ones -- the direct stores cost ~4 us of the r02a kernel's 17).  kRows = 76 (taller
+// maps): 155 KB image, 8 waves, direct stores.
 template <int kRows, bool OUT16>
-__global__ void __launch_bounds__(64 * kCellWaves)
+__global__ void __launch_bounds__(kRows <= 38 ? 1024 : 512)
 roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const float *__restrict__ rois, int roi_cols, int R,
                       int outh, int outw, float scale, float *__restrict__ y, int rsplit, const RoiBinTables tables) {
+    constexpr int kCellWaves = kRows <= 38 ? 16 : 8;
+    constexpr bool STAGED = kRows <= 38;
     __shared__ __attribute__((aligned(16))) float4 cells[kRows * kCellPitch * 2];
     __shared__ __attribute__((aligned(16))) RoiBinTables tb;
+    __shared__ __attribute__((aligned(16))) float stage[STAGED ? kCellWaves : 1][STAGED ? 8 * kMaxBins : 4];
     __shared__ int next_roi;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -554,7 +547,8 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
         // per bin: first / last map row as float4 indices (clamped into the map so an empty bin still reads valid cells); the bin's
         // first cell seeds the maximum (the oracle's scan order)
         int r0[2], r1[2];
-        float4 first[2], acc[2];
+        float4 acc[2];
+        float nan_probe = 0.0f;
         const int c_lo = min(ws, W - 1), c_hi = min(max(we - 1, c_lo), W - 1);      // first / last column of the bin, inside the map
         const int c_first = c_lo * 2 + cq;
         bool any_empty = we <= ws;
@@ -563,8 +557,8 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
             const int h0 = min(max(hs[s], 0), H - 1);
             r0[s] = h0 * (kCellPitch * 2);
             r1[s] = min(max(he[s] - 1, h0), H - 1) * (kCellPitch * 2);
-            first[s] = cells[r0[s] + c_first];
-            acc[s] = first[s];
+            acc[s] = cells[r0[s] + c_first];
+            nan_probe += (acc[s].x + acc[s].y) + (acc[s].z + acc[s].w);     // NaN iff one of the eight first cells is
             any_empty = any_empty || (he[s] <= hs[s]);
         }
 #pragma unroll 1
@@ -575,20 +569,56 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
             else if (nc == 2) cells_scan_chunk<2>(cells, k0, c_lo, c_hi, cq, r0, r1, mbh, acc);
             else cells_scan_chunk<1>(cells, k0, c_lo, c_hi, cq, r0, r1, mbh, acc);
         }
-        // rare fix-ups behind ONE wave-level test: a NaN first cell stays (`>` never replaces it: x + y + z + w is NaN iff one of them
-        // is), an empty bin is 0
-        const float nan_probe = (first[0].x + first[0].y) + (first[0].z + first[0].w) + (first[1].x + first[1].y) + (first[1].z + first[1].w);
+        // rare fix-ups behind ONE wave-level test: a NaN first cell stays (`>` never replaces it: the sum of the eight first cells
+        // is NaN iff one of them is; they are re-read then), an empty bin is 0
         if (__any((nan_probe != nan_probe) || any_empty)) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const bool empty = (he[s] <= hs[s]) || (we <= ws);
-                if (first[s].x != first[s].x) acc[s].x = first[s].x;
-                if (first[s].y != first[s].y) acc[s].y = first[s].y;
-                if (first[s].z != first[s].z) acc[s].z = first[s].z;
-                if (first[s].w != first[s].w) acc[s].w = first[s].w;
+                const float4 first = cells[r0[s] + c_first];
+                if (first.x != first.x) acc[s].x = first.x;
+                if (first.y != first.y) acc[s].y = first.y;
+                if (first.z != first.z) acc[s].z = first.z;
+                if (first.w != first.w) acc[s].w = first.w;
                 if (empty) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+        if constexpr (STAGED) {
+            float *sv = stage[wave];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int ph = 2 * pg + s;
+                const float o[4] = {acc[s].x, acc[s].y, acc[s].z, acc[s].w};
+                if (pw_on && ph < outh) {
+                    float *d = sv + (4 * cq) * bins + ph * outw + pw;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) d[q * bins] = o[q];
+                }
+            }
+            frcnn_wave_sync();     // the wave's own LDS writes above are read by other lanes below (DS ops of a wave are in order)
+            // (r, c0 .. c0 + cg, :, :) is one contiguous run of cg*bins floats of y
+            const int cg = min(8, C - c0), run = cg * bins;
+            const size_t dst = ((size_t)r * C + c0) * bins;
+            if constexpr (OUT16) {
+                uint16_t *y16 = reinterpret_cast<uint16_t *>(y);
+                if ((run & 3) == 0 && (dst & 3) == 0) {
+                    for (int i = lane; i < run / 4; i += 64) {
+                        const float4 v4 = reinterpret_cast<const float4 *>(sv)[i];
+                        uint2 pk;
+                        pk.x = roi_f32_to_bf16(v4.x) | (roi_f32_to_bf16(v4.y) << 16);
+                        pk.y = roi_f32_to_bf16(v4.z) | (roi_f32_to_bf16(v4.w) << 16);
+                        reinterpret_cast<uint2 *>(y16 + dst)[i] = pk;
+                    }
+                } else {
+                    for (int i = lane; i < run; i += 64) y16[dst + i] = (uint16_t)roi_f32_to_bf16(sv[i]);
+                }
+            } else if ((run & 3) == 0 && (dst & 3) == 0) {
+                for (int i = lane; i < run / 4; i += 64) reinterpret_cast<float4 *>(y + dst)[i] = reinterpret_cast<const float4 *>(sv)[i];
+            } else {
+                for (int i = lane; i < run; i += 64) y[dst + i] = sv[i];
+            }
+            frcnn_wave_sync();     // the slot is rewritten by the next RoI only after these reads were issued
+        } else {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const int ph = 2 * pg + s;
@@ -604,6 +634,7 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
                     }
                 }
             }
+        }
         }
     }
 }
@@ -634,11 +665,11 @@ static bool roi_cells_launch(const float *x, int C, int H, int W, const float *r
     if (W > kCellPitch || H > 76) return false;
     if ((size_t)C * H * W * sizeof(float) >= (1ull << 31)) return false;      // the map is read through a 32-bit buffer descriptor
     const int cgroups = frcnn_cdiv(C, 8);
-    const int per_cu = H <= 38 ? 2 : 1;
-    const char *mul = getenv("FRCNN_ROI_SPLIT_MUL");                         // tuning hook: workgroups per resident slot (default 1)
+    const int waves = H <= 38 ? 16 : 8;
+    const char *mul = getenv("FRCNN_ROI_SPLIT_MUL");                         // tuning hook: workgroups per CU (default 1)
     const int rounds = mul && atoi(mul) > 0 ? atoi(mul) : 1;
-    int rsplit = frcnn_cdiv(rounds * per_cu * frcnn_roi_cu_count(), cgroups);  // about `per_cu` resident workgroups per CU
-    const int max_split = frcnn_cdiv(R, kCellWaves);                         // at least one RoI per wave
+    int rsplit = frcnn_cdiv(rounds * frcnn_roi_cu_count(), cgroups);         // one resident workgroup per CU
+    const int max_split = frcnn_cdiv(R, waves);                              // at least one RoI per wave
     if (rsplit > max_split) rsplit = max_split;
     if (rsplit < 1) rsplit = 1;
     RoiBinTables tables;
@@ -656,7 +687,7 @@ static bool roi_cells_launch(const float *x, int C, int H, int W, const float *r
             tables.tabmax[t][ext] = (uint8_t)m;
         }
     }
-    const dim3 grid(cgroups, rsplit), blk(64 * kCellWaves);
+    const dim3 grid(cgroups, rsplit), blk(64 * waves);
     if (H <= 38) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<38, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, tables);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<76, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, tables);
     return true;

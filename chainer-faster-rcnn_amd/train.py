@@ -49,6 +49,9 @@ def trunk_backward(trainer, layer_inputs, g):
             g = rt.maxpool2x2_bwd(xin, g)
             continue
         name = l[0]
+        keep = getattr(trainer, "keep_dy", None)
+        if keep is not None and name in keep:                     # tests: the (input, upstream gradient) pair a weight gradient was computed from
+            trainer.kept_dy[name] = (xin, g.clone() if hasattr(g, "clone") else g.copy())
         rt.conv_wgrad(xin, g, 3, out=trainer.grad[name + "/W"])
         rt.bias_grad(g, out=trainer.grad[name + "/b"])
         if hasattr(trainer, "_grads_ready"):

@@ -96,6 +96,23 @@ def check_nms_random(rt, n=700, seeds=(0, 1), thrs=(0.3, 0.5, 0.7)):
             assert host(rt, keep)[:nk].tolist() == want, (seed, thr)
 
 
+def check_nms_staged(rt, n=1200, seeds=(0, 1)):
+    """keep[:max_out] with a small max_out: the two-stage form (mask + scan of the first 4 * max_out boxes, then -- only if that did
+    not yield max_out survivors -- of the rest).  Sparse boxes finish in stage one; a dense pile does not and needs stage two."""
+    for seed in seeds:
+        rs = np.random.RandomState(seed)
+        for dense in (False, True):
+            span = 120 if dense else 900
+            x1 = rs.uniform(0, span, n); y1 = rs.uniform(0, span, n)
+            d = np.stack([x1, y1, x1 + rs.uniform(40, 200, n), y1 + rs.uniform(40, 200, n), rs.permutation(n) / float(n)], 1).astype(np.float32)
+            for max_out in (20, 48):
+                want = O.cpu_nms(d, 0.7)[:max_out]
+                keep, nk = rt.nms(dev(rt, d), 0.7, max_out=max_out)
+                nk = int(host(rt, nk)[0])
+                assert nk == len(want) and host(rt, keep)[:nk].tolist() == want, (seed, dense, max_out, nk, len(want))
+                assert (host(rt, keep)[nk:] == -1).all()
+
+
 def check_nms_batched(rt, groups=5, n=300):
     """forward.py:48-58: per-class cpu_nms(thresh=0.3) on (300,5) -- all classes in one call."""
     rs = np.random.RandomState(5)

@@ -43,6 +43,10 @@ def test_nms_above_single_wave_capacity(rt):
     P.check_nms_random(rt, n=17000, seeds=(0,), thrs=(0.5,))
 
 
+def test_nms_staged(rt):
+    P.check_nms_staged(rt, n=5000, seeds=(0, 1))
+
+
 def test_nms_batched(rt):
     P.check_nms_batched(rt, groups=20, n=300)
 

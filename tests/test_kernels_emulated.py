@@ -41,6 +41,10 @@ def test_gpu_nms_reference_ffi(rt):
     P.check_gpu_nms_ffi(rt, tags=("n300_t03", "n65_t05", "n1_t07"))
 
 
+def test_nms_staged(rt):
+    P.check_nms_staged(rt, n=1200, seeds=(0,))
+
+
 def test_nms_batched(rt):
     P.check_nms_batched(rt, groups=3, n=150)
 
