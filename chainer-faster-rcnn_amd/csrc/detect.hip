@@ -128,12 +128,12 @@ dets_keys_kernel(const float *__restrict__ dets, int n, int n_pad, unsigned long
 // ------------------------------------------------------------------------------------------------
 // Bitonic sort (descending) of one 1024-key tile by one 256-thread workgroup (one wave per SIMD of a CU; the 22 tiles of a
 // 600 x 1000 image run on 22 CUs -- the network is VALU-issue-bound, so 4096-key tiles on 6 CUs were 1.5x slower: r02 measurement).
-// Thread t holds elements t, t + 256, t + 512, t + 768 in registers, so a compare-exchange at distance j is
-//   j >= 256    between two of the thread's own registers          (no communication)
-//   j <  64     with lane ^ j of the same wave                      (__shfl_xor: no LDS image, no barrier)
-//   otherwise   with another wave                                   (through LDS, two barriers)
-// 55 network steps, of which only 7 touch LDS (the all-LDS version of round 1 ran 55 barrier-separated passes).
-// Element i keeps the larger key of the pair (i, i ^ j) iff (i & j) == 0 is equal to ((i & k) == 0): the usual bitonic rule, descending.
+// Thread t holds the four CONSECUTIVE elements 4t .. 4t+3 in registers, so a compare-exchange at distance j is
+//   j = 1, 2       between two of the thread's own registers          (no communication: 19 of the 55 network steps)
+//   j = 4 .. 128   with lane ^ (j / 4) of the same wave                (__shfl_xor: no LDS image, no barrier: 33 steps)
+//   j = 256, 512   with another wave                                   (through LDS, two barriers: 3 steps)
+// (the all-LDS version of round 1 ran 55 barrier-separated passes).  Element i keeps the larger key of the pair (i, i ^ j) iff
+// (i & j) == 0 is equal to ((i & k) == 0): the usual bitonic rule, descending.
 __global__ void __launch_bounds__(kSortThreads)
 tile_sort_kernel(unsigned long long *__restrict__ keys, size_t slab) {
     __shared__ unsigned long long s[kSortTile];
@@ -142,38 +142,38 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, size_t slab) {
     const int tid = threadIdx.x;
     unsigned long long key[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) key[r] = g[r * kSortThreads + tid];
+    for (int r = 0; r < 4; ++r) key[r] = g[tid * 4 + r];
     for (int k = 2; k <= kSortTile; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j >= kSortThreads) {
-                const int dr = j / kSortThreads;                   // 1 or 2
+            if (j < 4) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    if ((r & dr) == 0) {
-                        const int i = r * kSortThreads + tid;
+                    if ((r & j) == 0) {
+                        const int i = tid * 4 + r;
                         const bool desc = (i & k) == 0;
-                        const unsigned long long a = key[r], b = key[r | dr];
+                        const unsigned long long a = key[r], b = key[r | j];
                         const bool swap = desc ? (a < b) : (a > b);
-                        if (swap) { key[r] = b; key[r | dr] = a; }
+                        if (swap) { key[r] = b; key[r | j] = a; }
                     }
                 }
             } else {
+                const int dt = j >> 2;                             // partner thread = tid ^ dt, same register
                 unsigned long long other[4];
-                if (j >= 64) {
+                if (dt >= 64) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s[r * kSortThreads + tid] = key[r];
                     __syncthreads();
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) other[r] = s[r * kSortThreads + (tid ^ j)];
+                    for (int r = 0; r < 4; ++r) other[r] = s[r * kSortThreads + (tid ^ dt)];
                     __syncthreads();
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) other[r] = __shfl_xor(key[r], j);
+                    for (int r = 0; r < 4; ++r) other[r] = __shfl_xor(key[r], dt);
                 }
+                // (i & j) and (i & k) do not depend on r here (j, k >= 4): one decision per thread and step
+                const bool keep_max = (((tid * 4) & j) == 0) == (((tid * 4) & k) == 0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int i = r * kSortThreads + tid;
-                    const bool keep_max = ((i & j) == 0) == ((i & k) == 0);
                     const bool gt = other[r] > key[r];
                     key[r] = (keep_max == gt) ? other[r] : key[r];
                 }
@@ -181,7 +181,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, size_t slab) {
         }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) g[r * kSortThreads + tid] = key[r];
+    for (int r = 0; r < 4; ++r) g[tid * 4 + r] = key[r];
 }
 
 // Global rank by merging: rank(key) = sum over all sorted tiles of (number of elements > key) (keys are unique, so in the key's
@@ -272,11 +272,11 @@ __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_
 // (or for degenerate areas) the reference's own expression is evaluated.
 template <bool FASTMM>
 __device__ __forceinline__ unsigned long long nms_tile_words(const float4 rb, const float rarea_l, const float4 cb, const float carea,
-                                                             int t_rows, bool diag, bool col_ok, int lane, double thresh) {
+                                                             int t_begin, int t_rows, bool diag, bool col_ok, int lane, double thresh) {
     const float thr_f = (float)thresh;
     const bool lane_fast = (thresh > 1e-6) && (carea > 0.0f);
     unsigned long long word = 0ull;
-    for (int t = 0; t < t_rows; ++t) {
+    for (int t = t_begin; t < t_rows; ++t) {
         const float rx1 = lane_bcast(rb.x, t), ry1 = lane_bcast(rb.y, t), rx2 = lane_bcast(rb.z, t), ry2 = lane_bcast(rb.w, t);
         const float rarea = lane_bcast(rarea_l, t);
         float xx1, yy1, xx2, yy2, w, h;
@@ -318,9 +318,11 @@ nms_mask_kernel(const float *__restrict__ sorted_boxes, const int *__restrict__ 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // tiles of the upper triangle, enumerated column by column (column cc holds rows 0 .. cc); this launch covers columns
-    // [cc_lo, cc_hi) of the STATIC pitch (it is sized before m is known): tile T' = T + tri(cc_lo), tri(k) = k (k + 1) / 2
+    // [cc_lo, cc_hi) of the STATIC pitch (it is sized before m is known): tile T' = T + tri(cc_lo), tri(k) = k (k + 1) / 2.
+    // One workgroup = one tile, its four waves take 16 rows each: a tile is a chain of 64 dependent steps (~0.2 us each for a lone
+    // wave), and the first stage of a staged NMS has fewer tiles than the chip has SIMDs -- its latency is the length of that chain
     const long long tri_lo = (long long)cc_lo * (cc_lo + 1) / 2;
-    const long long Tp = (long long)blockIdx.x * 4 + wave + tri_lo;
+    const long long Tp = (long long)blockIdx.x + tri_lo;
     if (Tp >= (long long)cc_hi * (cc_hi + 1) / 2) return;
     int cc = (int)((sqrt(8.0 * (double)Tp + 1.0) - 1.0) * 0.5);
     cc = min(max(cc, 0), pitch - 1);
@@ -335,12 +337,12 @@ nms_mask_kernel(const float *__restrict__ sorted_boxes, const int *__restrict__ 
     if (r < m) rb = reinterpret_cast<const float4 *>(sorted_boxes)[r];
     const float carea = (cb.z - cb.x + 1.0f) * (cb.w - cb.y + 1.0f);  // areas, cpu_nms.pyx:25
     const float rarea_l = (rb.z - rb.x + 1.0f) * (rb.w - rb.y + 1.0f);
-    const int t_rows = min(kChunk, m - rc * kChunk);
+    const int t_begin = wave * 16, t_rows = min(min(kChunk, m - rc * kChunk), t_begin + 16);
     const float probe = (cb.x + cb.y) + (cb.z + cb.w) + (rb.x + rb.y) + (rb.z + rb.w);       // NaN iff any coordinate of the tile is
     unsigned long long word;
-    if (__any(probe != probe)) word = nms_tile_words<false>(rb, rarea_l, cb, carea, t_rows, cc == rc, c < m, lane, thresh);
-    else word = nms_tile_words<true>(rb, rarea_l, cb, carea, t_rows, cc == rc, c < m, lane, thresh);
-    if (r < m) mask[(size_t)r * pitch + cc] = word;
+    if (__any(probe != probe)) word = nms_tile_words<false>(rb, rarea_l, cb, carea, t_begin, t_rows, cc == rc, c < m, lane, thresh);
+    else word = nms_tile_words<true>(rb, rarea_l, cb, carea, t_begin, t_rows, cc == rc, c < m, lane, thresh);
+    if (r < m && (lane >> 4) == wave) mask[(size_t)r * pitch + cc] = word;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -602,20 +604,39 @@ nms_scan_col_kernel(const unsigned long long *__restrict__ mask, int pitch, cons
     }
     __builtin_amdgcn_wave_barrier();
     const int c_stop = min(c_end, n_chunks);
-    auto gather = [&](int col, int upto) -> unsigned long long {   // this lane's share of OR { mask[kept row][col] }
+    // this lane's share of OR { mask[kept row][col] : the first `upto` kept rows }.  Row indices first (LDS), then ALL the 8-byte
+    // gathers of a batch in flight together (8 per lane = 512 kept rows per batch): a loop of dependent index -> word pairs would
+    // serialise into two memory round trips per row
+    auto gather = [&](int col, int upto) -> unsigned long long {
         unsigned long long acc = 0ull;
-        if (col < n_chunks)
-            for (int k = lane; k < upto; k += 64) {
-                const int row = k < kKeptLds ? kept_list[k] : keep_pos[k];
-                acc |= mask[(size_t)row * pitch + col];
+        if (col >= n_chunks) return acc;
+        const int lds_upto = min(upto, kKeptLds);
+        for (int k0 = 0; k0 < lds_upto; k0 += 512) {
+            int rows[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = k0 + q * 64 + lane;
+                rows[q] = k < lds_upto ? kept_list[k] : -1;
             }
+            unsigned long long v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = rows[q] >= 0 ? mask[(size_t)rows[q] * pitch + col] : 0ull;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc |= v[q];
+        }
+        for (int k = kKeptLds + lane; k < upto; k += 64) acc |= mask[(size_t)keep_pos[k] * pitch + col];   // beyond the LDS list (rare)
         return acc;
+    };
+    auto uniform64 = [&](unsigned long long v) -> unsigned long long {       // tell the compiler a wave-uniform value IS uniform (-> SGPRs)
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+        return ((unsigned long long)hi << 32) | lo;
     };
     auto load_word = [&](int c, int col) -> unsigned long long {
         const int row = c * kChunk + lane;
         return (c < n_chunks && col < n_chunks && row < m) ? mask[(size_t)row * pitch + col] : 0ull;
     };
-    unsigned long long removed = first_stage ? 0ull : wave_or_u64(gather(c_begin, n_kept));
+    unsigned long long removed = first_stage ? 0ull : uniform64(wave_or_u64(gather(c_begin, n_kept)));
     unsigned long long diag = load_word(c_begin, c_begin), sup = load_word(c_begin, c_begin + 1);
     for (int c = c_begin; c < c_stop && n_kept < limit; ++c) {
         if (n_kept > kKeptLds) frcnn_drain_vmem();                  // rows past the LDS list are read back from keep_pos: written by this wave
@@ -643,7 +664,7 @@ nms_scan_col_kernel(const unsigned long long *__restrict__ mask, int pitch, cons
             if (idx < kKeptLds) kept_list[idx] = c * kChunk + lane;
         }
         n_kept += __popcll(kept);
-        removed = wave_or_u64(part_next | (mine ? sup : 0ull));
+        removed = uniform64(wave_or_u64(part_next | (mine ? sup : 0ull)));
         diag = diag_n;
         sup = sup_n;
         __builtin_amdgcn_wave_barrier();                            // kept_list: written above, read by other lanes in the next gather
@@ -677,8 +698,8 @@ static bool scan_one_chunk_per_trip() {
     return e && e[0] == '1';
 }
 
-// blocks (4 tiles each) of a mask launch over columns [lo, hi) of the upper triangle
-static int mask_blocks(int lo, int hi) { return (int)((((long long)hi * (hi + 1) - (long long)lo * (lo + 1)) / 2 + 3) / 4); }
+// blocks (one tile each) of a mask launch over columns [lo, hi) of the upper triangle
+static int mask_blocks(int lo, int hi) { return (int)(((long long)hi * (hi + 1) - (long long)lo * (lo + 1)) / 2); }
 // first-stage width of a staged NMS: 4 x post_nms_top_n boxes (a greedy NMS that keeps `limit` boxes has usually done so long before
 // it has looked at 4 x limit of them: 610 of 6000 on the benchmark image); 0 = one stage
 static int nms_stage_chunks(int pitch, int max_out) {

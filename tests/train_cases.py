@@ -106,13 +106,17 @@ def check_vgg_step(rt, im_h=160, im_w=224, seed=0):
     model.load_params(params)
     model.rpn_train = True
     tr = RPNTrainer(model)
-    # the weight gradients of the 600 x 1000 / 300 x 500 layers are 150 000 ... 600 000-term fp32 sums: judged against a float64
-    # accumulation of the same fp32 upstream gradient (the fp32 autograd value's own distance from it is reported)
-    big = ("conv1_1", "conv1_2", "conv2_1", "conv2_2") if im_h * im_w >= 300000 else ()
+    # Full size (600 x 1000): two fp32 implementations of a 14-layer backward pass take a handful of DIFFERENT discrete decisions (a
+    # ReLU whose pre-activation is 1e-8, a max-pool tie); each flips one pixel's gradient, and every upstream gradient moves by
+    # ~sqrt(flips / pixels) of its scale -- measured 1.1e-3 ... 1.3e-3 on two layers, all others < 1e-3.  So at full size every conv
+    # KERNEL is judged on its own inputs -- float64 accumulation of exactly the (input, upstream gradient) pair it consumed, 1e-4 --
+    # and the end-to-end comparison with the fp32 autograd gets 3e-3.  At the small size the plain 1e-3 bar applies.
+    full = im_h * im_w >= 300000
+    big = tuple(l[0] for l in LAYERS if l != "pool") if full else ()
     tr.keep_dy, tr.kept_dy = set(big), {}
     np.random.seed(11)
     out = tr.forward_backward(Variable(x), Variable(info), Variable(gt))
-    want_loss, want = oracle_step(params, x, gt, info, LAYERS, 16, (8, 16, 32), 11, f64_wgrad=big)
+    want_loss, want = oracle_step(params, x, gt, info, LAYERS, 16, (8, 16, 32), 11, f64_wgrad=big[:2])
     l = tr.losses_host(out)
     assert abs(l["rpn_loss"] - want_loss) <= 1e-4 * abs(want_loss), (l, want_loss)
     got = tr.grads_chainer_layout()
@@ -122,12 +126,8 @@ def check_vgg_step(rt, im_h=160, im_w=224, seed=0):
             continue
         scale = max(np.abs(want[k]).max(), 1e-8)
         err = np.abs(got[k] - want[k]).max() / scale
-        tol = 1e-3
-        if k + "@f64" in want:
-            # Two fp32 implementations of a 14-layer backward pass also take a handful of DIFFERENT discrete decisions (a ReLU whose
-            # pre-activation is 1e-8, a max-pool tie): each flips one pixel's gradient, and a 600 000-pixel weight gradient moves by
-            # ~sqrt(flips / pixels) of its scale.  So for the full-size layers the KERNEL is judged on its own inputs -- float64
-            # accumulation of exactly the (input, upstream gradient) pair it consumed, 1e-4 -- and the end-to-end figure gets 3e-3.
+        tol = 3e-3 if full else 1e-3
+        if full and k.startswith("trunk/") and k.endswith("/W"):
             import torch
             name = k.split("/")[1]
             xin, dy = tr.kept_dy[name]
@@ -136,11 +136,12 @@ def check_vgg_step(rt, im_h=160, im_w=224, seed=0):
                                               tuple(got[k].shape), torch.from_numpy(dy).double().reshape(1, dy.shape[-3], dy.shape[-2], dy.shape[-1]),
                                               padding=1).numpy()
             kerr = float(np.abs(got[k] - ref).max() / max(np.abs(ref).max(), 1e-8))
-            notes[k] = {"kernel_vs_f64_on_its_own_inputs": kerr, "end_to_end_vs_torch_fp32": float(err),
-                        "torch_fp32_vs_its_own_f64": float(np.abs(want[k] - want[k + "@f64"]).max() / scale)}
+            notes[name] = {"kernel_vs_f64": float("%.2g" % kerr), "end_to_end": float("%.2g" % err)}
+            if k + "@f64" in want:
+                notes[name]["torch_fp32_vs_its_own_f64"] = float("%.2g" % (np.abs(want[k] - want[k + "@f64"]).max() / scale))
             assert kerr <= 1e-4, (k, kerr)
-            tol = 3e-3
-        worst = max(worst, err if tol == 1e-3 else min(err, 1e-3))
+            worst_kernel = max(locals().get("worst_kernel", 0.0), kerr)
+        worst = max(worst, err)
         assert err <= tol, (k, err)
     if notes:
         print("\nfull-size weight gradients: %s" % notes)
