@@ -567,13 +567,8 @@ nms_scan_wave_kernel(const unsigned long long *__restrict__ mask, int pitch, con
 // between; a later stage finds n_out[0] >= limit (or no chunks left) and exits at once -- see frcnn_proposals.
 constexpr int kKeptLds = 2048;
 
-__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {
-    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        lo |= (uint32_t)__shfl_xor((int)lo, d);
-        hi |= (uint32_t)__shfl_xor((int)hi, d);
-    }
+__device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) {      // wave-uniform result
+    const uint32_t lo = frcnn_wave_or_u32((uint32_t)v), hi = frcnn_wave_or_u32((uint32_t)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
 
@@ -636,9 +631,16 @@ nms_scan_col_kernel(const unsigned long long *__restrict__ mask, int pitch, cons
         const int row = c * kChunk + lane;
         return (c < n_chunks && col < n_chunks && row < m) ? mask[(size_t)row * pitch + col] : 0ull;
     };
-    unsigned long long removed = first_stage ? 0ull : uniform64(wave_or_u64(gather(c_begin, n_kept)));
-    unsigned long long diag = load_word(c_begin, c_begin), sup = load_word(c_begin, c_begin + 1);
+    unsigned long long removed = first_stage ? 0ull : wave_or_u64(gather(c_begin, n_kept));
+    // The diagonal / super-diagonal words of the NEXT chunk are fetched a chunk ahead and handed over through LDS: the resolve loop
+    // then reads registers that an LDS load produced, so the compiler's s_waitcnt vmcnt(0) in front of it is gone and the gathers
+    // issued just before it really are in flight while it runs (with a register hand-over the first v_readlane waited for them).
+    __shared__ unsigned long long handover[2][64];
+    handover[0][lane] = load_word(c_begin, c_begin);
+    handover[1][lane] = load_word(c_begin, c_begin + 1);
     for (int c = c_begin; c < c_stop && n_kept < limit; ++c) {
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long diag = handover[0][lane], sup = handover[1][lane];
         if (n_kept > kKeptLds) frcnn_drain_vmem();                  // rows past the LDS list are read back from keep_pos: written by this wave
         const unsigned long long part_next = gather(c + 1, n_kept); // in flight while the chunk is resolved
         const unsigned long long diag_n = load_word(c + 1, c + 1), sup_n = load_word(c + 1, c + 2);
@@ -664,9 +666,9 @@ nms_scan_col_kernel(const unsigned long long *__restrict__ mask, int pitch, cons
             if (idx < kKeptLds) kept_list[idx] = c * kChunk + lane;
         }
         n_kept += __popcll(kept);
-        removed = uniform64(wave_or_u64(part_next | (mine ? sup : 0ull)));
-        diag = diag_n;
-        sup = sup_n;
+        removed = wave_or_u64(part_next | (mine ? sup : 0ull));
+        handover[0][lane] = diag_n;
+        handover[1][lane] = sup_n;
         __builtin_amdgcn_wave_barrier();                            // kept_list: written above, read by other lanes in the next gather
     }
     if (lane == 0) n_out[0] = n_kept;

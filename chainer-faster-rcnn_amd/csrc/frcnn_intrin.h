@@ -16,6 +16,19 @@ __device__ __forceinline__ float frcnn_min_f32(float a, float b) {
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// OR of a 32-bit value over the 64 lanes of the wave, returned wave-uniform (SGPR): four DPP row shifts, two row broadcasts and a
+// v_readlane -- 7 VALU instructions, no LDS crossbar round trips (six ds_bpermute steps cost ~6 x 100+ cycles of latency each).
+__device__ __forceinline__ uint32_t frcnn_wave_or_u32(uint32_t v) {
+    int x = (int)v;
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);    // row_shr:1
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);    // row_shr:2
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);    // row_shr:4
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);    // row_shr:8   -> lane 15 of each row holds the row's OR
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);    // row_bcast:15 into rows 1 and 3
+    x |= __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);    // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's OR
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+
 // v_max3_f32: max(max(a, b), c) with the same NaN rule, one instruction for two updates of a running maximum
 __device__ __forceinline__ float frcnn_max3_f32(float a, float b, float c) {
     float r;

@@ -65,6 +65,23 @@ class TorchDeviceMemory(object):
     def synchronize(self):
         self.torch.cuda.current_stream(self.device).synchronize()
 
+    def side_stream(self, *arrays):
+        """Context manager: launches inside it go to a second HIP stream that starts after everything already enqueued on the
+        current one (the trainers run the discarded ProposalLayer of an RPN step there, under the backward pass).  `arrays` are
+        marked as used by that stream so the caching allocator does not hand their memory out early.  join_side_stream() makes the
+        current stream wait for it."""
+        torch = self.torch
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self._side.wait_stream(torch.cuda.current_stream(self.device))
+        for a in arrays:
+            a.record_stream(self._side)
+        return torch.cuda.stream(self._side)
+
+    def join_side_stream(self):
+        if getattr(self, "_side", None) is not None:
+            self.torch.cuda.current_stream(self.device).wait_stream(self._side)
+
     def dtype_of(self, t):
         return {v: k for k, v in self._dt.items()}[t.dtype]
 

@@ -195,8 +195,10 @@ class RPNTrainer(_BucketedAllReduce):
         score, prob, bbox = rt.rpn_heads(mid, rpn._heads_packed)
         if self.run_proposal_layer:
             # region_proposal_network.py:123-126: `proposals, probs = self.proposal_layer(...)` in train mode (12000 -> NMS -> 2000);
-            # nothing downstream consumes it in rpn_train mode (faster_rcnn.py:115-116 returns the loss) -- kept for inspection
-            self.proposals = rpn.proposal_layer.forward_device(prob, bbox, im_h, im_w)
+            # nothing downstream consumes it in rpn_train mode (faster_rcnn.py:115-116 returns the loss) -- kept for inspection.
+            # Its sequential NMS pass keeps one wave busy for ~0.5 ms: it runs on a second stream, under the backward pass.
+            with rt.mem.side_stream(prob, bbox):
+                self.proposals = rpn.proposal_layer.forward_device(prob, bbox, im_h, im_w)
         A = self.A
         H, W = int(feat.shape[2]), int(feat.shape[3])
         NP = int(rpn._heads_packed[0].shape[1])
@@ -214,6 +216,8 @@ class RPNTrainer(_BucketedAllReduce):
         g = rt.conv_ex(draw.reshape(1, NP, H, W), self.wd_heads, self.zero_bias, 1, act=2, mask=mid)
         # ---- rpn_conv_3x3, then the trunk in reverse
         trunk_backward(self, list(zip(self.layers, inputs)) + [(("rpn_conv_3x3", 0, 0), feat)], g)
+        if self.run_proposal_layer:
+            rt.mem.join_side_stream()
         return dict(losses=losses)
 
     def update(self):

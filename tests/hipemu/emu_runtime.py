@@ -54,6 +54,13 @@ class HostMemory(object):
     def synchronize(self):
         pass
 
+    def side_stream(self, *arrays):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def join_side_stream(self):
+        pass
+
     def dtype_of(self, a):
         return {np.dtype(v): k for k, v in _NP.items()}[a.dtype]
 

@@ -2,6 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 static inline float frcnn_max_f32(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+static inline uint32_t frcnn_wave_or_u32(uint32_t v) {
+    int x = (int)v;
+    for (int d = 32; d > 0; d >>= 1) x |= __shfl_xor(x, d);
+    return (uint32_t)x;
+}
 static inline float frcnn_min_f32(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a < b ? a : b)); }
 static inline float frcnn_max3_f32(float a, float b, float c) { return frcnn_max_f32(frcnn_max_f32(a, b), c); }
 
