@@ -6,9 +6,9 @@
 // `>` in fp32, leaves the reduction to the host and is never called (proposal_layer.py:180-187).
 //
 // Device pipeline (one stream, no host round trip, caller-owned workspace):
-//   proposal_decode_kernel  anchor (h,w,a) -> decode -> clip -> min-size test; writes the box, the fg score
-//                           and a 64-bit sort key  (ordered score bits << 32) | ~index   (0 = filtered out)
-//   tile_sort_kernel        bitonic sort of 1024-key tiles in LDS (descending)
+//   tile_sort_kernel<true>  anchor (h,w,a) -> decode -> clip -> min-size test; writes the box and the fg score, makes the 64-bit
+//                           sort key  (ordered score bits << 32) | ~index   (0 = filtered out)  in registers and bitonic-sorts
+//                           its 1024-key tile (descending; wave shuffles, LDS for 3 of the 55 steps)
 //   rank_scatter_kernel     global rank of a key = its position in its own tile + the number of larger
 //                           keys in every other tile (branch-free binary searches, L2 resident);
 //                           ranks < min(n_valid, pre_nms_top_n) are gathered into score order
@@ -33,7 +33,7 @@ namespace {
 
 constexpr int kSortTile = 1024;   // keys per bitonic tile (one 256-thread workgroup, 4 keys per thread)
 constexpr int kSortThreads = 256;
-constexpr int kRankTiles = 4;     // tiles searched together by rank_scatter_kernel (independent binary searches in flight)
+constexpr int kRankTiles = 8;     // tiles searched together by rank_scatter_kernel (independent binary searches in flight)
 constexpr int kChunk = 64;        // NMS chunk = wave width
 
 __device__ __forceinline__ uint32_t ordered_bits(float f) {
@@ -62,54 +62,46 @@ struct Anchors {           // generate_anchors output, passed by value in the ke
 // proposal_layer.py:135-154 + bbox_transform.py:41-109, one thread per anchor.
 // Thread t -> (a = t / HW, p = t % HW) so the 4 delta reads and the score read are coalesced over p; the
 // anchor's position in the reference's enumeration is idx = p*A + a (proposal_layer.py:219-220).
-__global__ void __launch_bounds__(256)
-proposal_decode_kernel(const float *__restrict__ cls_prob, const float *__restrict__ bbox_pred, int A, int H, int W,
-                       Anchors anchors, int feat_stride, int im_h, int im_w, float min_size,
-                       float *__restrict__ boxes, float *__restrict__ scores, unsigned long long *__restrict__ keys,
-                       int n_pad, int *__restrict__ counters) {
-    const int HW = H * W;
-    const int n = A * HW;
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    int valid = 0;
-    if (t < n) {
-        const int a = t / HW, p = t - a * HW;
-        const int h = p / W, w = p - h * W;
-        const uint32_t idx = (uint32_t)(p * A + a);
-        // all_bbox = anchors + shifts in float64, then .astype(float32) (proposal_layer.py:200-221)
-        const double sx = (double)(w * feat_stride), sy = (double)(h * feat_stride);
-        const float bx1 = (float)(anchors.a[a][0] + sx), by1 = (float)(anchors.a[a][1] + sy);
-        const float bx2 = (float)(anchors.a[a][2] + sx), by2 = (float)(anchors.a[a][3] + sy);
-        // rpn_bbox_pred.transpose(1,2,0).reshape(-1,4): channel = a*4 + coord (proposal_layer.py:138)
-        const float dx = bbox_pred[(size_t)(a * 4 + 0) * HW + p], dy = bbox_pred[(size_t)(a * 4 + 1) * HW + p];
-        const float dw = bbox_pred[(size_t)(a * 4 + 2) * HW + p], dh = bbox_pred[(size_t)(a * 4 + 3) * HW + p];
-        // bbox_transform_inv (bbox_transform.py:51-74): separate multiplies and adds, no clamp on dw/dh
-        const float widths = bx2 - bx1 + 1.0f, heights = by2 - by1 + 1.0f;
-        const float ctr_x = bx1 + 0.5f * widths, ctr_y = by1 + 0.5f * heights;
-        const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
-        const float pw = (float)exp((double)dw) * widths, ph = (float)exp((double)dh) * heights;
-        float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
-        // clip_boxes (bbox_transform.py:88-98): maximum(minimum(v, int(dim-1)), 0)
-        const float mx = (float)(im_w - 1), my = (float)(im_h - 1);
-        x1 = clip_like_numpy(x1, mx); y1 = clip_like_numpy(y1, my);
-        x2 = clip_like_numpy(x2, mx); y2 = clip_like_numpy(y2, my);
-        // filter_boxes (bbox_transform.py:105-108); NaN compares false -> dropped
-        const float ws = x2 - x1 + 1.0f, hs = y2 - y1 + 1.0f;
-        valid = (ws >= min_size) && (hs >= min_size);
-        // fg score: rpn_cls_prob[A:].transpose(1,2,0) (proposal_layer.py:152-153)
-        const float sc = cls_prob[(size_t)(A + a) * HW + p];
-        reinterpret_cast<float4 *>(boxes)[idx] = make_float4(x1, y1, x2, y2);
-        scores[idx] = sc;
-        keys[idx] = valid ? make_key(sc, idx) : 0ull;
-    } else if (t < n_pad) {
-        keys[t] = 0ull;   // padding of the last sort tile
-    }
-    // n_valid: every block leaves ITS count in counters[1 + blockIdx.x] (plain stores: no zeroed counter, no memset launch, no
-    // atomics); rank_scatter_kernel's first block adds them up into counters[0] for the NMS kernels
-    __shared__ int wave_count[4];
-    const unsigned long long bal = __ballot(valid);
-    if ((threadIdx.x & 63) == 0) wave_count[threadIdx.x >> 6] = (int)__popcll(bal);
-    __syncthreads();
-    if (threadIdx.x == 0) counters[1 + blockIdx.x] = wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+// Decode anchor t = a * HW + p (coalesced over p), write its box / score at the reference's enumeration index idx = p * A + a and
+// return its sort key (0 = filtered out or past the end).
+struct DecodeArgs {
+    const float *cls_prob, *bbox_pred;
+    int A, H, W, feat_stride, im_h, im_w;
+    float min_size;
+    float *boxes, *scores;
+};
+__device__ __forceinline__ unsigned long long decode_anchor(const DecodeArgs &d, const Anchors &anchors, int t) {
+    const int HW = d.H * d.W;
+    if (t >= d.A * HW) return 0ull;
+    const int A = d.A, W = d.W;
+    const int a = t / HW, p = t - a * HW;
+    const int h = p / W, w = p - h * W;
+    const uint32_t idx = (uint32_t)(p * A + a);
+    // all_bbox = anchors + shifts in float64, then .astype(float32) (proposal_layer.py:200-221)
+    const double sx = (double)(w * d.feat_stride), sy = (double)(h * d.feat_stride);
+    const float bx1 = (float)(anchors.a[a][0] + sx), by1 = (float)(anchors.a[a][1] + sy);
+    const float bx2 = (float)(anchors.a[a][2] + sx), by2 = (float)(anchors.a[a][3] + sy);
+    // rpn_bbox_pred.transpose(1,2,0).reshape(-1,4): channel = a*4 + coord (proposal_layer.py:138)
+    const float dx = d.bbox_pred[(size_t)(a * 4 + 0) * HW + p], dy = d.bbox_pred[(size_t)(a * 4 + 1) * HW + p];
+    const float dw = d.bbox_pred[(size_t)(a * 4 + 2) * HW + p], dh = d.bbox_pred[(size_t)(a * 4 + 3) * HW + p];
+    // bbox_transform_inv (bbox_transform.py:51-74): separate multiplies and adds, no clamp on dw/dh
+    const float widths = bx2 - bx1 + 1.0f, heights = by2 - by1 + 1.0f;
+    const float ctr_x = bx1 + 0.5f * widths, ctr_y = by1 + 0.5f * heights;
+    const float pcx = dx * widths + ctr_x, pcy = dy * heights + ctr_y;
+    const float pw = (float)exp((double)dw) * widths, ph = (float)exp((double)dh) * heights;
+    float x1 = pcx - 0.5f * pw, y1 = pcy - 0.5f * ph, x2 = pcx + 0.5f * pw, y2 = pcy + 0.5f * ph;
+    // clip_boxes (bbox_transform.py:88-98): maximum(minimum(v, int(dim-1)), 0)
+    const float mx = (float)(d.im_w - 1), my = (float)(d.im_h - 1);
+    x1 = clip_like_numpy(x1, mx); y1 = clip_like_numpy(y1, my);
+    x2 = clip_like_numpy(x2, mx); y2 = clip_like_numpy(y2, my);
+    // filter_boxes (bbox_transform.py:105-108); NaN compares false -> dropped
+    const float ws = x2 - x1 + 1.0f, hs = y2 - y1 + 1.0f;
+    const bool valid = (ws >= d.min_size) && (hs >= d.min_size);
+    // fg score: rpn_cls_prob[A:].transpose(1,2,0) (proposal_layer.py:152-153)
+    const float sc = d.cls_prob[(size_t)(A + a) * HW + p];
+    reinterpret_cast<float4 *>(d.boxes)[idx] = make_float4(x1, y1, x2, y2);
+    d.scores[idx] = sc;
+    return valid ? make_key(sc, idx) : 0ull;
 }
 
 // keys for frcnn_nms(): every row of the (n,5) dets array takes part.
@@ -134,15 +126,38 @@ dets_keys_kernel(const float *__restrict__ dets, int n, int n_pad, unsigned long
 //   j = 256, 512   with another wave                                   (through LDS, two barriers: 3 steps)
 // (the all-LDS version of round 1 ran 55 barrier-separated passes).  Element i keeps the larger key of the pair (i, i ^ j) iff
 // (i & j) == 0 is equal to ((i & k) == 0): the usual bitonic rule, descending.
+// DECODE: the tile's keys are not read but MADE here -- anchors t = tile * 1024 + r * 256 + tid are decoded (ProposalLayer's
+// bbox_transform_inv / clip / filter, see decode_anchor) straight into the sort registers: the stand-alone decode launch (5 us of
+// mostly launch latency) and its 8-byte-per-anchor key round trip are gone.  Which tile a key starts in is irrelevant: ranks are global.
+// The tile's count of valid anchors goes to counters[1 + tile] (summed by rank_scatter_kernel).
+template <bool DECODE>
 __global__ void __launch_bounds__(kSortThreads)
-tile_sort_kernel(unsigned long long *__restrict__ keys, size_t slab) {
+tile_sort_kernel(unsigned long long *__restrict__ keys, size_t slab, DecodeArgs dec, Anchors anchors, int *__restrict__ counters) {
     __shared__ unsigned long long s[kSortTile];
     keys = slab_ptr(keys, slab);
     unsigned long long *g = keys + (size_t)blockIdx.x * kSortTile;
     const int tid = threadIdx.x;
     unsigned long long key[4];
+    if constexpr (DECODE) {
+        int n_valid = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) key[r] = g[tid * 4 + r];
+        for (int r = 0; r < 4; ++r) {
+            key[r] = decode_anchor(dec, anchors, blockIdx.x * kSortTile + r * kSortThreads + tid);
+            n_valid += key[r] != 0ull;
+        }
+        __shared__ int wave_count[kSortThreads / 64];
+        for (int d = 32; d > 0; d >>= 1) n_valid += __shfl_xor(n_valid, d);
+        if ((tid & 63) == 0) wave_count[tid >> 6] = n_valid;
+        __syncthreads();
+        if (tid == 0) {
+            int c = 0;
+            for (int w = 0; w < kSortThreads / 64; ++w) c += wave_count[w];
+            counters[1 + blockIdx.x] = c;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) key[r] = g[tid * 4 + r];
+    }
     for (int k = 2; k <= kSortTile; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
             if (j < 4) {
@@ -305,16 +320,35 @@ __device__ __forceinline__ unsigned long long nms_tile_words(const float4 rb, co
     return word;
 }
 
+// Everything the sequential pass needs; passed by value so the second-stage mask launch can run it itself (see below).
+struct ScanArgs {
+    const unsigned long long *mask;
+    int pitch;
+    const int *counters_in;
+    int top_k, max_out;
+    const int32_t *order;
+    const float *sorted_boxes, *sorted_scores;
+    int32_t *keep_pos, *out_index;
+    float *out_boxes, *out_scores;
+    int32_t *n_out;
+    int out_capacity;
+    size_t slab, out_gs;
+};
+__device__ void nms_scan_col_body(const ScanArgs &a, int c_begin, int c_end, int first_stage, int last_stage, int lane);
+
+// `tail`: this is the SECOND stage of a staged NMS.  When the first stage's scan already kept `limit` boxes, every workgroup returns at
+// once (and no further launch follows).  Otherwise the workgroups compute their tiles, publish them (agent-scope release) and draw a
+// ticket; the one that draws the last ticket acquires and runs the rest of the sequential pass on its first wave -- the second stage
+// costs ONE launch, and ~4 us of launch latency instead of ~9 when it has nothing to do.
 __global__ void __launch_bounds__(256)
 nms_mask_kernel(const float *__restrict__ sorted_boxes, const int *__restrict__ counters, int top_k, double thresh,
-                unsigned long long *__restrict__ mask, int pitch, size_t slab, int cc_lo, int cc_hi, const int32_t *__restrict__ n_done,
-                int max_out) {
+                unsigned long long *__restrict__ mask, int pitch, size_t slab, int cc_lo, int cc_hi, int max_out, int tail, ScanArgs scan,
+                int *__restrict__ ticket) {
     sorted_boxes = slab_ptr(sorted_boxes, slab); counters = slab_ptr(counters, slab); mask = slab_ptr(mask, slab);
     int m = counters[0];
     if (top_k > 0 && top_k < m) m = top_k;
     const int n_chunks = (m + kChunk - 1) / kChunk;
-    // second stage of a staged launch: nothing to do when the first stage's scan already kept `limit` boxes
-    if (n_done && n_done[blockIdx.z] >= ((max_out > 0 && max_out < m) ? max_out : m)) return;
+    if (tail && (scan.n_out[blockIdx.z] >= ((max_out > 0 && max_out < m) ? max_out : m) || cc_lo >= n_chunks)) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // tiles of the upper triangle, enumerated column by column (column cc holds rows 0 .. cc); this launch covers columns
@@ -323,26 +357,38 @@ nms_mask_kernel(const float *__restrict__ sorted_boxes, const int *__restrict__ 
     // wave), and the first stage of a staged NMS has fewer tiles than the chip has SIMDs -- its latency is the length of that chain
     const long long tri_lo = (long long)cc_lo * (cc_lo + 1) / 2;
     const long long Tp = (long long)blockIdx.x + tri_lo;
-    if (Tp >= (long long)cc_hi * (cc_hi + 1) / 2) return;
     int cc = (int)((sqrt(8.0 * (double)Tp + 1.0) - 1.0) * 0.5);
     cc = min(max(cc, 0), pitch - 1);
     while (cc > 0 && (long long)cc * (cc + 1) / 2 > Tp) --cc;
     while ((long long)(cc + 1) * (cc + 2) / 2 <= Tp) ++cc;
     cc = __builtin_amdgcn_readfirstlane(cc);
     const int rc = __builtin_amdgcn_readfirstlane((int)(Tp - (long long)cc * (cc + 1) / 2));
-    if (rc >= n_chunks || cc >= n_chunks) return;                      // wave-uniform
-    const int c = cc * kChunk + lane, r = rc * kChunk + lane;
-    float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), rb = cb;
-    if (c < m) cb = reinterpret_cast<const float4 *>(sorted_boxes)[c];
-    if (r < m) rb = reinterpret_cast<const float4 *>(sorted_boxes)[r];
-    const float carea = (cb.z - cb.x + 1.0f) * (cb.w - cb.y + 1.0f);  // areas, cpu_nms.pyx:25
-    const float rarea_l = (rb.z - rb.x + 1.0f) * (rb.w - rb.y + 1.0f);
-    const int t_begin = wave * 16, t_rows = min(min(kChunk, m - rc * kChunk), t_begin + 16);
-    const float probe = (cb.x + cb.y) + (cb.z + cb.w) + (rb.x + rb.y) + (rb.z + rb.w);       // NaN iff any coordinate of the tile is
-    unsigned long long word;
-    if (__any(probe != probe)) word = nms_tile_words<false>(rb, rarea_l, cb, carea, t_begin, t_rows, cc == rc, c < m, lane, thresh);
-    else word = nms_tile_words<true>(rb, rarea_l, cb, carea, t_begin, t_rows, cc == rc, c < m, lane, thresh);
-    if (r < m && (lane >> 4) == wave) mask[(size_t)r * pitch + cc] = word;
+    if (cc < cc_hi && rc < n_chunks && cc < n_chunks) {                // wave-uniform
+        const int c = cc * kChunk + lane, r = rc * kChunk + lane;
+        float4 cb = make_float4(0.f, 0.f, 0.f, 0.f), rb = cb;
+        if (c < m) cb = reinterpret_cast<const float4 *>(sorted_boxes)[c];
+        if (r < m) rb = reinterpret_cast<const float4 *>(sorted_boxes)[r];
+        const float carea = (cb.z - cb.x + 1.0f) * (cb.w - cb.y + 1.0f);  // areas, cpu_nms.pyx:25
+        const float rarea_l = (rb.z - rb.x + 1.0f) * (rb.w - rb.y + 1.0f);
+        const int t_begin = wave * 16, t_rows = min(min(kChunk, m - rc * kChunk), t_begin + 16);
+        const float probe = (cb.x + cb.y) + (cb.z + cb.w) + (rb.x + rb.y) + (rb.z + rb.w);       // NaN iff any coordinate of the tile is
+        unsigned long long word;
+        if (__any(probe != probe)) word = nms_tile_words<false>(rb, rarea_l, cb, carea, t_begin, t_rows, cc == rc, c < m, lane, thresh);
+        else word = nms_tile_words<true>(rb, rarea_l, cb, carea, t_begin, t_rows, cc == rc, c < m, lane, thresh);
+        if (r < m && (lane >> 4) == wave) mask[(size_t)r * pitch + cc] = word;
+    }
+    if (!tail) return;
+    // publish, count in, and let the last workgroup finish the sequential pass
+    __shared__ int s_last;
+    frcnn_drain_vmem();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        frcnn_release_agent();
+        s_last = frcnn_ticket(slab_ptr(ticket, slab)) == (int)gridDim.x - 1;
+        if (s_last) frcnn_acquire_agent();
+    }
+    __syncthreads();
+    if (s_last && wave == 0) nms_scan_col_body(scan, cc_lo, pitch, 0, 1, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -572,12 +618,15 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__global__ void __launch_bounds__(64)
-nms_scan_col_kernel(const unsigned long long *__restrict__ mask, int pitch, const int *__restrict__ counters_in, int top_k,
-                    int max_out, const int32_t *__restrict__ order, const float *__restrict__ sorted_boxes,
-                    const float *__restrict__ sorted_scores, int32_t *__restrict__ keep_pos, int32_t *__restrict__ out_index,
-                    float *__restrict__ out_boxes, float *__restrict__ out_scores, int32_t *__restrict__ n_out,
-                    int out_capacity, size_t slab, size_t out_gs, int c_begin, int c_end, int first_stage, int last_stage) {
+__device__ void nms_scan_col_body(const ScanArgs &a, int c_begin, int c_end, int first_stage, int last_stage, int lane) {
+    const unsigned long long *mask = a.mask;
+    const int pitch = a.pitch, top_k = a.top_k, max_out = a.max_out, out_capacity = a.out_capacity;
+    const int *counters_in = a.counters_in;
+    const int32_t *order = a.order;
+    const float *sorted_boxes = a.sorted_boxes, *sorted_scores = a.sorted_scores;
+    int32_t *keep_pos = a.keep_pos, *out_index = a.out_index, *n_out = a.n_out;
+    float *out_boxes = a.out_boxes, *out_scores = a.out_scores;
+    const size_t slab = a.slab, out_gs = a.out_gs;
     __shared__ int kept_list[kKeptLds];
     const int gz = blockIdx.z;
     counters_in = slab_ptr(counters_in, slab); mask = slab_ptr(mask, slab); order = slab_ptr(order, slab);
@@ -590,7 +639,6 @@ nms_scan_col_kernel(const unsigned long long *__restrict__ mask, int pitch, cons
     if (top_k > 0 && top_k < m) m = top_k;
     const int limit = (max_out > 0 && max_out < m) ? max_out : m;
     const int n_chunks = (m + kChunk - 1) / kChunk;
-    const int lane = threadIdx.x;
     int n_kept = 0;
     if (!first_stage) {
         n_kept = n_out[0];
@@ -688,10 +736,16 @@ nms_scan_col_kernel(const unsigned long long *__restrict__ mask, int pitch, cons
     }
 }
 
+__global__ void __launch_bounds__(64)
+nms_scan_col_kernel(ScanArgs a, int c_begin, int c_end, int first_stage, int last_stage, int *__restrict__ ticket) {
+    if (ticket && threadIdx.x == 0) *slab_ptr(ticket, a.slab) = 0;       // the second stage's arrival counter (see nms_mask_kernel)
+    nms_scan_col_body(a, c_begin, c_end, first_stage, last_stage, (int)threadIdx.x);
+}
+
 // ------------------------------------------------------------------------------------------------
 struct Layout {   // carve-up of the caller's workspace (per group)
     size_t counters, keys, boxes, scores, order, sboxes, sscores, keep_pos, mask, total;
-    int n_pad, n_tiles, m_max, pitch;
+    int n_pad, n_tiles, m_max, pitch, ticket_index;
 };
 
 // FRCNN_NMS_SCAN=1: the one-chunk-per-trip single-wave scan of round 1 (A/B measurements); default: four chunks per trip
@@ -720,7 +774,8 @@ static Layout make_layout(int n_total, int top_k, bool own_boxes) {
     if (L.m_max < 1) L.m_max = 1;
     L.pitch = frcnn_cdiv(L.m_max, kChunk);
     size_t o = 0;
-    L.counters = o; o += frcnn_align256((size_t)(1 + L.n_pad / 256) * sizeof(int));   // [0] n_valid, [1 + b] decode block b's count
+    L.ticket_index = 1 + L.n_pad / 256;                                               // [0] n_valid, [1 + b] tile b's count, then the stage-2 ticket
+    L.counters = o; o += frcnn_align256((size_t)(2 + L.n_pad / 256) * sizeof(int));
     L.keys = o; o += frcnn_align256((size_t)L.n_pad * 8);
     L.boxes = o; o += own_boxes ? frcnn_align256((size_t)(n_total > 0 ? n_total : 1) * 16) : 0;
     L.scores = o; o += own_boxes ? frcnn_align256((size_t)(n_total > 0 ? n_total : 1) * 4) : 0;
@@ -734,14 +789,17 @@ static Layout make_layout(int n_total, int top_k, bool own_boxes) {
 }
 
 // Mask + sequential pass of one (possibly batched) NMS problem, in one or two stages (see nms_scan_col_kernel).
-static void launch_mask_and_scan(hipStream_t stream, int groups, const Layout &L, const float *sboxes, const int *counters, int top_k,
+static void launch_mask_and_scan(hipStream_t stream, int groups, const Layout &L, const float *sboxes, int *counters, int top_k,
                                  double thresh, int max_out, unsigned long long *mask, const int32_t *order, const float *sscores,
                                  int32_t *keep_pos, int32_t *out_index, float *out_boxes, float *out_scores, int32_t *n_out,
                                  int out_capacity, size_t slab, size_t out_gs) {
     const dim3 blk(256);
+    const ScanArgs sa{mask, L.pitch, counters, top_k, max_out, order, sboxes, sscores, keep_pos, out_index, out_boxes, out_scores, n_out,
+                      out_capacity, slab, out_gs};
+    int *ticket = counters + L.ticket_index;
     if (scan_one_chunk_per_trip()) {                       // round-1 row-form scan (A/B measurements)
         hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_blocks(0, L.pitch), 1, groups), blk, 0, stream, sboxes, counters, top_k, thresh, mask,
-                           L.pitch, slab, 0, L.pitch, (const int32_t *)nullptr, max_out);
+                           L.pitch, slab, 0, L.pitch, max_out, 0, sa, ticket);
         if (L.pitch <= 128)
             hipLaunchKernelGGL(nms_scan_wave_kernel<2>, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, top_k, max_out, order,
                                sboxes, sscores, keep_pos, out_index, out_boxes, out_scores, n_out, out_capacity, slab, out_gs);
@@ -756,15 +814,11 @@ static void launch_mask_and_scan(hipStream_t stream, int groups, const Layout &L
     const int S = nms_stage_chunks(L.pitch, max_out);
     const int hi0 = S > 0 ? S : L.pitch;
     hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_blocks(0, hi0), 1, groups), blk, 0, stream, sboxes, counters, top_k, thresh, mask, L.pitch,
-                       slab, 0, hi0, (const int32_t *)nullptr, max_out);
-    hipLaunchKernelGGL(nms_scan_col_kernel, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, top_k, max_out, order, sboxes,
-                       sscores, keep_pos, out_index, out_boxes, out_scores, n_out, out_capacity, slab, out_gs, 0, hi0, 1, S > 0 ? 0 : 1);
-    if (S > 0) {
+                       slab, 0, hi0, max_out, 0, sa, ticket);
+    hipLaunchKernelGGL(nms_scan_col_kernel, dim3(1, 1, groups), dim3(64), 0, stream, sa, 0, hi0, 1, S > 0 ? 0 : 1, S > 0 ? ticket : (int *)nullptr);
+    if (S > 0)            // second stage: the rest of the mask AND (by its last workgroup) the rest of the sequential pass, if still needed
         hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_blocks(S, L.pitch), 1, groups), blk, 0, stream, sboxes, counters, top_k, thresh, mask,
-                           L.pitch, slab, S, L.pitch, (const int32_t *)n_out, max_out);
-        hipLaunchKernelGGL(nms_scan_col_kernel, dim3(1, 1, groups), dim3(64), 0, stream, mask, L.pitch, counters, top_k, max_out, order, sboxes,
-                           sscores, keep_pos, out_index, out_boxes, out_scores, n_out, out_capacity, slab, out_gs, S, L.pitch, 0, 1);
-    }
+                           L.pitch, slab, S, L.pitch, max_out, 1, sa, ticket);
 }
 
 }  // namespace
@@ -797,7 +851,8 @@ int frcnn_nms_batched(const float *dets, int groups, int n, double thresh, int m
     const dim3 blk(256);
     hipLaunchKernelGGL(dets_keys_kernel, dim3(frcnn_cdiv(L.n_pad, 256), 1, groups), blk, 0, stream, dets, n, L.n_pad, keys,
                        counters, (size_t)n * 5, gs);
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(L.n_tiles, 1, groups), dim3(kSortThreads), 0, stream, keys, gs);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(tile_sort_kernel<false>), dim3(L.n_tiles, 1, groups), dim3(kSortThreads), 0, stream, keys, gs, DecodeArgs{},
+                       Anchors{}, (int *)nullptr);
     hipLaunchKernelGGL(rank_scatter_kernel, dim3(frcnn_cdiv(L.n_pad, 256), 1, groups), blk, 0, stream, keys, L.n_tiles, dets, 5,
                        dets + 4, 5, 0, counters, 0, order, sboxes, sscores, (size_t)n * 5, gs);
     launch_mask_and_scan(stream, groups, L, sboxes, counters, 0, thresh, max_out, mask, order, sscores, keep_pos, keep, (float *)nullptr,
@@ -840,11 +895,10 @@ int frcnn_proposals(const float *rpn_cls_prob, const float *rpn_bbox_pred, int A
     for (int a = 0; a < A; ++a)
         for (int c = 0; c < 4; ++c) anc.a[a][c] = anchors_host[a * 4 + c];
     const dim3 blk(256);
-    hipLaunchKernelGGL(proposal_decode_kernel, dim3(frcnn_cdiv(L.n_pad, 256)), blk, 0, stream, rpn_cls_prob, rpn_bbox_pred, A, H, W,
-                       anc, feat_stride, im_h, im_w, min_size, boxes, scores, keys, L.n_pad, counters);
-    hipLaunchKernelGGL(tile_sort_kernel, dim3(L.n_tiles), dim3(kSortThreads), 0, stream, keys, (size_t)0);
+    const DecodeArgs dec{rpn_cls_prob, rpn_bbox_pred, A, H, W, feat_stride, im_h, im_w, min_size, boxes, scores};
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(tile_sort_kernel<true>), dim3(L.n_tiles), dim3(kSortThreads), 0, stream, keys, (size_t)0, dec, anc, counters);
     hipLaunchKernelGGL(rank_scatter_kernel, dim3(frcnn_cdiv(L.n_pad, 256)), blk, 0, stream, keys, L.n_tiles, boxes, 4, scores, 1,
-                       pre_nms_top_n, counters, L.n_pad / 256, order, sboxes, sscores, (size_t)0, (size_t)0);
+                       pre_nms_top_n, counters, L.n_tiles, order, sboxes, sscores, (size_t)0, (size_t)0);
     launch_mask_and_scan(stream, 1, L, sboxes, counters, pre_nms_top_n, nms_thresh, post_nms_top_n, mask, order, sscores, keep_pos, src_index,
                          rois, probs, n_out, (post_nms_top_n > 0 && post_nms_top_n < L.m_max) ? post_nms_top_n : L.m_max, (size_t)0, (size_t)0);
     return frcnn_launch_status();
