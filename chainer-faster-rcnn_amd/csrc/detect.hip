@@ -33,7 +33,7 @@ namespace {
 
 constexpr int kSortTile = 1024;   // keys per bitonic tile (one 256-thread workgroup, 4 keys per thread)
 constexpr int kSortThreads = 256;
-constexpr int kRankTiles = 8;     // tiles searched together by rank_scatter_kernel (independent binary searches in flight)
+constexpr int kRankTiles = 4;     // tiles searched together (8 = 128 KB of LDS, one workgroup per CU: measured slower) by rank_scatter_kernel (independent binary searches in flight)
 constexpr int kChunk = 64;        // NMS chunk = wave width
 
 __device__ __forceinline__ uint32_t ordered_bits(float f) {
@@ -229,6 +229,29 @@ rank_scatter_kernel(const unsigned long long *__restrict__ keys, int n_tiles, co
         __syncthreads();
         if (threadIdx.x == 0) cw[0] = partial[0] + partial[1] + partial[2] + partial[3];
     }
+    // Keys that cannot be among the top_k need no rank: the q-th key of EVERY tile, q = ceil(top_k / n_tiles), is >= the global
+    // top_k-th key's lower bound L = min over tiles of tile[q - 1] (the top q of each tile are n_tiles * q >= top_k keys >= L), so a
+    // key < L has at least top_k larger ones.  Tiles are sorted: whole workgroups at the tail of a tile fall out here.
+    if (top_k > 0 && (long long)top_k < (long long)n_tiles * kSortTile) {
+        const int q = (top_k + n_tiles - 1) / n_tiles;
+        if (q <= kSortTile) {
+            __shared__ unsigned long long s_lb;
+            if (threadIdx.x < 64) {
+                unsigned long long lb = ~0ull;
+                for (int tl = threadIdx.x; tl < n_tiles; tl += 64) { const unsigned long long v = keys[(size_t)tl * kSortTile + q - 1]; lb = v < lb ? v : lb; }
+                uint32_t lo = (uint32_t)lb, hi = (uint32_t)(lb >> 32);
+                for (int d = 32; d > 0; d >>= 1) {
+                    const uint32_t olo = (uint32_t)__shfl_xor((int)lo, d), ohi = (uint32_t)__shfl_xor((int)hi, d);
+                    const unsigned long long o = ((unsigned long long)ohi << 32) | olo, me = ((unsigned long long)hi << 32) | lo;
+                    if (o < me) { lo = olo; hi = ohi; }
+                }
+                if (threadIdx.x == 0) s_lb = ((unsigned long long)hi << 32) | lo;
+            }
+            __syncthreads();
+            const unsigned long long first_key = keys[(size_t)blockIdx.x * blockDim.x];      // the workgroup's largest key (its tile is sorted)
+            if (first_key < s_lb) return;                                                       // workgroup-uniform
+        }
+    }
     const int n_groups = (n_tiles + kRankTiles - 1) / kRankTiles;
     unsigned long long stage[SQ];
 #pragma unroll
@@ -334,7 +357,7 @@ struct ScanArgs {
     int out_capacity;
     size_t slab, out_gs;
 };
-__device__ void nms_scan_col_body(const ScanArgs &a, int c_begin, int c_end, int first_stage, int last_stage, int lane);
+__device__ __forceinline__ void nms_scan_col_body(const ScanArgs &a, int c_begin, int c_end, int first_stage, int last_stage, int lane);
 
 // `tail`: this is the SECOND stage of a staged NMS.  When the first stage's scan already kept `limit` boxes, every workgroup returns at
 // once (and no further launch follows).  Otherwise the workgroups compute their tiles, publish them (agent-scope release) and draw a
@@ -618,7 +641,7 @@ __device__ __forceinline__ unsigned long long wave_or_u64(unsigned long long v) 
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__device__ void nms_scan_col_body(const ScanArgs &a, int c_begin, int c_end, int first_stage, int last_stage, int lane) {
+__device__ __forceinline__ void nms_scan_col_body(const ScanArgs &a, int c_begin, int c_end, int first_stage, int last_stage, int lane) {
     const unsigned long long *mask = a.mask;
     const int pitch = a.pitch, top_k = a.top_k, max_out = a.max_out, out_capacity = a.out_capacity;
     const int *counters_in = a.counters_in;
