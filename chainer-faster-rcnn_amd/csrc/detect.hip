@@ -126,7 +126,7 @@ dets_keys_kernel(const float *__restrict__ dets, int n, int n_pad, unsigned long
 //   j = 256, 512   with another wave                                   (through LDS, two barriers: 3 steps)
 // (the all-LDS version of round 1 ran 55 barrier-separated passes).  Element i keeps the larger key of the pair (i, i ^ j) iff
 // (i & j) == 0 is equal to ((i & k) == 0): the usual bitonic rule, descending.
-// DECODE: the tile's keys are not read but MADE here -- anchors t = tile * 1024 + r * 256 + tid are decoded (ProposalLayer's
+// DECODE: the tile's keys are not read but MADE here -- 16 runs of 64 anchors, dealt round-robin over the tiles, are decoded (ProposalLayer's
 // bbox_transform_inv / clip / filter, see decode_anchor) straight into the sort registers: the stand-alone decode launch (5 us of
 // mostly launch latency) and its 8-byte-per-anchor key round trip are gone.  Which tile a key starts in is irrelevant: ranks are global.
 // The tile's count of valid anchors goes to counters[1 + tile] (summed by rank_scatter_kernel).
@@ -142,7 +142,10 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, size_t slab, DecodeArgs 
         int n_valid = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            key[r] = decode_anchor(dec, anchors, blockIdx.x * kSortTile + r * kSortThreads + tid);
+            // 64-anchor runs (coalesced) dealt round-robin to the tiles: every tile is a uniform sample of all positions and anchor
+            // shapes, so its q-th key is a tight lower bound of the global cut and rank_scatter_kernel can skip most keys
+            const int run = (r * (kSortThreads / 64) + (tid >> 6)) * (int)gridDim.x + (int)blockIdx.x;
+            key[r] = decode_anchor(dec, anchors, run * 64 + (tid & 63));
             n_valid += key[r] != 0ull;
         }
         __shared__ int wave_count[kSortThreads / 64];
