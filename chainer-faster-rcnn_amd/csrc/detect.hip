@@ -142,8 +142,7 @@ tile_sort_kernel(unsigned long long *__restrict__ keys, size_t slab, DecodeArgs 
         int n_valid = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            // 64-anchor runs (coalesced) dealt round-robin to the tiles: every tile is a uniform sample of all positions and anchor
-            // shapes, so its q-th key is a tight lower bound of the global cut and rank_scatter_kernel can skip most keys
+            // 64-anchor runs (coalesced) dealt round-robin to the tiles: every tile is a uniform sample of all positions and anchor shapes
             const int run = (r * (kSortThreads / 64) + (tid >> 6)) * (int)gridDim.x + (int)blockIdx.x;
             key[r] = decode_anchor(dec, anchors, run * 64 + (tid & 63));
             n_valid += key[r] != 0ull;
@@ -231,29 +230,6 @@ rank_scatter_kernel(const unsigned long long *__restrict__ keys, int n_tiles, co
         if ((threadIdx.x & 63) == 0) partial[threadIdx.x >> 6] = acc;
         __syncthreads();
         if (threadIdx.x == 0) cw[0] = partial[0] + partial[1] + partial[2] + partial[3];
-    }
-    // Keys that cannot be among the top_k need no rank: the q-th key of EVERY tile, q = ceil(top_k / n_tiles), is >= the global
-    // top_k-th key's lower bound L = min over tiles of tile[q - 1] (the top q of each tile are n_tiles * q >= top_k keys >= L), so a
-    // key < L has at least top_k larger ones.  Tiles are sorted: whole workgroups at the tail of a tile fall out here.
-    if (top_k > 0 && (long long)top_k < (long long)n_tiles * kSortTile) {
-        const int q = (top_k + n_tiles - 1) / n_tiles;
-        if (q <= kSortTile) {
-            __shared__ unsigned long long s_lb;
-            if (threadIdx.x < 64) {
-                unsigned long long lb = ~0ull;
-                for (int tl = threadIdx.x; tl < n_tiles; tl += 64) { const unsigned long long v = keys[(size_t)tl * kSortTile + q - 1]; lb = v < lb ? v : lb; }
-                uint32_t lo = (uint32_t)lb, hi = (uint32_t)(lb >> 32);
-                for (int d = 32; d > 0; d >>= 1) {
-                    const uint32_t olo = (uint32_t)__shfl_xor((int)lo, d), ohi = (uint32_t)__shfl_xor((int)hi, d);
-                    const unsigned long long o = ((unsigned long long)ohi << 32) | olo, me = ((unsigned long long)hi << 32) | lo;
-                    if (o < me) { lo = olo; hi = ohi; }
-                }
-                if (threadIdx.x == 0) s_lb = ((unsigned long long)hi << 32) | lo;
-            }
-            __syncthreads();
-            const unsigned long long first_key = keys[(size_t)blockIdx.x * blockDim.x];      // the workgroup's largest key (its tile is sorted)
-            if (first_key < s_lb) return;                                                       // workgroup-uniform
-        }
     }
     const int n_groups = (n_tiles + kRankTiles - 1) / kRankTiles;
     unsigned long long stage[SQ];
