@@ -404,8 +404,13 @@ conv_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy
 // base is a scalar offset, the per-lane offset (column, or out-of-range for padding / beyond the image) is fixed for the tile, so a
 // DMA costs a handful of SALU operations and no VALU -- and no staging registers: two workgroups per CU, one's MFMAs over the
 // other's loads, plus fragment reads software-pipelined one step ahead of the MFMAs.
-template <int KS>
-__global__ void __launch_bounds__(256, 2)
+// DB = double-buffered LDS images (103 KB: one workgroup per CU, one wave per SIMD): tile b+1's DMAs are issued right after the
+// barrier that hands over tile b and land under tile b's 288 MFMAs per wave -- the single-buffer form (two workgroups per CU, each
+// alternating "load, wait, compute") left the matrix pipe idle whenever both workgroups of a CU were waiting: 96 TFLOP/s vs the
+// forward kernel's 125 (r01 / r02 kernel stats).  One fence-less barrier per tile, no counted waits (a wave issues 80 DMAs per tile,
+// more than vmcnt can count: the wait for tile b+1 is the vmcnt(0) at the top of the next trip, a whole compute phase later).
+template <int KS, bool DB = false>
+__global__ void __launch_bounds__(256, DB ? 1 : 2)
 conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slabs, int Cin, int Cout, int H, int W,
                       int xtiles, int nblocks, int splits) {
     constexpr int T = KS * KS, PAD = KS / 2;
@@ -413,8 +418,9 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
     constexpr int HR = WG_ROWS + KS - 1;
     constexpr int CHP = HR * HP + ((HR * HP) % 2 == 0 ? 1 : 0);
     constexpr int DP = WG_ROWS * 32 + 1;
-    __shared__ float x_lds[64 * CHP];
-    __shared__ float dy_lds[64 * DP];
+    constexpr int NB = DB ? 2 : 1;
+    __shared__ float x_lds[NB][64 * CHP];
+    __shared__ float dy_lds[NB][64 * DP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wci = wave & 1, wco = wave >> 1;
@@ -432,7 +438,8 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
     static_assert(WG_ROWS == 2, "a dy piece is the two 32-pixel rows of one channel");
-    for (int b = b_begin; b < b_end; ++b) {
+    // DMA of tile b into LDS image `buf`: wave w moves channels w, w+4, ... (16 channels: HR x rows + 1 dy piece each)
+    auto issue = [&](int b, int buf) {
         const int tx = b % xtiles, ty = b / xtiles;
         const int x0 = tx * 32, y0 = ty * WG_ROWS;
         // per-lane parts, fixed for the tile.  x piece = one halo row of one channel (HP floats: lanes >= HP sit it out), columns
@@ -443,8 +450,6 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
         // dy piece = both rows of one channel (64 floats): lane -> (row lane>>5, column lane&31)
         const int dgy = y0 + (lane >> 5), dgx = x0 + (lane & 31);
         const uint32_t vd = (dgy < H && dgx < W) ? (uint32_t)((lane >> 5) * W + (lane & 31)) * 4u : kBufOob;
-        if (b != b_begin) frcnn_barrier_nofence();            // every wave is done reading the previous tile
-        // wave w moves channels w, w+4, ... (16 channels: HR x rows + 1 dy piece each)
 #pragma unroll 1
         for (int q = 0; q < 16; ++q) {
             const int c = wave + 4 * q;
@@ -454,16 +459,16 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                 const int gy = y0 - PAD + hr;
                 const bool row_ok = gc < Cin && gy >= 0 && gy < H;              // wave-uniform
                 const uint32_t so = row_ok ? (uint32_t)(((size_t)gc * H + gy) * W + xs) * 4u : 0u;
-                if (lane < HP) frcnn_buf_load_lds_b32(xbuf, &x_lds[c * CHP + hr * HP], row_ok ? vx : kBufOob, so);
+                if (lane < HP) frcnn_buf_load_lds_b32(xbuf, &x_lds[buf][c * CHP + hr * HP], row_ok ? vx : kBufOob, so);
             }
             const bool ch_ok = gco < Cout && y0 < H;
             const uint32_t so = ch_ok ? (uint32_t)(((size_t)gco * H + y0) * W + x0) * 4u : 0u;
-            frcnn_buf_load_lds_b32(dbuf, &dy_lds[c * DP], ch_ok ? vd : kBufOob, so);
+            frcnn_buf_load_lds_b32(dbuf, &dy_lds[buf][c * DP], ch_ok ? vd : kBufOob, so);
         }
-        frcnn_wait_vmcnt<0>();
-        frcnn_barrier_nofence();
-        const float *xa = x_lds + (wci * 32 + l31) * CHP + khalf;
-        const float *db = dy_lds + (wco * 32 + l31) * DP + khalf;
+    };
+    auto compute = [&](int buf) {
+        const float *xa = x_lds[buf] + (wci * 32 + l31) * CHP + khalf;
+        const float *db = dy_lds[buf] + (wco * 32 + l31) * DP + khalf;
         // step s = (row r, pixel pair pp): one dy value and the T shifted x values feed T MFMAs; the fragments of step s+1 are
         // read before the MFMAs of step s are issued (register double buffer, two steps per trip so it is indexed statically)
         constexpr int NSTEP = WG_ROWS * 16;
@@ -485,6 +490,25 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][t], bv[1], acc[t], 0, 0, 0);
+        }
+    };
+    if constexpr (DB) {
+        if (b_begin < b_end) issue(b_begin, 0);
+        int buf = 0;
+        for (int b = b_begin; b < b_end; ++b) {
+            frcnn_wait_vmcnt<0>();                                // tile b's pieces of THIS wave have landed ...
+            frcnn_barrier_nofence();                              // ... everybody's have, and everybody is done with tile b-1's image
+            if (b + 1 < b_end) issue(b + 1, buf ^ 1);
+            compute(buf);
+            buf ^= 1;
+        }
+    } else {
+        for (int b = b_begin; b < b_end; ++b) {
+            if (b != b_begin) frcnn_barrier_nofence();            // every wave is done reading the previous tile
+            issue(b, 0);
+            frcnn_wait_vmcnt<0>();
+            frcnn_barrier_nofence();
+            compute(0);
         }
     }
     float *slab = slabs + (size_t)split * ((size_t)Cin * T * Cout);
@@ -631,13 +655,19 @@ gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ id
 
 struct WgradPlan { int xtiles, nblocks, splits, ci_tiles, co_tiles; size_t slab_floats; };
 
+static bool wgrad_double_buffered() {
+    const char *e = getenv("FRCNN_WGRAD_DB");                   // A/B hook: 0 = the single-buffer kernel of round 1
+    return !(e && e[0] == '0');
+}
+
 static WgradPlan plan_wgrad(int Cin, int Cout, int H, int W, int ks) {
     WgradPlan p;
     p.xtiles = frcnn_cdiv(W, 32);
     p.nblocks = p.xtiles * frcnn_cdiv(H, WG_ROWS);
     p.ci_tiles = frcnn_cdiv(Cin, 64);
     p.co_tiles = frcnn_cdiv(Cout, 64);
-    int s = frcnn_cdiv(512, p.ci_tiles * p.co_tiles);          // about two workgroups per CU
+    // 3x3 double-buffered kernel: one workgroup per CU; the single-buffer forms (1x1, FRCNN_WGRAD_DB=0): about two per CU
+    int s = frcnn_cdiv((ks == 3 && wgrad_double_buffered()) ? frcnn_cu_count() : 2 * frcnn_cu_count(), p.ci_tiles * p.co_tiles);
     if (s > p.nblocks) s = p.nblocks;
     if (s < 1) s = 1;
     p.splits = s;
@@ -823,7 +853,8 @@ int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int 
     float *slabs = (float *)workspace;
     const dim3 grid(p.ci_tiles, p.co_tiles, p.splits);
     const bool reg = getenv("FRCNN_WGRAD_REG") != nullptr;        // A/B hook: the register-staged kernel
-    if (ksize == 3 && !reg) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
+    if (ksize == 3 && !reg && wgrad_double_buffered()) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
+    else if (ksize == 3 && !reg) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
     else if (ksize == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<3>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
     else if (!reg) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<1>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<1>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Summarise the FETCH_SIZE / WRITE_SIZE passes of `rocprofv3 --pmc` over bench.py (scripts/r02_gpu_f.sh) into
+profiles/r02_hbm_traffic_pmc[_bf16].json.  Counters are per dispatch, in KB, summed over the L2 channels; they sit on the L2's
+fabric side (Infinity-Cache hits are counted).  Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE reports HALF the
+bytes of 16-byte-per-lane loads (`buffer_load_dwordx4 ... lds` included).  The bf16 kernels load 16 B per lane only -> FETCH x 2.
+The fp32 conv kernel mixes 4-byte (activation rows, calibrated 1:1 in round 1) and 16-byte (weight panels) loads, which the counter
+cannot separate: both the raw figure and the all-16-byte upper bound (FETCH x 2) are recorded, and the UPPER bound is what bench.py
+reports as roofline.traffic."""
+import collections
+import csv
+import json
+import sys
+
+
+def main(out_dir, dtype):
+    acc = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open("%s/traffic_%s_%s/t_counter_collection.csv" % (out_dir, dtype, c))):
+            if r["Counter_Name"] == c:
+                name = r["Kernel_Name"].replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "")
+                per[name.split("(")[0]].append(float(r["Counter_Value"]))
+        acc[c] = per
+    out = {}
+    for name in sorted(set(acc["FETCH_SIZE"]) | set(acc["WRITE_SIZE"])):
+        f, w = acc["FETCH_SIZE"].get(name, []), acc["WRITE_SIZE"].get(name, [])
+        out[name[:90]] = {"launches": len(f), "FETCH_SIZE_KB_per_launch": sum(f) / max(1, len(f)), "WRITE_SIZE_KB_per_launch": sum(w) / max(1, len(w))}
+
+    def family(pred):
+        fl = [v for n, vs in acc["FETCH_SIZE"].items() if pred(n) for v in vs]
+        wl = [v for n, vs in acc["WRITE_SIZE"].items() if pred(n) for v in vs]
+        return len(fl), 1024.0 * sum(fl) / max(1, len(fl)), 1024.0 * sum(wl) / max(1, len(wl))
+    summ = {"command": "python bench.py --dtype %s --steps 3 --warmup 2 --no-cpu-baseline --no-stage-events (two passes: --pmc FETCH_SIZE, --pmc WRITE_SIZE, "
+                       "--kernel-trace only)" % dtype}
+    if dtype == "f32":
+        n, fb, wb = family(lambda s: s.startswith("conv_mfma_f32_kernel<3"))
+        summ["conv_mfma_f32_kernel"] = {"launches_counted": n, "fetch_bytes_per_launch_raw": fb, "write_bytes_per_launch": wb,
+                                        "hbm_bytes_per_launch_raw": fb + wb,
+                                        "hbm_bytes_per_launch": 2.0 * fb + wb,
+                                        "correction": "FETCH x 2 applied to ALL fetches (upper bound: the weight panels are 16-byte-per-lane LDS-DMA "
+                                                      "loads, which FETCH_SIZE halves; the 4-byte activation loads are counted 1:1)"}
+    else:
+        n, fb, wb = family(lambda s: s.startswith("conv_dma_bf16_kernel") or s.startswith("conv_mfma_bf16_kernel<3"))
+        summ["conv_bf16_kernel"] = {"launches_counted": n, "fetch_bytes_per_launch_raw": fb, "write_bytes_per_launch": wb,
+                                    "hbm_bytes_per_launch": 2.0 * fb + wb,
+                                    "correction": "FETCH x 2 (every global read of the kernel is a 16-byte-per-lane buffer_load ... lds)"}
+    n, fb, wb = family(lambda s: s.startswith("roi_pool_cells_kernel"))
+    summ["roi_pool_cells_kernel"] = {"launches_counted": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                                     "note": "4-byte-per-lane reads (1:1); algorithmic 4.90 MB read + 30.11 MB (fp32) / 15.05 MB (bf16) written"}
+    out["_summary"] = summ
+    name = "r02_hbm_traffic_pmc.json" if dtype == "f32" else "r02_hbm_traffic_pmc_bf16.json"
+    json.dump(out, open("%s/%s" % (out_dir, name), "w"), indent=1, sort_keys=True)
+    print(json.dumps(summ, indent=1))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
