@@ -405,9 +405,9 @@ conv_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy
 // DMA costs a handful of SALU operations and no VALU -- and no staging registers: two workgroups per CU, one's MFMAs over the
 // other's loads, plus fragment reads software-pipelined one step ahead of the MFMAs.
 // DB = double-buffered LDS images (103 KB: one workgroup per CU, one wave per SIMD): tile b+1's DMAs are issued right after the
-// barrier that hands over tile b and land under tile b's 288 MFMAs per wave -- the single-buffer form (two workgroups per CU, each
-// alternating "load, wait, compute") left the matrix pipe idle whenever both workgroups of a CU were waiting: 96 TFLOP/s vs the
-// forward kernel's 125 (r01 / r02 kernel stats).  One fence-less barrier per tile, no counted waits (a wave issues 80 DMAs per tile,
+// barrier that hands over tile b and land under tile b's 288 MFMAs per wave.  An experiment kept behind FRCNN_WGRAD_DB=1: it measured
+// 3.6 % SLOWER per training step than the single-buffer form at two workgroups per CU (see wgrad_double_buffered()).
+// One fence-less barrier per tile, no counted waits (a wave issues 80 DMAs per tile,
 // more than vmcnt can count: the wait for tile b+1 is the vmcnt(0) at the top of the next trip, a whole compute phase later).
 template <int KS, bool DB = false>
 __global__ void __launch_bounds__(256, DB ? 1 : 2)
@@ -655,9 +655,12 @@ gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ id
 
 struct WgradPlan { int xtiles, nblocks, splits, ci_tiles, co_tiles; size_t slab_floats; };
 
+// FRCNN_WGRAD_DB=1 selects the double-buffered 3x3 kernel (one workgroup per CU).  Measured on MI355X (r02, bench.py --mode train):
+// 12.03 ms / step vs 11.61 ms for the single-buffer kernel at two workgroups per CU -- one wave per SIMD does not keep the fp32
+// matrix pipe fed even with its loads hidden; the second wave does more than the overlap.  So it is NOT the default.
 static bool wgrad_double_buffered() {
-    const char *e = getenv("FRCNN_WGRAD_DB");                   // A/B hook: 0 = the single-buffer kernel of round 1
-    return !(e && e[0] == '0');
+    const char *e = getenv("FRCNN_WGRAD_DB");
+    return e && e[0] == '1';
 }
 
 static WgradPlan plan_wgrad(int Cin, int Cout, int H, int W, int ks) {
