@@ -33,12 +33,7 @@ namespace {
 constexpr int kCK = 16;                 // channels per K-chunk = the MFMA's k extent
 constexpr int kPitchB = 48;             // LDS bytes per (pixel | weight row): 32 B of data + 16 B pad
 
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);        // NaN stays NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                                  // round to nearest even
-    return (uint16_t)(u >> 16);
-}
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return (uint16_t)(frcnn_pack_bf16x2(f, 0.0f) & 0xffffu); }   // nearest even
 
 // maximum of four packed bf16 pairs, lane-wise per 16-bit half (a maximum of bf16 values is a bf16 value: exact)
 __device__ __forceinline__ uint32_t bf16x2_max4(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
@@ -88,8 +83,8 @@ __device__ __forceinline__ void conv_bf16_epilogue(frcnn_f32x16 (&acc)[RW * COB]
                     if (relu) v[t] = fmaxf(v[t], 0.0f);
                 }
                 uint2 pk;
-                pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                pk.x = frcnn_pack_bf16x2(v[0], v[1]);
+                pk.y = frcnn_pack_bf16x2(v[2], v[3]);
                 *reinterpret_cast<uint2 *>(ot + ((wrow * RW + j) * 32 + l31) * OP + col * 2) = pk;
             }
         __syncthreads();

@@ -246,12 +246,7 @@ __device__ __forceinline__ void roi_scan_lane(const float *pc, int ws, int bw, i
     }
 }
 
-__device__ __forceinline__ uint32_t roi_f32_to_bf16(float f) {          // round to nearest even, the bf16 stack's conversion
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
+__device__ __forceinline__ uint32_t roi_f32_to_bf16(float f) { return frcnn_pack_bf16x2(f, 0.0f) & 0xffffu; }   // nearest even (v_cvt_pk_bf16_f32)
 
 // OUT16: y is raw bf16 (uint16) -- what the bf16 FC head consumes; pooling itself stays fp32 (a max of fp32 values, then ONE rounding:
 // the same bits as pooling to fp32 and converting afterwards, without the 30 MB fp32 round trip)
@@ -356,8 +351,8 @@ roi_pool_planes_kernel(const float *__restrict__ x, int C, int H, int W, const f
                 for (int i = lane; i < run / 4; i += 64) {
                     const float4 v = reinterpret_cast<const float4 *>(sv)[i];
                     uint2 pk;
-                    pk.x = roi_f32_to_bf16(v.x) | (roi_f32_to_bf16(v.y) << 16);
-                    pk.y = roi_f32_to_bf16(v.z) | (roi_f32_to_bf16(v.w) << 16);
+                    pk.x = frcnn_pack_bf16x2(v.x, v.y);
+                    pk.y = frcnn_pack_bf16x2(v.z, v.w);
                     reinterpret_cast<uint2 *>(y16 + dst)[i] = pk;
                 }
             } else {
@@ -605,8 +600,8 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
                     for (int i = lane; i < run / 4; i += 64) {
                         const float4 v4 = reinterpret_cast<const float4 *>(sv)[i];
                         uint2 pk;
-                        pk.x = roi_f32_to_bf16(v4.x) | (roi_f32_to_bf16(v4.y) << 16);
-                        pk.y = roi_f32_to_bf16(v4.z) | (roi_f32_to_bf16(v4.w) << 16);
+                        pk.x = frcnn_pack_bf16x2(v4.x, v4.y);
+                        pk.y = frcnn_pack_bf16x2(v4.z, v4.w);
                         reinterpret_cast<uint2 *>(y16 + dst)[i] = pk;
                     }
                 } else {

@@ -2,6 +2,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 static inline float frcnn_max_f32(float a, float b) { return (a != a) ? b : ((b != b) ? a : (a > b ? a : b)); }
+static inline uint32_t hipemu_f32_to_bf16_rne(float f) {
+    unsigned u; memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40;
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+static inline uint32_t frcnn_pack_bf16x2(float lo, float hi) { return (hipemu_f32_to_bf16_rne(lo) & 0xffffu) | (hipemu_f32_to_bf16_rne(hi) << 16); }
 static inline uint32_t frcnn_wave_or_u32(uint32_t v) {
     int x = (int)v;
     for (int d = 32; d > 0; d >>= 1) x |= __shfl_xor(x, d);
