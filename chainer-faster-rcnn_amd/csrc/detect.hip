@@ -26,6 +26,7 @@
 // `(double)iou >= thresh` (cpu_nms.pyx:18,66).
 #include "frcnn_common.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <frcnn_intrin.h>
 #include <frcnn_sync.h>     // angle brackets: shadowed by the test emulator
 
@@ -287,9 +288,13 @@ __device__ __forceinline__ float lane_bcast(float v, int src) { return __int_as_
 // v_max_f32 / v_min_f32 each instead of compare + select -- identical values (only the sign of a zero can differ, and xx2 - xx1 does
 // not see it).  The threshold test avoids the division: |inter - thr * uni| outside a 1e-4 relative band decides at once; inside it
 // (or for degenerate areas) the reference's own expression is evaluated.
-template <bool FASTMM>
+// DIAG: the tile lies on the diagonal (rows and columns are the same 64 boxes).  Only later boxes can be suppressed by row t, and the
+// lane additionally collects ITS COLUMN of the tile -- bit (t - t_begin) of `colpiece` = "row t (< lane) suppresses this lane's box" --
+// which is what lets the sequential pass resolve a chunk with wave-wide steps instead of one box at a time (nms_scan_col_body).
+template <bool FASTMM, bool DIAG>
 __device__ __forceinline__ unsigned long long nms_tile_words(const float4 rb, const float rarea_l, const float4 cb, const float carea,
-                                                             int t_begin, int t_rows, bool diag, bool col_ok, int lane, double thresh) {
+                                                             int t_begin, int t_rows, bool col_ok, int lane, double thresh,
+                                                             uint32_t &colpiece) {
     const float thr_f = (float)thresh;
     const bool lane_fast = (thresh > 1e-6) && (carea > 0.0f);
     unsigned long long word = 0ull;
@@ -316,7 +321,10 @@ __device__ __forceinline__ unsigned long long nms_tile_words(const float4 rb, co
             if (in_band) sup = (double)(inter / uni) >= thresh;                  // exact: IEEE divide, double compare (:65-66)
         }
         unsigned long long bal = __ballot(sup && col_ok);
-        if (diag) bal &= (t == 63) ? 0ull : (~0ull << (t + 1));                  // only later boxes can be suppressed by row t
+        if constexpr (DIAG) {
+            bal &= (t == 63) ? 0ull : (~0ull << (t + 1));                        // only later boxes can be suppressed by row t
+            if (sup && col_ok && lane > t) colpiece |= 1u << (t - t_begin);
+        }
         if (lane == t) word = bal;
     }
     return word;
@@ -335,6 +343,7 @@ struct ScanArgs {
     int32_t *n_out;
     int out_capacity;
     size_t slab, out_gs;
+    unsigned long long *colw;     // [pitch][64]: column words of the diagonal tiles (bit t of colw[c][l]: box c*64+t suppresses box c*64+l, t < l)
 };
 __device__ __forceinline__ void nms_scan_col_body(const ScanArgs &a, int c_begin, int c_end, int first_stage, int last_stage, int lane);
 
@@ -357,8 +366,10 @@ nms_mask_kernel(const float *__restrict__ sorted_boxes, const int *__restrict__ 
     // [cc_lo, cc_hi) of the STATIC pitch (it is sized before m is known): tile T' = T + tri(cc_lo), tri(k) = k (k + 1) / 2.
     // One workgroup = one tile, its four waves take 16 rows each: a tile is a chain of 64 dependent steps (~0.2 us each for a lone
     // wave), and the first stage of a staged NMS has fewer tiles than the chip has SIMDs -- its latency is the length of that chain
-    const long long tri_lo = (long long)cc_lo * (cc_lo + 1) / 2;
-    const long long Tp = (long long)blockIdx.x + tri_lo;
+    const long long tri_lo = (long long)cc_lo * (cc_lo + 1) / 2, tri_hi = (long long)cc_hi * (cc_hi + 1) / 2;
+    // a second-stage launch has a FIXED number of workgroups that stride over its tiles: when it has nothing to do, its cost is the
+    // dispatch of those workgroups (4.9 us for the 4275 one-tile workgroups of the 6000-box problem)
+    for (long long Tp = (long long)blockIdx.x + tri_lo; Tp < tri_hi; Tp += gridDim.x) {
     int cc = (int)((sqrt(8.0 * (double)Tp + 1.0) - 1.0) * 0.5);
     cc = min(max(cc, 0), pitch - 1);
     while (cc > 0 && (long long)cc * (cc + 1) / 2 > Tp) --cc;
@@ -375,9 +386,19 @@ nms_mask_kernel(const float *__restrict__ sorted_boxes, const int *__restrict__ 
         const int t_begin = wave * 16, t_rows = min(min(kChunk, m - rc * kChunk), t_begin + 16);
         const float probe = (cb.x + cb.y) + (cb.z + cb.w) + (rb.x + rb.y) + (rb.z + rb.w);       // NaN iff any coordinate of the tile is
         unsigned long long word;
-        if (__any(probe != probe)) word = nms_tile_words<false>(rb, rarea_l, cb, carea, t_begin, t_rows, cc == rc, c < m, lane, thresh);
-        else word = nms_tile_words<true>(rb, rarea_l, cb, carea, t_begin, t_rows, cc == rc, c < m, lane, thresh);
+        uint32_t colpiece = 0u;
+        const bool has_nan = __any(probe != probe);
+        if (cc == rc) {
+            if (has_nan) word = nms_tile_words<false, true>(rb, rarea_l, cb, carea, t_begin, t_rows, c < m, lane, thresh, colpiece);
+            else word = nms_tile_words<true, true>(rb, rarea_l, cb, carea, t_begin, t_rows, c < m, lane, thresh, colpiece);
+            // the four waves' 16-row pieces of a lane's column word are the four 16-bit quarters of one 64-bit word
+            reinterpret_cast<uint16_t *>(slab_ptr(scan.colw, slab))[((size_t)cc * kChunk + lane) * 4 + wave] = (uint16_t)colpiece;
+        } else {
+            if (has_nan) word = nms_tile_words<false, false>(rb, rarea_l, cb, carea, t_begin, t_rows, c < m, lane, thresh, colpiece);
+            else word = nms_tile_words<true, false>(rb, rarea_l, cb, carea, t_begin, t_rows, c < m, lane, thresh, colpiece);
+        }
         if (r < m && (lane >> 4) == wave) mask[(size_t)r * pitch + cc] = word;
+    }
     }
     if (!tail) return;
     // publish, count in, and let the last workgroup finish the sequential pass
@@ -632,6 +653,7 @@ __device__ __forceinline__ void nms_scan_col_body(const ScanArgs &a, int c_begin
     __shared__ int kept_list[kKeptLds];
     const int gz = blockIdx.z;
     counters_in = slab_ptr(counters_in, slab); mask = slab_ptr(mask, slab); order = slab_ptr(order, slab);
+    const unsigned long long *colw = slab_ptr((const unsigned long long *)a.colw, slab);
     sorted_boxes = slab_ptr(sorted_boxes, slab); sorted_scores = slab_ptr(sorted_scores, slab); keep_pos = slab_ptr(keep_pos, slab);
     if (out_index) out_index += gz * out_gs;
     if (out_boxes) out_boxes += gz * out_gs * 4;
@@ -686,29 +708,32 @@ __device__ __forceinline__ void nms_scan_col_body(const ScanArgs &a, int c_begin
     // then reads registers that an LDS load produced, so the compiler's s_waitcnt vmcnt(0) in front of it is gone and the gathers
     // issued just before it really are in flight while it runs (with a register hand-over the first v_readlane waited for them).
     __shared__ unsigned long long handover[2][64];
-    handover[0][lane] = load_word(c_begin, c_begin);
+    auto load_col = [&](int c) -> unsigned long long { return c < n_chunks ? colw[(size_t)c * kChunk + lane] : 0ull; };
+    handover[0][lane] = load_col(c_begin);
     handover[1][lane] = load_word(c_begin, c_begin + 1);
+    const unsigned long long below = (1ull << lane) - 1ull;
     for (int c = c_begin; c < c_stop && n_kept < limit; ++c) {
         __builtin_amdgcn_wave_barrier();
-        const unsigned long long diag = handover[0][lane], sup = handover[1][lane];
+        const unsigned long long suppressors = handover[0][lane] & below, sup = handover[1][lane];
         if (n_kept > kKeptLds) frcnn_drain_vmem();                  // rows past the LDS list are read back from keep_pos: written by this wave
         const unsigned long long part_next = gather(c + 1, n_kept); // in flight while the chunk is resolved
-        const unsigned long long diag_n = load_word(c + 1, c + 1), sup_n = load_word(c + 1, c + 2);
+        const unsigned long long col_n = load_col(c + 1), sup_n = load_word(c + 1, c + 2);
         const int in_chunk = min(kChunk, m - c * kChunk);
         const unsigned long long valid = in_chunk == 64 ? ~0ull : ((1ull << in_chunk) - 1ull);
-        unsigned long long alive = ~removed & valid;
-        const int dlo = (int)(uint32_t)diag, dhi = (int)(uint32_t)(diag >> 32);
-        unsigned long long kept = 0ull;
-        int budget = limit - n_kept;
-        while (alive != 0ull && budget > 0) {
-            const int i = __ffsll((long long)alive) - 1;
-            kept |= 1ull << i;
-            --budget;
-            const uint32_t slo = (uint32_t)__builtin_amdgcn_readlane(dlo, i);
-            const uint32_t shi = (uint32_t)__builtin_amdgcn_readlane(dhi, i);
-            alive &= ~(((unsigned long long)shi << 32) | slo);
-            alive &= ~(1ull << i);
+        // Resolve the diagonal block with wave-wide steps.  U = undecided boxes (wave-uniform), kept = decided survivors.  A box none of
+        // whose suppressors (earlier boxes of the chunk with IoU over the threshold: its column word) is still undecided is KEPT -- each
+        // of them has been removed, or this box would have been removed with them below; a box with a suppressor among the newly kept
+        // is REMOVED.  The lowest undecided box always qualifies, so the loop ends after (longest suppression chain) rounds -- a
+        // handful -- instead of one scalar round per kept box; the result is the greedy pass's own (unique) fixed point.
+        unsigned long long U = ~removed & valid, kept = 0ull;
+        while (U != 0ull) {
+            const unsigned long long nk = __ballot(((U >> lane) & 1ull) && (suppressors & U) == 0ull);
+            kept |= nk;
+            U &= ~nk;
+            U &= ~__ballot(((U >> lane) & 1ull) && (suppressors & nk) != 0ull);
         }
+        const int budget = limit - n_kept;
+        if (__popcll(kept) > budget) kept = __ballot(((kept >> lane) & 1ull) && __popcll(kept & below) < budget);   // the first `budget`
         const bool mine = (kept >> lane) & 1ull;
         if (mine) {
             const int idx = n_kept + __popcll(kept & ((1ull << lane) - 1ull));
@@ -717,7 +742,7 @@ __device__ __forceinline__ void nms_scan_col_body(const ScanArgs &a, int c_begin
         }
         n_kept += __popcll(kept);
         removed = wave_or_u64(part_next | (mine ? sup : 0ull));
-        handover[0][lane] = diag_n;
+        handover[0][lane] = col_n;
         handover[1][lane] = sup_n;
         __builtin_amdgcn_wave_barrier();                            // kept_list: written above, read by other lanes in the next gather
     }
@@ -746,7 +771,7 @@ nms_scan_col_kernel(ScanArgs a, int c_begin, int c_end, int first_stage, int las
 
 // ------------------------------------------------------------------------------------------------
 struct Layout {   // carve-up of the caller's workspace (per group)
-    size_t counters, keys, boxes, scores, order, sboxes, sscores, keep_pos, mask, total;
+    size_t counters, keys, boxes, scores, order, sboxes, sscores, keep_pos, mask, colw, total;
     int n_pad, n_tiles, m_max, pitch, ticket_index;
 };
 
@@ -768,6 +793,13 @@ static int nms_stage_chunks(int pitch, int max_out) {
     return (s + 8 <= pitch) ? s : 0;                                   // not worth two launches for the last few columns
 }
 
+// workgroups of a second-stage mask launch (FRCNN_NMS_TAIL_WGS overrides: A/B measurements)
+static int nms_tail_workgroups() {
+    const char *e = getenv("FRCNN_NMS_TAIL_WGS");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 4 * frcnn_cu_count();
+}
+
 static Layout make_layout(int n_total, int top_k, bool own_boxes) {
     Layout L;
     L.n_tiles = frcnn_cdiv(n_total > 0 ? n_total : 1, kSortTile);
@@ -786,6 +818,7 @@ static Layout make_layout(int n_total, int top_k, bool own_boxes) {
     L.sscores = o; o += frcnn_align256((size_t)L.m_max * 4);
     L.keep_pos = o; o += frcnn_align256((size_t)L.m_max * 4);
     L.mask = o; o += frcnn_align256((size_t)L.m_max * L.pitch * 8);
+    L.colw = o; o += frcnn_align256((size_t)L.pitch * kChunk * 8);
     L.total = o;
     return L;
 }
@@ -797,7 +830,7 @@ static void launch_mask_and_scan(hipStream_t stream, int groups, const Layout &L
                                  int out_capacity, size_t slab, size_t out_gs) {
     const dim3 blk(256);
     const ScanArgs sa{mask, L.pitch, counters, top_k, max_out, order, sboxes, sscores, keep_pos, out_index, out_boxes, out_scores, n_out,
-                      out_capacity, slab, out_gs};
+                      out_capacity, slab, out_gs, (unsigned long long *)((char *)mask + (L.colw - L.mask))};
     int *ticket = counters + L.ticket_index;
     if (scan_one_chunk_per_trip()) {                       // round-1 row-form scan (A/B measurements)
         hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_blocks(0, L.pitch), 1, groups), blk, 0, stream, sboxes, counters, top_k, thresh, mask,
@@ -819,8 +852,8 @@ static void launch_mask_and_scan(hipStream_t stream, int groups, const Layout &L
                        slab, 0, hi0, max_out, 0, sa, ticket);
     hipLaunchKernelGGL(nms_scan_col_kernel, dim3(1, 1, groups), dim3(64), 0, stream, sa, 0, hi0, 1, S > 0 ? 0 : 1, S > 0 ? ticket : (int *)nullptr);
     if (S > 0)            // second stage: the rest of the mask AND (by its last workgroup) the rest of the sequential pass, if still needed
-        hipLaunchKernelGGL(nms_mask_kernel, dim3(mask_blocks(S, L.pitch), 1, groups), blk, 0, stream, sboxes, counters, top_k, thresh, mask,
-                           L.pitch, slab, S, L.pitch, max_out, 1, sa, ticket);
+        hipLaunchKernelGGL(nms_mask_kernel, dim3(std::min(mask_blocks(S, L.pitch), nms_tail_workgroups()), 1, groups), blk, 0, stream, sboxes,
+                           counters, top_k, thresh, mask, L.pitch, slab, S, L.pitch, max_out, 1, sa, ticket);
 }
 
 }  // namespace

@@ -113,6 +113,35 @@ def check_nms_staged(rt, n=1200, seeds=(0, 1)):
                 assert (host(rt, keep)[nk:] == -1).all()
 
 
+def check_nms_staged_strided_tail(rt):
+    """The second-stage mask launch strides a fixed number of workgroups over its tiles: force far fewer workgroups than tiles."""
+    import os
+    os.environ["FRCNN_NMS_TAIL_WGS"] = "7"
+    try:
+        check_nms_staged(rt, n=1200, seeds=(2,))
+    finally:
+        del os.environ["FRCNN_NMS_TAIL_WGS"]
+
+
+def check_nms_chains(rt, n=200):
+    """Worst cases for the wave-parallel resolve of a 64-box chunk (nms_scan_col_body): suppression CHAINS.  Boxes slide along a line in
+    score order so that box i overlaps box i+1 .. i+k above the threshold and nothing beyond: greedy NMS keeps every (k+1)-th box and
+    the chunk needs one resolve round per kept box (k = 1: 32 rounds per chunk).  Also a pile of identical boxes (one survivor) and a
+    max_out cut that falls inside a chunk."""
+    for step, thr in ((10.0, 0.7), (4.0, 0.7), (30.0, 0.3), (1.0, 0.5)):
+        x1 = np.arange(n, dtype=np.float64) * step
+        d = np.stack([x1, np.zeros(n), x1 + 99.0, np.full(n, 49.0), 1.0 - np.arange(n) / float(n)], 1).astype(np.float32)
+        want = O.cpu_nms(d, thr)
+        for max_out in (0, 7, len(want) - 1):
+            w = want if max_out <= 0 else want[:max_out]
+            keep, nk = rt.nms(dev(rt, d), thr, max_out=max_out)
+            nk = int(host(rt, nk)[0])
+            assert nk == len(w) and host(rt, keep)[:nk].tolist() == w, (step, thr, max_out, nk, len(w))
+    d = np.tile(np.array([[10, 10, 60, 60, 0]], np.float32), (130, 1)); d[:, 4] = 1.0 - np.arange(130) / 130.0
+    keep, nk = rt.nms(dev(rt, d), 0.7)
+    assert int(host(rt, nk)[0]) == 1 and int(host(rt, keep)[0]) == 0
+
+
 def check_nms_batched(rt, groups=5, n=300):
     """forward.py:48-58: per-class cpu_nms(thresh=0.3) on (300,5) -- all classes in one call."""
     rs = np.random.RandomState(5)

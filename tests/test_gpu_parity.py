@@ -47,6 +47,14 @@ def test_nms_staged(rt):
     P.check_nms_staged(rt, n=5000, seeds=(0, 1))
 
 
+def test_nms_chains(rt):
+    P.check_nms_chains(rt, n=1500)
+
+
+def test_nms_staged_strided_tail(rt):
+    P.check_nms_staged_strided_tail(rt)
+
+
 def test_nms_batched(rt):
     P.check_nms_batched(rt, groups=20, n=300)
 

@@ -45,6 +45,14 @@ def test_nms_staged(rt):
     P.check_nms_staged(rt, n=1200, seeds=(0,))
 
 
+def test_nms_chains(rt):
+    P.check_nms_chains(rt, n=150)
+
+
+def test_nms_staged_strided_tail(rt):
+    P.check_nms_staged_strided_tail(rt)
+
+
 def test_nms_batched(rt):
     P.check_nms_batched(rt, groups=3, n=150)
 
