@@ -415,11 +415,11 @@ __device__ __forceinline__ float4 max4_3(float4 a, float4 b, float4 c) {
 // in flight per step), row addresses advance by one pitch and saturate at the bin's last row (a duplicate read cannot displace a
 // maximum), and the next step's cells are fetched before the current step's maxima are taken.
 template <int NC>
-__device__ __forceinline__ void cells_scan_chunk(const float4 *__restrict__ cells, int k0, int c_lo2, int c_hi2, int cq,
+__device__ __forceinline__ void cells_scan_chunk(const float4 *__restrict__ cells, int k0, int c_lo, int c_hi, int cq,
                                                  const int (&r0)[2], const int (&r1)[2], int mbh, float4 (&acc)[2]) {
     int ca[NC];                                     // float4 index of column k0 + q of the lane's bin, saturating at its last column
-#pragma unroll                                      // (c_lo2 / c_hi2 = 2 x the column: a cell is two float4)
-    for (int q = 0; q < NC; ++q) ca[q] = min(c_lo2 + 2 * (k0 + q), c_hi2) + cq;
+#pragma unroll
+    for (int q = 0; q < NC; ++q) ca[q] = min(c_lo + k0 + q, c_hi) * 2 + cq;
     int row[2] = {r0[0], r0[1]};                    // float4 index of the current map row of each bin
     float4 buf[2][NC];                              // one register buffer per bin: bin 1's cells are in flight while bin 0's maxima are
                                                     // taken and vice versa (two buffers per bin did not fit the 128-register budget of
@@ -458,77 +458,22 @@ __device__ __forceinline__ void cells_scan_chunk(const float4 *__restrict__ cell
 template <int kRows, bool OUT16>
 __global__ void __launch_bounds__(kRows <= 38 ? 1024 : 512)
 roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const float *__restrict__ rois, int roi_cols, int R,
-                      int outh, int outw, float scale, float *__restrict__ y, int rsplit, const RoiBinTables tables, int dbg) {
+                      int outh, int outw, float scale, float *__restrict__ y, int rsplit, const RoiBinTables tables) {
     constexpr int kCellWaves = kRows <= 38 ? 16 : 8;
     constexpr bool STAGED = kRows <= 38;
     __shared__ __attribute__((aligned(16))) float4 cells[kRows * kCellPitch * 2];
     __shared__ __attribute__((aligned(16))) RoiBinTables tb;
     __shared__ __attribute__((aligned(16))) float stage[STAGED ? kCellWaves : 1][STAGED ? 8 * kMaxBins : 4];
-    // Per-RoI geometry is computed ONCE per workgroup (by 8 threads per RoI, while the map loads are in flight) instead of by every
-    // wave that picks the RoI up: the pass itself starts from three LDS reads.  geo_w[slot][pw] = 2 c_lo | 2 c_hi << 8 | empty << 16
-    // (first / last column of the bin as float4 indices), geo_h[slot][ph] = r0 | empty << 15 | r1 << 16 (first / last row as float4
-    // indices), geo_m = widest | tallest << 8 bin of the RoI; entries past outw / outh repeat the last bin (the idle lanes shadow it:
-    // same addresses -> LDS broadcast).  The waves draw slots with an atomic counter, one draw AHEAD: the next
-    // slot's number and geometry are fetched while the current RoI is scanned, so a pass does not start with a chain of dependent
-    // LDS round trips (longest-first ordering of the slots measured 0.3 us slower than arrival order and was dropped).
-    constexpr int kGeoSlots = kRows <= 38 ? 128 : 32;        // 8 threads per slot: one pass of the workgroup (the 76-row image leaves 5 KB)
-    __shared__ uint32_t geo_w[kGeoSlots][8];
-    __shared__ uint32_t geo_h[kGeoSlots][8];
-    __shared__ uint16_t geo_m[kGeoSlots];
     __shared__ int next_roi;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int HW = H * W, bins = outh * outw;
     const int c0 = blockIdx.x * 8;
     const int g0 = blockIdx.y;
-    const int n_slots = g0 < R ? (R - g0 + rsplit - 1) / rsplit : 0;        // this workgroup's RoIs: g0 + slot * rsplit
-    constexpr int kThreads = 64 * kCellWaves;
-    static_assert(kGeoSlots * 8 <= kThreads, "one thread per (slot, bin index)");
-    const int my_sl = tid >> 3, my_p = tid & 7;
 
-    auto load_roi = [&](int base) -> float4 {                             // x1, y1, x2, y2 of this thread's slot
-        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (my_sl < kGeoSlots && base + my_sl < n_slots) {
-            const float *pr = rois + (size_t)roi_cols * (g0 + (base + my_sl) * rsplit) + (roi_cols - 4);
-            q = make_float4(pr[0], pr[1], pr[2], pr[3]);
-        }
-        return q;
-    };
-    auto build_geometry = [&](int base, const float4 q) {
-        const int nb = min(n_slots - base, kGeoSlots);
-        if (my_sl < nb) {
-            const int sl = my_sl, p = my_p;
-            // Python round() on the float32 product = round-half-to-even (roi_geometry)
-            const int xs = (int)rintf(q.x * scale), ys = (int)rintf(q.y * scale);
-            const int rw = max((int)rintf(q.z * scale) - xs + 1, 1), rh = max((int)rintf(q.w * scale) - ys + 1, 1);
-            const int pw = min(p, outw - 1), ph = min(p, outh - 1);
-            int ws, we, hs, he, mbw, mbh;
-            if (rw < kTabExt && rh < kTabExt) {
-                const int tw = tb.tab[1][rw][pw], th = tb.tab[0][rh][ph];
-                ws = min(max((tw & 255) + xs, 0), W); we = min(max((tw >> 8) + xs, 0), W);
-                hs = min(max((th & 255) + ys, 0), H); he = min(max((th >> 8) + ys, 0), H);
-                mbw = tb.tabmax[1][rw]; mbh = tb.tabmax[0][rh];
-            } else {                                                        // huge RoI: the arithmetic itself, trip counts = the map
-                bin_range(pw, rw, outw, xs, W, ws, we);
-                bin_range(ph, rh, outh, ys, H, hs, he);
-                mbw = W; mbh = H;
-            }
-            mbw = min(mbw, W); mbh = min(mbh, H);
-            // clamped into the map so that an empty bin still reads valid cells
-            const int c_lo = min(ws, W - 1), c_hi = min(max(we - 1, c_lo), W - 1);
-            const int h0 = min(max(hs, 0), H - 1), h1 = min(max(he - 1, h0), H - 1);
-            geo_w[sl][p] = (uint32_t)(c_lo * 2) | ((uint32_t)(c_hi * 2) << 8) | ((we <= ws) ? 1u << 16 : 0u);
-            geo_h[sl][p] = (uint32_t)(h0 * (kCellPitch * 2)) | ((he <= hs) ? 1u << 15 : 0u) | ((uint32_t)(h1 * (kCellPitch * 2)) << 16);
-            if (p == 0) geo_m[sl] = (uint16_t)(mbw | (mbh << 8));
-        }
-        if (tid == 0) next_roi = 0;
-        __syncthreads();
-    };
-
-    // ---- the first batch's RoIs, then 8 channel planes -> cells: one map row per wave and step (coalesced NCHW rows) through a
-    //      buffer descriptor -- rows past H, columns past W and channels past C are out-of-range offsets that load 0: no branches;
-    //      all loads are issued before the table copy and the geometry pass below and land during them
-    const float4 roi_first = load_roi(0);
+    // ---- 8 channel planes -> cells: one map row per wave and step (coalesced NCHW rows) through a buffer descriptor -- rows past
+    //      H, columns past W and channels past C are out-of-range offsets that load 0: no branches; all loads are issued before the
+    //      table copy below and land during it
     constexpr int kRowsPerWave = (kRows + kCellWaves - 1) / kCellWaves;
     const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)C * HW * sizeof(float)));
     float v[kRowsPerWave][8];
@@ -539,13 +484,12 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[i][c] = frcnn_buf_load_f32(xbuf, base + (uint32_t)(c * HW * 4));   // c0 + c >= C: past the end -> 0
     }
+    if (tid == 0) next_roi = 0;
     {
         const uint32_t *src = reinterpret_cast<const uint32_t *>(&tables);
         uint32_t *dst = reinterpret_cast<uint32_t *>(&tb);
-        for (int e = tid; e < (int)(sizeof(RoiBinTables) / 4); e += kThreads) dst[e] = src[e];
+        for (int e = tid; e < (int)(sizeof(RoiBinTables) / 4); e += 64 * kCellWaves) dst[e] = src[e];
     }
-    __syncthreads();
-    build_geometry(0, roi_first);
 #pragma unroll
     for (int i = 0; i < kRowsPerWave; ++i) {
         const int h = wave + i * kCellWaves;
@@ -563,69 +507,69 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
     const int j = in_a ? (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12)) : (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16));
     const int pg = (lane >> 5) * 2 + (in_a ? 0 : 1);
     const int cq = j & 1;
-    const int pw = j >> 1;                          // 0 .. 7; bins past outw - 1 (and rows past outh - 1) shadow the last one
-    const bool pw_on = pw < outw;
+    const bool pw_on = (j >> 1) < outw;
+    const int pw = min(j >> 1, outw - 1);           // an idle lane shadows the last column bin: same addresses -> LDS broadcast, no conflict
 
-    if (dbg & 2) return;                                                 // ablation: prologue only
-    for (int base = 0; base < n_slots; base += kGeoSlots) {
-    if (base > 0) { __syncthreads(); build_geometry(base, load_roi(base)); }
-    const int nb = min(n_slots - base, kGeoSlots);
-    auto grab = [&]() -> int {
-        int d = 0;
-        if (lane == 0) d = atomicAdd(&next_roi, 1);
-        return __builtin_amdgcn_readfirstlane(d);
-    };
-    int draw = grab();
-    uint32_t gw_n = 0u, gm_n = 0u;
-    uint2 gh_n = make_uint2(0u, 0u);
-    auto fetch_geo = [&](int d) {
-        if (d < nb) {
-            gw_n = geo_w[d][pw];
-            gh_n = *reinterpret_cast<const uint2 *>(&geo_h[d][2 * pg]);
-            gm_n = geo_m[d];
-        }
-    };
-    fetch_geo(draw);
     for (;;) {
-        if (draw >= nb) break;
-        const int sl = draw;
-        const int r = g0 + (base + sl) * rsplit;
-        const uint32_t gw = gw_n;
-        const uint2 gh = gh_n;
-        const int gm = __builtin_amdgcn_readfirstlane((int)gm_n);
-        draw = grab();                                                   // one draw ahead
-        fetch_geo(draw);
-        const int mbw = (dbg & 4) ? 0 : (gm & 255), mbh = gm >> 8;           // (ablation 4: no scan)
-        const int c_lo2 = (int)(gw & 255u), c_hi2 = (int)((gw >> 8) & 255u);
-        const int c_first = c_lo2 + cq;
+        int slot = 0;
+        if (lane == 0) slot = atomicAdd(&next_roi, 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        const int r = g0 + slot * rsplit;
+        if (r >= R) break;
+        const RoiGeom g = roi_geometry(rois + (size_t)roi_cols * r + (roi_cols - 5), scale);
+        int ws, we, hs[2], he[2], mbw, mbh;
+        if (g.rw < kTabExt && g.rh < kTabExt) {                         // wave-uniform
+            const int tw = tb.tab[1][g.rw][pw];
+            ws = min(max((tw & 255) + g.xs, 0), W);
+            we = min(max((tw >> 8) + g.xs, 0), W);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int th = tb.tab[0][g.rh][min(2 * pg + s, 7)];
+                hs[s] = min(max((th & 255) + g.ys, 0), H);
+                he[s] = min(max((th >> 8) + g.ys, 0), H);
+            }
+            mbw = tb.tabmax[1][g.rw];
+            mbh = tb.tabmax[0][g.rh];
+        } else {                                                        // huge RoI: the arithmetic itself, trip counts = the map
+            bin_range(min(pw, outw - 1), g.rw, outw, g.xs, W, ws, we);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) bin_range(min(2 * pg + s, outh - 1), g.rh, outh, g.ys, H, hs[s], he[s]);
+            mbw = W;
+            mbh = H;
+        }
+        mbw = min(__builtin_amdgcn_readfirstlane(mbw), W);
+        mbh = min(__builtin_amdgcn_readfirstlane(mbh), H);
+        // per bin: first / last map row as float4 indices (clamped into the map so an empty bin still reads valid cells); the bin's
+        // first cell seeds the maximum (the oracle's scan order)
         int r0[2], r1[2];
-        r0[0] = (int)(gh.x & 0x7fffu); r1[0] = (int)(gh.x >> 16);
-        r0[1] = (int)(gh.y & 0x7fffu); r1[1] = (int)(gh.y >> 16);
-        const bool empty_w = (gw >> 16) & 1u;
-        const bool empty_h[2] = {(bool)((gh.x >> 15) & 1u), (bool)((gh.y >> 15) & 1u)};
-        const bool any_empty = empty_w || empty_h[0] || empty_h[1];
-        // the bin's first cell seeds the maximum (the oracle's scan order)
         float4 acc[2];
         float nan_probe = 0.0f;
+        const int c_lo = min(ws, W - 1), c_hi = min(max(we - 1, c_lo), W - 1);      // first / last column of the bin, inside the map
+        const int c_first = c_lo * 2 + cq;
+        bool any_empty = we <= ws;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
+            const int h0 = min(max(hs[s], 0), H - 1);
+            r0[s] = h0 * (kCellPitch * 2);
+            r1[s] = min(max(he[s] - 1, h0), H - 1) * (kCellPitch * 2);
             acc[s] = cells[r0[s] + c_first];
             nan_probe += (acc[s].x + acc[s].y) + (acc[s].z + acc[s].w);     // NaN iff one of the eight first cells is
+            any_empty = any_empty || (he[s] <= hs[s]);
         }
 #pragma unroll 1
         for (int k0 = 0; k0 < mbw; k0 += 4) {
             const int nc = min(mbw - k0, 4);                            // wave-uniform
-            if (nc >= 4) cells_scan_chunk<4>(cells, k0, c_lo2, c_hi2, cq, r0, r1, mbh, acc);
-            else if (nc == 3) cells_scan_chunk<3>(cells, k0, c_lo2, c_hi2, cq, r0, r1, mbh, acc);
-            else if (nc == 2) cells_scan_chunk<2>(cells, k0, c_lo2, c_hi2, cq, r0, r1, mbh, acc);
-            else cells_scan_chunk<1>(cells, k0, c_lo2, c_hi2, cq, r0, r1, mbh, acc);
+            if (nc >= 4) cells_scan_chunk<4>(cells, k0, c_lo, c_hi, cq, r0, r1, mbh, acc);
+            else if (nc == 3) cells_scan_chunk<3>(cells, k0, c_lo, c_hi, cq, r0, r1, mbh, acc);
+            else if (nc == 2) cells_scan_chunk<2>(cells, k0, c_lo, c_hi, cq, r0, r1, mbh, acc);
+            else cells_scan_chunk<1>(cells, k0, c_lo, c_hi, cq, r0, r1, mbh, acc);
         }
         // rare fix-ups behind ONE wave-level test: a NaN first cell stays (`>` never replaces it: the sum of the eight first cells
         // is NaN iff one of them is; they are re-read then), an empty bin is 0
         if (__any((nan_probe != nan_probe) || any_empty)) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const bool empty = empty_h[s] || empty_w;
+                const bool empty = (he[s] <= hs[s]) || (we <= ws);
                 const float4 first = cells[r0[s] + c_first];
                 if (first.x != first.x) acc[s].x = first.x;
                 if (first.y != first.y) acc[s].y = first.y;
@@ -633,10 +577,6 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
                 if (first.w != first.w) acc[s].w = first.w;
                 if (empty) acc[s] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-        }
-        if (dbg & 8) {                                                   // ablation: no output (keep the maxima alive)
-            if (acc[0].x + acc[1].y + acc[0].z + acc[1].w == 12345.678f) y[0] = acc[0].x;
-            continue;
         }
         if constexpr (STAGED) {
             float *sv = stage[wave];
@@ -692,7 +632,6 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
         }
         }
     }
-    }
 }
 
 // dx[c, argmax] += dy for every (roi, c, bin) with argmax >= 0 (Chainer backward_cpu).  fp32 atomics:
@@ -728,8 +667,6 @@ static bool roi_cells_launch(const float *x, int C, int H, int W, const float *r
     const int max_split = frcnn_cdiv(R, waves);                              // at least one RoI per wave
     if (rsplit > max_split) rsplit = max_split;
     if (rsplit < 1) rsplit = 1;
-    const char *fix = getenv("FRCNN_ROI_RSPLIT");                             // test hook: RoI groups per channel group
-    if (fix && atoi(fix) > 0) rsplit = atoi(fix);
     RoiBinTables tables;
     memset(&tables, 0, sizeof(tables));
     for (int t = 0; t < 2; ++t) {
@@ -745,11 +682,9 @@ static bool roi_cells_launch(const float *x, int C, int H, int W, const float *r
             tables.tabmax[t][ext] = (uint8_t)m;
         }
     }
-    const char *dbg_s = getenv("FRCNN_ROI_DBG");
-    const int dbg = dbg_s ? atoi(dbg_s) : 0;
     const dim3 grid(cgroups, rsplit), blk(64 * waves);
-    if (H <= 38) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<38, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, tables, dbg);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<76, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, tables, dbg);
+    if (H <= 38) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<38, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, tables);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<76, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, tables);
     return true;
 }
 

@@ -245,6 +245,22 @@ def check_roi_pool_cells(rt):
             assert np.array_equal(y5.view(np.uint16), want_bits.view(np.uint16).reshape(y5.shape))
 
 
+def check_roi_pool_cells_batches(rt):
+    """More RoIs per workgroup than one geometry batch holds (128 slots for the 38-row image, 32 for the 76-row one): force ONE RoI
+    group per channel group so a workgroup walks all the RoIs in several batches."""
+    import os
+    os.environ["FRCNN_ROI_RSPLIT"] = "1"
+    try:
+        for (R, C, H, W, seed) in [(300, 8, 12, 17, 7), (70, 8, 50, 40, 8)]:
+            rs = np.random.RandomState(seed)
+            x, rois = roi_case(rs, R, C, H, W)
+            want = O.roi_pooling_2d(x, rois, 7, 7, 0.0625)
+            got = host(rt, rt.roi_pool_fwd(dev(rt, x[0]), dev(rt, rois), 7, 7, 0.0625))
+            assert np.array_equal(got, want), (R, C, H, W)
+    finally:
+        del os.environ["FRCNN_ROI_RSPLIT"]
+
+
 # ------------------------------------------------------------------------------------------- conv stack
 def check_conv3x3(rt, Cin, Cout, H, W, cfg=-1, seed=0, relu=True):
     rs = np.random.RandomState(seed)

@@ -81,6 +81,10 @@ def test_roi_pool_cells_kernel(rt):
     P.check_roi_pool_cells(rt)
 
 
+def test_roi_pool_cells_batches(rt):
+    P.check_roi_pool_cells_batches(rt)
+
+
 def test_roi_pool_kernels_agree_at_full_size(rt, monkeypatch):
     """The cell-major kernel (default) and the plane kernel (FRCNN_ROI_KERNEL=planes) give the same 300 x 512 x 7 x 7 bits."""
     rs = np.random.RandomState(3)

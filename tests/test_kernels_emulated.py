@@ -65,6 +65,10 @@ def test_roi_pool_cells_kernel(rt):
     P.check_roi_pool_cells(rt)
 
 
+def test_roi_pool_cells_batches(rt):
+    P.check_roi_pool_cells_batches(rt)
+
+
 def test_roi_pool(rt):
     P.check_roi_pool(rt, R=9, C=128, H=12, W=17)
     P.check_roi_pool(rt, R=5, C=64, H=38, W=63, seed=1)     # VEC=1 path (C % 128 != 0)
