@@ -1,0 +1,383 @@
+// conv_f32s.hip -- fp32 3x3 convolution on the bf16 matrix cores: every fp32 operand is carried as THREE bf16 terms
+// (x = h + m + l exactly: 8 + 8 + 8 mantissa bits) and a product block is six v_mfma_f32_32x32x16_bf16
+//     h.h + h.m + m.h + h.l + l.h + m.m            (the dropped terms m.l, l.m, l.l are below 2^-24 of the product)
+// accumulated in fp32 -- the same 2^-24-per-product accuracy class as v_mfma_f32_32x32x2_f32 (measured against a float64
+// convolution the two differ from it by the same few 1e-7, tests/test_gpu_parity.py), at 16 / 6 = 2.7x the matrix-core rate
+// of the native fp32 instruction.  Same reference interface as conv.hip (L.Convolution2D(ci, co, 3, 1, 1) + F.relu
+// [+ F.max_pooling_2d(2, 2)], /root/reference/models/vgg16.py:39-82; rpn_conv_3x3, region_proposal_network.py:53).
+//
+// Layout ("split tensors").  Activations [3 parts][C/16][H][W][16] bf16 -- each part is exactly the channel-blocked tensor
+// of conv_bf16.hip -- and weights [3 parts][C/16][tap][CoutP][16] bf16: 6 bytes per fp32 value.  A layer's epilogue splits its
+// fp32 result (after bias / ReLU / the fused 2x2 max-pool, all in fp32) into the three parts, so the chain never round-trips
+// through fp32 tensors; h + m + l reproduces the fp32 value bit for bit (frcnn_f32s_to_nchw_f32).
+//
+// Kernel = the LDS-DMA structure of conv_dma_bf16_kernel (tile 64 couts x 4 rows x 32 px, 4 waves = 2 cout blocks x 2 row
+// pairs, buffer_load_dwordx4 ... lds, XOR-swizzled 32-byte rows) with a 74 KB stage per 16-channel K-chunk: the three parts of the
+// 6 x 34 halo (3 x 208 rows) and of the 9 x 64 weight panel (3 x 576 rows).  Per chunk a wave reads 81 fragments (ds_read_b128)
+// for 108 MFMAs -- 0.75 LDS reads and 0.7 KB of DMA per MFMA against 1.17 and 1.4 KB in the plain bf16 kernel, which is what
+// lets the matrix pipe run instead of waiting on staging.  Two workgroups per CU (single-stage rings: one computes while the
+// other's chunk lands).
+#include "frcnn_common.h"
+#include <stdlib.h>
+#include <string.h>
+#include <frcnn_buffer.h>   // angle brackets: shadowed by the test emulator
+#include <frcnn_intrin.h>
+#include <frcnn_sync.h>
+
+namespace {
+
+constexpr int kCK = 16;                 // channels per K-chunk = the MFMA's k extent
+constexpr int kParts = 3;
+
+__device__ __forceinline__ float bf16_hi_as_f32(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+__device__ __forceinline__ float bf16_lo_as_f32(uint32_t packed) { return __uint_as_float(packed << 16); }
+
+// (v0, v1) -> the three packed bf16 pairs (h, m, l) with h + m + l == v exactly (round to nearest even at every step; the
+// differences are exact in fp32)
+__device__ __forceinline__ void split3_pair(float v0, float v1, uint32_t &h, uint32_t &m, uint32_t &l) {
+    h = frcnn_pack_bf16x2(v0, v1);
+    const float d0 = v0 - bf16_lo_as_f32(h), d1 = v1 - bf16_hi_as_f32(h);
+    m = frcnn_pack_bf16x2(d0, d1);
+    l = frcnn_pack_bf16x2(d0 - bf16_lo_as_f32(m), d1 - bf16_hi_as_f32(m));
+}
+
+// ABL = timing ablations (WRONG results; scripts/conv_f32s_bench.py only): 1 no DMA, 4 no fragment reads / MFMAs
+template <int WPS, int ABL = 0, int NS = 1>
+__global__ void __launch_bounds__(256, WPS)
+conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
+                 int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles, int stag_bit, int stag_sleep) {
+    constexpr int KS = 3, TAPS = 9, PAD = 1;
+    constexpr int RW = 2, BROWS = 4, BCO = 64;
+    constexpr int HR = BROWS + KS - 1, HPX = 32 + KS - 1;
+    constexpr int IN_ROWS = HR * HPX;                         // 204 halo pixels per part, 32 B each
+    constexpr int IN_ROWS_P = 208;                            // padded to a multiple of 16 rows: the swizzle phase is the same in every part
+    constexpr int W_ROWS = TAPS * BCO;                        // 576 weight rows per part
+    constexpr int IN_PIECES = (kParts * IN_ROWS_P * 2 + 63) / 64;   // 1 KB pieces (64 lanes x 16 B): 20
+    constexpr int W_PIECES = kParts * W_ROWS * 2 / 64;        // 54
+    constexpr int PIECES = IN_PIECES + W_PIECES;              // 74
+    constexpr int IN_BYTES = IN_PIECES * 1024, STAGE_BYTES = PIECES * 1024;
+    constexpr int PPW = (PIECES + 3) / 4;                     // pieces per wave (wave w moves pieces w, w+4, ...)
+    static_assert(IN_PIECES % 4 == 0, "a group of four pieces comes from one tensor");
+    constexpr int OP = BCO * 2 + 16;                          // epilogue tile: LDS bytes per pixel and part (128 B + pad)
+    static_assert(kParts * BROWS * 32 * OP <= STAGE_BYTES, "epilogue tiles must fit in the stage");
+    __shared__ __attribute__((aligned(1024))) unsigned char ring[NS * STAGE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wco = wave & 1, wrow = wave >> 1;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int tile = blockIdx.x;
+    const int tx = tile % xtiles, ty = (tile / xtiles) % ytiles, cot = tile / (xtiles * ytiles);
+    const int x0 = tx * 32, y0 = ty * BROWS, co0 = cot * BCO;
+    const int nchunks = CinP / kCK;
+    const uint32_t x_part_bytes = (uint32_t)((size_t)H * W * CinP * 2), w_part_bytes = (uint32_t)((size_t)TAPS * CoutP * CinP * 2);
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, kParts * x_part_bytes);
+    const frcnn_buf_t wbuf = frcnn_make_buf(wp, kParts * w_part_bytes);
+    const uint32_t x_chunk_bytes = (uint32_t)(H * W) * 32u, w_chunk_bytes = (uint32_t)(TAPS * CoutP) * 32u;
+
+    // source offset (chunk 0) of the 16 bytes this lane contributes to each of its wave's pieces: slot s of a region holds
+    // (row R = s >> 1, half (s & 1) ^ ((R >> 3) & 1)); input rows R = part * 208 + halo pixel, weight rows R = part * 576 + tap * 64 + cout
+    uint32_t poff[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int pid = wave + 4 * q;
+        if (pid < IN_PIECES) {
+            const int sl = pid * 64 + lane, R = sl >> 1, half = (sl & 1) ^ ((R >> 3) & 1);
+            const int part = R / IN_ROWS_P, P = R - part * IN_ROWS_P;
+            const int hr = P / HPX, hx = P - hr * HPX;
+            const int gy = y0 - PAD + hr, gx = x0 - PAD + hx;
+            const bool inside = part < kParts && P < IN_ROWS && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            poff[q] = inside ? (uint32_t)part * x_part_bytes + (uint32_t)((gy * W + gx) * 32 + half * 16) : kBufOob;
+        } else {
+            const int sl = (pid - IN_PIECES) * 64 + lane, R = sl >> 1, half = (sl & 1) ^ ((R >> 3) & 1);
+            const int part = R / W_ROWS, r = R - part * W_ROWS;
+            const int tap = r / BCO, col = r - tap * BCO;
+            poff[q] = (pid < PIECES && co0 + col < CoutP) ? (uint32_t)part * w_part_bytes + (uint32_t)((tap * CoutP + co0 + col) * 32 + half * 16) : kBufOob;
+        }
+    }
+    auto issue = [&](int chunk, int stage) {
+        if constexpr ((ABL & 1) != 0) return;
+        unsigned char *dst = ring + stage * STAGE_BYTES + wave * 1024;
+        const uint32_t xs = (uint32_t)chunk * x_chunk_bytes, ws = (uint32_t)chunk * w_chunk_bytes;
+#pragma unroll
+        for (int q = 0; q < PPW; ++q) {
+            if (4 * q + 3 < IN_PIECES) frcnn_buf_load_lds_b128(xbuf, dst + q * 4096, poff[q], xs);
+            else if (4 * q + 3 < PIECES || wave + 4 * q < PIECES) frcnn_buf_load_lds_b128(wbuf, dst + q * 4096, poff[q], ws);
+        }
+    };
+
+    // fragment byte offsets inside the stage (swizzled).  A = weight row part*576 + tap*64 + wco*32 + l31 (the part / tap offsets are
+    // multiples of 16 rows: compile-time immediates), B = halo row part*208 + (2 wrow + r)*34 + l31 + kx
+    const uint32_t a_off = (uint32_t)(IN_BYTES + (wco * 32 + l31) * 32 + ((khalf ^ ((l31 >> 3) & 1)) << 4));
+    uint32_t b_off[RW + KS - 1][KS];
+#pragma unroll
+    for (int r = 0; r < RW + KS - 1; ++r)
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            const int P = (wrow * RW + r) * HPX + l31 + kx;
+            b_off[r][kx] = (uint32_t)(P * 32 + ((khalf ^ ((P >> 3) & 1)) << 4));
+        }
+
+    // two accumulator sets per output row: the large terms (h.h, h.m, m.h) and the small ones (h.l, l.h, m.m) -- four independent
+    // MFMA chains per wave, and the 2^-16-sized terms are summed among themselves before they meet the large sum
+    frcnn_f32x16 acc[RW], acs[RW];
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = acs[j][r] = 0.0f;
+
+    auto compute = [&](int stage) {
+        if constexpr ((ABL & 4) != 0) return;
+        const unsigned char *st = ring + stage * STAGE_BYTES;
+#pragma unroll
+        for (int ky = 0; ky < KS; ++ky) {
+            uint4 a[kParts][KS], b[kParts][RW][KS];
+#pragma unroll
+            for (int p = 0; p < kParts; ++p)
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) {
+                    a[p][kx] = *reinterpret_cast<const uint4 *>(st + a_off + (p * W_ROWS + (ky * KS + kx) * BCO) * 32);
+#pragma unroll
+                    for (int j = 0; j < RW; ++j) b[p][j][kx] = *reinterpret_cast<const uint4 *>(st + b_off[ky + j][kx] + p * IN_ROWS_P * 32);
+                }
+#pragma unroll
+            for (int kx = 0; kx < KS; ++kx) {
+#pragma unroll
+                for (int j = 0; j < RW; ++j) acs[j] = frcnn_mfma_32x32x16_bf16(a[2][kx], b[0][j][kx], acs[j]);     // l.h
+#pragma unroll
+                for (int j = 0; j < RW; ++j) acc[j] = frcnn_mfma_32x32x16_bf16(a[1][kx], b[0][j][kx], acc[j]);     // m.h
+#pragma unroll
+                for (int j = 0; j < RW; ++j) acs[j] = frcnn_mfma_32x32x16_bf16(a[0][kx], b[2][j][kx], acs[j]);     // h.l
+#pragma unroll
+                for (int j = 0; j < RW; ++j) acc[j] = frcnn_mfma_32x32x16_bf16(a[0][kx], b[1][j][kx], acc[j]);     // h.m
+#pragma unroll
+                for (int j = 0; j < RW; ++j) acs[j] = frcnn_mfma_32x32x16_bf16(a[1][kx], b[1][j][kx], acs[j]);     // m.m
+#pragma unroll
+                for (int j = 0; j < RW; ++j) acc[j] = frcnn_mfma_32x32x16_bf16(a[0][kx], b[0][j][kx], acc[j]);     // h.h
+            }
+        }
+    };
+
+    // single-stage ring: the co-resident workgroup's MFMAs cover this one's wait for its chunk -- IF the two are out of phase.
+    // Workgroups that start together and do equal work stay in lockstep (both wait for DMA, then both compute: no overlap at all),
+    // and their successors inherit it; so half of the first resident set starts late by about one chunk's compute time.
+    if (stag_sleep > 0 && (int)blockIdx.x < 4096 && (((int)blockIdx.x >> stag_bit) & 1)) frcnn_sleep_64clk(stag_sleep);
+    if constexpr (NS == 1) {
+    for (int c = 0; c < nchunks; ++c) {
+        issue(c, 0);
+        frcnn_wait_vmcnt<0>();
+        frcnn_barrier_nofence();
+        compute(0);
+        if (c + 1 < nchunks) frcnn_barrier_nofence();           // everybody is done reading before the stage is refilled
+    }
+    } else {
+        // two stages, ONE workgroup per CU: chunk c+1 lands while chunk c feeds the MFMAs
+        issue(0, 0);
+        frcnn_wait_vmcnt<0>();
+        frcnn_barrier_nofence();
+        for (int c = 0; c < nchunks; ++c) {
+            if (c + 1 < nchunks) issue(c + 1, (c + 1) & 1);
+            compute(c & 1);
+            if (c + 1 < nchunks) {
+                frcnn_wait_vmcnt<0>();                            // chunk c+1 has landed for this wave ...
+                frcnn_barrier_nofence();                          // ... and for everybody, and everybody is done reading stage c & 1
+            }
+        }
+    }
+    __syncthreads();                                            // the stage becomes the epilogue's output tiles
+
+    // ---- epilogue: register r of lane l = cout (r&3) + 8*(r>>2) + 4*khalf of pixel l31, rows y0 + 2 wrow + j
+    float v[RW][16];
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            float t = (acc[j][r] + acs[j][r]) + (co < Cout ? bias[co] : 0.0f);
+            if (relu) t = fmaxf(t, 0.0f);
+            v[j][r] = t;
+        }
+    const int px = x0 + l31;
+    if (out_mode == 1) {                                        // fp32 NCHW (the last layer of a chain)
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const int py = y0 + wrow * RW + j;
+            if (px >= W || py >= H) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (co < Cout) reinterpret_cast<float *>(y)[(size_t)co * H * W + (size_t)py * W + px] = v[j][r];
+            }
+        }
+        return;
+    }
+    uint16_t *y16 = reinterpret_cast<uint16_t *>(y);
+    if (out_mode == 2) {
+        // F.max_pooling_2d(2, 2) (cover_all) fused, in fp32 BEFORE the split: the wave's two rows are one window row pair (tiles
+        // start at even rows), the horizontal neighbour is the next lane; windows cut by the map's edge use what is inside
+        const int py = y0 + wrow * RW;
+        const bool has_row1 = py + 1 < H, has_col1 = px + 1 < W;
+        const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+        const size_t y_part = (size_t)CoutP * OH * OW;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float pv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float top = v[0][4 * g + t], col = has_row1 ? fmaxf(top, v[1][4 * g + t]) : top;
+                const float nb = __shfl_xor(col, 1);
+                pv[t] = has_col1 ? fmaxf(col, nb) : col;
+            }
+            uint32_t hp[2], mp[2], lp[2];
+            split3_pair(pv[0], pv[1], hp[0], mp[0], lp[0]);
+            split3_pair(pv[2], pv[3], hp[1], mp[1], lp[1]);
+            if ((l31 & 1) == 0) {
+                const int colc = wco * 32 + 8 * g + 4 * khalf;                 // first of four consecutive couts (within the tile)
+                unsigned char *o = ring + (wrow * 16 + (l31 >> 1)) * OP + colc * 2;
+                *reinterpret_cast<uint2 *>(o) = make_uint2(hp[0], hp[1]);
+                *reinterpret_cast<uint2 *>(o + (BROWS / 2) * 16 * OP) = make_uint2(mp[0], mp[1]);
+                *reinterpret_cast<uint2 *>(o + 2 * (BROWS / 2) * 16 * OP) = make_uint2(lp[0], lp[1]);
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < kParts * (BROWS / 2) * 16 * 8; e += 256) {       // 16-byte vectors: (part, cout block of 16, pooled pixel, half)
+            const int part = e / ((BROWS / 2) * 16 * 8), e1 = e - part * ((BROWS / 2) * 16 * 8);
+            const int cbl = e1 / ((BROWS / 2) * 16 * 2), rem = e1 - cbl * ((BROWS / 2) * 16 * 2);
+            const int opix = rem >> 1, half = rem & 1;
+            const int oy = (y0 >> 1) + (opix >> 4), ox = (x0 >> 1) + (opix & 15), co = co0 + cbl * 16;
+            if (oy < OH && ox < OW && co < CoutP)
+                *reinterpret_cast<uint4 *>(y16 + part * y_part + (((size_t)(co >> 4) * OH + oy) * OW + ox) * 16 + half * 8) =
+                    *reinterpret_cast<const uint4 *>(ring + (part * (BROWS / 2) * 16 + opix) * OP + (cbl * 2 + half) * 16);
+        }
+        return;
+    }
+    // out_mode 0: split tensor, same size.  Transposed through LDS so that each 16-cout block of a tile row leaves as one
+    // contiguous run of 32 px x 32 B per part
+    const size_t y_part = (size_t)CoutP * H * W;
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint32_t hp[2], mp[2], lp[2];
+            split3_pair(v[j][4 * g], v[j][4 * g + 1], hp[0], mp[0], lp[0]);
+            split3_pair(v[j][4 * g + 2], v[j][4 * g + 3], hp[1], mp[1], lp[1]);
+            const int colc = wco * 32 + 8 * g + 4 * khalf;
+            unsigned char *o = ring + ((wrow * RW + j) * 32 + l31) * OP + colc * 2;
+            *reinterpret_cast<uint2 *>(o) = make_uint2(hp[0], hp[1]);
+            *reinterpret_cast<uint2 *>(o + BROWS * 32 * OP) = make_uint2(mp[0], mp[1]);
+            *reinterpret_cast<uint2 *>(o + 2 * BROWS * 32 * OP) = make_uint2(lp[0], lp[1]);
+        }
+    __syncthreads();
+    for (int e = tid; e < kParts * BROWS * 32 * 8; e += 256) {                 // 16-byte vectors: (part, cout block of 16, pixel, half)
+        const int part = e / (BROWS * 32 * 8), e1 = e - part * (BROWS * 32 * 8);
+        const int cbl = e1 / (BROWS * 32 * 2), rem = e1 - cbl * (BROWS * 32 * 2);
+        const int pix = rem >> 1, half = rem & 1;
+        const int py = y0 + (pix >> 5), qx = x0 + (pix & 31), co = co0 + cbl * 16;
+        if (py < H && qx < W && co < CoutP)
+            *reinterpret_cast<uint4 *>(y16 + part * y_part + (((size_t)(co >> 4) * H + py) * W + qx) * 16 + half * 8) =
+                *reinterpret_cast<const uint4 *>(ring + (part * BROWS * 32 + pix) * OP + (cbl * 2 + half) * 16);
+    }
+}
+
+// (Cout, Cin, 3, 3) fp32 -> [3 parts][CinP/16][tap][CoutP][16] bf16, zero padded
+__global__ void __launch_bounds__(256)
+pack_w_f32s_kernel(const float *__restrict__ w, int Cout, int Cin, int taps, int CoutP, int CinP, uint16_t *__restrict__ wp) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)taps * CoutP * CinP;
+    if (i >= total) return;
+    const int c16 = (int)(i % 16), co = (int)((i / 16) % CoutP), tap = (int)((i / (16 * (size_t)CoutP)) % taps);
+    const int ci = (int)(i / (16 * (size_t)CoutP * taps)) * 16 + c16;
+    const float v = (co < Cout && ci < Cin) ? w[((size_t)co * Cin + ci) * taps + tap] : 0.0f;
+    uint32_t h, m, l;
+    split3_pair(v, 0.0f, h, m, l);
+    wp[i] = (uint16_t)h; wp[total + i] = (uint16_t)m; wp[2 * total + i] = (uint16_t)l;
+}
+
+// (C,H,W) fp32 -> [3][CP/16][H*W][16] bf16 parts, channels C..CP-1 zero
+__global__ void __launch_bounds__(256)
+nchw_to_f32s_kernel(const float *__restrict__ x, int C, int HW, int CP, uint16_t *__restrict__ y) {
+    const size_t total = (size_t)HW * CP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c16 = (int)(i % 16);
+        const size_t p = (i / 16) % HW;
+        const int c = (int)(i / (16 * (size_t)HW)) * 16 + c16;
+        uint32_t h, m, l;
+        split3_pair(c < C ? x[(size_t)c * HW + p] : 0.0f, 0.0f, h, m, l);
+        y[i] = (uint16_t)h; y[total + i] = (uint16_t)m; y[2 * total + i] = (uint16_t)l;
+    }
+}
+
+// [3][CP/16][H*W][16] bf16 parts -> (C,H,W) fp32 (h + m + l: exact) through a 64x65 LDS tile
+__global__ void __launch_bounds__(256)
+f32s_to_nchw_kernel(const uint16_t *__restrict__ x, int C, int HW, int CP, float *__restrict__ y) {
+    __shared__ float tile[64][65];
+    const size_t part = (size_t)HW * CP;
+    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {
+        const int p = p0 + i, c = c0 + tx;
+        float v = 0.0f;
+        if (p < HW && c < C) {
+            const size_t o = ((size_t)(c >> 4) * HW + p) * 16 + (c & 15);
+            v = (__uint_as_float((uint32_t)x[o] << 16) + __uint_as_float((uint32_t)x[part + o] << 16)) + __uint_as_float((uint32_t)x[2 * part + o] << 16);
+        }
+        tile[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, p = p0 + tx;
+        if (c < C && p < HW) y[(size_t)c * HW + p] = tile[tx][i];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int frcnn_f32s_pack_conv_w(const float *w, int Cout, int Cin, uint16_t *w_packed, void *stream) {
+    if (!w || !w_packed || Cout < 1 || Cin < 1) return FRCNN_ERR_INVALID;
+    const int CoutP = (Cout + 15) / 16 * 16, CinP = (Cin + 15) / 16 * 16;
+    const size_t total = (size_t)9 * CoutP * CinP;
+    hipLaunchKernelGGL(pack_w_f32s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, 9, CoutP, CinP, w_packed);
+    return frcnn_launch_status();
+}
+
+int frcnn_f32s_from_nchw_f32(const float *x, int C, int H, int W, uint16_t *y, void *stream) {
+    if (!x || !y || C < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    const int CP = (C + 15) / 16 * 16;
+    const size_t total = (size_t)H * W * CP;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(nchw_to_f32s_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, C, H * W, CP, y);
+    return frcnn_launch_status();
+}
+
+int frcnn_f32s_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, void *stream) {
+    if (!x || !y || C < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    const int CP = (C + 15) / 16 * 16;
+    hipLaunchKernelGGL(f32s_to_nchw_kernel, dim3(frcnn_cdiv(H * W, 64), frcnn_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, x, C, H * W, CP, y);
+    return frcnn_launch_status();
+}
+
+int frcnn_conv3x3_f32s(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H, int W, int relu, int out_mode,
+                       void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    if (out_mode < 0 || out_mode > 2 || (out_mode == 2 && !relu)) return FRCNN_ERR_INVALID;
+    const int CinP = (Cin + 15) / 16 * 16, CoutP = (Cout + 15) / 16 * 16;
+    if ((size_t)kParts * H * W * CinP * 2 >= (1ull << 31) || (size_t)kParts * 9 * CoutP * CinP * 2 >= (1ull << 31)) return FRCNN_ERR_INVALID;   // 32-bit buffer offsets, top bit = out of range
+    const int xtiles = frcnn_cdiv(W, 32), ytiles = frcnn_cdiv(H, 4), cotiles = frcnn_cdiv(CoutP, 64);
+    const dim3 grid((unsigned)((long)xtiles * ytiles * cotiles));
+    const char *stag_env = getenv("FRCNN_F32S_STAGGER");             // "<bit>,<sleep in 64-clock units>" (tuning hook)
+    int stag_bit = 8, stag_sleep = 0;
+    if (stag_env) { stag_bit = atoi(stag_env); const char *c = strchr(stag_env, ','); stag_sleep = c ? atoi(c + 1) : 80; }
+    const char *abl_env = getenv("FRCNN_F32S_ABL");
+    const int abl = abl_env ? atoi(abl_env) : 0;
+    if (abl == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<2, 1>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, stag_bit, stag_sleep);
+    else if (abl == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<2, 4>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, stag_bit, stag_sleep);
+    else if (abl == 20) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<1, 0, 2>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, stag_bit, stag_sleep);
+    else if (abl == 21) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<1, 1, 2>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, stag_bit, stag_sleep);
+    else if (abl == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<2, 5>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, stag_bit, stag_sleep);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<2>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, stag_bit, stag_sleep);
+    return frcnn_launch_status();
+}
+
+}  // extern "C"

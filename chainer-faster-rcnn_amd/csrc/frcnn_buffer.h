@@ -63,3 +63,9 @@ __device__ __forceinline__ void frcnn_wait_vmcnt() { asm volatile("s_waitcnt vmc
 __device__ __forceinline__ void frcnn_barrier_nofence() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// idle for about n x 64 clocks (s_sleep takes a 7-bit immediate)
+__device__ __forceinline__ void frcnn_sleep_64clk(int n) {
+    for (; n >= 127; n -= 127) __builtin_amdgcn_s_sleep(127);
+    for (; n >= 16; n -= 16) __builtin_amdgcn_s_sleep(16);
+    for (; n > 0; --n) __builtin_amdgcn_s_sleep(1);
+}

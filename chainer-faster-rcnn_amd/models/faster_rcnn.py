@@ -132,7 +132,7 @@ class FasterRCNN(object):
         tr = getattr(self, "_last_trainer", None)
         if tr is not None:
             tr.sync_params()                                 # packed training weights -> (co,ci,3,3) / (out,in) arrays on the links
-        if self.conv_dtype == "bf16":
+        if self.conv_dtype in ("bf16", "f32s"):
             for link in getattr(self.trunk, "links", {}).values():
                 link.refresh_bf16()
             self.RPN.rpn_conv_3x3.refresh_bf16()
@@ -165,7 +165,8 @@ class FasterRCNN(object):
         feat = self.trunk(x, timer=timer, collect=collect) if collect is not None else self.trunk(x, timer=timer)
         C, H, W = [int(v) for v in feat.shape[1:]]
         x_bf16 = getattr(self.trunk, "feat_bf16", None) if self.conv_dtype == "bf16" else None
-        rpn_h, score, prob, bbox = self.RPN.heads(feat, want_score=False, timer=timer, x_bf16=x_bf16)
+        x_split = getattr(self.trunk, "feat_split", None) if self.conv_dtype == "f32s" else None
+        rpn_h, score, prob, bbox = self.RPN.heads(feat, want_score=False, timer=timer, x_bf16=x_bf16, x_split=x_split)
         if keep:
             rois, probs, n_out, src_index = self.RPN.proposal_layer.forward_device(prob, bbox, im_h, im_w, want_index=True)
         else:

@@ -20,7 +20,7 @@ class Conv3x3(object):
 
     def __init__(self, rt, cin, cout, conv_dtype="f32"):
         self.rt, self.cin, self.cout, self.conv_dtype = rt, cin, cout, conv_dtype
-        self.W = self.b = self.Wp = self.Wb = None
+        self.W = self.b = self.Wp = self.Wb = self.Ws = None
 
     def set(self, W, b):
         rt = self.rt
@@ -39,6 +39,8 @@ class Conv3x3(object):
     def refresh_bf16(self):
         if self.conv_dtype == "bf16":
             self.Wb = self.rt.bf16_pack_conv_w(self.W, 3)     # [tap][CoutP][CinP] bf16 (csrc/conv_bf16.hip)
+        elif self.conv_dtype == "f32s":
+            self.Ws = self.rt.f32s_pack_conv_w(self.W)        # three bf16 terms per fp32 weight (csrc/conv_f32s.hip)
 
     def __call__(self, x, relu=True, out=None, cfg=-1):
         return self.rt.conv3x3(x, self.Wp, self.b, relu=relu, out=out, cfg=cfg)
@@ -52,11 +54,18 @@ class Conv3x3(object):
         return self.rt.conv_bf16(x_blk, self.Wb, self.b, self.cin, self.cout, 3, relu=relu, out_f32_nchw=out_f32_nchw, pool=pool)
 
 
+    def f32s(self, x_split, relu=True, out_f32_nchw=False, pool=False):
+        """x split tensor [3][CinP/16][H][W][16] -> split tensor (or fp32 NCHW): the fp32 convolution as six bf16 MFMA products."""
+        return self.rt.conv3x3_f32s(x_split, self.Ws, self.b, self.cin, self.cout, relu=relu, out_f32_nchw=out_f32_nchw, pool=pool)
+
+
 class VGG16Prev(object):
     def __init__(self, train=False, runtime=None, layers=None, conv_dtype="f32"):
         self.rt = runtime or default_runtime()
         self.train = train
-        self.conv_dtype = conv_dtype                                      # "f32" (BASELINE config 2) or "bf16" (config 3)
+        # "f32" (BASELINE config 2: fp32 MFMA), "f32s" (the same fp32 convolutions computed as six bf16 MFMA products of 3-way
+        # split operands -- csrc/conv_f32s.hip) or "bf16" (config 3)
+        self.conv_dtype = conv_dtype
         self.fuse_pool = True        # inference: conv -> ReLU -> pool as one launch (the trainer keeps the pre-pool maps instead)
         self.layers = list(layers) if layers is not None else LAYERS     # (tests build narrow / shallow variants)
         self.links = {}
@@ -82,6 +91,8 @@ class VGG16Prev(object):
         assert h.ndim == 4 and int(h.shape[0]) == 1, "batch size 1 (models/faster_rcnn.py:77)"
         if self.conv_dtype == "bf16":
             return self._call_bf16(h, timer, collect)
+        if self.conv_dtype == "f32s":
+            return self._call_f32s(h, timer, collect)
         n_pool, skip = 0, False
         for idx, l in enumerate(self.layers):
             if l == "pool":
@@ -132,6 +143,41 @@ class VGG16Prev(object):
                     collect["pool%d" % (n_pool + 1) if fuse else l[0]] = (h, cout)
         self.feat_bf16 = h                   # the channel-blocked bf16 map itself: the RPN's bf16 conv takes it as is
         feat = rt.bf16_to_nchw(h, cout)
+        if timer:
+            timer.mark("to_nchw")
+        return feat
+
+
+    def _call_f32s(self, x, timer, collect=None):
+        """fp32 chain on split tensors: fp32 NCHW image -> three bf16 terms per value (exact) -> 13 convolutions, each an fp32
+        convolution (six bf16 MFMA products, fp32 accumulation, bias / ReLU / max-pool in fp32, result split again) -> conv5_3 back
+        as fp32 NCHW (h + m + l: exact)."""
+        rt = self.rt
+        h = rt.f32s_from_nchw(x)
+        n_pool, cout, skip = 0, int(x.shape[1]), False
+        as_nchw = lambda t, c: rt.f32s_to_nchw(t, c)
+        for idx, l in enumerate(self.layers):
+            if l == "pool":
+                n_pool += 1
+                if skip:
+                    skip = False
+                    continue
+                h = rt.f32s_from_nchw(rt.maxpool2x2(as_nchw(h, cout)))        # unfused pool (tests only): through fp32 NCHW
+                if timer:
+                    timer.mark("pool%d" % n_pool)
+                if collect is not None:
+                    collect["pool%d" % n_pool] = as_nchw(h, cout)
+            else:
+                fuse = self.fuse_pool and idx + 1 < len(self.layers) and self.layers[idx + 1] == "pool"
+                h = self.links[l[0]].f32s(h, relu=True, pool=fuse)
+                skip = fuse
+                cout = l[2]
+                if timer:
+                    timer.mark(l[0])
+                if collect is not None:
+                    collect["pool%d" % (n_pool + 1) if fuse else l[0]] = as_nchw(h, cout)
+        self.feat_split = h                  # the split tensor itself: the RPN's convolution takes it as is
+        feat = rt.f32s_to_nchw(h, cout)
         if timer:
             timer.mark("to_nchw")
         return feat

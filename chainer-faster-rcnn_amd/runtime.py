@@ -365,6 +365,42 @@ class Runtime(object):
                                        int(act), m.ptr(ws), ws.shape[0], m.stream()), "frcnn_conv_f32_ex")
         return y
 
+    # ------------------------------------------------------------------ fp32 convolution on split (3 x bf16) tensors (csrc/conv_f32s.hip)
+    def f32s_pack_conv_w(self, w):
+        m, L = self.mem, self.lib
+        co, ci = int(w.shape[0]), int(w.shape[1])
+        wp = m.empty((3, self.bf16_pad(ci) // 16, 9, self.bf16_pad(co), 16), "i16")
+        _lib.check(L.frcnn_f32s_pack_conv_w(m.ptr(w), co, ci, m.ptr(wp), m.stream()), "frcnn_f32s_pack_conv_w")
+        return wp
+
+    def f32s_from_nchw(self, x):
+        m, L = self.mem, self.lib
+        C, H, W = [int(v) for v in x.shape[-3:]]
+        y = m.empty((3, self.bf16_pad(C) // 16, H, W, 16), "i16")
+        _lib.check(L.frcnn_f32s_from_nchw_f32(m.ptr(x), C, H, W, m.ptr(y), m.stream()), "frcnn_f32s_from_nchw_f32")
+        return y
+
+    def f32s_to_nchw(self, x, C):
+        m, L = self.mem, self.lib
+        H, W = int(x.shape[2]), int(x.shape[3])
+        y = m.empty((1, int(C), H, W), "f32")
+        _lib.check(L.frcnn_f32s_to_nchw_f32(m.ptr(x), int(C), H, W, m.ptr(y), m.stream()), "frcnn_f32s_to_nchw_f32")
+        return y
+
+    def conv3x3_f32s(self, x, w_packed, bias, cin, cout, relu=True, out_f32_nchw=False, pool=False):
+        """x split tensor [3][CinP/16][H][W][16] -> split tensor (optionally ReLU + 2x2 max-pooled), or (1,Cout,H,W) fp32."""
+        m, L = self.mem, self.lib
+        H, W = int(x.shape[2]), int(x.shape[3])
+        assert int(x.shape[0]) == 3 and int(x.shape[1]) * 16 == self.bf16_pad(cin) and int(w_packed.shape[1]) * 16 == self.bf16_pad(cin)
+        if pool:
+            y = m.empty((3, self.bf16_pad(cout) // 16, (H + 1) // 2, (W + 1) // 2, 16), "i16")
+        else:
+            y = m.empty((1, int(cout), H, W), "f32") if out_f32_nchw else m.empty((3, self.bf16_pad(cout) // 16, H, W, 16), "i16")
+        mode = 2 if pool else (1 if out_f32_nchw else 0)
+        _lib.check(L.frcnn_conv3x3_f32s(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(y), int(cin), int(cout), H, W, int(bool(relu)), mode,
+                                        m.stream()), "frcnn_conv3x3_f32s")
+        return y
+
     # ------------------------------------------------------------------ bf16 convolution stack (raw bf16 bits live in int16 arrays)
     def bf16_pad(self, c):
         return (int(c) + 15) // 16 * 16

@@ -197,6 +197,19 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
                       int Cout, int H, int W, int ksize, int act, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* ---- fp32 convolution on the bf16 matrix cores ("split" tensors) ------------------------------------------
+ * Same reference interface as frcnn_conv3x3_f32 (L.Convolution2D(ci, co, 3, 1, 1) + F.relu [+ F.max_pooling_2d(2,2)]:
+ * models/vgg16.py:39-82, region_proposal_network.py:53), fp32 results: every fp32 operand is carried as three bf16 terms
+ * h + m + l (exact) and a product block is six v_mfma_f32_32x32x16_bf16 (h.h, h.m, m.h, h.l, l.h, m.m; what is dropped is
+ * below 2^-24 of the product), fp32 accumulation.  A split tensor is [3 parts][CP/16][H][W][16] bf16 (CP = C rounded up to 16),
+ * split weights [3][CinP/16][tap][CoutP][16].  out_mode 0: y = split tensor (CoutP, H, W); 2: ReLU + 2x2 max-pool (cover_all,
+ * in fp32 before the split) fused, y = split tensor (CoutP, ceil(H/2), ceil(W/2)); 1: y = (Cout,H,W) fp32 NCHW. */
+int frcnn_f32s_pack_conv_w(const float *w, int Cout, int Cin, uint16_t *w_packed, void *stream);
+int frcnn_f32s_from_nchw_f32(const float *x, int C, int H, int W, uint16_t *y, void *stream);
+int frcnn_f32s_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, void *stream);
+int frcnn_conv3x3_f32s(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
+                       int W, int relu, int out_mode, void *stream);
+
 /* ---- bf16 convolution stack (BASELINE config 3: bf16 convs / fp32 RoI) -----------------------------------
  * Same reference interface as the fp32 stack (L.Convolution2D + F.relu, F.MaxPooling2D: models/vgg16.py:39-68,
  * region_proposal_network.py:53-57); operands rounded to bf16 (nearest even), fp32 accumulation on

@@ -30,3 +30,4 @@ static inline void frcnn_buf_load_lds_b32(frcnn_buf_t b, void *lds_wave_base, ui
 }
 template <int N> static inline void frcnn_wait_vmcnt() {}
 static inline void frcnn_barrier_nofence() { __syncthreads(); }
+static inline void frcnn_sleep_64clk(int) {}

@@ -501,6 +501,87 @@ def check_conv_bf16(rt, Cin, Cout, H, W, ksize=3, relu=True, seed=0):
     assert np.array_equal(back[0], got[:, :, :Cout].transpose(2, 0, 1))
 
 
+def split_parts_to_nchw(parts, C):
+    """[3][CP/16][H][W][16] raw bf16 bits -> the three fp32 terms, each (C, H, W)."""
+    out = []
+    for p in range(3):
+        hwc = from_bf16_bits(blocked_to_hwc(parts[p]))
+        out.append(hwc[:, :, :C].transpose(2, 0, 1))
+    return out
+
+
+def check_conv_f32s(rt, Cin, Cout, H, W, relu=True, seed=0, tol=3e-6):
+    """fp32 convolution on split (3 x bf16) tensors, csrc/conv_f32s.hip: the conversion is exact (h + m + l == x bit for bit), the
+    result is an fp32 convolution -- compared with a FLOAT64 convolution of the same fp32 operands next to the native fp32 MFMA
+    kernel (same accuracy class: the two errors may differ by a small factor, not by orders of magnitude) -- and the three output
+    forms (fp32 NCHW, split tensor, split tensor after the fused ReLU + 2x2 max-pool) agree exactly with one another."""
+    import torch
+    rs = np.random.RandomState(seed)
+    x = rs.randn(1, Cin, H, W).astype(np.float32)
+    x[0, :, 0, 0] = [1e-30 * (i + 1) for i in range(Cin)]                    # tiny magnitudes: the low terms underflow gracefully
+    w = (rs.randn(Cout, Cin, 3, 3) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    b = (rs.randn(Cout) * 0.1).astype(np.float32)
+    xd = rt.f32s_from_nchw(dev(rt, x))
+    parts = split_parts_to_nchw(host(rt, xd), Cin)
+    assert np.array_equal((parts[0] + parts[1]) + parts[2], x[0])            # exact 3-term representation
+    assert np.array_equal(host(rt, rt.f32s_to_nchw(xd, Cin)), x)
+    want64 = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1).numpy()
+    if relu:
+        want64 = np.maximum(want64, 0)
+    wpk = rt.f32s_pack_conv_w(dev(rt, w))
+    bd = dev(rt, b)
+    y = host(rt, rt.conv3x3_f32s(xd, wpk, bd, Cin, Cout, relu=relu, out_f32_nchw=True))
+    scale = max(np.abs(want64).max(), 1e-6)
+    err = np.abs(y - want64).max() / scale
+    assert err <= tol, err
+    if Cout % 64 == 0:                                                       # the native fp32 MFMA kernel next to it
+        yn = host(rt, rt.conv3x3(dev(rt, x), rt.pack_conv3x3_w(dev(rt, w)), bd, relu=relu))
+        err_n = np.abs(yn - want64).max() / scale
+        assert err <= 4 * err_n + 2e-7, (err, err_n)
+    ys = rt.conv3x3_f32s(xd, wpk, bd, Cin, Cout, relu=relu)
+    assert np.array_equal(host(rt, rt.f32s_to_nchw(ys, Cout)), y)            # the split output carries the fp32 result exactly
+    pad = host(rt, ys)[:, :, :, :, :]
+    if rt.bf16_pad(Cout) != Cout:
+        assert not blocked_to_hwc(pad[0])[:, :, Cout:].any()
+    if relu:
+        yp = rt.conv3x3_f32s(xd, wpk, bd, Cin, Cout, relu=True, pool=True)
+        assert np.array_equal(host(rt, rt.f32s_to_nchw(yp, Cout)), O.max_pool_2x2(y))
+
+
+def rel_err(got, want):
+    want = np.asarray(want, dtype=np.float32)
+    return float(np.abs(np.asarray(got, dtype=np.float32) - want).max() / max(float(np.abs(want).max()), 1e-30))
+
+
+def check_f32s_pipeline_small(rt, im_h=22, im_w=37):
+    """conv_dtype="f32s" through the model classes on a narrow trunk (conv, fused conv+pool, an unfused pool, the RPN convolution and
+    heads): the same fp32 network as conv_dtype="f32", within accumulation-order noise of it and of the oracle."""
+    import functools
+    import train_cases as T
+    from chainer_faster_rcnn_amd.models import FasterRCNN, VGG16Prev
+    params = T.small_params(seed=3)
+    x = np.random.RandomState(5).randn(1, 3, im_h, im_w).astype(np.float32)
+    outs = {}
+    for dt in ("f32", "f32s"):
+        model = FasterRCNN(trunk_class=functools.partial(VGG16Prev, layers=T.SMALL_LAYERS), rpn_in_ch=64, rpn_mid_ch=64, feat_stride=4,
+                           anchor_scales=(2, 4, 8), runtime=rt, conv_dtype=dt)
+        model.trunk.load_params(params, "trunk/")
+        model.RPN.load_params(params, "RPN/")
+        feat = model.trunk(dev(rt, x))
+        xs = getattr(model.trunk, "feat_split", None)
+        h, score, prob, bbox = model.RPN.heads(feat, want_score=True, x_split=xs)
+        outs[dt] = [host(rt, t) for t in (feat, h, prob, bbox)]
+        if dt == "f32s":
+            model.trunk.fuse_pool = False                              # the unfused pool path agrees with the fused one exactly
+            assert np.array_equal(host(rt, model.trunk(dev(rt, x))), outs[dt][0])
+    h_ = x
+    for l in T.SMALL_LAYERS:
+        h_ = O.max_pool_2x2(h_) if l == "pool" else O.relu(O.conv2d(h_, params["trunk/%s/W" % l[0]], params["trunk/%s/b" % l[0]], 1))
+    assert rel_err(outs["f32s"][0], h_) <= 5e-6 and rel_err(outs["f32"][0], h_) <= 5e-6
+    for a, b in zip(outs["f32"], outs["f32s"]):
+        assert rel_err(b, a) <= 5e-6, rel_err(b, a)
+
+
 def check_conv_bf16_pool(rt, Cin, Cout, H, W, seed=0):
     """out_mode 2: bf16 conv + ReLU + 2x2 ceil-mode pool in one launch == the two separate bf16 launches, bit for bit."""
     rs = np.random.RandomState(seed)

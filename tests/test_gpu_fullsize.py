@@ -66,6 +66,28 @@ def test_vgg16_forward_600x1000_fp32(rt, oracle_forward):
     assert np.array_equal(np.rint(dev["rois"][:300] * np.float32(0.0625)), np.rint(p2 * np.float32(0.0625)))
 
 
+def test_vgg16_forward_600x1000_f32s(rt, oracle_forward):
+    """The fp32 network with its 14 3x3 convolutions computed as six bf16 MFMA products of 3-way split operands (csrc/conv_f32s.hip):
+    held to the SAME bars as the native fp32 path -- it is an fp32 computation (dropped terms < 2^-24 of a product)."""
+    from chainer_faster_rcnn_amd.models import FasterRCNN
+    from oracle import parity
+    params, x, info, dbg = oracle_forward
+    model = FasterRCNN(runtime=rt, conv_dtype="f32s")
+    model.load_params(params)
+    dev = parity.device_forward_host(rt, model, rt.mem.from_numpy(x), IM_H, IM_W)
+    rep = parity.compare_forward(params, info, dbg, dev, layer_tol=1e-3, head_tol=1e-3)
+    _report("f32s_600x1000", rep)
+    assert set(rep["layers_rel_err"]) >= {"conv1_1", "pool1", "conv2_1", "pool2", "conv3_1", "conv3_2", "pool3", "conv4_1", "conv4_2",
+                                          "pool4", "conv5_1", "conv5_2", "conv5_3"}
+    assert rep["layers_worst"] <= 2e-5 and rep["conv5_3_rel_err"] <= 2e-5 and rep["rpn_h_rel_err"] <= 2e-5       # measured: the native path's few 1e-6
+    assert rep["rpn_cls_prob_rel_err"] <= 1e-4 and rep["rpn_bbox_pred_rel_err"] <= 1e-4
+    assert rep["proposals_index_exact_given_device_maps"] and rep["proposals_scores_exact_given_device_maps"]
+    assert rep["pool5_exact"]
+    assert rep["cls_prob_rel_err"] <= 1e-3 and rep["pred_boxes_rel_err"] <= 1e-3
+    assert rep["n_rois"] == 300 and rep["ok"]
+    assert rep["from_image_index_match_set"] >= 295                                             # the same proposals as the oracle's from the image
+
+
 def test_vgg16_forward_600x1000_bf16(rt, oracle_forward):
     """configs[2]: bf16 convolutions + bf16 FC head (fp32 accumulate), proposals / RoI pooling / decode fp32.  Features within
     3e-2 of the oracle's fp32 feature scale; the fp32 stages exact given the device's own maps."""

@@ -429,3 +429,16 @@ def test_captured_forward_matches_eager(rt):
 def test_empty_proposals_pipeline(rt):
     P.check_empty_proposals_pipeline(rt)
 
+
+def test_conv_f32s_split_bf16(rt):
+    """fp32 convolution as six bf16 MFMA products of 3-way split operands (csrc/conv_f32s.hip) at VGG channel counts."""
+    P.check_conv_f32s(rt, 16, 64, 9, 37)
+    P.check_conv_f32s(rt, 3, 64, 61, 97, seed=1)
+    P.check_conv_f32s(rt, 64, 64, 75, 125, seed=2)
+    P.check_conv_f32s(rt, 256, 256, 38, 63, seed=3)
+    P.check_conv_f32s(rt, 512, 512, 19, 32, seed=4)
+    P.check_conv_f32s(rt, 48, 80, 21, 30, relu=False, seed=5)
+
+
+def test_f32s_pipeline_small(rt):
+    P.check_f32s_pipeline_small(rt, im_h=90, im_w=131)

@@ -226,3 +226,13 @@ def test_conv_workspace_self_cleaning(rt):
 def test_empty_proposals_pipeline(rt):
     P.check_empty_proposals_pipeline(rt)
 
+
+def test_conv_f32s_split_bf16(rt):
+    """fp32 convolution as six bf16 MFMA products of 3-way split operands (csrc/conv_f32s.hip)."""
+    P.check_conv_f32s(rt, 16, 64, 9, 37)                  # one chunk, ragged rows / columns, odd sizes through the fused pool
+    P.check_conv_f32s(rt, 3, 64, 6, 34, seed=1)           # conv1_1: channels padded 3 -> 16; two x tiles
+    P.check_conv_f32s(rt, 48, 80, 5, 30, relu=False, seed=2)   # three chunks; 80 couts: a ragged second cout tile
+
+
+def test_f32s_pipeline_small(rt):
+    P.check_f32s_pipeline_small(rt)
