@@ -45,7 +45,8 @@ __device__ __forceinline__ void split3_pair(float v0, float v1, uint32_t &h, uin
 template <int WPS, int ABL = 0, int NS = 1>
 __global__ void __launch_bounds__(256, WPS)
 conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
-                 int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles, int stag_bit, int stag_sleep) {
+                 int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles, int nsplit,
+                 float *__restrict__ partial_ws, int *__restrict__ tile_counters) {
     constexpr int KS = 3, TAPS = 9, PAD = 1;
     constexpr int RW = 2, BROWS = 4, BCO = 64;
     constexpr int HR = BROWS + KS - 1, HPX = 32 + KS - 1;
@@ -61,14 +62,19 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
     constexpr int OP = BCO * 2 + 16;                          // epilogue tile: LDS bytes per pixel and part (128 B + pad)
     static_assert(kParts * BROWS * 32 * OP <= STAGE_BYTES, "epilogue tiles must fit in the stage");
     __shared__ __attribute__((aligned(1024))) unsigned char ring[NS * STAGE_BYTES];
+    __shared__ int s_ticket;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave & 1, wrow = wave >> 1;
     const int l31 = lane & 31, khalf = lane >> 5;
-    const int tile = blockIdx.x;
+    // split-K for launches with fewer tiles than the chip has room for (the 38x63 maps: 160 tiles, 512 workgroup slots): `nsplit`
+    // consecutive workgroups share a tile, each takes a contiguous range of the K-chunks, the last to finish sums the pieces in
+    // split order (deterministic) and runs the epilogue
+    const int tile = blockIdx.x / nsplit, split = blockIdx.x - tile * nsplit;
     const int tx = tile % xtiles, ty = (tile / xtiles) % ytiles, cot = tile / (xtiles * ytiles);
     const int x0 = tx * 32, y0 = ty * BROWS, co0 = cot * BCO;
-    const int nchunks = CinP / kCK;
+    const int all_chunks = CinP / kCK;
+    const int c_first = split * all_chunks / nsplit, nchunks = (split + 1) * all_chunks / nsplit - c_first;
     const uint32_t x_part_bytes = (uint32_t)((size_t)H * W * CinP * 2), w_part_bytes = (uint32_t)((size_t)TAPS * CoutP * CinP * 2);
     const frcnn_buf_t xbuf = frcnn_make_buf(x, kParts * x_part_bytes);
     const frcnn_buf_t wbuf = frcnn_make_buf(wp, kParts * w_part_bytes);
@@ -97,7 +103,7 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
     auto issue = [&](int chunk, int stage) {
         if constexpr ((ABL & 1) != 0) return;
         unsigned char *dst = ring + stage * STAGE_BYTES + wave * 1024;
-        const uint32_t xs = (uint32_t)chunk * x_chunk_bytes, ws = (uint32_t)chunk * w_chunk_bytes;
+        const uint32_t xs = (uint32_t)(c_first + chunk) * x_chunk_bytes, ws = (uint32_t)(c_first + chunk) * w_chunk_bytes;
 #pragma unroll
         for (int q = 0; q < PPW; ++q) {
             if (4 * q + 3 < IN_PIECES) frcnn_buf_load_lds_b128(xbuf, dst + q * 4096, poff[q], xs);
@@ -157,10 +163,8 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
         }
     };
 
-    // single-stage ring: the co-resident workgroup's MFMAs cover this one's wait for its chunk -- IF the two are out of phase.
-    // Workgroups that start together and do equal work stay in lockstep (both wait for DMA, then both compute: no overlap at all),
-    // and their successors inherit it; so half of the first resident set starts late by about one chunk's compute time.
-    if (stag_sleep > 0 && (int)blockIdx.x < 4096 && (((int)blockIdx.x >> stag_bit) & 1)) frcnn_sleep_64clk(stag_sleep);
+    // single-stage ring: the co-resident workgroup's MFMAs cover this one's wait for its chunk.  (Starting half of the resident
+    // workgroups late, so that pairs cannot run in lockstep, measured no different: r02j.)
     if constexpr (NS == 1) {
     for (int c = 0; c < nchunks; ++c) {
         issue(c, 0);
@@ -183,6 +187,45 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
             }
         }
     }
+#pragma unroll
+    for (int j = 0; j < RW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] += acs[j][r];
+    if (nsplit > 1) {
+        // publish this split's accumulators (fragment-linear float4s, write-through: no release fence needed), take a ticket
+        const size_t slot_floats = (size_t)256 * RW * 16;
+        const frcnn_buf_t pbuf = frcnn_make_buf(partial_ws + ((size_t)tile * nsplit + split) * slot_floats, (uint32_t)(slot_floats * sizeof(float)));
+#pragma unroll
+        for (int j = 0; j < RW; ++j)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                frcnn_buf_store_f32x4_wt(pbuf, (uint32_t)(((j * 4 + r4) * 256 + tid) * 16),
+                                         make_float4(acc[j][4 * r4], acc[j][4 * r4 + 1], acc[j][4 * r4 + 2], acc[j][4 * r4 + 3]));
+        frcnn_drain_vmem();
+        __syncthreads();
+        if (tid == 0) s_ticket = frcnn_ticket(&tile_counters[tile]);
+        __syncthreads();
+        if (s_ticket != nsplit - 1) return;                       // workgroup-uniform
+        if (tid == 0) {
+            frcnn_acquire_agent();
+            frcnn_counter_reset(&tile_counters[tile]);            // leave the counter page zeroed for the next launch
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < RW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+        for (int q = 0; q < nsplit; ++q) {
+            const float4 *piece = reinterpret_cast<const float4 *>(partial_ws + ((size_t)tile * nsplit + q) * slot_floats);
+#pragma unroll
+            for (int j = 0; j < RW; ++j)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 t = piece[(size_t)(j * 4 + r4) * 256 + tid];
+                    acc[j][4 * r4] += t.x; acc[j][4 * r4 + 1] += t.y; acc[j][4 * r4 + 2] += t.z; acc[j][4 * r4 + 3] += t.w;
+                }
+        }
+    }
     __syncthreads();                                            // the stage becomes the epilogue's output tiles
 
     // ---- epilogue: register r of lane l = cout (r&3) + 8*(r>>2) + 4*khalf of pixel l31, rows y0 + 2 wrow + j
@@ -192,7 +235,7 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            float t = (acc[j][r] + acs[j][r]) + (co < Cout ? bias[co] : 0.0f);
+            float t = acc[j][r] + (co < Cout ? bias[co] : 0.0f);
             if (relu) t = fmaxf(t, 0.0f);
             v[j][r] = t;
         }
@@ -357,27 +400,68 @@ int frcnn_f32s_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, voi
     return frcnn_launch_status();
 }
 
-int frcnn_conv3x3_f32s(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H, int W, int relu, int out_mode,
-                       void *stream_) {
+constexpr size_t kF32sCounterPageBytes = 64 * 1024;
+
+// split-K factor: launches that leave most of the chip's 2 x CUs workgroup slots empty split their K range (FRCNN_F32S_SPLIT overrides)
+static int conv_f32s_pick_split(long tiles, int chunks) {
+    const char *e = getenv("FRCNN_F32S_SPLIT");
+    int s = e ? atoi(e) : (int)((2L * frcnn_cu_count()) / (tiles > 0 ? tiles : 1));      // fill the slots once: 160 tiles on 512 slots -> 3
+    if (s > 4) s = 4;
+    if (s < 1) s = 1;
+    while (s > 1 && chunks / s < 4) --s;                          // a split should still carry a few chunks
+    return s;
+}
+
+size_t frcnn_conv_f32s_workspace_bytes(int Cin, int Cout, int H, int W) {
+    if (Cin < 1 || Cout < 1 || H < 1 || W < 1) return 0;
+    const long tiles = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4) * frcnn_cdiv((Cout + 15) / 16 * 16, 64);
+    return kF32sCounterPageBytes + (size_t)tiles * 4 * 256 * 32 * sizeof(float);      // up to 4 splits x 32 KB of accumulators per tile
+}
+
+int frcnn_conv_f32s_workspace_init(void *workspace, size_t workspace_bytes, void *stream) {
+    if (!workspace || workspace_bytes < kF32sCounterPageBytes) return FRCNN_ERR_INVALID;
+    FRCNN_HIP_TRY(hipMemsetAsync(workspace, 0, kF32sCounterPageBytes, (hipStream_t)stream));
+    return FRCNN_OK;
+}
+
+int frcnn_conv3x3_f32s_ws(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H, int W, int relu, int out_mode,
+                          void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
     if (out_mode < 0 || out_mode > 2 || (out_mode == 2 && !relu)) return FRCNN_ERR_INVALID;
     const int CinP = (Cin + 15) / 16 * 16, CoutP = (Cout + 15) / 16 * 16;
     if ((size_t)kParts * H * W * CinP * 2 >= (1ull << 31) || (size_t)kParts * 9 * CoutP * CinP * 2 >= (1ull << 31)) return FRCNN_ERR_INVALID;   // 32-bit buffer offsets, top bit = out of range
     const int xtiles = frcnn_cdiv(W, 32), ytiles = frcnn_cdiv(H, 4), cotiles = frcnn_cdiv(CoutP, 64);
-    const dim3 grid((unsigned)((long)xtiles * ytiles * cotiles));
-    const char *stag_env = getenv("FRCNN_F32S_STAGGER");             // "<bit>,<sleep in 64-clock units>" (tuning hook)
-    int stag_bit = 8, stag_sleep = 0;
-    if (stag_env) { stag_bit = atoi(stag_env); const char *c = strchr(stag_env, ','); stag_sleep = c ? atoi(c + 1) : 80; }
+    const long tiles = (long)xtiles * ytiles * cotiles;
+    // split-K needs the workspace (partial tiles + the zeroed counter page); without one every tile is whole
+    int nsplit = 1;
+    if (workspace && tiles * 4 <= 16384) {
+        nsplit = conv_f32s_pick_split(tiles, CinP / kCK);
+        if (workspace_bytes < kF32sCounterPageBytes + (size_t)tiles * nsplit * 256 * 32 * sizeof(float)) nsplit = 1;
+    }
+    float *partials = nsplit > 1 ? (float *)((char *)workspace + kF32sCounterPageBytes) : nullptr;
+    int *counters = nsplit > 1 ? (int *)workspace : nullptr;
+    const dim3 grid((unsigned)(tiles * nsplit));
     const char *abl_env = getenv("FRCNN_F32S_ABL");
     const int abl = abl_env ? atoi(abl_env) : 0;
-    if (abl == 1) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<2, 1>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, stag_bit, stag_sleep);
-    else if (abl == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<2, 4>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, stag_bit, stag_sleep);
-    else if (abl == 20) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<1, 0, 2>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, stag_bit, stag_sleep);
-    else if (abl == 21) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<1, 1, 2>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, stag_bit, stag_sleep);
-    else if (abl == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<2, 5>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, stag_bit, stag_sleep);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<2>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, stag_bit, stag_sleep);
+#define FRCNN_F32S_LAUNCH(...) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<__VA_ARGS__>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, nsplit, partials, counters)
+    switch (abl) {
+#ifdef FRCNN_TIMING_ABLATIONS                                   // WRONG results: sweeps only, never shipped
+        case 1: FRCNN_F32S_LAUNCH(2, 1); break;
+        case 4: FRCNN_F32S_LAUNCH(2, 4); break;
+        case 5: FRCNN_F32S_LAUNCH(2, 5); break;
+        case 21: FRCNN_F32S_LAUNCH(1, 1, 2); break;
+#endif
+        case 20: FRCNN_F32S_LAUNCH(1, 0, 2); break;              // two-stage ring, one workgroup per CU (measured slower: kept for A/B runs)
+        default: FRCNN_F32S_LAUNCH(2);
+    }
+#undef FRCNN_F32S_LAUNCH
     return frcnn_launch_status();
+}
+
+int frcnn_conv3x3_f32s(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H, int W, int relu, int out_mode,
+                       void *stream) {
+    return frcnn_conv3x3_f32s_ws(x, w_packed, bias, y, Cin, Cout, H, W, relu, out_mode, nullptr, 0, stream);
 }
 
 }  // extern "C"

@@ -397,8 +397,11 @@ class Runtime(object):
         else:
             y = m.empty((1, int(cout), H, W), "f32") if out_f32_nchw else m.empty((3, self.bf16_pad(cout) // 16, H, W, 16), "i16")
         mode = 2 if pool else (1 if out_f32_nchw else 0)
-        _lib.check(L.frcnn_conv3x3_f32s(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(y), int(cin), int(cout), H, W, int(bool(relu)), mode,
-                                        m.stream()), "frcnn_conv3x3_f32s")
+        ws = self.workspace("conv_f32s", L.frcnn_conv_f32s_workspace_bytes(int(cin), int(cout), H, W),
+                            init=lambda w: _lib.check(L.frcnn_conv_f32s_workspace_init(m.ptr(w), w.shape[0], m.stream()),
+                                                      "frcnn_conv_f32s_workspace_init"))
+        _lib.check(L.frcnn_conv3x3_f32s_ws(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(y), int(cin), int(cout), H, W, int(bool(relu)), mode,
+                                           m.ptr(ws), ws.shape[0], m.stream()), "frcnn_conv3x3_f32s_ws")
         return y
 
     # ------------------------------------------------------------------ bf16 convolution stack (raw bf16 bits live in int16 arrays)

@@ -209,6 +209,12 @@ int frcnn_f32s_from_nchw_f32(const float *x, int C, int H, int W, uint16_t *y, v
 int frcnn_f32s_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, void *stream);
 int frcnn_conv3x3_f32s(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
                        int W, int relu, int out_mode, void *stream);
+/* the same with a workspace (frcnn_conv_f32s_workspace_bytes; its first 64 KB zeroed ONCE by frcnn_conv_f32s_workspace_init --
+ * every launch leaves them zero): lets launches with few tiles (38x63 maps) split their K range over several workgroups */
+size_t frcnn_conv_f32s_workspace_bytes(int Cin, int Cout, int H, int W);
+int frcnn_conv_f32s_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
+int frcnn_conv3x3_f32s_ws(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
+                          int W, int relu, int out_mode, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- bf16 convolution stack (BASELINE config 3: bf16 convs / fp32 RoI) -----------------------------------
  * Same reference interface as the fp32 stack (L.Convolution2D + F.relu, F.MaxPooling2D: models/vgg16.py:39-68,

@@ -234,5 +234,12 @@ def test_conv_f32s_split_bf16(rt):
     P.check_conv_f32s(rt, 48, 80, 5, 30, relu=False, seed=2)   # three chunks; 80 couts: a ragged second cout tile
 
 
+@pytest.mark.parametrize("split", ["2", "3"])
+def test_conv_f32s_split_k(rt, monkeypatch, split):
+    """Few-tile launches split their K range over several workgroups (ticket + deterministic fix-up by the last one)."""
+    monkeypatch.setenv("FRCNN_F32S_SPLIT", split)
+    P.check_conv_f32s(rt, 192, 64, 5, 33, seed=6)          # 12 chunks: 2 or 3 splits of >= 4
+
+
 def test_f32s_pipeline_small(rt):
     P.check_f32s_pipeline_small(rt)
