@@ -218,6 +218,67 @@ def graph_time_us(torch, fn, launches_per_replay, replays):
     return e0.elapsed_time(e1) * 1e3 / (replays * launches_per_replay)
 
 
+def f32s_conv_chain(rt, model, x):
+    """The 14 convolution launches of the f32s model (first layer straight from the fp32 image, fused pools, rpn_conv_3x3)."""
+    def chain():
+        tr_ = model.trunk
+        h, n_l = None, len(tr_.layers)
+        for idx, l in enumerate(tr_.layers):
+            if l == "pool":
+                continue
+            link = tr_.links[l[0]]
+            if h is None:
+                h = rt.conv1_f32s(x, link.W, link.b, relu=True)
+            else:
+                h = link.f32s(h, relu=True, pool=(idx + 1 < n_l and tr_.layers[idx + 1] == "pool"))
+        return model.RPN.rpn_conv_3x3.f32s(h, relu=True, out_f32_nchw=True)
+    return chain
+
+
+def split_variant(args, torch, rt, params, x, dbg, flops_total):
+    """The SAME fp32 network with its 3x3 convolutions computed as six bf16 MFMA products of 3-way split fp32 operands (fp32
+    accumulation; csrc/conv_f32s.hip), timed like the contract line (K hipGraph replays) and checked against the same oracle
+    forward.  Reported next to the native-fp32-MFMA contract line, not instead of it."""
+    from chainer_faster_rcnn_amd.graph import CapturedForward
+    from chainer_faster_rcnn_amd.models import FasterRCNN
+    model = FasterRCNN(runtime=rt, conv_dtype="f32s")
+    model.load_params(params)
+    for _ in range(max(args.warmup, 3)):
+        model.forward_device(x, IM_H, IM_W)
+    torch.cuda.synchronize()
+    graph = CapturedForward(model, x, IM_H, IM_W, warmup=1)
+    graph.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"what": ("fp32 tensors and results; every 3x3 convolution = six v_mfma_f32_32x32x16_bf16 products of 3-way split fp32 operands "
+                    "(h.h, h.m, m.h, h.l, l.h, m.m; dropped terms < 2^-24 of a product), fp32 accumulation; head / proposals / RoI pooling "
+                    "as in the contract line.  `python bench.py --dtype f32s` prints this variant as its own line."),
+           "value": args.steps / dt, "unit": "img/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "launch": "hipGraph replay"}
+    try:
+        conv_ms = graph_time_us(torch, f32s_conv_chain(rt, model, x), 1, max(args.steps, 100)) / 1e3
+        out.update(conv_ms_per_image=conv_ms, conv_algorithmic_tflops=flops_total / (conv_ms * 1e-3) / 1e12,
+                   mfma_executed_tflops=6 * flops_total / (conv_ms * 1e-3) / 1e12,
+                   frac_of_bf16_mfma_peak=6 * flops_total / (conv_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS)
+    except Exception as e:
+        print("f32s conv-chain graph failed (%s)" % (e,), file=sys.stderr)
+        torch.cuda.synchronize()
+    if dbg is not None:
+        try:
+            from oracle import parity
+            info = np.array([[IM_H, IM_W]], dtype=np.int32)
+            rep = parity.compare_forward(params, info, dbg, parity.device_forward_host(rt, model, x, IM_H, IM_W), layer_tol=1e-3, head_tol=1e-3)
+            out["parity"] = {k: rep[k] for k in ("ok", "layers_worst", "conv5_3_rel_err", "rpn_cls_prob_rel_err", "rpn_bbox_pred_rel_err",
+                                                 "proposals_index_exact_given_device_maps", "from_image_index_match_positional", "pool5_exact",
+                                                 "cls_prob_rel_err", "pred_boxes_rel_err", "end_to_end_cls_prob_rel_err", "tolerances")}
+        except Exception as e:
+            out["parity"] = {"ok": False, "error": repr(e)}
+    return out
+
+
 def train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note):
     """BASELINE.json configs[4]: train_rpn.py's step -- forward, ProposalLayer (train top-N, discarded, as the reference runs it),
     anchor targets, losses, backward, the all-reduce of the flat gradient buffer (RCCL), fused MomentumSGD+WD -- one synthetic
@@ -301,6 +362,8 @@ def main():
     ap.add_argument("--cpu-samples", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-stage-events", action="store_true")
+    ap.add_argument("--no-split-variant", action="store_true",
+                    help="f32 inference line only: skip the second measurement with the convolutions computed as bf16x6 split products")
     ap.add_argument("--no-train-proposals", action="store_true",
                     help="--mode train: skip the ProposalLayer(12000/2000) launch sequence the reference runs and discards in every RPN step")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
@@ -423,16 +486,7 @@ def main():
                 def conv_chain():
                     return model.RPN.rpn_conv_3x3(model.trunk(x), relu=True)
             elif args.dtype == "f32s":
-                xsp = rt.f32s_from_nchw(x)                     # the image split and the final split -> fp32 copy are not convs
-
-                def conv_chain():
-                    tr_ = model.trunk
-                    h, n_l = xsp, len(tr_.layers)
-                    for idx, l in enumerate(tr_.layers):
-                        if l == "pool":
-                            continue
-                        h = tr_.links[l[0]].f32s(h, relu=True, pool=(idx + 1 < n_l and tr_.layers[idx + 1] == "pool"))
-                    return model.RPN.rpn_conv_3x3.f32s(h, relu=True, out_f32_nchw=True)
+                conv_chain = f32s_conv_chain(rt, model, x)
             else:
                 xb = rt.bf16_from_nchw(x)                      # the fp32 -> bf16 image conversion and the final bf16 -> fp32 copy are not convs
 
@@ -531,6 +585,7 @@ def main():
                               "roi_pool_algorithmic_mb": roi_bytes / 1e6,
                               "roi_pool_gbps": roi_bytes / (roi_us * 1e-6) / 1e9,
                               "roi_pool_frac_of_hbm_peak": roi_bytes / (roi_us * 1e-6) / 1e9 / PEAK_HBM_GBPS}
+        dbg = None
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"], dbg = cpu_baseline(params, x_host, args.cpu_samples)
             try:
@@ -542,6 +597,13 @@ def main():
                 res["parity"] = rep
             except Exception as e:
                 res["parity"] = {"ok": False, "error": repr(e)}
+        if world == 1 and args.dtype == "f32" and not args.no_split_variant:
+            try:
+                from chainer_faster_rcnn_amd.models.vgg16 import LAYERS as _L
+                res["f32_split_products"] = split_variant(args, torch, rt, params, x, dbg, sum(conv_flops(_L, IM_H, IM_W)[0].values()))
+            except Exception as e:
+                res["f32_split_products"] = {"error": repr(e)}
+                torch.cuda.synchronize()
         print(json.dumps(res))
     if dist is not None:
         dist.barrier()

@@ -141,9 +141,15 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
             for (int p = 0; p < kParts; ++p)
 #pragma unroll
                 for (int kx = 0; kx < KS; ++kx) {
+                    if constexpr ((ABL & 8) != 0) {                   // no fragment reads: the MFMA ceiling of this loop
+                        a[p][kx] = make_uint4(lane + p, kx, ky, stage);
+#pragma unroll
+                        for (int j = 0; j < RW; ++j) b[p][j][kx] = make_uint4(lane + j, kx, p, ky);
+                    } else {
                     a[p][kx] = *reinterpret_cast<const uint4 *>(st + a_off + (p * W_ROWS + (ky * KS + kx) * BCO) * 32);
 #pragma unroll
                     for (int j = 0; j < RW; ++j) b[p][j][kx] = *reinterpret_cast<const uint4 *>(st + b_off[ky + j][kx] + p * IN_ROWS_P * 32);
+                    }
                 }
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
@@ -321,6 +327,132 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
     }
 }
 
+// First layer (Cin * 9 <= 32: conv1_1, 3 channels): the fp32 NCHW image goes in as it is.  K = (ci, tap) padded to 32 = two MFMA
+// k-steps; the weight fragments (64 couts x 32 k, three parts) live in registers for the whole kernel; a workgroup holds the fp32
+// halo of an 8-row x 64-px tile in LDS (8 KB), each wave builds the im2col B fragments of a 32-px row segment from it (16 ds_read_b32,
+// the 3-way split in registers) -- 24 MFMAs per 32 px x 64 couts -- and writes the split output straight from the accumulators
+// (8-byte pieces: 4 consecutive couts of a pixel).  The generic kernel would stage 74 KB per tile for 3 real channels and run
+// 108 MFMAs per 2 rows: 131 us on the 600x1000 image; this one is bound by its 230 MB of output.
+template <int NCB>                                   // cout blocks of 32
+__global__ void __launch_bounds__(256)
+conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, uint16_t *__restrict__ y, int Cin,
+                  int Cout, int H, int W, int relu) {
+    constexpr int TR = 8, TW = 64, HR = TR + 2, PITCH = TW + 4;        // LDS row: 66 used of 68 floats
+    constexpr int CMAX = 3;
+    __shared__ float xt[CMAX * HR * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
+    const int K = Cin * 9;
+    // ---- halo tile (zero outside the image and for channels >= Cin)
+    for (int e = tid; e < CMAX * HR * (TW + 2); e += 256) {
+        const int ci = e / (HR * (TW + 2)), rem = e - ci * (HR * (TW + 2));
+        const int r = rem / (TW + 2), c = rem - r * (TW + 2);
+        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
+        xt[(ci * HR + r) * PITCH + c] = (ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((size_t)ci * H + gy) * W + gx] : 0.0f;
+    }
+    // ---- weight fragments: lane (cout l31 of block cb, k = 16 s + 8 khalf + e), k = ci * 9 + tap; the three parts of (Cout, K) fp32
+    uint4 a[NCB][2][kParts];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            uint32_t hp[4], mp[4], lp[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int k = 16 * s2 + 8 * khalf + 2 * e, co = cb * 32 + l31;
+                const float w0 = (co < Cout && k < K) ? w[(size_t)co * K + k] : 0.0f;
+                const float w1 = (co < Cout && k + 1 < K) ? w[(size_t)co * K + k + 1] : 0.0f;
+                split3_pair(w0, w1, hp[e], mp[e], lp[e]);
+            }
+            a[cb][s2][0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+            a[cb][s2][1] = make_uint4(mp[0], mp[1], mp[2], mp[3]);
+            a[cb][s2][2] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+        }
+    // ---- per-lane LDS offsets of the 16 im2col elements (floats), relative to (row 2 * wave, column 0) of the tile
+    int boff[2][8];
+    bool bval[2][8];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = 16 * s2 + 8 * khalf + e;
+            const int kk = k < K ? k : 0;
+            const int ci = kk / 9, tap = kk - ci * 9, ky = tap / 3, kx = tap - ky * 3;
+            bval[s2][e] = k < K;
+            boff[s2][e] = (ci * HR + 2 * wave + ky) * PITCH + kx + l31;
+        }
+    __syncthreads();
+    const int CoutP = (Cout + 15) / 16 * 16;
+    const size_t y_part = (size_t)CoutP * H * W;
+    // ---- units: wave w owns tile rows 2w, 2w + 1, two 32-px segments each
+#pragma unroll 1
+    for (int u = 0; u < 4; ++u) {
+        const int i = u >> 1, seg = u & 1;
+        const int py = y0 + 2 * wave + i, px = x0 + seg * 32 + l31;
+        if (py >= H || x0 + seg * 32 >= W) continue;                   // wave-uniform
+        uint4 b[2][kParts];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = xt[boff[s2][e] + i * PITCH + seg * 32];
+                v[e] = bval[s2][e] ? t : 0.0f;                         // k >= K: the weight is zero, but 0 x garbage must stay 0
+            }
+            uint32_t hp[4], mp[4], lp[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split3_pair(v[2 * e], v[2 * e + 1], hp[e], mp[e], lp[e]);
+            b[s2][0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+            b[s2][1] = make_uint4(mp[0], mp[1], mp[2], mp[3]);
+            b[s2][2] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+        }
+        frcnn_f32x16 acc[NCB], acs[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[cb][r] = acs[cb][r] = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acs[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][2], b[s2][0], acs[cb]);     // l.h
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][1], b[s2][0], acc[cb]);     // m.h
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acs[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][2], acs[cb]);     // h.l
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][1], acc[cb]);     // h.m
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acs[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][1], b[s2][1], acs[cb]);     // m.m
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][0], acc[cb]);     // h.h
+        }
+        if (px >= W) continue;                                         // (after the MFMAs: they need the whole wave)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = cb * 32 + 8 * g + 4 * khalf;            // first of four consecutive couts
+                float v[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    v[t] = (acc[cb][4 * g + t] + acs[cb][4 * g + t]) + (co + t < Cout ? bias[co + t] : 0.0f);
+                    if (relu) v[t] = fmaxf(v[t], 0.0f);
+                }
+                uint32_t hp[2], mp[2], lp[2];
+                split3_pair(v[0], v[1], hp[0], mp[0], lp[0]);
+                split3_pair(v[2], v[3], hp[1], mp[1], lp[1]);
+                if (co < CoutP) {
+                    uint16_t *o = y + (((size_t)(co >> 4) * H + py) * W + px) * 16 + (co & 15);
+                    *reinterpret_cast<uint2 *>(o) = make_uint2(hp[0], hp[1]);
+                    *reinterpret_cast<uint2 *>(o + y_part) = make_uint2(mp[0], mp[1]);
+                    *reinterpret_cast<uint2 *>(o + 2 * y_part) = make_uint2(lp[0], lp[1]);
+                }
+            }
+    }
+}
+
 // (Cout, Cin, 3, 3) fp32 -> [3 parts][CinP/16][tap][CoutP][16] bf16, zero padded
 __global__ void __launch_bounds__(256)
 pack_w_f32s_kernel(const float *__restrict__ w, int Cout, int Cin, int taps, int CoutP, int CinP, uint16_t *__restrict__ wp) {
@@ -400,6 +532,14 @@ int frcnn_f32s_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, voi
     return frcnn_launch_status();
 }
 
+int frcnn_conv1_f32s(const float *x, const float *w, const float *bias, uint16_t *y, int Cin, int Cout, int H, int W, int relu, void *stream) {
+    if (!x || !w || !bias || !y || Cin < 1 || Cin > 3 || Cout < 1 || Cout > 64 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    const dim3 grid(frcnn_cdiv(W, 64), frcnn_cdiv(H, 8));
+    if (Cout > 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu);
+    return frcnn_launch_status();
+}
+
 constexpr size_t kF32sCounterPageBytes = 64 * 1024;
 
 // split-K factor: launches that leave most of the chip's 2 x CUs workgroup slots empty split their K range (FRCNN_F32S_SPLIT overrides)
@@ -450,6 +590,8 @@ int frcnn_conv3x3_f32s_ws(const uint16_t *x, const uint16_t *w_packed, const flo
         case 1: FRCNN_F32S_LAUNCH(2, 1); break;
         case 4: FRCNN_F32S_LAUNCH(2, 4); break;
         case 5: FRCNN_F32S_LAUNCH(2, 5); break;
+        case 9: FRCNN_F32S_LAUNCH(2, 9); break;
+        case 8: FRCNN_F32S_LAUNCH(2, 8); break;
         case 21: FRCNN_F32S_LAUNCH(1, 1, 2); break;
 #endif
         case 20: FRCNN_F32S_LAUNCH(1, 0, 2); break;              // two-stage ring, one workgroup per CU (measured slower: kept for A/B runs)

@@ -153,7 +153,7 @@ class VGG16Prev(object):
         convolution (six bf16 MFMA products, fp32 accumulation, bias / ReLU / max-pool in fp32, result split again) -> conv5_3 back
         as fp32 NCHW (h + m + l: exact)."""
         rt = self.rt
-        h = rt.f32s_from_nchw(x)
+        h = None                             # the image is split lazily: a first layer with <= 3 input channels reads it as fp32 NCHW
         n_pool, cout, skip = 0, int(x.shape[1]), False
         as_nchw = lambda t, c: rt.f32s_to_nchw(t, c)
         for idx, l in enumerate(self.layers):
@@ -162,6 +162,8 @@ class VGG16Prev(object):
                 if skip:
                     skip = False
                     continue
+                if h is None:
+                    h = rt.f32s_from_nchw(x)
                 h = rt.f32s_from_nchw(rt.maxpool2x2(as_nchw(h, cout)))        # unfused pool (tests only): through fp32 NCHW
                 if timer:
                     timer.mark("pool%d" % n_pool)
@@ -169,7 +171,13 @@ class VGG16Prev(object):
                     collect["pool%d" % n_pool] = as_nchw(h, cout)
             else:
                 fuse = self.fuse_pool and idx + 1 < len(self.layers) and self.layers[idx + 1] == "pool"
-                h = self.links[l[0]].f32s(h, relu=True, pool=fuse)
+                link = self.links[l[0]]
+                if h is None and not fuse and l[1] <= 3 and l[2] <= 64 and not getattr(self, "generic_first_layer", False):
+                    h = rt.conv1_f32s(x, link.W, link.b, relu=True)           # conv1_1: straight from the fp32 NCHW image
+                else:
+                    if h is None:
+                        h = rt.f32s_from_nchw(x)
+                    h = link.f32s(h, relu=True, pool=fuse)
                 skip = fuse
                 cout = l[2]
                 if timer:

@@ -209,6 +209,10 @@ int frcnn_f32s_from_nchw_f32(const float *x, int C, int H, int W, uint16_t *y, v
 int frcnn_f32s_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, void *stream);
 int frcnn_conv3x3_f32s(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
                        int W, int relu, int out_mode, void *stream);
+/* first layer (Cin <= 3, Cout <= 64; models/vgg16.py:39 conv1_1): x = the fp32 NCHW image, w = Chainer's (Cout,Cin,3,3) fp32 as it
+ * is, y = split tensor (CoutP, H, W) */
+int frcnn_conv1_f32s(const float *x, const float *w, const float *bias, uint16_t *y, int Cin, int Cout, int H, int W, int relu,
+                     void *stream);
 /* the same with a workspace (frcnn_conv_f32s_workspace_bytes; its first 64 KB zeroed ONCE by frcnn_conv_f32s_workspace_init --
  * every launch leaves them zero): lets launches with few tiles (38x63 maps) split their K range over several workgroups */
 size_t frcnn_conv_f32s_workspace_bytes(int Cin, int Cout, int H, int W);

@@ -548,6 +548,26 @@ def check_conv_f32s(rt, Cin, Cout, H, W, relu=True, seed=0, tol=3e-6):
         assert np.array_equal(host(rt, rt.f32s_to_nchw(yp, Cout)), O.max_pool_2x2(y))
 
 
+def check_conv1_f32s(rt, Cin, Cout, H, W, relu=True, seed=0):
+    """First-layer form (fp32 NCHW image in, split tensor out): against a float64 convolution and against the generic split kernel."""
+    import torch
+    rs = np.random.RandomState(seed)
+    x = (rs.randn(1, Cin, H, W) * 60).astype(np.float32)                    # mean-subtracted pixel magnitudes
+    w = (rs.randn(Cout, Cin, 3, 3) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    b = (rs.randn(Cout) * 0.1).astype(np.float32)
+    want64 = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1).numpy()
+    if relu:
+        want64 = np.maximum(want64, 0)
+    ys = rt.conv1_f32s(dev(rt, x), dev(rt, w), dev(rt, b), relu=relu)
+    got = host(rt, rt.f32s_to_nchw(ys, Cout))
+    scale = np.abs(want64).max()
+    assert np.abs(got - want64).max() <= 1e-6 * scale, np.abs(got - want64).max() / scale
+    if rt.bf16_pad(Cout) != Cout:
+        assert not blocked_to_hwc(host(rt, ys)[0])[:, :, Cout:].any()
+    gen = host(rt, rt.conv3x3_f32s(rt.f32s_from_nchw(dev(rt, x)), rt.f32s_pack_conv_w(dev(rt, w)), dev(rt, b), Cin, Cout, relu=relu, out_f32_nchw=True))
+    assert np.abs(got - gen).max() <= 1e-6 * scale
+
+
 def rel_err(got, want):
     want = np.asarray(want, dtype=np.float32)
     return float(np.abs(np.asarray(got, dtype=np.float32) - want).max() / max(float(np.abs(want).max()), 1e-30))
@@ -572,8 +592,11 @@ def check_f32s_pipeline_small(rt, im_h=22, im_w=37):
         h, score, prob, bbox = model.RPN.heads(feat, want_score=True, x_split=xs)
         outs[dt] = [host(rt, t) for t in (feat, h, prob, bbox)]
         if dt == "f32s":
-            model.trunk.fuse_pool = False                              # the unfused pool path agrees with the fused one exactly
+            model.trunk.fuse_pool = False                              # the unfused pool path agrees with the fused one exactly ...
+            model.trunk.generic_first_layer = True
             assert np.array_equal(host(rt, model.trunk(dev(rt, x))), outs[dt][0])
+            model.trunk.generic_first_layer = False                    # ... and the first-layer kernel (fp32 NCHW image in) to rounding
+            assert rel_err(host(rt, model.trunk(dev(rt, x))), outs[dt][0]) <= 2e-6
     h_ = x
     for l in T.SMALL_LAYERS:
         h_ = O.max_pool_2x2(h_) if l == "pool" else O.relu(O.conv2d(h_, params["trunk/%s/W" % l[0]], params["trunk/%s/b" % l[0]], 1))

@@ -442,3 +442,9 @@ def test_conv_f32s_split_bf16(rt):
 
 def test_f32s_pipeline_small(rt):
     P.check_f32s_pipeline_small(rt, im_h=90, im_w=131)
+
+
+def test_conv1_f32s_first_layer(rt):
+    P.check_conv1_f32s(rt, 3, 64, 75, 203)
+    P.check_conv1_f32s(rt, 3, 64, 600, 1000, seed=2)
+    P.check_conv1_f32s(rt, 1, 24, 37, 65, relu=False, seed=1)

@@ -243,3 +243,8 @@ def test_conv_f32s_split_k(rt, monkeypatch, split):
 
 def test_f32s_pipeline_small(rt):
     P.check_f32s_pipeline_small(rt)
+
+
+def test_conv1_f32s_first_layer(rt):
+    P.check_conv1_f32s(rt, 3, 64, 11, 70)                  # two x tiles (64 + 6 px), two y tiles, ragged rows
+    P.check_conv1_f32s(rt, 1, 24, 5, 33, relu=False, seed=1)   # one channel (K = 9), 24 couts: one block, padded to 32
