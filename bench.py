@@ -241,7 +241,7 @@ def split_variant(args, torch, rt, params, x, dbg, flops_total):
     forward.  Reported next to the native-fp32-MFMA contract line, not instead of it."""
     from chainer_faster_rcnn_amd.graph import CapturedForward
     from chainer_faster_rcnn_amd.models import FasterRCNN
-    model = FasterRCNN(runtime=rt, conv_dtype="f32s")
+    model = FasterRCNN(runtime=rt, conv_dtype="f32s", head_dtype="f32s")
     model.load_params(params)
     for _ in range(max(args.warmup, 3)):
         model.forward_device(x, IM_H, IM_W)
@@ -255,8 +255,8 @@ def split_variant(args, torch, rt, params, x, dbg, flops_total):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     out = {"what": ("fp32 tensors and results; every 3x3 convolution = six v_mfma_f32_32x32x16_bf16 products of 3-way split fp32 operands "
-                    "(h.h, h.m, m.h, h.l, l.h, m.m; dropped terms < 2^-24 of a product), fp32 accumulation; head / proposals / RoI pooling "
-                    "as in the contract line.  `python bench.py --dtype f32s` prints this variant as its own line."),
+                    "(h.h, h.m, m.h, h.l, l.h, m.m; dropped terms < 2^-24 of a product), fp32 accumulation, and the four fully connected layers "
+                    "likewise; proposals / RoI pooling / decode as in the contract line.  `python bench.py --dtype f32s` prints this variant as its own line."),
            "value": args.steps / dt, "unit": "img/s", "ms_per_step": dt / args.steps * 1e3, "steps": args.steps, "launch": "hipGraph replay"}
     try:
         conv_ms = graph_time_us(torch, f32s_conv_chain(rt, model, x), 1, max(args.steps, 100)) / 1e3
@@ -413,8 +413,8 @@ def main():
     rt = pkg.runtime.Runtime(pkg._lib.load(), pkg.runtime.TorchDeviceMemory("cuda:%d" % local_rank))
     params = synthetic.params(seed=1)
     # f32s: the fp32 network of configs[1] with every 3x3 convolution computed as six bf16 MFMA products of 3-way split fp32
-    # operands (fp32 accumulation; csrc/conv_f32s.hip); head, proposals, RoI pooling as in f32
-    model = FasterRCNN(runtime=rt, conv_dtype=args.dtype, head_dtype="f32" if args.dtype == "f32s" else args.dtype)
+    # operands (fp32 accumulation; csrc/conv_f32s.hip), the four fully connected layers likewise; proposals, RoI pooling, decode as in f32
+    model = FasterRCNN(runtime=rt, conv_dtype=args.dtype, head_dtype=args.dtype)
     model.load_params(params)
     x_host = synthetic.image(seed=rank, h=IM_H, w=IM_W)          # every rank its own image (1 img / GPU)
     x = rt.mem.from_numpy(x_host)
@@ -540,8 +540,8 @@ def main():
                "config": {"workload": ("VGG16 inference, 1xMI355X per image, batch 1, 300 proposals post-NMS, fp32 "
                                        "(BASELINE.json configs[1]); 1 image per GPU per step") if args.dtype == "f32" else
                                       ("VGG16 inference, 1xMI355X per image, batch 1, 300 proposals post-NMS, fp32 tensors and results "
-                                       "(BASELINE.json configs[1]); the 14 3x3 convolutions run as six bf16 MFMA products of 3-way split fp32 "
-                                       "operands with fp32 accumulation (dropped terms < 2^-24 of a product)") if args.dtype == "f32s" else
+                                       "(BASELINE.json configs[1]); the 14 3x3 convolutions and the 4 fully connected layers run as six bf16 MFMA products of "
+                                       "3-way split fp32 operands with fp32 accumulation (dropped terms < 2^-24 of a product)") if args.dtype == "f32s" else
                                       ("VGG16 inference, data-parallel 1 img/GPU, bf16 convs + bf16 FC head (fp32 accumulate) / fp32 proposals, "
                                        "RoI pooling, decode (BASELINE.json configs[2])"),
                           "image": "1x3x600x1000", "global_batch": world, "launch": "hipGraph replay" if use_graph else "eager", "parallelism": "dp%d (images sharded, no collective)" % world,

@@ -296,7 +296,7 @@ template <int NS, int WPS, int RPW = 1, int ABL = 0>   // ABL: 1 no DMA, 4 no co
 __global__ void __launch_bounds__(256, WPS)
 conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
                      int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles, int nsplit,
-                     float *__restrict__ partial_ws, int *__restrict__ tile_counters) {
+                     float *__restrict__ partial_ws, int *__restrict__ tile_counters, int xcd_cotiles) {
     constexpr int KS = 3, TAPS = 9, PAD = 1;
     constexpr int COB = RPW >= 3 ? 2 : 1;                       // cout blocks per wave
     constexpr int RW = RPW == 1 ? 2 : (RPW == 2 ? 4 : (RPW == 3 ? 2 : 4));
@@ -321,7 +321,17 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
     // split-K for launches with fewer tiles than the chip has room for (the 38x63 maps: 160 tiles on 256 CUs): `nsplit`
     // consecutive workgroups share a tile, each takes a contiguous range of the K-chunks, the last to finish sums the
     // pieces in split order (deterministic) and runs the epilogue -- the stream-K fix-up of conv.hip, with fixed ranges
-    const int tile = blockIdx.x / nsplit, split = blockIdx.x - tile * nsplit;
+    int tile = blockIdx.x / nsplit, split = blockIdx.x - tile * nsplit;
+    if (xcd_cotiles > 0) {
+        // XCD-aware order (launches with 1, 2, 4 or 8 cout tiles): workgroups are dealt to the 8 XCDs round-robin, so XCD x works on
+        // cout tile x % cotiles only -- its L2 holds ONE 64-cout weight slab instead of all of them (conv_f32s.hip measured 5-10 %)
+        const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3, G = 8 / xcd_cotiles;
+        const int u = j * G + xcd / xcd_cotiles;                   // (pixel tile, K split) unit of this XCD's cout tile
+        const int pt = u / nsplit;
+        if (pt >= xtiles * ytiles) return;                       // (the grid is padded to a multiple of 8)
+        split = u - pt * nsplit;
+        tile = (xcd % xcd_cotiles) * xtiles * ytiles + pt;
+    }
     const int tx = tile % xtiles, ty = (tile / xtiles) % ytiles, cot = tile / (xtiles * ytiles);
     const int x0 = tx * 32, y0 = ty * BROWS, co0 = cot * BCO;
     const int all_chunks = CinP / kCK;
@@ -669,16 +679,22 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
     int *counters = nsplit > 1 ? (int *)workspace : nullptr;
     if (ksize == 3 && big) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3, 4>), grid, dim3(512), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
     else if (ksize == 3 && mode > 0) {
-        const dim3 dgrid((unsigned)(dma_tiles * nsplit));
+        dim3 dgrid((unsigned)(dma_tiles * nsplit));
+        int xcd_cotiles = 0;
+        const char *xcd_env = getenv("FRCNN_BF16_XCD");               // 1 enables: measured 1.5 % SLOWER on the VGG chain here (r02n), so off
+        if ((cotiles == 1 || cotiles == 2 || cotiles == 4 || cotiles == 8) && xcd_env && xcd_env[0] == '1') {
+            xcd_cotiles = cotiles;
+            dgrid = dim3((unsigned)(8 * frcnn_cdiv((int)((long)xtiles * yt * nsplit), 8 / cotiles)));
+        }
 #define FRCNN_DMA_CASE(NS, WPS, RPW)                                                                                                     \
     case NS * 100 + WPS * 10 + RPW:                                                                                                      \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dma_bf16_kernel<NS, WPS, RPW>), dgrid, dim3(256), 0, stream, x, w_packed, bias, y, CinP,  \
-                           Cout, CoutP, H, W, relu, out_mode, xtiles, yt, nsplit, partials, counters);                                    \
+                           Cout, CoutP, H, W, relu, out_mode, xtiles, yt, nsplit, partials, counters, xcd_cotiles);                       \
         break;
 #define FRCNN_DMA_ABL(NS, WPS, A)                                                                                                        \
     case NS * 1000 + WPS * 100 + 10 + A:                                                                                                 \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_dma_bf16_kernel<NS, WPS, 1, A>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP,   \
-                           Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, 1, nullptr, nullptr);                                       \
+                           Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, 1, nullptr, nullptr, 0);                                    \
         break;
         switch (mode) {
             FRCNN_DMA_CASE(3, 2, 1) FRCNN_DMA_CASE(2, 3, 1) FRCNN_DMA_CASE(1, 4, 1) FRCNN_DMA_CASE(1, 3, 2) FRCNN_DMA_CASE(2, 2, 2)

@@ -46,7 +46,7 @@ template <int WPS, int ABL = 0, int NS = 1>
 __global__ void __launch_bounds__(256, WPS)
 conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
                  int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles, int nsplit,
-                 float *__restrict__ partial_ws, int *__restrict__ tile_counters) {
+                 float *__restrict__ partial_ws, int *__restrict__ tile_counters, int xcd_cotiles) {
     constexpr int KS = 3, TAPS = 9, PAD = 1;
     constexpr int RW = 2, BROWS = 4, BCO = 64;
     constexpr int HR = BROWS + KS - 1, HPX = 32 + KS - 1;
@@ -70,7 +70,18 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
     // split-K for launches with fewer tiles than the chip has room for (the 38x63 maps: 160 tiles, 512 workgroup slots): `nsplit`
     // consecutive workgroups share a tile, each takes a contiguous range of the K-chunks, the last to finish sums the pieces in
     // split order (deterministic) and runs the epilogue
-    const int tile = blockIdx.x / nsplit, split = blockIdx.x - tile * nsplit;
+    int tile = blockIdx.x / nsplit;
+    int split = blockIdx.x - tile * nsplit;
+    if (xcd_cotiles > 0) {
+        // XCD-aware order (launches with 1, 2, 4 or 8 cout tiles): workgroups are dealt to the 8 XCDs round-robin, so
+        // XCD x works on cout tile x % cotiles only -- its L2 holds ONE 64-cout weight slab (<= 1.8 MB) instead of all of them
+        const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3, G = 8 / xcd_cotiles;
+        const int u = j * G + xcd / xcd_cotiles;                   // (pixel tile, K split) unit of this XCD's cout tile
+        const int pt = u / nsplit;
+        if (pt >= xtiles * ytiles) return;                       // (the grid is padded to a multiple of 8)
+        split = u - pt * nsplit;
+        tile = (xcd % xcd_cotiles) * xtiles * ytiles + pt;
+    }
     const int tx = tile % xtiles, ty = (tile / xtiles) % ytiles, cot = tile / (xtiles * ytiles);
     const int x0 = tx * 32, y0 = ty * BROWS, co0 = cot * BCO;
     const int all_chunks = CinP / kCK;
@@ -581,10 +592,18 @@ int frcnn_conv3x3_f32s_ws(const uint16_t *x, const uint16_t *w_packed, const flo
     }
     float *partials = nsplit > 1 ? (float *)((char *)workspace + kF32sCounterPageBytes) : nullptr;
     int *counters = nsplit > 1 ? (int *)workspace : nullptr;
-    const dim3 grid((unsigned)(tiles * nsplit));
+    dim3 grid((unsigned)(tiles * nsplit));
+    int xcd_cotiles = 0;
+    // 1 enables.  Four back-to-back launches of one layer gain 5-10 % from it (r02j), the real 14-layer chain nothing (r02o: 2.131 vs
+    // 2.142 ms) -- between different layers the slabs are cold either way -- so the plain order stays the default
+    const char *xcd_env = getenv("FRCNN_F32S_XCD");
+    if ((cotiles == 1 || cotiles == 2 || cotiles == 4 || cotiles == 8) && xcd_env && xcd_env[0] == '1') {
+        xcd_cotiles = cotiles;
+        grid = dim3((unsigned)(8 * frcnn_cdiv(xtiles * ytiles * nsplit, 8 / cotiles)));
+    }
     const char *abl_env = getenv("FRCNN_F32S_ABL");
     const int abl = abl_env ? atoi(abl_env) : 0;
-#define FRCNN_F32S_LAUNCH(...) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<__VA_ARGS__>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, nsplit, partials, counters)
+#define FRCNN_F32S_LAUNCH(...) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<__VA_ARGS__>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, nsplit, partials, counters, xcd_cotiles)
     switch (abl) {
 #ifdef FRCNN_TIMING_ABLATIONS                                   // WRONG results: sweeps only, never shipped
         case 1: FRCNN_F32S_LAUNCH(2, 1); break;
@@ -604,6 +623,194 @@ int frcnn_conv3x3_f32s_ws(const uint16_t *x, const uint16_t *w_packed, const flo
 int frcnn_conv3x3_f32s(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H, int W, int relu, int out_mode,
                        void *stream) {
     return frcnn_conv3x3_f32s_ws(x, w_packed, bias, y, Cin, Cout, H, W, relu, out_mode, nullptr, 0, stream);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------
+// Fully connected layers on split tensors: y(M,N) = act(x(M,K) @ W(N,K)^T + b) in fp32, the products as six bf16 MFMAs of the 3-way
+// split operands (L.Linear + F.relu, /root/reference/models/faster_rcnn.py:33-36,127-134).  x and W are [3 parts][rows][K] bf16 (K
+// contiguous: a lane's eight consecutive k-values are one 16-byte read).  Workgroup = 4 waves along N: tile (32*AM) x 128, K panels of
+// 32 (64 B per row and part) through LDS-DMA -- 1 KB pieces of 16 rows, 16-byte group g of row r in slot 4r + (g ^ ((r >> 2) & 3)), so
+// the 16 lanes of a ds_read_b128 group (16 consecutive rows, one group index) fall on 16 distinct bank slots -- single-stage ring, two
+// workgroups per CU, split-K partial slabs + one reduce / bias / ReLU pass that can write the result split again.
+namespace {
+
+constexpr int kFK = 32;             // k per panel
+
+template <int AM>
+__global__ void __launch_bounds__(256, 2)
+linear_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ w, float *__restrict__ part, int M, int N, int K, int k_per_split) {
+    constexpr int BM = 32 * AM, BN = 128;
+    constexpr int XP = kParts * BM / 16, WP = kParts * BN / 16;   // 1 KB pieces (16 rows each)
+    constexpr int PIECES = XP + WP, PPW = (PIECES + 3) / 4;
+    constexpr int X_BYTES = XP * 1024, STAGE = PIECES * 1024;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int k_begin = blockIdx.z * k_per_split, k_end = min(K, k_begin + k_per_split);
+    const int nchunks = (k_end - k_begin) / kFK;             // whole panels: the host guarantees K % 32 == 0
+    const uint32_t x_part_bytes = (uint32_t)((size_t)M * K * 2), w_part_bytes = (uint32_t)((size_t)N * K * 2);
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, kParts * x_part_bytes);
+    const frcnn_buf_t wbuf = frcnn_make_buf(w, kParts * w_part_bytes);
+    // piece p of the x region: rows R = p * 16 .. + 15 of [part][BM]; of the w region likewise over [part][BN]
+    uint32_t poff[PPW];
+    bool isx[PPW];
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+        const int pid = wave + 4 * q;
+        isx[q] = pid < XP;
+        const int sl = (isx[q] ? pid : pid - XP) * 64 + lane, R = sl >> 2, g = (sl & 3) ^ ((R >> 2) & 3);
+        const int rows = isx[q] ? BM : BN;
+        const int p = R / rows, r = R - p * rows;
+        const int gr = (isx[q] ? m0 : n0) + r;
+        const bool ok = pid < PIECES && p < kParts && gr < (isx[q] ? M : N);
+        poff[q] = ok ? (uint32_t)p * (isx[q] ? x_part_bytes : w_part_bytes) + (uint32_t)(((size_t)gr * K + k_begin + 8 * g) * 2) : kBufOob;
+    }
+    auto issue = [&](int chunk) {
+        unsigned char *dst = lds + wave * 1024;
+        const uint32_t so = (uint32_t)chunk * (kFK * 2);
+#pragma unroll
+        for (int q = 0; q < PPW; ++q)
+            if (4 * q + 3 < PIECES || wave + 4 * q < PIECES) frcnn_buf_load_lds_b128(isx[q] ? xbuf : wbuf, dst + q * 4096, poff[q], so);
+    };
+    frcnn_f32x16 acc[AM];
+#pragma unroll
+    for (int i = 0; i < AM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    // fragment offsets: row r of a region, k-step ks -> group 2 ks + khalf
+    auto frag_off = [&](int r, int ks) { return (uint32_t)(r * 64 + (((2 * ks + khalf) ^ ((r >> 2) & 3)) << 4)); };
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        issue(chunk);
+        frcnn_wait_vmcnt<0>();
+        frcnn_barrier_nofence();
+#pragma unroll
+        for (int ks = 0; ks < kFK / 16; ++ks) {
+            uint4 b[kParts];
+#pragma unroll
+            for (int p = 0; p < kParts; ++p) b[p] = *reinterpret_cast<const uint4 *>(lds + X_BYTES + frag_off(p * BN + wave * 32 + l31, ks));
+#pragma unroll
+            for (int i = 0; i < AM; ++i) {
+                uint4 a[kParts];
+#pragma unroll
+                for (int p = 0; p < kParts; ++p) a[p] = *reinterpret_cast<const uint4 *>(lds + frag_off(p * BM + 32 * i + l31, ks));
+                acc[i] = frcnn_mfma_32x32x16_bf16(a[2], b[0], acc[i]);     // l.h
+                acc[i] = frcnn_mfma_32x32x16_bf16(a[0], b[2], acc[i]);     // h.l
+                acc[i] = frcnn_mfma_32x32x16_bf16(a[1], b[1], acc[i]);     // m.m
+                acc[i] = frcnn_mfma_32x32x16_bf16(a[1], b[0], acc[i]);     // m.h
+                acc[i] = frcnn_mfma_32x32x16_bf16(a[0], b[1], acc[i]);     // h.m
+                acc[i] = frcnn_mfma_32x32x16_bf16(a[0], b[0], acc[i]);     // h.h
+            }
+        }
+        if (chunk + 1 < nchunks) frcnn_barrier_nofence();         // everybody is done reading before the stage is refilled
+    }
+    float *out = part + (size_t)blockIdx.z * M * N;
+    const int n = n0 + wave * 32 + l31;
+    if (n < N) {
+#pragma unroll
+        for (int i = 0; i < AM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (m < M) out[(size_t)m * N + n] = acc[i][r];
+            }
+    }
+}
+
+// sum of the split-K slabs + bias (+ ReLU) -> fp32 (out_split 0) or the three bf16 parts [3][M][N] (out_split 1)
+__global__ void __launch_bounds__(256)
+linear_reduce_f32s_kernel(const float *__restrict__ part, const float *__restrict__ bias, void *__restrict__ y, int M, int N, int splits, int relu, int out_split) {
+    const size_t total = (size_t)M * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.0f;
+        for (int s = 0; s < splits; ++s) v += part[(size_t)s * total + i];
+        v += bias[i % N];
+        if (relu) v = fmaxf(v, 0.0f);
+        if (out_split) {
+            uint32_t h, m, l;
+            split3_pair(v, 0.0f, h, m, l);
+            uint16_t *o = reinterpret_cast<uint16_t *>(y);
+            o[i] = (uint16_t)h; o[total + i] = (uint16_t)m; o[2 * total + i] = (uint16_t)l;
+        } else reinterpret_cast<float *>(y)[i] = v;
+    }
+}
+
+// flat fp32 array -> [3][n] bf16 parts, and back (h + m + l: exact)
+__global__ void __launch_bounds__(256)
+f32s_split_kernel(const float *__restrict__ x, size_t n, uint16_t *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t h, m, l;
+        split3_pair(x[i], 0.0f, h, m, l);
+        y[i] = (uint16_t)h; y[n + i] = (uint16_t)m; y[2 * n + i] = (uint16_t)l;
+    }
+}
+__global__ void __launch_bounds__(256)
+f32s_join_kernel(const uint16_t *__restrict__ x, size_t n, float *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = (__uint_as_float((uint32_t)x[i] << 16) + __uint_as_float((uint32_t)x[n + i] << 16)) + __uint_as_float((uint32_t)x[2 * n + i] << 16);
+}
+
+struct LinPlanS { int am, mblocks, nblocks, splits, k_per_split; };
+static LinPlanS plan_linear_f32s(int M, int N, int K) {
+    LinPlanS p;
+    p.am = (M > 96) ? 5 : (M > 32 ? 3 : 1);
+    p.mblocks = frcnn_cdiv(M, 32 * p.am);
+    p.nblocks = frcnn_cdiv(N, 128);
+    const int tiles = p.mblocks * p.nblocks, kchunks = K / kFK;
+    int splits = frcnn_cdiv(2 * frcnn_cu_count(), tiles);          // two workgroups per CU
+    if (splits > kchunks / 8) splits = kchunks / 8;
+    if (splits < 1) splits = 1;
+    if (splits > 64) splits = 64;
+    p.k_per_split = frcnn_cdiv(kchunks, splits) * kFK;
+    p.splits = frcnn_cdiv(K, p.k_per_split);
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int frcnn_f32s_split(const float *x, size_t n, uint16_t *y, void *stream) {
+    if (n == 0) return FRCNN_OK;
+    if (!x || !y) return FRCNN_ERR_INVALID;
+    const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(f32s_split_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, y);
+    return frcnn_launch_status();
+}
+
+int frcnn_f32s_join(const uint16_t *x, size_t n, float *y, void *stream) {
+    if (n == 0) return FRCNN_OK;
+    if (!x || !y) return FRCNN_ERR_INVALID;
+    const int blocks = (int)((n + 255) / 256 < 16384 ? (n + 255) / 256 : 16384);
+    hipLaunchKernelGGL(f32s_join_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, y);
+    return frcnn_launch_status();
+}
+
+size_t frcnn_linear_f32s_workspace_bytes(int M, int N, int K) {
+    if (M < 1 || N < 1 || K < 1) return 0;
+    const LinPlanS p = plan_linear_f32s(M, N, K);
+    return frcnn_align256((size_t)p.splits * M * N * sizeof(float));
+}
+
+int frcnn_linear_f32s(const uint16_t *x, const uint16_t *w, const float *bias, void *y, int M, int N, int K, int relu, int out_split, void *workspace,
+                      size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !w || !bias || !y || M < 1 || N < 1 || K < 1 || (K % kFK) != 0) return FRCNN_ERR_INVALID;
+    if ((size_t)kParts * M * K * 2 >= (1ull << 31) || (size_t)kParts * N * K * 2 >= (1ull << 31)) return FRCNN_ERR_INVALID;
+    const LinPlanS p = plan_linear_f32s(M, N, K);
+    if (!workspace || workspace_bytes < (size_t)p.splits * M * N * sizeof(float)) return FRCNN_ERR_INVALID;
+    float *part = (float *)workspace;
+    const dim3 grid(p.nblocks, p.mblocks, p.splits);
+    if (p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_f32s_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    else if (p.am == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_f32s_kernel<3>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_f32s_kernel<1>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    const size_t total = (size_t)M * N;
+    const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(linear_reduce_f32s_kernel, dim3(blocks), dim3(256), 0, stream, part, bias, y, M, N, p.splits, relu, out_split);
+    return frcnn_launch_status();
 }
 
 }  // extern "C"

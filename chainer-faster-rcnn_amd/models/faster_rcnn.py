@@ -37,12 +37,18 @@ class Linear(object):
     def refresh_bf16(self):
         if self.dtype == "bf16":
             self.Wb = self.rt.to_bf16(self.W)              # raw bf16 bits, (out, in): K-contiguous for the MFMA B operand
+        elif self.dtype == "f32s":
+            self.Ws = self.rt.f32s_split(self.W)           # the three bf16 terms of every fp32 weight, (3, out, in)
 
     def __call__(self, x, relu=False):
         return self.rt.linear(x, self.W, self.b, relu=relu)
 
     def bf16(self, x_bits, relu=False, out_bf16=False):
         return self.rt.linear_bf16(x_bits, self.Wb, self.b, relu=relu, out_bf16=out_bf16)
+
+    def f32s(self, x_parts, relu=False, out_split=False):
+        """The fp32 layer as six bf16 MFMA products of the 3-way split operands (csrc/conv_f32s.hip); x (3,M,K) split tensor."""
+        return self.rt.linear_f32s(x_parts, self.Ws, self.b, relu=relu, out_split=out_split)
 
 
 class FasterRCNN(object):
@@ -53,7 +59,9 @@ class FasterRCNN(object):
                  conv_dtype="f32", head_dtype="f32"):
         """conv_dtype: "f32" = BASELINE config 2 (fp32 everywhere); "bf16" = config 3 (trunk + RPN convolutions in bf16 on
         v_mfma_f32_32x32x16_bf16; proposals and RoI pooling in fp32).  head_dtype: the four L.Linear layers of the RCNN
-        head, "f32" or "bf16" (bf16 operands, fp32 accumulation; box decoding and the class softmax stay fp32)."""
+        head, "f32" or "bf16" (bf16 operands, fp32 accumulation; box decoding and the class softmax stay fp32).  "f32s" (either): the
+        fp32 layers computed as six bf16 MFMA products of 3-way split fp32 operands, fp32 accumulation (csrc/conv_f32s.hip) -- fp32
+        tensors and fp32-class results on the bf16 matrix cores."""
         self.rt = runtime or default_runtime()
         self.conv_dtype, self.head_dtype = conv_dtype, head_dtype
         self.trunk = trunk_class(runtime=self.rt, conv_dtype=conv_dtype) if conv_dtype != "f32" else trunk_class(runtime=self.rt)
@@ -179,7 +187,15 @@ class FasterRCNN(object):
             pool5 = rt.roi_pool_fwd_chw(feat, rois, 7, 7, self._spatial_scale)    # rois (R,4): concat (:123-124) folded in
             pool5_bits = None
         mark("roi_pool")
-        if self.head_dtype == "bf16":
+        if self.head_dtype == "f32s":
+            fc6 = self.fc6.f32s(rt.f32s_split(pool5.reshape(int(pool5.shape[0]), -1)), relu=True, out_split=True)
+            mark("fc6")
+            fc7 = self.fc7.f32s(fc6, relu=True, out_split=True)
+            mark("fc7")
+            head = self.head_out.f32s(fc7)
+            if keep:
+                fc6, fc7 = rt.f32s_join(fc6), rt.f32s_join(fc7)
+        elif self.head_dtype == "bf16":
             if pool5_bits is None:
                 pool5_bits = rt.to_bf16(pool5.reshape(int(pool5.shape[0]), -1))
             fc6 = self.fc6.bf16(pool5_bits, relu=True, out_bf16=True)

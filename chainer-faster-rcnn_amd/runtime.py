@@ -387,6 +387,31 @@ class Runtime(object):
         _lib.check(L.frcnn_f32s_to_nchw_f32(m.ptr(x), int(C), H, W, m.ptr(y), m.stream()), "frcnn_f32s_to_nchw_f32")
         return y
 
+    def f32s_split(self, x):
+        """fp32 array -> its three bf16 terms, shape (3,) + x.shape (raw bits in an int16 array); h + m + l == x exactly."""
+        m, L = self.mem, self.lib
+        y = m.empty((3,) + tuple(int(v) for v in x.shape), "i16")
+        _lib.check(L.frcnn_f32s_split(m.ptr(x), int(np.prod(x.shape)), m.ptr(y), m.stream()), "frcnn_f32s_split")
+        return y
+
+    def f32s_join(self, parts):
+        m, L = self.mem, self.lib
+        y = m.empty(tuple(int(v) for v in parts.shape[1:]), "f32")
+        _lib.check(L.frcnn_f32s_join(m.ptr(parts), int(np.prod(parts.shape[1:])), m.ptr(y), m.stream()), "frcnn_f32s_join")
+        return y
+
+    def linear_f32s(self, x_parts, w_parts, bias, relu=False, out_split=False):
+        """x (3,M,K), w (3,N,K) split tensors, bias (N,) fp32 -> (M,N) fp32, or its parts (3,M,N) when out_split."""
+        m, L = self.mem, self.lib
+        M, K = int(x_parts.shape[1]), int(x_parts.shape[2])
+        N = int(w_parts.shape[1])
+        assert int(w_parts.shape[2]) == K and int(x_parts.shape[0]) == 3 and int(w_parts.shape[0]) == 3
+        y = m.empty((3, M, N), "i16") if out_split else m.empty((M, N), "f32")
+        ws = self.workspace("linear", L.frcnn_linear_f32s_workspace_bytes(M, N, K))
+        _lib.check(L.frcnn_linear_f32s(m.ptr(x_parts), m.ptr(w_parts), m.ptr(bias), m.ptr(y), M, N, K, int(bool(relu)), int(bool(out_split)),
+                                       m.ptr(ws), ws.shape[0], m.stream()), "frcnn_linear_f32s")
+        return y
+
     def conv1_f32s(self, x, w, bias, relu=True):
         """First layer: x (1,Cin<=3,H,W) fp32 NCHW, w (Cout<=64,Cin,3,3) fp32 -> split tensor [3][CoutP/16][H][W][16]."""
         m, L = self.mem, self.lib

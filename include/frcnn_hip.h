@@ -220,6 +220,15 @@ int frcnn_conv_f32s_workspace_init(void *workspace, size_t workspace_bytes, void
 int frcnn_conv3x3_f32s_ws(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
                           int W, int relu, int out_mode, void *workspace, size_t workspace_bytes, void *stream);
 
+/* fully connected layers on split tensors (L.Linear + F.relu, models/faster_rcnn.py:33-36,127-134): x = [3][M][K], w = [3][N][K]
+ * bf16 parts (frcnn_f32s_split of the fp32 (M,K) / (N,K) arrays), K % 32 == 0; y = (M,N) fp32, or its three parts [3][M][N] when
+ * out_split (the next layer's x).  frcnn_f32s_join: parts -> fp32 (h + m + l, exact). */
+int frcnn_f32s_split(const float *x, size_t n, uint16_t *y, void *stream);
+int frcnn_f32s_join(const uint16_t *x, size_t n, float *y, void *stream);
+size_t frcnn_linear_f32s_workspace_bytes(int M, int N, int K);
+int frcnn_linear_f32s(const uint16_t *x, const uint16_t *w, const float *bias, void *y, int M, int N, int K, int relu,
+                      int out_split, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ---- bf16 convolution stack (BASELINE config 3: bf16 convs / fp32 RoI) -----------------------------------
  * Same reference interface as the fp32 stack (L.Convolution2D + F.relu, F.MaxPooling2D: models/vgg16.py:39-68,
  * region_proposal_network.py:53-57); operands rounded to bf16 (nearest even), fp32 accumulation on

@@ -48,11 +48,10 @@ def main():
                 os.environ["FRCNN_F32S_ABL"] = abl
                 print("   ablation %s: %.1f us" % (abl, graph_us(f_split, 4, replays=10)))
         os.environ["FRCNN_F32S_ABL"] = "0"
-        for st in os.environ.get("STAGS", "").split(";"):
-            if st:
-                os.environ["FRCNN_F32S_STAGGER"] = st
-                print("   stagger %s: %.1f us" % (st, graph_us(f_split, 4, replays=10)))
-        os.environ.pop("FRCNN_F32S_STAGGER", None)
+        if os.environ.get("XCD_AB"):
+            os.environ["FRCNN_F32S_XCD"] = "0"
+            print("   linear tile order: %.1f us" % graph_us(f_split, 4, replays=10))
+            os.environ.pop("FRCNN_F32S_XCD", None)
         us_s = graph_us(f_split, 4, replays=10)
         us_n = graph_us(f_native, 4, replays=10)
         gf = 2.0 * ci * co * 9 * h * w / 1e9

@@ -690,6 +690,29 @@ def check_linear_bf16(rt, M, N, K, relu, seed=0):
     assert np.all(np.abs(y16 - want) <= np.abs(want) * 2.0 ** -8 + 3e-5 * np.abs(want).max())
 
 
+def check_linear_f32s(rt, M, N, K, relu, seed=0):
+    """fp32 L.Linear on split tensors: against a float64 product (next to the native fp32 kernel), the split output form, and the
+    split / join conversions."""
+    rs = np.random.RandomState(seed)
+    x = rs.randn(M, K).astype(np.float32)
+    w = (rs.randn(N, K) / np.sqrt(K)).astype(np.float32)
+    b = (rs.randn(N) * 0.1).astype(np.float32)
+    xs, ws_ = rt.f32s_split(dev(rt, x)), rt.f32s_split(dev(rt, w))
+    parts = from_bf16_bits(host(rt, xs))
+    assert np.array_equal((parts[0] + parts[1]) + parts[2], x) and np.array_equal(host(rt, rt.f32s_join(xs)), x)
+    want = x.astype(np.float64) @ w.astype(np.float64).T + b
+    if relu:
+        want = np.maximum(want, 0)
+    y = host(rt, rt.linear_f32s(xs, ws_, dev(rt, b), relu=relu))
+    scale = np.abs(want).max()
+    err = np.abs(y - want).max() / scale
+    yn = host(rt, rt.linear(dev(rt, x), dev(rt, w), dev(rt, b), relu=relu))
+    err_n = np.abs(yn - want).max() / scale
+    assert err <= 3e-6 and err <= 4 * err_n + 2e-7, (err, err_n)
+    y3 = rt.linear_f32s(xs, ws_, dev(rt, b), relu=relu, out_split=True)
+    assert np.array_equal(host(rt, rt.f32s_join(y3)), y)
+
+
 def check_conv_relu_pool(rt, Cin, Cout, H, W, seed=0):
     """act = 4: conv + bias + ReLU + F.MaxPooling2D(2,2) (cover_all) in one launch, vs the three separate oracle steps."""
     rs = np.random.RandomState(seed)

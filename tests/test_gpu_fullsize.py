@@ -72,7 +72,7 @@ def test_vgg16_forward_600x1000_f32s(rt, oracle_forward):
     from chainer_faster_rcnn_amd.models import FasterRCNN
     from oracle import parity
     params, x, info, dbg = oracle_forward
-    model = FasterRCNN(runtime=rt, conv_dtype="f32s")
+    model = FasterRCNN(runtime=rt, conv_dtype="f32s", head_dtype="f32s")
     model.load_params(params)
     dev = parity.device_forward_host(rt, model, rt.mem.from_numpy(x), IM_H, IM_W)
     rep = parity.compare_forward(params, info, dbg, dev, layer_tol=1e-3, head_tol=1e-3)

@@ -239,6 +239,9 @@ def test_conv_f32s_split_k(rt, monkeypatch, split):
     """Few-tile launches split their K range over several workgroups (ticket + deterministic fix-up by the last one)."""
     monkeypatch.setenv("FRCNN_F32S_SPLIT", split)
     P.check_conv_f32s(rt, 192, 64, 5, 33, seed=6)          # 12 chunks: 2 or 3 splits of >= 4
+    monkeypatch.setenv("FRCNN_F32S_XCD", "1")              # the XCD-aware (pixel tile, split) enumeration (off by default)
+    P.check_conv_f32s(rt, 192, 64, 5, 33, seed=6)
+    P.check_conv_f32s(rt, 16, 128, 9, 37, seed=7)
 
 
 def test_f32s_pipeline_small(rt):
@@ -248,3 +251,8 @@ def test_f32s_pipeline_small(rt):
 def test_conv1_f32s_first_layer(rt):
     P.check_conv1_f32s(rt, 3, 64, 11, 70)                  # two x tiles (64 + 6 px), two y tiles, ragged rows
     P.check_conv1_f32s(rt, 1, 24, 5, 33, relu=False, seed=1)   # one channel (K = 9), 24 couts: one block, padded to 32
+
+
+def test_linear_f32s(rt):
+    P.check_linear_f32s(rt, 37, 116, 96, relu=False)            # AM = 3, one ragged N block (the stacked head: 116 columns)
+    P.check_linear_f32s(rt, 100, 160, 320, relu=True, seed=1)   # AM = 5, two N blocks, split-K
