@@ -554,9 +554,17 @@ int frcnn_conv1_f32s(const float *x, const float *w, const float *bias, uint16_t
 constexpr size_t kF32sCounterPageBytes = 64 * 1024;
 
 // split-K factor: launches that leave most of the chip's 2 x CUs workgroup slots empty split their K range (FRCNN_F32S_SPLIT overrides)
+constexpr long kF32sMaxSplitTiles = 2048;     // launches with more tiles than this never split
+
+// split-K factor: only launches that cannot fill the chip's 2 x CUs workgroup slots ONCE split (160 tiles on 512 slots -> 3).
+// Filling the last partial round of bigger launches the same way (conv3_x: 1216 tiles -> 2 splits, conv4_x: 608 -> 4) measured
+// 5 % faster on conv4_2/3 and 12 % SLOWER on conv3_x / conv4_1 (r02o): a workgroup left alone on its CU runs almost twice as fast,
+// so a thin last round costs far less than the slot count suggests, and every split pays its own prologue and partial tile.
+// (FRCNN_F32S_SPLIT overrides.)
 static int conv_f32s_pick_split(long tiles, int chunks) {
     const char *e = getenv("FRCNN_F32S_SPLIT");
-    int s = e ? atoi(e) : (int)((2L * frcnn_cu_count()) / (tiles > 0 ? tiles : 1));      // fill the slots once: 160 tiles on 512 slots -> 3
+    int s = e ? atoi(e) : (int)((2L * frcnn_cu_count()) / (tiles > 0 ? tiles : 1));
+    if (tiles > kF32sMaxSplitTiles && !e) s = 1;
     if (s > 4) s = 4;
     if (s < 1) s = 1;
     while (s > 1 && chunks / s < 4) --s;                          // a split should still carry a few chunks
@@ -565,7 +573,8 @@ static int conv_f32s_pick_split(long tiles, int chunks) {
 
 size_t frcnn_conv_f32s_workspace_bytes(int Cin, int Cout, int H, int W) {
     if (Cin < 1 || Cout < 1 || H < 1 || W < 1) return 0;
-    const long tiles = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4) * frcnn_cdiv((Cout + 15) / 16 * 16, 64);
+    long tiles = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4) * frcnn_cdiv((Cout + 15) / 16 * 16, 64);
+    if (tiles > kF32sMaxSplitTiles) tiles = 0;                                         // never split: counters only
     return kF32sCounterPageBytes + (size_t)tiles * 4 * 256 * 32 * sizeof(float);      // up to 4 splits x 32 KB of accumulators per tile
 }
 
