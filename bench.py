@@ -218,8 +218,8 @@ def graph_time_us(torch, fn, launches_per_replay, replays):
     return e0.elapsed_time(e1) * 1e3 / (replays * launches_per_replay)
 
 
-def f32s_conv_chain(rt, model, x):
-    """The 14 convolution launches of the f32s model (first layer straight from the fp32 image, fused pools, rpn_conv_3x3)."""
+def f32s_conv_chain(rt, model, x, bf16=False):
+    """The 14 convolution launches of the f32s (or bf16) model: first layer straight from the fp32 image, fused pools, rpn_conv_3x3."""
     def chain():
         tr_ = model.trunk
         h, n_l = None, len(tr_.layers)
@@ -227,11 +227,12 @@ def f32s_conv_chain(rt, model, x):
             if l == "pool":
                 continue
             link = tr_.links[l[0]]
+            pool = idx + 1 < n_l and tr_.layers[idx + 1] == "pool"
             if h is None:
-                h = rt.conv1_f32s(x, link.W, link.b, relu=True)
+                h = rt.conv1_bf16(x, link.W, link.b, relu=True) if bf16 else rt.conv1_f32s(x, link.W, link.b, relu=True)
             else:
-                h = link.f32s(h, relu=True, pool=(idx + 1 < n_l and tr_.layers[idx + 1] == "pool"))
-        return model.RPN.rpn_conv_3x3.f32s(h, relu=True, out_f32_nchw=True)
+                h = link.bf16(h, relu=True, pool=pool) if bf16 else link.f32s(h, relu=True, pool=pool)
+        return model.RPN.rpn_conv_3x3.bf16(h, relu=True) if bf16 else model.RPN.rpn_conv_3x3.f32s(h, relu=True, out_f32_nchw=True)
     return chain
 
 
@@ -488,16 +489,7 @@ def main():
             elif args.dtype == "f32s":
                 conv_chain = f32s_conv_chain(rt, model, x)
             else:
-                xb = rt.bf16_from_nchw(x)                      # the fp32 -> bf16 image conversion and the final bf16 -> fp32 copy are not convs
-
-                def conv_chain():
-                    tr_ = model.trunk
-                    h, n_l = xb, len(tr_.layers)
-                    for idx, l in enumerate(tr_.layers):
-                        if l == "pool":
-                            continue
-                        h = tr_.links[l[0]].bf16(h, relu=True, pool=(idx + 1 < n_l and tr_.layers[idx + 1] == "pool"))
-                    return model.RPN.rpn_conv_3x3.bf16(h, relu=True)
+                conv_chain = f32s_conv_chain(rt, model, x, bf16=True)
             conv_chain_ms = graph_time_us(torch, conv_chain, 1, iso_replays) / 1e3
         except Exception as e:
             print("conv-chain graph failed (%s): roofline from the per-stage events" % (e,), file=sys.stderr)

@@ -344,13 +344,18 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
 // the 3-way split in registers) -- 24 MFMAs per 32 px x 64 couts -- and writes the split output straight from the accumulators
 // (8-byte pieces: 4 consecutive couts of a pixel).  The generic kernel would stage 74 KB per tile for 3 real channels and run
 // 108 MFMAs per 2 rows: 131 us on the 600x1000 image; this one is bound by its 230 MB of output.
-template <int NCB>                                   // cout blocks of 32
-__global__ void __launch_bounds__(256)
+// SPLIT = false: the plain bf16 form of the same kernel (conv_bf16.hip's chain: operands rounded to bf16, one MFMA per k-step, the
+// result rounded to bf16 once) -- only the h terms exist.
+template <int NCB, bool SPLIT = true>                // cout blocks of 32
+__global__ void __launch_bounds__(256, 2)
 conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, uint16_t *__restrict__ y, int Cin,
                   int Cout, int H, int W, int relu) {
     constexpr int TR = 8, TW = 64, HR = TR + 2, PITCH = TW + 4;        // LDS row: 66 used of 68 floats
     constexpr int CMAX = 3;
     __shared__ float xt[CMAX * HR * PITCH];
+    constexpr int NPARTS = SPLIT ? kParts : 1;
+    constexpr int OPX = 32 + 16;                                       // output staging: bytes per (pixel, 16-cout block) + pad
+    __shared__ __attribute__((aligned(16))) unsigned char ot[4][2 * NCB][32 * OPX];     // per wave: one part of a unit's tile, [cout block of 16][px]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, khalf = lane >> 5;
@@ -364,7 +369,8 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
         xt[(ci * HR + r) * PITCH + c] = (ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((size_t)ci * H + gy) * W + gx] : 0.0f;
     }
     // ---- weight fragments: lane (cout l31 of block cb, k = 16 s + 8 khalf + e), k = ci * 9 + tap; the three parts of (Cout, K) fp32
-    uint4 a[NCB][2][kParts];
+    constexpr int NP = SPLIT ? kParts : 1;
+    uint4 a[NCB][2][NP];
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -378,8 +384,10 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
                 split3_pair(w0, w1, hp[e], mp[e], lp[e]);
             }
             a[cb][s2][0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-            a[cb][s2][1] = make_uint4(mp[0], mp[1], mp[2], mp[3]);
-            a[cb][s2][2] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+            if constexpr (SPLIT) {
+                a[cb][s2][1] = make_uint4(mp[0], mp[1], mp[2], mp[3]);
+                a[cb][s2][2] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+            }
         }
     // ---- per-lane LDS offsets of the 16 im2col elements (floats), relative to (row 2 * wave, column 0) of the tile
     int boff[2][8];
@@ -403,7 +411,7 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
         const int i = u >> 1, seg = u & 1;
         const int py = y0 + 2 * wave + i, px = x0 + seg * 32 + l31;
         if (py >= H || x0 + seg * 32 >= W) continue;                   // wave-uniform
-        uint4 b[2][kParts];
+        uint4 b[2][NP];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             float v[8];
@@ -416,30 +424,36 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) split3_pair(v[2 * e], v[2 * e + 1], hp[e], mp[e], lp[e]);
             b[s2][0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-            b[s2][1] = make_uint4(mp[0], mp[1], mp[2], mp[3]);
-            b[s2][2] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+            if constexpr (SPLIT) {
+                b[s2][1] = make_uint4(mp[0], mp[1], mp[2], mp[3]);
+                b[s2][2] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+            }
         }
-        frcnn_f32x16 acc[NCB], acs[NCB];
+        frcnn_f32x16 acc[NCB];                                         // (one accumulator per cout block: 24 MFMAs per unit, registers matter more)
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[cb][r] = acs[cb][r] = 0.0f;
+            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
+            if constexpr (SPLIT) {
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acs[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][2], b[s2][0], acs[cb]);     // l.h
+                for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][NP - 1], b[s2][0], acc[cb]);     // l.h
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][1], b[s2][0], acc[cb]);     // m.h
+                for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][NP / 2], b[s2][0], acc[cb]);     // m.h
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acs[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][2], acs[cb]);     // h.l
+                for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][NP - 1], acc[cb]);     // h.l
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][1], acc[cb]);     // h.m
+                for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][NP / 2], acc[cb]);     // h.m
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acs[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][1], b[s2][1], acs[cb]);     // m.m
+                for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][NP / 2], b[s2][NP / 2], acc[cb]);     // m.m
+            }
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][0], acc[cb]);     // h.h
         }
-        if (px >= W) continue;                                         // (after the MFMAs: they need the whole wave)
+        // the unit's 32 px x (32 NCB) couts go through the wave's LDS tile, one part at a time, so that every 16-cout block leaves as ONE
+        // contiguous run of 32 px x 32 B (16-byte stores, consecutive lanes consecutive addresses) instead of 8-byte pieces 32 bytes apart
+        uint2 pk[NPARTS][NCB][4];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
@@ -448,19 +462,38 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
                 float v[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    v[t] = (acc[cb][4 * g + t] + acs[cb][4 * g + t]) + (co + t < Cout ? bias[co + t] : 0.0f);
+                    v[t] = acc[cb][4 * g + t] + (co + t < Cout ? bias[co + t] : 0.0f);
                     if (relu) v[t] = fmaxf(v[t], 0.0f);
                 }
                 uint32_t hp[2], mp[2], lp[2];
                 split3_pair(v[0], v[1], hp[0], mp[0], lp[0]);
                 split3_pair(v[2], v[3], hp[1], mp[1], lp[1]);
-                if (co < CoutP) {
-                    uint16_t *o = y + (((size_t)(co >> 4) * H + py) * W + px) * 16 + (co & 15);
-                    *reinterpret_cast<uint2 *>(o) = make_uint2(hp[0], hp[1]);
-                    *reinterpret_cast<uint2 *>(o + y_part) = make_uint2(mp[0], mp[1]);
-                    *reinterpret_cast<uint2 *>(o + 2 * y_part) = make_uint2(lp[0], lp[1]);
+                pk[0][cb][g] = make_uint2(hp[0], hp[1]);
+                if constexpr (SPLIT) {
+                    pk[NPARTS / 2][cb][g] = make_uint2(mp[0], mp[1]);
+                    pk[NPARTS - 1][cb][g] = make_uint2(lp[0], lp[1]);
                 }
             }
+#pragma unroll
+        for (int part = 0; part < NPARTS; ++part) {
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int co = cb * 32 + 8 * g + 4 * khalf;
+                    *reinterpret_cast<uint2 *>(&ot[wave][co >> 4][l31 * OPX + (co & 15) * 2]) = pk[part][cb][g];
+                }
+            __builtin_amdgcn_wave_barrier();                           // the wave's own LDS writes, read by other lanes below
+#pragma unroll
+            for (int b16 = 0; b16 < 2 * NCB; ++b16) {
+                const int q = lane >> 1, half = lane & 1;              // pixel, 16-byte half of its 32-byte cout block
+                const uint4 val = *reinterpret_cast<const uint4 *>(&ot[wave][b16][q * OPX + half * 16]);
+                const int qx = x0 + seg * 32 + q;
+                if (qx < W && b16 * 16 < CoutP)
+                    *reinterpret_cast<uint4 *>(y + part * y_part + (((size_t)b16 * H + py) * W + qx) * 16 + half * 8) = val;
+            }
+            __builtin_amdgcn_wave_barrier();                           // the tile is rewritten only after these reads were issued
+        }
     }
 }
 
@@ -548,6 +581,14 @@ int frcnn_conv1_f32s(const float *x, const float *w, const float *bias, uint16_t
     const dim3 grid(frcnn_cdiv(W, 64), frcnn_cdiv(H, 8));
     if (Cout > 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu);
+    return frcnn_launch_status();
+}
+
+int frcnn_conv1_bf16(const float *x, const float *w, const float *bias, uint16_t *y, int Cin, int Cout, int H, int W, int relu, void *stream) {
+    if (!x || !w || !bias || !y || Cin < 1 || Cin > 3 || Cout < 1 || Cout > 64 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    const dim3 grid(frcnn_cdiv(W, 64), frcnn_cdiv(H, 8));
+    if (Cout > 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu);
     return frcnn_launch_status();
 }
 

@@ -119,7 +119,7 @@ class VGG16Prev(object):
     def _call_bf16(self, x, timer, collect=None):
         """bf16 chain: fp32 NCHW image -> channel-blocked bf16 -> 13 bf16 convs / 4 pools -> conv5_3 back as fp32 NCHW."""
         rt = self.rt
-        h = rt.bf16_from_nchw(x)
+        h = None                             # converted lazily: a first layer with <= 3 input channels reads the fp32 NCHW image itself
         n_pool, cout, skip = 0, int(x.shape[1]), False
         for idx, l in enumerate(self.layers):
             if l == "pool":
@@ -127,6 +127,8 @@ class VGG16Prev(object):
                 if skip:
                     skip = False
                     continue
+                if h is None:
+                    h = rt.bf16_from_nchw(x)
                 h = rt.maxpool2x2_bf16(h)
                 if timer:
                     timer.mark("pool%d" % n_pool)
@@ -134,7 +136,13 @@ class VGG16Prev(object):
                     collect["pool%d" % n_pool] = (h, cout)
             else:
                 fuse = self.fuse_pool and idx + 1 < len(self.layers) and self.layers[idx + 1] == "pool"
-                h = self.links[l[0]].bf16(h, relu=True, pool=fuse)
+                link = self.links[l[0]]
+                if h is None and not fuse and l[1] <= 3 and l[2] <= 64 and not getattr(self, "generic_first_layer", False):
+                    h = rt.conv1_bf16(x, link.W, link.b, relu=True)            # conv1_1: straight from the fp32 NCHW image
+                else:
+                    if h is None:
+                        h = rt.bf16_from_nchw(x)
+                    h = link.bf16(h, relu=True, pool=fuse)
                 skip = fuse
                 cout = l[2]
                 if timer:

@@ -421,6 +421,15 @@ class Runtime(object):
         _lib.check(L.frcnn_conv1_f32s(m.ptr(x), m.ptr(w), m.ptr(bias), m.ptr(y), cin, cout, H, W, int(bool(relu)), m.stream()), "frcnn_conv1_f32s")
         return y
 
+    def conv1_bf16(self, x, w, bias, relu=True):
+        """First layer of the bf16 chain: x (1,Cin<=3,H,W) fp32 NCHW, w (Cout<=64,Cin,3,3) fp32 -> [CoutP/16][H][W][16] bf16."""
+        m, L = self.mem, self.lib
+        cin, H, W = [int(v) for v in x.shape[-3:]]
+        cout = int(w.shape[0])
+        y = m.empty((self.bf16_pad(cout) // 16, H, W, 16), "i16")
+        _lib.check(L.frcnn_conv1_bf16(m.ptr(x), m.ptr(w), m.ptr(bias), m.ptr(y), cin, cout, H, W, int(bool(relu)), m.stream()), "frcnn_conv1_bf16")
+        return y
+
     def conv3x3_f32s(self, x, w_packed, bias, cin, cout, relu=True, out_f32_nchw=False, pool=False):
         """x split tensor [3][CinP/16][H][W][16] -> split tensor (optionally ReLU + 2x2 max-pooled), or (1,Cout,H,W) fp32."""
         m, L = self.mem, self.lib

@@ -213,6 +213,10 @@ int frcnn_conv3x3_f32s(const uint16_t *x, const uint16_t *w_packed, const float 
  * is, y = split tensor (CoutP, H, W) */
 int frcnn_conv1_f32s(const float *x, const float *w, const float *bias, uint16_t *y, int Cin, int Cout, int H, int W, int relu,
                      void *stream);
+/* the same kernel in plain bf16 arithmetic (operands rounded to bf16, fp32 accumulation, y = [CoutP/16][H][W][16] bf16): the first
+ * layer of the bf16 chain without the fp32 -> blocked-bf16 image conversion and without 13 padded channels of MFMA work */
+int frcnn_conv1_bf16(const float *x, const float *w, const float *bias, uint16_t *y, int Cin, int Cout, int H, int W, int relu,
+                     void *stream);
 /* the same with a workspace (frcnn_conv_f32s_workspace_bytes; its first 64 KB zeroed ONCE by frcnn_conv_f32s_workspace_init --
  * every launch leaves them zero): lets launches with few tiles (38x63 maps) split their K range over several workgroups */
 size_t frcnn_conv_f32s_workspace_bytes(int Cin, int Cout, int H, int W);

@@ -605,6 +605,22 @@ def check_f32s_pipeline_small(rt, im_h=22, im_w=37):
         assert rel_err(b, a) <= 5e-6, rel_err(b, a)
 
 
+def check_conv1_bf16(rt, Cin, Cout, H, W, seed=0):
+    """First-layer bf16 kernel (fp32 NCHW image in, blocked bf16 out) == the generic bf16 kernel on the converted image: same operands
+    (bf16-rounded image and weights), fp32 accumulation in a different order, one bf16 rounding of the result."""
+    rs = np.random.RandomState(seed)
+    x = (rs.randn(1, Cin, H, W) * 60).astype(np.float32)
+    w = (rs.randn(Cout, Cin, 3, 3) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    b = (rs.randn(Cout) * 0.1).astype(np.float32)
+    xb, _ = to_bf16(x)
+    wb, _ = to_bf16(w)
+    want = O.relu(O.conv2d(xb, wb, b, 1))[0].transpose(1, 2, 0)
+    got = from_bf16_bits(blocked_to_hwc(host(rt, rt.conv1_bf16(dev(rt, x), dev(rt, w), dev(rt, b), relu=True))))
+    assert got.shape == (H, W, rt.bf16_pad(Cout)) and not got[:, :, Cout:].any()
+    scale = np.abs(want).max()
+    assert np.all(np.abs(got[:, :, :Cout] - want) <= np.abs(want) * 2.0 ** -8 + 2e-5 * scale)
+
+
 def check_conv_bf16_pool(rt, Cin, Cout, H, W, seed=0):
     """out_mode 2: bf16 conv + ReLU + 2x2 ceil-mode pool in one launch == the two separate bf16 launches, bit for bit."""
     rs = np.random.RandomState(seed)

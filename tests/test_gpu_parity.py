@@ -455,3 +455,8 @@ def test_linear_f32s(rt):
     P.check_linear_f32s(rt, 300, 4096, 4096, relu=True, seed=1)      # fc7
     P.check_linear_f32s(rt, 300, 512, 25088, relu=True, seed=2)      # fc6's K
     P.check_linear_f32s(rt, 300, 116, 4096, relu=False, seed=3)      # the stacked cls_score / bbox_pred head
+
+
+def test_conv1_bf16_first_layer(rt):
+    P.check_conv1_bf16(rt, 3, 64, 75, 203)
+    P.check_conv1_bf16(rt, 3, 64, 600, 1000, seed=2)

@@ -256,3 +256,8 @@ def test_conv1_f32s_first_layer(rt):
 def test_linear_f32s(rt):
     P.check_linear_f32s(rt, 37, 116, 96, relu=False)            # AM = 3, one ragged N block (the stacked head: 116 columns)
     P.check_linear_f32s(rt, 100, 160, 320, relu=True, seed=1)   # AM = 5, two N blocks, split-K
+
+
+def test_conv1_bf16_first_layer(rt):
+    P.check_conv1_bf16(rt, 3, 64, 11, 70)
+    P.check_conv1_bf16(rt, 1, 24, 5, 33, seed=1)
