@@ -39,8 +39,14 @@ def main(out_dir, dtype):
                                         "hbm_bytes_per_launch": 2.0 * fb + wb,
                                         "correction": "FETCH x 2 applied to ALL fetches (upper bound: the weight panels are 16-byte-per-lane LDS-DMA "
                                                       "loads, which FETCH_SIZE halves; the 4-byte activation loads are counted 1:1)"}
+    elif dtype == "f32s":
+        n, fb, wb = family(lambda s: s.startswith("conv_f32s_kernel") or s.startswith("conv1_f32s_kernel"))
+        summ["conv_f32s_kernel"] = {"launches_counted": n, "fetch_bytes_per_launch_raw": fb, "write_bytes_per_launch": wb,
+                                    "hbm_bytes_per_launch": 2.0 * fb + wb,
+                                    "correction": "FETCH x 2 (16-byte-per-lane buffer_load ... lds; the first layer's 4-byte image reads are "
+                                                  "7 MB of the total: counted twice, an upper bound)"}
     else:
-        n, fb, wb = family(lambda s: s.startswith("conv_dma_bf16_kernel") or s.startswith("conv_mfma_bf16_kernel<3"))
+        n, fb, wb = family(lambda s: s.startswith("conv_dma_bf16_kernel") or s.startswith("conv_mfma_bf16_kernel<3") or s.startswith("conv1_f32s_kernel"))
         summ["conv_bf16_kernel"] = {"launches_counted": n, "fetch_bytes_per_launch_raw": fb, "write_bytes_per_launch": wb,
                                     "hbm_bytes_per_launch": 2.0 * fb + wb,
                                     "correction": "FETCH x 2 (every global read of the kernel is a 16-byte-per-lane buffer_load ... lds)"}
@@ -48,7 +54,7 @@ def main(out_dir, dtype):
     summ["roi_pool_cells_kernel"] = {"launches_counted": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                                      "note": "4-byte-per-lane reads (1:1); algorithmic 4.90 MB read + 30.11 MB (fp32) / 15.05 MB (bf16) written"}
     out["_summary"] = summ
-    name = "r02_hbm_traffic_pmc.json" if dtype == "f32" else "r02_hbm_traffic_pmc_bf16.json"
+    name = {"f32": "r02_hbm_traffic_pmc.json", "bf16": "r02_hbm_traffic_pmc_bf16.json", "f32s": "r02_hbm_traffic_pmc_f32s.json"}[dtype]
     json.dump(out, open("%s/%s" % (out_dir, name), "w"), indent=1, sort_keys=True)
     print(json.dumps(summ, indent=1))
 

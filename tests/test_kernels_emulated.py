@@ -239,9 +239,9 @@ def test_conv_f32s_split_k(rt, monkeypatch, split):
     """Few-tile launches split their K range over several workgroups (ticket + deterministic fix-up by the last one)."""
     monkeypatch.setenv("FRCNN_F32S_SPLIT", split)
     P.check_conv_f32s(rt, 192, 64, 5, 33, seed=6)          # 12 chunks: 2 or 3 splits of >= 4
-    monkeypatch.setenv("FRCNN_F32S_XCD", "1")              # the XCD-aware (pixel tile, split) enumeration (off by default)
-    P.check_conv_f32s(rt, 192, 64, 5, 33, seed=6)
-    P.check_conv_f32s(rt, 16, 128, 9, 37, seed=7)
+    if split == "2":
+        monkeypatch.setenv("FRCNN_F32S_XCD", "1")          # the XCD-aware (pixel tile, split) enumeration (off by default)
+        P.check_conv_f32s(rt, 192, 128, 5, 33, seed=6)     # two cout tiles: two XCDs per tile
 
 
 def test_f32s_pipeline_small(rt):
