@@ -286,7 +286,9 @@ def train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_not
     VOC-shaped image per GPU per step."""
     from chainer_faster_rcnn_amd.train import RPNTrainer, TorchComm
     model.rpn_train = True
-    tr = RPNTrainer(model, comm=TorchComm() if dist is not None else None, run_proposal_layer=not args.no_train_proposals)
+    # --dtype f32s in train mode: forward and input-gradient convolutions as bf16x6 split products (weight gradients on the fp32 kernel)
+    conv_math = "split" if args.dtype == "f32s" else "mfma"
+    tr = RPNTrainer(model, comm=TorchComm() if dist is not None else None, run_proposal_layer=not args.no_train_proposals, conv_math=conv_math)
     rs = np.random.RandomState(rank)
     G = 4
     w, h = rs.uniform(32, 400, G), rs.uniform(32, 400, G)
@@ -342,9 +344,12 @@ def train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_not
               (("start", "fwd_bwd"), ("fwd_bwd", "all_reduce"), ("all_reduce", "update"))}
         print(json.dumps({"metric": "images/sec RPN training step VGG16 600x1000", "value": world * args.steps / dt, "unit": "img/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32s" if conv_math == "split" else "f32", "data": "synthetic",
                           "config": {"workload": "train_rpn.py end-to-end RPN training step, 1 image per GPU, all-reduce of the flat fp32 gradient "
-                                                 "buffer in 3 buckets overlapped with the backward pass (BASELINE.json configs[4])",
+                                                 "buffer in 3 buckets overlapped with the backward pass (BASELINE.json configs[4])" +
+                                                 ("; forward and input-gradient convolutions as six bf16 MFMA products of 3-way split fp32 operands, "
+                                                  "weight gradients on the fp32 MFMA kernel" if conv_math == "split" else ""),
+                                     "conv_math": conv_math,
                                      "proposal_layer_in_step": (not args.no_train_proposals),
                                      "grad_buffer_mb": tr.n_flat * 4 / 1e6, "global_batch": world, "ranks_share_gpus": shared_note},
                           "ms_per_step_without_proposal_layer": other_ms,

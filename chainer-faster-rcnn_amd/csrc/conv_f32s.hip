@@ -46,7 +46,8 @@ template <int WPS, int ABL = 0, int NS = 1>
 __global__ void __launch_bounds__(256, WPS)
 conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
                  int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles, int nsplit,
-                 float *__restrict__ partial_ws, int *__restrict__ tile_counters, int xcd_cotiles) {
+                 float *__restrict__ partial_ws, int *__restrict__ tile_counters, int xcd_cotiles, float *__restrict__ y_nchw,
+                 const float *__restrict__ mask) {
     constexpr int KS = 3, TAPS = 9, PAD = 1;
     constexpr int RW = 2, BROWS = 4, BCO = 64;
     constexpr int HR = BROWS + KS - 1, HPX = 32 + KS - 1;
@@ -257,6 +258,25 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
             v[j][r] = t;
         }
     const int px = x0 + l31;
+    if (mask != nullptr || y_nchw != nullptr) {
+        // training forms.  mask (Cout,H,W) fp32: y = (mask > 0) ? y : 0 -- the input-gradient convolution of the backward pass with the
+        // producing ReLU's mask fused in (conv.hip act = 2).  y_nchw: the result ALSO as fp32 NCHW (the weight-gradient kernel, the
+        // bias gradient, the pool and the next layer's mask read fp32; the next convolution reads the split tensor)
+#pragma unroll
+        for (int j = 0; j < RW; ++j) {
+            const int py = y0 + wrow * RW + j;
+            if (px >= W || py >= H) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                if (co < Cout) {
+                    const size_t o = (size_t)co * H * W + (size_t)py * W + px;
+                    if (mask != nullptr && !(mask[o] > 0.0f)) v[j][r] = 0.0f;
+                    if (y_nchw != nullptr) y_nchw[o] = v[j][r];
+                }
+            }
+        }
+    }
     if (out_mode == 1) {                                        // fp32 NCHW (the last layer of a chain)
 #pragma unroll
         for (int j = 0; j < RW; ++j) {
@@ -511,6 +531,25 @@ pack_w_f32s_kernel(const float *__restrict__ w, int Cout, int Cin, int taps, int
     wp[i] = (uint16_t)h; wp[total + i] = (uint16_t)m; wp[2 * total + i] = (uint16_t)l;
 }
 
+// The trainer's PACKED fp32 weights wp[(ci * 9 + tap)][co] (conv.hip's layout, updated in place by the optimizer) -> split weights of
+// the forward convolution, or (dgrad) of the input-gradient convolution: channels swapped, taps rotated by 180 degrees --
+// w'[ci][co][tap'] = w[co][ci][8 - tap'] (train.hip pack_dgrad_w_kernel's rule)
+__global__ void __launch_bounds__(256)
+pack_w_f32s_from_packed_kernel(const float *__restrict__ wp, int Cin, int Cout, int dgrad, uint16_t *__restrict__ dst) {
+    const int KI = dgrad ? Cout : Cin, KO = dgrad ? Cin : Cout;        // reduction / output channels of the convolution being packed
+    const int KIP = (KI + 15) / 16 * 16, KOP = (KO + 15) / 16 * 16;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)9 * KOP * KIP;
+    if (i >= total) return;
+    const int c16 = (int)(i % 16), o = (int)((i / 16) % KOP), tap = (int)((i / (16 * (size_t)KOP)) % 9);
+    const int k = (int)(i / (16 * (size_t)KOP * 9)) * 16 + c16;
+    float v = 0.0f;
+    if (o < KO && k < KI) v = dgrad ? wp[((size_t)o * 9 + (8 - tap)) * Cout + k] : wp[((size_t)k * 9 + tap) * Cout + o];
+    uint32_t h, m, l;
+    split3_pair(v, 0.0f, h, m, l);
+    dst[i] = (uint16_t)h; dst[total + i] = (uint16_t)m; dst[2 * total + i] = (uint16_t)l;
+}
+
 // (C,H,W) fp32 -> [3][CP/16][H*W][16] bf16 parts, channels C..CP-1 zero
 __global__ void __launch_bounds__(256)
 nchw_to_f32s_kernel(const float *__restrict__ x, int C, int HW, int CP, uint16_t *__restrict__ y) {
@@ -557,6 +596,14 @@ int frcnn_f32s_pack_conv_w(const float *w, int Cout, int Cin, uint16_t *w_packed
     const int CoutP = (Cout + 15) / 16 * 16, CinP = (Cin + 15) / 16 * 16;
     const size_t total = (size_t)9 * CoutP * CinP;
     hipLaunchKernelGGL(pack_w_f32s_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, 9, CoutP, CinP, w_packed);
+    return frcnn_launch_status();
+}
+
+int frcnn_f32s_pack_from_packed(const float *w_packed_f32, int Cin, int Cout, int dgrad, uint16_t *w_split, void *stream) {
+    if (!w_packed_f32 || !w_split || Cin < 1 || Cout < 1) return FRCNN_ERR_INVALID;
+    const size_t total = (size_t)9 * ((Cout + 15) / 16 * 16) * ((Cin + 15) / 16 * 16);
+    hipLaunchKernelGGL(pack_w_f32s_from_packed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_packed_f32, Cin, Cout,
+                       dgrad ? 1 : 0, w_split);
     return frcnn_launch_status();
 }
 
@@ -625,9 +672,8 @@ int frcnn_conv_f32s_workspace_init(void *workspace, size_t workspace_bytes, void
     return FRCNN_OK;
 }
 
-int frcnn_conv3x3_f32s_ws(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H, int W, int relu, int out_mode,
-                          void *workspace, size_t workspace_bytes, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+static int conv3x3_f32s_launch(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, float *y_nchw, const float *mask, int Cin, int Cout,
+                               int H, int W, int relu, int out_mode, void *workspace, size_t workspace_bytes, hipStream_t stream) {
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
     if (out_mode < 0 || out_mode > 2 || (out_mode == 2 && !relu)) return FRCNN_ERR_INVALID;
     const int CinP = (Cin + 15) / 16 * 16, CoutP = (Cout + 15) / 16 * 16;
@@ -653,7 +699,7 @@ int frcnn_conv3x3_f32s_ws(const uint16_t *x, const uint16_t *w_packed, const flo
     }
     const char *abl_env = getenv("FRCNN_F32S_ABL");
     const int abl = abl_env ? atoi(abl_env) : 0;
-#define FRCNN_F32S_LAUNCH(...) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<__VA_ARGS__>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, nsplit, partials, counters, xcd_cotiles)
+#define FRCNN_F32S_LAUNCH(...) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<__VA_ARGS__>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, nsplit, partials, counters, xcd_cotiles, y_nchw, mask)
     switch (abl) {
 #ifdef FRCNN_TIMING_ABLATIONS                                   // WRONG results: sweeps only, never shipped
         case 1: FRCNN_F32S_LAUNCH(2, 1); break;
@@ -668,6 +714,18 @@ int frcnn_conv3x3_f32s_ws(const uint16_t *x, const uint16_t *w_packed, const flo
     }
 #undef FRCNN_F32S_LAUNCH
     return frcnn_launch_status();
+}
+
+int frcnn_conv3x3_f32s_ws(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H, int W, int relu, int out_mode,
+                          void *workspace, size_t workspace_bytes, void *stream) {
+    return conv3x3_f32s_launch(x, w_packed, bias, y, nullptr, nullptr, Cin, Cout, H, W, relu, out_mode, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int frcnn_conv3x3_f32s_train(const uint16_t *x, const uint16_t *w_packed, const float *bias, uint16_t *y_split, float *y_nchw, const float *mask, int Cin,
+                             int Cout, int H, int W, int relu, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!y_split && !y_nchw) return FRCNN_ERR_INVALID;
+    if (!y_split) return conv3x3_f32s_launch(x, w_packed, bias, y_nchw, nullptr, mask, Cin, Cout, H, W, relu, 1, workspace, workspace_bytes, (hipStream_t)stream);
+    return conv3x3_f32s_launch(x, w_packed, bias, y_split, y_nchw, mask, Cin, Cout, H, W, relu, 0, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int frcnn_conv3x3_f32s(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H, int W, int relu, int out_mode,

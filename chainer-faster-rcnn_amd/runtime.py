@@ -421,6 +421,29 @@ class Runtime(object):
         _lib.check(L.frcnn_conv1_f32s(m.ptr(x), m.ptr(w), m.ptr(bias), m.ptr(y), cin, cout, H, W, int(bool(relu)), m.stream()), "frcnn_conv1_f32s")
         return y
 
+    def f32s_pack_from_packed(self, w_packed_f32, cin, cout, dgrad=False, out=None):
+        """The trainer's packed fp32 weights (cin*9, cout) -> split weights of the forward / input-gradient convolution."""
+        m, L = self.mem, self.lib
+        ki, ko = (cout, cin) if dgrad else (cin, cout)
+        wp = out if out is not None else m.empty((3, self.bf16_pad(ki) // 16, 9, self.bf16_pad(ko), 16), "i16")
+        _lib.check(L.frcnn_f32s_pack_from_packed(m.ptr(w_packed_f32), int(cin), int(cout), int(bool(dgrad)), m.ptr(wp), m.stream()),
+                   "frcnn_f32s_pack_from_packed")
+        return wp
+
+    def conv3x3_f32s_train(self, x, w_packed, bias, cin, cout, relu=True, want_split=True, want_nchw=True, mask=None):
+        """Training forms of the split convolution: returns (split tensor or None, fp32 NCHW or None); mask (1,Cout,H,W) fp32."""
+        m, L = self.mem, self.lib
+        H, W = int(x.shape[2]), int(x.shape[3])
+        assert int(x.shape[0]) == 3 and int(x.shape[1]) * 16 == self.bf16_pad(cin) and int(w_packed.shape[1]) * 16 == self.bf16_pad(cin)
+        ys = m.empty((3, self.bf16_pad(cout) // 16, H, W, 16), "i16") if want_split else None
+        yn = m.empty((1, int(cout), H, W), "f32") if want_nchw else None
+        ws = self.workspace("conv_f32s", L.frcnn_conv_f32s_workspace_bytes(int(cin), int(cout), H, W),
+                            init=lambda w: _lib.check(L.frcnn_conv_f32s_workspace_init(m.ptr(w), w.shape[0], m.stream()),
+                                                      "frcnn_conv_f32s_workspace_init"))
+        _lib.check(L.frcnn_conv3x3_f32s_train(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(ys), m.ptr(yn), m.ptr(mask), int(cin), int(cout), H, W,
+                                              int(bool(relu)), m.ptr(ws), ws.shape[0], m.stream()), "frcnn_conv3x3_f32s_train")
+        return ys, yn
+
     def conv1_bf16(self, x, w, bias, relu=True):
         """First layer of the bf16 chain: x (1,Cin<=3,H,W) fp32 NCHW, w (Cout<=64,Cin,3,3) fp32 -> [CoutP/16][H][W][16] bf16."""
         m, L = self.mem, self.lib

@@ -62,6 +62,71 @@ def trunk_backward(trainer, layer_inputs, g):
     return g
 
 
+def _conv_dims(trainer, name):
+    link = dict(trainer.convs)[name]
+    return int(link.cin), int(link.cout)
+
+
+def trunk_forward_split(trainer, x):
+    """trunk_forward with the 3x3 convolutions (all but the 3-channel first one) computed as six bf16 MFMA products of 3-way split
+    fp32 operands (csrc/conv_f32s.hip): every convolution leaves its result as fp32 NCHW (what the weight-gradient kernel, pooling
+    and the ReLU masks read) and, when a convolution follows, as the split tensor that one reads.  -> (feat, inputs, feat_split)."""
+    model, rt = trainer.model, trainer.rt
+    layers = model.trunk.layers
+    inputs, h, hs = [], x, None
+    for idx, l in enumerate(layers):
+        inputs.append(h)
+        if l == "pool":
+            h, hs = rt.maxpool2x2(h), None
+            continue
+        name, link = l[0], model.trunk.links[l[0]]
+        if int(link.cin) <= 3:                                        # conv1_1: K = 27, the native kernel (no input gradient either)
+            h, hs = link(h, relu=True), None
+            continue
+        if hs is None:
+            hs = rt.f32s_from_nchw(h)
+        conv_next = idx + 1 == len(layers) or layers[idx + 1] != "pool"        # the last map feeds rpn_conv_3x3
+        rt.f32s_pack_from_packed(link.Wp, link.cin, link.cout, dgrad=False, out=trainer.ws_fwd[name])
+        hs, h = rt.conv3x3_f32s_train(hs, trainer.ws_fwd[name], link.b, link.cin, link.cout, relu=True, want_split=conv_next)
+    if hs is None:
+        hs = rt.f32s_from_nchw(h)                                     # (trunks that end in a pool or in the first layer)
+    return h, inputs, hs
+
+
+def trunk_backward_split(trainer, layer_inputs, g):
+    """trunk_backward with the input-gradient convolutions on split tensors; weight and bias gradients as before (fp32 NCHW)."""
+    rt = trainer.rt
+    first = trainer.convs[0][0]
+    links = dict(trainer.convs)
+    names = [l if l == "pool" else l[0] for l, _ in layer_inputs]
+    gs = None
+    for pos in range(len(layer_inputs) - 1, -1, -1):
+        l, xin = layer_inputs[pos]
+        if l == "pool":
+            g, gs = rt.maxpool2x2_bwd(xin, g), None
+            continue
+        name = l[0]
+        keep = getattr(trainer, "keep_dy", None)
+        if keep is not None and name in keep:
+            trainer.kept_dy[name] = (xin, g.clone() if hasattr(g, "clone") else g.copy())
+        rt.conv_wgrad(xin, g, 3, out=trainer.grad[name + "/W"])
+        rt.bias_grad(g, out=trainer.grad[name + "/b"])
+        if hasattr(trainer, "_grads_ready"):
+            trainer._grads_ready(name)
+        if name == first:
+            continue                                                  # the image needs no gradient
+        cin, cout = _conv_dims(trainer, name)
+        if cin <= 3:
+            continue
+        if gs is None:
+            gs = rt.f32s_from_nchw(g)
+        rt.f32s_pack_from_packed(links[name].Wp, cin, cout, dgrad=True, out=trainer.ws_dgrad[name])
+        below = names[pos - 1] if pos > 0 else None                   # who consumes dL/d(input): a convolution with an input gradient of its own?
+        below_conv = below is not None and below != "pool" and below != first and _conv_dims(trainer, below)[0] > 3
+        gs, g = rt.conv3x3_f32s_train(gs, trainer.ws_dgrad[name], trainer.zero_bias, cout, cin, relu=False, want_split=below_conv, mask=xin)
+    return g
+
+
 class _Seg(object):
     def __init__(self, name, shape, offset):
         self.name, self.shape, self.offset = name, tuple(shape), offset
@@ -130,10 +195,13 @@ class _BucketedAllReduce(_ParamArena):
 
 
 class RPNTrainer(_BucketedAllReduce):
-    def __init__(self, model, lr=0.001, momentum=0.9, weight_decay=0.0005, comm=None, run_proposal_layer=True):
+    def __init__(self, model, lr=0.001, momentum=0.9, weight_decay=0.0005, comm=None, run_proposal_layer=True, conv_math="mfma"):
+        """conv_math: "mfma" = forward and input-gradient convolutions on the fp32 MFMA kernel; "split" = the same fp32 convolutions as
+        six bf16 MFMA products of 3-way split operands (csrc/conv_f32s.hip; weight gradients stay on the fp32 kernel)."""
         self.model, self.rt = model, model.rt
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.comm = comm
+        self.conv_math = conv_math
         self.run_proposal_layer = run_proposal_layer
         self.proposals = None
         rt = self.rt
@@ -168,6 +236,11 @@ class RPNTrainer(_BucketedAllReduce):
         self.wd = {name: rt.mem.empty((int(link.Wp.shape[1]) * 9, int(link.Wp.shape[0]) // 9), "f32") for name, link in self.convs[1:]}
         self.wd_heads = rt.mem.empty((int(wp.shape[1]), int(wp.shape[0])), "f32")
         self.zero_bias = rt.mem.zeros((512,), "f32")
+        if conv_math == "split":                                      # split weights of the forward / input-gradient convolutions (re-packed every step)
+            pad = rt.bf16_pad
+            big = [(n, l) for n, l in self.convs if int(l.cin) > 3]
+            self.ws_fwd = {n: rt.mem.empty((3, pad(l.cin) // 16, 9, pad(l.cout), 16), "i16") for n, l in big}
+            self.ws_dgrad = {n: rt.mem.empty((3, pad(l.cout) // 16, 9, pad(l.cin), 16), "i16") for n, l in big}
         self._draw = None
         self.iteration = 0
         self._plan_buckets([n for n, _ in self.convs])       # heads follow rpn_conv_3x3 in the buffer and precede it in time
@@ -190,8 +263,14 @@ class RPNTrainer(_BucketedAllReduce):
         self._ensure_adopted()
         x = rt.asarray(unwrap(x), "f32")
         im_h, im_w = rpn.proposal_layer._img_hw(img_info)
-        feat, inputs = trunk_forward(model, x)                     # keeps every layer's input
-        mid = rpn.rpn_conv_3x3(feat, relu=True)
+        if self.conv_math == "split":
+            feat, inputs, feat_split = trunk_forward_split(self, x)
+            link = rpn.rpn_conv_3x3
+            rt.f32s_pack_from_packed(link.Wp, link.cin, link.cout, dgrad=False, out=self.ws_fwd["rpn_conv_3x3"])
+            _, mid = rt.conv3x3_f32s_train(feat_split, self.ws_fwd["rpn_conv_3x3"], link.b, link.cin, link.cout, relu=True, want_split=False)
+        else:
+            feat, inputs = trunk_forward(model, x)                     # keeps every layer's input
+            mid = rpn.rpn_conv_3x3(feat, relu=True)
         score, prob, bbox = rt.rpn_heads(mid, rpn._heads_packed)
         if self.run_proposal_layer:
             # region_proposal_network.py:123-126: `proposals, probs = self.proposal_layer(...)` in train mode (12000 -> NMS -> 2000);
@@ -215,7 +294,7 @@ class RPNTrainer(_BucketedAllReduce):
         rt.pack_conv_dgrad_w(rpn._heads_packed[0], 1, out=self.wd_heads)
         g = rt.conv_ex(draw.reshape(1, NP, H, W), self.wd_heads, self.zero_bias, 1, act=2, mask=mid)
         # ---- rpn_conv_3x3, then the trunk in reverse
-        trunk_backward(self, list(zip(self.layers, inputs)) + [(("rpn_conv_3x3", 0, 0), feat)], g)
+        (trunk_backward_split if self.conv_math == "split" else trunk_backward)(self, list(zip(self.layers, inputs)) + [(("rpn_conv_3x3", 0, 0), feat)], g)
         if self.run_proposal_layer:
             rt.mem.join_side_stream()
         return dict(losses=losses)

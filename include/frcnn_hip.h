@@ -224,6 +224,16 @@ int frcnn_conv_f32s_workspace_init(void *workspace, size_t workspace_bytes, void
 int frcnn_conv3x3_f32s_ws(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
                           int W, int relu, int out_mode, void *workspace, size_t workspace_bytes, void *stream);
 
+/* training forms (train_rpn.py's forward / backward through the trunk): the convolution with the result written as a
+ * split tensor (y_split, may be NULL) and / or as fp32 NCHW (y_nchw, may be NULL: the weight-gradient kernel, pooling and the ReLU masks
+ * read fp32), optionally masked -- y = (mask > 0) ? y : 0, mask (Cout,H,W) fp32: the input-gradient convolution with the producing
+ * ReLU's mask fused in.  frcnn_f32s_pack_from_packed: the trainer's packed fp32 weights [(ci*9+tap)][co] (frcnn_pack_conv3x3_w) ->
+ * split weights of the forward (dgrad 0) or of the input-gradient convolution (dgrad 1: channels swapped, taps rotated). */
+int frcnn_f32s_pack_from_packed(const float *w_packed_f32, int Cin, int Cout, int dgrad, uint16_t *w_split, void *stream);
+int frcnn_conv3x3_f32s_train(const uint16_t *x, const uint16_t *w_packed, const float *bias, uint16_t *y_split, float *y_nchw,
+                             const float *mask, int Cin, int Cout, int H, int W, int relu, void *workspace, size_t workspace_bytes,
+                             void *stream);
+
 /* fully connected layers on split tensors (L.Linear + F.relu, models/faster_rcnn.py:33-36,127-134): x = [3][M][K], w = [3][N][K]
  * bf16 parts (frcnn_f32s_split of the fp32 (M,K) / (N,K) arrays), K % 32 == 0; y = (M,N) fp32, or its three parts [3][M][N] when
  * out_split (the next layer's x).  frcnn_f32s_join: parts -> fp32 (h + m + l, exact). */

@@ -460,3 +460,8 @@ def test_linear_f32s(rt):
 def test_conv1_bf16_first_layer(rt):
     P.check_conv1_bf16(rt, 3, 64, 75, 203)
     P.check_conv1_bf16(rt, 3, 64, 600, 1000, seed=2)
+
+
+def test_rpn_train_step_split_products(rt):
+    T.check_small_step(rt, conv_math="split")
+    losses, worst = T.check_vgg_step(rt, conv_math="split")

@@ -391,3 +391,8 @@ def test_trainer_snapshot_fixture_and_resume(rt, tmp_path):
         t.step(Variable(x), Variable(info), Variable(gt))
     assert tr2.iteration == tr.iteration == 39
     assert np.array_equal(rt.mem.to_numpy(tr.W), rt.mem.to_numpy(tr2.W)) and np.array_equal(rt.mem.to_numpy(tr.V), rt.mem.to_numpy(tr2.V))
+
+
+def test_rpn_train_step_small_split_products(rt):
+    """The same step with the forward and input-gradient convolutions on split tensors (csrc/conv_f32s.hip, training forms)."""
+    T.check_small_step(rt, conv_math="split")

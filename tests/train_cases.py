@@ -50,7 +50,7 @@ def oracle_step(params, x, gt, info, layers, feat_stride, scales, seed, f64_wgra
     return loss, grads
 
 
-def check_small_step(rt, seed=0, im_h=40, im_w=56):
+def check_small_step(rt, seed=0, im_h=40, im_w=56, conv_math="mfma"):
     """forward + AnchorTargetLayer + losses + backward on the narrow trunk vs the oracle, then the SGD update."""
     from chainer_faster_rcnn_amd.chainer_compat import Variable
     from chainer_faster_rcnn_amd.train import RPNTrainer
@@ -62,7 +62,7 @@ def check_small_step(rt, seed=0, im_h=40, im_w=56):
     gt[0, :, 3] = np.minimum(gt[0, :, 1] + rs.uniform(8, 30, 3), im_h - 1)
     info = np.array([[im_h, im_w]], dtype=np.int32)
     model = build_small(rt, params)
-    tr = RPNTrainer(model)
+    tr = RPNTrainer(model, conv_math=conv_math)
     w0 = rt.mem.to_numpy(tr.W)
     np.random.seed(123)
     out = tr.forward_backward(Variable(x), Variable(info), Variable(gt))
@@ -87,7 +87,7 @@ def check_small_step(rt, seed=0, im_h=40, im_w=56):
     return l
 
 
-def check_vgg_step(rt, im_h=160, im_w=224, seed=0):
+def check_vgg_step(rt, im_h=160, im_w=224, seed=0, conv_math="mfma"):
     """One RPN training step of the real VGG-16 FasterRCNN (GPU suite): loss and every gradient vs the oracle's autograd."""
     from chainer_faster_rcnn_amd import synthetic
     from chainer_faster_rcnn_amd.chainer_compat import Variable
@@ -105,7 +105,7 @@ def check_vgg_step(rt, im_h=160, im_w=224, seed=0):
     model = FasterRCNN(runtime=rt)
     model.load_params(params)
     model.rpn_train = True
-    tr = RPNTrainer(model)
+    tr = RPNTrainer(model, conv_math=conv_math)
     # Full size (600 x 1000): two fp32 implementations of a 14-layer backward pass take a handful of DIFFERENT discrete decisions (a
     # ReLU whose pre-activation is 1e-8, a max-pool tie); each flips one pixel's gradient, and every upstream gradient moves by
     # ~sqrt(flips / pixels) of its scale -- measured 1.1e-3 ... 1.3e-3 on two layers, all others < 1e-3.  So at full size every conv
