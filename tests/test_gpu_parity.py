@@ -463,5 +463,9 @@ def test_conv1_bf16_first_layer(rt):
 
 
 def test_rpn_train_step_split_products(rt):
+    """RPNTrainer(conv_math="split"): forward and input-gradient convolutions as six bf16 MFMA products of 3-way split operands -- the
+    same bars as the fp32-MFMA step (loss 1e-4, every gradient 1e-3 of the oracle's autograd)."""
+    import train_cases as T
     T.check_small_step(rt, conv_math="split")
     losses, worst = T.check_vgg_step(rt, conv_math="split")
+    assert losses["rpn_loss"] > 0 and worst <= 1e-3
