@@ -369,7 +369,7 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
 template <int NCB, bool SPLIT = true>                // cout blocks of 32
 __global__ void __launch_bounds__(256, 2)
 conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, uint16_t *__restrict__ y, int Cin,
-                  int Cout, int H, int W, int relu) {
+                  int Cout, int H, int W, int relu, int w_is_packed, float *__restrict__ y_nchw) {
     constexpr int TR = 8, TW = 64, HR = TR + 2, PITCH = TW + 4;        // LDS row: 66 used of 68 floats
     constexpr int CMAX = 3;
     __shared__ float xt[CMAX * HR * PITCH];
@@ -399,8 +399,9 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int k = 16 * s2 + 8 * khalf + 2 * e, co = cb * 32 + l31;
-                const float w0 = (co < Cout && k < K) ? w[(size_t)co * K + k] : 0.0f;
-                const float w1 = (co < Cout && k + 1 < K) ? w[(size_t)co * K + k + 1] : 0.0f;
+                // w: Chainer's (Cout, Cin, 3, 3), or (w_is_packed) the trainers' packed [(ci * 9 + tap)][co]
+                const float w0 = (co < Cout && k < K) ? (w_is_packed ? w[(size_t)k * Cout + co] : w[(size_t)co * K + k]) : 0.0f;
+                const float w1 = (co < Cout && k + 1 < K) ? (w_is_packed ? w[(size_t)(k + 1) * Cout + co] : w[(size_t)co * K + k + 1]) : 0.0f;
                 split3_pair(w0, w1, hp[e], mp[e], lp[e]);
             }
             a[cb][s2][0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
@@ -484,6 +485,7 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
                 for (int t = 0; t < 4; ++t) {
                     v[t] = acc[cb][4 * g + t] + (co + t < Cout ? bias[co + t] : 0.0f);
                     if (relu) v[t] = fmaxf(v[t], 0.0f);
+                    if (y_nchw != nullptr && co + t < Cout && px < W) y_nchw[((size_t)(co + t) * H + py) * W + px] = v[t];   // training: fp32 NCHW as well
                 }
                 uint32_t hp[2], mp[2], lp[2];
                 split3_pair(v[0], v[1], hp[0], mp[0], lp[0]);
@@ -550,6 +552,43 @@ pack_w_f32s_from_packed_kernel(const float *__restrict__ wp, int Cin, int Cout, 
     dst[i] = (uint16_t)h; dst[total + i] = (uint16_t)m; dst[2 * total + i] = (uint16_t)l;
 }
 
+// All layers of a trainer in ONE launch (26 launches of 8 us each otherwise, every step): up to 16 layers, each block looks its layer up
+struct PackManyArgs {
+    const float *wp[16];
+    uint16_t *fwd[16], *dgr[16];
+    int cin[16], cout[16];
+    unsigned block_end[16];                          // exclusive prefix of 256-element blocks
+    int n;
+};
+__global__ void __launch_bounds__(256)
+pack_w_f32s_many_kernel(const PackManyArgs a) {
+    int li = 0;
+    while (li + 1 < a.n && blockIdx.x >= a.block_end[li]) ++li;
+    const unsigned b0 = li == 0 ? 0u : a.block_end[li - 1];
+    const int Cin = a.cin[li], Cout = a.cout[li];
+    const int CinP = (Cin + 15) / 16 * 16, CoutP = (Cout + 15) / 16 * 16;
+    const size_t i = (size_t)(blockIdx.x - b0) * 256 + threadIdx.x;
+    const size_t total = (size_t)9 * CoutP * CinP;
+    if (i >= total) return;
+    const float *wp = a.wp[li];
+    {   // forward: [CinP/16][tap][CoutP][16]
+        const int c16 = (int)(i % 16), o = (int)((i / 16) % CoutP), tap = (int)((i / (16 * (size_t)CoutP)) % 9);
+        const int k = (int)(i / (16 * (size_t)CoutP * 9)) * 16 + c16;
+        uint32_t h, m, l;
+        split3_pair((o < Cout && k < Cin) ? wp[((size_t)k * 9 + tap) * Cout + o] : 0.0f, 0.0f, h, m, l);
+        uint16_t *d = a.fwd[li];
+        d[i] = (uint16_t)h; d[total + i] = (uint16_t)m; d[2 * total + i] = (uint16_t)l;
+    }
+    if (a.dgr[li] != nullptr) {   // input gradient: [CoutP/16][tap][CinP][16], taps rotated
+        const int c16 = (int)(i % 16), o = (int)((i / 16) % CinP), tap = (int)((i / (16 * (size_t)CinP)) % 9);
+        const int k = (int)(i / (16 * (size_t)CinP * 9)) * 16 + c16;
+        uint32_t h, m, l;
+        split3_pair((o < Cin && k < Cout) ? wp[((size_t)o * 9 + (8 - tap)) * Cout + k] : 0.0f, 0.0f, h, m, l);
+        uint16_t *d = a.dgr[li];
+        d[i] = (uint16_t)h; d[total + i] = (uint16_t)m; d[2 * total + i] = (uint16_t)l;
+    }
+}
+
 // (C,H,W) fp32 -> [3][CP/16][H*W][16] bf16 parts, channels C..CP-1 zero
 __global__ void __launch_bounds__(256)
 nchw_to_f32s_kernel(const float *__restrict__ x, int C, int HW, int CP, uint16_t *__restrict__ y) {
@@ -607,6 +646,24 @@ int frcnn_f32s_pack_from_packed(const float *w_packed_f32, int Cin, int Cout, in
     return frcnn_launch_status();
 }
 
+int frcnn_f32s_pack_many(const frcnn_f32s_pack_desc *layers, int n, void *stream) {
+    if (!layers || n < 1 || n > 16) return FRCNN_ERR_INVALID;
+    PackManyArgs a;
+    memset(&a, 0, sizeof(a));
+    unsigned blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!layers[i].w_packed_f32 || !layers[i].w_split_fwd || layers[i].Cin < 1 || layers[i].Cout < 1) return FRCNN_ERR_INVALID;
+        a.wp[i] = layers[i].w_packed_f32; a.fwd[i] = layers[i].w_split_fwd; a.dgr[i] = layers[i].w_split_dgrad;
+        a.cin[i] = layers[i].Cin; a.cout[i] = layers[i].Cout;
+        const size_t total = (size_t)9 * ((layers[i].Cout + 15) / 16 * 16) * ((layers[i].Cin + 15) / 16 * 16);
+        blocks += (unsigned)((total + 255) / 256);
+        a.block_end[i] = blocks;
+    }
+    a.n = n;
+    hipLaunchKernelGGL(pack_w_f32s_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return frcnn_launch_status();
+}
+
 int frcnn_f32s_from_nchw_f32(const float *x, int C, int H, int W, uint16_t *y, void *stream) {
     if (!x || !y || C < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
     const int CP = (C + 15) / 16 * 16;
@@ -626,16 +683,25 @@ int frcnn_f32s_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, voi
 int frcnn_conv1_f32s(const float *x, const float *w, const float *bias, uint16_t *y, int Cin, int Cout, int H, int W, int relu, void *stream) {
     if (!x || !w || !bias || !y || Cin < 1 || Cin > 3 || Cout < 1 || Cout > 64 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
     const dim3 grid(frcnn_cdiv(W, 64), frcnn_cdiv(H, 8));
-    if (Cout > 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu);
+    if (Cout > 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu, 0, (float *)nullptr);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu, 0, (float *)nullptr);
+    return frcnn_launch_status();
+}
+
+int frcnn_conv1_f32s_train(const float *x, const float *w_packed_f32, const float *bias, uint16_t *y_split, float *y_nchw, int Cin, int Cout, int H, int W,
+                           int relu, void *stream) {
+    if (!x || !w_packed_f32 || !bias || !y_split || Cin < 1 || Cin > 3 || Cout < 1 || Cout > 64 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    const dim3 grid(frcnn_cdiv(W, 64), frcnn_cdiv(H, 8));
+    if (Cout > 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, x, w_packed_f32, bias, y_split, Cin, Cout, H, W, relu, 1, y_nchw);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, w_packed_f32, bias, y_split, Cin, Cout, H, W, relu, 1, y_nchw);
     return frcnn_launch_status();
 }
 
 int frcnn_conv1_bf16(const float *x, const float *w, const float *bias, uint16_t *y, int Cin, int Cout, int H, int W, int relu, void *stream) {
     if (!x || !w || !bias || !y || Cin < 1 || Cin > 3 || Cout < 1 || Cout > 64 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
     const dim3 grid(frcnn_cdiv(W, 64), frcnn_cdiv(H, 8));
-    if (Cout > 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu);
+    if (Cout > 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu, 0, (float *)nullptr);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu, 0, (float *)nullptr);
     return frcnn_launch_status();
 }
 

@@ -82,6 +82,23 @@ class TorchDeviceMemory(object):
         if getattr(self, "_side", None) is not None:
             self.torch.cuda.current_stream(self.device).wait_stream(self._side)
 
+    def early_stream(self):
+        """Context manager: a stream that does NOT wait for the current one -- for work that depends on nothing already enqueued (the
+        trainers' AnchorTargetLayer: ground truth in, labels out, with a host round trip in the middle) so that its host part overlaps
+        whatever the GPU is still executing.  join_early_stream(*outputs) makes the current stream wait for it and marks the
+        outputs as used there."""
+        torch = self.torch
+        if getattr(self, "_early", None) is None:
+            self._early = torch.cuda.Stream(device=self.device)
+        return torch.cuda.stream(self._early)
+
+    def join_early_stream(self, *outputs):
+        cur = self.torch.cuda.current_stream(self.device)
+        cur.wait_stream(self._early)
+        for a in outputs:
+            if a is not None and hasattr(a, "record_stream"):
+                a.record_stream(cur)
+
     def dtype_of(self, t):
         return {v: k for k, v in self._dt.items()}[t.dtype]
 
@@ -430,6 +447,17 @@ class Runtime(object):
                    "frcnn_f32s_pack_from_packed")
         return wp
 
+    def f32s_pack_many(self, layers):
+        """layers: [(packed fp32 weights (cin*9, cout), split fwd weights, split dgrad weights or None, cin, cout)], at most 16: ONE launch."""
+        import ctypes
+
+        class Desc(ctypes.Structure):
+            _fields_ = [("w", ctypes.c_void_p), ("fwd", ctypes.c_void_p), ("dgr", ctypes.c_void_p), ("cin", ctypes.c_int), ("cout", ctypes.c_int)]
+        m, L = self.mem, self.lib
+        val = lambda t: None if t is None else m.ptr(t).value
+        arr = (Desc * len(layers))(*[Desc(val(w), val(f), val(d), int(ci), int(co)) for (w, f, d, ci, co) in layers])
+        _lib.check(L.frcnn_f32s_pack_many(ctypes.cast(arr, ctypes.c_void_p), len(layers), m.stream()), "frcnn_f32s_pack_many")
+
     def conv3x3_f32s_train(self, x, w_packed, bias, cin, cout, relu=True, want_split=True, want_nchw=True, mask=None):
         """Training forms of the split convolution: returns (split tensor or None, fp32 NCHW or None); mask (1,Cout,H,W) fp32."""
         m, L = self.mem, self.lib
@@ -442,6 +470,16 @@ class Runtime(object):
                                                       "frcnn_conv_f32s_workspace_init"))
         _lib.check(L.frcnn_conv3x3_f32s_train(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(ys), m.ptr(yn), m.ptr(mask), int(cin), int(cout), H, W,
                                               int(bool(relu)), m.ptr(ws), ws.shape[0], m.stream()), "frcnn_conv3x3_f32s_train")
+        return ys, yn
+
+    def conv1_f32s_train(self, x, w_packed_f32, bias, cout, relu=True):
+        """First layer, training form: packed fp32 weights (cin*9, cout) -> (split tensor, fp32 NCHW)."""
+        m, L = self.mem, self.lib
+        cin, H, W = [int(v) for v in x.shape[-3:]]
+        ys = m.empty((3, self.bf16_pad(cout) // 16, H, W, 16), "i16")
+        yn = m.empty((1, int(cout), H, W), "f32")
+        _lib.check(L.frcnn_conv1_f32s_train(m.ptr(x), m.ptr(w_packed_f32), m.ptr(bias), m.ptr(ys), m.ptr(yn), cin, int(cout), H, W, int(bool(relu)),
+                                            m.stream()), "frcnn_conv1_f32s_train")
         return ys, yn
 
     def conv1_bf16(self, x, w, bias, relu=True):

@@ -80,13 +80,15 @@ def trunk_forward_split(trainer, x):
             h, hs = rt.maxpool2x2(h), None
             continue
         name, link = l[0], model.trunk.links[l[0]]
-        if int(link.cin) <= 3:                                        # conv1_1: K = 27, the native kernel (no input gradient either)
-            h, hs = link(h, relu=True), None
+        if int(link.cin) <= 3:                                        # conv1_1: the first-layer kernel, fp32 NCHW image in
+            if idx == 0 and int(link.cout) <= 64 and idx + 1 < len(layers) and layers[idx + 1] != "pool":
+                hs, h = rt.conv1_f32s_train(h, link.Wp, link.b, link.cout, relu=True)
+            else:
+                h, hs = link(h, relu=True), None
             continue
         if hs is None:
             hs = rt.f32s_from_nchw(h)
         conv_next = idx + 1 == len(layers) or layers[idx + 1] != "pool"        # the last map feeds rpn_conv_3x3
-        rt.f32s_pack_from_packed(link.Wp, link.cin, link.cout, dgrad=False, out=trainer.ws_fwd[name])
         hs, h = rt.conv3x3_f32s_train(hs, trainer.ws_fwd[name], link.b, link.cin, link.cout, relu=True, want_split=conv_next)
     if hs is None:
         hs = rt.f32s_from_nchw(h)                                     # (trunks that end in a pool or in the first layer)
@@ -120,7 +122,6 @@ def trunk_backward_split(trainer, layer_inputs, g):
             continue
         if gs is None:
             gs = rt.f32s_from_nchw(g)
-        rt.f32s_pack_from_packed(links[name].Wp, cin, cout, dgrad=True, out=trainer.ws_dgrad[name])
         below = names[pos - 1] if pos > 0 else None                   # who consumes dL/d(input): a convolution with an input gradient of its own?
         below_conv = below is not None and below != "pool" and below != first and _conv_dims(trainer, below)[0] > 3
         gs, g = rt.conv3x3_f32s_train(gs, trainer.ws_dgrad[name], trainer.zero_bias, cout, cin, relu=False, want_split=below_conv, mask=xin)
@@ -263,10 +264,23 @@ class RPNTrainer(_BucketedAllReduce):
         self._ensure_adopted()
         x = rt.asarray(unwrap(x), "f32")
         im_h, im_w = rpn.proposal_layer._img_hw(img_info)
+        # ---- targets first, on their own stream: AnchorTargetLayer depends on the ground truth and the map size only, and its fg / bg
+        #      subsample runs on the HOST (NumPy's global RNG, the reference's call sequence) -- a device round trip.  Python runs a whole
+        #      step ahead of the GPU, so here the round trip overlaps the previous step's backward pass; after the forward pass (where
+        #      the reference has it) it drained the stream and left the GPU idle while the host sampled (0.4 ms per step).  One draw
+        #      per step either way: the RNG sequence is the reference's.
+        H, W = int(x.shape[2]), int(x.shape[3])
+        for l in self.layers:
+            if l == "pool":
+                H, W = (H + 1) // 2, (W + 1) // 2
+        with rt.mem.early_stream():                                  # its own stream: it must not wait for the previous step's backward
+            labels, targets, inds, n_in, _ = self.atl.forward_device(H, W, gt_boxes, im_h, im_w)
+        rt.mem.join_early_stream(labels, targets, inds)
         if self.conv_math == "split":
+            # split weights of every forward / input-gradient convolution from the current (packed fp32) weights: one launch
+            rt.f32s_pack_many([(l.Wp, self.ws_fwd[n], self.ws_dgrad[n], l.cin, l.cout) for n, l in self.convs if int(l.cin) > 3])
             feat, inputs, feat_split = trunk_forward_split(self, x)
             link = rpn.rpn_conv_3x3
-            rt.f32s_pack_from_packed(link.Wp, link.cin, link.cout, dgrad=False, out=self.ws_fwd["rpn_conv_3x3"])
             _, mid = rt.conv3x3_f32s_train(feat_split, self.ws_fwd["rpn_conv_3x3"], link.b, link.cin, link.cout, relu=True, want_split=False)
         else:
             feat, inputs = trunk_forward(model, x)                     # keeps every layer's input
@@ -279,10 +293,9 @@ class RPNTrainer(_BucketedAllReduce):
             with rt.mem.side_stream(prob, bbox):
                 self.proposals = rpn.proposal_layer.forward_device(prob, bbox, im_h, im_w)
         A = self.A
-        H, W = int(feat.shape[2]), int(feat.shape[3])
+        assert (H, W) == (int(feat.shape[2]), int(feat.shape[3]))
         NP = int(rpn._heads_packed[0].shape[1])
-        # ---- targets and losses
-        labels, targets, inds, n_in, _ = self.atl.forward_device(H, W, gt_boxes, im_h, im_w)
+        # ---- losses
         if self._draw is None or tuple(self._draw.shape) != (NP, H, W):
             self._draw = rt.mem.zeros((NP, H, W), "f32")             # rows >= 6A (channel padding) stay zero
         draw = self._draw

@@ -230,6 +230,16 @@ int frcnn_conv3x3_f32s_ws(const uint16_t *x, const uint16_t *w_packed, const flo
  * ReLU's mask fused in.  frcnn_f32s_pack_from_packed: the trainer's packed fp32 weights [(ci*9+tap)][co] (frcnn_pack_conv3x3_w) ->
  * split weights of the forward (dgrad 0) or of the input-gradient convolution (dgrad 1: channels swapped, taps rotated). */
 int frcnn_f32s_pack_from_packed(const float *w_packed_f32, int Cin, int Cout, int dgrad, uint16_t *w_split, void *stream);
+/* the same for up to 16 layers in ONE launch (a trainer re-packs every layer every step); w_split_dgrad may be NULL */
+typedef struct {
+    const float *w_packed_f32;
+    uint16_t *w_split_fwd, *w_split_dgrad;
+    int Cin, Cout;
+} frcnn_f32s_pack_desc;
+int frcnn_f32s_pack_many(const frcnn_f32s_pack_desc *layers, int n, void *stream);
+/* first layer, training form: w = the trainers' packed fp32 weights [(ci*9+tap)][co]; y_split and (may be NULL) y_nchw (Cout,H,W) fp32 */
+int frcnn_conv1_f32s_train(const float *x, const float *w_packed_f32, const float *bias, uint16_t *y_split, float *y_nchw, int Cin,
+                           int Cout, int H, int W, int relu, void *stream);
 int frcnn_conv3x3_f32s_train(const uint16_t *x, const uint16_t *w_packed, const float *bias, uint16_t *y_split, float *y_nchw,
                              const float *mask, int Cin, int Cout, int H, int W, int relu, void *workspace, size_t workspace_bytes,
                              void *stream);

@@ -61,6 +61,13 @@ class HostMemory(object):
     def join_side_stream(self):
         pass
 
+    def early_stream(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def join_early_stream(self, *outputs):
+        pass
+
     def dtype_of(self, a):
         return {np.dtype(v): k for k, v in _NP.items()}[a.dtype]
 

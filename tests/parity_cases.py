@@ -548,6 +548,27 @@ def check_conv_f32s(rt, Cin, Cout, H, W, relu=True, seed=0, tol=3e-6):
         assert np.array_equal(host(rt, rt.f32s_to_nchw(yp, Cout)), O.max_pool_2x2(y))
 
 
+def check_f32s_weight_packs(rt, Cin=20, Cout=40, seed=0):
+    """The three ways to split weights agree bit for bit: from Chainer's (Cout,Cin,3,3) array, from the trainer's packed fp32 layout
+    (one layer), and the all-layers-in-one-launch form; the input-gradient pack is the forward pack of the flipped / transposed weights."""
+    rs = np.random.RandomState(seed)
+    w = rs.randn(Cout, Cin, 3, 3).astype(np.float32)
+    wp = rt.pack_conv3x3_w(dev(rt, w))                                   # (Cin*9, Cout) fp32
+    a = host(rt, rt.f32s_pack_conv_w(dev(rt, w)))
+    b = host(rt, rt.f32s_pack_from_packed(wp, Cin, Cout, dgrad=False))
+    assert np.array_equal(a, b)
+    wt = np.ascontiguousarray(w[:, :, ::-1, ::-1].transpose(1, 0, 2, 3))   # (Cin, Cout, 3, 3): channels swapped, taps rotated
+    d_want = host(rt, rt.f32s_pack_conv_w(dev(rt, wt)))
+    d = host(rt, rt.f32s_pack_from_packed(wp, Cin, Cout, dgrad=True))
+    assert np.array_equal(d, d_want)
+    f2, d2 = rt.mem.empty(a.shape, "i16"), rt.mem.empty(d.shape, "i16")
+    w3 = rs.randn(16, 3, 3, 3).astype(np.float32)
+    f3 = rt.mem.empty((3, 1, 9, 16, 16), "i16")
+    rt.f32s_pack_many([(wp, f2, d2, Cin, Cout), (rt.pack_conv3x3_w(dev(rt, w3)), f3, None, 3, 16)])
+    assert np.array_equal(host(rt, f2), a) and np.array_equal(host(rt, d2), d_want)
+    assert np.array_equal(host(rt, f3), host(rt, rt.f32s_pack_conv_w(dev(rt, w3))))
+
+
 def check_conv1_f32s(rt, Cin, Cout, H, W, relu=True, seed=0):
     """First-layer form (fp32 NCHW image in, split tensor out): against a float64 convolution and against the generic split kernel."""
     import torch
@@ -566,6 +587,9 @@ def check_conv1_f32s(rt, Cin, Cout, H, W, relu=True, seed=0):
         assert not blocked_to_hwc(host(rt, ys)[0])[:, :, Cout:].any()
     gen = host(rt, rt.conv3x3_f32s(rt.f32s_from_nchw(dev(rt, x)), rt.f32s_pack_conv_w(dev(rt, w)), dev(rt, b), Cin, Cout, relu=relu, out_f32_nchw=True))
     assert np.abs(got - gen).max() <= 1e-6 * scale
+    # training form: the trainers' packed fp32 weights in, the split tensor AND fp32 NCHW out -- the same values bit for bit
+    ys2, yn2 = rt.conv1_f32s_train(dev(rt, x), rt.pack_conv3x3_w(dev(rt, w)), dev(rt, b), Cout, relu=relu)
+    assert np.array_equal(host(rt, ys2), host(rt, ys)) and np.array_equal(host(rt, yn2), got)
 
 
 def rel_err(got, want):

@@ -469,3 +469,7 @@ def test_rpn_train_step_split_products(rt):
     T.check_small_step(rt, conv_math="split")
     losses, worst = T.check_vgg_step(rt, conv_math="split")
     assert losses["rpn_loss"] > 0 and worst <= 1e-3
+
+
+def test_f32s_weight_packs(rt):
+    P.check_f32s_weight_packs(rt)

@@ -261,3 +261,7 @@ def test_linear_f32s(rt):
 def test_conv1_bf16_first_layer(rt):
     P.check_conv1_bf16(rt, 3, 64, 11, 70)
     P.check_conv1_bf16(rt, 1, 24, 5, 33, seed=1)
+
+
+def test_f32s_weight_packs(rt):
+    P.check_f32s_weight_packs(rt)
