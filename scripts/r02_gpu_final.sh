@@ -19,6 +19,7 @@ echo "== bench f32 default steps"; timeout 600 python bench.py --no-cpu-baseline
 echo "== bench bf16"; timeout 600 python bench.py --dtype bf16 --steps 50 --warmup 5 > $O/r02_bench_bf16.json 2>> $O/bench.err; echo "rc=$?"; cut -c1-200 $O/r02_bench_bf16.json
 echo "== bench f32s"; timeout 600 python bench.py --dtype f32s --steps 100 --warmup 5 > $O/r02_bench_f32s.json 2>> $O/bench.err; echo "rc=$?"; cut -c1-200 $O/r02_bench_f32s.json
 echo "== bench train"; timeout 600 python bench.py --mode train --steps 20 --warmup 3 > $O/r02_bench_train.json 2>> $O/bench.err; echo "rc=$?"; cut -c1-200 $O/r02_bench_train.json
+echo "== bench train f32s"; timeout 600 python bench.py --mode train --dtype f32s --steps 20 --warmup 3 > $O/r02_bench_train_f32s.json 2>> $O/bench.err; echo "rc=$?"; cut -c1-200 $O/r02_bench_train_f32s.json
 echo "== 2-rank gloo smoke (self-launch)"; timeout 600 python bench.py --gpus 2 --steps 10 --warmup 2 > $O/r02_bench_2rank_gloo_infer.json 2> $O/bench_2rank.err; echo "rc=$?"; cut -c1-200 $O/r02_bench_2rank_gloo_infer.json
 timeout 600 python bench.py --gpus 2 --mode train --steps 6 --warmup 1 > $O/r02_bench_2rank_gloo_train.json 2>> $O/bench_2rank.err; echo "rc=$?"; cut -c1-200 $O/r02_bench_2rank_gloo_train.json
 echo "== rocprof kernel stats"; cd /tmp
