@@ -232,6 +232,8 @@ def test_conv_f32s_split_bf16(rt):
     P.check_conv_f32s(rt, 16, 64, 9, 37)                  # one chunk, ragged rows / columns, odd sizes through the fused pool
     P.check_conv_f32s(rt, 3, 64, 6, 34, seed=1)           # conv1_1: channels padded 3 -> 16; two x tiles
     P.check_conv_f32s(rt, 48, 80, 5, 30, relu=False, seed=2)   # three chunks; 80 couts: a ragged second cout tile
+    P.check_conv_f32s(rt, 1, 21, 1, 1, seed=3)            # one pixel, one channel, 21 couts
+    P.check_conv_f32s(rt, 17, 33, 3, 65, relu=False, seed=4)   # 17 -> 32 padded channels, three x tiles, fewer rows than a tile
 
 
 @pytest.mark.parametrize("split", ["2", "3"])
