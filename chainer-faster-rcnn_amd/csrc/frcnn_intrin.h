@@ -54,3 +54,16 @@ __device__ __forceinline__ frcnn_f32x16 frcnn_mfma_32x32x16_bf16(uint4 a, uint4 
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
+
+// v_alignbit_b32: bits [sh+31 : sh] of the 64-bit value hi:lo
+__device__ __forceinline__ uint32_t frcnn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+
+// (v0, v1) -> the three packed bf16 pairs (h, m, l) with h + m + l == v exactly (round to nearest even at every step; the
+// differences are exact in fp32): the "split tensors" of conv_f32s.hip
+__device__ __forceinline__ void frcnn_split3_pair(float v0, float v1, uint32_t &h, uint32_t &m, uint32_t &l) {
+    h = frcnn_pack_bf16x2(v0, v1);
+    const float d0 = v0 - __uint_as_float(h << 16), d1 = v1 - __uint_as_float(h & 0xffff0000u);
+    m = frcnn_pack_bf16x2(d0, d1);
+    l = frcnn_pack_bf16x2(d0 - __uint_as_float(m << 16), d1 - __uint_as_float(m & 0xffff0000u));
+}
+

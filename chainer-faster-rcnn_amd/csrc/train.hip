@@ -17,6 +17,7 @@
 #include "frcnn_common.h"
 #include <stdlib.h>
 #include <frcnn_buffer.h>   // angle brackets: shadowed by the test emulator
+#include <frcnn_intrin.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -522,6 +523,148 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
         }
 }
 
+// The same weight gradient on the bf16 matrix cores with fp32-class results (conv_f32s.hip's scheme: every fp32 value carried as
+// three bf16 terms, six v_mfma_f32_32x32x16_bf16 products per block, fp32 accumulation).  The PIXELS are the reduction axis, so the
+// MFMA's eight consecutive k-values of a lane are eight consecutive pixels of one channel's row: the workgroup reads the fp32 NCHW
+// tensors x and dy as they are (two pixels per load), splits each pair in registers and keeps pixel-contiguous bf16 rows in LDS --
+// x [part][ci][4 halo rows][96 B], dy [part][co][2 rows][64 B], channel pitches 400 / 144 B = odd multiples of 16 B, so the 16 lanes
+// of a ds_read_b128 group (16 channels, one pixel offset) fall on 16 distinct bank slots.  A tap's horizontal shift of +-1 pixel is
+// 2 bytes -- no aligned 16-byte read exists for it -- so a lane reads the aligned eight pixels plus the dword on either side and
+// builds the two shifted fragments with five v_alignbit_b32.  Per 16-pixel step a wave reads 30 fragments pieces for 54 MFMAs; each
+// value is split once per workgroup and used by 32 x 9 x 6 MFMA rows, so the split costs nothing next to the matrix work; and the
+// operands a step needs are 17 KB per 108 MFMAs (the forward kernel: 74 KB) -- this kernel is bound by the matrix pipe, not by
+// staging.  One workgroup per CU (104 KB of LDS, 144 accumulator registers); the next tile's global loads are in flight during the
+// current tile's MFMAs.  Slabs, split order and the reduce pass are the fp32 kernel's.
+__global__ void __launch_bounds__(256, 1)
+conv_wgrad_f32s_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slabs, int Cin, int Cout, int H, int W,
+                       int xtiles, int nblocks, int splits) {
+    constexpr int T = 9, HR = WG_ROWS + 2;
+    constexpr int XROW = 96, XCH = HR * XROW + 16;             // bytes: a halo row (16 B lead-in, 34 px, pad), a channel (odd multiple of 16)
+    constexpr int DROW = 64, DCH = WG_ROWS * DROW + 16;        // a dy row (32 px), a channel
+    constexpr int XPART = 64 * XCH, DPART = 64 * DCH;
+    __shared__ __attribute__((aligned(16))) unsigned char x_lds[3 * XPART];
+    __shared__ __attribute__((aligned(16))) unsigned char dy_lds[3 * DPART];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wci = wave & 1, wco = wave >> 1;
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int HWs = H * W;
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, split = blockIdx.z;
+    const int b_begin = (int)((long long)split * nblocks / splits), b_end = (int)((long long)(split + 1) * nblocks / splits);
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)Cin * HWs * sizeof(float)));
+    const frcnn_buf_t dbuf = frcnn_make_buf(dy, (uint32_t)((size_t)Cout * HWs * sizeof(float)));
+
+    f32x16 acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // staging: pixel PAIRS.  x: 64 channels x 4 halo rows x 18 pairs (px x0-2 .. x0+33) = 4608 pairs, 18 per thread; dy: 64 x 2 x 16
+    // pairs = 2048, 8 per thread.  The pair -> (channel, row, pair) map is fixed; only the tile origin moves.
+    constexpr int XQ = 18, DQ = 8;
+    float xv[XQ][2], dv[DQ][2];
+    auto fetch = [&](int b) {
+        const int tx = b % xtiles, ty = b / xtiles;
+        const int x0 = tx * 32, y0 = ty * WG_ROWS;
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int e = tid + 256 * q, c = e / (HR * 18), rem = e - c * (HR * 18), hr = rem / 18, p = rem - hr * 18;
+            const int gc = ci0 + c, gy = y0 - 1 + hr, gx = x0 - 2 + 2 * p;
+            const bool row_ok = gc < Cin && gy >= 0 && gy < H;
+            const uint32_t base = (uint32_t)(((size_t)gc * H + gy) * W) * 4u;
+            xv[q][0] = frcnn_buf_load_f32(xbuf, (row_ok && gx >= 0 && gx < W) ? base + (uint32_t)gx * 4u : kBufOob);
+            xv[q][1] = frcnn_buf_load_f32(xbuf, (row_ok && gx + 1 >= 0 && gx + 1 < W) ? base + (uint32_t)(gx + 1) * 4u : kBufOob);
+        }
+#pragma unroll
+        for (int q = 0; q < DQ; ++q) {
+            const int e = tid + 256 * q, c = e >> 5, rem = e & 31, r = rem >> 4, p = rem & 15;
+            const int gc = co0 + c, gy = y0 + r, gx = x0 + 2 * p;
+            const bool row_ok = gc < Cout && gy < H;
+            const uint32_t base = (uint32_t)(((size_t)gc * H + gy) * W) * 4u;
+            dv[q][0] = frcnn_buf_load_f32(dbuf, (row_ok && gx < W) ? base + (uint32_t)gx * 4u : kBufOob);
+            dv[q][1] = frcnn_buf_load_f32(dbuf, (row_ok && gx + 1 < W) ? base + (uint32_t)(gx + 1) * 4u : kBufOob);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) {
+            const int e = tid + 256 * q, c = e / (HR * 18), rem = e - c * (HR * 18), hr = rem / 18, p = rem - hr * 18;
+            uint32_t h, m, l;
+            frcnn_split3_pair(xv[q][0], xv[q][1], h, m, l);
+            unsigned char *d = x_lds + c * XCH + hr * XROW + 12 + 4 * p;          // px x0 sits at byte 16 of a row
+            *reinterpret_cast<uint32_t *>(d) = h;
+            *reinterpret_cast<uint32_t *>(d + XPART) = m;
+            *reinterpret_cast<uint32_t *>(d + 2 * XPART) = l;
+        }
+#pragma unroll
+        for (int q = 0; q < DQ; ++q) {
+            const int e = tid + 256 * q, c = e >> 5, rem = e & 31, r = rem >> 4, p = rem & 15;
+            uint32_t h, m, l;
+            frcnn_split3_pair(dv[q][0], dv[q][1], h, m, l);
+            unsigned char *d = dy_lds + c * DCH + r * DROW + 4 * p;
+            *reinterpret_cast<uint32_t *>(d) = h;
+            *reinterpret_cast<uint32_t *>(d + DPART) = m;
+            *reinterpret_cast<uint32_t *>(d + 2 * DPART) = l;
+        }
+    };
+    auto compute = [&]() {
+        const unsigned char *xa = x_lds + (wci * 32 + l31) * XCH + 16 + 16 * khalf;     // this lane's eight pixels of a 16-pixel step
+        const unsigned char *db = dy_lds + (wco * 32 + l31) * DCH + 16 * khalf;
+#pragma unroll 1
+        for (int s = 0; s < WG_ROWS * 2; ++s) {                                          // (row r, 16-pixel step ks)
+            const int r = s >> 1, ks = s & 1;
+            uint4 bfr[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bfr[p] = *reinterpret_cast<const uint4 *>(db + p * DPART + r * DROW + ks * 32);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                uint4 a[3][3];                                                           // [part][kx]
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const unsigned char *row = xa + p * XPART + (r + ky) * XROW + ks * 32;
+                    const uint4 mid = *reinterpret_cast<const uint4 *>(row);
+                    const uint32_t lo = *reinterpret_cast<const uint32_t *>(row - 4), hi = *reinterpret_cast<const uint32_t *>(row + 16);
+                    const uint32_t s01 = frcnn_alignbit(mid.y, mid.x, 16), s12 = frcnn_alignbit(mid.z, mid.y, 16), s23 = frcnn_alignbit(mid.w, mid.z, 16);
+                    a[p][0] = make_uint4(frcnn_alignbit(mid.x, lo, 16), s01, s12, s23);    // pixels -1 .. +6: tap column 0
+                    a[p][1] = mid;
+                    a[p][2] = make_uint4(s01, s12, s23, frcnn_alignbit(hi, mid.w, 16));    // pixels +1 .. +8: tap column 2
+                }
+                // six products per tap; the three taps of the row take turns so that consecutive MFMAs never share an accumulator
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[2][kx], bfr[0], acc[ky * 3 + kx]);     // l.h
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[0][kx], bfr[2], acc[ky * 3 + kx]);     // h.l
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[1][kx], bfr[1], acc[ky * 3 + kx]);     // m.m
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[1][kx], bfr[0], acc[ky * 3 + kx]);     // m.h
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[0][kx], bfr[1], acc[ky * 3 + kx]);     // h.m
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[0][kx], bfr[0], acc[ky * 3 + kx]);     // h.h
+            }
+        }
+    };
+    if (b_begin < b_end) fetch(b_begin);
+    for (int b = b_begin; b < b_end; ++b) {
+        if (b != b_begin) __syncthreads();                         // every wave is done reading the previous tile
+        stage();
+        __syncthreads();
+        if (b + 1 < b_end) fetch(b + 1);                           // in flight during this tile's MFMAs
+        compute();
+    }
+    float *slab = slabs + (size_t)split * ((size_t)Cin * T * Cout);
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ci = ci0 + wci * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
+            const int co = co0 + wco * 32 + l31;
+            if (ci < Cin && co < Cout) slab[((size_t)ci * T + t) * Cout + co] = acc[t][r];
+        }
+}
+
 __global__ void __launch_bounds__(256)
 wgrad_reduce_kernel(const float *__restrict__ slabs, size_t n, int splits, float *__restrict__ dwp) {
     // slabs are added in split order (deterministic); four slabs' loads are in flight at a time and each thread owns four
@@ -865,6 +1008,28 @@ int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int 
     const size_t work = (n / 4 + 255) / 256 + 1;
     const int blocks = (int)(work < 4096 ? work : 4096);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, n, p.splits, dw_packed);
+    return frcnn_launch_status();
+}
+
+int frcnn_conv_wgrad_f32s(const float *x, const float *dy, float *dw_packed, int Cin, int Cout, int H, int W, void *workspace, size_t workspace_bytes,
+                          void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !dy || !dw_packed || Cin < 1 || Cout < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cout * H * W * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;
+    WgradPlan p = plan_wgrad(Cin, Cout, H, W, 3);
+    if (!workspace || workspace_bytes < p.slab_floats * p.splits * sizeof(float)) return FRCNN_ERR_INVALID;   // the fp32 kernel's workspace fits
+    int s = frcnn_cdiv(frcnn_cu_count(), p.ci_tiles * p.co_tiles);                   // ONE workgroup per CU
+    const char *se = getenv("FRCNN_WGRAD_F32S_SPLITS");
+    if (se && atoi(se) > 0) s = atoi(se);
+    if (s > p.splits) s = p.splits;
+    if (s > p.nblocks) s = p.nblocks;
+    if (s < 1) s = 1;
+    float *slabs = (float *)workspace;
+    hipLaunchKernelGGL(conv_wgrad_f32s_kernel, dim3(p.ci_tiles, p.co_tiles, s), dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, s);
+    const size_t n = p.slab_floats;
+    const size_t work = (n / 4 + 255) / 256 + 1;
+    const int blocks = (int)(work < 4096 ? work : 4096);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, n, s, dw_packed);
     return frcnn_launch_status();
 }
 

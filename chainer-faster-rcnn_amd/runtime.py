@@ -721,6 +721,17 @@ class Runtime(object):
                    "frcnn_conv_wgrad_f32")
         return dw
 
+    def conv_wgrad_f32s(self, x, dy, out=None):
+        """The 3x3 weight gradient as bf16x6 split products (csrc/train.hip conv_wgrad_f32s_kernel); same layout as conv_wgrad."""
+        m, L = self.mem, self.lib
+        ci, H, W = [int(v) for v in x.shape[-3:]]
+        co = int(dy.shape[-3])
+        dw = out if out is not None else m.empty((ci * 9, co), "f32")
+        ws = self.workspace("wgrad", L.frcnn_conv_wgrad_workspace_bytes(ci, co, H, W, 3))
+        _lib.check(L.frcnn_conv_wgrad_f32s(m.ptr(x), m.ptr(dy), m.ptr(dw), ci, co, H, W, m.ptr(ws), ws.shape[0], m.stream()),
+                   "frcnn_conv_wgrad_f32s")
+        return dw
+
     def sgd_momentum_wd(self, w, grad, velocity, lr, momentum, weight_decay):
         m, L = self.mem, self.lib
         n = int(np.prod(w.shape))

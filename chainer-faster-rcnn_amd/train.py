@@ -111,7 +111,7 @@ def trunk_backward_split(trainer, layer_inputs, g):
         keep = getattr(trainer, "keep_dy", None)
         if keep is not None and name in keep:
             trainer.kept_dy[name] = (xin, g.clone() if hasattr(g, "clone") else g.copy())
-        rt.conv_wgrad(xin, g, 3, out=trainer.grad[name + "/W"])
+        rt.conv_wgrad_f32s(xin, g, out=trainer.grad[name + "/W"])  # split products too: fp32 NCHW in, the split happens in the kernel
         rt.bias_grad(g, out=trainer.grad[name + "/b"])
         if hasattr(trainer, "_grads_ready"):
             trainer._grads_ready(name)
@@ -198,7 +198,8 @@ class _BucketedAllReduce(_ParamArena):
 class RPNTrainer(_BucketedAllReduce):
     def __init__(self, model, lr=0.001, momentum=0.9, weight_decay=0.0005, comm=None, run_proposal_layer=True, conv_math="mfma"):
         """conv_math: "mfma" = forward and input-gradient convolutions on the fp32 MFMA kernel; "split" = the same fp32 convolutions as
-        six bf16 MFMA products of 3-way split operands (csrc/conv_f32s.hip; weight gradients stay on the fp32 kernel)."""
+        six bf16 MFMA products of 3-way split operands (csrc/conv_f32s.hip), the 3x3 weight gradients likewise (csrc/train.hip
+        conv_wgrad_f32s_kernel)."""
         self.model, self.rt = model, model.rt
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         self.comm = comm

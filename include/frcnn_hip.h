@@ -244,6 +244,11 @@ int frcnn_conv3x3_f32s_train(const uint16_t *x, const uint16_t *w_packed, const 
                              const float *mask, int Cin, int Cout, int H, int W, int relu, void *workspace, size_t workspace_bytes,
                              void *stream);
 
+/* the 3x3 weight gradient (frcnn_conv_wgrad_f32's arguments and result, its workspace) computed as six bf16 MFMA products of the 3-way
+ * split fp32 operands: x and dy are the fp32 NCHW tensors as they are, the split happens inside the kernel */
+int frcnn_conv_wgrad_f32s(const float *x, const float *dy, float *dw_packed, int Cin, int Cout, int H, int W, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
 /* fully connected layers on split tensors (L.Linear + F.relu, models/faster_rcnn.py:33-36,127-134): x = [3][M][K], w = [3][N][K]
  * bf16 parts (frcnn_f32s_split of the fp32 (M,K) / (N,K) arrays), K % 32 == 0; y = (M,N) fp32, or its three parts [3][M][N] when
  * out_split (the next layer's x).  frcnn_f32s_join: parts -> fp32 (h + m + l, exact). */

@@ -410,6 +410,22 @@ def check_conv_backward(rt, Cin, Cout, H, W, ksize=3, seed=0):
         assert np.abs(dx - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6)
 
 
+def check_conv_wgrad_f32s(rt, Cin, Cout, H, W, seed=0):
+    """The 3x3 weight gradient as six bf16 MFMA products of 3-way split operands: against a FLOAT64 accumulation of the same fp32
+    inputs, next to the fp32 MFMA kernel (same error class)."""
+    import torch
+    rs = np.random.RandomState(seed)
+    x = np.maximum(rs.randn(1, Cin, H, W), 0).astype(np.float32)
+    dy = (rs.randn(1, Cout, H, W) * 0.1).astype(np.float32)
+    want = torch.nn.grad.conv2d_weight(torch.from_numpy(x).double(), (Cout, Cin, 3, 3), torch.from_numpy(dy).double(), padding=1).numpy()
+    want = want.reshape(Cout, Cin * 9).T
+    scale = max(np.abs(want).max(), 1e-12)
+    got = host(rt, rt.conv_wgrad_f32s(dev(rt, x), dev(rt, dy)))
+    nat = host(rt, rt.conv_wgrad(dev(rt, x), dev(rt, dy), 3))
+    err, err_n = np.abs(got - want).max() / scale, np.abs(nat - want).max() / scale
+    assert err <= 3e-6 and err <= 4 * err_n + 2e-7, (err, err_n)
+
+
 def check_maxpool_bwd(rt, C, H, W, seed=0):
     rs = np.random.RandomState(seed)
     x = np.maximum(rs.randn(1, C, H, W), 0).astype(np.float32)                 # many exact ties at 0

@@ -473,3 +473,10 @@ def test_rpn_train_step_split_products(rt):
 
 def test_f32s_weight_packs(rt):
     P.check_f32s_weight_packs(rt)
+
+
+def test_conv_wgrad_f32s(rt):
+    P.check_conv_wgrad_f32s(rt, 64, 64, 5, 37)
+    P.check_conv_wgrad_f32s(rt, 3, 64, 61, 97, seed=1)
+    P.check_conv_wgrad_f32s(rt, 128, 256, 75, 125, seed=2)
+    P.check_conv_wgrad_f32s(rt, 512, 512, 38, 63, seed=3)

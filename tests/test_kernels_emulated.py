@@ -267,3 +267,8 @@ def test_conv1_bf16_first_layer(rt):
 
 def test_f32s_weight_packs(rt):
     P.check_f32s_weight_packs(rt)
+
+
+def test_conv_wgrad_f32s(rt):
+    P.check_conv_wgrad_f32s(rt, 64, 64, 5, 37)               # two x tiles, three row tiles (ragged), one (ci, co) tile
+    P.check_conv_wgrad_f32s(rt, 3, 80, 4, 33, seed=1)         # conv1_1's 3 input channels; 80 couts: a ragged second co tile
