@@ -535,12 +535,14 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
 // operands a step needs are 17 KB per 108 MFMAs (the forward kernel: 74 KB) -- this kernel is bound by the matrix pipe, not by
 // staging.  One workgroup per CU (104 KB of LDS, 144 accumulator registers); the next tile's global loads are in flight during the
 // current tile's MFMAs.  Slabs, split order and the reduce pass are the fp32 kernel's.
+constexpr int kSRows = 3;                      // tile rows of the split kernel (x halo: 5 rows; 135 KB of LDS)
 __global__ void __launch_bounds__(256, 1)
 conv_wgrad_f32s_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slabs, int Cin, int Cout, int H, int W,
                        int xtiles, int nblocks, int splits) {
-    constexpr int T = 9, HR = WG_ROWS + 2;
+    constexpr int T = 9, HR = kSRows + 2;
     constexpr int XROW = 96, XCH = HR * XROW + 16;             // bytes: a halo row (16 B lead-in, 34 px, pad), a channel (odd multiple of 16)
-    constexpr int DROW = 64, DCH = WG_ROWS * DROW + 16;        // a dy row (32 px), a channel
+    constexpr int DROW = 64, DCH = kSRows * DROW + 16;         // a dy row (32 px), a channel
+    static_assert((XCH / 16) % 2 == 1 && (DCH / 16) % 2 == 1, "channel pitches must be odd multiples of 16 bytes");
     constexpr int XPART = 64 * XCH, DPART = 64 * DCH;
     __shared__ __attribute__((aligned(16))) unsigned char x_lds[3 * XPART];
     __shared__ __attribute__((aligned(16))) unsigned char dy_lds[3 * DPART];
@@ -560,89 +562,132 @@ conv_wgrad_f32s_kernel(const float *__restrict__ x, const float *__restrict__ dy
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
-    // staging: pixel PAIRS.  x: 64 channels x 4 halo rows x 18 pairs (px x0-2 .. x0+33) = 4608 pairs, 18 per thread; dy: 64 x 2 x 16
-    // pairs = 2048, 8 per thread.  The pair -> (channel, row, pair) map is fixed; only the tile origin moves.
-    constexpr int XQ = 18, DQ = 8;
-    float xv[XQ][2], dv[DQ][2];
+    // staging: pixel QUADS (16 bytes of fp32 in, 8 bytes of bf16 per part out).  x: 64 channels x HR halo rows x 9 quads (px x0-2 ..
+    // x0+33); dy: 64 x kSRows x 8 quads.  The quad -> (channel, row, quad) map is fixed per thread -- LDS offset, channel base and the
+    // (row, column) offsets relative to the tile origin are computed ONCE; only the origin moves.
+    constexpr int XN = 64 * HR * 9, DN = 64 * kSRows * 8;
+    constexpr int XQ = (XN + 255) / 256, DQ = (DN + 255) / 256;
+    int x_lo[XQ], x_dx[XQ], x_dr[XQ], d_lo[DQ], d_dx[DQ], d_dr[DQ];
+    uint32_t x_cb[XQ], d_cb[DQ];
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) {
+        const int e = tid + 256 * q, c = e / (HR * 9), rem = e - c * (HR * 9), hr = rem / 9, pq = rem - hr * 9;
+        const bool ok = e < XN && ci0 + c < Cin;
+        x_lo[q] = c * XCH + hr * XROW + 12 + 8 * pq;                  // px x0 sits at byte 16 of a row
+        x_dx[q] = 4 * pq - 2;
+        x_dr[q] = ok ? hr - 1 : -(1 << 20);                           // an invalid quad's row is never inside the image
+        x_cb[q] = (uint32_t)((size_t)(ci0 + c) * HWs) * 4u;
+    }
+#pragma unroll
+    for (int q = 0; q < DQ; ++q) {
+        const int e = tid + 256 * q, c = e / (kSRows * 8), rem = e - c * (kSRows * 8), r = rem >> 3, pq = rem & 7;
+        const bool ok = e < DN && co0 + c < Cout;
+        d_lo[q] = c * DCH + r * DROW + 8 * pq;
+        d_dx[q] = 4 * pq;
+        d_dr[q] = ok ? r : -(1 << 20);
+        d_cb[q] = (uint32_t)((size_t)(co0 + c) * HWs) * 4u;
+    }
+    float xv[XQ][4], dv[DQ][4];
     auto fetch = [&](int b) {
         const int tx = b % xtiles, ty = b / xtiles;
-        const int x0 = tx * 32, y0 = ty * WG_ROWS;
+        const int x0 = tx * 32, y0 = ty * kSRows;
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
-            const int e = tid + 256 * q, c = e / (HR * 18), rem = e - c * (HR * 18), hr = rem / 18, p = rem - hr * 18;
-            const int gc = ci0 + c, gy = y0 - 1 + hr, gx = x0 - 2 + 2 * p;
-            const bool row_ok = gc < Cin && gy >= 0 && gy < H;
-            const uint32_t base = (uint32_t)(((size_t)gc * H + gy) * W) * 4u;
-            xv[q][0] = frcnn_buf_load_f32(xbuf, (row_ok && gx >= 0 && gx < W) ? base + (uint32_t)gx * 4u : kBufOob);
-            xv[q][1] = frcnn_buf_load_f32(xbuf, (row_ok && gx + 1 >= 0 && gx + 1 < W) ? base + (uint32_t)(gx + 1) * 4u : kBufOob);
+            const int gy = y0 + x_dr[q], gx = x0 + x_dx[q];
+            const bool row_ok = gy >= 0 && gy < H;
+            const uint32_t base = x_cb[q] + (uint32_t)(gy * W + gx) * 4u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[q][j] = frcnn_buf_load_f32(xbuf, (row_ok && gx + j >= 0 && gx + j < W) ? base + 4u * j : kBufOob);
         }
 #pragma unroll
         for (int q = 0; q < DQ; ++q) {
-            const int e = tid + 256 * q, c = e >> 5, rem = e & 31, r = rem >> 4, p = rem & 15;
-            const int gc = co0 + c, gy = y0 + r, gx = x0 + 2 * p;
-            const bool row_ok = gc < Cout && gy < H;
-            const uint32_t base = (uint32_t)(((size_t)gc * H + gy) * W) * 4u;
-            dv[q][0] = frcnn_buf_load_f32(dbuf, (row_ok && gx < W) ? base + (uint32_t)gx * 4u : kBufOob);
-            dv[q][1] = frcnn_buf_load_f32(dbuf, (row_ok && gx + 1 < W) ? base + (uint32_t)(gx + 1) * 4u : kBufOob);
+            const int gy = y0 + d_dr[q], gx = x0 + d_dx[q];
+            const bool row_ok = gy >= 0 && gy < H;
+            const uint32_t base = d_cb[q] + (uint32_t)(gy * W + gx) * 4u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dv[q][j] = frcnn_buf_load_f32(dbuf, (row_ok && gx + j < W) ? base + 4u * j : kBufOob);
         }
     };
     auto stage = [&]() {
 #pragma unroll
         for (int q = 0; q < XQ; ++q) {
-            const int e = tid + 256 * q, c = e / (HR * 18), rem = e - c * (HR * 18), hr = rem / 18, p = rem - hr * 18;
-            uint32_t h, m, l;
-            frcnn_split3_pair(xv[q][0], xv[q][1], h, m, l);
-            unsigned char *d = x_lds + c * XCH + hr * XROW + 12 + 4 * p;          // px x0 sits at byte 16 of a row
-            *reinterpret_cast<uint32_t *>(d) = h;
-            *reinterpret_cast<uint32_t *>(d + XPART) = m;
-            *reinterpret_cast<uint32_t *>(d + 2 * XPART) = l;
+            if (XN % 256 != 0 && q == XQ - 1 && tid + 256 * q >= XN) continue;
+            uint32_t h0, m0, l0, h1, m1, l1;
+            frcnn_split3_pair(xv[q][0], xv[q][1], h0, m0, l0);
+            frcnn_split3_pair(xv[q][2], xv[q][3], h1, m1, l1);
+            unsigned char *d = x_lds + x_lo[q];                       // (4-byte aligned: two dword stores per part)
+            *reinterpret_cast<uint32_t *>(d) = h0; *reinterpret_cast<uint32_t *>(d + 4) = h1;
+            *reinterpret_cast<uint32_t *>(d + XPART) = m0; *reinterpret_cast<uint32_t *>(d + XPART + 4) = m1;
+            *reinterpret_cast<uint32_t *>(d + 2 * XPART) = l0; *reinterpret_cast<uint32_t *>(d + 2 * XPART + 4) = l1;
         }
 #pragma unroll
         for (int q = 0; q < DQ; ++q) {
-            const int e = tid + 256 * q, c = e >> 5, rem = e & 31, r = rem >> 4, p = rem & 15;
-            uint32_t h, m, l;
-            frcnn_split3_pair(dv[q][0], dv[q][1], h, m, l);
-            unsigned char *d = dy_lds + c * DCH + r * DROW + 4 * p;
-            *reinterpret_cast<uint32_t *>(d) = h;
-            *reinterpret_cast<uint32_t *>(d + DPART) = m;
-            *reinterpret_cast<uint32_t *>(d + 2 * DPART) = l;
+            if (DN % 256 != 0 && q == DQ - 1 && tid + 256 * q >= DN) continue;
+            uint32_t h0, m0, l0, h1, m1, l1;
+            frcnn_split3_pair(dv[q][0], dv[q][1], h0, m0, l0);
+            frcnn_split3_pair(dv[q][2], dv[q][3], h1, m1, l1);
+            unsigned char *d = dy_lds + d_lo[q];                      // 8-byte aligned
+            *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(d + DPART) = make_uint2(m0, m1);
+            *reinterpret_cast<uint2 *>(d + 2 * DPART) = make_uint2(l0, l1);
         }
     };
     auto compute = [&]() {
         const unsigned char *xa = x_lds + (wci * 32 + l31) * XCH + 16 + 16 * khalf;     // this lane's eight pixels of a 16-pixel step
         const unsigned char *db = dy_lds + (wco * 32 + l31) * DCH + 16 * khalf;
+        // unit u = (row r, 16-pixel step ks, tap row ky): 18 MFMAs.  One wave per SIMD has nobody to hide an LDS round trip behind, so
+        // the raw reads of unit u+1 are issued BEFORE the MFMAs of unit u (register double buffer, two units per trip so that it is
+        // indexed statically); the compiler's own schedule read each fragment right before its use: 9 exposed round trips per step
+        constexpr int NU = kSRows * 2 * 3;
+        struct Raw { uint4 mid[3]; uint32_t lo[3], hi[3]; uint4 b[3]; };
+        auto load = [&](int u, Raw &w) {
+            const int sidx = u / 3, ky = u - sidx * 3, r = sidx >> 1, ks = sidx & 1;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const unsigned char *row = xa + p * XPART + (r + ky) * XROW + ks * 32;
+                w.mid[p] = *reinterpret_cast<const uint4 *>(row);
+                w.lo[p] = *reinterpret_cast<const uint32_t *>(row - 4);
+                w.hi[p] = *reinterpret_cast<const uint32_t *>(row + 16);
+                w.b[p] = *reinterpret_cast<const uint4 *>(db + p * DPART + r * DROW + ks * 32);
+            }
+        };
+        auto mfmas = [&](int ky, const Raw &w) {
+            uint4 a[3][3];                                                               // [part][kx]
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const uint4 mid = w.mid[p];
+                const uint32_t s01 = frcnn_alignbit(mid.y, mid.x, 16), s12 = frcnn_alignbit(mid.z, mid.y, 16), s23 = frcnn_alignbit(mid.w, mid.z, 16);
+                a[p][0] = make_uint4(frcnn_alignbit(mid.x, w.lo[p], 16), s01, s12, s23);   // pixels -1 .. +6: tap column 0
+                a[p][1] = mid;
+                a[p][2] = make_uint4(s01, s12, s23, frcnn_alignbit(w.hi[p], mid.w, 16));   // pixels +1 .. +8: tap column 2
+            }
+            // six products per tap; the three taps of the row take turns so that consecutive MFMAs never share an accumulator
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[2][kx], w.b[0], acc[ky * 3 + kx]);     // l.h
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[0][kx], w.b[2], acc[ky * 3 + kx]);     // h.l
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[1][kx], w.b[1], acc[ky * 3 + kx]);     // m.m
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[1][kx], w.b[0], acc[ky * 3 + kx]);     // m.h
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[0][kx], w.b[1], acc[ky * 3 + kx]);     // h.m
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[0][kx], w.b[0], acc[ky * 3 + kx]);     // h.h
+        };
+        static_assert(NU % 6 == 0, "six units per trip: the tap row index is static");
+        Raw w0, w1;
+        load(0, w0);
 #pragma unroll 1
-        for (int s = 0; s < WG_ROWS * 2; ++s) {                                          // (row r, 16-pixel step ks)
-            const int r = s >> 1, ks = s & 1;
-            uint4 bfr[3];
+        for (int u = 0; u < NU; u += 6) {
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bfr[p] = *reinterpret_cast<const uint4 *>(db + p * DPART + r * DROW + ks * 32);
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                uint4 a[3][3];                                                           // [part][kx]
-#pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    const unsigned char *row = xa + p * XPART + (r + ky) * XROW + ks * 32;
-                    const uint4 mid = *reinterpret_cast<const uint4 *>(row);
-                    const uint32_t lo = *reinterpret_cast<const uint32_t *>(row - 4), hi = *reinterpret_cast<const uint32_t *>(row + 16);
-                    const uint32_t s01 = frcnn_alignbit(mid.y, mid.x, 16), s12 = frcnn_alignbit(mid.z, mid.y, 16), s23 = frcnn_alignbit(mid.w, mid.z, 16);
-                    a[p][0] = make_uint4(frcnn_alignbit(mid.x, lo, 16), s01, s12, s23);    // pixels -1 .. +6: tap column 0
-                    a[p][1] = mid;
-                    a[p][2] = make_uint4(s01, s12, s23, frcnn_alignbit(hi, mid.w, 16));    // pixels +1 .. +8: tap column 2
-                }
-                // six products per tap; the three taps of the row take turns so that consecutive MFMAs never share an accumulator
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[2][kx], bfr[0], acc[ky * 3 + kx]);     // l.h
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[0][kx], bfr[2], acc[ky * 3 + kx]);     // h.l
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[1][kx], bfr[1], acc[ky * 3 + kx]);     // m.m
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[1][kx], bfr[0], acc[ky * 3 + kx]);     // m.h
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[0][kx], bfr[1], acc[ky * 3 + kx]);     // h.m
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = frcnn_mfma_32x32x16_bf16(a[0][kx], bfr[0], acc[ky * 3 + kx]);     // h.h
+            for (int v = 0; v < 6; v += 2) {
+                load(u + v + 1, w1);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas(v % 3, w0);
+                if (u + v + 2 < NU) load(u + v + 2, w0);
+                __builtin_amdgcn_sched_barrier(0);
+                mfmas((v + 1) % 3, w1);
             }
         }
     };
@@ -1018,6 +1063,7 @@ int frcnn_conv_wgrad_f32s(const float *x, const float *dy, float *dw_packed, int
     if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cout * H * W * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;
     WgradPlan p = plan_wgrad(Cin, Cout, H, W, 3);
     if (!workspace || workspace_bytes < p.slab_floats * p.splits * sizeof(float)) return FRCNN_ERR_INVALID;   // the fp32 kernel's workspace fits
+    p.nblocks = p.xtiles * frcnn_cdiv(H, kSRows);                                   // this kernel's tiles are kSRows x 32 px
     int s = frcnn_cdiv(frcnn_cu_count(), p.ci_tiles * p.co_tiles);                   // ONE workgroup per CU
     const char *se = getenv("FRCNN_WGRAD_F32S_SPLITS");
     if (se && atoi(se) > 0) s = atoi(se);
