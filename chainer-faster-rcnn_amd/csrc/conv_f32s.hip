@@ -29,17 +29,8 @@ namespace {
 constexpr int kCK = 16;                 // channels per K-chunk = the MFMA's k extent
 constexpr int kParts = 3;
 
-__device__ __forceinline__ float bf16_hi_as_f32(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
-__device__ __forceinline__ float bf16_lo_as_f32(uint32_t packed) { return __uint_as_float(packed << 16); }
-
-// (v0, v1) -> the three packed bf16 pairs (h, m, l) with h + m + l == v exactly (round to nearest even at every step; the
-// differences are exact in fp32)
-__device__ __forceinline__ void split3_pair(float v0, float v1, uint32_t &h, uint32_t &m, uint32_t &l) {
-    h = frcnn_pack_bf16x2(v0, v1);
-    const float d0 = v0 - bf16_lo_as_f32(h), d1 = v1 - bf16_hi_as_f32(h);
-    m = frcnn_pack_bf16x2(d0, d1);
-    l = frcnn_pack_bf16x2(d0 - bf16_lo_as_f32(m), d1 - bf16_hi_as_f32(m));
-}
+// (v0, v1) -> the three packed bf16 pairs (h, m, l) with h + m + l == v exactly: frcnn_split3_pair (frcnn_intrin.h)
+__device__ __forceinline__ void split3_pair(float v0, float v1, uint32_t &h, uint32_t &m, uint32_t &l) { frcnn_split3_pair(v0, v1, h, m, l); }
 
 // ABL = timing ablations (WRONG results; scripts/conv_f32s_bench.py only): 1 no DMA, 4 no fragment reads / MFMAs
 template <int WPS, int ABL = 0, int NS = 1>
