@@ -455,7 +455,9 @@ __device__ __forceinline__ void cells_scan_chunk(const float4 *__restrict__ cell
 // in which a RoI's [8][7][7] block is assembled, so it leaves as ONE contiguous float4-coalesced run: full 128-byte lines, 2 store
 // instructions per RoI instead of 8 scattered ones -- the direct stores cost ~4 us of the r02a kernel's 17).  kRows = 76 (taller
 // maps): 155 KB image, 8 waves, direct stores.
-template <int kRows, bool OUT16>
+// OUT16: 0 = fp32, 1 = raw bf16 (one rounding of the fp32 maximum), 2 = the three bf16 terms of the fp32 maximum ([3][R][C*bins]: the
+// split tensor the fully connected layers of conv_f32s.hip read -- h + m + l is the fp32 value, exactly)
+template <int kRows, int OUT16>
 __global__ void __launch_bounds__(kRows <= 38 ? 1024 : 512)
 roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const float *__restrict__ rois, int roi_cols, int R,
                       int outh, int outw, float scale, float *__restrict__ y, int rsplit, const RoiBinTables tables, int dbg) {
@@ -654,7 +656,27 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
             // (r, c0 .. c0 + cg, :, :) is one contiguous run of cg*bins floats of y
             const int cg = min(8, C - c0), run = cg * bins;
             const size_t dst = ((size_t)r * C + c0) * bins;
-            if constexpr (OUT16) {
+            if constexpr (OUT16 == 2) {
+                uint16_t *y16 = reinterpret_cast<uint16_t *>(y);
+                const size_t part = (size_t)R * C * bins;
+                if ((run & 3) == 0 && (dst & 3) == 0) {
+                    for (int i = lane; i < run / 4; i += 64) {
+                        const float4 v4 = reinterpret_cast<const float4 *>(sv)[i];
+                        uint32_t h0, m0, l0, h1, m1, l1;
+                        frcnn_split3_pair(v4.x, v4.y, h0, m0, l0);
+                        frcnn_split3_pair(v4.z, v4.w, h1, m1, l1);
+                        reinterpret_cast<uint2 *>(y16 + dst)[i] = make_uint2(h0, h1);
+                        reinterpret_cast<uint2 *>(y16 + part + dst)[i] = make_uint2(m0, m1);
+                        reinterpret_cast<uint2 *>(y16 + 2 * part + dst)[i] = make_uint2(l0, l1);
+                    }
+                } else {
+                    for (int i = lane; i < run; i += 64) {
+                        uint32_t h, m, l;
+                        frcnn_split3_pair(sv[i], 0.0f, h, m, l);
+                        y16[dst + i] = (uint16_t)h; y16[part + dst + i] = (uint16_t)m; y16[2 * part + dst + i] = (uint16_t)l;
+                    }
+                }
+            } else if constexpr (OUT16 == 1) {
                 uint16_t *y16 = reinterpret_cast<uint16_t *>(y);
                 if ((run & 3) == 0 && (dst & 3) == 0) {
                     for (int i = lane; i < run / 4; i += 64) {
@@ -684,7 +706,13 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (cbase + q < C) {
-                        if constexpr (OUT16) reinterpret_cast<uint16_t *>(y)[dst + (size_t)q * bins] = (uint16_t)roi_f32_to_bf16(o[q]);
+                        if constexpr (OUT16 == 2) {
+                            uint32_t h, m, l;
+                            frcnn_split3_pair(o[q], 0.0f, h, m, l);
+                            uint16_t *y16 = reinterpret_cast<uint16_t *>(y) + dst + (size_t)q * bins;
+                            const size_t part = (size_t)R * C * bins;
+                            y16[0] = (uint16_t)h; y16[part] = (uint16_t)m; y16[2 * part] = (uint16_t)l;
+                        } else if constexpr (OUT16 == 1) reinterpret_cast<uint16_t *>(y)[dst + (size_t)q * bins] = (uint16_t)roi_f32_to_bf16(o[q]);
                         else y[dst + (size_t)q * bins] = o[q];
                     }
                 }
@@ -713,7 +741,7 @@ static int frcnn_roi_cu_count();
 
 // Launch the cell-major kernel when the map fits its LDS image (W <= 64 cells per row; H <= 38: two workgroups per CU,
 // H <= 76: one).  FRCNN_ROI_KERNEL=planes keeps the plane kernel (A/B measurements).  Returns false when it does not apply.
-template <bool OUT16>
+template <int OUT16>
 static bool roi_cells_launch(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
                              float scale, float *y, hipStream_t stream) {
     const char *sel = getenv("FRCNN_ROI_KERNEL");
@@ -812,7 +840,7 @@ int frcnn_roi_pool_fwd_chw(const float *x, int C, int H, int W, const float *roi
     if (!x || !rois || !y || C < 1 || H < 1 || W < 1 || R < 0) return FRCNN_ERR_INVALID;
     if (outh < 1 || outw < 1 || outh > 7 || outw > 7 || (roi_cols != 4 && roi_cols != 5)) return FRCNN_ERR_INVALID;
     if (R == 0) return FRCNN_OK;
-    if (!argmax && roi_cells_launch<false>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, y, stream)) return frcnn_launch_status();
+    if (!argmax && roi_cells_launch<0>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, y, stream)) return frcnn_launch_status();
     const int cg = roi_planes_per_group(C, H, W, outh, outw);
     if (cg == 0) {     // map too large for LDS-resident planes: channel-last gather kernel
         if (!workspace || workspace_bytes < frcnn_roi_pool_workspace_bytes(C, H, W)) return FRCNN_ERR_INVALID;
@@ -834,13 +862,23 @@ int frcnn_roi_pool_fwd_chw(const float *x, int C, int H, int W, const float *roi
     return frcnn_launch_status();
 }
 
+int frcnn_roi_pool_fwd_chw_f32s(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw, float spatial_scale,
+                                uint16_t *y_parts, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !rois || !y_parts || C < 1 || H < 1 || W < 1 || R < 0) return FRCNN_ERR_INVALID;
+    if (outh < 1 || outw < 1 || outh > 7 || outw > 7 || (roi_cols != 4 && roi_cols != 5)) return FRCNN_ERR_INVALID;
+    if (R == 0) return FRCNN_OK;
+    if (roi_cells_launch<2>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, reinterpret_cast<float *>(y_parts), stream)) return frcnn_launch_status();
+    return FRCNN_ERR_INVALID;                        // cell-major kernel only (maps up to 76 x 64): pool in fp32 and frcnn_f32s_split otherwise
+}
+
 int frcnn_roi_pool_fwd_chw_bf16(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
                                 float spatial_scale, uint16_t *y, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !rois || !y || C < 1 || H < 1 || W < 1 || R < 0) return FRCNN_ERR_INVALID;
     if (outh < 1 || outw < 1 || outh > 7 || outw > 7 || (roi_cols != 4 && roi_cols != 5)) return FRCNN_ERR_INVALID;
     if (R == 0) return FRCNN_OK;
-    if (roi_cells_launch<true>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, reinterpret_cast<float *>(y), stream)) return frcnn_launch_status();
+    if (roi_cells_launch<1>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, reinterpret_cast<float *>(y), stream)) return frcnn_launch_status();
     const int cg = roi_planes_per_group(C, H, W, outh, outw);
     if (cg == 0) return FRCNN_ERR_INVALID;          // plane-resident kernel only: convert an fp32 result with frcnn_f32_to_bf16 instead
     const int cgroups = frcnn_cdiv(C, cg);

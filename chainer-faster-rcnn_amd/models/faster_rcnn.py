@@ -180,7 +180,11 @@ class FasterRCNN(object):
         else:
             rois, probs, n_out = self.RPN.proposal_layer.forward_device(prob, bbox, im_h, im_w)
         mark("proposals")
-        if self.head_dtype == "bf16" and not keep:
+        pool5_split = None
+        if self.head_dtype == "f32s" and not keep and H <= 76 and W <= 64:
+            pool5 = pool5_split = rt.roi_pool_fwd_chw_f32s(feat, rois, 7, 7, self._spatial_scale)   # fp32 maxima, stored as their three bf16 terms
+            pool5_bits = None
+        elif self.head_dtype == "bf16" and not keep:
             pool5 = rt.roi_pool_fwd_chw_bf16(feat, rois, 7, 7, self._spatial_scale)       # pooled in fp32, stored as bf16 bits
             pool5_bits = pool5
         else:
@@ -188,7 +192,9 @@ class FasterRCNN(object):
             pool5_bits = None
         mark("roi_pool")
         if self.head_dtype == "f32s":
-            fc6 = self.fc6.f32s(rt.f32s_split(pool5.reshape(int(pool5.shape[0]), -1)), relu=True, out_split=True)
+            if pool5_split is None:
+                pool5_split = rt.f32s_split(pool5.reshape(int(pool5.shape[0]), -1))
+            fc6 = self.fc6.f32s(pool5_split, relu=True, out_split=True)
             mark("fc6")
             fc7 = self.fc7.f32s(fc6, relu=True, out_split=True)
             mark("fc7")

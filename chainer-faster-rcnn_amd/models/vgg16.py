@@ -162,6 +162,7 @@ class VGG16Prev(object):
         as fp32 NCHW (h + m + l: exact)."""
         rt = self.rt
         h = None                             # the image is split lazily: a first layer with <= 3 input channels reads it as fp32 NCHW
+        feat = None
         n_pool, cout, skip = 0, int(x.shape[1]), False
         as_nchw = lambda t, c: rt.f32s_to_nchw(t, c)
         for idx, l in enumerate(self.layers):
@@ -185,7 +186,11 @@ class VGG16Prev(object):
                 else:
                     if h is None:
                         h = rt.f32s_from_nchw(x)
-                    h = link.f32s(h, relu=True, pool=fuse)
+                    if idx + 1 == len(self.layers) and not fuse:
+                        # the last convolution writes its result twice: the split tensor (rpn_conv_3x3's input) and fp32 NCHW (RoI pooling)
+                        h, feat = rt.conv3x3_f32s_train(h, link.Ws, link.b, l[1], l[2], relu=True, want_split=True, want_nchw=True)
+                    else:
+                        h = link.f32s(h, relu=True, pool=fuse)
                 skip = fuse
                 cout = l[2]
                 if timer:
@@ -193,9 +198,10 @@ class VGG16Prev(object):
                 if collect is not None:
                     collect["pool%d" % (n_pool + 1) if fuse else l[0]] = as_nchw(h, cout)
         self.feat_split = h                  # the split tensor itself: the RPN's convolution takes it as is
-        feat = rt.f32s_to_nchw(h, cout)
-        if timer:
-            timer.mark("to_nchw")
+        if feat is None:                     # (a trunk that ends in a pool or in its first layer)
+            feat = rt.f32s_to_nchw(h, cout)
+            if timer:
+                timer.mark("to_nchw")
         return feat
 
 

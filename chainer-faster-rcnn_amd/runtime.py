@@ -222,6 +222,16 @@ class Runtime(object):
                                                  m.ptr(y), m.stream()), "frcnn_roi_pool_fwd_chw_bf16")
         return y
 
+    def roi_pool_fwd_chw_f32s(self, x, rois, outh, outw, scale):
+        """The same pooling with the fp32 maxima written as their three bf16 terms, (3, R, C*outh*outw): the split FC head's input."""
+        m, L = self.mem, self.lib
+        C, H, W = [int(v) for v in x.shape[-3:]]
+        R = int(rois.shape[0])
+        y = m.empty((3, R, C * outh * outw), "i16")
+        _lib.check(L.frcnn_roi_pool_fwd_chw_f32s(m.ptr(x), C, H, W, m.ptr(rois), R, int(rois.shape[1]), outh, outw, float(scale),
+                                                 m.ptr(y), m.stream()), "frcnn_roi_pool_fwd_chw_f32s")
+        return y
+
     def chw_to_hwc(self, x):
         m, L = self.mem, self.lib
         C, H, W = [int(v) for v in x.shape[-3:]]

@@ -106,6 +106,10 @@ int frcnn_roi_pool_fwd_hwc(const float *xt, int C, int H, int W, const float *ro
 int frcnn_roi_pool_fwd_chw(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols,
                            int outh, int outw, float spatial_scale, float *y, int32_t *argmax, void *workspace,
                            size_t workspace_bytes, void *stream);
+/* the same pooling with the fp32 maxima written as their three bf16 terms, y_parts = [3][R][C*outh*outw] (h + m + l = the fp32
+ * value, exactly): the split tensor frcnn_linear_f32s reads (cell-major kernel only: maps up to 76 x 64) */
+int frcnn_roi_pool_fwd_chw_f32s(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
+                                float spatial_scale, uint16_t *y_parts, void *stream);
 /* the same with the pooled values written as raw bf16 (one rounding of the fp32 maximum): the input of the bf16 FC head
  * (BASELINE config 3) without the fp32 pool5 round trip.  Plane-resident kernel only (maps whose plane fits in LDS). */
 int frcnn_roi_pool_fwd_chw_bf16(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh,

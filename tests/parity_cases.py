@@ -239,6 +239,10 @@ def check_roi_pool_cells(rt):
         got = host(rt, rt.roi_pool_fwd(dev(rt, x[0]), dev(rt, rois), oh, ow, 0.0625))
         assert np.array_equal(np.isnan(got), np.isnan(want)), (R, C, H, W)
         assert np.array_equal(np.nan_to_num(got, nan=-1.0), np.nan_to_num(want, nan=-1.0)), (R, C, H, W, oh, ow)
+        if W <= 64 and hasattr(rt, "roi_pool_fwd_chw_f32s") and seed in (0, 1, 3, 5):     # split-tensor output: h + m + l == the fp32 maxima
+            ysp = rt.roi_pool_fwd_chw_f32s(dev(rt, x[0]), dev(rt, np.ascontiguousarray(rois[:, 1:])), oh, ow, 0.0625)
+            back = host(rt, rt.f32s_join(ysp)).reshape(want.shape)
+            assert np.array_equal(np.isnan(back), np.isnan(want)) and np.array_equal(np.nan_to_num(back, nan=-1.0), np.nan_to_num(want, nan=-1.0))
         if W <= 64 and hasattr(rt, "roi_pool_fwd_chw_bf16") and seed in (1, 3):
             _, want_bits = to_bf16(want.reshape(R, -1))
             y5 = host(rt, rt.roi_pool_fwd_chw_bf16(dev(rt, x[0]), dev(rt, np.ascontiguousarray(rois[:, 1:])), oh, ow, 0.0625))
@@ -562,6 +566,15 @@ def check_conv_f32s(rt, Cin, Cout, H, W, relu=True, seed=0, tol=3e-6):
     if relu:
         yp = rt.conv3x3_f32s(xd, wpk, bd, Cin, Cout, relu=True, pool=True)
         assert np.array_equal(host(rt, rt.f32s_to_nchw(yp, Cout)), O.max_pool_2x2(y))
+    # training forms: both outputs in one launch, bit-identical to the separate ones; with a mask, y = (mask > 0) ? y : 0
+    ys2, yn2 = rt.conv3x3_f32s_train(xd, wpk, bd, Cin, Cout, relu=relu)
+    assert np.array_equal(host(rt, yn2), y) and np.array_equal(host(rt, ys2), host(rt, ys))
+    mask = (rs.rand(1, Cout, H, W) > 0.4).astype(np.float32) * rs.rand(1, Cout, H, W).astype(np.float32)
+    ys3, yn3 = rt.conv3x3_f32s_train(xd, wpk, bd, Cin, Cout, relu=relu, mask=dev(rt, mask))
+    assert np.array_equal(host(rt, yn3), np.where(mask > 0, y, 0).astype(np.float32))
+    assert np.array_equal(host(rt, rt.f32s_to_nchw(ys3, Cout)), host(rt, yn3))
+    _, yn4 = rt.conv3x3_f32s_train(xd, wpk, bd, Cin, Cout, relu=relu, want_split=False, mask=dev(rt, mask))
+    assert np.array_equal(host(rt, yn4), host(rt, yn3))
 
 
 def check_f32s_weight_packs(rt, Cin=20, Cout=40, seed=0):
