@@ -710,6 +710,9 @@ static int conv_f32s_pick_split(long tiles, int chunks) {
     const char *e = getenv("FRCNN_F32S_SPLIT");
     int s = e ? atoi(e) : (int)((2L * frcnn_cu_count()) / (tiles > 0 ? tiles : 1));
     if (tiles > kF32sMaxSplitTiles && !e) s = 1;
+    // a launch that fills the slots once and leaves a thin second round (conv4_2/3: 608 tiles) gains 5 % from two splits when its
+    // chunk loop is long enough to carry them (512 input channels); with 256 channels (conv4_1) it loses (r02o)
+    if (!e && tiles > 2L * frcnn_cu_count() && 2 * tiles <= 3 * 2L * frcnn_cu_count() && chunks >= 32) s = 2;
     if (s > 4) s = 4;
     if (s < 1) s = 1;
     while (s > 1 && chunks / s < 4) --s;                          // a split should still carry a few chunks
