@@ -460,7 +460,13 @@ __device__ __forceinline__ void cells_scan_chunk(const float4 *__restrict__ cell
 template <int kRows, int OUT16>
 __global__ void __launch_bounds__(kRows <= 38 ? 1024 : 512)
 roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const float *__restrict__ rois, int roi_cols, int R,
-                      int outh, int outw, float scale, float *__restrict__ y, int rsplit, const RoiBinTables tables, int dbg) {
+                      int outh, int outw, float scale, float *__restrict__ y, int rsplit, const RoiBinTables tables, int dbg_arg) {
+#ifdef FRCNN_TIMING_ABLATIONS                    // tuning builds only (scripts/roi_ablate.py): 2 prologue only, 4 no scan, 8 no output -- WRONG results
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#endif
     constexpr int kCellWaves = kRows <= 38 ? 16 : 8;
     constexpr bool STAGED = kRows <= 38;
     __shared__ __attribute__((aligned(16))) float4 cells[kRows * kCellPitch * 2];
@@ -773,8 +779,11 @@ static bool roi_cells_launch(const float *x, int C, int H, int W, const float *r
             tables.tabmax[t][ext] = (uint8_t)m;
         }
     }
+    int dbg = 0;
+#ifdef FRCNN_TIMING_ABLATIONS
     const char *dbg_s = getenv("FRCNN_ROI_DBG");
-    const int dbg = dbg_s ? atoi(dbg_s) : 0;
+    dbg = dbg_s ? atoi(dbg_s) : 0;
+#endif
     const dim3 grid(cgroups, rsplit), blk(64 * waves);
     if (H <= 38) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<38, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, tables, dbg);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<76, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, tables, dbg);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Timing ablations of roi_pool_cells_kernel on the benchmark's own map and RoIs (FRCNN_ROI_DBG bits: 1 arrival order instead of
-longest-first, 2 prologue only, 4 no scan, 8 no output).  GPU only."""
+longest-first, 2 prologue only, 4 no scan, 8 no output).  Needs a tuning build of the library (FRCNN_TIMING_ABLATIONS=1 python
+chainer-faster-rcnn_amd/csrc/build.py --force: see scripts/r02_gpu_l.sh); the shipped build ignores FRCNN_ROI_DBG.  GPU only."""
 import os
 import sys
 
