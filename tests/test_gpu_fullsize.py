@@ -117,6 +117,16 @@ def test_rpn_train_step_600x1000(rt):
     assert losses["rpn_loss"] > 0 and worst <= 3e-3
 
 
+def test_rpn_train_step_600x1000_split_products(rt):
+    """The same step with RPNTrainer(conv_math="split"): forward, input-gradient and weight-gradient convolutions as six bf16 MFMA
+    products of 3-way split fp32 operands -- the SAME bars as the fp32-MFMA step above (the weight-gradient kernel judged on its own
+    inputs against a float64 accumulation, 1e-4; end to end 3e-3)."""
+    import train_cases as T
+    losses, worst = T.check_vgg_step(rt, im_h=IM_H, im_w=IM_W, seed=0, conv_math="split")
+    print("\nPARITY rpn_train_600x1000_split_products %s" % json.dumps({"losses": losses, "worst_grad_rel_err_end_to_end": float(worst)}))
+    assert losses["rpn_loss"] > 0 and worst <= 3e-3
+
+
 def test_resnet101_config4_600x1000(rt):
     """configs[3]: ResNet-101 trunk at 600 x 1000 (res5 = 2048 x 19 x 32, stride 32), ProposalLayer at 1000 / 300."""
     from chainer_faster_rcnn_amd import synthetic
