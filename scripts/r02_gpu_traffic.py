@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Summarise the FETCH_SIZE / WRITE_SIZE passes of `rocprofv3 --pmc` over bench.py (scripts/r02_gpu_f.sh) into
+"""Summarise the FETCH_SIZE / WRITE_SIZE passes of `rocprofv3 --pmc` over bench.py (scripts/r02_gpu_final.sh) into
 profiles/r02_hbm_traffic_pmc[_bf16].json.  Counters are per dispatch, in KB, summed over the L2 channels; they sit on the L2's
 fabric side (Infinity-Cache hits are counted).  Correction (MI355X_MICROARCH.md, HBM section): on gfx950 FETCH_SIZE reports HALF the
 bytes of 16-byte-per-lane loads (`buffer_load_dwordx4 ... lds` included).  The bf16 kernels load 16 B per lane only -> FETCH x 2.
