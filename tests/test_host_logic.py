@@ -30,7 +30,7 @@ def test_device_library_builds_and_exports_every_declared_symbol():
     assert norm(ref) in norm(hdr)
     import chainer_faster_rcnn_amd as pkg
     assert sorted(pkg._lib.SIGNATURES) == _declared()   # the binding table mirrors the header one to one
-    assert lib.frcnn_abi_version() == 13
+    assert lib.frcnn_abi_version() == 14
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -118,3 +118,29 @@ def test_roi_pooling_function_object(golden):
     assert np.allclose(gx, O.roi_pooling_2d_backward(np.ones_like(want), am, rois, x.shape))
     with pytest.raises(ValueError):
         roi_pooling_2d(x, rois[:, :4], 7, 7, 1 / 16., runtime=rt)
+
+
+def test_split_tensor_entry_points_reject_bad_arguments():
+    """The fp32-on-bf16-matrix-cores entry points (csrc/conv_f32s.hip, train.hip) fail with FRCNN_ERR_INVALID, not with a launch, on
+    arguments outside their contract (checked on the host-compiled library: no GPU needed)."""
+    import ctypes
+    from emu_runtime import emu_runtime
+    rt = emu_runtime()
+    L, m = rt.lib, rt.mem
+    buf = m.empty((4096,), "f32")
+    p = m.ptr(buf)
+    INVALID = -1 if not hasattr(L, "FRCNN_ERR_INVALID") else L.FRCNN_ERR_INVALID
+    bad = [
+        L.frcnn_conv3x3_f32s(p, p, p, p, 16, 16, 4, 4, 1, 5, None),                      # out_mode out of range
+        L.frcnn_conv3x3_f32s(p, p, p, p, 16, 16, 4, 4, 0, 2, None),                      # fused pool needs the ReLU
+        L.frcnn_conv3x3_f32s(None, p, p, p, 16, 16, 4, 4, 1, 0, None),
+        L.frcnn_conv1_f32s(p, p, p, p, 4, 64, 4, 4, 1, None),                            # first-layer kernel: Cin <= 3
+        L.frcnn_conv1_f32s(p, p, p, p, 3, 65, 4, 4, 1, None),                            # ... and Cout <= 64
+        L.frcnn_linear_f32s(p, p, p, p, 4, 8, 40, 0, 0, p, 4096 * 4, None),              # K % 32 != 0
+        L.frcnn_linear_f32s(p, p, p, p, 4, 8, 64, 0, 0, None, 0, None),                  # no workspace
+        L.frcnn_conv3x3_f32s_train(p, p, p, None, None, None, 16, 16, 4, 4, 1, None, 0, None),    # neither output
+        L.frcnn_conv_wgrad_f32s(p, p, p, 16, 16, 4, 4, None, 0, None),                   # no workspace
+        L.frcnn_f32s_pack_many(None, 1, None),
+        L.frcnn_roi_pool_fwd_chw_f32s(p, 8, 100, 100, p, 4, 4, 7, 7, ctypes.c_float(0.0625), p, None),   # map too large for the cell kernel
+    ]
+    assert all(rc != 0 for rc in bad), bad
