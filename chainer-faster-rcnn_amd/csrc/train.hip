@@ -226,21 +226,28 @@ rpn_loss_kernel(const float *__restrict__ score, const float *__restrict__ bbox_
 // ------------------------------------------------------------------------------------------------
 // F.max_pooling_2d(2, 2) backward, gather form: an input cell receives the window's gradient iff it is the FIRST
 // maximum of its window in (ky, kx) scan order (Chainer's im2col argmax); windows do not overlap, so no atomics.
+// One thread per WINDOW: its four cells are read once (the cell-per-thread form read the window four times and spent three 64-bit
+// divisions per cell), its gradient once, its four outputs written as two pairs.
 __global__ void __launch_bounds__(256)
 maxpool2x2_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx, int C, int H, int W, int OH, int OW) {
-    const size_t total = (size_t)C * H * W;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int w = (int)(i % W), h = (int)((i / W) % H), c = (int)(i / ((size_t)W * H));
-        const int oh = h >> 1, ow = w >> 1;
-        const float *p = x + ((size_t)c * H + 2 * oh) * W + 2 * ow;
-        const bool hasx = 2 * ow + 1 < W, hasy = 2 * oh + 1 < H;
-        float m = p[0];
+    const uint32_t total = (uint32_t)C * OH * OW;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t ow = i % (uint32_t)OW, t = i / (uint32_t)OW, oh = t % (uint32_t)OH, c = t / (uint32_t)OH;
+        const size_t base = ((size_t)c * H + 2 * oh) * W + 2 * ow;
+        const float *p = x + base;
+        const bool hasx = 2 * ow + 1 < (uint32_t)W, hasy = 2 * oh + 1 < (uint32_t)H;
+        const float v0 = p[0], v1 = hasx ? p[1] : 0.0f, v2 = hasy ? p[W] : 0.0f, v3 = (hasx && hasy) ? p[W + 1] : 0.0f;
+        float m = v0;
         int arg = 0;
-        if (hasx && p[1] > m) { m = p[1]; arg = 1; }
-        if (hasy && p[W] > m) { m = p[W]; arg = 2; }
-        if (hasx && hasy && p[W + 1] > m) { m = p[W + 1]; arg = 3; }
-        const int me = (h & 1) * 2 + (w & 1);
-        dx[i] = (me == arg) ? dy[((size_t)c * OH + oh) * OW + ow] : 0.0f;
+        if (hasx && v1 > m) { m = v1; arg = 1; }
+        if (hasy && v2 > m) { m = v2; arg = 2; }
+        if (hasx && hasy && v3 > m) { m = v3; arg = 3; }
+        const float g = dy[i];
+        float *d = dx + base;
+        d[0] = arg == 0 ? g : 0.0f;
+        if (hasx) d[1] = arg == 1 ? g : 0.0f;
+        if (hasy) d[W] = arg == 2 ? g : 0.0f;
+        if (hasx && hasy) d[W + 1] = arg == 3 ? g : 0.0f;
     }
 }
 
@@ -254,7 +261,19 @@ bias_grad_partial_kernel(const float *__restrict__ dy, int HW, int parts, float 
     const int begin = part * per, end = min(HW, begin + per);
     const float *p = dy + (size_t)c * HW;
     float s = 0.0f;
-    for (int i = begin + threadIdx.x; i < end; i += 256) s += p[i];
+    // float4 loads over the 16-byte aligned middle of the slice, scalars at its ragged ends (a thread's partial sum is then added
+    // in a fixed order: still deterministic, though not the scalar loop's order)
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(p + begin);
+    int head = (int)(((16 - (addr & 15)) & 15) >> 2);
+    if (head > end - begin) head = end - begin;
+    const int n4 = (end - begin - head) >> 2;
+    if ((int)threadIdx.x < head) s += p[begin + threadIdx.x];
+    const float4 *p4 = reinterpret_cast<const float4 *>(p + begin + head);
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = p4[i];
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+    for (int i = begin + head + 4 * n4 + threadIdx.x; i < end; i += 256) s += p[i];
     red[threadIdx.x] = s;
     __syncthreads();
     for (int q = 128; q > 0; q >>= 1) {
@@ -992,7 +1011,8 @@ int frcnn_scatter_rows_f32(const float *src, const int32_t *idx, int n, int cols
 int frcnn_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int C, int H, int W, void *stream) {
     if (!x || !dy || !dx || C < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
     const int OH = (H + 1) / 2, OW = (W + 1) / 2;
-    const size_t total = (size_t)C * H * W;
+    const size_t total = (size_t)C * OH * OW;                     // one thread per window
+    if (total >= (1ull << 32)) return FRCNN_ERR_INVALID;
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dy, dx, C, H, W, OH, OW);
     return frcnn_launch_status();
