@@ -351,59 +351,67 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
 
 // First layer (Cin * 9 <= 32: conv1_1, 3 channels): the fp32 NCHW image goes in as it is.  K = (ci, tap) padded to 32 = two MFMA
 // k-steps; the weight fragments (64 couts x 32 k, three parts) live in registers for the whole kernel; a workgroup holds the fp32
-// halo of an 8-row x 64-px tile in LDS (8 KB), each wave builds the im2col B fragments of a 32-px row segment from it (16 ds_read_b32,
-// the 3-way split in registers) -- 24 MFMAs per 32 px x 64 couts -- and writes the split output straight from the accumulators
-// (8-byte pieces: 4 consecutive couts of a pixel).  The generic kernel would stage 74 KB per tile for 3 real channels and run
-// 108 MFMAs per 2 rows: 131 us on the 600x1000 image; this one is bound by its 230 MB of output.
+// halo of a 4-row x 64-px tile in LDS (5 KB), each wave builds the im2col B fragments of a 32-px row segment from it (16 ds_read_b32,
+// the 3-way split in registers) -- 24 MFMAs per 32 px x 64 couts -- and the split output leaves through the wave's LDS tile as
+// contiguous 1 KB runs.  The generic kernel would stage 74 KB per tile for 3 real channels and run 108 MFMAs per 2 rows: 131 us on
+// the 600x1000 image; this one is bound by its 230 MB of output.
+// PERSISTENT: the launch holds as many workgroups as the chip seats at once and each strides over the tiles, so the prologue (32
+// weight loads per lane, gathered across the (Cout, K) matrix -- issued as ONE batch: clamped index, unconditional load, value
+// select; the first version's predicated loads each waited for the previous one, ~20 us per workgroup) is paid once, and the next
+// tile's halo (5 loads per thread, same batch form) is in flight while the current tile's units run.
 // SPLIT = false: the plain bf16 form of the same kernel (conv_bf16.hip's chain: operands rounded to bf16, one MFMA per k-step, the
 // result rounded to bf16 once) -- only the h terms exist.
-template <int NCB, bool SPLIT = true>                // cout blocks of 32
-__global__ void __launch_bounds__(256, 2)
+template <int NCB, bool SPLIT = true, bool DUAL = false>        // cout blocks of 32; DUAL: the fp32 NCHW map as well (training)
+__global__ void __launch_bounds__(256, SPLIT ? 2 : 4)
 conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, uint16_t *__restrict__ y, int Cin,
-                  int Cout, int H, int W, int relu, int w_is_packed, float *__restrict__ y_nchw) {
-    constexpr int TR = 8, TW = 64, HR = TR + 2, PITCH = TW + 4;        // LDS row: 66 used of 68 floats
+                  int Cout, int H, int W, int relu, int w_is_packed, float *__restrict__ y_nchw, int xtiles, int ntiles) {
+    constexpr int TR = 4, TW = 64, HR = TR + 2, PITCH = TW + 4;        // LDS row: 66 used of 68 floats; tile row = wave
     constexpr int CMAX = 3;
     __shared__ float xt[CMAX * HR * PITCH];
+    __shared__ __attribute__((aligned(16))) float sbias[32 * NCB];
     constexpr int NPARTS = SPLIT ? kParts : 1;
     constexpr int OPX = 32 + 16;                                       // output staging: bytes per (pixel, 16-cout block) + pad
     __shared__ __attribute__((aligned(16))) unsigned char ot[4][2 * NCB][32 * OPX];     // per wave: one part of a unit's tile, [cout block of 16][px]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, khalf = lane >> 5;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TR;
     const int K = Cin * 9;
-    // ---- halo tile (zero outside the image and for channels >= Cin)
-    for (int e = tid; e < CMAX * HR * (TW + 2); e += 256) {
-        const int ci = e / (HR * (TW + 2)), rem = e - ci * (HR * (TW + 2));
-        const int r = rem / (TW + 2), c = rem - r * (TW + 2);
-        const int gy = y0 - 1 + r, gx = x0 - 1 + c;
-        xt[(ci * HR + r) * PITCH + c] = (ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((size_t)ci * H + gy) * W + gx] : 0.0f;
-    }
+    if (tid < 32 * NCB) sbias[tid] = tid < Cout ? bias[tid] : 0.0f;
+    const frcnn_buf_t wbuf = frcnn_make_buf(w, (uint32_t)(Cout * K) * 4u);
+    const int wk = w_is_packed ? Cout : 1, wc = w_is_packed ? 1 : K;   // element strides of (k, cout) in w
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)Cin * H * W * 4));
     // ---- weight fragments: lane (cout l31 of block cb, k = 16 s + 8 khalf + e), k = ci * 9 + tap; the three parts of (Cout, K) fp32
     constexpr int NP = SPLIT ? kParts : 1;
     uint4 a[NCB][2][NP];
+    {
+        float wv[NCB][2][8];
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb)
+        for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            uint32_t hp[4], mp[4], lp[4];
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int k = 16 * s2 + 8 * khalf + 2 * e, co = cb * 32 + l31;
-                // w: Chainer's (Cout, Cin, 3, 3), or (w_is_packed) the trainers' packed [(ci * 9 + tap)][co]
-                const float w0 = (co < Cout && k < K) ? (w_is_packed ? w[(size_t)k * Cout + co] : w[(size_t)co * K + k]) : 0.0f;
-                const float w1 = (co < Cout && k + 1 < K) ? (w_is_packed ? w[(size_t)(k + 1) * Cout + co] : w[(size_t)co * K + k + 1]) : 0.0f;
-                split3_pair(w0, w1, hp[e], mp[e], lp[e]);
+                for (int e = 0; e < 8; ++e) {
+                    const int k = 16 * s2 + 8 * khalf + e, co = cb * 32 + l31;
+                    // w: Chainer's (Cout, Cin, 3, 3), or (w_is_packed) the trainers' packed [(ci * 9 + tap)][co]; out of range -> 0
+                    wv[cb][s2][e] = frcnn_buf_load_f32(wbuf, (co < Cout && k < K) ? (uint32_t)(k * wk + co * wc) * 4u : kBufOob);
+                }
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                uint32_t hp[4], mp[4], lp[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split3_pair(wv[cb][s2][2 * e], wv[cb][s2][2 * e + 1], hp[e], mp[e], lp[e]);
+                a[cb][s2][0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+                if constexpr (SPLIT) {
+                    a[cb][s2][1] = make_uint4(mp[0], mp[1], mp[2], mp[3]);
+                    a[cb][s2][2] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
+                }
             }
-            a[cb][s2][0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-            if constexpr (SPLIT) {
-                a[cb][s2][1] = make_uint4(mp[0], mp[1], mp[2], mp[3]);
-                a[cb][s2][2] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
-            }
-        }
-    // ---- per-lane LDS offsets of the 16 im2col elements (floats), relative to (row 2 * wave, column 0) of the tile
+    }
+    // ---- per-lane LDS offsets of the 16 im2col elements (floats), relative to column 0 of the wave's tile row
+    // (k >= K: the weight is zero and the element read instead -- k = 0, the pixel's own first tap -- is a finite image value)
     int boff[2][8];
-    bool bval[2][8];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -411,101 +419,140 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
             const int k = 16 * s2 + 8 * khalf + e;
             const int kk = k < K ? k : 0;
             const int ci = kk / 9, tap = kk - ci * 9, ky = tap / 3, kx = tap - ky * 3;
-            bval[s2][e] = k < K;
-            boff[s2][e] = (ci * HR + 2 * wave + ky) * PITCH + kx + l31;
+            boff[s2][e] = (ci * HR + wave + ky) * PITCH + kx + l31;
         }
-    __syncthreads();
+    // ---- halo loads: wave w fetches halo rows w, w + 4, ... (row = ci * HR + r, wave-uniform) at column `lane`; the two columns past
+    // 64 of all 18 rows are one more load of threads 0..35.  Zero outside the image and for channels >= Cin (out-of-range offset).
+    constexpr int HROWS = CMAX * HR, HIT = (HROWS + 3) / 4;
+    float hv[HIT + 1];
+    auto load_halo = [&](int tile) {
+        const int ty = tile / xtiles, tx = tile - ty * xtiles;
+        const int gx0 = tx * TW - 1, gy0 = ty * TR - 1;
+#pragma unroll
+        for (int j = 0; j < HIT; ++j) {
+            const int row = wave + 4 * j, ci = row / HR, gy = gy0 + row - ci * HR, gx = gx0 + lane;
+            const bool ok = row < HROWS && ci < Cin && gy >= 0 && gy < H && gx >= 0 && gx < W;
+            hv[j] = frcnn_buf_load_f32(xbuf, ok ? (uint32_t)((ci * H + gy) * W + gx) * 4u : kBufOob);
+        }
+        {
+            const int row = tid >> 1, ci = row / HR, gy = gy0 + row - ci * HR, gx = gx0 + TW + (tid & 1);
+            const bool ok = row < HROWS && ci < Cin && gy >= 0 && gy < H && gx < W;
+            hv[HIT] = frcnn_buf_load_f32(xbuf, ok ? (uint32_t)((ci * H + gy) * W + gx) * 4u : kBufOob);
+        }
+    };
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int j = 0; j < HIT; ++j)
+            if (wave + 4 * j < HROWS) xt[(wave + 4 * j) * PITCH + lane] = hv[j];
+        if (tid < 2 * HROWS) xt[(tid >> 1) * PITCH + TW + (tid & 1)] = hv[HIT];
+    };
     const int CoutP = (Cout + 15) / 16 * 16;
     const size_t y_part = (size_t)CoutP * H * W;
-    // ---- units: wave w owns tile rows 2w, 2w + 1, two 32-px segments each
+    const uint32_t plane_bytes = (uint32_t)(H * W) * 32u;              // one 16-cout block of one part
+    frcnn_buf_t ybuf[NPARTS];
+#pragma unroll
+    for (int part = 0; part < NPARTS; ++part) ybuf[part] = frcnn_make_buf(y + part * y_part, (uint32_t)(y_part * 2));
+    const frcnn_buf_t nbuf = frcnn_make_buf(y_nchw, DUAL ? (uint32_t)((size_t)Cout * H * W * 4) : 0u);
+    int tile = blockIdx.x;
+    if (tile < ntiles) load_halo(tile);
 #pragma unroll 1
-    for (int u = 0; u < 4; ++u) {
-        const int i = u >> 1, seg = u & 1;
-        const int py = y0 + 2 * wave + i, px = x0 + seg * 32 + l31;
-        if (py >= H || x0 + seg * 32 >= W) continue;                   // wave-uniform
-        uint4 b[2][NP];
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int ty = tile / xtiles, tx = tile - ty * xtiles;
+        const int x0 = tx * TW, y0 = ty * TR;
+        __syncthreads();                                               // the previous tile's units have read xt
+        store_halo();
+        __syncthreads();
+        if (tile + (int)gridDim.x < ntiles) load_halo(tile + gridDim.x);        // in flight under the units below
+        const int py = y0 + wave;
+        if (py >= H) continue;                                         // wave-uniform (no barrier below in this iteration)
+        // ---- units: wave w owns tile row w, two 32-px segments
+#pragma unroll 1
+        for (int seg = 0; seg < 2; ++seg) {
+            if (x0 + seg * 32 >= W) continue;                          // wave-uniform
+            const int px = x0 + seg * 32 + l31;
+            uint4 b[2][NP];
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            float v[8];
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float t = xt[boff[s2][e] + i * PITCH + seg * 32];
-                v[e] = bval[s2][e] ? t : 0.0f;                         // k >= K: the weight is zero, but 0 x garbage must stay 0
-            }
-            uint32_t hp[4], mp[4], lp[4];
+                for (int e = 0; e < 8; ++e) v[e] = xt[boff[s2][e] + seg * 32];
+                uint32_t hp[4], mp[4], lp[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split3_pair(v[2 * e], v[2 * e + 1], hp[e], mp[e], lp[e]);
-            b[s2][0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
-            if constexpr (SPLIT) {
-                b[s2][1] = make_uint4(mp[0], mp[1], mp[2], mp[3]);
-                b[s2][2] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
-            }
-        }
-        frcnn_f32x16 acc[NCB];                                         // (one accumulator per cout block: 24 MFMAs per unit, registers matter more)
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            if constexpr (SPLIT) {
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][NP - 1], b[s2][0], acc[cb]);     // l.h
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][NP / 2], b[s2][0], acc[cb]);     // m.h
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][NP - 1], acc[cb]);     // h.l
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][NP / 2], acc[cb]);     // h.m
-#pragma unroll
-                for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][NP / 2], b[s2][NP / 2], acc[cb]);     // m.m
-            }
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][0], acc[cb]);     // h.h
-        }
-        // the unit's 32 px x (32 NCB) couts go through the wave's LDS tile, one part at a time, so that every 16-cout block leaves as ONE
-        // contiguous run of 32 px x 32 B (16-byte stores, consecutive lanes consecutive addresses) instead of 8-byte pieces 32 bytes apart
-        uint2 pk[NPARTS][NCB][4];
-#pragma unroll
-        for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = cb * 32 + 8 * g + 4 * khalf;            // first of four consecutive couts
-                float v[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    v[t] = acc[cb][4 * g + t] + (co + t < Cout ? bias[co + t] : 0.0f);
-                    if (relu) v[t] = fmaxf(v[t], 0.0f);
-                    if (y_nchw != nullptr && co + t < Cout && px < W) y_nchw[((size_t)(co + t) * H + py) * W + px] = v[t];   // training: fp32 NCHW as well
-                }
-                uint32_t hp[2], mp[2], lp[2];
-                split3_pair(v[0], v[1], hp[0], mp[0], lp[0]);
-                split3_pair(v[2], v[3], hp[1], mp[1], lp[1]);
-                pk[0][cb][g] = make_uint2(hp[0], hp[1]);
+                for (int e = 0; e < 4; ++e) split3_pair(v[2 * e], v[2 * e + 1], hp[e], mp[e], lp[e]);
+                b[s2][0] = make_uint4(hp[0], hp[1], hp[2], hp[3]);
                 if constexpr (SPLIT) {
-                    pk[NPARTS / 2][cb][g] = make_uint2(mp[0], mp[1]);
-                    pk[NPARTS - 1][cb][g] = make_uint2(lp[0], lp[1]);
+                    b[s2][1] = make_uint4(mp[0], mp[1], mp[2], mp[3]);
+                    b[s2][2] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
                 }
             }
+            frcnn_f32x16 acc[NCB];                                     // (one accumulator per cout block: 24 MFMAs per unit, registers matter more)
 #pragma unroll
-        for (int part = 0; part < NPARTS; ++part) {
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                if constexpr (SPLIT) {
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][NP - 1], b[s2][0], acc[cb]);     // l.h
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][NP / 2], b[s2][0], acc[cb]);     // m.h
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][NP - 1], acc[cb]);     // h.l
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][NP / 2], acc[cb]);     // h.m
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][NP / 2], b[s2][NP / 2], acc[cb]);     // m.m
+                }
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][0], acc[cb]);     // h.h
+            }
+            // the unit's 32 px x (32 NCB) couts go through the wave's LDS tile, one part at a time, so that every 16-cout block leaves as
+            // ONE contiguous run of 32 px x 32 B (16-byte stores, consecutive lanes consecutive addresses) instead of 8-byte pieces 32
+            // bytes apart
+            uint2 pk[NPARTS][NCB][4];
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int co = cb * 32 + 8 * g + 4 * khalf;
-                    *reinterpret_cast<uint2 *>(&ot[wave][co >> 4][l31 * OPX + (co & 15) * 2]) = pk[part][cb][g];
-                }
-            __builtin_amdgcn_wave_barrier();                           // the wave's own LDS writes, read by other lanes below
+                    const int co = cb * 32 + 8 * g + 4 * khalf;        // first of four consecutive couts
+                    const float4 bq = *reinterpret_cast<const float4 *>(&sbias[co]);
+                    float v[4] = {acc[cb][4 * g] + bq.x, acc[cb][4 * g + 1] + bq.y, acc[cb][4 * g + 2] + bq.z, acc[cb][4 * g + 3] + bq.w};
 #pragma unroll
-            for (int b16 = 0; b16 < 2 * NCB; ++b16) {
-                const int q = lane >> 1, half = lane & 1;              // pixel, 16-byte half of its 32-byte cout block
-                const uint4 val = *reinterpret_cast<const uint4 *>(&ot[wave][b16][q * OPX + half * 16]);
-                const int qx = x0 + seg * 32 + q;
-                if (qx < W && b16 * 16 < CoutP)
-                    *reinterpret_cast<uint4 *>(y + part * y_part + (((size_t)b16 * H + py) * W + qx) * 16 + half * 8) = val;
+                    for (int t = 0; t < 4; ++t) {
+                        if (relu) v[t] = fmaxf(v[t], 0.0f);
+                        if constexpr (DUAL)                                    // training: fp32 NCHW as well
+                            frcnn_buf_store_f32(nbuf, (co + t < Cout && px < W) ? (uint32_t)(((co + t) * H + py) * W + px) * 4u : kBufOob, v[t]);
+                    }
+                    uint32_t hp[2], mp[2], lp[2];
+                    split3_pair(v[0], v[1], hp[0], mp[0], lp[0]);
+                    split3_pair(v[2], v[3], hp[1], mp[1], lp[1]);
+                    pk[0][cb][g] = make_uint2(hp[0], hp[1]);
+                    if constexpr (SPLIT) {
+                        pk[NPARTS / 2][cb][g] = make_uint2(mp[0], mp[1]);
+                        pk[NPARTS - 1][cb][g] = make_uint2(lp[0], lp[1]);
+                    }
+                }
+            const int q = lane >> 1, half = lane & 1;                  // pixel, 16-byte half of its 32-byte cout block
+            const int qx = x0 + seg * 32 + q;
+            const uint32_t yoff = qx < W ? (uint32_t)((py * W + qx) * 32 + half * 16) : kBufOob;       // bytes inside a 16-cout block plane
+#pragma unroll
+            for (int part = 0; part < NPARTS; ++part) {
+#pragma unroll
+                for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int co = cb * 32 + 8 * g + 4 * khalf;
+                        *reinterpret_cast<uint2 *>(&ot[wave][co >> 4][l31 * OPX + (co & 15) * 2]) = pk[part][cb][g];
+                    }
+                __builtin_amdgcn_wave_barrier();                       // the wave's own LDS writes, read by other lanes below
+#pragma unroll
+                for (int b16 = 0; b16 < 2 * NCB; ++b16) {
+                    const uint4 val = *reinterpret_cast<const uint4 *>(&ot[wave][b16][q * OPX + half * 16]);
+                    if (b16 * 16 < CoutP) frcnn_buf_store_b128(ybuf[part], yoff + (uint32_t)b16 * plane_bytes, val);
+                }
+                __builtin_amdgcn_wave_barrier();                       // the tile is rewritten only after these reads were issued
             }
-            __builtin_amdgcn_wave_barrier();                           // the tile is rewritten only after these reads were issued
         }
     }
 }
@@ -671,28 +718,47 @@ int frcnn_f32s_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, voi
     return frcnn_launch_status();
 }
 
+// persistent first-layer launch: as many workgroups as the chip seats at once (2 per CU for the split form, 4 for the bf16 form:
+// the kernels' __launch_bounds__), each strides over the tiles
+static int conv1_grid(int ntiles, bool split) {
+    const char *e = getenv("FRCNN_CONV1_WGS_PER_CU");
+    const int per_cu = e && atoi(e) > 0 ? atoi(e) : (split ? 2 : 4);
+    const char *g = getenv("FRCNN_CONV1_GRID");                        // tests: an exact workgroup count (the strided tile loop on small images)
+    const long slots = g && atoi(g) > 0 ? atoi(g) : (long)frcnn_cu_count() * per_cu;
+    return (int)(ntiles < slots ? ntiles : slots);
+}
+
 int frcnn_conv1_f32s(const float *x, const float *w, const float *bias, uint16_t *y, int Cin, int Cout, int H, int W, int relu, void *stream) {
     if (!x || !w || !bias || !y || Cin < 1 || Cin > 3 || Cout < 1 || Cout > 64 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
-    const dim3 grid(frcnn_cdiv(W, 64), frcnn_cdiv(H, 8));
-    if (Cout > 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu, 0, (float *)nullptr);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu, 0, (float *)nullptr);
+    if ((size_t)H * W * 64 * 2 >= (1ull << 31)) return FRCNN_ERR_INVALID;          // one part of the output behind a 32-bit buffer range
+    const int xtiles = frcnn_cdiv(W, 64), ntiles = xtiles * frcnn_cdiv(H, 4);
+    const dim3 grid(conv1_grid(ntiles, true));
+    if (Cout > 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu, 0, (float *)nullptr, xtiles, ntiles);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu, 0, (float *)nullptr, xtiles, ntiles);
     return frcnn_launch_status();
 }
 
 int frcnn_conv1_f32s_train(const float *x, const float *w_packed_f32, const float *bias, uint16_t *y_split, float *y_nchw, int Cin, int Cout, int H, int W,
                            int relu, void *stream) {
     if (!x || !w_packed_f32 || !bias || !y_split || Cin < 1 || Cin > 3 || Cout < 1 || Cout > 64 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
-    const dim3 grid(frcnn_cdiv(W, 64), frcnn_cdiv(H, 8));
-    if (Cout > 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<2>), grid, dim3(256), 0, (hipStream_t)stream, x, w_packed_f32, bias, y_split, Cin, Cout, H, W, relu, 1, y_nchw);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<1>), grid, dim3(256), 0, (hipStream_t)stream, x, w_packed_f32, bias, y_split, Cin, Cout, H, W, relu, 1, y_nchw);
+    if ((size_t)H * W * 64 * 2 >= (1ull << 31)) return FRCNN_ERR_INVALID;          // one part of the output behind a 32-bit buffer range
+    const int xtiles = frcnn_cdiv(W, 64), ntiles = xtiles * frcnn_cdiv(H, 4);
+    const dim3 grid(conv1_grid(ntiles, true));
+#define FRCNN_CONV1_TRAIN(NCB, DUAL_) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<NCB, true, DUAL_>), grid, dim3(256), 0, (hipStream_t)stream, x, \
+                                                         w_packed_f32, bias, y_split, Cin, Cout, H, W, relu, 1, y_nchw, xtiles, ntiles)
+    if (y_nchw != nullptr) { if (Cout > 32) FRCNN_CONV1_TRAIN(2, true); else FRCNN_CONV1_TRAIN(1, true); }
+    else { if (Cout > 32) FRCNN_CONV1_TRAIN(2, false); else FRCNN_CONV1_TRAIN(1, false); }
+#undef FRCNN_CONV1_TRAIN
     return frcnn_launch_status();
 }
 
 int frcnn_conv1_bf16(const float *x, const float *w, const float *bias, uint16_t *y, int Cin, int Cout, int H, int W, int relu, void *stream) {
     if (!x || !w || !bias || !y || Cin < 1 || Cin > 3 || Cout < 1 || Cout > 64 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
-    const dim3 grid(frcnn_cdiv(W, 64), frcnn_cdiv(H, 8));
-    if (Cout > 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu, 0, (float *)nullptr);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu, 0, (float *)nullptr);
+    if ((size_t)H * W * 64 * 2 >= (1ull << 31)) return FRCNN_ERR_INVALID;          // one part of the output behind a 32-bit buffer range
+    const int xtiles = frcnn_cdiv(W, 64), ntiles = xtiles * frcnn_cdiv(H, 4);
+    const dim3 grid(conv1_grid(ntiles, false));
+    if (Cout > 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<2, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu, 0, (float *)nullptr, xtiles, ntiles);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<1, false>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, y, Cin, Cout, H, W, relu, 0, (float *)nullptr, xtiles, ntiles);
     return frcnn_launch_status();
 }
 

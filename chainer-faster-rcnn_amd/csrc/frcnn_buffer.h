@@ -34,6 +34,18 @@ __device__ __forceinline__ void frcnn_buf_store_f32x4_wt(frcnn_buf_t b, uint32_t
     __builtin_amdgcn_raw_buffer_store_b128(u, b, (int)byte_off, 0, /*aux: sc1*/ 16);
 }
 
+// plain 16-byte store through a descriptor: a 32-bit offset register instead of a 64-bit address pair per store, and lanes whose
+// offset is kBufOob store nothing (no exec-mask branch around ragged edges)
+__device__ __forceinline__ void frcnn_buf_store_b128(frcnn_buf_t b, uint32_t byte_off, uint4 v) {
+    frcnn_u32x4 u;
+    u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
+    __builtin_amdgcn_raw_buffer_store_b128(u, b, (int)byte_off, 0, 0);
+}
+
+__device__ __forceinline__ void frcnn_buf_store_f32(frcnn_buf_t b, uint32_t byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b, (int)byte_off, 0, 0);
+}
+
 // LDS-DMA: one wave-instruction moves 64 x 16 bytes from the buffer straight into LDS at lds_wave_base + 16 * lane -- no staging
 // VGPRs, no ds_write.  The destination is lane-linear by construction (any swizzle goes on the per-lane SOURCE offset and on the
 // reader, cdna_hip_programming.md rule 21); out-of-range lanes deposit zeros; `soff` is a wave-uniform byte offset added after the

@@ -17,6 +17,12 @@ static inline float4 frcnn_buf_load_f32x4(frcnn_buf_t b, uint32_t off) {
 static inline void frcnn_buf_store_f32x4_wt(frcnn_buf_t b, uint32_t off, float4 v) {
     if ((uint64_t)off + 16 <= b.bytes) memcpy(const_cast<char *>(b.base) + off, &v, 16);
 }
+static inline void frcnn_buf_store_b128(frcnn_buf_t b, uint32_t off, uint4 v) {
+    if ((uint64_t)off + 16 <= b.bytes) memcpy(const_cast<char *>(b.base) + off, &v, 16);
+}
+static inline void frcnn_buf_store_f32(frcnn_buf_t b, uint32_t off, float v) {
+    if ((uint64_t)off + 4 <= b.bytes) memcpy(const_cast<char *>(b.base) + off, &v, 4);
+}
 static inline void frcnn_buf_load_lds_b128(frcnn_buf_t b, void *lds_wave_base, uint32_t off, uint32_t soff) {
     // lane-linear destination; the range check sees the per-lane offset only (soff is added after it), as on the hardware
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);

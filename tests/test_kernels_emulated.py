@@ -251,8 +251,17 @@ def test_f32s_pipeline_small(rt):
 
 
 def test_conv1_f32s_first_layer(rt):
-    P.check_conv1_f32s(rt, 3, 64, 11, 70)                  # two x tiles (64 + 6 px), two y tiles, ragged rows
+    P.check_conv1_f32s(rt, 3, 64, 11, 70)                  # two x tiles (64 + 6 px), three y tiles, ragged rows
     P.check_conv1_f32s(rt, 1, 24, 5, 33, relu=False, seed=1)   # one channel (K = 9), 24 couts: one block, padded to 32
+
+
+@pytest.mark.parametrize("grid", ["1", "4"])
+def test_conv1_persistent_tile_loop(rt, monkeypatch, grid):
+    """The first-layer kernel is a persistent launch: with fewer workgroups than tiles every workgroup strides over several tiles
+    (next halo prefetched under the current tile's units) -- forced here on a six-tile image; 4 workgroups = an uneven split."""
+    monkeypatch.setenv("FRCNN_CONV1_GRID", grid)
+    P.check_conv1_f32s(rt, 3, 64, 11, 70, seed=3)
+    P.check_conv1_bf16(rt, 3, 64, 11, 70, seed=3)
 
 
 def test_linear_f32s(rt):
