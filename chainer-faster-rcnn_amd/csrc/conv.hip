@@ -335,6 +335,9 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
             }
         }
 
+        // The epilogues fetch everything they read (bias; the mask of the training / residual forms) in ONE batch before their first
+        // store: written as load - use - store per element, the compiler waited for every load with vmcnt(0), i.e. also for the
+        // previous element's store to be acknowledged -- 16-32 dependent memory round trips per tile.
         if (finish && relu == 4) {
             // epilogue with F.MaxPooling2D(2, 2) (cover_all) fused behind the ReLU: the wave's two rows are one window row
             // pair (tile rows start at multiples of 4), the horizontal neighbour is the next lane.  y is (Cout, ceil(H/2), ceil(W/2)).
@@ -344,15 +347,19 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
                 const bool has_row1 = py + 1 < H, has_right = px + 1 < W;
 #pragma unroll
                 for (int i = 0; i < ACO; ++i) {
+                    const int cob = co0 + wco * (32 * ACO) + 32 * i + 4 * khalf;       // cout of register 0; register r: + (r&3) + 8*(r>>2)
+                    float4 bq[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4 *>(&bias[cob + 8 * g]);      // Cout % BCO == 0: in range
+                    float *yo = y + (size_t)cob * OH * OW + (size_t)(py >> 1) * OW + (px >> 1);
+                    const bool writer = (l31 & 1) == 0 && px < W && py < H;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         float m = has_row1 ? fmaxf(acc[i][0][r], acc[i][1][r]) : acc[i][0][r];
                         const float right = __shfl_xor(m, 1);
                         if (has_right) m = fmaxf(m, right);
-                        if ((l31 & 1) == 0 && px < W && py < H) {
-                            const int co = co0 + wco * (32 * ACO) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                            y[(size_t)co * OH * OW + (size_t)(py >> 1) * OW + (px >> 1)] = fmaxf(m + bias[co], 0.0f);   // max, +bias, ReLU commute
-                        }
+                        const float b = (r & 3) == 0 ? bq[r >> 2].x : ((r & 3) == 1 ? bq[r >> 2].y : ((r & 3) == 2 ? bq[r >> 2].z : bq[r >> 2].w));
+                        if (writer) yo[(size_t)((r & 3) + 8 * (r >> 2)) * OH * OW] = fmaxf(m + b, 0.0f);   // max, +bias, ReLU commute
                     }
                 }
             }
@@ -361,20 +368,35 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
             const int px = x0 + l31;
 #pragma unroll
             for (int i = 0; i < ACO; ++i) {
+                const int cob = co0 + wco * (32 * ACO) + 32 * i + 4 * khalf;
+                float4 bq[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4 *>(&bias[cob + 8 * g]);
 #pragma unroll
                 for (int j = 0; j < APX; ++j) {
                     const int py = y0 + b_row + j;
                     if (px < W && py < H) {
+                        const size_t o0 = (size_t)cob * HW + (size_t)py * W + px;
+                        float v[16];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int co = co0 + wco * (32 * ACO) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                            float v = acc[i][j][r] + bias[co];
-                            const size_t o = (size_t)co * HW + (size_t)py * W + px;
-                            if (relu == 1) v = fmaxf(v, 0.0f);
-                            else if (relu == 2) v = mask[o] > 0.0f ? v : 0.0f;      // backward through the ReLU that produced `mask`
-                            else if (relu == 3) v = fmaxf(v + mask[o], 0.0f);       // residual add + ReLU (ResNet bottleneck tail)
-                            y[o] = v;
+                            const float b = (r & 3) == 0 ? bq[r >> 2].x : ((r & 3) == 1 ? bq[r >> 2].y : ((r & 3) == 2 ? bq[r >> 2].z : bq[r >> 2].w));
+                            v[r] = acc[i][j][r] + b;
                         }
+                        if (relu == 2 || relu == 3) {
+                            float mv[16];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) mv[r] = mask[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * HW];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r)
+                                v[r] = relu == 2 ? (mv[r] > 0.0f ? v[r] : 0.0f)         // backward through the ReLU that produced `mask`
+                                                 : fmaxf(v[r] + mv[r], 0.0f);           // residual add + ReLU (ResNet bottleneck tail)
+                        } else if (relu == 1) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) v[r] = fmaxf(v[r], 0.0f);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) y[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * HW] = v[r];
                     }
                 }
             }

@@ -66,6 +66,17 @@ __device__ __forceinline__ void conv_bf16_epilogue(frcnn_f32x16 (&acc)[RW * COB]
     const int l31 = lane & 31, khalf = lane >> 5;
     // epilogue: register r of lane l = cout (r&3) + 8*(r>>2) + 4*khalf of pixel l31
     const int px = x0 + l31;
+    // this lane's bias values, fetched as ONE batch before anything is stored (out-of-range couts read 0 through the buffer range
+    // check): as predicated loads inside the loops below they cost a dependent memory round trip per group of four
+    const frcnn_buf_t bbuf = frcnn_make_buf(bias, (uint32_t)Cout * 4u);
+    float bv[COB][16];
+#pragma unroll
+    for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                bv[cb][4 * g + t] = frcnn_buf_load_f32(bbuf, (uint32_t)(co0 + (wco0 + cb) * 32 + 8 * g + 4 * khalf + t) * 4u);
     if (out_mode == 0 || out_mode == 2) {
         // bf16 channel-blocked output: transpose through LDS so that each 16-cout block of a tile row leaves as one contiguous
         // run of 32 px x 32 B (16-byte stores, consecutive lanes consecutive addresses)
@@ -79,7 +90,7 @@ __device__ __forceinline__ void conv_bf16_epilogue(frcnn_f32x16 (&acc)[RW * COB]
                 float v[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    v[t] = acc[cb * RW + j][4 * g + t] + (co0 + col + t < Cout ? bias[co0 + col + t] : 0.0f);
+                    v[t] = acc[cb * RW + j][4 * g + t] + bv[cb][4 * g + t];
                     if (relu) v[t] = fmaxf(v[t], 0.0f);
                 }
                 uint2 pk;
@@ -118,22 +129,23 @@ __device__ __forceinline__ void conv_bf16_epilogue(frcnn_f32x16 (&acc)[RW * COB]
                     *reinterpret_cast<const uint4 *>(ot + pix * OP + (cbl * 2 + half) * 16);
         }
     } else {
+        // fp32 NCHW (Cout, H, W): straight-line buffer stores, lanes / couts outside the map store nothing (offset out of range)
+        const frcnn_buf_t ybuf = frcnn_make_buf(y, (uint32_t)((size_t)Cout * H * W * 4));
 #pragma unroll
         for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
         for (int j = 0; j < RW; ++j) {
             const int py = y0 + wrow * RW + j;
-            if (px >= W || py >= H) continue;
+            const bool inside = px < W && py < H;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int co = co0 + (wco0 + cb) * 32 + 8 * g + 4 * khalf;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    if (co + t < Cout) {
-                        float v = acc[cb * RW + j][4 * g + t] + bias[co + t];
-                        if (relu) v = fmaxf(v, 0.0f);
-                        reinterpret_cast<float *>(y)[(size_t)(co + t) * H * W + (size_t)py * W + px] = v;      // fp32 NCHW
-                    }
+                for (int t = 0; t < 4; ++t) {
+                    float v = acc[cb * RW + j][4 * g + t] + bv[cb][4 * g + t];
+                    if (relu) v = fmaxf(v, 0.0f);
+                    frcnn_buf_store_f32(ybuf, (inside && co + t < Cout) ? (uint32_t)(((co + t) * H + py) * W + px) * 4u : kBufOob, v);
+                }
             }
         }
     }
@@ -635,6 +647,7 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
     if ((ksize != 1 && ksize != 3) || out_mode < 0 || out_mode > 2 || (out_mode == 2 && !relu)) return FRCNN_ERR_INVALID;
+    if (out_mode == 1 && (size_t)Cout * H * W * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;       // the fp32 output sits behind a 32-bit buffer range
     const int CinP = frcnn_bf16_padded_channels(Cin), CoutP = frcnn_bf16_padded_channels(Cout);
     if ((size_t)H * W * CinP * 2 >= (1ull << 31) || (size_t)ksize * ksize * CoutP * CinP * 2 >= (1ull << 31)) return FRCNN_ERR_INVALID;
     const int xtiles = frcnn_cdiv(W, 32), cotiles = frcnn_cdiv(CoutP, 64);

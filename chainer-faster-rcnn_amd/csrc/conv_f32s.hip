@@ -239,32 +239,52 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
 
     // ---- epilogue: register r of lane l = cout (r&3) + 8*(r>>2) + 4*khalf of pixel l31, rows y0 + 2 wrow + j
     float v[RW][16];
+    {
+        const frcnn_buf_t bbuf = frcnn_make_buf(bias, (uint32_t)Cout * 4u);    // couts past Cout read 0 (range check): one branch-free batch
+        float bv[16];
 #pragma unroll
-    for (int j = 0; j < RW; ++j)
+        for (int r = 0; r < 16; ++r) bv[r] = frcnn_buf_load_f32(bbuf, (uint32_t)(co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf) * 4u);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-            float t = acc[j][r] + (co < Cout ? bias[co] : 0.0f);
-            if (relu) t = fmaxf(t, 0.0f);
-            v[j][r] = t;
-        }
+        for (int j = 0; j < RW; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float t = acc[j][r] + bv[r];
+                if (relu) t = fmaxf(t, 0.0f);
+                v[j][r] = t;
+            }
+    }
     const int px = x0 + l31;
     if (mask != nullptr || y_nchw != nullptr) {
         // training forms.  mask (Cout,H,W) fp32: y = (mask > 0) ? y : 0 -- the input-gradient convolution of the backward pass with the
         // producing ReLU's mask fused in (conv.hip act = 2).  y_nchw: the result ALSO as fp32 NCHW (the weight-gradient kernel, the
         // bias gradient, the pool and the next layer's mask read fp32; the next convolution reads the split tensor)
+        // (buffer loads / stores with 32-bit offsets: all of a row's mask values are fetched in one batch before the first store -- as
+        // load - test - store per element every load waited for the previous store's acknowledgement; lanes and couts outside the
+        // map get an out-of-range offset: they load 0 and store nothing)
+        const uint32_t map_bytes = (uint32_t)((size_t)Cout * H * W * 4);
+        const frcnn_buf_t mbuf = frcnn_make_buf(mask, mask != nullptr ? map_bytes : 0u);
+        const frcnn_buf_t nbuf = frcnn_make_buf(y_nchw, y_nchw != nullptr ? map_bytes : 0u);
 #pragma unroll
         for (int j = 0; j < RW; ++j) {
             const int py = y0 + wrow * RW + j;
-            if (px >= W || py >= H) continue;
+            const bool inside = px < W && py < H;
+            uint32_t o[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf;
-                if (co < Cout) {
-                    const size_t o = (size_t)co * H * W + (size_t)py * W + px;
-                    if (mask != nullptr && !(mask[o] > 0.0f)) v[j][r] = 0.0f;
-                    if (y_nchw != nullptr) y_nchw[o] = v[j][r];
-                }
+                o[r] = (inside && co < Cout) ? (uint32_t)((co * H + py) * W + px) * 4u : kBufOob;
+            }
+            if (mask != nullptr) {
+                float mv[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mv[r] = frcnn_buf_load_f32(mbuf, o[r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (!(mv[r] > 0.0f)) v[j][r] = 0.0f;
+            }
+            if (y_nchw != nullptr) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) frcnn_buf_store_f32(nbuf, o[r], v[j][r]);
             }
         }
     }
@@ -804,6 +824,7 @@ static int conv3x3_f32s_launch(const uint16_t *x, const uint16_t *w_packed, cons
     if (out_mode < 0 || out_mode > 2 || (out_mode == 2 && !relu)) return FRCNN_ERR_INVALID;
     const int CinP = (Cin + 15) / 16 * 16, CoutP = (Cout + 15) / 16 * 16;
     if ((size_t)kParts * H * W * CinP * 2 >= (1ull << 31) || (size_t)kParts * 9 * CoutP * CinP * 2 >= (1ull << 31)) return FRCNN_ERR_INVALID;   // 32-bit buffer offsets, top bit = out of range
+    if ((mask || y_nchw) && (size_t)Cout * H * W * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;     // the fp32 maps sit behind 32-bit buffer ranges
     const int xtiles = frcnn_cdiv(W, 32), ytiles = frcnn_cdiv(H, 4), cotiles = frcnn_cdiv(CoutP, 64);
     const long tiles = (long)xtiles * ytiles * cotiles;
     // split-K needs the workspace (partial tiles + the zeroed counter page); without one every tile is whole
