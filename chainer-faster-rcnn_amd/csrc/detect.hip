@@ -234,8 +234,12 @@ rank_scatter_kernel(const unsigned long long *__restrict__ keys, int n_tiles, co
     }
     const int n_groups = (n_tiles + kRankTiles - 1) / kRankTiles;
     unsigned long long stage[SQ];
+    // (all of a group's loads go out before the first LDS store: written as load + store per element the compiler put a full
+    // vmcnt(0) wait between them -- SQ dependent memory round trips before the first search)
 #pragma unroll
-    for (int q = 0; q < SQ; ++q) { const int i = threadIdx.x + 256 * q; tile[0][i] = i < n_keys ? keys[i] : 0ull; }   // a missing tile is all zeros: nothing in it is > key
+    for (int q = 0; q < SQ; ++q) { const int i = threadIdx.x + 256 * q; stage[q] = i < n_keys ? keys[i] : 0ull; }    // a missing tile is all zeros: nothing in it is > key
+#pragma unroll
+    for (int q = 0; q < SQ; ++q) tile[0][threadIdx.x + 256 * q] = stage[q];
     __syncthreads();
     int rank = 0, cur = 0;
     for (int o = 0; o < n_groups; ++o) {

@@ -535,8 +535,17 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
 
     // ---- the first batch's RoIs, then 8 channel planes -> cells: one map row per wave and step (coalesced NCHW rows) through a
     //      buffer descriptor -- rows past H, columns past W and channels past C are out-of-range offsets that load 0: no branches;
-    //      all loads are issued before the table copy and the geometry pass below and land during them
+    //      all loads are issued before the table copy to LDS and the geometry pass below and land during them
     const float4 roi_first = load_roi(0);
+    // the bin tables (a by-value kernel argument, 2.4 KB): their loads go out BEFORE the map's -- loads return in order, so issued after
+    // them the copy to LDS (and with it the geometry pass) waited for the whole map to land
+    constexpr int kTabWords = (int)(sizeof(RoiBinTables) / 4), kTabPerThread = (kTabWords + 64 * kCellWaves - 1) / (64 * kCellWaves);
+    uint32_t tabv[kTabPerThread];
+#pragma unroll
+    for (int q = 0; q < kTabPerThread; ++q) {
+        const int e = tid + q * 64 * kCellWaves;
+        tabv[q] = e < kTabWords ? reinterpret_cast<const uint32_t *>(&tables)[e] : 0u;
+    }
     constexpr int kRowsPerWave = (kRows + kCellWaves - 1) / kCellWaves;
     const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)C * HW * sizeof(float)));
     float v[kRowsPerWave][8];
@@ -547,10 +556,10 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[i][c] = frcnn_buf_load_f32(xbuf, base + (uint32_t)(c * HW * 4));   // c0 + c >= C: past the end -> 0
     }
-    {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(&tables);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(&tb);
-        for (int e = tid; e < (int)(sizeof(RoiBinTables) / 4); e += kThreads) dst[e] = src[e];
+#pragma unroll
+    for (int q = 0; q < kTabPerThread; ++q) {
+        const int e = tid + q * kThreads;
+        if (e < kTabWords) reinterpret_cast<uint32_t *>(&tb)[e] = tabv[q];
     }
     __syncthreads();
     build_geometry(0, roi_first);
