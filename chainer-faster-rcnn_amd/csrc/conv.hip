@@ -484,6 +484,100 @@ static void launch_softmax_channels(const float *score, int n_ch, int HW, float 
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(softmax_channels_kernel<0>), grid, blk, 0, stream, score, n_ch, HW, prob);
 }
 
+// The RPN heads as ONE launch: the stacked 1x1 convolution + the 2A-way softmax.  On the 38x63 map the convolution kernel above
+// has 38 tiles of 16 sequential K-chunks (21 us: launch + a dependent staging round trip per chunk on 38 of 256 CUs) and the softmax is
+// a second launch (5 us).  Here a 512-thread workgroup owns 32 pixels and ALL 64 stacked output channels; its 8 waves split the input
+// channels (K) and read their MFMA fragments straight from global memory -- B = h[c][p0 + lane] is a coalesced 128-byte row piece, A =
+// w_packed[c][cout] likewise -- 48 loads in flight per lane, no LDS staging, no barrier inside the K range; the eight partial tiles meet
+// in LDS, are added in wave order (deterministic) with the bias, leave as `raw` rows, and the first 32 threads run the reference's
+// softmax over the 2A score channels (region_proposal_network.py:119; same operations as softmax_channels_kernel) on the tile in LDS.
+constexpr int kHeadWaves = 8, kHeadBatch = 16;          // K steps (of 2 channels) whose loads are issued together
+__global__ void __launch_bounds__(64 * kHeadWaves)
+rpn_heads_fused_kernel(const float *__restrict__ h, const float *__restrict__ wp, const float *__restrict__ bp, float *__restrict__ raw,
+                       float *__restrict__ prob, int Cmid, int HW, int n_score) {
+    constexpr int NP = 64;
+    __shared__ float part[kHeadWaves][NP][32];
+    __shared__ float outt[NP][33];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int p0 = blockIdx.x * 32;
+    // channels per wave: a whole number of load batches; channels past Cmid are out-of-range offsets (they load 0)
+    const int KW = (Cmid + kHeadWaves * 2 * kHeadBatch - 1) / (kHeadWaves * 2 * kHeadBatch) * (2 * kHeadBatch);
+    const frcnn_buf_t hbuf = frcnn_make_buf(h, (uint32_t)((size_t)Cmid * HW * 4));
+    const frcnn_buf_t wbuf = frcnn_make_buf(wp, (uint32_t)(Cmid * NP) * 4u);
+    const uint32_t px_off = p0 + l31 < HW ? (uint32_t)(p0 + l31) * 4u : kBufOob;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+    // two register sets: the next batch's 48 loads are issued before the current batch's MFMAs (for Cmid = 512 a wave has two
+    // batches: everything it reads is in flight at once)
+    float bvA[kHeadBatch], a0A[kHeadBatch], a1A[kHeadBatch], bvB[kHeadBatch], a0B[kHeadBatch], a1B[kHeadBatch];
+    auto fetch = [&](int cb, float (&bv)[kHeadBatch], float (&a0)[kHeadBatch], float (&a1)[kHeadBatch]) {
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) {
+            const uint32_t c = (uint32_t)(cb + 2 * u + khalf);
+            bv[u] = frcnn_buf_load_f32(hbuf, c * (uint32_t)HW * 4u + px_off);
+            a0[u] = frcnn_buf_load_f32(wbuf, (c * NP + l31) * 4u);
+            a1[u] = frcnn_buf_load_f32(wbuf, (c * NP + 32 + l31) * 4u);
+        }
+    };
+    auto mm = [&](const float (&bv)[kHeadBatch], const float (&a0)[kHeadBatch], const float (&a1)[kHeadBatch]) {
+#pragma unroll
+        for (int u = 0; u < kHeadBatch; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], bv[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], bv[u], acc1, 0, 0, 0);
+        }
+    };
+    int cb = wave * KW;
+    const int c_end = cb + KW;
+    fetch(cb, bvA, a0A, a1A);
+    for (;;) {
+        if (cb + 2 * kHeadBatch < c_end) fetch(cb + 2 * kHeadBatch, bvB, a0B, a1B);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(bvA, a0A, a1A);
+        cb += 2 * kHeadBatch;
+        if (cb >= c_end) break;
+        if (cb + 2 * kHeadBatch < c_end) fetch(cb + 2 * kHeadBatch, bvA, a0A, a1A);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(bvB, a0B, a1B);
+        cb += 2 * kHeadBatch;
+        if (cb >= c_end) break;
+    }
+    // D register r of lane l = cout (r&3) + 8*(r>>2) + 4*(l>>5), pixel l&31
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+        part[wave][co][l31] = acc0[r];
+        part[wave][32 + co][l31] = acc1[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NP * 32 / (64 * kHeadWaves); ++q) {
+        const int o = tid + q * 64 * kHeadWaves, co = o >> 5, px = o & 31;
+        float v = part[0][co][px];
+#pragma unroll
+        for (int w = 1; w < kHeadWaves; ++w) v += part[w][co][px];
+        v += bp[co];
+        outt[co][px] = v;
+        if (p0 + px < HW) raw[(size_t)co * HW + p0 + px] = v;
+    }
+    __syncthreads();
+    if (tid < 32 && p0 + tid < HW) {
+        float v[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) v[c] = c < n_score ? outt[c][tid] : 0.0f;
+        float m = v[0];
+#pragma unroll
+        for (int c = 1; c < 32; ++c) if (c < n_score) m = fmaxf(m, v[c]);
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) if (c < n_score) { v[c] = expf(v[c] - m); sum += v[c]; }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) if (c < n_score) prob[(size_t)c * HW + p0 + tid] = v[c] / sum;
+    }
+}
+
 // ---- ResNet stem / stride helpers (models/resnet.py -> chainer ResNetLayers: conv1 7x7/2 pad 3, max-pool 3x3/2, stride-2 1x1) ----
 // im2col of the 7x7 / stride 2 / pad 3 stem: cols[(ci*49 + ky*7 + kx)][oy*OW + ox] = x[ci][2*oy - 3 + ky][2*ox - 3 + kx] (0 outside);
 // rows Cin*49 .. Kp-1 are zero padding.  The stem then runs as a 1x1 convolution on the MFMA kernel.
@@ -778,6 +872,14 @@ int frcnn_rpn_heads_f32(const float *h, int Cmid, int H, int W, int A, const flo
     hipStream_t stream = (hipStream_t)stream_;
     if (!h || !w_packed || !b_packed || !raw || !cls_prob || Cmid < 1 || H < 1 || W < 1 || A < 1) return FRCNN_ERR_INVALID;
     const int NP = frcnn_rpn_heads_padded_channels(A);
+    // one fused launch when the stacked heads fit one 64-channel block and the softmax fits its register tile (A <= 10: every
+    // configuration of the reference); FRCNN_RPN_HEADS=conv keeps the two-launch form reachable (tests compare the two)
+    const char *form = getenv("FRCNN_RPN_HEADS");
+    if (NP == 64 && 2 * A <= 32 && (size_t)Cmid * H * W * 4 < (1ull << 31) && !(form && form[0] == 'c')) {
+        hipLaunchKernelGGL(rpn_heads_fused_kernel, dim3(frcnn_cdiv(H * W, 32)), dim3(64 * kHeadWaves), 0, stream, h, w_packed, b_packed, raw,
+                           cls_prob, Cmid, H * W, 2 * A);
+        return frcnn_launch_status();
+    }
     const int st = launch_conv<1, 2, 2, 1, 1, 32, true, 3, 0, true>(h, w_packed, b_packed, raw, Cmid, NP, H, W, 0, 0, nullptr, 0, stream);
     if (st != FRCNN_OK) return st;
     launch_softmax_channels(raw, 2 * A, H * W, cls_prob, stream);

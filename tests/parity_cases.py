@@ -306,6 +306,22 @@ def check_rpn_heads(rt, Cmid=128, H=9, W=13, A=9, seed=0):
     assert np.allclose(host(rt, pr), prob, rtol=1e-4, atol=1e-6)
     assert np.allclose(host(rt, bb), bbox, rtol=1e-4, atol=1e-5)
     assert np.allclose(host(rt, pr).sum(axis=1), 1.0, atol=1e-5)
+    return host(rt, s), host(rt, pr), host(rt, bb)
+
+
+def check_rpn_heads_forms(rt, monkeypatch, **kw):
+    """The fused heads launch (K split over the workgroup's waves, softmax on the tile) against the two-launch form (the 1x1 case of
+    the convolution kernel + softmax_channels_kernel): same values up to the order of the fp32 additions, and the probabilities are
+    the same softmax operations applied to the fused launch's own scores."""
+    fused = check_rpn_heads(rt, **kw)
+    monkeypatch.setenv("FRCNN_RPN_HEADS", "conv")
+    conv = check_rpn_heads(rt, **kw)
+    monkeypatch.delenv("FRCNN_RPN_HEADS")
+    for a, b in zip(fused, conv):
+        assert np.abs(a - b).max() <= 2e-6 * max(np.abs(b).max(), 1.0)
+    s = fused[0].astype(np.float32)
+    e = np.exp(s - s.max(axis=1, keepdims=True), dtype=np.float32)
+    assert np.abs(fused[1] - e / e.sum(axis=1, keepdims=True, dtype=np.float32)).max() <= 1e-6
 
 
 def check_linear(rt, M, N, K, relu, seed=0):

@@ -131,8 +131,9 @@ def test_maxpool(rt):
     P.check_maxpool(rt, 8, 600, 1000)
 
 
-def test_rpn_heads(rt):
-    P.check_rpn_heads(rt, Cmid=512, H=38, W=63)
+def test_rpn_heads(rt, monkeypatch):
+    P.check_rpn_heads_forms(rt, monkeypatch, Cmid=512, H=38, W=63)
+    P.check_rpn_heads_forms(rt, monkeypatch, Cmid=272, H=19, W=32, A=3, seed=1)
 
 
 def test_linear(rt):

@@ -99,8 +99,9 @@ def test_maxpool(rt):
     P.check_maxpool(rt, 2, 8, 6)
 
 
-def test_rpn_heads(rt):
-    P.check_rpn_heads(rt, Cmid=128, H=5, W=15)
+def test_rpn_heads(rt, monkeypatch):
+    P.check_rpn_heads_forms(rt, monkeypatch, Cmid=128, H=5, W=15)        # 75 px: two whole pixel tiles + 11; waves 0-3 hold channels
+    P.check_rpn_heads_forms(rt, monkeypatch, Cmid=272, H=3, W=7, A=3, seed=1)   # two load batches per wave, the last one ragged; A = 3
 
 
 def test_linear(rt):
