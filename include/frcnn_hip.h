@@ -155,7 +155,8 @@ int frcnn_maxpool2x2_f32(const float *x, float *y, int C, int H, int W, void *st
  *       layout -> one stacked, zero-padded (Cmid, NP) matrix + (NP) bias, NP = frcnn_rpn_heads_padded_channels(A)
  *   frcnn_rpn_heads_f32: h (Cmid,H,W) -> raw (NP,H,W): rows [0,2A) = rpn_cls_score, rows [2A,6A) =
  *       rpn_bbox_pred (contiguous NCHW blocks, use them in place); cls_prob (2A,H,W) = softmax over ALL
- *       2A score channels (axis 1), as the reference does.
+ *       2A score channels (axis 1), as the reference does.  One launch for A <= 10 (both heads as a K-split 1x1
+ *       convolution on fp32 MFMA + the softmax on the tile); larger A: the convolution kernel + a softmax launch.
  */
 int frcnn_rpn_heads_padded_channels(int A);
 int frcnn_rpn_heads_pack(const float *w_cls, const float *b_cls, const float *w_bbox, const float *b_bbox,
@@ -214,7 +215,8 @@ int frcnn_f32s_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, voi
 int frcnn_conv3x3_f32s(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
                        int W, int relu, int out_mode, void *stream);
 /* first layer (Cin <= 3, Cout <= 64; models/vgg16.py:39 conv1_1): x = the fp32 NCHW image, w = Chainer's (Cout,Cin,3,3) fp32 as it
- * is, y = split tensor (CoutP, H, W) */
+ * is, y = split tensor (CoutP, H, W).  A persistent launch (as many workgroups as the chip seats, striding over the tiles); the
+ * outputs sit behind 32-bit buffer ranges: H * W * 128 bytes (one part) must stay below 2 GiB, else FRCNN_ERR_INVALID. */
 int frcnn_conv1_f32s(const float *x, const float *w, const float *bias, uint16_t *y, int Cin, int Cout, int H, int W, int relu,
                      void *stream);
 /* the same kernel in plain bf16 arithmetic (operands rounded to bf16, fp32 accumulation, y = [CoutP/16][H][W][16] bf16): the first
