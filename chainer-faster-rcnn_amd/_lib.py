@@ -58,6 +58,7 @@ SIGNATURES = {
     "frcnn_conv3x3_f32s": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "frcnn_conv1_f32s": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "frcnn_conv1_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "frcnn_conv1_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "frcnn_f32s_pack_from_packed": (_I, [_P, _I, _I, _I, _P, _P]),
     "frcnn_f32s_pack_many": (_I, [_P, _I, _P]),
     "frcnn_conv_wgrad_f32s": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _S, _P]),

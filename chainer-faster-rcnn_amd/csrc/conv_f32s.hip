@@ -381,8 +381,12 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
 // tile's halo (5 loads per thread, same batch form) is in flight while the current tile's units run.
 // SPLIT = false: the plain bf16 form of the same kernel (conv_bf16.hip's chain: operands rounded to bf16, one MFMA per k-step, the
 // result rounded to bf16 once) -- only the h terms exist.
-template <int NCB, bool SPLIT = true, bool DUAL = false>        // cout blocks of 32; DUAL: the fp32 NCHW map as well (training)
-__global__ void __launch_bounds__(256, SPLIT ? 2 : 4)
+// F32: native fp32 arithmetic (v_mfma_f32_32x32x2_f32, K = 28 = 14 k-steps, fp32 weights in registers) and ONLY the fp32 NCHW output:
+// conv1_1 of the fp32 chain (conv.hip's generic kernel writes that layer's 154 MB with 4-byte stores: 68 us).
+// The fp32 NCHW map (DUAL, F32) leaves through a wave-private LDS tile [cout][32 px] as 16-byte stores along the row (eight couts x 128
+// bytes per instruction) -- as 4-byte stores per accumulator register the same 154 MB took ~70 us.
+template <int NCB, bool SPLIT = true, bool DUAL = false, bool F32 = false>        // cout blocks of 32; DUAL: the fp32 NCHW map as well (training)
+__global__ void __launch_bounds__(256, F32 ? 3 : (SPLIT ? 2 : 4))
 conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, uint16_t *__restrict__ y, int Cin,
                   int Cout, int H, int W, int relu, int w_is_packed, float *__restrict__ y_nchw, int xtiles, int ntiles) {
     constexpr int TR = 4, TW = 64, HR = TR + 2, PITCH = TW + 4;        // LDS row: 66 used of 68 floats; tile row = wave
@@ -391,7 +395,10 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
     __shared__ __attribute__((aligned(16))) float sbias[32 * NCB];
     constexpr int NPARTS = SPLIT ? kParts : 1;
     constexpr int OPX = 32 + 16;                                       // output staging: bytes per (pixel, 16-cout block) + pad
-    __shared__ __attribute__((aligned(16))) unsigned char ot[4][2 * NCB][32 * OPX];     // per wave: one part of a unit's tile, [cout block of 16][px]
+    __shared__ __attribute__((aligned(16))) unsigned char ot[F32 ? 1 : 4][F32 ? 1 : 2 * NCB][F32 ? 16 : 32 * OPX];     // per wave: one part of a unit's tile, [cout block of 16][px]
+    constexpr bool NCHW = DUAL || F32;
+    constexpr int NTP = 36;                                            // fp32 NCHW staging: floats per cout row (32 px + pad)
+    __shared__ __attribute__((aligned(16))) float nt[NCHW ? 4 : 1][NCHW ? 32 * NCB : 1][NCHW ? NTP : 4];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, khalf = lane >> 5;
@@ -402,8 +409,26 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
     const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)Cin * H * W * 4));
     // ---- weight fragments: lane (cout l31 of block cb, k = 16 s + 8 khalf + e), k = ci * 9 + tap; the three parts of (Cout, K) fp32
     constexpr int NP = SPLIT ? kParts : 1;
+    constexpr int KS32 = 14;                                           // F32: k-steps of two (k = 2 s + khalf < 28)
+    float aw[F32 ? NCB : 1][F32 ? KS32 : 1];
+    int boff32[F32 ? KS32 : 1];
+    if constexpr (F32) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int st = 0; st < KS32; ++st) {
+                const int k = 2 * st + khalf, co = cb * 32 + l31;
+                aw[cb][st] = frcnn_buf_load_f32(wbuf, (co < Cout && k < K) ? (uint32_t)(k * wk + co * wc) * 4u : kBufOob);
+            }
+#pragma unroll
+        for (int st = 0; st < KS32; ++st) {
+            const int k = 2 * st + khalf, kk = k < K ? k : 0;
+            const int ci = kk / 9, tap = kk - ci * 9, ky = tap / 3, kx = tap - ky * 3;
+            boff32[st] = (ci * HR + wave + ky) * PITCH + kx + l31;
+        }
+    }
     uint4 a[NCB][2][NP];
-    {
+    if constexpr (!F32) {
         float wv[NCB][2][8];
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb)
@@ -472,7 +497,7 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
     frcnn_buf_t ybuf[NPARTS];
 #pragma unroll
     for (int part = 0; part < NPARTS; ++part) ybuf[part] = frcnn_make_buf(y + part * y_part, (uint32_t)(y_part * 2));
-    const frcnn_buf_t nbuf = frcnn_make_buf(y_nchw, DUAL ? (uint32_t)((size_t)Cout * H * W * 4) : 0u);
+    const frcnn_buf_t nbuf = frcnn_make_buf(y_nchw, NCHW ? (uint32_t)((size_t)Cout * H * W * 4) : 0u);
     int tile = blockIdx.x;
     if (tile < ntiles) load_halo(tile);
 #pragma unroll 1
@@ -489,8 +514,21 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
 #pragma unroll 1
         for (int seg = 0; seg < 2; ++seg) {
             if (x0 + seg * 32 >= W) continue;                          // wave-uniform
-            const int px = x0 + seg * 32 + l31;
             uint4 b[2][NP];
+            frcnn_f32x16 acc[NCB];                                     // (one accumulator per cout block: 24 MFMAs per unit, registers matter more)
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+            if constexpr (F32) {
+                float bx[KS32];
+#pragma unroll
+                for (int st = 0; st < KS32; ++st) bx[st] = xt[boff32[st] + seg * 32];
+#pragma unroll
+                for (int st = 0; st < KS32; ++st)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; ++cb) acc[cb] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[cb][st], bx[st], acc[cb], 0, 0, 0);
+            } else {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 float v[8];
@@ -505,11 +543,6 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
                     b[s2][2] = make_uint4(lp[0], lp[1], lp[2], lp[3]);
                 }
             }
-            frcnn_f32x16 acc[NCB];                                     // (one accumulator per cout block: 24 MFMAs per unit, registers matter more)
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 if constexpr (SPLIT) {
@@ -527,6 +560,7 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
 #pragma unroll
                 for (int cb = 0; cb < NCB; ++cb) acc[cb] = frcnn_mfma_32x32x16_bf16(a[cb][s2][0], b[s2][0], acc[cb]);     // h.h
             }
+            }
             // the unit's 32 px x (32 NCB) couts go through the wave's LDS tile, one part at a time, so that every 16-cout block leaves as
             // ONE contiguous run of 32 px x 32 B (16-byte stores, consecutive lanes consecutive addresses) instead of 8-byte pieces 32
             // bytes apart
@@ -541,9 +575,9 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         if (relu) v[t] = fmaxf(v[t], 0.0f);
-                        if constexpr (DUAL)                                    // training: fp32 NCHW as well
-                            frcnn_buf_store_f32(nbuf, (co + t < Cout && px < W) ? (uint32_t)(((co + t) * H + py) * W + px) * 4u : kBufOob, v[t]);
+                        if constexpr (NCHW) nt[wave][co + t][l31] = v[t];      // the fp32 NCHW map (training forms / the fp32 chain)
                     }
+                    if constexpr (F32) continue;
                     uint32_t hp[2], mp[2], lp[2];
                     split3_pair(v[0], v[1], hp[0], mp[0], lp[0]);
                     split3_pair(v[2], v[3], hp[1], mp[1], lp[1]);
@@ -553,6 +587,26 @@ conv1_f32s_kernel(const float *__restrict__ x, const float *__restrict__ w, cons
                         pk[NPARTS - 1][cb][g] = make_uint2(lp[0], lp[1]);
                     }
                 }
+            if constexpr (NCHW) {
+                __builtin_amdgcn_wave_barrier();
+                const int cr = lane >> 3, p4 = (lane & 7) * 4, qx4 = x0 + seg * 32 + p4;
+                const bool ragged = x0 + seg * 32 + 32 > W;            // wave-uniform: the segment crosses the map's right edge
+#pragma unroll
+                for (int i = 0; i < 4 * NCB; ++i) {
+                    const int co = 8 * i + cr;
+                    const float4 q4 = *reinterpret_cast<const float4 *>(&nt[wave][co][p4]);
+                    const uint32_t o = (uint32_t)((co * H + py) * W + qx4) * 4u;
+                    frcnn_buf_store_b128(nbuf, (co < Cout && qx4 + 3 < W) ? o : kBufOob, make_uint4(__float_as_uint(q4.x), __float_as_uint(q4.y), __float_as_uint(q4.z), __float_as_uint(q4.w)));
+                    if (ragged) {                                      // the partial group of four at the edge, element by element
+                        const bool part_grp = co < Cout && !(qx4 + 3 < W);
+                        frcnn_buf_store_f32(nbuf, (part_grp && qx4 < W) ? o : kBufOob, q4.x);
+                        frcnn_buf_store_f32(nbuf, (part_grp && qx4 + 1 < W) ? o + 4u : kBufOob, q4.y);
+                        frcnn_buf_store_f32(nbuf, (part_grp && qx4 + 2 < W) ? o + 8u : kBufOob, q4.z);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();                       // nt is rewritten by the next unit only after these reads
+            }
+            if constexpr (F32) continue;
             const int q = lane >> 1, half = lane & 1;                  // pixel, 16-byte half of its 32-byte cout block
             const int qx = x0 + seg * 32 + q;
             const uint32_t yoff = qx < W ? (uint32_t)((py * W + qx) * 32 + half * 16) : kBufOob;       // bytes inside a 16-cout block plane
@@ -738,11 +792,11 @@ int frcnn_f32s_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, voi
     return frcnn_launch_status();
 }
 
-// persistent first-layer launch: as many workgroups as the chip seats at once (2 per CU for the split form, 4 for the bf16 form:
-// the kernels' __launch_bounds__), each strides over the tiles
-static int conv1_grid(int ntiles, bool split) {
+// persistent first-layer launch: as many workgroups as the chip seats at once (2 per CU for the split form, 4 for the bf16 form, 3
+// for the fp32 form: the kernels' __launch_bounds__), each strides over the tiles
+static int conv1_grid(int ntiles, bool split, int seats = 0) {
     const char *e = getenv("FRCNN_CONV1_WGS_PER_CU");
-    const int per_cu = e && atoi(e) > 0 ? atoi(e) : (split ? 2 : 4);
+    const int per_cu = e && atoi(e) > 0 ? atoi(e) : (seats > 0 ? seats : (split ? 2 : 4));
     const char *g = getenv("FRCNN_CONV1_GRID");                        // tests: an exact workgroup count (the strided tile loop on small images)
     const long slots = g && atoi(g) > 0 ? atoi(g) : (long)frcnn_cu_count() * per_cu;
     return (int)(ntiles < slots ? ntiles : slots);
@@ -769,6 +823,18 @@ int frcnn_conv1_f32s_train(const float *x, const float *w_packed_f32, const floa
     if (y_nchw != nullptr) { if (Cout > 32) FRCNN_CONV1_TRAIN(2, true); else FRCNN_CONV1_TRAIN(1, true); }
     else { if (Cout > 32) FRCNN_CONV1_TRAIN(2, false); else FRCNN_CONV1_TRAIN(1, false); }
 #undef FRCNN_CONV1_TRAIN
+    return frcnn_launch_status();
+}
+
+// conv1_1 of the fp32 chain (frcnn_conv3x3_f32 hands layers with Cin <= 3 and Cout <= 64 over): fp32 NCHW image in, the trainers' packed
+// weights [(ci * 9 + tap)][Cout], fp32 NCHW out, native fp32 MFMA arithmetic
+int frcnn_conv1_f32(const float *x, const float *w_packed, const float *bias, float *y, int Cin, int Cout, int H, int W, int relu, void *stream) {
+    if (!x || !w_packed || !bias || !y || Cin < 1 || Cin > 3 || Cout < 1 || Cout > 64 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    if ((size_t)H * W * 64 * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;          // the output behind a 32-bit buffer range
+    const int xtiles = frcnn_cdiv(W, 64), ntiles = xtiles * frcnn_cdiv(H, 4);
+    const dim3 grid(conv1_grid(ntiles, false, 3));
+    if (Cout > 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<2, false, false, true>), grid, dim3(256), 0, (hipStream_t)stream, x, w_packed, bias, (uint16_t *)nullptr, Cin, Cout, H, W, relu, 1, y, xtiles, ntiles);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv1_f32s_kernel<1, false, false, true>), grid, dim3(256), 0, (hipStream_t)stream, x, w_packed, bias, (uint16_t *)nullptr, Cin, Cout, H, W, relu, 1, y, xtiles, ntiles);
     return frcnn_launch_status();
 }
 

@@ -46,6 +46,8 @@ def trunk_backward(trainer, layer_inputs, g):
     links = dict(trainer.convs)
     for l, xin in reversed(layer_inputs):
         if l == "pool":
+            if getattr(trainer, "keep_dy", None) is not None:        # tests: the pre-pool maps (near-tie windows = where two fp32 passes may route differently)
+                trainer.kept_dy.setdefault("pool_inputs", []).append(xin)
             g = rt.maxpool2x2_bwd(xin, g)
             continue
         name = l[0]
@@ -105,6 +107,8 @@ def trunk_backward_split(trainer, layer_inputs, g):
     for pos in range(len(layer_inputs) - 1, -1, -1):
         l, xin = layer_inputs[pos]
         if l == "pool":
+            if getattr(trainer, "keep_dy", None) is not None:
+                trainer.kept_dy.setdefault("pool_inputs", []).append(xin)
             g, gs = rt.maxpool2x2_bwd(xin, g), None
             continue
         name = l[0]

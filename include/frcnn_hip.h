@@ -223,6 +223,11 @@ int frcnn_conv1_f32s(const float *x, const float *w, const float *bias, uint16_t
  * layer of the bf16 chain without the fp32 -> blocked-bf16 image conversion and without 13 padded channels of MFMA work */
 int frcnn_conv1_bf16(const float *x, const float *w, const float *bias, uint16_t *y, int Cin, int Cout, int H, int W, int relu,
                      void *stream);
+/* and in native fp32 arithmetic (v_mfma_f32_32x32x2_f32): conv1_1 of the fp32 chain -- x = fp32 NCHW image, w_packed = the packed
+ * weights of frcnn_pack_conv3x3_w [(ci * 9 + tap)][Cout], y = (Cout, H, W) fp32 NCHW.  frcnn_conv3x3_f32 hands such layers
+ * (Cin <= 3, Cout <= 64, plain bias / ReLU epilogue) to it on its own. */
+int frcnn_conv1_f32(const float *x, const float *w_packed, const float *bias, float *y, int Cin, int Cout, int H, int W, int relu,
+                    void *stream);
 /* the same with a workspace (frcnn_conv_f32s_workspace_bytes; its first 64 KB zeroed ONCE by frcnn_conv_f32s_workspace_init --
  * every launch leaves them zero): lets launches with few tiles (38x63 maps) split their K range over several workgroups */
 size_t frcnn_conv_f32s_workspace_bytes(int Cin, int Cout, int H, int W);

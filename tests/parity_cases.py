@@ -637,6 +637,28 @@ def check_conv1_f32s(rt, Cin, Cout, H, W, relu=True, seed=0):
     assert np.array_equal(host(rt, ys2), host(rt, ys)) and np.array_equal(host(rt, yn2), got)
 
 
+def check_conv1_f32(rt, monkeypatch, Cin, Cout, H, W, relu=True, seed=0):
+    """conv1_1 of the fp32 chain through frcnn_conv3x3_f32: the first-layer kernel (native fp32 MFMA, 16-byte NCHW stores) against a
+    float64 convolution and against the generic kernel on the same call (FRCNN_CONV1_F32=generic)."""
+    import torch
+    rs = np.random.RandomState(seed)
+    x = (rs.randn(1, Cin, H, W) * 60).astype(np.float32)
+    w = (rs.randn(Cout, Cin, 3, 3) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    b = (rs.randn(Cout) * 0.1).astype(np.float32)
+    want64 = torch.nn.functional.conv2d(torch.from_numpy(x).double(), torch.from_numpy(w).double(), torch.from_numpy(b).double(), padding=1).numpy()
+    if relu:
+        want64 = np.maximum(want64, 0)
+    xd, wp, bd = dev(rt, x), rt.pack_conv3x3_w(dev(rt, w)), dev(rt, b)
+    got = host(rt, rt.conv3x3(xd, wp, bd, relu=relu))
+    scale = np.abs(want64).max()
+    assert got.shape == want64.shape and np.abs(got - want64).max() <= 1e-6 * scale, np.abs(got - want64).max() / scale
+    if Cout % 64 == 0:                          # (the generic kernel takes whole 64-cout tiles only)
+        monkeypatch.setenv("FRCNN_CONV1_F32", "generic")
+        gen = host(rt, rt.conv3x3(xd, wp, bd, relu=relu))
+        monkeypatch.delenv("FRCNN_CONV1_F32")
+        assert np.abs(got - gen).max() <= 2e-6 * scale
+
+
 def rel_err(got, want):
     want = np.asarray(want, dtype=np.float32)
     return float(np.abs(np.asarray(got, dtype=np.float32) - want).max() / max(float(np.abs(want).max()), 1e-30))

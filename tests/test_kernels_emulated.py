@@ -256,6 +256,14 @@ def test_conv1_f32s_first_layer(rt):
     P.check_conv1_f32s(rt, 1, 24, 5, 33, relu=False, seed=1)   # one channel (K = 9), 24 couts: one block, padded to 32
 
 
+def test_conv1_f32_first_layer(rt, monkeypatch):
+    P.check_conv1_f32(rt, monkeypatch, 3, 64, 11, 70)                      # ragged right edge (70 = 64 + 6: a partial group of four)
+    P.check_conv1_f32(rt, monkeypatch, 3, 64, 6, 67, seed=2)               # W % 4 != 0: unaligned 16-byte stores, 3-px tail
+    P.check_conv1_f32(rt, monkeypatch, 1, 24, 5, 33, relu=False, seed=1)   # one channel, one cout block, no ReLU
+    monkeypatch.setenv("FRCNN_CONV1_GRID", "2")                            # the strided tile loop
+    P.check_conv1_f32(rt, monkeypatch, 3, 64, 11, 70, seed=3)
+
+
 @pytest.mark.parametrize("grid", ["1", "4"])
 def test_conv1_persistent_tile_loop(rt, monkeypatch, grid):
     """The first-layer kernel is a persistent launch: with fewer workgroups than tiles every workgroup strides over several tiles
