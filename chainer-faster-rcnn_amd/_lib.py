@@ -84,6 +84,7 @@ SIGNATURES = {
     "frcnn_linear_bf16_workspace_bytes": (_S, [_I, _I, _I]),
     "frcnn_linear_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_softmax_channels_f32": (_I, [_P, _I, _I, _P, _P]),
+    "frcnn_rpn_heads_bf16": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "frcnn_im2col7x7s2_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "frcnn_maxpool3x3s2_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "frcnn_subsample2_f32": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -585,6 +585,93 @@ nhwc_bf16_to_nchw_kernel(const uint16_t *__restrict__ x, int C, int HW, int CP, 
     }
 }
 
+// The RPN heads of the bf16 chain as ONE launch (the fp32 form: rpn_heads_fused_kernel, conv.hip): the stacked 1x1 convolution of the
+// channel-blocked bf16 map + the 2A-way softmax.  On the 38x63 map the 1x1 case of conv_mfma_bf16_kernel has 20 tiles of 32 sequential
+// K-chunks (22 us) and the softmax is a second launch (5 us).  Here a 512-thread workgroup owns 32 pixels and all (<= 64) stacked
+// output channels, its 8 waves split the K-chunks and read their MFMA fragments straight from global memory -- both layouts are
+// fragment-ready: a chunk's 32 px of h ([C/16][HW][16]) and 32 weight rows ([C/16][CoutP][16]) are contiguous 1 KB runs, 16 bytes per
+// lane -- no LDS staging, no barrier inside the K range; the partial tiles meet in LDS, are added in wave order with the bias, leave as
+// the fp32 (n_out, HW) map, and the first 32 threads run the reference's softmax over the 2A score rows on the tile
+// (region_proposal_network.py:119).  Same operands as the two-launch form (bf16 x bf16 products are exact in fp32): the results differ
+// by the order of the fp32 additions only.
+constexpr int kHeadWavesB = 8, kHeadChunksB = 4;          // K-chunks (16 channels) whose loads a wave issues together
+__global__ void __launch_bounds__(64 * kHeadWavesB)
+rpn_heads_bf16_fused_kernel(const uint16_t *__restrict__ h, const uint16_t *__restrict__ wp, const float *__restrict__ bias, float *__restrict__ raw,
+                            float *__restrict__ prob, int CinP, int CoutP, int HW, int n_out, int n_score) {
+    __shared__ float part[kHeadWavesB][64][32];
+    __shared__ float outt[64][33];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int p0 = blockIdx.x * 32;
+    const int nchunks = CinP / kCK;
+    const int per_wave = (nchunks + kHeadWavesB * kHeadChunksB - 1) / (kHeadWavesB * kHeadChunksB) * kHeadChunksB;   // whole load batches
+    const frcnn_buf_t hbuf = frcnn_make_buf(h, (uint32_t)((size_t)CinP * HW * 2));
+    const frcnn_buf_t wbuf = frcnn_make_buf(wp, (uint32_t)((size_t)CinP * CoutP * 2));
+    // per-lane byte offsets inside a chunk (out of range: pixels past the map, weight rows past CoutP -> zeros)
+    const uint32_t b_off = p0 + l31 < HW ? (uint32_t)((p0 + l31) * 32 + khalf * 16) : kBufOob;
+    uint32_t a_off[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) a_off[cb] = cb * 32 + l31 < CoutP ? (uint32_t)((cb * 32 + l31) * 32 + khalf * 16) : kBufOob;
+    const uint32_t h_chunk = (uint32_t)HW * 32u, w_chunk = (uint32_t)CoutP * 32u;
+    frcnn_f32x16 acc[2];
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
+    for (int c0 = wave * per_wave; c0 < (wave + 1) * per_wave; c0 += kHeadChunksB) {
+        float4 bq[kHeadChunksB], aq[kHeadChunksB][2];
+#pragma unroll
+        for (int u = 0; u < kHeadChunksB; ++u) {
+            // chunks past the end of the tensors are out-of-range offsets: h_chunk * c >= the buffer size for c >= nchunks
+            const uint32_t c = (uint32_t)(c0 + u);
+            bq[u] = frcnn_buf_load_f32x4(hbuf, c < (uint32_t)nchunks ? b_off + c * h_chunk : kBufOob);
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) aq[u][cb] = frcnn_buf_load_f32x4(wbuf, c < (uint32_t)nchunks ? a_off[cb] + c * w_chunk : kBufOob);
+        }
+        __builtin_amdgcn_sched_barrier(0);                             // all of the batch's loads in flight before the first MFMA waits
+#pragma unroll
+        for (int u = 0; u < kHeadChunksB; ++u) {
+            const uint4 bv = make_uint4(__float_as_uint(bq[u].x), __float_as_uint(bq[u].y), __float_as_uint(bq[u].z), __float_as_uint(bq[u].w));
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const uint4 av = make_uint4(__float_as_uint(aq[u][cb].x), __float_as_uint(aq[u][cb].y), __float_as_uint(aq[u][cb].z), __float_as_uint(aq[u][cb].w));
+                acc[cb] = frcnn_mfma_32x32x16_bf16(av, bv, acc[cb]);
+            }
+        }
+    }
+    // D register r of lane l = cout (r&3) + 8*(r>>2) + 4*(l>>5), pixel l&31
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[wave][cb * 32 + (r & 3) + 8 * (r >> 2) + 4 * khalf][l31] = acc[cb][r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 64 * 32 / (64 * kHeadWavesB); ++q) {
+        const int o = tid + q * 64 * kHeadWavesB, co = o >> 5, px = o & 31;
+        float v = part[0][co][px];
+#pragma unroll
+        for (int w = 1; w < kHeadWavesB; ++w) v += part[w][co][px];
+        v += co < n_out ? bias[co] : 0.0f;
+        outt[co][px] = v;
+        if (co < n_out && p0 + px < HW) raw[(size_t)co * HW + p0 + px] = v;
+    }
+    __syncthreads();
+    if (tid < 32 && p0 + tid < HW) {
+        float v[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) v[c] = c < n_score ? outt[c][tid] : 0.0f;
+        float m = v[0];
+#pragma unroll
+        for (int c = 1; c < 32; ++c) if (c < n_score) m = fmaxf(m, v[c]);
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 32; ++c) if (c < n_score) { v[c] = expf(v[c] - m); sum += v[c]; }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) if (c < n_score) prob[(size_t)c * HW + p0 + tid] = v[c] / sum;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -734,6 +821,16 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
 #undef FRCNN_ABL_CASE
     }
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<1, 2>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
+    return frcnn_launch_status();
+}
+
+int frcnn_rpn_heads_bf16(const uint16_t *h, int Cmid, int H, int W, int A, const uint16_t *w_packed, const float *bias, float *raw, float *cls_prob,
+                         void *stream) {
+    if (!h || !w_packed || !bias || !raw || !cls_prob || Cmid < 1 || H < 1 || W < 1 || A < 1 || 6 * A > 64 || 2 * A > 32) return FRCNN_ERR_INVALID;
+    const int CinP = frcnn_bf16_padded_channels(Cmid), CoutP = frcnn_bf16_padded_channels(6 * A);
+    if ((size_t)CinP * H * W * 2 >= (1ull << 31)) return FRCNN_ERR_INVALID;
+    hipLaunchKernelGGL(rpn_heads_bf16_fused_kernel, dim3(frcnn_cdiv(H * W, 32)), dim3(64 * kHeadWavesB), 0, (hipStream_t)stream, h, w_packed, bias, raw,
+                       cls_prob, CinP, CoutP, H * W, 6 * A, 2 * A);
     return frcnn_launch_status();
 }
 

@@ -98,9 +98,12 @@ class RegionProposalNetwork(object):
         if timer:
             timer.mark("rpn_conv_3x3")
         wb, bb = self._heads_bf16
-        raw = rt.conv_bf16(h, wb, bb, self.mid_ch, 6 * A, 1, relu=False, out_f32_nchw=True)       # (1, 6A, H, W) fp32
-        score, bbox = raw[:, :2 * A], raw[:, 2 * A:]
-        prob = rt.softmax_channels(score[0])
+        if 6 * A <= 64 and os.environ.get("FRCNN_RPN_HEADS", "")[:1] != "c":
+            score, prob, bbox = rt.rpn_heads_bf16(h, wb, bb, self.mid_ch, A)                      # one launch (csrc/conv_bf16.hip)
+        else:
+            raw = rt.conv_bf16(h, wb, bb, self.mid_ch, 6 * A, 1, relu=False, out_f32_nchw=True)   # (1, 6A, H, W) fp32
+            score, bbox = raw[:, :2 * A], raw[:, 2 * A:]
+            prob = rt.softmax_channels(score[0])
         if timer:
             timer.mark("rpn_heads")
         return h, score, prob, bbox

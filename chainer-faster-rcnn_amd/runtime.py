@@ -587,6 +587,17 @@ class Runtime(object):
                                        ws.shape[0], m.stream()), "frcnn_linear_bf16")
         return y
 
+    def rpn_heads_bf16(self, h_blk, w_packed, bias, cmid, A):
+        """h_blk [CmidP/16][H][W][16] bf16, stacked bf16-packed 1x1 weights, (6A,) fp32 bias -> (rpn_cls_score (1,2A,H,W),
+        rpn_cls_prob (1,2A,H,W), rpn_bbox_pred (1,4A,H,W)) fp32: both heads and the softmax in one launch."""
+        m, L = self.mem, self.lib
+        H, W = int(h_blk.shape[1]), int(h_blk.shape[2])
+        raw = m.empty((1, 6 * A, H, W), "f32")
+        prob = m.empty((1, 2 * A, H, W), "f32")
+        _lib.check(L.frcnn_rpn_heads_bf16(m.ptr(h_blk), int(cmid), H, W, int(A), m.ptr(w_packed), m.ptr(bias), m.ptr(raw), m.ptr(prob),
+                                          m.stream()), "frcnn_rpn_heads_bf16")
+        return raw[:, :2 * A], prob, raw[:, 2 * A:]
+
     def softmax_channels(self, score):
         """(n_ch, H, W) fp32 -> softmax over the channel axis."""
         m, L = self.mem, self.lib

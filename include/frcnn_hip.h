@@ -283,6 +283,13 @@ int frcnn_bf16_from_nchw_f32(const float *x, int C, int H, int W, uint16_t *y, v
 int frcnn_bf16_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, void *stream);
 int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
                     int W, int ksize, int relu, int out_mode, void *stream);
+/* The RPN heads of the bf16 chain in one launch (models/region_proposal_network.py:118-120): h = rpn_conv_3x3's channel-blocked
+ * bf16 output [CmidP/16][H][W][16], w_packed = frcnn_bf16_pack_conv_w (ksize 1) of the stacked (6A, Cmid) matrix (rpn_cls_score rows,
+ * then rpn_bbox_pred rows), bias (6A) fp32 -> raw (6A, H, W) fp32 (rows [0,2A) = rpn_cls_score, [2A,6A) = rpn_bbox_pred) and
+ * cls_prob (2A, H, W) = softmax over all 2A score rows.  6A <= 64 (A <= 10).  Same operands as frcnn_conv_bf16 (ksize 1, out_mode 1)
+ * + frcnn_softmax_channels_f32; the fp32 additions run in a different order. */
+int frcnn_rpn_heads_bf16(const uint16_t *h, int Cmid, int H, int W, int A, const uint16_t *w_packed, const float *bias, float *raw,
+                         float *cls_prob, void *stream);
 /* the same with a workspace, which lets launches with fewer tiles than the chip has room for (the 38x63 maps) split K
  * across workgroups (deterministic: partial tiles are summed in split order by the last arriver).  Same contract as the
  * fp32 conv workspace: its first 64 KB are tile counters -- zero them once (frcnn_conv_bf16_workspace_init), every

@@ -510,6 +510,26 @@ def blocked_to_hwc(a):
     return np.ascontiguousarray(a.transpose(1, 2, 0, 3)).reshape(h, w, cb * 16)
 
 
+def check_rpn_heads_bf16(rt, Cmid, H, W, A=9, seed=0):
+    """The bf16 chain's RPN heads in one launch against the two-launch form (1x1 bf16 convolution writing fp32 NCHW + the channel
+    softmax) on the same operands, and against a float64 accumulation of the bf16-rounded operands."""
+    rs = np.random.RandomState(seed)
+    h = np.abs(rs.randn(1, Cmid, H, W)).astype(np.float32)
+    w = (rs.randn(6 * A, Cmid, 1, 1) * 0.05).astype(np.float32)
+    b = (rs.randn(6 * A) * 0.1).astype(np.float32)
+    hb = rt.bf16_from_nchw(dev(rt, h))
+    wp, bd = rt.bf16_pack_conv_w(dev(rt, w), 1), dev(rt, b)
+    score, prob, bbox = [host(rt, t) for t in rt.rpn_heads_bf16(hb, wp, bd, Cmid, A)]
+    raw = host(rt, rt.conv_bf16(hb, wp, bd, Cmid, 6 * A, 1, relu=False, out_f32_nchw=True))
+    prob2 = host(rt, rt.softmax_channels(dev(rt, np.ascontiguousarray(score[0]))))
+    scale = np.abs(raw).max()
+    assert score.shape == (1, 2 * A, H, W) and bbox.shape == (1, 4 * A, H, W) and prob.shape == (1, 2 * A, H, W)
+    assert np.abs(score - raw[:, :2 * A]).max() <= 2e-6 * scale and np.abs(bbox - raw[:, 2 * A:]).max() <= 2e-6 * scale
+    assert np.array_equal(prob, prob2)                       # the same softmax operations on the fused launch's own scores
+    want = np.einsum("oc,chw->ohw", to_bf16(w)[0].reshape(6 * A, Cmid).astype(np.float64), to_bf16(h)[0][0].astype(np.float64)) + b[:, None, None]
+    assert np.abs(np.concatenate([score, bbox], 1)[0] - want).max() <= 2e-6 * scale
+
+
 def check_conv_bf16(rt, Cin, Cout, H, W, ksize=3, relu=True, seed=0):
     rs = np.random.RandomState(seed)
     x = rs.randn(1, Cin, H, W).astype(np.float32)

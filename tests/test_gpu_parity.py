@@ -458,6 +458,11 @@ def test_linear_f32s(rt):
     P.check_linear_f32s(rt, 300, 116, 4096, relu=False, seed=3)      # the stacked cls_score / bbox_pred head
 
 
+def test_rpn_heads_bf16_fused(rt):
+    P.check_rpn_heads_bf16(rt, 512, 38, 63)
+    P.check_rpn_heads_bf16(rt, 208, 19, 32, A=3, seed=1)
+
+
 def test_conv1_f32_first_layer(rt, monkeypatch):
     P.check_conv1_f32(rt, monkeypatch, 3, 64, 75, 203)
     P.check_conv1_f32(rt, monkeypatch, 3, 64, 600, 1000, seed=2)

@@ -256,6 +256,11 @@ def test_conv1_f32s_first_layer(rt):
     P.check_conv1_f32s(rt, 1, 24, 5, 33, relu=False, seed=1)   # one channel (K = 9), 24 couts: one block, padded to 32
 
 
+def test_rpn_heads_bf16_fused(rt):
+    P.check_rpn_heads_bf16(rt, 128, 5, 15)                  # 8 chunks: waves 0-1 hold a batch each; 75 px = two tiles + 11
+    P.check_rpn_heads_bf16(rt, 208, 3, 7, A=3, seed=1)      # 13 chunks (a ragged last batch), 18 outputs: CoutP = 32, one cout block
+
+
 def test_conv1_f32_first_layer(rt, monkeypatch):
     P.check_conv1_f32(rt, monkeypatch, 3, 64, 11, 70)                      # ragged right edge (70 = 64 + 6: a partial group of four)
     P.check_conv1_f32(rt, monkeypatch, 3, 64, 6, 67, seed=2)               # W % 4 != 0: unaligned 16-byte stores, 3-px tail
