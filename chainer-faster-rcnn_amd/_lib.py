@@ -30,6 +30,7 @@ SIGNATURES = {
     "frcnn_roi_pool_fwd_hwc": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P]),
     "frcnn_roi_pool_fwd_chw": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _F, _P, _P, _P, _S, _P]),
     "frcnn_roi_pool_fwd_chw_bf16": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _F, _P, _P]),
+    "frcnn_roi_pool_fwd_blk_bf16": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _F, _P, _I, _P]),
     "frcnn_roi_pool_fwd_chw_f32s": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _F, _P, _P]),
     "frcnn_roi_pool_fwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _F, _P, _P, _P, _S, _P]),
     "frcnn_roi_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),

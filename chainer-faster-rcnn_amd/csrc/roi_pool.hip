@@ -457,7 +457,9 @@ __device__ __forceinline__ void cells_scan_chunk(const float4 *__restrict__ cell
 // maps): 155 KB image, 8 waves, direct stores.
 // OUT16: 0 = fp32, 1 = raw bf16 (one rounding of the fp32 maximum), 2 = the three bf16 terms of the fp32 maximum ([3][R][C*bins]: the
 // split tensor the fully connected layers of conv_f32s.hip read -- h + m + l is the fp32 value, exactly)
-template <int kRows, int OUT16>
+// IN16: the map is the bf16 chain's channel-blocked tensor [CP/16][H][W][16] (x reinterpreted): a cell's eight channels are ONE 16-byte
+// load (three loads per lane for the 38-row image instead of 24) and no fp32 NCHW copy of the map has to exist.
+template <int kRows, int OUT16, bool IN16 = false>
 __global__ void __launch_bounds__(kRows <= 38 ? 1024 : 512)
 roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const float *__restrict__ rois, int roi_cols, int R,
                       int outh, int outw, float scale, float *__restrict__ y, int rsplit, const RoiBinTables tables, int dbg_arg) {
@@ -547,14 +549,26 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
         tabv[q] = e < kTabWords ? reinterpret_cast<const uint32_t *>(&tables)[e] : 0u;
     }
     constexpr int kRowsPerWave = (kRows + kCellWaves - 1) / kCellWaves;
-    const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)C * HW * sizeof(float)));
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, IN16 ? (uint32_t)((size_t)((C + 15) / 16 * 16) * HW * 2) : (uint32_t)((size_t)C * HW * sizeof(float)));
     float v[kRowsPerWave][8];
 #pragma unroll
     for (int i = 0; i < kRowsPerWave; ++i) {
         const int h = wave + i * kCellWaves;
-        const uint32_t base = (h < H && lane < W) ? (uint32_t)((c0 * HW + h * W + lane) * 4) : kBufOob;
+        if constexpr (IN16) {
+            // channels c0 .. c0 + 7 of pixel (h, lane): half (c0 / 8) & 1 of channel block c0 / 16 (channels past C are the tensor's zero padding)
+            const uint32_t off = (h < H && lane < W) ? (uint32_t)((((c0 >> 4) * HW + h * W + lane) * 32) + ((c0 >> 3) & 1) * 16) : kBufOob;
+            const float4 q = frcnn_buf_load_f32x4(xbuf, off);
+            const uint32_t u[4] = {__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z), __float_as_uint(q.w)};
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[i][c] = frcnn_buf_load_f32(xbuf, base + (uint32_t)(c * HW * 4));   // c0 + c >= C: past the end -> 0
+            for (int c = 0; c < 4; ++c) {
+                v[i][2 * c] = __uint_as_float(u[c] << 16);
+                v[i][2 * c + 1] = __uint_as_float(u[c] & 0xffff0000u);
+            }
+        } else {
+            const uint32_t base = (h < H && lane < W) ? (uint32_t)((c0 * HW + h * W + lane) * 4) : kBufOob;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[i][c] = frcnn_buf_load_f32(xbuf, base + (uint32_t)(c * HW * 4));   // c0 + c >= C: past the end -> 0
+        }
     }
 #pragma unroll
     for (int q = 0; q < kTabPerThread; ++q) {
@@ -756,7 +770,7 @@ static int frcnn_roi_cu_count();
 
 // Launch the cell-major kernel when the map fits its LDS image (W <= 64 cells per row; H <= 38: two workgroups per CU,
 // H <= 76: one).  FRCNN_ROI_KERNEL=planes keeps the plane kernel (A/B measurements).  Returns false when it does not apply.
-template <int OUT16>
+template <int OUT16, bool IN16 = false>
 static bool roi_cells_launch(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
                              float scale, float *y, hipStream_t stream) {
     const char *sel = getenv("FRCNN_ROI_KERNEL");
@@ -794,8 +808,8 @@ static bool roi_cells_launch(const float *x, int C, int H, int W, const float *r
     dbg = dbg_s ? atoi(dbg_s) : 0;
 #endif
     const dim3 grid(cgroups, rsplit), blk(64 * waves);
-    if (H <= 38) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<38, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, tables, dbg);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<76, OUT16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, tables, dbg);
+    if (H <= 38) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<38, OUT16, IN16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, tables, dbg);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_cells_kernel<76, OUT16, IN16>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, tables, dbg);
     return true;
 }
 
@@ -911,6 +925,18 @@ int frcnn_roi_pool_fwd_chw_bf16(const float *x, int C, int H, int W, const float
     hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_planes_kernel<false, true>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw,
                        spatial_scale, reinterpret_cast<float *>(y), (int32_t *)nullptr, cg, per_block);
     return frcnn_launch_status();
+}
+
+int frcnn_roi_pool_fwd_blk_bf16(const uint16_t *x_blk, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
+                                float spatial_scale, void *y, int out_bf16, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x_blk || !rois || !y || C < 1 || H < 1 || W < 1 || R < 0) return FRCNN_ERR_INVALID;
+    if (outh < 1 || outw < 1 || outh > 7 || outw > 7 || (roi_cols != 4 && roi_cols != 5)) return FRCNN_ERR_INVALID;
+    if (R == 0) return FRCNN_OK;
+    const float *x = reinterpret_cast<const float *>(x_blk);
+    const bool ok = out_bf16 ? roi_cells_launch<1, true>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, reinterpret_cast<float *>(y), stream)
+                             : roi_cells_launch<0, true>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, reinterpret_cast<float *>(y), stream);
+    return ok ? frcnn_launch_status() : FRCNN_ERR_INVALID;       // cell-major kernel only (maps up to 76 x 64): frcnn_bf16_to_nchw_f32 + frcnn_roi_pool_fwd_chw otherwise
 }
 
 int frcnn_roi_pool_fwd(const float *x, int C, int H, int W, const float *rois, int R, int outh, int outw, float spatial_scale,

@@ -170,9 +170,23 @@ class FasterRCNN(object):
         if getattr(self, "_head_dirty", True):
             self._stack_head()
         mark = timer.mark if timer else (lambda name: None)
-        feat = self.trunk(x, timer=timer, collect=collect) if collect is not None else self.trunk(x, timer=timer)
-        C, H, W = [int(v) for v in feat.shape[1:]]
+        # bf16 chain: RoI pooling reads the channel-blocked bf16 map itself (a cell's eight channels are one 16-byte load), so the fp32
+        # NCHW copy of conv5_3 is only made when somebody asks for the intermediate maps
+        blk_pool = self.conv_dtype == "bf16" and not keep and collect is None and hasattr(self.trunk, "_call_bf16")
+        if blk_pool:
+            self.trunk.skip_nchw = True
+        try:
+            feat = self.trunk(x, timer=timer, collect=collect) if collect is not None else self.trunk(x, timer=timer)
+        finally:
+            if blk_pool:
+                self.trunk.skip_nchw = False
         x_bf16 = getattr(self.trunk, "feat_bf16", None) if self.conv_dtype == "bf16" else None
+        if feat is None:
+            C, H, W = self.trunk.feat_shape[1:]
+            if H > 76 or W > 64:                             # beyond the cell-major kernel's LDS image: pool from an fp32 NCHW copy
+                feat = rt.bf16_to_nchw(x_bf16, C)
+        else:
+            C, H, W = [int(v) for v in feat.shape[1:]]
         x_split = getattr(self.trunk, "feat_split", None) if self.conv_dtype == "f32s" else None
         rpn_h, score, prob, bbox = self.RPN.heads(feat, want_score=False, timer=timer, x_bf16=x_bf16, x_split=x_split)
         if keep:
@@ -185,10 +199,16 @@ class FasterRCNN(object):
             pool5 = pool5_split = rt.roi_pool_fwd_chw_f32s(feat, rois, 7, 7, self._spatial_scale)   # fp32 maxima, stored as their three bf16 terms
             pool5_bits = None
         elif self.head_dtype == "bf16" and not keep:
-            pool5 = rt.roi_pool_fwd_chw_bf16(feat, rois, 7, 7, self._spatial_scale)       # pooled in fp32, stored as bf16 bits
+            if feat is None:
+                pool5 = rt.roi_pool_fwd_blk_bf16(x_bf16, C, rois, 7, 7, self._spatial_scale, out_bf16=True)
+            else:
+                pool5 = rt.roi_pool_fwd_chw_bf16(feat, rois, 7, 7, self._spatial_scale)   # pooled in fp32, stored as bf16 bits
             pool5_bits = pool5
         else:
-            pool5 = rt.roi_pool_fwd_chw(feat, rois, 7, 7, self._spatial_scale)    # rois (R,4): concat (:123-124) folded in
+            if feat is None:
+                pool5 = rt.roi_pool_fwd_blk_bf16(x_bf16, C, rois, 7, 7, self._spatial_scale, out_bf16=False)
+            else:
+                pool5 = rt.roi_pool_fwd_chw(feat, rois, 7, 7, self._spatial_scale)    # rois (R,4): concat (:123-124) folded in
             pool5_bits = None
         mark("roi_pool")
         if self.head_dtype == "f32s":

@@ -77,7 +77,7 @@ class RegionProposalNetwork(object):
         """(h, rpn_cls_score, rpn_cls_prob, rpn_bbox_pred) -- region_proposal_network.py:117-120.  x_bf16: the same map as the
         channel-blocked bf16 array the bf16 trunk produced (skips re-converting the fp32 copy)."""
         if self.conv_dtype == "bf16":
-            return self._heads_bf16_path(self.rt.asarray(unwrap(x), "f32"), timer, x_bf16)
+            return self._heads_bf16_path(None if x_bf16 is not None else self.rt.asarray(unwrap(x), "f32"), timer, x_bf16)
         if self.conv_dtype == "f32s":           # the fp32 convolution on split tensors (csrc/conv_f32s.hip), fp32 NCHW out; heads as in fp32
             xs = x_split if x_split is not None else self.rt.f32s_from_nchw(self.rt.asarray(unwrap(x), "f32"))
             h = self.rpn_conv_3x3.f32s(xs, relu=True, out_f32_nchw=True)

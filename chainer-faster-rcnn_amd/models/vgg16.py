@@ -150,6 +150,9 @@ class VGG16Prev(object):
                 if collect is not None:                      # channel-blocked bf16 arrays: (array, channels)
                     collect["pool%d" % (n_pool + 1) if fuse else l[0]] = (h, cout)
         self.feat_bf16 = h                   # the channel-blocked bf16 map itself: the RPN's bf16 conv takes it as is
+        self.feat_shape = (1, cout, int(h.shape[1]), int(h.shape[2]))
+        if getattr(self, "skip_nchw", False):
+            return None                      # the caller pools straight from the blocked map (FasterRCNN.forward_device)
         feat = rt.bf16_to_nchw(h, cout)
         if timer:
             timer.mark("to_nchw")

@@ -222,6 +222,17 @@ class Runtime(object):
                                                  m.ptr(y), m.stream()), "frcnn_roi_pool_fwd_chw_bf16")
         return y
 
+    def roi_pool_fwd_blk_bf16(self, x_blk, C, rois, outh, outw, scale, out_bf16=False):
+        """RoI pooling straight from the bf16 chain's channel-blocked map [CP/16][H][W][16] -> (R, C, outh, outw) fp32, or raw bf16
+        bits (R, C*outh*outw) for the bf16 FC head.  Maps up to 76 x 64 (the cell-major kernel's LDS image)."""
+        m, L = self.mem, self.lib
+        H, W = int(x_blk.shape[1]), int(x_blk.shape[2])
+        R = int(rois.shape[0])
+        y = m.empty((R, int(C) * outh * outw), "i16") if out_bf16 else m.empty((R, int(C), outh, outw), "f32")
+        _lib.check(L.frcnn_roi_pool_fwd_blk_bf16(m.ptr(x_blk), int(C), H, W, m.ptr(rois), R, int(rois.shape[1]), outh, outw, float(scale),
+                                                 m.ptr(y), int(bool(out_bf16)), m.stream()), "frcnn_roi_pool_fwd_blk_bf16")
+        return y
+
     def roi_pool_fwd_chw_f32s(self, x, rois, outh, outw, scale):
         """The same pooling with the fp32 maxima written as their three bf16 terms, (3, R, C*outh*outw): the split FC head's input."""
         m, L = self.mem, self.lib

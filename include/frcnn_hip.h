@@ -114,6 +114,12 @@ int frcnn_roi_pool_fwd_chw_f32s(const float *x, int C, int H, int W, const float
  * (BASELINE config 3) without the fp32 pool5 round trip.  Plane-resident kernel only (maps whose plane fits in LDS). */
 int frcnn_roi_pool_fwd_chw_bf16(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh,
                                 int outw, float spatial_scale, uint16_t *y, void *stream);
+/* the same pooling straight from the bf16 chain's channel-blocked map x_blk = [CP/16][H][W][16] bf16 (CP = C rounded up to 16): a
+ * cell's eight channels are one 16-byte load and no fp32 NCHW copy of conv5_3 has to exist.  y = (R, C, outh, outw) fp32, or raw
+ * bf16 bits when out_bf16 (values are bf16 to begin with: exact).  Cell-major kernel only (maps up to 76 x 64), else
+ * FRCNN_ERR_INVALID: frcnn_bf16_to_nchw_f32 + frcnn_roi_pool_fwd_chw then. */
+int frcnn_roi_pool_fwd_blk_bf16(const uint16_t *x_blk, int C, int H, int W, const float *rois, int R, int roi_cols, int outh,
+                                int outw, float spatial_scale, void *y, int out_bf16, void *stream);
 int frcnn_roi_pool_fwd(const float *x, int C, int H, int W, const float *rois, int R, int outh, int outw,
                        float spatial_scale, float *y, int32_t *argmax, void *workspace,
                        size_t workspace_bytes, void *stream);

@@ -265,6 +265,21 @@ def check_roi_pool_cells_batches(rt):
         del os.environ["FRCNN_ROI_RSPLIT"]
 
 
+def check_roi_pool_blk_bf16(rt, R, C, H, W, seed=0):
+    """RoI pooling straight from the bf16 chain's channel-blocked map == the oracle's pooling of the same (bf16-valued) map, bit for
+    bit -- fp32 output and raw-bf16 output (a maximum of bf16 values is one of them: no rounding happens)."""
+    rs = np.random.RandomState(seed)
+    x, rois = roi_case(rs, R, C, H, W)
+    xb = to_bf16(x)[0]                                                   # the map's values ARE bf16 numbers
+    want = O.roi_pooling_2d(xb, rois, 7, 7, 0.0625)
+    blk = rt.bf16_from_nchw(dev(rt, xb))
+    assert np.array_equal(from_bf16_bits(host(rt, blk)).transpose(0, 3, 1, 2).reshape(-1, H, W)[:C], xb[0])      # the layout the kernel reads
+    got = host(rt, rt.roi_pool_fwd_blk_bf16(blk, C, dev(rt, rois[:, 1:].copy()), 7, 7, 0.0625))
+    assert got.shape == want.shape and np.array_equal(got, want), (R, C, H, W)
+    bits = host(rt, rt.roi_pool_fwd_blk_bf16(blk, C, dev(rt, rois), 7, 7, 0.0625, out_bf16=True))
+    assert np.array_equal(from_bf16_bits(bits).reshape(want.shape), want)
+
+
 # ------------------------------------------------------------------------------------------- conv stack
 def check_conv3x3(rt, Cin, Cout, H, W, cfg=-1, seed=0, relu=True):
     rs = np.random.RandomState(seed)
@@ -778,6 +793,11 @@ def check_vgg_bf16_forward(rt, im_h, im_w, seed=5):
     cp, pb, _ = O.rcnn_head(params, pool5, rois, info)                       # bf16 head vs the fp32 oracle on the same pool5
     assert np.abs(host(rt, out["cls_prob"])[:n] - cp).max() < 2e-2
     assert np.abs(host(rt, out["pred_boxes"])[:n] - pb).max() < 2e-2 * max(im_h, im_w)
+    # the inference path proper (keep=False) pools straight from the channel-blocked bf16 map and never makes the fp32 NCHW copy:
+    # same detections, bit for bit
+    out2 = model.forward_device(rt.mem.from_numpy(x), im_h, im_w)
+    for k in ("n_out", "rois", "cls_prob", "pred_boxes"):
+        assert np.array_equal(host(rt, out2[k]), host(rt, out[k])), k
     return err
 
 

@@ -458,6 +458,12 @@ def test_linear_f32s(rt):
     P.check_linear_f32s(rt, 300, 116, 4096, relu=False, seed=3)      # the stacked cls_score / bbox_pred head
 
 
+def test_roi_pool_from_blocked_bf16(rt):
+    P.check_roi_pool_blk_bf16(rt, 300, 512, 38, 63)
+    P.check_roi_pool_blk_bf16(rt, 40, 24, 12, 17, seed=1)
+    P.check_roi_pool_blk_bf16(rt, 64, 136, 75, 64, seed=2)
+
+
 def test_rpn_heads_bf16_fused(rt):
     P.check_rpn_heads_bf16(rt, 512, 38, 63)
     P.check_rpn_heads_bf16(rt, 208, 19, 32, A=3, seed=1)

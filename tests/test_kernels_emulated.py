@@ -256,6 +256,11 @@ def test_conv1_f32s_first_layer(rt):
     P.check_conv1_f32s(rt, 1, 24, 5, 33, relu=False, seed=1)   # one channel (K = 9), 24 couts: one block, padded to 32
 
 
+def test_roi_pool_from_blocked_bf16(rt):
+    P.check_roi_pool_blk_bf16(rt, 40, 24, 12, 17)               # 24 channels: the second block's upper half is padding
+    P.check_roi_pool_blk_bf16(rt, 9, 40, 50, 40, seed=1)         # the 76-row image, five channel groups (the last one in block 2, lower half)
+
+
 def test_rpn_heads_bf16_fused(rt):
     P.check_rpn_heads_bf16(rt, 128, 5, 15)                  # 8 chunks: waves 0-1 hold a batch each; 75 px = two tiles + 11
     P.check_rpn_heads_bf16(rt, 208, 3, 7, A=3, seed=1)      # 13 chunks (a ragged last batch), 18 outputs: CoutP = 32, one cout block

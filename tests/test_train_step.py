@@ -312,6 +312,23 @@ def test_bf16_copies_follow_the_optimizer(rt):
     assert np.array_equal(after, want)
 
 
+def test_bf16_inference_pools_from_the_blocked_map(rt):
+    """forward_device() of a bf16 model (keep=False: the inference path) pools straight from the channel-blocked bf16 conv5_3 map;
+    with keep=True the fp32 NCHW copy is made and pooled: the same detections, bit for bit."""
+    model, _ = _small_full_model(rt, conv_dtype="bf16", head_dtype="bf16")
+    x, _, _ = _step_inputs()
+    xd = rt.mem.from_numpy(x)
+    a = model.forward_device(xd, 40, 56, keep=True)
+    b = model.forward_device(xd, 40, 56)
+    assert getattr(model.trunk, "feat_shape", None) is not None
+    for k in ("n_out", "rois", "cls_prob", "pred_boxes"):
+        assert np.array_equal(rt.mem.to_numpy(a[k]), rt.mem.to_numpy(b[k])), k
+    model2, _ = _small_full_model(rt, conv_dtype="bf16", head_dtype="f32")      # bf16 convs, fp32 head: fp32 pool5 from the blocked map
+    a, b = model2.forward_device(xd, 40, 56, keep=True), model2.forward_device(xd, 40, 56)
+    for k in ("n_out", "rois", "cls_prob", "pred_boxes"):
+        assert np.array_equal(rt.mem.to_numpy(a[k]), rt.mem.to_numpy(b[k])), k
+
+
 # ---- snapshots in chainer's on-disk scheme (SURVEY 8f rank 4; fixtures hand-built by tests/make_chainer_snapshot.py)
 def _fixture_model(rt):
     import functools
