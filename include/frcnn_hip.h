@@ -111,7 +111,8 @@ int frcnn_roi_pool_fwd_chw(const float *x, int C, int H, int W, const float *roi
 int frcnn_roi_pool_fwd_chw_f32s(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
                                 float spatial_scale, uint16_t *y_parts, void *stream);
 /* the same with the pooled values written as raw bf16 (one rounding of the fp32 maximum): the input of the bf16 FC head
- * (BASELINE config 3) without the fp32 pool5 round trip.  Plane-resident kernel only (maps whose plane fits in LDS). */
+ * (BASELINE config 3) without the fp32 pool5 round trip.  LDS-resident kernels only (the cell-major kernel for maps up to 76 x 64,
+ * else the plane kernel while a plane fits in LDS); FRCNN_ERR_INVALID beyond that: pool in fp32 and convert with frcnn_f32_to_bf16. */
 int frcnn_roi_pool_fwd_chw_bf16(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh,
                                 int outw, float spatial_scale, uint16_t *y, void *stream);
 /* the same pooling straight from the bf16 chain's channel-blocked map x_blk = [CP/16][H][W][16] bf16 (CP = C rounded up to 16): a
