@@ -25,6 +25,7 @@
 #include "frcnn_common.h"
 #include <frcnn_sync.h>   // angle brackets: the test emulator shadows these headers via its include path
 #include <frcnn_buffer.h>
+#include <frcnn_intrin.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -322,6 +323,8 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
                     float4 v[ACO * APX * 4];
 #pragma unroll
                     for (int e = 0; e < ACO * APX * 4; ++e) v[e] = piece[(size_t)e * NT + tid];       // all loads of a piece in flight
+#pragma unroll
+                    for (int e = 0; e < ACO * APX * 4; ++e) frcnn_pin(v[e]);          // (else: load - wait - add, one vector at a time, for every piece after the first)
 #pragma unroll
                     for (int i = 0; i < ACO; ++i)
 #pragma unroll

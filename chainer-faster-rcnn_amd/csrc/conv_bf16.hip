@@ -515,6 +515,8 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
 #pragma unroll
             for (int e = 0; e < NV; ++e) v[e] = piece[(size_t)e * 256 + tid];
 #pragma unroll
+            for (int e = 0; e < NV; ++e) frcnn_pin(v[e]);               // one batch of loads per piece (else: load - wait - add per vector)
+#pragma unroll
             for (int j = 0; j < NACC; ++j)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {

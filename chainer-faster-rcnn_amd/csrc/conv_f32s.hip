@@ -226,11 +226,16 @@ conv_f32s_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
         for (int q = 0; q < nsplit; ++q) {
             const float4 *piece = reinterpret_cast<const float4 *>(partial_ws + ((size_t)tile * nsplit + q) * slot_floats);
+            float4 v[RW * 4];
+#pragma unroll
+            for (int e = 0; e < RW * 4; ++e) v[e] = piece[(size_t)e * 256 + tid];
+#pragma unroll
+            for (int e = 0; e < RW * 4; ++e) frcnn_pin(v[e]);           // one batch of loads per piece (else: load - wait - add per vector)
 #pragma unroll
             for (int j = 0; j < RW; ++j)
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
-                    const float4 t = piece[(size_t)(j * 4 + r4) * 256 + tid];
+                    const float4 t = v[j * 4 + r4];
                     acc[j][4 * r4] += t.x; acc[j][4 * r4 + 1] += t.y; acc[j][4 * r4 + 2] += t.z; acc[j][4 * r4 + 3] += t.w;
                 }
         }

@@ -1,0 +1,52 @@
+"""Static regression check on the compiled kernels (no GPU: hipcc -S cross-compiles gfx950): the kernels whose prologues / epilogues
+were found waiting for their global loads ONE AT A TIME (`s_waitcnt vmcnt(0)` after every predicated load of an
+unrolled load - use - store loop) keep their loads batched.  The measure is crude on purpose -- the number of full waits in the
+kernel's listing, bounded a little above today's value and far below what the serialised forms had (in parentheses)."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "chainer-faster-rcnn_amd", "csrc")
+
+# file -> [(mangled-name fragment, most full waits allowed)]
+BOUNDS = {
+    "detect": [("rank_scatter_kernel", 8)],                                                      # (21)
+    "conv_f32s": [("conv1_f32s_kernelILi2ELb1ELb0ELb0E", 4), ("conv1_f32s_kernelILi2ELb0ELb0ELb0E", 4),   # (34: 32 weight loads in the prologue)
+                  ("conv1_f32s_kernelILi2ELb0ELb0ELb1E", 4), ("conv_f32s_kernelILi2ELi0ELi1E", 10)],       # (40: the training forms' mask loads)
+    "conv_bf16": [("conv_dma_bf16_kernelILi1ELi4ELi1ELi0E", 8), ("conv_dma_bf16_kernelILi2ELi3ELi1ELi0E", 9),   # (15: bias groups; fp32-NCHW output)
+                  ("conv_mfma_bf16_kernelILi1ELi2ELi0E", 8), ("rpn_heads_bf16_fused_kernel", 6)],
+    "conv": [("conv_mfma_f32_kernelILi3ELi2ELi2ELi1ELi1ELi4ELb1ELi4ELi0ELb1E", 12),                 # (60: bias / mask per register)
+             ("conv_mfma_f32_kernelILi3ELi2ELi2ELi1ELi2ELi8ELb1ELi3ELi0ELb1E", 22), ("rpn_heads_fused_kernel", 6)],
+}
+
+
+def full_waits(asm_path):
+    counts, name = {}, None
+    for ln in open(asm_path):
+        m = re.match(r"^(_Z\w+):", ln)
+        if m:
+            name = m.group(1)
+            counts[name] = 0
+        elif name is not None and ln.startswith(".Lfunc_end"):
+            name = None
+        elif name is not None and "s_waitcnt vmcnt(0)" in ln:
+            counts[name] += 1
+    return counts
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc (cross-compiles without a GPU)")
+@pytest.mark.parametrize("src", sorted(BOUNDS))
+def test_loads_stay_batched(src, tmp_path):
+    asm = str(tmp_path / (src + ".s"))
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
+                    os.path.join(CSRC, src + ".hip"), "-o", asm], check=True, stderr=subprocess.DEVNULL)
+    counts = full_waits(asm)
+    for frag, bound in BOUNDS[src]:
+        hits = {k: v for k, v in counts.items() if frag in k}
+        assert hits, "kernel %s not found in %s.hip" % (frag, src)
+        for k, v in hits.items():
+            assert v <= bound, "%s: %d full vmcnt waits (bound %d): a load - wait - store chain is back (scripts/isa_wait_scan.py)" % (k, v, bound)
