@@ -4,6 +4,7 @@ barriers; the parity tests proper run the same checks on the real library under 
 import sys
 import os
 
+import numpy as np
 import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
@@ -254,6 +255,27 @@ def test_f32s_pipeline_small(rt):
 def test_conv1_f32s_first_layer(rt):
     P.check_conv1_f32s(rt, 3, 64, 11, 70)                  # two x tiles (64 + 6 px), three y tiles, ragged rows
     P.check_conv1_f32s(rt, 1, 24, 5, 33, relu=False, seed=1)   # one channel (K = 9), 24 couts: one block, padded to 32
+
+
+def test_first_layer_heads_and_blocked_pooling_on_ragged_shapes(rt, monkeypatch):
+    """A seeded sweep of awkward shapes (maps smaller than a tile, channel counts that fill neither a block of 32 nor of 16, a single
+    pixel) through the kernels added late in round 2: the first-layer kernel in its three arithmetic forms, both fused RPN-heads
+    launches, RoI pooling from the channel-blocked map."""
+    rs = np.random.RandomState(123)
+    for t in range(5):
+        cin, cout = int(rs.randint(1, 4)), int(rs.choice([1, 7, 16, 31, 32, 33, 48, 64]))
+        h, w = int(rs.randint(1, 10)), int(rs.randint(1, 80))
+        if cout % 4 == 0:
+            P.check_conv1_f32(rt, monkeypatch, cin, cout, h, w, relu=bool(rs.randint(2)), seed=t)
+        P.check_conv1_f32s(rt, cin, cout, h, w, relu=bool(rs.randint(2)), seed=t)
+        P.check_conv1_bf16(rt, cin, cout, h, w, seed=t)
+    for t in range(3):
+        cmid, h, w, a = int(rs.choice([16, 48, 100, 130])), int(rs.randint(1, 6)), int(rs.randint(1, 40)), int(rs.choice([1, 3, 9, 10]))
+        P.check_rpn_heads_forms(rt, monkeypatch, Cmid=cmid, H=h, W=w, A=a, seed=t)
+        P.check_rpn_heads_bf16(rt, cmid, h, w, A=a, seed=t)
+    for t in range(3):
+        c, h, w, r = int(rs.choice([1, 9, 24, 33])), int(rs.randint(2, 40)), int(rs.randint(2, 64)), int(rs.randint(1, 40))
+        P.check_roi_pool_blk_bf16(rt, r, c, h, w, seed=t)
 
 
 def test_roi_pool_from_blocked_bf16(rt):
