@@ -408,8 +408,12 @@ class RCNNTrainer(_BucketedAllReduce):
 
     HEAD = ("fc6", "fc7", "cls_score", "bbox_pred")
 
-    def __init__(self, model, lr=0.001, momentum=0.9, weight_decay=0.0005, dropout_ratio=0.5, comm=None):
+    def __init__(self, model, lr=0.001, momentum=0.9, weight_decay=0.0005, dropout_ratio=0.5, comm=None, conv_math="mfma"):
+        """conv_math: as in RPNTrainer -- "mfma" = the trunk's forward / input-gradient / weight-gradient convolutions on the fp32 MFMA
+        kernels, "split" = the same fp32 convolutions as six bf16 MFMA products of 3-way split operands (csrc/conv_f32s.hip)."""
         from .models.proposal_target_layer import ProposalTargetLayer
+        assert conv_math in ("mfma", "split")
+        self.conv_math = conv_math
         self.model, self.rt = model, model.rt
         self.lr, self.momentum, self.weight_decay, self.dropout_ratio, self.comm = lr, momentum, weight_decay, dropout_ratio, comm
         rt = self.rt
@@ -434,6 +438,11 @@ class RCNNTrainer(_BucketedAllReduce):
         self.grad = {k: rt.mem.view(self.G, sg.offset, sg.shape) for k, sg in segs.items()}
         self.wd = {name: rt.mem.empty((int(link.Wp.shape[1]) * 9, int(link.Wp.shape[0]) // 9), "f32") for name, link in self.convs[1:]}
         self.zero_bias = rt.mem.zeros((max(512, max(int(getattr(model, n).W.shape[1]) for n in self.HEAD)),), "f32")
+        if conv_math == "split":                                      # split weights of the forward / input-gradient convolutions (re-packed every step)
+            pad = rt.bf16_pad
+            big = [(n, l) for n, l in self.convs if int(l.cin) > 3]
+            self.ws_fwd = {n: rt.mem.empty((3, pad(l.cin) // 16, 9, pad(l.cout), 16), "i16") for n, l in big}
+            self.ws_dgrad = {n: rt.mem.empty((3, pad(l.cout) // 16, 9, pad(l.cin), 16), "i16") for n, l in big}
         self.iteration = 0
         # the head (fc6: 411 MB of gradients) is complete before the trunk's backward starts: its bucket rides under all of it
         self._plan_buckets([n for n, _ in self.convs] + list(self.HEAD))
@@ -481,7 +490,13 @@ class RCNNTrainer(_BucketedAllReduce):
         self._ensure_adopted()
         x = rt.asarray(unwrap(x), "f32")
         im_h, im_w = model.RPN.proposal_layer._img_hw(img_info)
-        feat, inputs = trunk_forward(model, x)
+        if self.conv_math == "split":
+            big = [(n, l) for n, l in self.convs if int(l.cin) > 3]
+            if big:
+                rt.f32s_pack_many([(l.Wp, self.ws_fwd[n], self.ws_dgrad[n], l.cin, l.cout) for n, l in big])
+            feat, inputs, _ = trunk_forward_split(self, x)
+        else:
+            feat, inputs = trunk_forward(model, x)
         C, H, W = [int(v) for v in feat.shape[1:]]
         _, _, prob, bbox = model.RPN.heads(feat, want_score=False)
         rois, _, n_out = model.RPN.proposal_layer.forward_device(prob, bbox, im_h, im_w)      # RPN.train is False in rcnn_train mode
@@ -516,7 +531,7 @@ class RCNNTrainer(_BucketedAllReduce):
             self._grads_ready(n_)
         # ---- RoI pooling (arg-max scatter) and the trunk; feat = relu(conv5_3): mask before entering conv5_3's backward
         gfeat = rt.relu_bwd_(rt.roi_pool_bwd(gp.reshape(n, C, 7, 7), argmax, C, H, W), feat)
-        trunk_backward(self, list(zip(self.layers, inputs)), gfeat)
+        (trunk_backward_split if self.conv_math == "split" else trunk_backward)(self, list(zip(self.layers, inputs)), gfeat)
         return dict(losses=losses, n_rois=n, keep_inds=keep)
 
     def update(self):

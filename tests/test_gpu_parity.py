@@ -406,6 +406,14 @@ def test_rcnn_train_step_vgg16(rt):
     assert losses["loss_rcnn"] > 0 and worst <= 1e-3
 
 
+def test_rcnn_train_step_split_products(rt):
+    """RCNNTrainer(conv_math="split") on the small network and on VGG-16: the stage-2 step's trunk convolutions as split products."""
+    import train_cases as T
+    T.check_small_rcnn_step(rt, conv_math="split")
+    losses, worst = T.check_vgg_rcnn_step(rt, conv_math="split")
+    assert losses["loss_rcnn"] > 0 and worst <= 1e-3
+
+
 def test_conv_workspace_self_cleaning(rt):
     P.check_conv_workspace_self_cleaning(rt)
 

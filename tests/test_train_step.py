@@ -162,6 +162,12 @@ def test_rcnn_train_step_small(rt):
     T.check_small_rcnn_step(rt)
 
 
+def test_rcnn_train_step_small_split_products(rt):
+    """RCNNTrainer(conv_math="split"): the stage-2 step with the trunk's forward / input-gradient / weight-gradient convolutions as
+    six bf16 MFMA products of 3-way split operands -- the same bars as the fp32-MFMA step."""
+    T.check_small_rcnn_step(rt, conv_math="split")
+
+
 def test_gradient_buckets_tile_the_flat_buffer(rt):
     """Data-parallel buckets: contiguous tail ranges of the flat gradient buffer in backward order, together covering it exactly
     once, each closed by a layer whose gradients are the last of the bucket to be produced."""

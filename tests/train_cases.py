@@ -179,13 +179,13 @@ def small_head_params(rs, ch=64, hidden=128, ncls=21):
     return p
 
 
-def check_rcnn_step(rt, model, params, layers, x, gt, info, feat_stride, seed=0):
+def check_rcnn_step(rt, model, params, layers, x, gt, info, feat_stride, seed=0, conv_math="mfma"):
     """Stage-2 step vs the oracle: the device's own proposals, ProposalTargetLayer sample and dropout masks are handed to the
     oracle's autograd restatement; loss and every trunk / head gradient within 1e-3 relative."""
     from chainer_faster_rcnn_amd.chainer_compat import Variable
     from chainer_faster_rcnn_amd.train import RCNNTrainer
     model.rcnn_train = True
-    tr = RCNNTrainer(model)
+    tr = RCNNTrainer(model, conv_math=conv_math)
     # dropout masks fixed up front (the proposal count is not known before the forward: draw for the capacity, slice below)
     rs = np.random.RandomState(seed)
     cap = model.RPN.proposal_layer.TEST_RPN_POST_NMS_TOP_N
@@ -230,7 +230,7 @@ def check_rcnn_step(rt, model, params, layers, x, gt, info, feat_stride, seed=0)
     return l, worst
 
 
-def check_small_rcnn_step(rt, seed=0, im_h=48, im_w=64):
+def check_small_rcnn_step(rt, seed=0, im_h=48, im_w=64, conv_math="mfma"):
     rs = np.random.RandomState(seed)
     params = small_params()
     params.update(small_head_params(rs))
@@ -244,10 +244,10 @@ def check_small_rcnn_step(rt, seed=0, im_h=48, im_w=64):
         getattr(model, n).set(params[n + "/W"], params[n + "/b"])
     model.RPN.proposal_layer.RPN_MIN_SIZE = 4
     model.RPN.proposal_layer._min_size = 4
-    return check_rcnn_step(rt, model, params, SMALL_LAYERS, x, gt, info, 4, seed)
+    return check_rcnn_step(rt, model, params, SMALL_LAYERS, x, gt, info, 4, seed, conv_math=conv_math)
 
 
-def check_vgg_rcnn_step(rt, im_h=160, im_w=224, seed=0):
+def check_vgg_rcnn_step(rt, im_h=160, im_w=224, seed=0, conv_math="mfma"):
     """Stage-2 step of the real VGG-16 FasterRCNN (GPU suite)."""
     from chainer_faster_rcnn_amd import synthetic
     from chainer_faster_rcnn_amd.models import FasterRCNN
@@ -259,4 +259,4 @@ def check_vgg_rcnn_step(rt, im_h=160, im_w=224, seed=0):
     info = np.array([[im_h, im_w]], dtype=np.int32)
     model = FasterRCNN(runtime=rt)
     model.load_params(params)
-    return check_rcnn_step(rt, model, params, LAYERS, x, gt, info, 16, seed)
+    return check_rcnn_step(rt, model, params, LAYERS, x, gt, info, 16, seed, conv_math=conv_math)
