@@ -23,6 +23,7 @@
 #include <frcnn_buffer.h>   // angle brackets: shadowed by the test emulator
 #include <frcnn_intrin.h>
 #include <frcnn_sync.h>
+#include "frcnn_reduce.h"
 
 namespace {
 
@@ -1051,9 +1052,9 @@ __global__ void __launch_bounds__(256)
 linear_reduce_f32s_kernel(const float *__restrict__ part, const float *__restrict__ bias, void *__restrict__ y, int M, int N, int splits, int relu, int out_split) {
     const size_t total = (size_t)M * N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        float v = 0.0f;
-        for (int s = 0; s < splits; ++s) v += part[(size_t)s * total + i];
-        v += bias[i % N];
+        const float b = bias[i % N];                         // issued ahead of the slab loads: it is used last
+        float v = frcnn_sum_splits(part, total, i, splits);
+        v += b;
         if (relu) v = fmaxf(v, 0.0f);
         if (out_split) {
             uint32_t h, m, l;

@@ -60,6 +60,7 @@ __device__ __forceinline__ frcnn_f32x16 frcnn_mfma_32x32x16_bf16(uint4 a, uint4 
 // have arrived before anything after it runs, so a batch of loads followed by pins is issued as a batch and waited for once.  (Without
 // it the compiler is free to pair each load with its first use -- load, s_waitcnt vmcnt(0), add -- one dependent round trip per vector.)
 __device__ __forceinline__ void frcnn_pin(float4 &v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void frcnn_pin(float &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ uint32_t frcnn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 
 // (v0, v1) -> the three packed bf16 pairs (h, m, l) with h + m + l == v exactly (round to nearest even at every step; the

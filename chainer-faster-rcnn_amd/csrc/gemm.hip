@@ -13,6 +13,7 @@
 #include "frcnn_common.h"
 #include <stdlib.h>
 #include <frcnn_buffer.h>   // angle brackets: shadowed by the test emulator
+#include "frcnn_reduce.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -231,9 +232,9 @@ linear_reduce_kernel(const float *__restrict__ part, const float *__restrict__ b
                      int relu) {
     const size_t total = (size_t)M * N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        float v = 0.0f;
-        for (int s = 0; s < splits; ++s) v += part[(size_t)s * total + i];
-        v += bias[i % N];
+        const float b = bias[i % N];                         // issued ahead of the slab loads: it is used last
+        float v = frcnn_sum_splits(part, total, i, splits);
+        v += b;
         if (relu) v = fmaxf(v, 0.0f);
         y[i] = v;
     }
