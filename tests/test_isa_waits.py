@@ -19,6 +19,7 @@ BOUNDS = {
                   ("conv1_f32s_kernelILi2ELb0ELb0ELb1E", 4), ("conv_f32s_kernelILi2ELi0ELi1E", 10)],       # (40: the training forms' mask loads)
     "conv_bf16": [("conv_dma_bf16_kernelILi1ELi4ELi1ELi0E", 8), ("conv_dma_bf16_kernelILi2ELi3ELi1ELi0E", 9),   # (15: bias groups; fp32-NCHW output)
                   ("conv_mfma_bf16_kernelILi1ELi2ELi0E", 8), ("rpn_heads_bf16_fused_kernel", 6)],
+    "gemm": [("linear_reduce_kernel", 5)],                                                       # (one full wait per split-K slab, in a loop)
     "conv": [("conv_mfma_f32_kernelILi3ELi2ELi2ELi1ELi1ELi4ELb1ELi4ELi0ELb1E", 12),                 # (60: bias / mask per register)
              ("conv_mfma_f32_kernelILi3ELi2ELi2ELi1ELi2ELi8ELb1ELi3ELi0ELb1E", 22), ("rpn_heads_fused_kernel", 6)],
 }
