@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <frcnn_buffer.h>   // angle brackets: shadowed by the test emulator
 #include <frcnn_intrin.h>
+#include "frcnn_reduce.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -287,9 +288,7 @@ __global__ void __launch_bounds__(256)
 bias_grad_final_kernel(const float *__restrict__ partial, int C, int parts, float *__restrict__ db) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    float s = 0.0f;
-    for (int q = 0; q < parts; ++q) s += partial[(size_t)c * parts + q];
-    db[c] = s;
+    db[c] = frcnn_sum_splits(partial + (size_t)c * parts, 1, 0, parts);          // in part order, loads in batches of eight (frcnn_reduce.h)
 }
 
 // forward-packed (Cin*9, Cout) -> the packed weights of the input-gradient convolution: (Cout*9, Cin) with the taps
