@@ -42,6 +42,16 @@ __device__ __forceinline__ void frcnn_buf_store_b128(frcnn_buf_t b, uint32_t byt
     __builtin_amdgcn_raw_buffer_store_b128(u, b, (int)byte_off, 0, 0);
 }
 
+// 16-byte store at (per-lane offset, range-checked) + (wave-uniform scalar offset, added after the check), cache policy AUX as a
+// template argument: 0 = write-back, 16 = sc1 (write-through: the bytes leave the L2 while the kernel is still running instead of
+// after its last wave -- 30 MB of output cost 3.6 us that way and 4.5 us as plain stores, scripts/micro/store_micro.hip)
+template <int AUX>
+__device__ __forceinline__ void frcnn_buf_store_f32x4_soff(frcnn_buf_t b, uint32_t byte_off, uint32_t soff, float4 v) {
+    frcnn_u32x4 u;
+    u.x = __float_as_uint(v.x); u.y = __float_as_uint(v.y); u.z = __float_as_uint(v.z); u.w = __float_as_uint(v.w);
+    __builtin_amdgcn_raw_buffer_store_b128(u, b, (int)byte_off, (int)soff, AUX);
+}
+
 __device__ __forceinline__ void frcnn_buf_store_f32(frcnn_buf_t b, uint32_t byte_off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b, (int)byte_off, 0, 0);
 }

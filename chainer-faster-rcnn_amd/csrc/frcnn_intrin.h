@@ -72,3 +72,13 @@ __device__ __forceinline__ void frcnn_split3_pair(float v0, float v1, uint32_t &
     l = frcnn_pack_bf16x2(d0 - __uint_as_float(m << 16), d1 - __uint_as_float(m & 0xffff0000u));
 }
 
+
+// ds_append: ONE wave-level LDS operation that adds the number of active lanes to a counter and hands every lane the old value.  The
+// hardware addresses the counter through M0[15:0]: it must sit in the first 64 KB of the workgroup's LDS.
+__device__ __forceinline__ int frcnn_lds_append(int *ctr) {
+    return __builtin_amdgcn_ds_append((__attribute__((address_space(3))) int *)ctr);
+}
+// DPP wave_shl:1 -- lane l receives lane l + 1's value, lane 63 receives 0: one VALU instruction, no LDS crossbar trip
+__device__ __forceinline__ float frcnn_wave_shl1_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, false));
+}

@@ -21,6 +21,8 @@
 #include <frcnn_intrin.h>   // angle brackets: shadowed by the test emulator
 #include <frcnn_buffer.h>
 #include <math.h>
+#include <algorithm>
+#include <type_traits>
 #include <stdlib.h>
 #include <string.h>
 
@@ -752,6 +754,395 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Quad-cell forward (round 3; the default when the map fits 38 x 64).  What round 2's counters and round 3's micro-measurements
+// (scripts/micro/store_micro.hip) say about this operation on the MI355X:
+//   * a launch in a chain of graph nodes costs 2.7 us before it does anything, and 30.1 MB of output cost 3.6 us more with
+//     write-through (sc1) 16-byte stores -- but 4.5 us with plain stores: the dirty lines sit in the 32 MB of L2 and are written back
+//     AFTER the last wave has finished (the "parts that add up" of round 2's ablation), and 7-10 us as direct 4-byte stores;
+//   * the prologue is pure latency: 76 KB of map per CU cost 1.05 us, 38 KB 0.6 us;
+//   * everything in between is VALU and LDS issue (4 clocks per VALU instruction and wave, 4+ per ds_read_b128; SQ counters): the
+//     cell-major kernel spent 219 VALU instructions and ~24 LDS reads per (RoI, 8 channels), 37 % of its LDS cycles on bank conflicts.
+// So: a workgroup holds FOUR channels of the map as 16-byte cells (38 KB; one ds_read_b128 = the four channels of one cell), a lane
+// owns ONE bin (ph, pw) of the RoI its wave is working on and all four channels of it, and the address arithmetic is gone:
+//   * the bins of one RoI differ in width (height) by at most one cell -- floor / ceil of multiples of the same stride -- so with
+//     mbw (mbh) the RoI's widest (tallest) bin, EVERY lane reads the same number of columns: c0, c0 + tw, ... (immediate offsets of
+//     the ds_read: the count is wave-uniform, one unrolled body per value) and its own last column; likewise rows.  A duplicate read
+//     cannot change a maximum and nothing outside the bin is ever read.  Per pass a lane builds four base addresses
+//     (first | last row) + (first | last column) from two packed LDS words and advances two of them per row step;
+//   * a second image holds T11[h][w] = max of the 2 x 2 cells at (h, w): RoIs whose bins are all at least 2 x 2 (extent >= 8 cells
+//     both ways: most) are covered with 2 x 2 tiles -- a quarter of the reads and of the maxima (3.5 instead of 8.5 reads per pass on
+//     the benchmark's RoIs);
+//   * lanes are dealt to bins by the hardware's ds_read_b128 lane groups: the 16 lanes that share an LDS cycle hold two adjacent bin
+//     rows (8 columns each, the eighth shadows the seventh), which with the odd row pitch keeps them on different banks most of the
+//     time (simulated 1.36 cycles per group instead of 2.04 for lane = 8 ph + pw; scripts/micro/lds_sim.py);
+//   * RoIs that do not fit the pattern (bins emptied or narrowed by the map's edge) and maps that hold a NaN take the general path
+//     (saturating addresses on the plain image, first-cell rule restored): correct, not fast, and rare;
+//   * bin edges are the oracle's double arithmetic (bin_range), ONE thread per RoI on three waves that do nothing else, while the
+//     other thirteen fetch the map (three rows + one halo row each) and build the tile image from registers (the horizontal pair
+//     maximum is a DPP wave shift);
+//   * the RoI's [4][7][7] block is assembled in the wave's 784-byte LDS slot and leaves as ONE run of 16-byte write-through stores
+//     through a buffer descriptor (scalar base: no address VALU).
+// Scan order = the oracle's: the bin's first cell seeds the maximum, later NaNs never win, a NaN first cell stays (general path).
+constexpr int kQuadPitch = 65;           // cells per LDS row: odd, so vertically adjacent cells sit 16 B apart in the bank pattern
+constexpr int kQuadRows = 38;
+constexpr int kQuadImgBytes = kQuadRows * kQuadPitch * 16;
+constexpr int kQuadWaves = 16;
+constexpr int kQuadLoadWaves = 13;       // waves 0 .. 12 fetch three map rows each (+ one halo row)
+constexpr int kQuadProducers = kQuadWaves - kQuadLoadWaves;              // waves 13 .. 15 build the RoI geometry, one RoI per lane
+constexpr int kQuadGeoSlots = 64 * kQuadProducers;                       // RoIs per geometry batch
+constexpr int kQuadTabExt = 64;
+// LDS layout (one block, carved by hand: ds_append addresses its counter through M0[15:0], so the counter must sit below 64 KB --
+// the compiler put a separate __shared__ int behind the images and the hardware wrapped the address into them)
+constexpr int kQuadOffCtr = 0;                                           // int: draw counter, NaN flag
+constexpr int kQuadOffGeoM = 32;                                         // uint2 [slots]: column word, row word
+constexpr int kQuadOffGeoW = kQuadOffGeoM + kQuadGeoSlots * 8;           // uint32 [slots][8]
+constexpr int kQuadOffGeoH = kQuadOffGeoW + kQuadGeoSlots * 32;          // uint2 [slots][8]
+constexpr int kQuadOffStage = kQuadOffGeoH + kQuadGeoSlots * 64;         // float [waves][2][4 * kMaxBins]
+constexpr int kQuadOffImg = (kQuadOffStage + kQuadWaves * 2 * 4 * kMaxBins * 4 + 15) / 16 * 16;    // float4 [2][rows * pitch]
+constexpr int kQuadOffTab = kQuadOffImg + 2 * kQuadImgBytes;            // uint16 [producers][2][ext][8]: each producer's copy of the edge rows
+constexpr int kQuadLdsBytes = kQuadOffTab + kQuadProducers * 2 * kQuadTabExt * 16;
+static_assert(kQuadOffImg % 16 == 0 && kQuadOffStage % 16 == 0 && kQuadOffTab % 16 == 0, "16-byte LDS accesses");
+
+// Bin edges per extent, built on the HOST with the oracle's double arithmetic -- floor(p * (e / out)), ceil((p + 1) * (e / out)): IEEE
+// double division / multiplication / floor / ceil are correctly rounded, so the host's values are the device's (7 * (29 / 7.) =
+// 29.000000000000004 -> ceil 30 included) -- and handed to the kernel by value (2 KB of kernel arguments).  Row = seven bins as
+// lo | hi << 8 and a meta word = largest bin | last hi << 8.  Extents of 64 and more (a RoI larger than the map) take the double
+// arithmetic itself on the device.
+struct RoiEdgeTable {
+    uint16_t row[2][kQuadTabExt][8];     // [0] columns (outw), [1] rows (outh)
+};
+
+// The waves of a workgroup draw RoIs from an LDS counter with ds_append: ONE wave-level operation that adds the number of active
+// lanes (64: the draw loop runs with every lane on) and returns the old value -- no single-lane branch and none of the ten-instruction
+// mbcnt sequence `if (lane == 0) atomicAdd(...)` compiles to.  The counter therefore counts in units of 64.
+__device__ __forceinline__ int quad_draw(unsigned char *lds) {
+    return frcnn_lds_append(reinterpret_cast<int *>(lds + kQuadOffCtr)) >> 6;
+}
+__device__ __forceinline__ float4 quad_cell(const unsigned char *lds, uint32_t off) { return *reinterpret_cast<const float4 *>(lds + off); }
+
+// One RoI's bin for this lane: gw / gh = the lane's column and row words, mw / mh = the RoI's (wave-uniform) meta words.
+__device__ __forceinline__ float4 quad_scan_slot(const unsigned char *img, uint32_t gw, uint2 gh, uint32_t mw, uint32_t mh) {
+    const int nc = (int)(mw & 255u), nr = (int)(mh & 255u);
+    float4 acc;
+    if (!(mw >> 17)) {
+        // tiles: columns cl, cl + tw, ... and the bin's own last tile column ch; rows likewise (a / b advance, c / d = last row).
+        // A duplicate read cannot change a maximum.
+        const uint32_t t2 = (mw >> 16) & 1u;
+        const uint32_t cl = gw & 0xffffu, ch = gw >> 16;
+        uint32_t a = gh.x + cl, b = gh.x + ch;
+        const uint32_t c = gh.y + cl, d = gh.y + ch;
+        const uint32_t cstep = 16u << t2, rstep = (uint32_t)(kQuadPitch * 16) << t2;
+        acc = max4(quad_cell(img, c), quad_cell(img, d));
+#pragma unroll 1
+        for (int k = 1; k < nc - 1; ++k) acc = max4(acc, quad_cell(img, c + k * cstep));
+#pragma unroll 1
+        for (int j = 1; j < nr; ++j) {
+            acc = max4_3(acc, quad_cell(img, a), quad_cell(img, b));
+#pragma unroll 1
+            for (int k = 1; k < nc - 1; ++k) acc = max4(acc, quad_cell(img, a + k * cstep));
+            a += rstep; b += rstep;
+        }
+    } else {
+        // general path: saturating rows / columns over the RoI's largest bin shape on the plain cells; the first cell seeds the
+        // maximum and a NaN first cell stays (`>` never replaces it), an empty bin is 0
+        const uint32_t cl = gw & 0x7fffu, ch = (gw >> 16) & 0x7fffu, r0 = gh.x, r1 = gh.y & 0x7fffffffu;
+        const bool empty = ((gw >> 15) & 1u) || (gh.y >> 31);
+        const float4 first = quad_cell(img, r0 + cl);
+        acc = first;
+#pragma unroll 1
+        for (int j = 0; j < nr; ++j) {
+            const uint32_t rr = min(r0 + (uint32_t)j * (kQuadPitch * 16), r1);
+#pragma unroll 1
+            for (int k = 0; k < nc; ++k) acc = max4(acc, quad_cell(img, rr + min(cl + 16u * k, ch)));
+        }
+        if (first.x != first.x) acc.x = first.x;
+        if (first.y != first.y) acc.y = first.y;
+        if (first.z != first.z) acc.z = first.z;
+        if (first.w != first.w) acc.w = first.w;
+        if (empty) acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    return acc;
+}
+
+// BINS: outh * outw as a compile-time constant (49 for the 7 x 7 head: the staging stores get immediate offsets and pair up as
+// ds_write2_b32), or 0 = any shape up to 7 x 7
+template <int ST, int BINS>
+__global__ void __launch_bounds__(64 * kQuadWaves)
+roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const float *__restrict__ rois, int roi_cols, int R,
+                      int outh, int outw, float scale, float *__restrict__ y, int rsplit, const RoiEdgeTable etab, int dbg_arg) {
+#ifdef FRCNN_TIMING_ABLATIONS                    // tuning builds only (scripts/micro): 2 prologue only, 4 no scan, 8 no staging / output, 16 no stores -- WRONG results
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#endif
+    __shared__ __attribute__((aligned(16))) unsigned char lds[kQuadLdsBytes];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int HW = H * W, bins = BINS ? BINS : outh * outw;
+    const int c0 = blockIdx.x * 4;
+    const int g0 = blockIdx.y;
+    const int n_slots = g0 < R ? (R - g0 + rsplit - 1) / rsplit : 0;        // this workgroup's RoIs: g0 + slot * rsplit
+    int *const ctr = reinterpret_cast<int *>(lds + kQuadOffCtr);
+#ifdef FRCNN_TIMING_ABLATIONS
+    // dbg & 128: per-wave s_memtime stamps into y (use with dbg & 16: no output stores): [wg][wave][32] uint32
+    uint32_t *stamps = reinterpret_cast<uint32_t *>(y) + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kQuadWaves + wave) * 32;
+    int n_stamp = 0;
+    auto stamp = [&]() { if ((dbg & 128) && n_stamp < 32) { const uint64_t t = __builtin_amdgcn_s_memtime(); if (lane == 0) stamps[n_stamp] = (uint32_t)t; ++n_stamp; } };
+#else
+    auto stamp = [&]() {};
+#endif
+    stamp();
+
+    // ---- RoI geometry: the three waves that fetch no map rows, ONE LANE PER RoI, all fourteen bin entries of it in sequence.  (Eight
+    //      lanes per RoI, one bin each, repeats the per-RoI arithmetic eight times: 100 VALU instructions per eight RoIs against 110 per
+    //      sixty-four here, and instruction issue is what the prologue waits for.)  The lane reads its extents' two 16-byte edge rows
+    //      from the wave's own LDS copy of the host table (no workgroup barrier between the copy and the look-up: DS operations of one
+    //      wave are in order) and writes its 8 + 8 entries as six 16-byte stores.
+    //   fast form (no bin touches the map's edge, so bin_range()'s clamps do nothing and every bin has its unclamped size >= 1):
+    //     geo_w[p] = byte offset of the bin's first tile column | of its last tile column << 16; geo_h[p] = byte offsets of its first and
+    //     last tile row, the image's offset included; meta = tile columns | 2 x 2 tiles << 16, tile rows
+    //   general form (some bin clamped, or the map holds a NaN): plain cells, clamped into the map, bit 15 / bit 31 = bin empty;
+    //     meta = widest bin | 1 << 17, tallest bin
+    const int pk = wave - kQuadLoadWaves;                                    // producer index, < 0 on the map waves
+    uint4 *const my_tab = reinterpret_cast<uint4 *>(lds + kQuadOffTab) + max(pk, 0) * (2 * kQuadTabExt);
+    auto roi_of_lane = [&](int base) -> float4 {
+        const int sl = pk * 64 + lane;
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (base + sl < n_slots) {
+            const float *pr = rois + (size_t)roi_cols * (g0 + (base + sl) * rsplit) + (roi_cols - 4);
+            q = make_float4(pr[0], pr[1], pr[2], pr[3]);
+        }
+        return q;
+    };
+    auto build_geometry = [&](int base, const float4 q, bool force_general) __attribute__((always_inline)) {
+        const int sl = pk * 64 + lane;
+        if (base + sl >= n_slots) return;
+        const int xs = (int)rintf(q.x * scale), ys = (int)rintf(q.y * scale);      // roi_geometry(): round-half-even of the fp32 product
+        const int rw = max((int)rintf(q.z * scale) - xs + 1, 1), rh = max((int)rintf(q.w * scale) - ys + 1, 1);
+        uint32_t rwq[4], rhq[4];                                             // the two edge rows: seven bins lo | hi << 8, then the meta word
+        if (rw < kQuadTabExt && rh < kQuadTabExt) {
+            const uint4 a = my_tab[rw], b = my_tab[kQuadTabExt + rh];
+            rwq[0] = a.x; rwq[1] = a.y; rwq[2] = a.z; rwq[3] = a.w; rhq[0] = b.x; rhq[1] = b.y; rhq[2] = b.z; rhq[3] = b.w;
+        } else {                                                           // a RoI larger than the map: bin_range()'s arithmetic itself
+            const double sw = (double)rw / (double)outw, sh = (double)rh / (double)outh;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { rwq[i] = 0u; rhq[i] = 0u; }
+#pragma unroll
+            for (int p = 0; p < 7; ++p) {
+                const int pw = min(p, outw - 1), ph = min(p, outh - 1);
+                const int lw = min((int)floor((double)pw * sw), 255), hw = min((int)ceil((double)(pw + 1) * sw), 255);   // far past the map either way:
+                const int lh = min((int)floor((double)ph * sh), 255), hh = min((int)ceil((double)(ph + 1) * sh), 255);   // the clamps below see to it
+                rwq[p >> 1] |= (uint32_t)(lw | (hw << 8)) << (16 * (p & 1));
+                rhq[p >> 1] |= (uint32_t)(lh | (hh << 8)) << (16 * (p & 1));
+            }
+            rwq[3] |= 0xffffu << 16; rhq[3] |= 0xffffu << 16;                // meta: largest bin 255, last hi 255 -> never "fast"; bounds only
+        }
+        const int mbw = (int)((rwq[3] >> 16) & 255u), hlw = (int)(rwq[3] >> 24), mbh = (int)((rhq[3] >> 16) & 255u), hlh = (int)(rhq[3] >> 24);
+        const bool fast = xs >= 0 && ys >= 0 && xs + hlw <= W && ys + hlh <= H && !force_general;
+        const bool t2 = rw > outw && rh > outh;                            // stride > 1 both ways <=> every (unclamped) bin is at least 2 x 2
+        uint32_t ew[8];
+        uint2 eh[8];
+        uint2 meta;
+        if (fast) {
+            const int tw = t2 ? 2 : 1;
+            const uint32_t off = t2 ? (uint32_t)kQuadImgBytes : 0u;
+            const uint32_t xlo = (uint32_t)(xs * 16), xhi = (uint32_t)((xs - tw) * 16);
+            const uint32_t ylo = off + (uint32_t)(ys * (kQuadPitch * 16)), yhi = off + (uint32_t)((ys - tw) * (kQuadPitch * 16));
+#pragma unroll
+            for (int p = 0; p < 7; ++p) {
+                const uint32_t cw = rwq[p >> 1] >> (16 * (p & 1)), rw_ = rhq[p >> 1] >> (16 * (p & 1));
+                const uint32_t lw = cw & 255u, hw = (cw >> 8) & 255u, lh = rw_ & 255u, hh = (rw_ >> 8) & 255u;
+                ew[p] = (lw * 16u + xlo) | ((hw * 16u + xhi) << 16);
+                eh[p] = make_uint2(lh * (uint32_t)(kQuadPitch * 16) + ylo, hh * (uint32_t)(kQuadPitch * 16) + yhi);
+            }
+            meta = make_uint2((uint32_t)((mbw + tw - 1) >> (tw - 1)) | (t2 ? 1u << 16 : 0u), (uint32_t)((mbh + tw - 1) >> (tw - 1)));
+        } else {
+#pragma unroll
+            for (int p = 0; p < 7; ++p) {
+                const uint32_t cw = rwq[p >> 1] >> (16 * (p & 1)), rw_ = rhq[p >> 1] >> (16 * (p & 1));
+                const int ws = min(max((int)(cw & 255u) + xs, 0), W), we = min(max((int)((cw >> 8) & 255u) + xs, 0), W);
+                const int hs = min(max((int)(rw_ & 255u) + ys, 0), H), he = min(max((int)((rw_ >> 8) & 255u) + ys, 0), H);
+                // clamped into the map so that an empty bin still reads valid cells
+                const int c_lo = min(ws, W - 1), c_hi = min(max(we - 1, c_lo), W - 1);
+                const int h0 = min(hs, H - 1), h1 = min(max(he - 1, h0), H - 1);
+                ew[p] = (uint32_t)(c_lo * 16) | ((uint32_t)(c_hi * 16) << 16) | ((we <= ws) ? 1u << 15 : 0u);
+                eh[p] = make_uint2((uint32_t)(h0 * (kQuadPitch * 16)), (uint32_t)(h1 * (kQuadPitch * 16)) | ((he <= hs) ? 1u << 31 : 0u));
+            }
+            meta = make_uint2((uint32_t)min(max(mbw, 1), W) | (1u << 17), (uint32_t)min(max(mbh, 1), H));
+        }
+        ew[7] = ew[6]; eh[7] = eh[6];                                        // the host table repeats the last bin past out - 1; the eighth entry does too
+        uint4 *gw = reinterpret_cast<uint4 *>(lds + kQuadOffGeoW) + sl * 2;
+        uint4 *gh = reinterpret_cast<uint4 *>(lds + kQuadOffGeoH) + sl * 4;
+        gw[0] = make_uint4(ew[0], ew[1], ew[2], ew[3]); gw[1] = make_uint4(ew[4], ew[5], ew[6], ew[7]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gh[i] = make_uint4(eh[2 * i].x, eh[2 * i].y, eh[2 * i + 1].x, eh[2 * i + 1].y);
+        reinterpret_cast<uint2 *>(lds + kQuadOffGeoM)[sl] = meta;
+    };
+
+    // ---- prologue.  Waves 0 .. 12: map rows 3 w .. 3 w + 3 (the fourth is the halo of the tile image) of four channel planes through
+    //      a buffer descriptor -- rows past H, columns past W, channels past C are out-of-range offsets that load 0.  Producers: their
+    //      copy of the edge rows, then their first step.  One barrier.
+    if (tid == 0) { ctr[0] = 0; ctr[1] = 0; }
+    float4 roi_q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pk >= 0) {
+        const uint4 t0 = *reinterpret_cast<const uint4 *>(&etab.row[0][lane][0]), t1 = *reinterpret_cast<const uint4 *>(&etab.row[1][lane][0]);
+        roi_q = roi_of_lane(0);
+        my_tab[lane] = t0;
+        my_tab[kQuadTabExt + lane] = t1;
+        frcnn_wave_sync();         // (the rows are read by other lanes of this wave: DS operations of one wave are in order)
+        build_geometry(0, roi_q, false);
+    } else {
+        const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)C * HW * sizeof(float)));
+        float v[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int h = 3 * wave + i;
+            const uint32_t base = (h < H && lane < W) ? (uint32_t)((c0 * HW + h * W + lane) * 4) : kBufOob;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[i][c] = frcnn_buf_load_f32(xbuf, base + (uint32_t)(c * HW * 4));   // c0 + c >= C: past the end -> 0
+        }
+        float4 *img0 = reinterpret_cast<float4 *>(lds + kQuadOffImg), *img1 = reinterpret_cast<float4 *>(lds + kQuadOffImg + kQuadImgBytes);
+        float t10[4][4];
+        float nan_sum = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                // the right-hand neighbour's value: DPP wave_shl:1 (lane l receives lane l + 1)
+                const float nb = frcnn_wave_shl1_f32(v[i][c]);
+                t10[i][c] = frcnn_max_f32(v[i][c], nb);
+                nan_sum += v[i][c];                                      // NaN iff one of the values is (or +inf and -inf meet: the
+            }                                                            // general path is merely slower)
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int h = 3 * wave + i;
+            if (h < kQuadRows) {
+                img0[h * kQuadPitch + lane] = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
+                img1[h * kQuadPitch + lane] = make_float4(frcnn_max_f32(t10[i][0], t10[i + 1][0]), frcnn_max_f32(t10[i][1], t10[i + 1][1]),
+                                                          frcnn_max_f32(t10[i][2], t10[i + 1][2]), frcnn_max_f32(t10[i][3], t10[i + 1][3]));
+            }
+        }
+        if (__any(nan_sum != nan_sum) && lane == 0) ctr[1] = 1;
+    }
+    // lane -> bin by the hardware's ds_read_b128 lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32): group g holds the bin
+    // rows 2 g and 2 g + 1, eight columns each
+    const int l5 = lane & 31;
+    const bool in_a = (l5 < 4) || (l5 >= 12 && l5 < 16) || (l5 >= 20 && l5 < 28);
+    const int gi = in_a ? (l5 < 4 ? l5 : (l5 < 16 ? l5 - 8 : l5 - 12)) : (l5 < 12 ? l5 - 4 : (l5 < 20 ? l5 - 8 : l5 - 16));
+    const int ph = 2 * ((lane >> 5) * 2 + (in_a ? 0 : 1)) + (gi >> 3), pw = gi & 7;
+    const bool lane_on = ph < outh && pw < outw;
+    const int cg = min(4, C - c0), run = cg * bins;
+    const bool vec_ok = (run & 3) == 0 && ((C * bins) & 3) == 0 && ((c0 * bins) & 3) == 0;
+    const frcnn_buf_t ybuf = frcnn_make_buf(y, (uint32_t)((size_t)R * C * bins * sizeof(float)));
+    float *sv = reinterpret_cast<float *>(lds + kQuadOffStage) + wave * (2 * 4 * kMaxBins);
+    float *sv_lane = sv + min(ph, outh - 1) * outw + min(pw, outw - 1);
+    const uint32_t st_off = (vec_ok && lane < run / 4 && !(dbg & 16)) ? (uint32_t)(lane * 16) : kBufOob;
+    const uint32_t run_bytes = (uint32_t)(C * bins) * 4u, c0_bytes = (uint32_t)(c0 * bins) * 4u;
+    const unsigned char *img = lds + kQuadOffImg;
+    const uint32_t *geo_w_lane = reinterpret_cast<const uint32_t *>(lds + kQuadOffGeoW) + pw;
+    const uint2 *geo_h_lane = reinterpret_cast<const uint2 *>(lds + kQuadOffGeoH) + ph;
+    const uint2 *geo_m = reinterpret_cast<const uint2 *>(lds + kQuadOffGeoM);
+    stamp();
+    __syncthreads();
+    const bool nan_map = __builtin_amdgcn_readfirstlane(ctr[1]) != 0;
+    stamp();
+    if (dbg & 2) return;
+
+    if (nan_map) {                                                       // rare: every RoI in the general form
+        if (pk >= 0) build_geometry(0, roi_q, true);
+        __syncthreads();
+    }
+    for (int base = 0; base < n_slots; base += kQuadGeoSlots) {
+    const int nb = min(n_slots - base, kQuadGeoSlots), npairs = (nb + 1) >> 1;
+    if (base > 0) {
+        __syncthreads();                                                     // everybody is done with the previous batch's entries
+        if (tid == 0) ctr[0] = 0;
+        if (pk >= 0) build_geometry(base, roi_of_lane(base), nan_map);
+        __syncthreads();
+    }
+    // The waves draw PAIRS of RoIs (2 d, 2 d + 1) and work on both at once: a pass is a chain of dependent LDS round trips (geometry ->
+    // cells -> staging slot -> store), and with four waves per SIMD nobody else hides them; two independent chains per wave do.
+    int static_draw = wave;
+    int draw = (dbg & 32) ? static_draw : __builtin_amdgcn_readfirstlane(quad_draw(lds));
+    uint32_t gw_n[2] = {0u, 0u};
+    uint2 gh_n[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)}, gm_n[2] = {make_uint2(0u, 0u), make_uint2(0u, 0u)};
+    auto fetch_geo = [&](int d) {
+        if (d < npairs) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int sl = min(2 * d + s2, nb - 1);                      // an odd tail repeats the last RoI (not stored)
+                gw_n[s2] = geo_w_lane[sl * 8]; gh_n[s2] = geo_h_lane[sl * 8]; gm_n[s2] = geo_m[sl];
+            }
+        }
+    };
+    fetch_geo(draw);
+    for (;;) {
+        if (draw >= npairs) break;
+        const int r0i = g0 + (base + 2 * draw) * rsplit;
+        const bool second = 2 * draw + 1 < nb;
+        int draw_v;
+        if (dbg & 32) { static_draw += kQuadWaves; draw_v = static_draw; }        // ablation: static hand-out
+        else draw_v = quad_draw(lds);                                    // one draw ahead: issued now, looked at after this pass's scan
+        const uint32_t gw0 = gw_n[0], gw1 = gw_n[1];
+        const uint2 gh0 = gh_n[0], gh1 = gh_n[1];
+        uint32_t mw0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gm_n[0].x), mh0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gm_n[0].y);
+        uint32_t mw1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gm_n[1].x), mh1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gm_n[1].y);
+        if (dbg & 4) { mw0 = (mw0 & ~255u) | 1u; mh0 = 1u; mw1 = (mw1 & ~255u) | 1u; mh1 = 1u; }
+        float4 acc0, acc1;
+        if (!((mw0 | mw1) >> 17) && (mw0 & 255u) <= 2u && mh0 <= 2u && (mw1 & 255u) <= 2u && mh1 <= 2u) {
+            // the common case: both RoIs take at most 2 x 2 tiles -- four reads each, eight in flight together (two each where the
+            // RoI has ONE tile row: its first row is its last row)
+            const uint32_t cl0 = gw0 & 0xffffu, ch0 = gw0 >> 16, cl1 = gw1 & 0xffffu, ch1 = gw1 >> 16;
+            const float4 c0v = quad_cell(img, gh0.y + cl0), d0 = quad_cell(img, gh0.y + ch0);
+            const float4 c1v = quad_cell(img, gh1.y + cl1), d1 = quad_cell(img, gh1.y + ch1);
+            acc0 = max4(c0v, d0);
+            acc1 = max4(c1v, d1);
+            if ((mh0 | mh1) > 1u) {
+                const float4 a0 = quad_cell(img, gh0.x + cl0), b0 = quad_cell(img, gh0.x + ch0);
+                const float4 a1 = quad_cell(img, gh1.x + cl1), b1 = quad_cell(img, gh1.x + ch1);
+                acc0 = max4_3(acc0, a0, b0);
+                acc1 = max4_3(acc1, a1, b1);
+            }
+        } else {
+            acc0 = quad_scan_slot(img, gw0, gh0, mw0, mh0);
+            acc1 = quad_scan_slot(img, gw1, gh1, mw1, mh1);
+        }
+        draw = __builtin_amdgcn_readfirstlane(draw_v);
+        fetch_geo(draw);
+        if (dbg & 8) {
+            if (acc0.x + acc0.y + acc0.z + acc0.w + acc1.x + acc1.y + acc1.z + acc1.w == 12345.678f) y[0] = acc0.x;
+            stamp();
+            continue;
+        }
+        if (lane_on) {
+            sv_lane[0] = acc0.x; sv_lane[bins] = acc0.y; sv_lane[2 * bins] = acc0.z; sv_lane[3 * bins] = acc0.w;
+            float *s1 = sv_lane + 4 * kMaxBins;
+            s1[0] = acc1.x; s1[bins] = acc1.y; s1[2 * bins] = acc1.z; s1[3 * bins] = acc1.w;
+        }
+        frcnn_wave_sync();     // the wave's own LDS writes above are read by other lanes below (DS ops of a wave are in order)
+        // (r, c0 .. c0 + cg, :, :) is one contiguous run of cg * bins floats of y
+        const uint32_t dst0 = (uint32_t)r0i * run_bytes + c0_bytes, dst1 = dst0 + (uint32_t)rsplit * run_bytes;
+        if (vec_ok) {
+            const int li = min(lane, 4 * kMaxBins / 4 - 1);
+            const float4 o0 = reinterpret_cast<const float4 *>(sv)[li], o1 = reinterpret_cast<const float4 *>(sv + 4 * kMaxBins)[li];
+            frcnn_buf_store_f32x4_soff<ST>(ybuf, st_off, dst0, o0);
+            if (second) frcnn_buf_store_f32x4_soff<ST>(ybuf, st_off, dst1, o1);
+        } else {
+            for (int i = lane; i < run; i += 64) {
+                y[(size_t)(dst0 / 4) + i] = sv[i];
+                if (second) y[(size_t)(dst1 / 4) + i] = sv[4 * kMaxBins + i];
+            }
+        }
+        frcnn_wave_sync();     // the slots are rewritten by the next pair only after these reads were issued
+        stamp();
+    }
+    }
+    stamp();
+}
+
 // dx[c, argmax] += dy for every (roi, c, bin) with argmax >= 0 (Chainer backward_cpu).  fp32 atomics:
 // the accumulation order differs from the reference's roi-major loop only in rounding.
 __global__ void __launch_bounds__(256)
@@ -768,26 +1159,7 @@ roi_pool_bwd_kernel(const float *__restrict__ dy, const int32_t *__restrict__ ar
 
 static int frcnn_roi_cu_count();
 
-// Launch the cell-major kernel when the map fits its LDS image (W <= 64 cells per row; H <= 38: two workgroups per CU,
-// H <= 76: one).  FRCNN_ROI_KERNEL=planes keeps the plane kernel (A/B measurements).  Returns false when it does not apply.
-template <int OUT16, bool IN16 = false>
-static bool roi_cells_launch(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
-                             float scale, float *y, hipStream_t stream) {
-    const char *sel = getenv("FRCNN_ROI_KERNEL");
-    if (sel && sel[0] == 'p') return false;
-    if (W > kCellPitch || H > 76) return false;
-    if ((size_t)C * H * W * sizeof(float) >= (1ull << 31)) return false;      // the map is read through a 32-bit buffer descriptor
-    const int cgroups = frcnn_cdiv(C, 8);
-    const int waves = H <= 38 ? 16 : 8;
-    const char *mul = getenv("FRCNN_ROI_SPLIT_MUL");                         // tuning hook: workgroups per CU (default 1)
-    const int rounds = mul && atoi(mul) > 0 ? atoi(mul) : 1;
-    int rsplit = frcnn_cdiv(rounds * frcnn_roi_cu_count(), cgroups);         // one resident workgroup per CU
-    const int max_split = frcnn_cdiv(R, waves);                              // at least one RoI per wave
-    if (rsplit > max_split) rsplit = max_split;
-    if (rsplit < 1) rsplit = 1;
-    const char *fix = getenv("FRCNN_ROI_RSPLIT");                             // test hook: RoI groups per channel group
-    if (fix && atoi(fix) > 0) rsplit = atoi(fix);
-    RoiBinTables tables;
+static void roi_fill_tables(RoiBinTables &tables, int outh, int outw) {
     memset(&tables, 0, sizeof(tables));
     for (int t = 0; t < 2; ++t) {
         const int out = t ? outw : outh;
@@ -802,6 +1174,75 @@ static bool roi_cells_launch(const float *x, int C, int H, int W, const float *r
             tables.tabmax[t][ext] = (uint8_t)m;
         }
     }
+}
+
+// RoiEdgeTable for one output shape: bin_range()'s double expressions for every extent below kQuadTabExt
+static void roi_fill_edge_table(RoiEdgeTable &t, int outh, int outw) {
+    memset(&t, 0, sizeof(t));
+    for (int dim = 0; dim < 2; ++dim) {
+        const int out = dim ? outh : outw;
+        for (int e = 0; e < kQuadTabExt; ++e) {
+            const double stride = (double)e / (double)out;
+            int mb = 0, hl = 0;
+            for (int p = 0; p < out; ++p) {
+                const int lo = (int)floor((double)p * stride), hi = (int)ceil((double)(p + 1) * stride);
+                t.row[dim][e][p] = (uint16_t)(lo | (hi << 8));
+                mb = std::max(mb, hi - lo); hl = hi;
+            }
+            for (int p = out; p < 7; ++p) t.row[dim][e][p] = t.row[dim][e][out - 1];   // entries past out - 1 repeat the last bin
+            t.row[dim][e][7] = (uint16_t)(mb | (hl << 8));                   // out <= 7: word 7 is free
+        }
+    }
+}
+
+// Launch the cell-major kernel when the map fits its LDS image (W <= 64 cells per row; H <= 38: two workgroups per CU,
+// H <= 76: one).  FRCNN_ROI_KERNEL=planes keeps the plane kernel (A/B measurements).  Returns false when it does not apply.
+template <int OUT16, bool IN16 = false>
+static bool roi_cells_launch(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
+                             float scale, float *y, hipStream_t stream) {
+    const char *sel = getenv("FRCNN_ROI_KERNEL");
+    if (sel && sel[0] == 'p') return false;
+    if (W > kCellPitch || H > 76) return false;
+    if ((size_t)C * H * W * sizeof(float) >= (1ull << 31)) return false;      // the map is read through a 32-bit buffer descriptor
+    if constexpr (OUT16 == 0 && !IN16) {
+        // round 3: the quad-cell kernel (fp32 in, fp32 out) wherever its 38-row image and its 32-bit output offsets fit
+        if (!(sel && sel[0] == 'c') && H <= 38 && W <= 64 && (size_t)R * C * outh * outw * sizeof(float) < (1ull << 32)) {
+            RoiEdgeTable qk;
+            roi_fill_edge_table(qk, outh, outw);
+            const int cquads = frcnn_cdiv(C, 4);
+            int rsplit = frcnn_cdiv(frcnn_roi_cu_count(), cquads);           // one resident workgroup per CU
+            const int max_split = frcnn_cdiv(R, kQuadWaves);                  // at least one RoI per wave
+            if (rsplit > max_split) rsplit = max_split;
+            if (rsplit < 1) rsplit = 1;
+            const char *fix = getenv("FRCNN_ROI_RSPLIT");                     // test hook: RoI groups per channel group
+            if (fix && atoi(fix) > 0) rsplit = atoi(fix);
+            const char *pad = getenv("FRCNN_ROI_LDS_PAD");                    // tuning hook: extra dynamic LDS (workgroups per CU)
+            const int dyn = pad ? atoi(pad) : 0;
+            const char *st = getenv("FRCNN_ROI_ST");                          // A/B hook: 0 = plain stores, default write-through
+            const dim3 grid(cquads, rsplit), blk(64 * kQuadWaves);
+            int qdbg = 0;
+#ifdef FRCNN_TIMING_ABLATIONS
+            const char *qdbg_s = getenv("FRCNN_ROI_DBG");
+            qdbg = qdbg_s ? atoi(qdbg_s) : 0;
+#endif
+            if (st && atoi(st) == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<0, 0>), grid, blk, dyn, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, qk, qdbg);
+            else if (outh * outw == 49) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<16, 49>), grid, blk, dyn, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, qk, qdbg);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<16, 0>), grid, blk, dyn, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, qk, qdbg);
+            return true;
+        }
+    }
+    const int cgroups = frcnn_cdiv(C, 8);
+    const int waves = H <= 38 ? 16 : 8;
+    const char *mul = getenv("FRCNN_ROI_SPLIT_MUL");                         // tuning hook: workgroups per CU (default 1)
+    const int rounds = mul && atoi(mul) > 0 ? atoi(mul) : 1;
+    int rsplit = frcnn_cdiv(rounds * frcnn_roi_cu_count(), cgroups);         // one resident workgroup per CU
+    const int max_split = frcnn_cdiv(R, waves);                              // at least one RoI per wave
+    if (rsplit > max_split) rsplit = max_split;
+    if (rsplit < 1) rsplit = 1;
+    const char *fix = getenv("FRCNN_ROI_RSPLIT");                             // test hook: RoI groups per channel group
+    if (fix && atoi(fix) > 0) rsplit = atoi(fix);
+    RoiBinTables tables;
+    roi_fill_tables(tables, outh, outw);
     int dbg = 0;
 #ifdef FRCNN_TIMING_ABLATIONS
     const char *dbg_s = getenv("FRCNN_ROI_DBG");

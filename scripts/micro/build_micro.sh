@@ -1,0 +1,11 @@
+#!/bin/bash
+# builds the standalone micro-benchmarks (no torch) into scripts/micro/_bin (git-ignored, travels with gpurun)
+set -e
+cd "$(dirname "$0")/../.."
+mkdir -p scripts/micro/_bin
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/micro/store_micro.hip -o scripts/micro/_bin/store_micro
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip scripts/micro/roi_micro.cpp -I include -L chainer-faster-rcnn_amd -lfrcnn_hip -Wl,-rpath,'$ORIGIN/../../../chainer-faster-rcnn_amd' -o scripts/micro/_bin/roi_micro
+# timing-ablation build of roi_pool.hip alone (FRCNN_ROI_DBG is honoured; WRONG results by design) + the same harness against it
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DFRCNN_TIMING_ABLATIONS -I include -I chainer-faster-rcnn_amd/csrc -shared chainer-faster-rcnn_amd/csrc/roi_pool.hip -o scripts/micro/_bin/libroi_abl.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip scripts/micro/roi_micro.cpp -I include -L scripts/micro/_bin -lroi_abl -Wl,-rpath,'$ORIGIN' -o scripts/micro/_bin/roi_micro_abl
+echo built

@@ -48,3 +48,19 @@ static inline void frcnn_split3_pair(float v0, float v1, uint32_t &h, uint32_t &
     m = frcnn_pack_bf16x2(d0, d1);
     l = frcnn_pack_bf16x2(d0 - __uint_as_float(m << 16), d1 - __uint_as_float(m & 0xffff0000u));
 }
+
+__attribute__((noinline)) static int frcnn_lds_append(int *ctr) {
+    int z = 0;
+    auto e = hipemu::wave_exchange(&z, sizeof(z), HIPEMU_SITE());
+    const int first = __builtin_ctzll(e.present);
+    int old = 0;
+    if (hipemu::G().cur->lane == first) { old = *ctr; *ctr += __builtin_popcountll(e.present); }
+    return __builtin_amdgcn_readfirstlane(old);
+}
+__attribute__((noinline)) static float frcnn_wave_shl1_f32(float v) {
+    auto e = hipemu::wave_exchange(&v, sizeof(v), HIPEMU_SITE());
+    const int s = hipemu::G().cur->lane + 1;
+    float r = 0.0f;
+    if (s < 64 && ((e.present >> s) & 1)) memcpy(&r, e.vals[s], sizeof(r));
+    return r;
+}
