@@ -514,7 +514,22 @@ def main():
                     rt.roi_pool_fwd_chw(feat, rois, 7, 7, 1.0 / 16, out=outs[state["i"] % 10])
                     state["i"] += 1
             iso["roi_pool_us"] = graph_time_us(torch, roi_seq, 8, max(iso_replays // 4, 25))
-            del outs
+            # the training forms (models/faster_rcnn.py:125-126 in rcnn_train mode): forward with argmax_data and backward, 65.1 MB each
+            ams = [rt.mem.empty((int(rois.shape[0]), 512, 7, 7), "i32") for _ in range(10)]
+            dxs = [rt.mem.empty(tuple(int(v) for v in feat.shape), "f32") for _ in range(4)]
+
+            def roi_am_seq():
+                for _ in range(8):
+                    rt.roi_pool_fwd_chw(feat, rois, 7, 7, 1.0 / 16, want_argmax=True, out=outs[state["i"] % 10], out_argmax=ams[state["i"] % 10])
+                    state["i"] += 1
+            iso["roi_pool_argmax_us"] = graph_time_us(torch, roi_am_seq, 8, max(iso_replays // 4, 25))
+
+            def roi_bwd_seq():
+                for _ in range(8):
+                    rt.roi_pool_bwd(outs[state["i"] % 10], ams[state["i"] % 10], 512, int(feat.shape[-2]), int(feat.shape[-1]), out=dxs[state["i"] % 4])
+                    state["i"] += 1
+            iso["roi_pool_bwd_us"] = graph_time_us(torch, roi_bwd_seq, 8, max(iso_replays // 4, 25))
+            del outs, ams, dxs
 
             def prop_seq():
                 for _ in range(8):
@@ -582,6 +597,13 @@ def main():
                               "roi_pool_algorithmic_mb": roi_bytes / 1e6,
                               "roi_pool_gbps": roi_bytes / (roi_us * 1e-6) / 1e9,
                               "roi_pool_frac_of_hbm_peak": roi_bytes / (roi_us * 1e-6) / 1e9 / PEAK_HBM_GBPS}
+            # training forms: map read + y AND argmax_data written (forward), dy and argmax_data read + dx written (backward)
+            train_bytes = (512 * fh * fw + 2 * 300 * 512 * 49) * 4 + 300 * 16
+            for key, tag in (("roi_pool_argmax_us", "roi_pool_fwd_argmax"), ("roi_pool_bwd_us", "roi_pool_bwd")):
+                if key in iso:
+                    res["nms_roi"][tag + "_us"] = iso[key]
+                    res["nms_roi"][tag + "_algorithmic_mb"] = train_bytes / 1e6
+                    res["nms_roi"][tag + "_frac_of_hbm_peak"] = train_bytes / (iso[key] * 1e-6) / 1e9 / PEAK_HBM_GBPS
         dbg = None
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"], dbg = cpu_baseline(params, x_host, args.cpu_samples)

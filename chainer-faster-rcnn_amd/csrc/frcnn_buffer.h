@@ -24,6 +24,12 @@ __device__ __forceinline__ float4 frcnn_buf_load_f32x4(frcnn_buf_t b, uint32_t b
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// 16-byte load at (per-lane offset, range-checked) + (wave-uniform scalar offset, added after the check)
+__device__ __forceinline__ float4 frcnn_buf_load_f32x4_soff(frcnn_buf_t b, uint32_t byte_off, uint32_t soff) {
+    const frcnn_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)byte_off, (int)soff, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 // Write-through (sc1) 16-byte store: the bytes leave this XCD's L2 for memory at once, so another workgroup -- on any
 // XCD -- that acquires AFTER the store has drained (s_waitcnt vmcnt(0)) reads them without the producer running an
 // agent-scope release fence (buffer_wbl2 writes back EVERY dirty line of the XCD's L2: ~3x the cost for tens of KB per

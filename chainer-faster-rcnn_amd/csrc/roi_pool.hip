@@ -799,10 +799,13 @@ constexpr int kQuadOffGeoM = 32;                                         // uint
 constexpr int kQuadOffGeoW = kQuadOffGeoM + kQuadGeoSlots * 8;           // uint32 [slots][8]
 constexpr int kQuadOffGeoH = kQuadOffGeoW + kQuadGeoSlots * 32;          // uint2 [slots][8]
 constexpr int kQuadOffStage = kQuadOffGeoH + kQuadGeoSlots * 64;         // float [waves][2][4 * kMaxBins]
-constexpr int kQuadOffImg = (kQuadOffStage + kQuadWaves * 2 * 4 * kMaxBins * 4 + 15) / 16 * 16;    // float4 [2][rows * pitch]
-constexpr int kQuadOffTab = kQuadOffImg + 2 * kQuadImgBytes;            // uint16 [producers][2][ext][8]: each producer's copy of the edge rows
-constexpr int kQuadLdsBytes = kQuadOffTab + kQuadProducers * 2 * kQuadTabExt * 16;
-static_assert(kQuadOffImg % 16 == 0 && kQuadOffStage % 16 == 0 && kQuadOffTab % 16 == 0, "16-byte LDS accesses");
+constexpr int kQuadStageFloats = 4 * kMaxBins;                          // one RoI's [4][7][7] block
+// (the arg-max form stages values AND indices: twice the slots)
+constexpr int quad_off_img(bool argmax) { return (kQuadOffStage + kQuadWaves * (argmax ? 4 : 2) * kQuadStageFloats * 4 + 15) / 16 * 16; }   // float4 [2][rows * pitch]
+constexpr int quad_off_tab(bool argmax) { return quad_off_img(argmax) + 2 * kQuadImgBytes; }      // uint16 [producers][2][ext][8]: each producer's copy of the edge rows
+constexpr int quad_lds_bytes(bool argmax) { return quad_off_tab(argmax) + kQuadProducers * 2 * kQuadTabExt * 16; }
+static_assert(quad_off_img(false) % 16 == 0 && quad_off_img(true) % 16 == 0 && kQuadOffStage % 16 == 0, "16-byte LDS accesses");
+static_assert(quad_lds_bytes(true) <= 160 * 1024, "LDS");
 
 // Bin edges per extent, built on the HOST with the oracle's double arithmetic -- floor(p * (e / out)), ceil((p + 1) * (e / out)): IEEE
 // double division / multiplication / floor / ceil are correctly rounded, so the host's values are the device's (7 * (29 / 7.) =
@@ -865,12 +868,48 @@ __device__ __forceinline__ float4 quad_scan_slot(const unsigned char *img, uint3
     return acc;
 }
 
+// The training form: maximum AND the position of the FIRST maximum (Chainer's argmax_data: h * W + w, -1 for an empty bin), exactly the
+// oracle's scan -- the bin's first cell seeds both, then strict `>` in row-major order.  Always on the plain cells with saturating
+// rows / columns over the RoI's largest bin shape: a cell read twice cannot displace itself under `>`, a NaN never wins and a NaN first
+// cell stays.  `pos` is tracked as the cell's byte offset in the LDS image and converted at the end.
+__device__ __forceinline__ void quad_scan_slot_argmax(const unsigned char *img, uint32_t gw, uint2 gh, uint32_t mw, uint32_t mh, int W,
+                                                      float4 &val, int4 &idx) {
+    const int nc = (int)(mw & 255u), nr = (int)(mh & 255u);
+    const uint32_t cl = gw & 0x7fffu, ch = (gw >> 16) & 0x7fffu, r0 = gh.x, r1 = gh.y & 0x7fffffffu;
+    const bool empty = ((gw >> 15) & 1u) || (gh.y >> 31);
+    float4 m = quad_cell(img, r0 + cl);
+    uint32_t px = r0 + cl, py = px, pz = px, pw_ = px;
+#pragma unroll 1
+    for (int j = 0; j < nr; ++j) {
+        const uint32_t rr = min(r0 + (uint32_t)j * (kQuadPitch * 16), r1);
+#pragma unroll 1
+        for (int k = 0; k < nc; ++k) {
+            const uint32_t a = rr + min(cl + 16u * k, ch);
+            const float4 v = quad_cell(img, a);
+            if (v.x > m.x) { m.x = v.x; px = a; }
+            if (v.y > m.y) { m.y = v.y; py = a; }
+            if (v.z > m.z) { m.z = v.z; pz = a; }
+            if (v.w > m.w) { m.w = v.w; pw_ = a; }
+        }
+    }
+    auto to_index = [&](uint32_t off) -> int {
+        const uint32_t q = off >> 4, h = (q * 64528u) >> 22;               // q / 65 for q < 2^18 (64528 * 65 = 2^22 + 16)
+        return (int)(q - h * (uint32_t)(kQuadPitch - W));                  // h * W + (q - 65 h)
+    };
+    static_assert(kQuadPitch == 65, "the division constant above");
+    val = empty ? make_float4(0.f, 0.f, 0.f, 0.f) : m;
+    idx = empty ? make_int4(-1, -1, -1, -1) : make_int4(to_index(px), to_index(py), to_index(pz), to_index(pw_));
+}
+
 // BINS: outh * outw as a compile-time constant (49 for the 7 x 7 head: the staging stores get immediate offsets and pair up as
 // ds_write2_b32), or 0 = any shape up to 7 x 7
-template <int ST, int BINS>
+// ARGMAX: the training form -- also writes argmax_data (int32, same shape as y); every RoI takes the plain-cell scan above.
+template <int ST, int BINS, bool ARGMAX = false>
 __global__ void __launch_bounds__(64 * kQuadWaves)
 roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const float *__restrict__ rois, int roi_cols, int R,
-                      int outh, int outw, float scale, float *__restrict__ y, int rsplit, const RoiEdgeTable etab, int dbg_arg) {
+                      int outh, int outw, float scale, float *__restrict__ y, int32_t *__restrict__ argmax, int rsplit, const RoiEdgeTable etab,
+                      int dbg_arg) {
+    constexpr int kQuadOffImg = quad_off_img(ARGMAX), kQuadOffTab = quad_off_tab(ARGMAX), kQuadLdsBytes = quad_lds_bytes(ARGMAX);
 #ifdef FRCNN_TIMING_ABLATIONS                    // tuning builds only (scripts/micro): 2 prologue only, 4 no scan, 8 no staging / output, 16 no stores -- WRONG results
     const int dbg = dbg_arg;
 #else
@@ -940,7 +979,7 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
             rwq[3] |= 0xffffu << 16; rhq[3] |= 0xffffu << 16;                // meta: largest bin 255, last hi 255 -> never "fast"; bounds only
         }
         const int mbw = (int)((rwq[3] >> 16) & 255u), hlw = (int)(rwq[3] >> 24), mbh = (int)((rhq[3] >> 16) & 255u), hlh = (int)(rhq[3] >> 24);
-        const bool fast = xs >= 0 && ys >= 0 && xs + hlw <= W && ys + hlh <= H && !force_general;
+        const bool fast = !ARGMAX && xs >= 0 && ys >= 0 && xs + hlw <= W && ys + hlh <= H && !force_general;
         const bool t2 = rw > outw && rh > outh;                            // stride > 1 both ways <=> every (unclamped) bin is at least 2 x 2
         uint32_t ew[8];
         uint2 eh[8];
@@ -1037,7 +1076,8 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
     const int cg = min(4, C - c0), run = cg * bins;
     const bool vec_ok = (run & 3) == 0 && ((C * bins) & 3) == 0 && ((c0 * bins) & 3) == 0;
     const frcnn_buf_t ybuf = frcnn_make_buf(y, (uint32_t)((size_t)R * C * bins * sizeof(float)));
-    float *sv = reinterpret_cast<float *>(lds + kQuadOffStage) + wave * (2 * 4 * kMaxBins);
+    const frcnn_buf_t abuf = frcnn_make_buf(ARGMAX ? (const void *)argmax : (const void *)y, (uint32_t)((size_t)R * C * bins * sizeof(float)));
+    float *sv = reinterpret_cast<float *>(lds + kQuadOffStage) + wave * ((ARGMAX ? 4 : 2) * kQuadStageFloats);
     float *sv_lane = sv + min(ph, outh - 1) * outw + min(pw, outw - 1);
     const uint32_t st_off = (vec_ok && lane < run / 4 && !(dbg & 16)) ? (uint32_t)(lane * 16) : kBufOob;
     const uint32_t run_bytes = (uint32_t)(C * bins) * 4u, c0_bytes = (uint32_t)(c0 * bins) * 4u;
@@ -1092,7 +1132,11 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
         uint32_t mw1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gm_n[1].x), mh1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)gm_n[1].y);
         if (dbg & 4) { mw0 = (mw0 & ~255u) | 1u; mh0 = 1u; mw1 = (mw1 & ~255u) | 1u; mh1 = 1u; }
         float4 acc0, acc1;
-        if (!((mw0 | mw1) >> 17) && (mw0 & 255u) <= 2u && mh0 <= 2u && (mw1 & 255u) <= 2u && mh1 <= 2u) {
+        int4 ai0 = make_int4(0, 0, 0, 0), ai1 = ai0;
+        if constexpr (ARGMAX) {
+            quad_scan_slot_argmax(img, gw0, gh0, mw0, mh0, W, acc0, ai0);
+            quad_scan_slot_argmax(img, gw1, gh1, mw1, mh1, W, acc1, ai1);
+        } else if (!((mw0 | mw1) >> 17) && (mw0 & 255u) <= 2u && mh0 <= 2u && (mw1 & 255u) <= 2u && mh1 <= 2u) {
             // the common case: both RoIs take at most 2 x 2 tiles -- four reads each, eight in flight together (two each where the
             // RoI has ONE tile row: its first row is its last row)
             const uint32_t cl0 = gw0 & 0xffffu, ch0 = gw0 >> 16, cl1 = gw1 & 0xffffu, ch1 = gw1 >> 16;
@@ -1119,21 +1163,35 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
         }
         if (lane_on) {
             sv_lane[0] = acc0.x; sv_lane[bins] = acc0.y; sv_lane[2 * bins] = acc0.z; sv_lane[3 * bins] = acc0.w;
-            float *s1 = sv_lane + 4 * kMaxBins;
+            float *s1 = sv_lane + kQuadStageFloats;
             s1[0] = acc1.x; s1[bins] = acc1.y; s1[2 * bins] = acc1.z; s1[3 * bins] = acc1.w;
+            if constexpr (ARGMAX) {
+                int *i0 = reinterpret_cast<int *>(sv_lane + 2 * kQuadStageFloats), *i1 = i0 + kQuadStageFloats;
+                i0[0] = ai0.x; i0[bins] = ai0.y; i0[2 * bins] = ai0.z; i0[3 * bins] = ai0.w;
+                i1[0] = ai1.x; i1[bins] = ai1.y; i1[2 * bins] = ai1.z; i1[3 * bins] = ai1.w;
+            }
         }
         frcnn_wave_sync();     // the wave's own LDS writes above are read by other lanes below (DS ops of a wave are in order)
         // (r, c0 .. c0 + cg, :, :) is one contiguous run of cg * bins floats of y
         const uint32_t dst0 = (uint32_t)r0i * run_bytes + c0_bytes, dst1 = dst0 + (uint32_t)rsplit * run_bytes;
         if (vec_ok) {
-            const int li = min(lane, 4 * kMaxBins / 4 - 1);
-            const float4 o0 = reinterpret_cast<const float4 *>(sv)[li], o1 = reinterpret_cast<const float4 *>(sv + 4 * kMaxBins)[li];
+            const int li = min(lane, kQuadStageFloats / 4 - 1);
+            const float4 o0 = reinterpret_cast<const float4 *>(sv)[li], o1 = reinterpret_cast<const float4 *>(sv + kQuadStageFloats)[li];
             frcnn_buf_store_f32x4_soff<ST>(ybuf, st_off, dst0, o0);
             if (second) frcnn_buf_store_f32x4_soff<ST>(ybuf, st_off, dst1, o1);
+            if constexpr (ARGMAX) {
+                const float4 j0 = reinterpret_cast<const float4 *>(sv + 2 * kQuadStageFloats)[li], j1 = reinterpret_cast<const float4 *>(sv + 3 * kQuadStageFloats)[li];
+                frcnn_buf_store_f32x4_soff<ST>(abuf, st_off, dst0, j0);
+                if (second) frcnn_buf_store_f32x4_soff<ST>(abuf, st_off, dst1, j1);
+            }
         } else {
             for (int i = lane; i < run; i += 64) {
                 y[(size_t)(dst0 / 4) + i] = sv[i];
-                if (second) y[(size_t)(dst1 / 4) + i] = sv[4 * kMaxBins + i];
+                if (second) y[(size_t)(dst1 / 4) + i] = sv[kQuadStageFloats + i];
+                if constexpr (ARGMAX) {
+                    argmax[(size_t)(dst0 / 4) + i] = reinterpret_cast<const int *>(sv)[2 * kQuadStageFloats + i];
+                    if (second) argmax[(size_t)(dst1 / 4) + i] = reinterpret_cast<const int *>(sv)[3 * kQuadStageFloats + i];
+                }
             }
         }
         frcnn_wave_sync();     // the slots are rewritten by the next pair only after these reads were issued
@@ -1154,6 +1212,80 @@ roi_pool_bwd_kernel(const float *__restrict__ dy, const int32_t *__restrict__ ar
             const int c = (int)((i / bins) % C);
             atomicAdd(&dx[(size_t)c * HW + a], dy[i]);
         }
+    }
+}
+
+// Backward, plane-resident (round 3): dx[c, argmax] += dy for every (roi, c, bin) with argmax >= 0 (Chainer backward_cpu).  One workgroup
+// owns FOUR channels of dx as planar fp32 accumulators in LDS (38 KB for the 38 x 63 map), streams the dy / argmax runs of all RoIs for
+// those channels (784 contiguous bytes per RoI: 16 bytes per lane, fully coalesced), adds into the LDS cells and writes its four
+// planes out once -- no memset of dx, no global atomics, each dy / argmax byte read once, each dx byte written once (65.1 MB).
+// The summation order over RoIs differs from the reference's loop only in rounding (as with the global atomics before).
+constexpr int kBwdWaves = 16;
+constexpr int kBwdMaxPlane = 38 * 64;      // floats per channel plane the LDS image holds (4 planes: 38.9 KB)
+__global__ void __launch_bounds__(64 * kBwdWaves)
+roi_pool_bwd_planes_kernel(const float *__restrict__ dy, const int32_t *__restrict__ argmax, int R, int C, int HW, int bins,
+                           float *__restrict__ dx, int dbg_arg) {
+#ifdef FRCNN_TIMING_ABLATIONS                    // tuning builds only: 1 plain read-modify-write, 2 integer atomics, 4 no LDS update (WRONG results), 8 ds_add_f32
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#endif
+    __shared__ __attribute__((aligned(16))) float planes[4 * kBwdMaxPlane];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c0 = blockIdx.x * 4;
+    const int run = 4 * bins;                                              // floats per RoI for this workgroup (C % 4 == 0, run % 4 == 0: host)
+    for (int i = tid; i < 4 * HW; i += 64 * kBwdWaves) planes[i] = 0.0f;
+    __syncthreads();
+    // lane l owns the floats 4 l .. 4 l + 3 of a run; their channels are loop-invariant
+    const int n4 = run / 4;
+    int ch[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ch[i] = min((4 * lane + i) / bins, 3) * HW;
+    const frcnn_buf_t dbuf = frcnn_make_buf(dy, (uint32_t)((size_t)R * C * bins * sizeof(float)));
+    const frcnn_buf_t abuf = frcnn_make_buf(argmax, (uint32_t)((size_t)R * C * bins * sizeof(float)));
+    const uint32_t voff = lane < n4 ? (uint32_t)(lane * 16) : kBufOob;
+    const uint32_t roi_bytes = (uint32_t)(C * bins) * 4u, c0_bytes = (uint32_t)(c0 * bins) * 4u;
+    // two RoIs per step: four 16-byte loads in flight per lane before the first atomic
+#pragma unroll 1
+    for (int r = 2 * wave; r < R; r += 2 * kBwdWaves) {
+        const uint32_t s0 = (uint32_t)r * roi_bytes + c0_bytes, s1 = s0 + roi_bytes;
+        const bool two = r + 1 < R;
+        const float4 g0 = frcnn_buf_load_f32x4_soff(dbuf, voff, s0), a0 = frcnn_buf_load_f32x4_soff(abuf, voff, s0);
+        const float4 g1 = frcnn_buf_load_f32x4_soff(dbuf, two ? voff : kBufOob, s1), a1 = frcnn_buf_load_f32x4_soff(abuf, two ? voff : kBufOob, s1);
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const int av[8] = {__float_as_int(a0.x), __float_as_int(a0.y), __float_as_int(a0.z), __float_as_int(a0.w),
+                           __float_as_int(a1.x), __float_as_int(a1.y), __float_as_int(a1.z), __float_as_int(a1.w)};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (lane < n4 && (i < 4 || two) && av[i] >= 0) {
+                float *cell = &planes[ch[i & 3] + av[i]];
+                if (dbg & 1) *cell += gv[i];
+                else if (dbg & 2) atomicAdd(reinterpret_cast<int *>(cell), __float_as_int(gv[i]));
+                else if (dbg & 4) { if (gv[i] == 12345.678f) *cell = 1.f; }
+                else if (dbg & 8) atomicAdd(cell, gv[i]);
+                else {
+                    // fp32 add as a compare-and-swap loop on the cell: the LDS's INTEGER atomics run at full rate, ds_add_f32 does not
+                    // (measured on this kernel: 78 us with ds_add_f32, 30 us this way, 18 us for the loads alone)
+                    int *ic = reinterpret_cast<int *>(cell);
+                    int old = *ic;
+                    for (;;) {
+                        const int want = __float_as_int(__int_as_float(old) + gv[i]);
+                        const int prev = atomicCAS(ic, old, want);
+                        if (prev == old) break;
+                        old = prev;
+                    }
+                }
+            }
+    }
+    __syncthreads();
+    // (c0 .. c0 + 3, :, :) is one contiguous run of 4 HW floats of dx
+    float *dst = dx + (size_t)c0 * HW;
+    if ((HW & 3) == 0) {
+        for (int i = tid; i < HW; i += 64 * kBwdWaves) reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(planes)[i];
+    } else {
+        for (int i = tid; i < 4 * HW; i += 64 * kBwdWaves) dst[i] = planes[i];
     }
 }
 
@@ -1195,6 +1327,39 @@ static void roi_fill_edge_table(RoiEdgeTable &t, int outh, int outw) {
     }
 }
 
+// Launch the quad-cell kernel (fp32 NCHW in, fp32 out; argmax != nullptr: the training form) wherever its 38-row image and its
+// 32-bit output offsets fit.  Returns false when it does not apply.
+static bool roi_quads_launch(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
+                             float scale, float *y, int32_t *argmax, hipStream_t stream) {
+    if (H > kQuadRows || W > 64) return false;
+    if ((size_t)C * H * W * sizeof(float) >= (1ull << 31)) return false;      // the map is read through a 32-bit buffer descriptor
+    if ((size_t)R * C * outh * outw * sizeof(float) >= (1ull << 32)) return false;
+    RoiEdgeTable qk;
+    roi_fill_edge_table(qk, outh, outw);
+    const int cquads = frcnn_cdiv(C, 4);
+    int rsplit = frcnn_cdiv(frcnn_roi_cu_count(), cquads);                   // one resident workgroup per CU
+    const int max_split = frcnn_cdiv(R, 2 * kQuadWaves);                      // at least one pair of RoIs per wave
+    if (rsplit > max_split) rsplit = max_split;
+    if (rsplit < 1) rsplit = 1;
+    const char *fix = getenv("FRCNN_ROI_RSPLIT");                             // test hook: RoI groups per channel group
+    if (fix && atoi(fix) > 0) rsplit = atoi(fix);
+    const char *st = getenv("FRCNN_ROI_ST");                                  // A/B hook: 0 = plain stores, default write-through
+    int qdbg = 0;
+#ifdef FRCNN_TIMING_ABLATIONS
+    const char *qdbg_s = getenv("FRCNN_ROI_DBG");
+    qdbg = qdbg_s ? atoi(qdbg_s) : 0;
+#endif
+    const dim3 grid(cquads, rsplit), blk(64 * kQuadWaves);
+    const bool b49 = outh * outw == 49;
+    if (argmax) {
+        if (b49) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<16, 49, true>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, argmax, rsplit, qk, qdbg);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<16, 0, true>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, argmax, rsplit, qk, qdbg);
+    } else if (st && atoi(st) == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<0, 0, false>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, argmax, rsplit, qk, qdbg);
+    else if (b49) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<16, 49, false>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, argmax, rsplit, qk, qdbg);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<16, 0, false>), grid, blk, 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, argmax, rsplit, qk, qdbg);
+    return true;
+}
+
 // Launch the cell-major kernel when the map fits its LDS image (W <= 64 cells per row; H <= 38: two workgroups per CU,
 // H <= 76: one).  FRCNN_ROI_KERNEL=planes keeps the plane kernel (A/B measurements).  Returns false when it does not apply.
 template <int OUT16, bool IN16 = false>
@@ -1205,31 +1370,7 @@ static bool roi_cells_launch(const float *x, int C, int H, int W, const float *r
     if (W > kCellPitch || H > 76) return false;
     if ((size_t)C * H * W * sizeof(float) >= (1ull << 31)) return false;      // the map is read through a 32-bit buffer descriptor
     if constexpr (OUT16 == 0 && !IN16) {
-        // round 3: the quad-cell kernel (fp32 in, fp32 out) wherever its 38-row image and its 32-bit output offsets fit
-        if (!(sel && sel[0] == 'c') && H <= 38 && W <= 64 && (size_t)R * C * outh * outw * sizeof(float) < (1ull << 32)) {
-            RoiEdgeTable qk;
-            roi_fill_edge_table(qk, outh, outw);
-            const int cquads = frcnn_cdiv(C, 4);
-            int rsplit = frcnn_cdiv(frcnn_roi_cu_count(), cquads);           // one resident workgroup per CU
-            const int max_split = frcnn_cdiv(R, kQuadWaves);                  // at least one RoI per wave
-            if (rsplit > max_split) rsplit = max_split;
-            if (rsplit < 1) rsplit = 1;
-            const char *fix = getenv("FRCNN_ROI_RSPLIT");                     // test hook: RoI groups per channel group
-            if (fix && atoi(fix) > 0) rsplit = atoi(fix);
-            const char *pad = getenv("FRCNN_ROI_LDS_PAD");                    // tuning hook: extra dynamic LDS (workgroups per CU)
-            const int dyn = pad ? atoi(pad) : 0;
-            const char *st = getenv("FRCNN_ROI_ST");                          // A/B hook: 0 = plain stores, default write-through
-            const dim3 grid(cquads, rsplit), blk(64 * kQuadWaves);
-            int qdbg = 0;
-#ifdef FRCNN_TIMING_ABLATIONS
-            const char *qdbg_s = getenv("FRCNN_ROI_DBG");
-            qdbg = qdbg_s ? atoi(qdbg_s) : 0;
-#endif
-            if (st && atoi(st) == 0) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<0, 0>), grid, blk, dyn, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, qk, qdbg);
-            else if (outh * outw == 49) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<16, 49>), grid, blk, dyn, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, qk, qdbg);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<16, 0>), grid, blk, dyn, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, rsplit, qk, qdbg);
-            return true;
-        }
+        if (!(sel && sel[0] == 'c') && roi_quads_launch(x, C, H, W, rois, R, roi_cols, outh, outw, scale, y, nullptr, stream)) return true;
     }
     const int cgroups = frcnn_cdiv(C, 8);
     const int waves = H <= 38 ? 16 : 8;
@@ -1314,6 +1455,11 @@ int frcnn_roi_pool_fwd_chw(const float *x, int C, int H, int W, const float *roi
     if (outh < 1 || outw < 1 || outh > 7 || outw > 7 || (roi_cols != 4 && roi_cols != 5)) return FRCNN_ERR_INVALID;
     if (R == 0) return FRCNN_OK;
     if (!argmax && roi_cells_launch<0>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, y, stream)) return frcnn_launch_status();
+    {
+        const char *sel = getenv("FRCNN_ROI_KERNEL");                         // A/B hook: p = the plane kernel for the arg-max form too
+        if (argmax && !(sel && (sel[0] == 'p' || sel[0] == 'c')) && roi_quads_launch(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, y, argmax, stream))
+            return frcnn_launch_status();
+    }
     const int cg = roi_planes_per_group(C, H, W, outh, outw);
     if (cg == 0) {     // map too large for LDS-resident planes: channel-last gather kernel
         if (!workspace || workspace_bytes < frcnn_roi_pool_workspace_bytes(C, H, W)) return FRCNN_ERR_INVALID;
@@ -1389,6 +1535,21 @@ int frcnn_roi_pool_bwd(const float *dy, const int32_t *argmax, int R, int C, int
                        void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!dy || !argmax || !dx || R < 0 || C < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    {
+        // plane-resident kernel: four channel planes of dx in LDS, no memset, no global atomics (FRCNN_ROI_BWD=atomic: the round-1 kernel)
+        const char *sel = getenv("FRCNN_ROI_BWD");
+        const int bins = outh * outw;
+        if (!(sel && sel[0] == 'a') && R > 0 && (C & 3) == 0 && H * W <= kBwdMaxPlane && bins >= 1 && bins <= 64 &&
+            (size_t)R * C * bins * sizeof(float) < (1ull << 32)) {
+            int bdbg = 0;
+#ifdef FRCNN_TIMING_ABLATIONS
+            const char *bdbg_s = getenv("FRCNN_ROI_BWD_DBG");
+            bdbg = bdbg_s ? atoi(bdbg_s) : 0;
+#endif
+            hipLaunchKernelGGL(roi_pool_bwd_planes_kernel, dim3(C / 4), dim3(64 * kBwdWaves), 0, stream, dy, argmax, R, C, H * W, bins, dx, bdbg);
+            return frcnn_launch_status();
+        }
+    }
     FRCNN_HIP_TRY(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)C * H * W, stream));
     const size_t total = (size_t)R * C * outh * outw;
     if (total == 0) return FRCNN_OK;

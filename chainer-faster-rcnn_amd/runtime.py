@@ -200,13 +200,13 @@ class Runtime(object):
                                         m.ptr(am), m.ptr(ws), ws.shape[0], m.stream()), "frcnn_roi_pool_fwd")
         return (y, am) if want_argmax else y
 
-    def roi_pool_fwd_chw(self, x, rois, outh, outw, scale, want_argmax=False, out=None):
+    def roi_pool_fwd_chw(self, x, rois, outh, outw, scale, want_argmax=False, out=None, out_argmax=None):
         """x (.., C, H, W) NCHW; rois (R,5) [batch,x1,y1,x2,y2] or (R,4) [x1,y1,x2,y2] (ProposalLayer's output)."""
         m, L = self.mem, self.lib
         C, H, W = [int(v) for v in x.shape[-3:]]
         R = int(rois.shape[0])
         y = out if out is not None else m.empty((R, C, outh, outw), "f32")
-        am = m.empty((R, C, outh, outw), "i32") if want_argmax else None
+        am = (out_argmax if out_argmax is not None else m.empty((R, C, outh, outw), "i32")) if want_argmax else None
         ws = self.workspace("roi_pool", L.frcnn_roi_pool_workspace_bytes(C, H, W))
         _lib.check(L.frcnn_roi_pool_fwd_chw(m.ptr(x), C, H, W, m.ptr(rois), R, int(rois.shape[1]), outh, outw, float(scale),
                                             m.ptr(y), m.ptr(am), m.ptr(ws), ws.shape[0], m.stream()), "frcnn_roi_pool_fwd_chw")
@@ -259,10 +259,10 @@ class Runtime(object):
                                             float(scale), m.ptr(y), m.ptr(am), m.stream()), "frcnn_roi_pool_fwd_hwc")
         return (y, am) if want_argmax else y
 
-    def roi_pool_bwd(self, dy, argmax, C, H, W):
+    def roi_pool_bwd(self, dy, argmax, C, H, W, out=None):
         m, L = self.mem, self.lib
         R, _, outh, outw = [int(v) for v in dy.shape]
-        dx = m.empty((1, C, H, W), "f32")
+        dx = out if out is not None else m.empty((1, C, H, W), "f32")
         _lib.check(L.frcnn_roi_pool_bwd(m.ptr(dy), m.ptr(argmax), R, C, H, W, outh, outw, m.ptr(dx), m.stream()),
                    "frcnn_roi_pool_bwd")
         return dx

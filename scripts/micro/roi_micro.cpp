@@ -57,6 +57,56 @@ int main(int argc, char **argv) {
     // clock ramp
     for (int i = 0; i < 3000; ++i) frcnn_roi_pool_fwd_chw(dx, C, H, W, drois, R, 4, 7, 7, 1.f / 16, ys[i % 10], nullptr, nullptr, 0, s);
     CK(hipStreamSynchronize(s));
+    // the training forms: forward with arg-max (65.1 MB algorithmic) and backward (65.1 MB), same graph-of-10 timing
+    {
+        int32_t *am[10]; float *dxs[10];
+        for (auto &q : am) CK(hipMalloc(&q, ybytes));
+        for (auto &q : dxs) CK(hipMalloc(&q, feat.size() * 4));
+        int32_t *amref; CK(hipMalloc(&amref, ybytes));
+        if (frcnn_roi_pool_fwd_hwc(dxt, C, H, W, drois, R, 4, 7, 7, 1.f / 16, yref, amref, s) != 0) { printf("reference launch failed\n"); return 1; }
+        std::vector<int32_t> ham((size_t)R * C * 49), hamref((size_t)R * C * 49);
+        CK(hipStreamSynchronize(s));
+        CK(hipMemcpy(hamref.data(), amref, ybytes, hipMemcpyDeviceToHost));
+        const int burst = getenv("ROI_MICRO_BURST") ? atoi(getenv("ROI_MICRO_BURST")) : 1;
+        for (const char *which : {"fwd+argmax", "fwd+argmax FRCNN_ROI_KERNEL=planes", "bwd", "bwd FRCNN_ROI_BWD=atomic", "bwd dbg1 plain rmw", "bwd dbg2 integer adds", "bwd dbg4 no update", "bwd dbg8 cas loop"}) {
+            if (strstr(which, "dbg8")) setenv("FRCNN_ROI_BWD_DBG", "8", 1);
+            if (strstr(which, "dbg1")) setenv("FRCNN_ROI_BWD_DBG", "1", 1);
+            if (strstr(which, "dbg2")) setenv("FRCNN_ROI_BWD_DBG", "2", 1);
+            if (strstr(which, "dbg4")) setenv("FRCNN_ROI_BWD_DBG", "4", 1);
+            const bool is_bwd = which[0] == 'b';
+            if (strstr(which, "planes")) setenv("FRCNN_ROI_KERNEL", "planes", 1);
+            if (strstr(which, "atomic")) setenv("FRCNN_ROI_BWD", "atomic", 1);
+            hipGraph_t g; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+            for (int i = 0; i < 10; ++i) {
+                const int st = is_bwd ? frcnn_roi_pool_bwd(ys[i], am[i], R, C, H, W, 7, 7, dxs[i], s)
+                                      : frcnn_roi_pool_fwd_chw(dx, C, H, W, drois, R, 4, 7, 7, 1.f / 16, ys[i], am[i], nullptr, 0, s);
+                if (st != 0) { printf("launch failed\n"); return 1; }
+            }
+            CK(hipStreamEndCapture(s, &g));
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            for (int i = 0; i < 5; ++i) CK(hipGraphLaunch(ge, s));
+            CK(hipStreamSynchronize(s));
+            std::vector<float> us;
+            for (int r = 0; r < 40; ++r) {
+                CK(hipEventRecord(e0, s));
+                for (int b = 0; b < burst; ++b) CK(hipGraphLaunch(ge, s));
+                CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); us.push_back(ms * 100.f / burst);
+            }
+            std::sort(us.begin(), us.end());
+            const char *verdict = "";
+            if (!is_bwd) {
+                CK(hipMemcpy(hy.data(), ys[3], ybytes, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(ham.data(), am[3], ybytes, hipMemcpyDeviceToHost));
+                verdict = (memcmp(hy.data(), href.data(), ybytes) == 0 && memcmp(ham.data(), hamref.data(), ybytes) == 0) ? "bit-exact (values and indices)" : "MISMATCH";
+            }
+            printf("%-40s best %6.2f us  median %6.2f us  (%.3f of 8 TB/s)  %s\n", which, us[0], us[us.size() / 2], 65.1e6 / (us[us.size() / 2] * 1e-6) / 8e12, verdict);
+            unsetenv("FRCNN_ROI_KERNEL"); unsetenv("FRCNN_ROI_BWD"); unsetenv("FRCNN_ROI_BWD_DBG");
+            CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+        }
+    }
     std::vector<std::string> settings;
     for (int i = 1; i < argc; ++i) settings.push_back(argv[i]);
     if (settings.empty()) settings.push_back("DEFAULT=1");

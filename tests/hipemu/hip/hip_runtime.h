@@ -48,6 +48,7 @@ static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 static inline int2 make_int2(int a, int b) { return int2{a, b}; }
 static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
+static inline int4 make_int4(int a, int b, int c, int d) { return int4{a, b, c, d}; }
 
 typedef struct ihipStream_t *hipStream_t;
 typedef int hipError_t;

@@ -14,6 +14,11 @@ static inline float frcnn_buf_load_f32(frcnn_buf_t b, uint32_t off) {
 static inline float4 frcnn_buf_load_f32x4(frcnn_buf_t b, uint32_t off) {
     return make_float4(frcnn_buf_load_f32(b, off), frcnn_buf_load_f32(b, off + 4), frcnn_buf_load_f32(b, off + 8), frcnn_buf_load_f32(b, off + 12));
 }
+static inline float4 frcnn_buf_load_f32x4_soff(frcnn_buf_t b, uint32_t off, uint32_t soff) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((uint64_t)off + 16 <= b.bytes) memcpy(&v, b.base + off + soff, 16);
+    return v;
+}
 static inline void frcnn_buf_store_f32x4_wt(frcnn_buf_t b, uint32_t off, float4 v) {
     if ((uint64_t)off + 16 <= b.bytes) memcpy(const_cast<char *>(b.base) + off, &v, 16);
 }
