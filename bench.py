@@ -280,6 +280,36 @@ def split_variant(args, torch, rt, params, x, dbg, flops_total):
     return out
 
 
+def emit_json_line(obj):
+    """The contract's ONE JSON line, as the LAST thing on stdout: RCCL writes a version banner through C stdio when its first
+    communicator comes up, which a buffered stdout flushes at exit -- after the line.  So: print, flush, then point file descriptor 1
+    at stderr for whatever the C runtime still holds."""
+    print(json.dumps(obj))
+    sys.stdout.flush()
+    try:
+        os.dup2(2, 1)
+    except OSError:
+        pass
+
+
+def gather_rank_times(torch, dist, dt, world):
+    """MAX over ranks of the timed interval (the contract's value) and every rank's own interval (rank 0 reports the spread)."""
+    if dist is None or world == 1:
+        return dt, [dt]
+    t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if dist.get_backend() == "gloo":
+        t = t.cpu()
+    ts = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(ts, t)
+    per = [float(v.item()) for v in ts]
+    return max(per), per
+
+
+def per_rank_block(per_rank, steps):
+    ms = [v / steps * 1e3 for v in per_rank]
+    return {"ms_per_step": [round(v, 4) for v in ms], "min_ms": round(min(ms), 4), "max_ms": round(max(ms), 4), "spread_ms": round(max(ms) - min(ms), 4)}
+
+
 def train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note):
     """BASELINE.json configs[4]: train_rpn.py's step -- forward, ProposalLayer (train top-N, discarded, as the reference runs it),
     anchor targets, losses, backward, the all-reduce of the flat gradient buffer (RCCL), fused MomentumSGD+WD -- one synthetic
@@ -288,7 +318,7 @@ def train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_not
     model.rpn_train = True
     # --dtype f32s in train mode: forward and input-gradient convolutions as bf16x6 split products (weight gradients on the fp32 kernel)
     conv_math = "split" if args.dtype == "f32s" else "mfma"
-    tr = RPNTrainer(model, comm=TorchComm() if dist is not None else None, run_proposal_layer=not args.no_train_proposals, conv_math=conv_math)
+    tr = RPNTrainer(model, comm=TorchComm(force_single_rank=args.dist_world1) if dist is not None else None, run_proposal_layer=not args.no_train_proposals, conv_math=conv_math)
     rs = np.random.RandomState(rank)
     G = 4
     w, h = rs.uniform(32, 400, G), rs.uniform(32, 400, G)
@@ -311,6 +341,8 @@ def train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_not
     torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = tr.step(x, info, gt_dev)
+    if getattr(getattr(tr, "comm", None), "trace", None) is not None:
+        tr.comm.trace.clear()                                       # host-side comm milliseconds of the timed steps only
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -335,14 +367,11 @@ def train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_not
             tr.step(x, info, gt_dev)
         barrier()
         other_ms = (time.perf_counter() - t1) / args.steps * 1e3
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, per_rank = gather_rank_times(torch, dist, dt, world)
     if rank == 0:
         st = {k: float(np.mean([a.elapsed_time(b) for a, b in zip(ev[p], ev[k])])) for p, k in
               (("start", "fwd_bwd"), ("fwd_bwd", "all_reduce"), ("all_reduce", "update"))}
-        print(json.dumps({"metric": "images/sec RPN training step VGG16 600x1000", "value": world * args.steps / dt, "unit": "img/s",
+        emit_json_line({"metric": "images/sec RPN training step VGG16 600x1000", "value": world * args.steps / dt, "unit": "img/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32s" if conv_math == "split" else "f32", "data": "synthetic",
                           "config": {"workload": "train_rpn.py end-to-end RPN training step, 1 image per GPU, all-reduce of the flat fp32 gradient "
@@ -352,8 +381,14 @@ def train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_not
                                      "conv_math": conv_math,
                                      "proposal_layer_in_step": (not args.no_train_proposals),
                                      "grad_buffer_mb": tr.n_flat * 4 / 1e6, "global_batch": world, "ranks_share_gpus": shared_note},
-                          "ms_per_step_without_proposal_layer": other_ms,
-                          "stages_ms": st, "losses": tr.losses_host(out)}))
+                          "ms_per_step_without_proposal_layer": other_ms, "ramp_seconds": args.ramp_seconds,
+                          "per_rank": per_rank_block(per_rank, args.steps),
+                          "dist": {"backend": (dist.get_backend() if dist is not None else None), "world_size": world,
+                                   "single_rank_process_group": bool(args.dist_world1 and world == 1),
+                                   "comm_host_ms_per_step": ({k: round(v[1] / max(args.steps, 1), 4) for k, v in tr.comm.trace.items()}
+                                                             if getattr(getattr(tr, "comm", None), "trace", None) else None)},
+                          "cpu_baseline": None if world == 1 else "not run: ranks > 1 (the N = 1 line carries it)",
+                          "stages_ms": st, "losses": tr.losses_host(out)})
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -378,6 +413,8 @@ def main():
                          "10 % of wall clock to host jitter on some boxes; off = eager launches)")
     ap.add_argument("--dtype", choices=["f32", "f32s", "bf16"], default="f32",
                     help="f32 = BASELINE.json configs[1] (the contract line); bf16 = configs[2]: bf16 convolutions, fp32 RoI / head")
+    ap.add_argument("--dist-world1", action="store_true",
+                    help="with one rank: still create the process group (nccl = RCCL) and run every collective of the N > 1 path through it")
     ap.add_argument("--mode", choices=["infer", "train"], default="infer",
                     help="infer = BASELINE.json configs[1] (the contract line); train = configs[4], the RPN training step")
     args = ap.parse_args()
@@ -390,6 +427,8 @@ def main():
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank != 0:
+        os.dup2(2, 1)                                              # only rank 0 owns stdout (the launcher merges the ranks' streams)
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # one rank per GPU.  Fewer GPUs than ranks (a 1-GPU box): the ranks share GPUs and talk over gloo -- RCCL refuses two ranks on one
@@ -404,9 +443,16 @@ def main():
         local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.dist_world1:
+        # --dist-world1: a process group of ONE rank -- RCCL initialisation, the bucketed async all-reduces on the collective stream and
+        # their stream waits all really execute on the one GPU a development box has (no peer: the sums are identities)
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 2000))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -538,10 +584,7 @@ def main():
         except Exception as e:
             print("isolated RoI / proposal graphs failed (%s)" % (e,), file=sys.stderr)
             torch.cuda.synchronize()
-    if dist is not None:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, per_rank = gather_rank_times(torch, dist, dt, world)
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -557,7 +600,11 @@ def main():
                                       ("VGG16 inference, data-parallel 1 img/GPU, bf16 convs + bf16 FC head (fp32 accumulate) / fp32 proposals, "
                                        "RoI pooling, decode (BASELINE.json configs[2])"),
                           "image": "1x3x600x1000", "global_batch": world, "launch": "hipGraph replay" if use_graph else "eager", "parallelism": "dp%d (images sharded, no collective)" % world,
-                          "n_rois_last_step": n_rois, "ranks_share_gpus": shared_note}}
+                          "n_rois_last_step": n_rois, "ranks_share_gpus": shared_note},
+               "ramp_seconds": args.ramp_seconds,
+               "per_rank": per_rank_block(per_rank, args.steps)}
+        if world > 1:
+            res["cpu_baseline"] = "not run: ranks > 1 (the N = 1 line carries it)"
         if timer:
             avg = timer.averages_ms()
             flops, (fh, fw) = conv_flops(LAYERS, IM_H, IM_W)
@@ -623,7 +670,7 @@ def main():
             except Exception as e:
                 res["f32_split_products"] = {"error": repr(e)}
                 torch.cuda.synchronize()
-        print(json.dumps(res))
+        emit_json_line(res)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -178,7 +178,7 @@ class _BucketedAllReduce(_ParamArena):
 
     def _grads_ready(self, name):
         k = self._closing.get(name)
-        if k is None or self.comm is None or self.comm.world_size <= 1:
+        if k is None or self.comm is None or not getattr(self.comm, "active", self.comm.world_size > 1):
             return
         _, start, end = self.buckets[k]
         self._works.append(self.comm.all_reduce_sum_async(self.G[start:end]))
@@ -191,7 +191,7 @@ class _BucketedAllReduce(_ParamArena):
     def all_reduce(self):
         """Sum the gradient buffer over the replicas (ParallelUpdater: grads are added, not averaged).  The buckets were launched
         during the backward pass (_grads_ready); this waits for them -- the update must see every sum."""
-        if self.comm is None or self.comm.world_size <= 1:
+        if self.comm is None or not getattr(self.comm, "active", self.comm.world_size > 1):
             return
         complete = len(self._works) == len(self.buckets)
         self._drain()
@@ -590,24 +590,83 @@ class RCNNTrainer(_BucketedAllReduce):
 
 
 class TorchComm(object):
-    """torch.distributed as the collective layer: backend "nccl" is RCCL on ROCm (xGMI), "gloo" on CPU."""
+    """torch.distributed as the collective layer: backend "nccl" is RCCL on ROCm (xGMI), "gloo" on CPU.
 
-    def __init__(self):
+    gloo with DEVICE tensors (ranks sharing one GPU: the functional smoke of the N > 1 path on a 1-GPU box) is staged by hand
+    through pinned host memory: the device -> host copy of a bucket rides on a copy stream behind the kernels that fill it, the
+    reduction itself runs on host tensors when the trainer waits, the sum goes back with one async copy.  (Handing gloo the device
+    tensor makes every call synchronise the whole device and poll: 2 s per step for three buckets, profiles/r02_bench_2rank_gloo_train.json.)
+    FRCNN_COMM_TRACE=1 collects host milliseconds per call kind in `self.trace`."""
+
+    def __init__(self, force_single_rank=False):
+        import os
+        import time
         import torch
         import torch.distributed as dist
-        self.torch, self.dist = torch, dist
+        self.torch, self.dist, self._time = torch, dist, time
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        # one rank normally skips the exchange; force_single_rank runs it anyway (bench.py --dist-world1, the RCCL smoke test)
+        self.active = dist.is_initialized() and (self.world_size > 1 or force_single_rank)
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.backend = dist.get_backend() if dist.is_initialized() else None
+        self._pinned, self._copy_stream = None, None
+        self.trace = {} if os.environ.get("FRCNN_COMM_TRACE") == "1" else None
+
+    def _note(self, kind, t0):
+        if self.trace is not None:
+            e = self.trace.setdefault(kind, [0, 0.0])
+            e[0] += 1
+            e[1] += (self._time.perf_counter() - t0) * 1e3
+
+    def _staged(self, t):
+        return self.backend == "gloo" and t.is_cuda
+
+    def _stage_out(self, t):
+        """Device slice -> pinned host slice on the copy stream, ordered behind everything already enqueued on the current stream."""
+        torch = self.torch
+        n = t.numel()
+        if self._pinned is None:
+            self._pinned = {}
+        key = (t.data_ptr(), n)                                    # a trainer's buckets are fixed slices of its gradient buffer
+        host = self._pinned.get(key)
+        if host is None:
+            host = self._pinned[key] = torch.empty(n, dtype=t.dtype).pin_memory()
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=t.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(t.device))
+        done = torch.cuda.Event()
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(ready)
+            host.copy_(t.reshape(-1), non_blocking=True)
+            done.record(self._copy_stream)
+        return ("staged", t, host, done)
 
     def all_reduce_sum(self, buf):
+        t0 = self._time.perf_counter()
         t = buf if isinstance(buf, self.torch.Tensor) else self.torch.from_numpy(buf)      # NumPy buffers are reduced in place
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        if self._staged(t):
+            self.wait(self._stage_out(t))
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        self._note("all_reduce_sum", t0)
 
     def all_reduce_sum_async(self, buf):
         """Launch the all-reduce of a (contiguous) slice now and return a handle: with RCCL it is enqueued behind the kernels
         already on the current stream and runs on the collective's stream, under whatever the caller launches next."""
+        t0 = self._time.perf_counter()
         t = buf if isinstance(buf, self.torch.Tensor) else self.torch.from_numpy(buf)
-        return self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=True)
+        w = self._stage_out(t) if self._staged(t) else self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, async_op=True)
+        self._note("launch", t0)
+        return w
 
     def wait(self, work):
-        work.wait()                                # RCCL: the current stream waits for the collective (no host block); gloo: blocks
+        t0 = self._time.perf_counter()
+        if isinstance(work, tuple) and work[0] == "staged":
+            _, t, host, done = work
+            done.synchronize()                                     # the bucket is on the host
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM)  # gloo, host tensors: blocks this thread only
+            t.reshape(-1).copy_(host, non_blocking=True)           # back on the current stream: later kernels see the sum
+        else:
+            work.wait()                                # RCCL: the current stream waits for the collective (no host block); gloo: blocks
+        self._note("wait", t0)

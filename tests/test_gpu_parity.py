@@ -222,6 +222,48 @@ def test_rpn_train_step_small(rt):
     T.check_small_step(rt)
 
 
+def test_rccl_single_rank_training_step(rt):
+    """RCCL really executes on the one GPU a test box has: a process group of ONE rank ("nccl" = RCCL on ROCm), the trainer's three
+    bucketed async all-reduces on the collective's stream and their stream waits (TorchComm(force_single_rank=True)) -- and the step
+    equals the same step without a communicator bit for bit (a one-rank sum is the identity).  train_rpn.py:162-174."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import train_cases as T
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.train import RPNTrainer, TorchComm
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(29500 + os.getpid() % 2000)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        assert dist.get_backend() == "nccl"
+        params = T.small_params()
+        rs = np.random.RandomState(3)
+        x = rs.randn(1, 3, 40, 56).astype(np.float32)
+        gt = P.gt_case(rs, 2, 40, 56)
+        gt[0, :, 2] = np.minimum(gt[0, :, 0] + 20, 55); gt[0, :, 3] = np.minimum(gt[0, :, 1] + 20, 39)
+        info = np.array([[40, 56]], dtype=np.int32)
+        got = []
+        for comm in (TorchComm(force_single_rank=True), None):
+            tr = RPNTrainer(T.build_small(rt, params), comm=comm)
+            for step in range(2):
+                np.random.seed(11 + step)
+                tr.step(Variable(x), Variable(info), Variable(gt))
+            if comm is not None:
+                assert comm.active and len(tr.buckets) == 3
+            got.append(rt.mem.to_numpy(tr.W).copy())
+        assert np.array_equal(got[0], got[1])
+        # a plain blocking all-reduce of a device buffer through the same communicator
+        buf = rt.mem.from_numpy(np.arange(1000, dtype=np.float32))
+        TorchComm(force_single_rank=True).all_reduce_sum(buf)
+        assert np.array_equal(rt.mem.to_numpy(buf), np.arange(1000, dtype=np.float32))
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_rpn_train_step_vgg16(rt):
     import train_cases as T
     losses, worst, flipped = T.check_vgg_step(rt)
