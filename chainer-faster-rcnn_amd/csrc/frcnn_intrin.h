@@ -64,7 +64,10 @@ __device__ __forceinline__ void frcnn_pin(float &v) { asm volatile("" : "+v"(v))
 __device__ __forceinline__ uint32_t frcnn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 
 // (v0, v1) -> the three packed bf16 pairs (h, m, l) with h + m + l == v exactly (round to nearest even at every step; the
-// differences are exact in fp32): the "split tensors" of conv_f32s.hip
+// differences are exact in fp32): the "split tensors" of conv_f32s.hip.  PRECONDITION: |v| finite and below the largest bf16
+// (3.39e38): for +-Inf, or a value whose bf16 rounding overflows, h is Inf and the lower terms are NaN (Inf - Inf), i.e. an overflowed
+// activation turns the whole six-product sum into NaN where the fp32 MFMA path would carry Inf.  Both mean "this step has
+// diverged"; the split path does not pay two extra VALU instructions per pair in its epilogues to tell them apart.
 __device__ __forceinline__ void frcnn_split3_pair(float v0, float v1, uint32_t &h, uint32_t &m, uint32_t &l) {
     h = frcnn_pack_bf16x2(v0, v1);
     const float d0 = v0 - __uint_as_float(h << 16), d1 = v1 - __uint_as_float(h & 0xffff0000u);

@@ -1366,7 +1366,7 @@ template <int OUT16, bool IN16 = false>
 static bool roi_cells_launch(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
                              float scale, float *y, hipStream_t stream) {
     const char *sel = getenv("FRCNN_ROI_KERNEL");
-    if (sel && sel[0] == 'p') return false;
+    if (sel && sel[0] == 'p' && OUT16 != 2 && !IN16) return false;           // A/B hook (the split-tensor and blocked-map forms have no plane kernel: they ignore it)
     if (W > kCellPitch || H > 76) return false;
     if ((size_t)C * H * W * sizeof(float) >= (1ull << 31)) return false;      // the map is read through a 32-bit buffer descriptor
     if constexpr (OUT16 == 0 && !IN16) {

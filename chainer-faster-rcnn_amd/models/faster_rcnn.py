@@ -134,12 +134,22 @@ class FasterRCNN(object):
         self._head_dirty = True
         self._derived_dirty = True
         if trainer is not None:
+            # EVERY trainer that has updated this model holds live packed weights for its own parameter set (after an rpn -> rcnn
+            # alternation the RPNTrainer still owns rpn_conv_3x3 and the RPN heads, the RCNNTrainer the trunk and the FC head):
+            # remember them all, most recent last, so that later syncs win where two trainers share the trunk
+            trs = [t for t in getattr(self, "_trainers", []) if t is not trainer]
+            trs.append(trainer)
+            self._trainers = trs
             self._last_trainer = trainer
 
+    def sync_trainers(self):
+        """Packed training weights of every trainer that has updated the model -> (co,ci,3,3) / (out,in) arrays on the links,
+        oldest first (the most recent trainer's view of shared parameters wins: they share one arena, so it is the same view)."""
+        for tr in getattr(self, "_trainers", []):
+            tr.sync_params()
+
     def _refresh_derived(self):
-        tr = getattr(self, "_last_trainer", None)
-        if tr is not None:
-            tr.sync_params()                                 # packed training weights -> (co,ci,3,3) / (out,in) arrays on the links
+        self.sync_trainers()                                 # packed training weights -> (co,ci,3,3) / (out,in) arrays on the links
         if self.conv_dtype in ("bf16", "f32s"):
             for link in getattr(self.trunk, "links", {}).values():
                 link.refresh_bf16()
@@ -195,7 +205,7 @@ class FasterRCNN(object):
             rois, probs, n_out = self.RPN.proposal_layer.forward_device(prob, bbox, im_h, im_w)
         mark("proposals")
         pool5_split = None
-        if self.head_dtype == "f32s" and not keep and H <= 76 and W <= 64:
+        if self.head_dtype == "f32s" and not keep and H <= 76 and W <= 64 and feat is not None:
             pool5 = pool5_split = rt.roi_pool_fwd_chw_f32s(feat, rois, 7, 7, self._spatial_scale)   # fp32 maxima, stored as their three bf16 terms
             pool5_bits = None
         elif self.head_dtype == "bf16" and not keep:

@@ -82,7 +82,7 @@ class TorchDeviceMemory(object):
         if getattr(self, "_side", None) is not None:
             self.torch.cuda.current_stream(self.device).wait_stream(self._side)
 
-    def early_stream(self):
+    def early_stream(self, *after):
         """Context manager: a stream that does NOT wait for the current one -- for work that depends on nothing already enqueued (the
         trainers' AnchorTargetLayer: ground truth in, labels out, with a host round trip in the middle) so that its host part overlaps
         whatever the GPU is still executing.  join_early_stream(*outputs) makes the current stream wait for it and marks the
@@ -90,6 +90,12 @@ class TorchDeviceMemory(object):
         torch = self.torch
         if getattr(self, "_early", None) is None:
             self._early = torch.cuda.Stream(device=self.device)
+        for a in after:
+            # a DEVICE input produced on the current stream (ground truth scaled / augmented on the GPU): the early stream waits for
+            # what is enqueued there now and the allocator keeps the array's memory until the early stream is done with it
+            if hasattr(a, "record_stream"):
+                self._early.wait_stream(torch.cuda.current_stream(self.device))
+                a.record_stream(self._early)
         return torch.cuda.stream(self._early)
 
     def join_early_stream(self, *outputs):

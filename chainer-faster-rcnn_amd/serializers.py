@@ -34,6 +34,8 @@ def namedparams(model):
 
 def save_npz(path, model, trainer=None):
     """Write the model's parameters; pass the RPNTrainer after training so the packed weights are synced back first."""
+    if hasattr(model, "sync_trainers"):
+        model.sync_trainers()          # every trainer that has updated the model (an rpn -> rcnn alternation leaves two)
     if trainer is not None:
         trainer.sync_params()
     rt = model.rt
@@ -52,6 +54,7 @@ def load_npz(path, model):
     # everything derived from the parameters (the stacked inference head above all: forward_device() would otherwise keep the OLD
     # cls_score / bbox_pred rows next to the new trunk) is rebuilt now; links adopted by a trainer were written through in place
     model._last_trainer = None
+    model._trainers = []
     if hasattr(model, "_stack_head") and all(getattr(model, n).W is not None for n in ("cls_score", "bbox_pred")):
         model._stack_head()
     return model
@@ -64,6 +67,8 @@ TRAINER_OPT = "updater/optimizer:main/"
 def save_trainer_npz(path, trainer):
     """Resumable snapshot of a training run (train_rpn.py:101-105): parameters + momentum velocities + iteration count."""
     model, rt = trainer.model, trainer.rt
+    if hasattr(model, "sync_trainers"):
+        model.sync_trainers()          # parameters another trainer of the same model owns (the RPN after an rpn -> rcnn alternation)
     trainer.sync_params()
     d = {TRAINER_MODEL + k: rt.mem.to_numpy(rt.mem.contiguous(v)) for k, v in namedparams(model)}
     for k, v in trainer.flat_to_chainer_layout(trainer.V).items():

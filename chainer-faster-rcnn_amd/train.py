@@ -278,8 +278,8 @@ class RPNTrainer(_BucketedAllReduce):
         for l in self.layers:
             if l == "pool":
                 H, W = (H + 1) // 2, (W + 1) // 2
-        with rt.mem.early_stream():                                  # its own stream: it must not wait for the previous step's backward
-            labels, targets, inds, n_in, _ = self.atl.forward_device(H, W, gt_boxes, im_h, im_w)
+        with rt.mem.early_stream(unwrap(gt_boxes)):                   # its own stream: it must not wait for the previous step's backward
+            labels, targets, inds, n_in, _ = self.atl.forward_device(H, W, gt_boxes, im_h, im_w)      # (host ground truth; a DEVICE array is waited for)
         rt.mem.join_early_stream(labels, targets, inds)
         if self.conv_math == "split":
             # split weights of every forward / input-gradient convolution from the current (packed fp32) weights: one launch

@@ -555,7 +555,7 @@ def _torch_rpn_losses(score, bbox_pred, labels, targets, inds_inside, n_all, fea
     loss_cls = torch.nn.functional.cross_entropy(s, mapped, ignore_index=-1, reduction="sum") / max(int((mapped != -1).sum()), 1)
     pred = bbox_pred.reshape(4, n_anchors, -1).permute(2, 1, 0).reshape(-1, 4)
     d = pred[torch.from_numpy(np.asarray(inds_inside, dtype=np.int64))].reshape(-1) - torch.from_numpy(
-        np.ascontiguousarray(targets, dtype=np.float32).ravel())
+        np.ascontiguousarray(targets, dtype=np.float32).ravel()).to(pred.dtype)
     a = d.abs()
     loss_bbox = torch.where(a < delta, 0.5 * d * d, delta * (a - 0.5 * delta)).sum() / pred.shape[0]
     return loss_cls, loss_bbox, loss_cls + lam * loss_bbox
@@ -570,17 +570,20 @@ def rpn_loss_grads(rpn_cls_score, rpn_bbox_pred, labels, targets, inds_inside, n
     return np.float32(lc.item()), np.float32(lb.item()), s.grad.numpy(), p.grad.numpy()
 
 
-def rpn_train_grads(p, x, labels, targets, inds_inside, n_all, delta=3.0, lam=1.0, layers=None, f64_wgrad=()):
+def rpn_train_grads(p, x, labels, targets, inds_inside, n_all, delta=3.0, lam=1.0, layers=None, f64_wgrad=(), float64=False):
     """One RPN-mode forward/backward of FasterRCNN (faster_rcnn.py:110-116 -> region_proposal_network.py:116-145):
     -> (rpn_loss, {chainer link path: gradient}) for the trunk and RPN parameters, given the anchor targets.
     f64_wgrad: trunk layer names whose WEIGHT gradient is additionally accumulated in float64 from the same fp32 upstream gradient
     (returned under "<path>/W@f64"): at 600 x 1000 a conv1_x weight gradient is a 600 000-term fp32 sum, and two correct fp32
-    implementations differ by more than the sum's own rounding -- the float64 value is the arbiter."""
+    implementations differ by more than the sum's own rounding -- the float64 value is the arbiter.
+    float64=True: the WHOLE forward/backward in float64 from the same fp32 parameters, image and targets -- the arbiter of an
+    end-to-end comparison between two fp32 implementations (tests/train_cases.py:check_vgg_step at 600 x 1000)."""
     import torch
     F = torch.nn.functional
     from_names = [k for k in p if k.startswith("trunk/") or k.startswith("RPN/")]
-    tp = {k: _t(p[k]).clone().requires_grad_(True) for k in from_names}
-    h = _t(x)
+    cast = (lambda a: _t(a).double()) if float64 else _t
+    tp = {k: cast(p[k]).clone().requires_grad_(True) for k in from_names}
+    h = cast(x)
     layers = layers or ["conv1_1", "conv1_2", "pool", "conv2_1", "conv2_2", "pool", "conv3_1", "conv3_2", "conv3_3", "pool",
                         "conv4_1", "conv4_2", "conv4_3", "pool", "conv5_1", "conv5_2", "conv5_3"]
     taps = {}

@@ -106,25 +106,85 @@ def test_vgg16_forward_600x1000_bf16(rt, oracle_forward):
     assert rep["ok"]
 
 
+def test_image_to_detections_600x1000(rt):
+    """forward.py:85-101 end to end on the device: uint8 HWC image -> img_preprocessing (mean subtraction + bilinear resize + HWC->CHW,
+    frcnn_preprocess_u8) -> FasterRCNN forward -> per-class NMS (0.3) + confidence cut (postprocess.detections), against the oracle's
+    chain from the SAME uint8 image.  Three links: (1) the preprocessed image within 2e-4 absolute; (2) the detection rows the device
+    derives from its own class probabilities / boxes equal 20 reference cpu_nms calls on those arrays bit for bit; (3) the final
+    lists agree with the oracle's: same number of detections per class, same order, boxes within 0.05 px, scores within 1e-4."""
+    from chainer_faster_rcnn_amd import synthetic
+    from chainer_faster_rcnn_amd.models import FasterRCNN
+    from chainer_faster_rcnn_amd.postprocess import PIXEL_MEANS, detections, img_preprocessing
+    from oracle import frcnn_oracle as O
+    rs = np.random.RandomState(7)
+    img = rs.randint(0, 256, (375, 625, 3)).astype(np.uint8)               # x 1.6 -> 600 x 1000
+    params = synthetic.params(seed=1)
+    conf = 0.05                                                            # random-init head: class probabilities sit around 1 / 21
+    # oracle chain
+    x_o, scale_o = O.img_preprocessing(img, PIXEL_MEANS)
+    assert x_o.shape == (3, IM_H, IM_W) and scale_o == 1.6
+    info = np.array([[IM_H, IM_W]], dtype=np.int32)
+    cls_o, boxes_o = O.faster_rcnn_forward(params, x_o[None], info)
+    want = {}
+    for c in range(1, cls_o.shape[1]):
+        d = np.hstack((boxes_o[:, 4 * c:4 * c + 4], cls_o[:, c:c + 1])).astype(np.float32)       # forward.py:50-53
+        d = d[O.cpu_nms(d, 0.3)]
+        d = d[d[:, -1] >= conf].copy()
+        d[:, :4] /= scale_o
+        want[c] = d
+    # device chain
+    x_d, scale_d = img_preprocessing(img, runtime=rt)
+    assert scale_d == scale_o and tuple(x_d.shape) == x_o.shape
+    pre_err = float(np.abs(rt.mem.to_numpy(x_d) - x_o).max())
+    model = FasterRCNN(runtime=rt)
+    model.load_params(params)
+    out = model.forward_device(x_d.reshape(1, 3, IM_H, IM_W), IM_H, IM_W)
+    n = int(rt.mem.to_numpy(out["n_out"])[0])
+    cp, pb = rt.mem.to_numpy(out["cls_prob"])[:n], rt.mem.to_numpy(out["pred_boxes"])[:n]
+    got = detections(rt.mem.from_numpy(cp), rt.mem.from_numpy(pb), 0.3, conf, im_scale=scale_d, runtime=rt)
+    counts, worst_box, worst_score, total = {}, 0.0, 0.0, 0
+    for c in range(1, cp.shape[1]):
+        d = np.hstack((pb[:, 4 * c:4 * c + 4], cp[:, c:c + 1])).astype(np.float32)
+        d = d[O.cpu_nms(d, 0.3)]
+        d = d[d[:, -1] >= conf].copy()
+        d[:, :4] /= scale_d
+        assert np.array_equal(got[c], d), ("device post-processing of its own maps", c)
+        counts[c] = (len(got[c]), len(want[c]))
+        total += len(got[c])
+    rep = {"n_rois_device": n, "n_rois_oracle": int(cls_o.shape[0]), "preprocess_max_abs_err": pre_err, "detections_device": total,
+           "detections_oracle": int(sum(len(v) for v in want.values()))}
+    same_counts = all(a == b for a, b in counts.values())
+    if same_counts:
+        for c in want:
+            if len(want[c]):
+                worst_box = max(worst_box, float(np.abs(got[c][:, :4] - want[c][:, :4]).max()))
+                worst_score = max(worst_score, float(np.abs(got[c][:, 4] - want[c][:, 4]).max()))
+    rep.update(same_counts_per_class=bool(same_counts), worst_box_abs_diff_px=worst_box, worst_score_abs_diff=worst_score)
+    _report("image_to_detections_600x1000", rep)
+    assert pre_err <= 2e-4 and n == cls_o.shape[0] and total > 100
+    assert same_counts, counts
+    assert worst_box <= 5e-2 and worst_score <= 1e-4
+
+
 def test_rpn_train_step_600x1000(rt):
     """configs[4] on one GPU: one RPN training step at 600 x 1000 -- loss within 1e-4; every conv weight-gradient KERNEL within 1e-4
     of a float64 accumulation of the very inputs it consumed; every gradient end to end (13 trunk convs, rpn_conv_3x3, both heads)
-    within 3e-3 of the oracle's fp32 autograd (discrete ReLU / max-pool decisions differ between two fp32 backward passes: see
-    tests/train_cases.py:check_vgg_step)."""
+    judged against the oracle's autograd run in FLOAT64: device_vs_f64 <= max(1e-3, 2 x torch_fp32_vs_f64), asserted inside
+    tests/train_cases.py:check_vgg_step, which prints the three-column table (no escape clause)."""
     import train_cases as T
-    losses, worst, flipped = T.check_vgg_step(rt, im_h=IM_H, im_w=IM_W, seed=0)
-    print("\nPARITY rpn_train_600x1000 %s" % json.dumps({"losses": losses, "worst_grad_rel_err_end_to_end": float(worst), "explained_by_near_tie_pool_windows": bool(flipped)}))
-    assert losses["rpn_loss"] > 0 and (worst <= 3e-3 or flipped)
+    losses, worst, _ = T.check_vgg_step(rt, im_h=IM_H, im_w=IM_W, seed=0)
+    print("\nPARITY rpn_train_600x1000 %s" % json.dumps({"losses": losses, "worst_grad_rel_err_vs_float64_autograd": float(worst)}))
+    assert losses["rpn_loss"] > 0
 
 
 def test_rpn_train_step_600x1000_split_products(rt):
     """The same step with RPNTrainer(conv_math="split"): forward, input-gradient and weight-gradient convolutions as six bf16 MFMA
     products of 3-way split fp32 operands -- the SAME bars as the fp32-MFMA step above (the weight-gradient kernel judged on its own
-    inputs against a float64 accumulation, 1e-4; end to end 3e-3)."""
+    inputs against a float64 accumulation, 1e-4; end to end against the float64 autograd, max(1e-3, 2 x torch's own fp32 distance))."""
     import train_cases as T
-    losses, worst, flipped = T.check_vgg_step(rt, im_h=IM_H, im_w=IM_W, seed=0, conv_math="split")
-    print("\nPARITY rpn_train_600x1000_split_products %s" % json.dumps({"losses": losses, "worst_grad_rel_err_end_to_end": float(worst), "explained_by_near_tie_pool_windows": bool(flipped)}))
-    assert losses["rpn_loss"] > 0 and (worst <= 3e-3 or flipped)
+    losses, worst, _ = T.check_vgg_step(rt, im_h=IM_H, im_w=IM_W, seed=0, conv_math="split")
+    print("\nPARITY rpn_train_600x1000_split_products %s" % json.dumps({"losses": losses, "worst_grad_rel_err_vs_float64_autograd": float(worst)}))
+    assert losses["rpn_loss"] > 0
 
 
 def test_resnet101_config4_600x1000(rt):

@@ -318,6 +318,62 @@ def test_bf16_copies_follow_the_optimizer(rt):
     assert np.array_equal(after, want)
 
 
+def test_alternation_then_bf16_inference_and_snapshot_see_both_trainers(rt, tmp_path):
+    """rpn -> rcnn on ONE bf16 model: the RCNNTrainer is the last trainer but owns only the trunk and the FC head; the RPN's
+    3x3 convolution and heads were trained by the RPNTrainer.  bf16 inference (derived copies) and a snapshot taken afterwards must carry
+    BOTH trainers' weights: a fresh model loaded with the live fp32 parameters gives the same detections, and so does one loaded from
+    the snapshot."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.serializers import load_npz, namedparams, save_npz, save_trainer_npz
+    from chainer_faster_rcnn_amd.train import RCNNTrainer, RPNTrainer
+    model, params = _small_full_model(rt, conv_dtype="bf16", head_dtype="bf16")
+    x, gt, info = _step_inputs()
+    xd = rt.mem.from_numpy(x)
+    model.rpn_train = True
+    t1 = RPNTrainer(model, lr=0.05)
+    np.random.seed(0)
+    t1.step(Variable(x), Variable(info), Variable(gt))
+    model.rcnn_train = True
+    t2 = RCNNTrainer(model, lr=0.05)
+    np.random.seed(1)
+    t2.step(Variable(x), Variable(info), Variable(gt))
+    model.rcnn_train = False
+    got = {k: rt.mem.to_numpy(v).copy() for k, v in model.forward_device(xd, 28, 40).items()}
+    # the live fp32 parameters (read AFTER the inference above synced every trainer)
+    live = {k: rt.mem.to_numpy(rt.mem.contiguous(v)).copy() for k, v in namedparams(model)}
+    assert not np.array_equal(live["RPN/rpn_conv_3x3/W"], params["RPN/rpn_conv_3x3/W"])          # the RPN trainer's update is there
+    assert not np.array_equal(live["fc6/W"], params["fc6/W"])                                      # and the RCNN trainer's
+    fresh, _ = _small_full_model(rt, conv_dtype="bf16", head_dtype="bf16")
+    fresh.load_params(live)
+    want = {k: rt.mem.to_numpy(v) for k, v in fresh.forward_device(xd, 28, 40).items()}
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    path = str(tmp_path / "alt.npz")
+    save_npz(path, model, trainer=t2)
+    with np.load(path) as f:
+        assert np.array_equal(f["RPN/rpn_conv_3x3/W"], live["RPN/rpn_conv_3x3/W"]) and np.array_equal(f["RPN/rpn_cls_score/W"], live["RPN/rpn_cls_score/W"])
+    tpath = str(tmp_path / "alt_trainer.npz")
+    save_trainer_npz(tpath, t2)
+    with np.load(tpath) as f:
+        assert np.array_equal(f["updater/model:main/RPN/rpn_conv_3x3/W"], live["RPN/rpn_conv_3x3/W"])
+    other, _ = _small_full_model(rt, conv_dtype="bf16", head_dtype="bf16")
+    load_npz(path, other)
+    back = {k: rt.mem.to_numpy(v) for k, v in other.forward_device(xd, 28, 40).items()}
+    for k in want:
+        assert np.array_equal(back[k], want[k]), k
+
+
+def test_bf16_convs_with_a_split_product_head(rt):
+    """FasterRCNN(conv_dtype='bf16', head_dtype='f32s') (forward_device() raised on the channel-blocked map): pool5 comes
+    from the blocked bf16 map in fp32 and is split for the head; same detections as the keep=True path, which pools the fp32 copy."""
+    model, _ = _small_full_model(rt, conv_dtype="bf16", head_dtype="f32s")
+    x, _, _ = _step_inputs()
+    xd = rt.mem.from_numpy(x)
+    a, b = model.forward_device(xd, 28, 40, keep=True), model.forward_device(xd, 28, 40)
+    for k in ("n_out", "rois", "cls_prob", "pred_boxes"):
+        assert np.array_equal(rt.mem.to_numpy(a[k]), rt.mem.to_numpy(b[k])), k
+
+
 def test_bf16_inference_pools_from_the_blocked_map(rt):
     """forward_device() of a bf16 model (keep=False: the inference path) pools straight from the channel-blocked bf16 conv5_3 map;
     with keep=True the fp32 NCHW copy is made and pooled: the same detections, bit for bit."""
