@@ -1,10 +1,17 @@
 #!/usr/bin/env python
-"""Time the ResNet-101 trunk alone and the config-4 FasterRCNN (ResNet-101, 1000/300 proposals) at 600x1000 (hipGraph replay).  GPU only."""
+"""BASELINE.json configs[3]: ResNet-101 backbone inference on one MI355X, 1000 pre-NMS / 300 post-NMS proposals, 600 x 1000, fp32
+(models/resnet.py:11-45 wired literally: res5 -> RPN(2048) -> RoI pooling at 1/32 -> fc6(2048*49) ...).  One JSON record:
+whole-forward hipGraph replay time, the trunk alone as its own hipGraph (HIP events on the launch stream) priced against the fp32
+MFMA peak with the trunk's algorithmic FLOPs, per-stage HIP events of eager forwards (fc6 = 300 x 100352 x 4096 called out), and the
+comparison of res5 / proposals with nothing (parity lives in tests/test_gpu_fullsize.py::test_resnet101_config4_600x1000).
+GPU only.  Usage: python scripts/resnet_bench.py [> profiles/r03_bench_resnet101.json]"""
+import json
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -12,6 +19,32 @@ import chainer_faster_rcnn_amd as pkg  # noqa: E402
 from chainer_faster_rcnn_amd import synthetic  # noqa: E402
 from chainer_faster_rcnn_amd.graph import CapturedForward  # noqa: E402
 from chainer_faster_rcnn_amd.models import FasterRCNN, ResNet101  # noqa: E402
+import bench  # noqa: E402  (EventTimer, graph_time_us, the peaks)
+
+
+def resnet_trunk_flops(h, w, blocks=(3, 4, 23, 3)):
+    """Algorithmic multiply-add FLOPs (2 per MAC; BN folded, bias / ReLU / pooling excluded) of chainer's ResNetLayers up to res5."""
+    def cdiv(a, b):
+        return -(-a // b)
+    per = {}
+    h1, w1 = (h + 2 * 3 - 7) // 2 + 1, (w + 2 * 3 - 7) // 2 + 1                       # conv1 7x7 / 2, pad 3
+    per["conv1"] = 2.0 * 3 * 49 * 64 * h1 * w1
+    hh, ww = cdiv(h1 - 3, 2) + 1, cdiv(w1 - 3, 2) + 1                                 # max_pooling_2d(3, stride 2), cover_all
+    cin = 64
+    for stage, (n, mid, stride) in enumerate(zip(blocks, (64, 128, 256, 512), (1, 2, 2, 2))):
+        out = mid * 4
+        tot = 0.0
+        for i in range(n):
+            s = stride if i == 0 else 1
+            ho, wo = cdiv(hh, s), cdiv(ww, s)                                           # 1x1 / s, pad 0
+            tot += 2.0 * cin * mid * ho * wo                                            # conv1 1x1 (stride on it: chainer's BottleNeckA)
+            tot += 2.0 * mid * 9 * mid * ho * wo                                        # conv2 3x3
+            tot += 2.0 * mid * out * ho * wo                                            # conv3 1x1
+            if i == 0:
+                tot += 2.0 * cin * out * ho * wo                                        # conv4: the projection shortcut
+            cin, hh, ww = out, ho, wo
+        per["res%d" % (stage + 2)] = tot
+    return per, (hh, ww)
 
 
 def main():
@@ -30,26 +63,48 @@ def main():
     model.load_params(params)
     model.RPN.proposal_layer._pre_nms_top_n, model.RPN.proposal_layer._post_nms_top_n = 1000, 300
     x = rt.mem.from_numpy(synthetic.image(seed=6, h=h, w=w) / 64.0)
-    for _ in range(3):
-        model.trunk(x)
+    t_ramp = time.perf_counter()
+    while time.perf_counter() - t_ramp < 1.0:                                          # clock ramp, untimed
+        model.forward_device(x, h, w)
+        torch.cuda.synchronize()
+    timer = bench.EventTimer(torch)
+    for _ in range(10):
+        timer.begin()
+        model.forward_device(x, h, w, timer=timer)
+        timer.end()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        model.trunk(x)
-    e1.record()
-    torch.cuda.synchronize()
-    print("resnet101 trunk (eager, GPU time incl. host gaps): %.2f ms" % (e0.elapsed_time(e1) / 5))
+    stages = timer.averages_ms()
+    trunk_ms = bench.graph_time_us(torch, lambda: model.trunk(x), 1, 100) / 1e3
     cap = CapturedForward(model, x, h, w)
     for _ in range(5):
         cap.replay()
     torch.cuda.synchronize()
+    steps = 100
     t0 = time.perf_counter()
-    for _ in range(20):
-        cap.replay()
+    for _ in range(steps):
+        out = cap.replay()
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / 20 * 1e3
-    print("config 4 (ResNet-101 FasterRCNN, 1000/300) hipGraph replay: %.2f ms/img = %.1f img/s" % (ms, 1e3 / ms))
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    per, (fh, fw) = resnet_trunk_flops(h, w)
+    trunk_flops = sum(per.values())
+    rpn_flops = 2.0 * 2048 * 9 * 512 * fh * fw
+    fc6_flops = 2.0 * 300 * 2048 * 49 * 4096
+    rec = {"metric": "images/sec ResNet-101 Faster R-CNN 600x1000", "value": 1e3 / ms, "unit": "img/s", "n_gpus": 1, "steps": steps, "warmup": 5,
+           "ms_per_step": ms, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "ResNet-101 backbone inference, 1xMI355X, batch 1, 1000 pre-NMS / 300 post-NMS proposals, fp32 "
+                                  "(BASELINE.json configs[3]); res5 at stride 32, RoI pooling at 1/32, fc6 over 2048 x 7 x 7",
+                      "image": "1x3x600x1000", "launch": "hipGraph replay", "n_rois_last_step": int(out["n_out"].cpu()[0]), "feature_map": [2048, fh, fw]},
+           "roofline": {"bound": "mfma", "kernel": "conv_mfma_f32_kernel (ResNet-101 trunk: 7x7/2 stem as im2col + 1x1, 33 bottlenecks of 1x1 / 3x3 / 1x1 "
+                                                     "with folded BatchNormalization and the residual epilogue): 104 convolution launches",
+                        "achieved": trunk_flops / (trunk_ms * 1e-3) / 1e12, "peak": bench.PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": trunk_flops / (trunk_ms * 1e-3) / 1e12 / bench.PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                        "trunk_ms": trunk_ms, "trunk_ms_source": "HIP events around 100 replays of a hipGraph holding exactly the trunk's launches",
+                        "algorithmic_gflop_trunk": trunk_flops / 1e9, "algorithmic_gflop_by_stage": {k: v / 1e9 for k, v in per.items()}},
+           "stages_ms": {k: round(v, 4) for k, v in stages.items()},
+           "fc6": {"shape": "300 x 100352 x 4096", "ms": stages.get("fc6"), "tflops": fc6_flops / (stages["fc6"] * 1e-3) / 1e12 if stages.get("fc6") else None,
+                   "weight_mb": 100352 * 4096 * 4 / 1e6},
+           "rpn_conv_3x3": {"gflop": rpn_flops / 1e9}}
+    bench.emit_json_line(rec)
 
 
 if __name__ == "__main__":

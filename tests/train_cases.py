@@ -160,8 +160,9 @@ def check_vgg_step(rt, im_h=160, im_w=224, seed=0, conv_math="mfma"):
             e_pair = float(np.abs(got[k] - want[k]).max() / max(float(np.abs(want[k]).max()), 1e-8))
             table[k] = {"device_vs_f64": float("%.3g" % e_dev), "torch_fp32_vs_f64": float("%.3g" % e_t32), "device_vs_torch_fp32": float("%.3g" % e_pair)}
             worst = max(worst, e_dev)
-            assert e_dev <= max(1e-3, 2.0 * e_t32), (k, table[k])
         print("\nPARITY_TABLE rpn_train_600x1000%s %s" % ("_split_products" if conv_math == "split" else "", json_dumps(table)))
+        for k, row in sorted(table.items()):
+            assert row["device_vs_f64"] <= max(1e-3, 2.0 * row["torch_fp32_vs_f64"]), (k, row)
         for k in sorted(want):                                    # and every weight-gradient KERNEL on its own inputs, as at the small size
             if k.startswith("trunk/") and k.endswith("/W"):
                 import torch
