@@ -280,6 +280,53 @@ def split_variant(args, torch, rt, params, x, dbg, flops_total):
     return out
 
 
+def bf16_variant(args, torch, rt, params, x, dbg, flops_total):
+    """BASELINE.json configs[2] on this GPU ("bf16 convs / fp32 RoI", 1 image per GPU): the bf16 chain (csrc/conv_bf16.hip: operands
+    rounded to bf16, fp32 accumulation on v_mfma_f32_32x32x16_bf16, bf16 FC head; proposals, RoI pooling, decode in fp32), timed like
+    the contract line (K hipGraph replays), its conv chain priced against the dense bf16 MFMA peak, and compared with the same oracle
+    forward.  Bit-exact proposal indices FROM THE IMAGE are claimed for the fp32 lines only: a bf16 trunk moves conv5_3 by ~1e-2."""
+    from chainer_faster_rcnn_amd.graph import CapturedForward
+    from chainer_faster_rcnn_amd.models import FasterRCNN
+    model = FasterRCNN(runtime=rt, conv_dtype="bf16", head_dtype="bf16")
+    model.load_params(params)
+    for _ in range(max(args.warmup, 3)):
+        model.forward_device(x, IM_H, IM_W)
+    torch.cuda.synchronize()
+    graph = CapturedForward(model, x, IM_H, IM_W, warmup=1)
+    graph.replay()
+    torch.cuda.synchronize()
+    steps = max(args.steps, 100)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"what": ("BASELINE.json configs[2] per GPU: the 13 trunk convolutions, rpn_conv_3x3, the RPN heads and the four FC layers with bf16 operands "
+                    "and fp32 accumulation (v_mfma_f32_32x32x16_bf16); proposals / RoI pooling / decode in fp32.  `python bench.py --dtype bf16` "
+                    "prints this configuration as its own line."),
+           "value": steps / dt, "unit": "img/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "launch": "hipGraph replay"}
+    try:
+        conv_ms = graph_time_us(torch, f32s_conv_chain(rt, model, x, bf16=True), 1, max(args.steps, 100)) / 1e3
+        out.update(conv_ms_per_image=conv_ms, conv_tflops=flops_total / (conv_ms * 1e-3) / 1e12,
+                   frac_of_bf16_mfma_peak=flops_total / (conv_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS)
+    except Exception as e:
+        print("bf16 conv-chain graph failed (%s)" % (e,), file=sys.stderr)
+        torch.cuda.synchronize()
+    if dbg is not None:
+        try:
+            from oracle import parity
+            info = np.array([[IM_H, IM_W]], dtype=np.int32)
+            rep = parity.compare_forward(params, info, dbg, parity.device_forward_host(rt, model, x, IM_H, IM_W), layer_tol=3e-2, head_tol=3e-2)
+            out["parity"] = {k: rep.get(k) for k in ("ok", "layers_worst", "conv5_3_rel_err", "rpn_cls_prob_rel_err", "rpn_bbox_pred_rel_err",
+                                                     "proposals_index_exact_given_device_maps", "from_image_index_match_positional",
+                                                     "from_image_index_match_set", "pool5_exact", "cls_prob_rel_err", "pred_boxes_rel_err", "tolerances")}
+            out["parity"]["claim"] = ("stage by stage, given the device's own maps: proposal indices and pool5 exact; from the IMAGE a bf16 trunk does not "
+                                      "reproduce the fp32 oracle's proposal indices (see from_image_index_match_*): that claim is made for the fp32 lines only")
+        except Exception as e:
+            out["parity"] = {"ok": False, "error": repr(e)}
+    return out
+
+
 def emit_json_line(obj):
     """The contract's ONE JSON line, as the LAST thing on stdout: RCCL writes a version banner through C stdio when its first
     communicator comes up, which a buffered stdout flushes at exit -- after the line.  So: print, flush, then point file descriptor 1
@@ -402,6 +449,7 @@ def main():
     ap.add_argument("--ramp-seconds", type=float, default=1.0, help="untimed clock-ramp preamble before the warm-up steps")
     ap.add_argument("--cpu-samples", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16-variant", action="store_true", help="skip the bf16_config3 block (BASELINE configs[2] per GPU) of the default line")
     ap.add_argument("--no-stage-events", action="store_true")
     ap.add_argument("--no-split-variant", action="store_true",
                     help="f32 inference line only: skip the second measurement with the convolutions computed as bf16x6 split products")
@@ -663,6 +711,13 @@ def main():
                 res["parity"] = rep
             except Exception as e:
                 res["parity"] = {"ok": False, "error": repr(e)}
+        if world == 1 and args.dtype == "f32" and not args.no_bf16_variant:
+            try:
+                from chainer_faster_rcnn_amd.models.vgg16 import LAYERS as _L3
+                res["bf16_config3"] = bf16_variant(args, torch, rt, params, x, dbg, sum(conv_flops(_L3, IM_H, IM_W)[0].values()))
+            except Exception as e:
+                res["bf16_config3"] = {"error": repr(e)}
+                torch.cuda.synchronize()
         if world == 1 and args.dtype == "f32" and not args.no_split_variant:
             try:
                 from chainer_faster_rcnn_amd.models.vgg16 import LAYERS as _L

@@ -388,10 +388,18 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
             }
         }
     };
-    // this wave's loads per chunk: the N of "all but the newest chunk have landed"
+    // this wave's loads per chunk (PPW, or PPW - 1 for the waves past the last piece): "at most k chunks of my loads still in flight"
+    // is one counted s_waitcnt with k x that number (vmcnt holds 63: k <= 4 here)
     const bool seven = wave < PIECES - 4 * (PPW - 1);
-    auto wait_all_but_newest = [&]() {
-        if (seven) frcnn_wait_vmcnt<PPW>(); else frcnn_wait_vmcnt<PPW - 1>();
+    auto wait_allow = [&](int k) {
+        static_assert(NS <= 6 && 4 * PPW <= 63, "vmcnt immediates below");
+        switch (k) {
+        case 0: frcnn_wait_vmcnt<0>(); break;
+        case 1: if (seven) frcnn_wait_vmcnt<PPW>(); else frcnn_wait_vmcnt<PPW - 1>(); break;
+        case 2: if (seven) frcnn_wait_vmcnt<2 * PPW>(); else frcnn_wait_vmcnt<2 * (PPW - 1)>(); break;
+        case 3: if (seven) frcnn_wait_vmcnt<3 * PPW>(); else frcnn_wait_vmcnt<3 * (PPW - 1)>(); break;
+        default: if (seven) frcnn_wait_vmcnt<4 * PPW>(); else frcnn_wait_vmcnt<4 * (PPW - 1)>(); break;
+        }
     };
 
     // fragment byte offsets inside a stage (swizzled): A = weight row tap*64 + wco*32 + l31, B = halo pixel (RW*wrow + r)*34 + l31 + kx
@@ -454,6 +462,54 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
         }
     };
 
+    // WPS == 1 (one workgroup per CU: launches with fewer tiles than CUs, the 38 x 63 maps): nobody else is resident to cover this
+    // workgroup's latencies, so besides the deep DMA ring the FRAGMENTS are double-buffered in registers (512 of them per lane at one
+    // wave per SIMD): chunk c+1's 21 ds_read_b128 are in flight while chunk c's 18 MFMAs run.  Read-then-multiply in one chunk cost
+    // ~340 LDS clocks + 576 MFMA clocks per chunk in sequence; deeper rings alone changed nothing (25.4 vs 23.4 us on conv5_1).
+    constexpr bool FDB = WPS == 1 && RPW == 1 && NS >= 3 && ABL == 0;
+    if constexpr (FDB) {
+        auto loadf = [&](uint4 (&a)[TAPS], uint4 (&b)[RW + KS - 1][KS], int stage) {
+            const unsigned char *st = ring + stage * STAGE_BYTES;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) a[tap] = *reinterpret_cast<const uint4 *>(st + a_off + tap * BCO * 32);
+#pragma unroll
+            for (int r = 0; r < RW + KS - 1; ++r)
+#pragma unroll
+                for (int kx = 0; kx < KS; ++kx) b[r][kx] = *reinterpret_cast<const uint4 *>(st + b_off[r][kx]);
+        };
+        auto mfmas = [&](const uint4 (&a)[TAPS], const uint4 (&b)[RW + KS - 1][KS]) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                const int ky = tap / KS, kx = tap % KS;
+#pragma unroll
+                for (int j = 0; j < RW; ++j) acc[j] = frcnn_mfma_32x32x16_bf16(a[tap], b[ky + j][kx], acc[j]);
+            }
+        };
+        // chunk s lives in stage s % NS.  Invariant after step(c): chunk c's fragments are in registers, chunks c+1 .. c+NS-1 landed or
+        // in flight.  advance(c, next): wait for chunk c+1, barrier (every wave's reads of stage(c) are complete: its fragments are in
+        // registers), refill stage(c) with chunk c+NS, start reading chunk c+1's fragments into `next`.
+        uint4 fa0[TAPS], fb0[RW + KS - 1][KS], fa1[TAPS], fb1[RW + KS - 1][KS];
+#pragma unroll
+        for (int c = 0; c < NS - 1; ++c)
+            if (c < nchunks) issue(c, c);
+        wait_allow(min(NS - 2, nchunks - 1));
+        frcnn_barrier_nofence();
+        if (NS - 1 < nchunks) issue(NS - 1, NS - 1);
+        loadf(fa0, fb0, 0);
+        auto advance = [&](int c, uint4 (&na)[TAPS], uint4 (&nb)[RW + KS - 1][KS]) {
+            wait_allow(min(c + NS - 1, nchunks - 1) - (c + 1));
+            frcnn_barrier_nofence();
+            if (c + NS < nchunks) issue(c + NS, c % NS);
+            loadf(na, nb, (c + 1) % NS);
+        };
+        for (int c = 0; c < nchunks; c += 2) {
+            if (c + 1 < nchunks) advance(c, fa1, fb1);
+            mfmas(fa0, fb0);
+            if (c + 1 >= nchunks) break;
+            if (c + 2 < nchunks) advance(c + 1, fa0, fb0);
+            mfmas(fa1, fb1);
+        }
+    } else
     if constexpr (NS == 1) {
         // single stage: no overlap inside the workgroup -- the other (up to five) workgroups of the CU run their MFMAs while this
         // one waits for its chunk; the small LDS footprint is what buys that occupancy
@@ -465,11 +521,13 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
             if (c + 1 < nchunks) frcnn_barrier_nofence();       // everybody is done reading before the stage is refilled
         }
     } else {
-    // prologue: NS-1 chunks in flight, chunk 0 landed
+    // prologue: NS-1 chunks in flight, chunk 0 landed.  Deep rings (NS 4 .. 6, one workgroup per CU) are for launches with fewer tiles
+    // than CUs (the 38 x 63 maps: 160 tiles): nobody else is resident to cover a chunk's DMA latency (~1 us for 25 KB against 0.24 us of
+    // MFMAs), so the workgroup itself keeps NS-1 chunks in flight
 #pragma unroll
     for (int c = 0; c < NS - 1; ++c)
         if (c < nchunks) issue(c, c);
-    if (NS == 3 && nchunks > 1) wait_all_but_newest(); else frcnn_wait_vmcnt<0>();
+    wait_allow(min(NS - 2, nchunks - 1));
     frcnn_barrier_nofence();
     int s_cur = 0, s_new = NS - 1;                               // stage of chunk c, stage chunk c+NS-1 goes to
     for (int c = 0; c < nchunks; ++c) {
@@ -477,8 +535,9 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
         if (more) issue(c + NS - 1, s_new);
         compute(s_cur);
         if (c + 1 < nchunks) {
-            // chunk c+1 must have landed for everybody, and everybody must be done reading stage s_cur before it is refilled
-            if (NS == 3 && more) wait_all_but_newest(); else frcnn_wait_vmcnt<0>();
+            // chunk c+1 must have landed for everybody (the chunks issued after it may still be in flight), and everybody must be done
+            // reading stage s_cur before it is refilled
+            wait_allow(min(c + NS - 1, nchunks - 1) - (c + 1));
             frcnn_barrier_nofence();
         }
         s_cur = s_cur + 1 == NS ? 0 : s_cur + 1;
@@ -765,7 +824,17 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
             const char *comma = strchr(def_env, ',');
             small_mode = comma ? atoi(comma + 1) : big_mode;
         }
-        mode = (long)grid.x >= 4L * frcnn_cu_count() ? big_mode : small_mode;
+        // measured picks per launch size (scripts/micro/conv_bf16_micro, r03: every mode on every VGG-16 layer shape at 600 x 1000):
+        //   >= 8 four-row tiles per CU (conv1_2, conv2_x)  8-row tiles, single stage (132): 44.3 / 25.2 / 40.2 us vs 47.5 / 27.4 / 43.5 with 141
+        //   4 .. 8 per CU (conv3_x)                        4-row tiles, single stage, six workgroups per CU (141)
+        //   2 .. 4 per CU with 32 K-chunks (conv4_2/3)     8-row tiles (132): 45.2 vs 46.6 us
+        //   fewer (conv4_1, the 38 x 63 maps)              two-stage ring (231)
+        const long per_cu4 = (long)grid.x / (frcnn_cu_count() > 0 ? frcnn_cu_count() : 256);
+        if (def_env) mode = (long)grid.x >= 4L * frcnn_cu_count() ? big_mode : small_mode;
+        else if (per_cu4 >= 8) mode = 132;
+        else if (per_cu4 >= 4) mode = 141;
+        else if (per_cu4 >= 2 && CinP >= 512) mode = 132;
+        else mode = 231;
     }
     const int rpw = (mode > 0 && mode < 1000) ? mode % 10 : 1;
     if (mode > 0 && (rpw < 1 || rpw > 4)) return FRCNN_ERR_INVALID;
@@ -801,6 +870,7 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
         break;
         switch (mode) {
             FRCNN_DMA_CASE(3, 2, 1) FRCNN_DMA_CASE(2, 3, 1) FRCNN_DMA_CASE(1, 4, 1) FRCNN_DMA_CASE(1, 3, 2) FRCNN_DMA_CASE(2, 2, 2)
+            FRCNN_DMA_CASE(3, 1, 1) FRCNN_DMA_CASE(4, 1, 1) FRCNN_DMA_CASE(5, 1, 1) FRCNN_DMA_CASE(6, 1, 1)
             FRCNN_DMA_CASE(2, 2, 3) FRCNN_DMA_CASE(2, 3, 3) FRCNN_DMA_CASE(3, 2, 3) FRCNN_DMA_CASE(2, 2, 4) FRCNN_DMA_CASE(3, 2, 4)
             FRCNN_DMA_CASE(1, 2, 4) FRCNN_DMA_CASE(1, 3, 3)
 #ifdef FRCNN_TIMING_ABLATIONS                                                                       // WRONG results: sweeps only, never shipped

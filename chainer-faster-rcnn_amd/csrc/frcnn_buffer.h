@@ -69,11 +69,20 @@ __device__ __forceinline__ void frcnn_buf_store_f32(frcnn_buf_t b, uint32_t byte
 // which is the point (it would drain vmcnt(0) at the next barrier and serialise the prefetch with the MFMAs).
 __device__ __forceinline__ void frcnn_buf_load_lds_b128(frcnn_buf_t b, void *lds_wave_base, uint32_t byte_off, uint32_t soff) {
     const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_wave_base;
+#ifdef FRCNN_DMA_KEEP_M0
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "s"(la), "v"(byte_off), "s"(b), "s"(soff)
                  : "memory");
+#else
+    // M0 is clobbered, not saved and restored: nothing else in these kernels reads it between two pieces (the compiler re-materialises
+    // it where IT needs it: ds_append, readlane), and the two extra scalar moves per 1 KB piece sat in the issue stream of every wave
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                 :
+                 : "s"(la), "v"(byte_off), "s"(b), "s"(soff)
+                 : "memory", "m0");
+#endif
 }
 // same, 4 bytes per lane: 256 B per wave-instruction at lds_wave_base + 4 * lane
 __device__ __forceinline__ void frcnn_buf_load_lds_b32(frcnn_buf_t b, void *lds_wave_base, uint32_t byte_off, uint32_t soff) {

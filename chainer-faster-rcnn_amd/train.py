@@ -291,6 +291,9 @@ class RPNTrainer(_BucketedAllReduce):
             feat, inputs = trunk_forward(model, x)                     # keeps every layer's input
             mid = rpn.rpn_conv_3x3(feat, relu=True)
         score, prob, bbox = rt.rpn_heads(mid, rpn._heads_packed)
+        if getattr(self, "keep_dy", None) is not None:               # tests: every activation map a ReLU / max-pool decision was taken on
+            self.kept_dy["rpn_mid"] = mid
+            self.kept_dy["layer_inputs"] = list(inputs) + [feat]
         if self.run_proposal_layer:
             # region_proposal_network.py:123-126: `proposals, probs = self.proposal_layer(...)` in train mode (12000 -> NMS -> 2000);
             # nothing downstream consumes it in rpn_train mode (faster_rcnn.py:115-116 returns the loss) -- kept for inspection.

@@ -610,6 +610,48 @@ def rpn_train_grads(p, x, labels, targets, inds_inside, n_all, delta=3.0, lam=1.
     return np.float32(total.item()), grads
 
 
+def rpn_train_grads_given_decisions(p, x, labels, targets, inds_inside, n_all, post_relu, pre_pool, rpn_mid, delta=3.0, lam=1.0, layers=None):
+    """rpn_train_grads(float64=True) with the DISCRETE decisions of another forward pass imposed: `post_relu[name]` is that pass's
+    (fp32) output of conv `name` after its ReLU -- the float64 pre-activation is multiplied by (post_relu > 0) instead of going through
+    relu() -- and `pre_pool[i]` is its input of the i-th 2x2 max-pool, whose window arg-maxima (first maximum in scan order) select the
+    cells of the float64 map; `rpn_mid` likewise for rpn_conv_3x3.  Every arithmetic step stays float64, so what comes out is "the
+    exact gradient of the function the other pass actually evaluated": a device pass whose gradients match THIS to 1e-5 differs from
+    the pure float64 pass only through the handful of ReLU signs / pool winners that fp32 rounding decides differently.
+    -> (loss, grads, n_relu_flips per layer vs the float64 pass's own decisions)."""
+    import torch
+    F = torch.nn.functional
+    from_names = [k for k in p if k.startswith("trunk/") or k.startswith("RPN/")]
+    tp = {k: _t(p[k]).double().clone().requires_grad_(True) for k in from_names}
+    h = _t(x).double()
+    layers = layers or ["conv1_1", "conv1_2", "pool", "conv2_1", "conv2_2", "pool", "conv3_1", "conv3_2", "conv3_3", "pool",
+                        "conv4_1", "conv4_2", "conv4_3", "pool", "conv5_1", "conv5_2", "conv5_3"]
+    flips, ip = {}, 0
+    for l in layers:
+        if l == "pool":
+            src = _t(pre_pool[ip]).reshape(1, *pre_pool[ip].shape[-3:])
+            ip += 1
+            _, idx = F.max_pool2d(src, 2, 2, ceil_mode=True, return_indices=True)
+            own = F.max_pool2d(h.detach(), 2, 2, ceil_mode=True, return_indices=True)[1]
+            flips["pool%d" % ip] = int((own != idx).sum())
+            h = h.flatten(2).gather(2, idx.flatten(2)).reshape(idx.shape)
+            continue
+        pre = F.conv2d(h, tp["trunk/%s/W" % l], tp["trunk/%s/b" % l], padding=1)
+        m = _t(post_relu[l]).reshape(pre.shape) > 0
+        flips[l] = int((m != (pre.detach() > 0)).sum())
+        h = pre * m
+    pre = F.conv2d(h, tp["RPN/rpn_conv_3x3/W"], tp["RPN/rpn_conv_3x3/b"], padding=1)
+    m = _t(rpn_mid).reshape(pre.shape) > 0
+    flips["rpn_conv_3x3"] = int((m != (pre.detach() > 0)).sum())
+    hh = pre * m
+    score = F.conv2d(hh, tp["RPN/rpn_cls_score/W"], tp["RPN/rpn_cls_score/b"])
+    bbox = F.conv2d(hh, tp["RPN/rpn_bbox_pred/W"], tp["RPN/rpn_bbox_pred/b"])
+    fh, fw = int(score.shape[2]), int(score.shape[3])
+    A = int(score.shape[1]) // 2
+    lc, lb, total = _torch_rpn_losses(score, bbox, labels, targets, inds_inside, n_all, fh, fw, A, delta, lam)
+    total.backward()
+    return float(total.item()), {k: v.grad.numpy() for k, v in tp.items()}, flips
+
+
 # --------------------------------------------------------------------------- ResNet trunk (chainer-ext)
 def resnet_forward(p, x, blocks=(3, 4, 23, 3), prefix="trunk/", eps=2e-5):
     """models/resnet.py:43-45 -> chainer ResNetLayers(...)(x, ['res5'], test=True)['res5'] [chainer-ext], restated with

@@ -1,0 +1,89 @@
+// conv_bf16_micro.cpp -- times frcnn_conv_bf16_ws (libfrcnn_hip.so) on the VGG-16 layer shapes at 600 x 1000 without torch: per layer a
+// captured graph of 10 back-to-back launches (outputs rotating over 3 buffers), bursts of graph launches between two events.
+// Usage: conv_bf16_micro [layer ...] with settings from the environment (FRCNN_BF16_DMA, FRCNN_BF16_DMA_DEFAULT, FRCNN_BF16_SPLIT ...)
+//        or conv_bf16_micro --modes "141 231 611" [layer ...] to sweep FRCNN_BF16_DMA per layer.
+// Values: uniform bf16 in [-1, 1) (weights x 0.05); results are not checked here (tests/ do that).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <random>
+#include <sstream>
+#include <string>
+#include <vector>
+#include "frcnn_hip.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+struct Layer { const char *name; int ci, co, h, w, pool; };
+static const Layer kLayers[] = {
+    {"conv1_2", 64, 64, 600, 1000, 1}, {"conv2_1", 64, 128, 300, 500, 0}, {"conv2_2", 128, 128, 300, 500, 1}, {"conv3_1", 128, 256, 150, 250, 0},
+    {"conv3_2", 256, 256, 150, 250, 0}, {"conv3_3", 256, 256, 150, 250, 1}, {"conv4_1", 256, 512, 75, 125, 0}, {"conv4_2", 512, 512, 75, 125, 0},
+    {"conv4_3", 512, 512, 75, 125, 1}, {"conv5_1", 512, 512, 38, 63, 0}};
+
+static uint16_t bf16_of(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (uint16_t)(u >> 16); }
+
+int main(int argc, char **argv) {
+    std::vector<std::string> modes, want;
+    for (int i = 1; i < argc; ++i) {
+        if (!strcmp(argv[i], "--modes") && i + 1 < argc) { std::istringstream ss(argv[++i]); std::string m; while (ss >> m) modes.push_back(m); }
+        else want.push_back(argv[i]);
+    }
+    if (modes.empty()) modes.push_back("");
+    hipStream_t s; CK(hipStreamCreate(&s));
+    const int burst = getenv("CONV_MICRO_BURST") ? atoi(getenv("CONV_MICRO_BURST")) : 20;
+    std::mt19937 g(1); std::uniform_real_distribution<float> u(-1.f, 1.f);
+    double total_us_best = 0;
+    for (const Layer &L : kLayers) {
+        if (!want.empty() && std::find(want.begin(), want.end(), std::string(L.name)) == want.end()) continue;
+        const int cip = frcnn_bf16_padded_channels(L.ci), cop = frcnn_bf16_padded_channels(L.co);
+        const size_t nx = (size_t)cip * L.h * L.w, nw = (size_t)9 * cop * cip, ny = (size_t)cop * L.h * L.w;
+        std::vector<uint16_t> hx(nx), hw(nw);
+        for (auto &e : hx) e = bf16_of(u(g));
+        for (auto &e : hw) e = bf16_of(0.05f * u(g));
+        uint16_t *dx, *dw, *dy[3]; float *db; void *ws;
+        CK(hipMalloc(&dx, nx * 2)); CK(hipMalloc(&dw, nw * 2)); CK(hipMalloc(&db, cop * 4)); CK(hipMemset(db, 0, cop * 4));
+        for (auto &p : dy) CK(hipMalloc(&p, ny * 2));
+        const size_t wsb = frcnn_conv_bf16_workspace_bytes(L.ci, L.co, L.h, L.w);
+        CK(hipMalloc(&ws, wsb));
+        if (frcnn_conv_bf16_workspace_init(ws, wsb, s) != 0) { printf("workspace init failed\n"); return 1; }
+        CK(hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, hw.data(), nw * 2, hipMemcpyHostToDevice));
+        const double gflop = 2.0 * L.h * L.w * L.co * L.ci * 9 / 1e9;
+        printf("%-8s %3d->%3d %4dx%-4d %6.1f GFLOP:", L.name, L.ci, L.co, L.h, L.w, gflop);
+        double best = 1e30;
+        for (const std::string &m : modes) {
+            if (!m.empty()) setenv("FRCNN_BF16_DMA", m.c_str(), 1);
+            hipGraph_t gr; hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+            bool ok = true;
+            for (int i = 0; i < 10; ++i)
+                ok = ok && frcnn_conv_bf16_ws(dx, dw, db, dy[i % 3], L.ci, L.co, L.h, L.w, 3, 1, L.pool ? 2 : 0, ws, wsb, s) == 0;
+            CK(hipStreamEndCapture(s, &gr));
+            if (!ok) { printf("  %s: launch refused", m.c_str()); CK(hipGraphDestroy(gr)); continue; }
+            CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ge, s));
+            CK(hipStreamSynchronize(s));
+            std::vector<float> us;
+            for (int r = 0; r < 7; ++r) {
+                CK(hipEventRecord(e0, s));
+                for (int b = 0; b < burst; ++b) CK(hipGraphLaunch(ge, s));
+                CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
+                float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1)); us.push_back(ms * 100.f / burst);
+            }
+            std::sort(us.begin(), us.end());
+            const double med = us[us.size() / 2];
+            best = std::min(best, med);
+            printf("  %s %6.1f us %5.0f TF", m.empty() ? "default" : m.c_str(), med, gflop / med * 1e-3);
+            CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(gr));
+        }
+        printf("\n");
+        total_us_best += best * (strcmp(L.name, "conv5_1") == 0 ? 4 : 1);      // conv5_1's shape runs four times in the chain (conv5_1..3, rpn_conv_3x3)
+        unsetenv("FRCNN_BF16_DMA");
+        CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(db)); CK(hipFree(ws)); for (auto &p : dy) CK(hipFree(p));
+    }
+    printf("sum of the best per layer (conv5_1 x 4, conv1_1 not included): %.1f us\n", total_us_best);
+    return 0;
+}
