@@ -73,8 +73,9 @@ def pmc_traffic(dtype):
     WRITE_SIZE in separate rocprofv3 --pmc runs); counters cannot be read from inside the process, so the bench line carries
     the last measured figure and names its source, or null when no PMC pass exists for this dtype."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    cands = {"f32": ["r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"], "bf16": ["r02_hbm_traffic_pmc_bf16.json"],
-             "f32s": ["r02_hbm_traffic_pmc_f32s.json"]}[dtype]
+    cands = {"f32": ["r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"],
+             "bf16": ["r03_hbm_traffic_pmc_bf16.json", "r02_hbm_traffic_pmc_bf16.json"],
+             "f32s": ["r03_hbm_traffic_pmc_f32s.json", "r02_hbm_traffic_pmc_f32s.json"]}[dtype]
     kernel = {"f32": "conv_mfma_f32_kernel", "bf16": "conv_bf16_kernel", "f32s": "conv_f32s_kernel"}[dtype]
     for name in cands:
         path = os.path.join(prof, name)

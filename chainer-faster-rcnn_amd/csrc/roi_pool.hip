@@ -1031,7 +1031,7 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
         my_tab[lane] = t0;
         my_tab[kQuadTabExt + lane] = t1;
         frcnn_wave_sync();         // (the rows are read by other lanes of this wave: DS operations of one wave are in order)
-        build_geometry(0, roi_q, false);
+        if (!(dbg & 256)) build_geometry(0, roi_q, false);
     } else {
         const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)C * HW * sizeof(float)));
         float v[4][4];
@@ -1058,9 +1058,9 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int h = 3 * wave + i;
-            if (h < kQuadRows) {
+            if (h < kQuadRows && !(dbg & 1024)) {
                 img0[h * kQuadPitch + lane] = make_float4(v[i][0], v[i][1], v[i][2], v[i][3]);
-                img1[h * kQuadPitch + lane] = make_float4(frcnn_max_f32(t10[i][0], t10[i + 1][0]), frcnn_max_f32(t10[i][1], t10[i + 1][1]),
+                if (!(dbg & 512)) img1[h * kQuadPitch + lane] = make_float4(frcnn_max_f32(t10[i][0], t10[i + 1][0]), frcnn_max_f32(t10[i][1], t10[i + 1][1]),
                                                           frcnn_max_f32(t10[i][2], t10[i + 1][2]), frcnn_max_f32(t10[i][3], t10[i + 1][3]));
             }
         }

@@ -53,8 +53,13 @@ def main(out_dir, dtype):
     n, fb, wb = family(lambda s: s.startswith("roi_pool_cells_kernel"))
     summ["roi_pool_cells_kernel"] = {"launches_counted": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                                      "note": "4-byte-per-lane reads (1:1); algorithmic 4.90 MB read + 30.11 MB (fp32) / 15.05 MB (bf16) written"}
+    n, fb, wb = family(lambda s: s.startswith("roi_pool_quads_kernel"))
+    summ["roi_pool_quads_kernel"] = {"launches_counted": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                                     "note": "round 3 kernel: 4-byte-per-lane map reads (1:1; each map row is fetched by two workgroups + one halo row in "
+                                             "three), write-through 16-byte stores; algorithmic 4.90 MB read + 30.11 MB written"}
     out["_summary"] = summ
-    name = {"f32": "r02_hbm_traffic_pmc.json", "bf16": "r02_hbm_traffic_pmc_bf16.json", "f32s": "r02_hbm_traffic_pmc_f32s.json"}[dtype]
+    prefix = sys.argv[3] if len(sys.argv) > 3 else "r02"
+    name = {"f32": prefix + "_hbm_traffic_pmc.json", "bf16": prefix + "_hbm_traffic_pmc_bf16.json", "f32s": prefix + "_hbm_traffic_pmc_f32s.json"}[dtype]
     json.dump(out, open("%s/%s" % (out_dir, name), "w"), indent=1, sort_keys=True)
     print(json.dumps(summ, indent=1))
 
