@@ -53,7 +53,13 @@ def main(out_dir, dtype):
     n, fb, wb = family(lambda s: s.startswith("roi_pool_cells_kernel"))
     summ["roi_pool_cells_kernel"] = {"launches_counted": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                                      "note": "4-byte-per-lane reads (1:1); algorithmic 4.90 MB read + 30.11 MB (fp32) / 15.05 MB (bf16) written"}
-    n, fb, wb = family(lambda s: s.startswith("roi_pool_quads_kernel"))
+    n, fb, wb = family(lambda s: s.startswith("roi_pool_quads_kernel") and s.rstrip().endswith("true>"))
+    summ["roi_pool_quads_kernel_argmax"] = {"launches_counted": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
+                                            "note": "the training form: y and argmax_data written; algorithmic 4.90 MB read + 60.2 MB written"}
+    n, fb, wb = family(lambda s: s.startswith("roi_pool_bwd_planes_kernel"))
+    summ["roi_pool_bwd_planes_kernel"] = {"launches_counted": n, "fetch_bytes_per_launch_raw": fb, "fetch_bytes_per_launch_x2": 2 * fb, "write_bytes_per_launch": wb,
+                                          "note": "16-byte-per-lane reads of dy and argmax_data (FETCH_SIZE halves those: x2); algorithmic 60.2 MB read + 4.90 MB written"}
+    n, fb, wb = family(lambda s: s.startswith("roi_pool_quads_kernel") and s.rstrip().endswith("false>"))
     summ["roi_pool_quads_kernel"] = {"launches_counted": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb,
                                      "note": "round 3 kernel: 4-byte-per-lane map reads (1:1; each map row is fetched by two workgroups + one halo row in "
                                              "three), write-through 16-byte stores; algorithmic 4.90 MB read + 30.11 MB written"}
