@@ -87,11 +87,18 @@ __device__ __forceinline__ void frcnn_buf_load_lds_b128(frcnn_buf_t b, void *lds
 // same, 4 bytes per lane: 256 B per wave-instruction at lds_wave_base + 4 * lane
 __device__ __forceinline__ void frcnn_buf_load_lds_b32(frcnn_buf_t b, void *lds_wave_base, uint32_t byte_off, uint32_t soff) {
     const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_wave_base;
+#ifdef FRCNN_DMA_KEEP_M0
     uint32_t keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "s"(la), "v"(byte_off), "s"(b), "s"(soff)
                  : "memory");
+#else
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"       // M0 clobbered, as in the 16-byte form
+                 :
+                 : "s"(la), "v"(byte_off), "s"(b), "s"(soff)
+                 : "memory", "m0");
+#endif
 }
 template <int N>
 __device__ __forceinline__ void frcnn_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }

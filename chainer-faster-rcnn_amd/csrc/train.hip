@@ -428,8 +428,13 @@ conv_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy
 // 3.6 % SLOWER per training step than the single-buffer form at two workgroups per CU (see wgrad_double_buffered()).
 // One fence-less barrier per tile, no counted waits (a wave issues 80 DMAs per tile,
 // more than vmcnt can count: the wait for tile b+1 is the vmcnt(0) at the top of the next trip, a whole compute phase later).
-template <int KS, bool DB = false>
-__global__ void __launch_bounds__(256, DB ? 1 : 2)
+// WPS = workgroups per CU the single-buffer form is compiled for: 2 (171 VGPRs) or 3 (168 VGPRs: three dwords of the tile set-up live in
+// scratch and are re-read once per tile, nothing in the MFMA loop; 3 x 51.4 KB of LDS).  ABL (timing ablations, WRONG results, only in
+// -DFRCNN_TIMING_ABLATIONS builds): 1 no DMA, 4 no MFMA phase, 8 no slab stores.
+// PRIO: the workgroups that share a CU (launch order: linear id / #CUs) run their MFMA phase at different wave priorities, so that two
+// of them that reach the phase together do not split the matrix pipe evenly and then both wait for their DMAs together.
+template <int KS, bool DB = false, int WPS = 2, int ABL = 0, bool PRIO = false>
+__global__ void __launch_bounds__(256, DB ? 1 : WPS)
 conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slabs, int Cin, int Cout, int H, int W,
                       int xtiles, int nblocks, int splits) {
     constexpr int T = KS * KS, PAD = KS / 2;
@@ -469,23 +474,39 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
         // dy piece = both rows of one channel (64 floats): lane -> (row lane>>5, column lane&31)
         const int dgy = y0 + (lane >> 5), dgx = x0 + (lane & 31);
         const uint32_t vd = (dgy < H && dgx < W) ? (uint32_t)((lane >> 5) * W + (lane & 31)) * 4u : kBufOob;
+        if constexpr ((ABL & 1) != 0) return;
+        // a channel's HR x pieces under ONE exec mask (lanes < HP), then the dy pieces with every lane: as `if (lane < HP) dma` per piece
+        // every piece paid an exec save / branch / restore of its own.  (The scalar row offsets are made uniform OUTSIDE the masked
+        // region: a wave collective inside it would not see every lane.)
 #pragma unroll 1
         for (int q = 0; q < 16; ++q) {
             const int c = wave + 4 * q;
-            const int gc = ci0 + c, gco = co0 + c;
+            const int gc = ci0 + c;
+            uint32_t so[HR];
+            bool row_ok[HR];
 #pragma unroll
             for (int hr = 0; hr < HR; ++hr) {
                 const int gy = y0 - PAD + hr;
-                const bool row_ok = gc < Cin && gy >= 0 && gy < H;              // wave-uniform
-                const uint32_t so = row_ok ? (uint32_t)(((size_t)gc * H + gy) * W + xs) * 4u : 0u;
-                if (lane < HP) frcnn_buf_load_lds_b32(xbuf, &x_lds[buf][c * CHP + hr * HP], row_ok ? vx : kBufOob, so);
+                row_ok[hr] = gc < Cin && gy >= 0 && gy < H;                       // wave-uniform
+                so[hr] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(row_ok[hr] ? (uint32_t)(((size_t)gc * H + gy) * W + xs) * 4u : 0u));
             }
+            if (lane < HP) {
+#pragma unroll
+                for (int hr = 0; hr < HR; ++hr)
+                    frcnn_buf_load_lds_b32(xbuf, &x_lds[buf][c * CHP + hr * HP], row_ok[hr] ? vx : kBufOob, so[hr]);
+            }
+        }
+#pragma unroll 1
+        for (int q = 0; q < 16; ++q) {
+            const int c = wave + 4 * q;
+            const int gco = co0 + c;
             const bool ch_ok = gco < Cout && y0 < H;
-            const uint32_t so = ch_ok ? (uint32_t)(((size_t)gco * H + y0) * W + x0) * 4u : 0u;
+            const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ch_ok ? (uint32_t)(((size_t)gco * H + y0) * W + x0) * 4u : 0u));
             frcnn_buf_load_lds_b32(dbuf, &dy_lds[buf][c * DP], ch_ok ? vd : kBufOob, so);
         }
     };
     auto compute = [&](int buf) {
+        if constexpr ((ABL & 4) != 0) return;
         const float *xa = x_lds[buf] + (wci * 32 + l31) * CHP + khalf;
         const float *db = dy_lds[buf] + (wco * 32 + l31) * DP + khalf;
         // step s = (row r, pixel pair pp): one dy value and the T shifted x values feed T MFMAs; the fragments of step s+1 are
@@ -511,6 +532,7 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
             for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][t], bv[1], acc[t], 0, 0, 0);
         }
     };
+    const int prio_class = PRIO ? (int)((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) / 256u) % WPS : 0;
     if constexpr (DB) {
         if (b_begin < b_end) issue(b_begin, 0);
         int buf = 0;
@@ -527,9 +549,12 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
             issue(b, 0);
             frcnn_wait_vmcnt<0>();
             frcnn_barrier_nofence();
+            if constexpr (PRIO) { if (prio_class == 0) __builtin_amdgcn_s_setprio(2); else if (prio_class == 1) __builtin_amdgcn_s_setprio(1); }
             compute(0);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
     }
+    if constexpr ((ABL & 8) != 0) { if (acc[0][0] != 12345.678f) return; }
     float *slab = slabs + (size_t)split * ((size_t)Cin * T * Cout);
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -869,6 +894,13 @@ static bool wgrad_double_buffered() {
     return e && e[0] == '1';
 }
 
+// workgroups per CU of the single-buffer 3x3 kernel (FRCNN_WGRAD_WPS=2|3: A/B hook; the default is the measured pick)
+static int wgrad_wgs_per_cu() {
+    const char *e = getenv("FRCNN_WGRAD_WPS");
+    if (e && (e[0] == '2' || e[0] == '3')) return e[0] - '0';
+    return 2;
+}
+
 static WgradPlan plan_wgrad(int Cin, int Cout, int H, int W, int ks) {
     WgradPlan p;
     p.xtiles = frcnn_cdiv(W, 32);
@@ -876,7 +908,7 @@ static WgradPlan plan_wgrad(int Cin, int Cout, int H, int W, int ks) {
     p.ci_tiles = frcnn_cdiv(Cin, 64);
     p.co_tiles = frcnn_cdiv(Cout, 64);
     // 3x3 double-buffered kernel: one workgroup per CU; the single-buffer forms (1x1, FRCNN_WGRAD_DB=0): about two per CU
-    int s = frcnn_cdiv((ks == 3 && wgrad_double_buffered()) ? frcnn_cu_count() : 2 * frcnn_cu_count(), p.ci_tiles * p.co_tiles);
+    int s = frcnn_cdiv((ks == 3 && wgrad_double_buffered()) ? frcnn_cu_count() : (ks == 3 ? wgrad_wgs_per_cu() : 2) * frcnn_cu_count(), p.ci_tiles * p.co_tiles);
     if (s > p.nblocks) s = p.nblocks;
     if (s < 1) s = 1;
     p.splits = s;
@@ -1064,7 +1096,25 @@ int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int 
     const dim3 grid(p.ci_tiles, p.co_tiles, p.splits);
     const bool reg = getenv("FRCNN_WGRAD_REG") != nullptr;        // A/B hook: the register-staged kernel
     if (ksize == 3 && !reg && wgrad_double_buffered()) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
-    else if (ksize == 3 && !reg) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
+    else if (ksize == 3 && !reg) {
+#define FRCNN_WGRAD_LAUNCH(WPS_, ABL_) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, WPS_, ABL_>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits)
+        const bool three = wgrad_wgs_per_cu() == 3;
+#ifdef FRCNN_TIMING_ABLATIONS
+        const char *ae = getenv("FRCNN_WGRAD_ABL");
+        const int abl = ae ? atoi(ae) : 0;
+        if (abl == 1) { if (three) FRCNN_WGRAD_LAUNCH(3, 1); else FRCNN_WGRAD_LAUNCH(2, 1); }
+        else if (abl == 4) { if (three) FRCNN_WGRAD_LAUNCH(3, 4); else FRCNN_WGRAD_LAUNCH(2, 4); }
+        else if (abl == 8) { if (three) FRCNN_WGRAD_LAUNCH(3, 8); else FRCNN_WGRAD_LAUNCH(2, 8); }
+        else if (abl == 5) { if (three) FRCNN_WGRAD_LAUNCH(3, 5); else FRCNN_WGRAD_LAUNCH(2, 5); }
+        else
+#endif
+        if (getenv("FRCNN_WGRAD_PRIO") != nullptr) {               // A/B hook
+            if (three) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, 3, 0, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, 2, 0, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
+        } else
+        if (three) FRCNN_WGRAD_LAUNCH(3, 0); else FRCNN_WGRAD_LAUNCH(2, 0);
+#undef FRCNN_WGRAD_LAUNCH
+    }
     else if (ksize == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<3>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
     else if (!reg) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<1>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<1>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);

@@ -61,7 +61,7 @@ class HostMemory(object):
     def join_side_stream(self):
         pass
 
-    def early_stream(self):
+    def early_stream(self, *after):                      # runtime.py: the side stream waits for the producers of `after`; the host runs in order
         import contextlib
         return contextlib.nullcontext()
 
