@@ -58,7 +58,15 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
     constexpr int BCO = 32 * ACO * WCO;
     constexpr int BROWS = APX * WPX;
     constexpr int TAPS = KS * KS, PAD = KS / 2;
-    constexpr int kHaloPitch = 32 + KS - 1;          // 32 pixels + left/right halo
+    // HB (the LDS-DMA form of the 3x3 kernels): the halo travels as 16-BYTE pieces.  A `buffer_load ... lds` costs the SIMD that issues it
+    // about 60 clocks of matrix-pipe time whatever it moves (r03 ablations: DESIGN 3.1), so the 4-byte form -- one lane per halo pixel,
+    // 9 pieces per 4-channel chunk -- spent a fifth of the kernel on DMA issue.  Here a lane moves FOUR pixels: a halo row is the ten
+    // aligned groups x0-4 .. x0+35 (pitch 40 floats, the tile's own halo starts at float 3), 2.5 pieces per chunk.  Sources need only
+    // 4-byte alignment and the range check is per dword (scripts/micro/dma_align_micro.hip).  A group that straddles the right image
+    // border (W % 4 != 0) brings up to three floats of the NEXT row along: the border tiles zero them after the chunk has landed.
+    constexpr bool HB = DMA && KS == 3;
+    constexpr int kHaloPitch = HB ? 40 : 32 + KS - 1;   // 32 pixels + left/right halo
+    constexpr int kHaloLead = HB ? 3 : 0;              // floats in front of halo column 0
     constexpr int HR = BROWS + KS - 1;
     constexpr int KR = CK * TAPS;
     constexpr int WV = KR * BCO / 4;                 // float4s of weights per chunk
@@ -67,7 +75,9 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
     constexpr int HIT = (HV + NT - 1) / NT;
     constexpr int FRAG = ACO * APX * 16;             // accumulator floats per thread
     __shared__ __attribute__((aligned(16))) float w_lds[2][KR][BCO];
-    constexpr int HVP = (HV + 63) / 64 * 64;          // a buffer holds whole 64-float DMA pieces (the tail lanes deposit zeros)
+    constexpr int HG = HV / 4;                        // HB: 16-byte groups per chunk
+    constexpr int HIT4 = (HG + NT - 1) / NT;
+    constexpr int HVP = HB ? (HG + 63) / 64 * 256 : (HV + 63) / 64 * 64;   // a buffer holds whole DMA pieces (the tail lanes deposit zeros)
     __shared__ __attribute__((aligned(16))) float in_lds[2][HVP];
     __shared__ int s_ticket;
 
@@ -130,6 +140,17 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
             const int row = v / (BCO / 4), c4 = v % (BCO / 4);
             woff[q] = (v < WV) ? (uint32_t)(row * Cout + co0 + c4 * 4) * 4u : kBufOob;
         }
+        if constexpr (HB) {
+#pragma unroll
+            for (int q = 0; q < HIT4; ++q) {                         // group e4 = (channel, halo row, group of four columns)
+                const int e4 = tid + q * NT;
+                const int c = e4 / (HR * 10), rem = e4 % (HR * 10);
+                const int hr = rem / 10, g4 = rem % 10;
+                const int gy = y0 - PAD + hr, gx = x0 - 4 + 4 * g4;
+                const bool inside = e4 < HG && gy >= 0 && gy < H && gx >= 0 && gx < W;
+                hoff[q] = inside ? (uint32_t)(c * HW + gy * W + gx) * 4u : kBufOob;
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < HIT; ++q) {
             const int e = tid + q * NT;
@@ -139,6 +160,15 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
             const bool inside = e < HV && gy >= 0 && gy < H && gx >= 0 && gx < W;
             hoff[q] = inside ? (uint32_t)(c * HW + gy * W + gx) * 4u : kBufOob;
         }
+        }
+        // HB: first float of a halo row that lies beyond the image although its 16-byte group started inside it (0 = none in this tile)
+        const int fix_lo = W - x0 + 4, fix_hi = (fix_lo + 3) & ~3;
+        const bool edge_fix = HB && (W & 3) != 0 && fix_lo > 0 && fix_lo < kHaloPitch;
+        auto edge_zero = [&](int buf) {                               // CK x HR rows, up to three floats each
+            const int row = tid / 3, i = fix_lo + tid % 3;
+            if (row < CK * HR && i < fix_hi) in_lds[buf][row * kHaloPitch + i] = 0.0f;
+            frcnn_barrier_nofence();
+        };
         auto fetch = [&](int chunk) {
             const uint32_t wb = (uint32_t)chunk * w_chunk_bytes, xb = (uint32_t)chunk * x_chunk_bytes;
 #pragma unroll
@@ -171,10 +201,17 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
                 for (int q = 0; q < WIT; ++q)
                     if ((q + 1) * NT <= WV || wave * 64 + q * NT < WV)
                         frcnn_buf_load_lds_b128(wbuf, reinterpret_cast<float4 *>(&w_lds[buf][0][0]) + q * NT + wave * 64, woff[q], wb);
+                if constexpr (HB) {
+#pragma unroll
+                    for (int q = 0; q < HIT4; ++q)
+                        if ((q + 1) * NT * 4 <= HVP || (wave * 64 + q * NT) * 4 < HVP)
+                            frcnn_buf_load_lds_b128(xbuf, &in_lds[buf][(q * NT + wave * 64) * 4], hoff[q], xb);
+                } else {
 #pragma unroll
                 for (int q = 0; q < HIT; ++q)
                     if ((q + 1) * NT <= HVP || wave * 64 + q * NT < HVP)
                         frcnn_buf_load_lds_b32(xbuf, &in_lds[buf][q * NT + wave * 64], hoff[q], xb);
+                }
                 return;
             }
             const long long wrem = (long long)(K - chunk * KR) * Cout, xrem = (long long)(Cin - chunk * CK) * HW;
@@ -184,10 +221,17 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
             for (int q = 0; q < WIT; ++q)
                 if ((q + 1) * NT <= WV || wave * 64 + q * NT < WV)
                     frcnn_buf_load_lds_b128(wb_c, reinterpret_cast<float4 *>(&w_lds[buf][0][0]) + q * NT + wave * 64, woff[q], 0);
+            if constexpr (HB) {
+#pragma unroll
+                for (int q = 0; q < HIT4; ++q)
+                    if ((q + 1) * NT * 4 <= HVP || (wave * 64 + q * NT) * 4 < HVP)
+                        frcnn_buf_load_lds_b128(xb_c, &in_lds[buf][(q * NT + wave * 64) * 4], hoff[q], 0);
+            } else {
 #pragma unroll
             for (int q = 0; q < HIT; ++q)
                 if ((q + 1) * NT <= HVP || wave * 64 + q * NT < HVP)
                     frcnn_buf_load_lds_b32(xb_c, &in_lds[buf][q * NT + wave * 64], hoff[q], 0);
+            }
         };
 
         f32x16 acc[ACO][APX];
@@ -202,6 +246,7 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
             issue(c_begin, 0);
             frcnn_wait_vmcnt<0>();
             frcnn_barrier_nofence();
+            if (edge_fix) edge_zero(0);
         } else {
             fetch(c_begin);
             stage(0);
@@ -215,10 +260,15 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
             }
             if (!DMA && more && ABL == 0) fetch(chunk + 1);
             constexpr int NSTEP = TAPS * (CK / 2);       // k-steps per chunk: step s = (tap, channel pair)
+            // The lane-dependent part of every fragment address (its half's channel, its column) is folded into two bases per chunk;
+            // what a step adds is a compile-time constant and rides in the ds_read offset field.  (Written as one index expression the
+            // compiler kept a base per (channel pair, tap row) and spent a v_add3_u32 per pair of reads -- and every VALU instruction
+            // between two v_mfma_f32_32x32x2_f32 costs the matrix pipe ~9 clocks: scripts/micro/mfma_dma_micro.hip.)
+            const float *a_base = &w_lds[cur][khalf * TAPS][a_col];
+            const float *b_base = &in_lds[cur][(khalf * HR + b_row) * kHaloPitch + kHaloLead + l31];
             auto frag = [&](int s, float *a, float *b) {
                 const int tap = s / (CK / 2), cp = s % (CK / 2);
                 const int ky = tap / KS, kx = tap % KS;
-                const int c = 2 * cp + khalf;
                 if constexpr (ABL == 3) {       // timing ablation only: operands from registers
 #pragma unroll
                     for (int i = 0; i < ACO; ++i) a[i] = (float)(lane + s + i);
@@ -227,9 +277,9 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
                     return;
                 }
 #pragma unroll
-                for (int i = 0; i < ACO; ++i) a[i] = w_lds[cur][c * TAPS + tap][a_col + 32 * i];
+                for (int i = 0; i < ACO; ++i) a[i] = a_base[(2 * cp * TAPS + tap) * BCO + 32 * i];
 #pragma unroll
-                for (int j = 0; j < APX; ++j) b[j] = in_lds[cur][(c * HR + b_row + j + ky) * kHaloPitch + l31 + kx];
+                for (int j = 0; j < APX; ++j) b[j] = b_base[(2 * cp * HR + j + ky) * kHaloPitch + kx];
             };
             if constexpr (PIPE) {
                 // fragments of step s+1 are read before the MFMAs of step s are issued (register double
@@ -261,6 +311,7 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
             if constexpr (DMA) {
                 frcnn_wait_vmcnt<0>();           // chunk + 1 has landed (nothing else is in flight)
                 frcnn_barrier_nofence();         // ... for everybody, and everybody is done reading buffer `cur`
+                if (edge_fix && more) edge_zero(cur ^ 1);
             } else {
                 if (more && ABL == 0) stage(cur ^ 1);
                 if (ABL < 2) __syncthreads();

@@ -94,9 +94,11 @@ __device__ __forceinline__ void frcnn_buf_load_lds_b32(frcnn_buf_t b, void *lds_
                  : "s"(la), "v"(byte_off), "s"(b), "s"(soff)
                  : "memory");
 #else
+    // (la / soff are wave-uniform by contract; inside a divergent region the compiler may still hold them in VGPRs, and the "s"
+    // constraint does not move them back: readfirstlane does, and folds away where the value already is scalar)
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds"       // M0 clobbered, as in the 16-byte form
                  :
-                 : "s"(la), "v"(byte_off), "s"(b), "s"(soff)
+                 : "s"(__builtin_amdgcn_readfirstlane((int)la)), "v"(byte_off), "s"(b), "s"(__builtin_amdgcn_readfirstlane((int)soff))
                  : "memory", "m0");
 #endif
 }

@@ -436,7 +436,7 @@ conv_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy
 template <int KS, bool DB = false, int WPS = 2, int ABL = 0, bool PRIO = false>
 __global__ void __launch_bounds__(256, DB ? 1 : WPS)
 conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slabs, int Cin, int Cout, int H, int W,
-                      int xtiles, int nblocks, int splits) {
+                      int xtiles, int nblocks, int splits, int prio_mode) {
     constexpr int T = KS * KS, PAD = KS / 2;
     constexpr int HP = 32 + KS - 1;
     constexpr int HR = WG_ROWS + KS - 1;
@@ -463,50 +463,93 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
 
     static_assert(WG_ROWS == 2, "a dy piece is the two 32-pixel rows of one channel");
     // DMA of tile b into LDS image `buf`: wave w moves channels w, w+4, ... (16 channels: HR x rows + 1 dy piece each)
-    auto issue = [&](int b, int buf) {
+    // DMA of a tile into LDS image `buf`: wave w moves channels w, w+4, ... (16 channels: HR x rows + 1 dy piece each).  issue_setup(b)
+    // fixes the per-lane parts for tile b, issue_channel(q, buf) moves the wave's q-th channel, issue(b, buf) = all of it at once.
+    int t_x0 = 0, t_y0 = 0, t_xs = 0;
+    uint32_t t_vx = kBufOob, t_vd = kBufOob;
+    auto issue_setup = [&](int b) {
         const int tx = b % xtiles, ty = b / xtiles;
-        const int x0 = tx * 32, y0 = ty * WG_ROWS;
+        t_x0 = tx * 32; t_y0 = ty * WG_ROWS;
         // per-lane parts, fixed for the tile.  x piece = one halo row of one channel (HP floats: lanes >= HP sit it out), columns
         // x0-PAD .. x0+32+PAD-1; the scalar row base points at column xs = max(x0-PAD, 0) so no offset is ever negative.
-        const int xs = x0 - PAD > 0 ? x0 - PAD : 0;
-        const int gx = x0 - PAD + lane;
-        const uint32_t vx = (lane < HP && gx >= 0 && gx < W) ? (uint32_t)(gx - xs) * 4u : kBufOob;
+        t_xs = t_x0 - PAD > 0 ? t_x0 - PAD : 0;
+        const int gx = t_x0 - PAD + lane;
+        t_vx = (lane < HP && gx >= 0 && gx < W) ? (uint32_t)(gx - t_xs) * 4u : kBufOob;
         // dy piece = both rows of one channel (64 floats): lane -> (row lane>>5, column lane&31)
-        const int dgy = y0 + (lane >> 5), dgx = x0 + (lane & 31);
-        const uint32_t vd = (dgy < H && dgx < W) ? (uint32_t)((lane >> 5) * W + (lane & 31)) * 4u : kBufOob;
+        const int dgy = t_y0 + (lane >> 5), dgx = t_x0 + (lane & 31);
+        t_vd = (dgy < H && dgx < W) ? (uint32_t)((lane >> 5) * W + (lane & 31)) * 4u : kBufOob;
+    };
+    // a channel's HR x pieces under ONE exec mask (lanes < HP), then its dy piece with every lane: as `if (lane < HP) dma` per piece
+    // every piece paid an exec save / branch / restore of its own.  (The scalar row offsets are made uniform OUTSIDE the masked
+    // region: a wave collective inside it would not see every lane.)
+    auto issue_channel = [&](int q, int buf) __attribute__((always_inline)) {
         if constexpr ((ABL & 1) != 0) return;
-        // a channel's HR x pieces under ONE exec mask (lanes < HP), then the dy pieces with every lane: as `if (lane < HP) dma` per piece
-        // every piece paid an exec save / branch / restore of its own.  (The scalar row offsets are made uniform OUTSIDE the masked
-        // region: a wave collective inside it would not see every lane.)
-#pragma unroll 1
-        for (int q = 0; q < 16; ++q) {
-            const int c = wave + 4 * q;
-            const int gc = ci0 + c;
-            uint32_t so[HR];
-            bool row_ok[HR];
+        const int c = wave + 4 * q;
+        const int gc = ci0 + c, gco = co0 + c;
+        uint32_t so[HR];
+        bool row_ok[HR];
 #pragma unroll
-            for (int hr = 0; hr < HR; ++hr) {
-                const int gy = y0 - PAD + hr;
-                row_ok[hr] = gc < Cin && gy >= 0 && gy < H;                       // wave-uniform
-                so[hr] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(row_ok[hr] ? (uint32_t)(((size_t)gc * H + gy) * W + xs) * 4u : 0u));
-            }
+        for (int hr = 0; hr < HR; ++hr) {
+            const int gy = t_y0 - PAD + hr;
+            row_ok[hr] = gc < Cin && gy >= 0 && gy < H;                       // wave-uniform
+            so[hr] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(row_ok[hr] ? (uint32_t)(((size_t)gc * H + gy) * W + t_xs) * 4u : 0u));
+        }
+        if (lane < HP) {
+#pragma unroll
+            for (int hr = 0; hr < HR; ++hr)
+                frcnn_buf_load_lds_b32(xbuf, &x_lds[buf][c * CHP + hr * HP], row_ok[hr] ? t_vx : kBufOob, so[hr]);
+        }
+        const bool ch_ok = gco < Cout && t_y0 < H;
+        const uint32_t sd = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ch_ok ? (uint32_t)(((size_t)gco * H + t_y0) * W + t_x0) * 4u : 0u));
+        frcnn_buf_load_lds_b32(dbuf, &dy_lds[buf][c * DP], ch_ok ? t_vd : kBufOob, sd);
+    };
+    // Lean form for workgroups whose 64 + 64 channels all exist (every VGG layer but conv1_1): nothing per piece but the LDS address, the
+    // scalar offset and the DMA itself.  Row validity is folded into one per-lane offset per halo row, once per tile (an invalid row's
+    // lanes are all out of range, so its scalar offset may be anything); the x pieces run under ONE exec mask, the dy pieces after them.
+    // (The general form spends ~11 instructions, 1.6 branches and a v_cndmask per piece; the issue stream is what the DMA phase costs.)
+    const bool full_tile = ci0 + 64 <= Cin && co0 + 64 <= Cout;
+    auto issue_lean = [&](int b, int buf) {
+        if constexpr ((ABL & 1) != 0) return;
+        issue_setup(b);
+        uint32_t vxr[HR];
+#pragma unroll
+        for (int hr = 0; hr < HR; ++hr) {
+            const int gy = t_y0 - PAD + hr;
+            vxr[hr] = (gy >= 0 && gy < H) ? t_vx : kBufOob;
+        }
+        const uint32_t chan_bytes = (uint32_t)HWs * 4u;
+        // 32-bit wrap-around is fine: a row above the image has no in-range lane, and row hr >= 1 adds hr * W * 4 back
+        uint32_t sx = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(((ci0 + wave) * H + t_y0 - PAD) * W + t_xs) * 4u));
+        uint32_t sd = (uint32_t)__builtin_amdgcn_readfirstlane((int)((uint32_t)(((co0 + wave) * H + t_y0) * W + t_x0) * 4u));
+        float *xl = &x_lds[buf][wave * CHP];
+        float *dl = &dy_lds[buf][wave * DP];
+#pragma unroll 4
+        for (int q = 0; q < 16; ++q) {
+            uint32_t so[HR];                                       // made uniform OUTSIDE the masked region (see issue_channel)
+#pragma unroll
+            for (int hr = 0; hr < HR; ++hr) so[hr] = (uint32_t)__builtin_amdgcn_readfirstlane((int)(sx + (uint32_t)(q * 4) * chan_bytes + (uint32_t)(hr * W) * 4u));
             if (lane < HP) {
 #pragma unroll
-                for (int hr = 0; hr < HR; ++hr)
-                    frcnn_buf_load_lds_b32(xbuf, &x_lds[buf][c * CHP + hr * HP], row_ok[hr] ? vx : kBufOob, so[hr]);
+                for (int hr = 0; hr < HR; ++hr) frcnn_buf_load_lds_b32(xbuf, xl + q * 4 * CHP + hr * HP, vxr[hr], so[hr]);
             }
-        }
-#pragma unroll 1
-        for (int q = 0; q < 16; ++q) {
-            const int c = wave + 4 * q;
-            const int gco = co0 + c;
-            const bool ch_ok = gco < Cout && y0 < H;
-            const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ch_ok ? (uint32_t)(((size_t)gco * H + y0) * W + x0) * 4u : 0u));
-            frcnn_buf_load_lds_b32(dbuf, &dy_lds[buf][c * DP], ch_ok ? vd : kBufOob, so);
+            frcnn_buf_load_lds_b32(dbuf, dl + q * 4 * DP, t_vd, (uint32_t)__builtin_amdgcn_readfirstlane((int)(sd + (uint32_t)(q * 4) * chan_bytes)));
         }
     };
-    auto compute = [&](int buf) {
-        if constexpr ((ABL & 4) != 0) return;
+    auto issue = [&](int b, int buf) {
+        if (full_tile) { issue_lean(b, buf); return; }
+        issue_setup(b);
+#pragma unroll 1
+        for (int q = 0; q < 16; ++q) issue_channel(q, buf);
+    };
+    // `stream_next`: the NEXT tile's DMAs (set up by issue_setup) are issued from inside this tile's MFMA stream, two channels per pair
+    // of steps over the first half of the tile.  A wave that issues v_mfma_f32_32x32x2_f32 back to back leaves the other waves of its
+    // SIMD no issue slot at all (scripts/micro/mfma_dma_micro.hip: not one instruction of a co-resident wave in 2.3 M clocks), so a
+    // second workgroup cannot load while this one multiplies -- but the wave's OWN next instruction issues in the shadow of its MFMA.
+    auto compute = [&](int buf, bool stream_next, int nbuf) {
+        if constexpr ((ABL & 4) != 0) {
+            if (stream_next) for (int q = 0; q < 16; ++q) issue_channel(q, nbuf);
+            return;
+        }
         const float *xa = x_lds[buf] + (wci * 32 + l31) * CHP + khalf;
         const float *db = dy_lds[buf] + (wco * 32 + l31) * DP + khalf;
         // step s = (row r, pixel pair pp): one dy value and the T shifted x values feed T MFMAs; the fragments of step s+1 are
@@ -520,27 +563,45 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
             for (int t = 0; t < T; ++t) a[t] = xa[(r + t / KS) * HP + 2 * pp + t % KS];
         };
         frag(0, av[0], bv[0]);
-#pragma unroll 1
+        // fully unrolled: every fragment address is the tile base plus a constant in the ds_read offset field (as a loop each pair of
+        // steps paid four v_add_u32 and a dozen scalar instructions for its addresses)
+#pragma unroll
         for (int s = 0; s < NSTEP; s += 2) {
             frag(s + 1, av[1], bv[1]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][t], bv[0], acc[t], 0, 0, 0);
+            if (stream_next && s < NSTEP / 2) {
+                issue_channel(s, nbuf);
+                issue_channel(s + 1, nbuf);
+            }
             if (s + 2 < NSTEP) frag(s + 2, av[0], bv[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][t], bv[1], acc[t], 0, 0, 0);
         }
     };
-    const int prio_class = PRIO ? (int)((blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) / 256u) % WPS : 0;
+    // class of this wave among the waves that share its SIMD = its hardware wave slot (HW_ID[3:0]); FRCNN_WGRAD_PRIO=2 staggers the
+    // classes once at the start instead (class k sleeps k x 8k clocks), =3 does both
+    int prio_class = 0;
+    if constexpr (PRIO) {
+        prio_class = (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) % (unsigned)WPS);
+        if ((prio_mode & 2) != 0) for (int k = 0; k < prio_class; ++k) __builtin_amdgcn_s_sleep(127);
+    }
     if constexpr (DB) {
         if (b_begin < b_end) issue(b_begin, 0);
         int buf = 0;
         for (int b = b_begin; b < b_end; ++b) {
             frcnn_wait_vmcnt<0>();                                // tile b's pieces of THIS wave have landed ...
             frcnn_barrier_nofence();                              // ... everybody's have, and everybody is done with tile b-1's image
-            if (b + 1 < b_end) issue(b + 1, buf ^ 1);
-            compute(buf);
+            const bool nxt = b + 1 < b_end;
+            if ((prio_mode & 4) != 0) {                          // DMA issue inside the MFMA stream
+                if (nxt) issue_setup(b + 1);
+                compute(buf, nxt, buf ^ 1);
+            } else {
+                if (nxt) issue(b + 1, buf ^ 1);
+                compute(buf, false, 0);
+            }
             buf ^= 1;
         }
     } else {
@@ -549,8 +610,8 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
             issue(b, 0);
             frcnn_wait_vmcnt<0>();
             frcnn_barrier_nofence();
-            if constexpr (PRIO) { if (prio_class == 0) __builtin_amdgcn_s_setprio(2); else if (prio_class == 1) __builtin_amdgcn_s_setprio(1); }
-            compute(0);
+            if constexpr (PRIO) { if ((prio_mode & 1) != 0) { if (prio_class == 0) __builtin_amdgcn_s_setprio(2); else if (prio_class == 1) __builtin_amdgcn_s_setprio(1); } }
+            compute(0, false, 0);
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
     }
@@ -564,6 +625,98 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
             const int co = co0 + wco * 32 + l31;
             if (ci < Cin && co < Cout) slab[((size_t)ci * T + t) * Cout + co] = acc[t][r];
         }
+}
+
+// First-layer form of the weight gradient (conv1_1: Cin * 9 <= 32).  The generic kernel above pads the 3 input channels to a 64-channel
+// tile and spends 21 of every 22 MFMA rows on zeros: 425 us for 2 GFLOP at 600 x 1000, more than any 44-GFLOP layer.  Here the MFMA's 32
+// A rows ARE the (channel, tap) pairs -- row m = ci * 9 + tap, exactly dWp's row index -- so one MFMA per 32 output channels and pixel
+// pair does all nine taps of all three channels: lane l supplies x[ci][y + ky - 1][x + kx - 1] from ITS OWN (ci, ky, kx) offset into the
+// halo image (one ds_read_b32), B is the dy fragment of the generic kernel.  A workgroup (4 waves) walks tiles of 2 rows x 32 px; each
+// wave takes a quarter of a tile's 32 pixel pairs with two accumulators (64 output channels); the four waves' sums meet in LDS in wave
+// order (deterministic), one slab per workgroup, wgrad_reduce_kernel as before.  The job is then bound by reading dy once (154 MB).
+__global__ void __launch_bounds__(256, 4)
+conv1_wgrad_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slabs, int Cin, int Cout, int H, int W,
+                   int xtiles, int nblocks, int splits) {
+    constexpr int KS = 3, T = 9, PAD = 1;
+    constexpr int HP = 32 + KS - 1, HR = WG_ROWS + KS - 1;
+    constexpr int CHP = HR * HP + 1, DP = WG_ROWS * 32 + 1;
+    __shared__ float x_lds[3 * CHP];
+    __shared__ float dy_lds[64 * DP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, khalf = lane >> 5;
+    const int co0 = blockIdx.y * 64, split = blockIdx.x;
+    const int b_begin = (int)((long long)split * nblocks / splits), b_end = (int)((long long)(split + 1) * nblocks / splits);
+    const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)Cin * H * W * sizeof(float)));
+    const frcnn_buf_t dbuf = frcnn_make_buf(dy, (uint32_t)((size_t)Cout * H * W * sizeof(float)));
+    const int rows_m = Cin * T;                             // valid A rows (27)
+    const int m_ci = l31 < rows_m ? l31 / T : 0, m_tap = l31 < rows_m ? l31 % T : 0;
+    const int a_off = m_ci * CHP + (m_tap / KS) * HP + m_tap % KS + khalf;     // rows >= rows_m read channel 0: their D rows are never stored
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    for (int b = b_begin; b < b_end; ++b) {
+        const int tx = b % xtiles, ty = b / xtiles;
+        const int x0 = tx * 32, y0 = ty * WG_ROWS;
+        if (b != b_begin) frcnn_barrier_nofence();                // every wave is done reading the previous tile
+        // x pieces: (channel, halo row) pairs, Cin * HR of them, wave w takes w, w + 4, ...; dy pieces: channel w, w + 4, ...
+        const int xs = x0 - PAD > 0 ? x0 - PAD : 0;
+        const int gx = x0 - PAD + lane;
+        const uint32_t vx = (lane < HP && gx >= 0 && gx < W) ? (uint32_t)(gx - xs) * 4u : kBufOob;
+        const int dgy = y0 + (lane >> 5), dgx = x0 + (lane & 31);
+        const uint32_t vd = (dgy < H && dgx < W) ? (uint32_t)((lane >> 5) * W + (lane & 31)) * 4u : kBufOob;
+        for (int pc = wave; pc < Cin * HR; pc += 4) {
+            const int c = pc / HR, hr = pc - c * HR;
+            const int gy = y0 - PAD + hr;
+            const bool row_ok = gy >= 0 && gy < H;
+            const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((int)(row_ok ? (uint32_t)(((size_t)c * H + gy) * W + xs) * 4u : 0u));
+            if (lane < HP) frcnn_buf_load_lds_b32(xbuf, &x_lds[c * CHP + hr * HP], row_ok ? vx : kBufOob, so);
+        }
+#pragma unroll 1
+        for (int q = 0; q < 16; ++q) {
+            const int c = wave + 4 * q;
+            const bool ch_ok = co0 + c < Cout && y0 < H;
+            const uint32_t so = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ch_ok ? (uint32_t)(((size_t)(co0 + c) * H + y0) * W + x0) * 4u : 0u));
+            frcnn_buf_load_lds_b32(dbuf, &dy_lds[c * DP], ch_ok ? vd : kBufOob, so);
+        }
+        frcnn_wait_vmcnt<0>();
+        frcnn_barrier_nofence();
+        // this wave's eight pixel pairs: steps 8 * wave .. + 7 of the tile's 32 (row r = s >> 4, pair pp = s & 15)
+        const float *xa = x_lds + a_off;
+        const float *d0 = dy_lds + l31 * DP + khalf, *d1 = dy_lds + (32 + l31) * DP + khalf;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int st = wave * 8 + i, r = st >> 4, pp = st & 15;
+            const float av = xa[r * HP + 2 * pp], b0 = d0[r * 32 + 2 * pp], b1 = d1[r * 32 + 2 * pp];
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc[1], 0, 0, 0);
+        }
+    }
+    // the four waves' partial sums, added in wave order in LDS ([32 rows][64 couts] over the dy image), then one slab per workgroup
+    float *red = dy_lds;
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * khalf;
+                    float *cell = red + m * 64 + j * 32 + l31;
+                    *cell = (w == 0 ? 0.0f : *cell) + acc[j][r];
+                }
+        }
+    }
+    __syncthreads();
+    float *slab = slabs + (size_t)split * ((size_t)rows_m * Cout);
+    for (int e = tid; e < rows_m * 64; e += 256) {
+        const int m = e >> 6, c = e & 63;
+        if (co0 + c < Cout) slab[(size_t)m * Cout + co0 + c] = red[m * 64 + c];
+    }
 }
 
 // The same weight gradient on the bf16 matrix cores with fp32-class results (conv_f32s.hip's scheme: every fp32 value carried as
@@ -889,10 +1042,11 @@ struct WgradPlan { int xtiles, nblocks, splits, ci_tiles, co_tiles; size_t slab_
 // FRCNN_WGRAD_DB=1 selects the double-buffered 3x3 kernel (one workgroup per CU).  Measured on MI355X (r02, bench.py --mode train):
 // 12.03 ms / step vs 11.61 ms for the single-buffer kernel at two workgroups per CU -- one wave per SIMD does not keep the fp32
 // matrix pipe fed even with its loads hidden; the second wave does more than the overlap.  So it is NOT the default.
-static bool wgrad_double_buffered() {
+static int wgrad_db_mode() {                                      // 0 single buffer, 1 double buffer (DMAs ahead of the MFMAs), 2 DMAs inside the MFMA stream
     const char *e = getenv("FRCNN_WGRAD_DB");
-    return e && e[0] == '1';
+    return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
 }
+static bool wgrad_double_buffered() { return wgrad_db_mode() != 0; }
 
 // workgroups per CU of the single-buffer 3x3 kernel (FRCNN_WGRAD_WPS=2|3: A/B hook; the default is the measured pick)
 static int wgrad_wgs_per_cu() {
@@ -901,12 +1055,26 @@ static int wgrad_wgs_per_cu() {
     return 2;
 }
 
+// conv1_1 (Cin * 9 <= 32) has its own kernel; FRCNN_WGRAD_CONV1=generic keeps the generic one on it (A/B, tests compare the two)
+static bool wgrad_first_layer_form(int Cin, int ks) {
+    if (ks != 3 || Cin * 9 > 32) return false;
+    const char *e = getenv("FRCNN_WGRAD_CONV1");
+    return !(e && e[0] == 'g');
+}
+
 static WgradPlan plan_wgrad(int Cin, int Cout, int H, int W, int ks) {
     WgradPlan p;
     p.xtiles = frcnn_cdiv(W, 32);
     p.nblocks = p.xtiles * frcnn_cdiv(H, WG_ROWS);
     p.ci_tiles = frcnn_cdiv(Cin, 64);
     p.co_tiles = frcnn_cdiv(Cout, 64);
+    if (wgrad_first_layer_form(Cin, ks)) {                       // four workgroups per CU, one slab each
+        int s1 = frcnn_cdiv(4 * frcnn_cu_count(), p.co_tiles);
+        if (s1 > p.nblocks) s1 = p.nblocks;
+        p.splits = s1 < 1 ? 1 : s1;
+        p.slab_floats = (size_t)Cin * ks * ks * Cout;
+        return p;
+    }
     // 3x3 double-buffered kernel: one workgroup per CU; the single-buffer forms (1x1, FRCNN_WGRAD_DB=0): about two per CU
     int s = frcnn_cdiv((ks == 3 && wgrad_double_buffered()) ? frcnn_cu_count() : (ks == 3 ? wgrad_wgs_per_cu() : 2) * frcnn_cu_count(), p.ci_tiles * p.co_tiles);
     if (s > p.nblocks) s = p.nblocks;
@@ -1093,11 +1261,18 @@ int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int 
     const WgradPlan p = plan_wgrad(Cin, Cout, H, W, ksize);
     if (!workspace || workspace_bytes < p.slab_floats * p.splits * sizeof(float)) return FRCNN_ERR_INVALID;
     float *slabs = (float *)workspace;
+    if (wgrad_first_layer_form(Cin, ksize)) {                  // conv1_1: the (channel, tap) pairs are the MFMA rows
+        hipLaunchKernelGGL(conv1_wgrad_kernel, dim3(p.splits, p.co_tiles), dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
+        const size_t n1 = p.slab_floats;
+        const size_t work1 = (n1 / 4 + 255) / 256 + 1;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)(work1 < 4096 ? work1 : 4096)), dim3(256), 0, stream, slabs, n1, p.splits, dw_packed);
+        return frcnn_launch_status();
+    }
     const dim3 grid(p.ci_tiles, p.co_tiles, p.splits);
     const bool reg = getenv("FRCNN_WGRAD_REG") != nullptr;        // A/B hook: the register-staged kernel
-    if (ksize == 3 && !reg && wgrad_double_buffered()) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
+    if (ksize == 3 && !reg && wgrad_double_buffered()) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, wgrad_db_mode() == 2 ? 4 : 0);
     else if (ksize == 3 && !reg) {
-#define FRCNN_WGRAD_LAUNCH(WPS_, ABL_) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, WPS_, ABL_>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits)
+#define FRCNN_WGRAD_LAUNCH(WPS_, ABL_) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, WPS_, ABL_>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, 0)
         const bool three = wgrad_wgs_per_cu() == 3;
 #ifdef FRCNN_TIMING_ABLATIONS
         const char *ae = getenv("FRCNN_WGRAD_ABL");
@@ -1108,15 +1283,16 @@ int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int 
         else if (abl == 5) { if (three) FRCNN_WGRAD_LAUNCH(3, 5); else FRCNN_WGRAD_LAUNCH(2, 5); }
         else
 #endif
-        if (getenv("FRCNN_WGRAD_PRIO") != nullptr) {               // A/B hook
-            if (three) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, 3, 0, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, 2, 0, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
+        if (const char *pe = getenv("FRCNN_WGRAD_PRIO")) {          // A/B hook: 1 priorities, 2 stagger, 3 both
+            const int pm = atoi(pe);
+            if (three) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, 3, 0, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, pm);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, 2, 0, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, pm);
         } else
         if (three) FRCNN_WGRAD_LAUNCH(3, 0); else FRCNN_WGRAD_LAUNCH(2, 0);
 #undef FRCNN_WGRAD_LAUNCH
     }
     else if (ksize == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<3>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
-    else if (!reg) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<1>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
+    else if (!reg) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<1>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, 0);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<1>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
     const size_t n = p.slab_floats;
     const size_t work = (n / 4 + 255) / 256 + 1;

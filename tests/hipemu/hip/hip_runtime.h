@@ -397,6 +397,7 @@ template <typename T> static inline T atomicCAS(T *p, T cmp, T v) { T o = *p; if
 static inline void __builtin_amdgcn_s_setprio(int) {}
 static inline void __builtin_amdgcn_sched_barrier(int) {}
 static inline void __builtin_amdgcn_s_sleep(int) {}
+static inline unsigned __builtin_amdgcn_s_getreg(int) { return 0; }   // HW_ID etc.: one wave slot on the host
 static inline float __fdividef(float a, float b) { return a / b; }
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }
 static inline unsigned __float_as_uint(float f) { unsigned i; memcpy(&i, &f, 4); return i; }

@@ -33,9 +33,11 @@ static inline void frcnn_buf_store_f32(frcnn_buf_t b, uint32_t off, float v) {
 }
 static inline void frcnn_buf_load_lds_b128(frcnn_buf_t b, void *lds_wave_base, uint32_t off, uint32_t soff) {
     // lane-linear destination; the range check sees the per-lane offset only (soff is added after it), as on the hardware
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((uint64_t)off + 16 <= b.bytes) memcpy(&v, b.base + off + soff, 16);
-    memcpy((char *)lds_wave_base + 16 * (threadIdx.x & 63), &v, 16);
+    // (per DWORD: a 16-byte access that straddles the end of the buffer keeps its in-range dwords -- scripts/micro/dma_align_micro.hip)
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < 4; ++k)
+        if ((uint64_t)off + 4 * k + 4 <= b.bytes) memcpy(&v[k], b.base + off + soff + 4 * k, 4);
+    memcpy((char *)lds_wave_base + 16 * (threadIdx.x & 63), v, 16);
 }
 static inline void frcnn_buf_load_lds_b32(frcnn_buf_t b, void *lds_wave_base, uint32_t off, uint32_t soff) {
     float v = 0.0f;

@@ -137,6 +137,26 @@ def test_conv_backward(rt):
     P.check_conv_backward(rt, 64, 64, 5, 40, ksize=1, seed=2)   # the RPN heads' 1x1
 
 
+@pytest.mark.parametrize("env", [{"FRCNN_WGRAD_WPS": "3"}, {"FRCNN_WGRAD_DB": "1"}, {"FRCNN_WGRAD_DB": "2"}, {"FRCNN_WGRAD_PRIO": "3"}])
+def test_conv_wgrad_forms(rt, monkeypatch, env):
+    """A/B forms of the 3x3 weight-gradient kernel: three workgroups per CU, double-buffered images with the next tile's DMAs ahead of /
+    inside the MFMA stream, wave priorities.  Several tiles per workgroup (the emulated chip has 3 CUs) and ragged borders."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    P.check_conv_backward(rt, 64, 64, 9, 70)
+    P.check_conv_backward(rt, 3, 64, 7, 33, seed=1)
+
+
+def test_conv1_wgrad_first_layer_form(rt, monkeypatch):
+    """conv1_1's weight gradient: the (channel, tap)-row kernel and the generic kernel (FRCNN_WGRAD_CONV1=generic) against the oracle;
+    several tiles per workgroup, ragged right / bottom borders, one and two input channels as well"""
+    for cin, h, w in ((3, 7, 33), (3, 12, 70), (1, 5, 40), (2, 9, 64)):
+        P.check_conv_backward(rt, cin, 64, h, w, seed=cin)
+    P.check_conv_backward(rt, 3, 128, 6, 37, seed=5)
+    monkeypatch.setenv("FRCNN_WGRAD_CONV1", "generic")
+    P.check_conv_backward(rt, 3, 64, 7, 33, seed=1)
+
+
 def test_maxpool_bwd(rt):
     P.check_maxpool_bwd(rt, 3, 7, 9)
     P.check_maxpool_bwd(rt, 2, 8, 6)
