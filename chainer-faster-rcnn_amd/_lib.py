@@ -103,6 +103,7 @@ SIGNATURES = {
     "frcnn_bias_grad_workspace_bytes": (_S, [_I, _I]),
     "frcnn_bias_grad_f32": (_I, [_P, _I, _I, _P, _P, _S, _P]),
     "frcnn_pack_conv_dgrad_w": (_I, [_P, _I, _I, _I, _P, _P]),
+    "frcnn_pack_conv_dgrad_w_many": (_I, [_P, _I, _P]),
     "frcnn_conv_wgrad_workspace_bytes": (_S, [_I, _I, _I, _I, _I]),
     "frcnn_conv_wgrad_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_sgd_momentum_wd": (_I, [_P, _P, _P, _S, _F, _F, _F, _P]),

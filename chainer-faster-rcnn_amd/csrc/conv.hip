@@ -758,6 +758,10 @@ static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows) {
     const long ntiles = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4) * (Cout / 64);
     const long slots = (long)frcnn_cu_count() * 3;
     if (ntiles >= 4 * slots) return 34;
+    // 128-cout tiles with four accumulators per wave (38, stream-K): -2 ... -4 % on the 300x500 ... 75x125 layers with >= 128 couts
+    // (r03: conv3_2 348 -> 335 us, conv4_2 345 -> 333, conv2_2 345 -> 338); the 38x63 maps (80 such tiles) stay on 64-cout tiles
+    static const bool wide_off = getenv("FRCNN_CONV_WIDE") && getenv("FRCNN_CONV_WIDE")[0] == '0';      // A/B hook
+    if (!wide_off && Cout % 128 == 0 && Cin >= 64 && (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4) * (Cout / 128) >= frcnn_cu_count()) return 238;
     if (two_rows) return 230;
     if (ntiles >= 2 * slots) return 46;            // same decomposition, 72 VGPRs: six workgroups per CU (+3 % on the 300x500 maps)
     return 236;
@@ -812,6 +816,9 @@ size_t frcnn_conv3x3_workspace_bytes(int Cin, int Cout, int H, int W) {
     }
     FRCNN_CONV_CASES(X)
     X(46, 2, 2, 1, 1, 4, true, 6)
+    X(37, 2, 2, 2, 2, 4, true, 3)
+    X(38, 2, 2, 2, 2, 4, true, 2)
+    X(39, 2, 2, 2, 2, 8, true, 1)
 #undef X
     return best;
 }
@@ -850,6 +857,11 @@ int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bi
         case 34: return launch_conv<3, 2, 2, 1, 2, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 36: return launch_conv<3, 2, 2, 1, 1, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 46: return launch_conv<3, 2, 2, 1, 1, 4, true, 6, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        // 128 couts x 4 rows: a wave owns 64 couts x 2 rows = four accumulators, so a step's two A and two B values (one ds_read2 each)
+        // feed FOUR MFMAs -- 0.5 LDS instructions per MFMA instead of 2 (the issue stream is what this kernel pays for)
+        case 37: return launch_conv<3, 2, 2, 2, 2, 4, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 38: return launch_conv<3, 2, 2, 2, 2, 4, true, 2, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 39: return launch_conv<3, 2, 2, 2, 2, 8, true, 1, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         default: return FRCNN_ERR_INVALID;
     }
 }
@@ -867,6 +879,7 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
         case 34: return launch_conv<3, 2, 2, 1, 2, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
         case 36: return launch_conv<3, 2, 2, 1, 1, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
         case 46: return launch_conv<3, 2, 2, 1, 1, 4, true, 6, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
+        case 38: return launch_conv<3, 2, 2, 2, 2, 4, true, 2, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
         default: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
     }
 }

@@ -15,6 +15,7 @@
 // Arithmetic parity: float64 where the reference is float64 (anchors, IoU, targets), float32 where it is float32
 // (the ground-truth side of bbox_transform), no FMA contraction (built with -ffp-contract=off).
 #include "frcnn_common.h"
+#include <string.h>
 #include <stdlib.h>
 #include <frcnn_buffer.h>   // angle brackets: shadowed by the test emulator
 #include <frcnn_intrin.h>
@@ -303,6 +304,29 @@ pack_dgrad_w_kernel(const float *__restrict__ wp, int Cin, int Cout, int taps, f
     wd[i] = wp[((size_t)ci * taps + (taps - 1 - t)) * Cout + co];
 }
 
+// the same for up to 16 layers in ONE launch (a training step re-packs every layer's weights after the optimizer has moved them:
+// 14 launches of 3-17 us each; worth 0.03 ms of the step); block b belongs to the first layer whose block_end exceeds it
+struct DgradPackArgs {
+    const float *wp[16];
+    float *wd[16];
+    int cin[16], cout[16], taps[16];
+    unsigned block_end[16];
+    int n;
+};
+__global__ void __launch_bounds__(256)
+pack_dgrad_w_many_kernel(DgradPackArgs a) {
+    int li = 0;
+    while (li + 1 < a.n && blockIdx.x >= a.block_end[li]) ++li;
+    const unsigned first = li == 0 ? 0u : a.block_end[li - 1];
+    const int Cin = a.cin[li], Cout = a.cout[li], taps = a.taps[li];
+    const size_t total = (size_t)Cin * Cout * taps;
+    const size_t i = (size_t)(blockIdx.x - first) * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int ci = (int)(i % Cin);
+    const int t = (int)((i / Cin) % taps), co = (int)(i / ((size_t)Cin * taps));
+    a.wd[li][i] = a.wp[li][((size_t)ci * taps + (taps - 1 - t)) * Cout + co];
+}
+
 // ------------------------------------------------------------------------------------------------
 // Weight gradient of a KS x KS / stride 1 / pad KS/2 convolution on v_mfma_f32_32x32x2_f32:
 //   dWp[(ci*T + tap)][co] = sum over pixels p of x[ci][p + offset(tap)] * dy[co][p]         (T = KS*KS)
@@ -541,15 +565,14 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
 #pragma unroll 1
         for (int q = 0; q < 16; ++q) issue_channel(q, buf);
     };
-    // `stream_next`: the NEXT tile's DMAs (set up by issue_setup) are issued from inside this tile's MFMA stream, two channels per pair
-    // of steps over the first half of the tile.  A wave that issues v_mfma_f32_32x32x2_f32 back to back leaves the other waves of its
-    // SIMD no issue slot at all (scripts/micro/mfma_dma_micro.hip: not one instruction of a co-resident wave in 2.3 M clocks), so a
-    // second workgroup cannot load while this one multiplies -- but the wave's OWN next instruction issues in the shadow of its MFMA.
-    auto compute = [&](int buf, bool stream_next, int nbuf) {
-        if constexpr ((ABL & 4) != 0) {
-            if (stream_next) for (int q = 0; q < 16; ++q) issue_channel(q, nbuf);
-            return;
-        }
+    // (r03: issuing the NEXT tile's DMAs from inside this tile's MFMA stream -- two channels per pair of steps -- measured 476 us on
+    // conv3_2 against 488 us with the DMAs ahead of the MFMAs and 373 us for this single-buffer form: a wave that issues
+    // v_mfma_f32_32x32x2_f32 back to back leaves the other waves of its SIMD no issue slot (scripts/micro/mfma_dma_micro.hip), and its own
+    // non-MFMA instructions are not free either; what pays is fewer instructions per piece, see issue_lean.)
+    // (r03: the bias gradient as a side sum of this loop -- `bsum += bv` once per step -- made the step 0.33 ms SLOWER than the two
+    // launches of frcnn_bias_grad_f32 it replaced: a VALU instruction between two fp32 MFMAs is not free, and every wave pays it.)
+    auto compute = [&](int buf) {
+        if constexpr ((ABL & 4) != 0) return;
         const float *xa = x_lds[buf] + (wci * 32 + l31) * CHP + khalf;
         const float *db = dy_lds[buf] + (wco * 32 + l31) * DP + khalf;
         // step s = (row r, pixel pair pp): one dy value and the T shifted x values feed T MFMAs; the fragments of step s+1 are
@@ -571,10 +594,6 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][t], bv[0], acc[t], 0, 0, 0);
-            if (stream_next && s < NSTEP / 2) {
-                issue_channel(s, nbuf);
-                issue_channel(s + 1, nbuf);
-            }
             if (s + 2 < NSTEP) frag(s + 2, av[0], bv[0]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -594,14 +613,8 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
         for (int b = b_begin; b < b_end; ++b) {
             frcnn_wait_vmcnt<0>();                                // tile b's pieces of THIS wave have landed ...
             frcnn_barrier_nofence();                              // ... everybody's have, and everybody is done with tile b-1's image
-            const bool nxt = b + 1 < b_end;
-            if ((prio_mode & 4) != 0) {                          // DMA issue inside the MFMA stream
-                if (nxt) issue_setup(b + 1);
-                compute(buf, nxt, buf ^ 1);
-            } else {
-                if (nxt) issue(b + 1, buf ^ 1);
-                compute(buf, false, 0);
-            }
+            if (b + 1 < b_end) issue(b + 1, buf ^ 1);
+            compute(buf);
             buf ^= 1;
         }
     } else {
@@ -611,7 +624,7 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
             frcnn_wait_vmcnt<0>();
             frcnn_barrier_nofence();
             if constexpr (PRIO) { if ((prio_mode & 1) != 0) { if (prio_class == 0) __builtin_amdgcn_s_setprio(2); else if (prio_class == 1) __builtin_amdgcn_s_setprio(1); } }
-            compute(0, false, 0);
+            compute(0);
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
     }
@@ -1042,11 +1055,10 @@ struct WgradPlan { int xtiles, nblocks, splits, ci_tiles, co_tiles; size_t slab_
 // FRCNN_WGRAD_DB=1 selects the double-buffered 3x3 kernel (one workgroup per CU).  Measured on MI355X (r02, bench.py --mode train):
 // 12.03 ms / step vs 11.61 ms for the single-buffer kernel at two workgroups per CU -- one wave per SIMD does not keep the fp32
 // matrix pipe fed even with its loads hidden; the second wave does more than the overlap.  So it is NOT the default.
-static int wgrad_db_mode() {                                      // 0 single buffer, 1 double buffer (DMAs ahead of the MFMAs), 2 DMAs inside the MFMA stream
+static bool wgrad_double_buffered() {
     const char *e = getenv("FRCNN_WGRAD_DB");
-    return (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
+    return e && e[0] == '1';
 }
-static bool wgrad_double_buffered() { return wgrad_db_mode() != 0; }
 
 // workgroups per CU of the single-buffer 3x3 kernel (FRCNN_WGRAD_WPS=2|3: A/B hook; the default is the measured pick)
 static int wgrad_wgs_per_cu() {
@@ -1247,6 +1259,23 @@ int frcnn_pack_conv_dgrad_w(const float *w_packed, int Cin, int Cout, int ksize,
     return frcnn_launch_status();
 }
 
+int frcnn_pack_conv_dgrad_w_many(const frcnn_dgrad_pack_desc *layers, int n, void *stream) {
+    if (!layers || n < 1 || n > 16) return FRCNN_ERR_INVALID;
+    DgradPackArgs a;
+    memset(&a, 0, sizeof(a));
+    unsigned blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const frcnn_dgrad_pack_desc &d = layers[i];
+        if (!d.w_packed || !d.w_dgrad || d.Cin < 1 || d.Cout < 1 || (d.ksize != 1 && d.ksize != 3)) return FRCNN_ERR_INVALID;
+        a.wp[i] = d.w_packed; a.wd[i] = d.w_dgrad; a.cin[i] = d.Cin; a.cout[i] = d.Cout; a.taps[i] = d.ksize * d.ksize;
+        blocks += (unsigned)(((size_t)d.Cin * d.Cout * d.ksize * d.ksize + 255) / 256);
+        a.block_end[i] = blocks;
+    }
+    a.n = n;
+    hipLaunchKernelGGL(pack_dgrad_w_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return frcnn_launch_status();
+}
+
 size_t frcnn_conv_wgrad_workspace_bytes(int Cin, int Cout, int H, int W, int ksize) {
     if (Cin < 1 || Cout < 1 || H < 1 || W < 1 || (ksize != 1 && ksize != 3)) return 0;
     const WgradPlan p = plan_wgrad(Cin, Cout, H, W, ksize);
@@ -1270,7 +1299,7 @@ int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int 
     }
     const dim3 grid(p.ci_tiles, p.co_tiles, p.splits);
     const bool reg = getenv("FRCNN_WGRAD_REG") != nullptr;        // A/B hook: the register-staged kernel
-    if (ksize == 3 && !reg && wgrad_double_buffered()) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, wgrad_db_mode() == 2 ? 4 : 0);
+    if (ksize == 3 && !reg && wgrad_double_buffered()) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, 0);
     else if (ksize == 3 && !reg) {
 #define FRCNN_WGRAD_LAUNCH(WPS_, ABL_) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, WPS_, ABL_>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, 0)
         const bool three = wgrad_wgs_per_cu() == 3;

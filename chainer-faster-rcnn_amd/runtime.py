@@ -5,6 +5,8 @@ all arithmetic happens inside libfrcnn_hip.so.
 """
 import ctypes
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -747,6 +749,22 @@ class Runtime(object):
         wd = out if out is not None else m.empty((co * ksize * ksize, ci), "f32")
         _lib.check(L.frcnn_pack_conv_dgrad_w(m.ptr(w_packed), ci, co, int(ksize), m.ptr(wd), m.stream()), "frcnn_pack_conv_dgrad_w")
         return wd
+
+    def pack_conv_dgrad_w_many(self, layers):
+        """layers: [(forward-packed weights (cin*k*k, cout), dgrad weights (cout*k*k, cin), ksize)], at most 16: ONE launch."""
+        import ctypes
+
+        class Desc(ctypes.Structure):
+            _fields_ = [("w", ctypes.c_void_p), ("wd", ctypes.c_void_p), ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("ks", ctypes.c_int)]
+        m, L = self.mem, self.lib
+        descs = []
+        for wp, wd, ks in layers:
+            co = int(wp.shape[1])
+            ci = int(wp.shape[0]) // (ks * ks)
+            assert tuple(wd.shape) == (co * ks * ks, ci)
+            descs.append(Desc(m.ptr(wp).value, m.ptr(wd).value, ci, co, int(ks)))
+        arr = (Desc * len(descs))(*descs)
+        _lib.check(L.frcnn_pack_conv_dgrad_w_many(ctypes.cast(arr, ctypes.c_void_p), len(descs), m.stream()), "frcnn_pack_conv_dgrad_w_many")
 
     def conv_wgrad(self, x, dy, ksize=3, out=None):
         """dW in the forward-packed layout (Cin*k*k, Cout)."""

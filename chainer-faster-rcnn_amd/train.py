@@ -22,6 +22,8 @@ models/faster_rcnn.py:115-116).  Convolution weights live in the kernels' packed
 ProposalLayer runs inside the training step exactly where the reference runs it (train-mode top-N 12000 / 2000,
 region_proposal_network.py:123-126) and its result is discarded, as there; `run_proposal_layer=False` skips it (same gradients).
 """
+import os
+
 import numpy as np
 
 from .chainer_compat import unwrap
@@ -59,7 +61,8 @@ def trunk_backward(trainer, layer_inputs, g):
         if hasattr(trainer, "_grads_ready"):
             trainer._grads_ready(name)                            # data parallel: a finished bucket starts its all-reduce now
         if name != first:                                         # the image needs no gradient
-            rt.pack_conv_dgrad_w(links[name].Wp, 3, out=trainer.wd[name])
+            if not getattr(trainer, "_dgrad_packed", False):          # (RPNTrainer re-packs every layer in one launch per step)
+                rt.pack_conv_dgrad_w(links[name].Wp, 3, out=trainer.wd[name])
             g = rt.conv_ex(g, trainer.wd[name], trainer.zero_bias, 3, act=2, mask=xin)
     return g
 
@@ -288,6 +291,10 @@ class RPNTrainer(_BucketedAllReduce):
             link = rpn.rpn_conv_3x3
             _, mid = rt.conv3x3_f32s_train(feat_split, self.ws_fwd["rpn_conv_3x3"], link.b, link.cin, link.cout, relu=True, want_split=False)
         else:
+            # weights of every input-gradient convolution (rotated / transposed copies of the current packed weights): one launch
+            if os.environ.get("FRCNN_DGRAD_PACK") != "each":          # (=each: A/B hook, one launch per layer inside the backward pass)
+                rt.pack_conv_dgrad_w_many([(l.Wp, self.wd[n], 3) for n, l in self.convs[1:]] + [(rpn._heads_packed[0], self.wd_heads, 1)])
+                self._dgrad_packed = True
             feat, inputs = trunk_forward(model, x)                     # keeps every layer's input
             mid = rpn.rpn_conv_3x3(feat, relu=True)
         score, prob, bbox = rt.rpn_heads(mid, rpn._heads_packed)
@@ -312,10 +319,12 @@ class RPNTrainer(_BucketedAllReduce):
         # ---- backward: heads (one 1x1 convolution over the stacked cls|bbox matrix)
         rt.conv_wgrad(mid, draw, 1, out=self.grad["heads/W"])
         rt.bias_grad(draw, out=self.grad["heads/b"])
-        rt.pack_conv_dgrad_w(rpn._heads_packed[0], 1, out=self.wd_heads)
+        if not getattr(self, "_dgrad_packed", False):
+            rt.pack_conv_dgrad_w(rpn._heads_packed[0], 1, out=self.wd_heads)
         g = rt.conv_ex(draw.reshape(1, NP, H, W), self.wd_heads, self.zero_bias, 1, act=2, mask=mid)
         # ---- rpn_conv_3x3, then the trunk in reverse
         (trunk_backward_split if self.conv_math == "split" else trunk_backward)(self, list(zip(self.layers, inputs)) + [(("rpn_conv_3x3", 0, 0), feat)], g)
+        self._dgrad_packed = False
         if self.run_proposal_layer:
             rt.mem.join_side_stream()
         return dict(losses=losses)

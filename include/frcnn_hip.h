@@ -372,6 +372,13 @@ int frcnn_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int C, 
 size_t frcnn_bias_grad_workspace_bytes(int C, int HW);
 int frcnn_bias_grad_f32(const float *dy, int C, int HW, float *db, void *workspace, size_t workspace_bytes, void *stream);
 int frcnn_pack_conv_dgrad_w(const float *w_packed, int Cin, int Cout, int ksize, float *w_dgrad, void *stream);
+/* frcnn_pack_conv_dgrad_w for up to 16 layers in one launch (the trainers re-pack every layer once per step) */
+typedef struct {
+    const float *w_packed;      /* (Cin*k*k, Cout) forward-packed */
+    float *w_dgrad;             /* (Cout*k*k, Cin) */
+    int Cin, Cout, ksize;
+} frcnn_dgrad_pack_desc;
+int frcnn_pack_conv_dgrad_w_many(const frcnn_dgrad_pack_desc *layers, int n, void *stream);
 size_t frcnn_conv_wgrad_workspace_bytes(int Cin, int Cout, int H, int W, int ksize);
 int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int Cin, int Cout, int H, int W, int ksize,
                          void *workspace, size_t workspace_bytes, void *stream);

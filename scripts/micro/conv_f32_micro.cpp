@@ -45,7 +45,10 @@ int main(int argc, char **argv) {
         hipGraph_t gr; hipGraphExec_t ge;
         CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
         bool ok = true;
-        for (int i = 0; i < 5; ++i) ok = ok && frcnn_conv_f32_ex(dx, dw, db, nullptr, dy[i % 3], L.ci, L.co, L.h, L.w, 3, L.pool ? 4 : 1, ws, wsb, s) == 0;
+        const char *cfg_env = getenv("CONV_MICRO_CFG");               // force a decomposition (frcnn_conv3x3_f32_cfg: plain ReLU epilogue)
+        for (int i = 0; i < 5; ++i)
+            ok = ok && (cfg_env ? frcnn_conv3x3_f32_cfg(dx, dw, db, dy[i % 3], L.ci, L.co, L.h, L.w, 1, atoi(cfg_env), ws, wsb, s)
+                                : frcnn_conv_f32_ex(dx, dw, db, nullptr, dy[i % 3], L.ci, L.co, L.h, L.w, 3, L.pool ? 4 : 1, ws, wsb, s)) == 0;
         CK(hipStreamEndCapture(s, &gr));
         if (!ok) { printf("%s: launch refused\n", L.name); return 1; }
         CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));

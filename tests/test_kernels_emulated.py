@@ -77,17 +77,17 @@ def test_roi_pool(rt):
     P.check_roi_pool(rt, R=6, C=6, H=70, W=90, seed=3)      # 3 planes per group (odd sizes: scalar copies)
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 8, 10, 11, 30, 35, 34, 36, 46])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 8, 10, 11, 30, 35, 34, 36, 46, 37, 38, 39])
 def test_conv3x3_cfg(rt, cfg):
     P.check_conv3x3(rt, 8, 128, 9, 37, cfg=cfg)
 
 
-@pytest.mark.parametrize("cfg", [201, 205, 210, 104, 110, 1205, 2205, 2210, 1010, 2010, 230, 235, 1235, 236, 234, 206, 246])
+@pytest.mark.parametrize("cfg", [201, 205, 210, 104, 110, 1205, 2205, 2210, 1010, 2010, 230, 235, 1235, 236, 234, 206, 246, 238, 237, 239])
 def test_conv3x3_streamk(rt, cfg):
     """stream-K work distribution: the emulated chip has 3 CUs, so tiles split unevenly into 2..4 pieces and the
     last-arriver fix-up (partial slots, tickets, piece-ordered sum) is exercised."""
     P.check_conv3x3(rt, 24, 128, 9, 70, cfg=cfg)
-    P.check_conv3x3(rt, 8, 64 if cfg % 100 != 1 and cfg % 100 != 4 else 128, 21, 33, cfg=cfg, seed=1)
+    P.check_conv3x3(rt, 8, 64 if cfg % 100 not in (1, 4, 37, 38, 39) else 128, 21, 33, cfg=cfg, seed=1)     # 128-cout tiles need Cout % 128 == 0
 
 
 def test_conv3x3_cin3_and_norelu(rt):
@@ -137,7 +137,7 @@ def test_conv_backward(rt):
     P.check_conv_backward(rt, 64, 64, 5, 40, ksize=1, seed=2)   # the RPN heads' 1x1
 
 
-@pytest.mark.parametrize("env", [{"FRCNN_WGRAD_WPS": "3"}, {"FRCNN_WGRAD_DB": "1"}, {"FRCNN_WGRAD_DB": "2"}, {"FRCNN_WGRAD_PRIO": "3"}])
+@pytest.mark.parametrize("env", [{"FRCNN_WGRAD_WPS": "3"}, {"FRCNN_WGRAD_DB": "1"}, {"FRCNN_WGRAD_PRIO": "3"}])
 def test_conv_wgrad_forms(rt, monkeypatch, env):
     """A/B forms of the 3x3 weight-gradient kernel: three workgroups per CU, double-buffered images with the next tile's DMAs ahead of /
     inside the MFMA stream, wave priorities.  Several tiles per workgroup (the emulated chip has 3 CUs) and ragged borders."""
