@@ -315,16 +315,29 @@ struct DgradPackArgs {
 };
 __global__ void __launch_bounds__(256)
 pack_dgrad_w_many_kernel(DgradPackArgs a) {
+    // per (layer, tap) this is a (Cin, Cout) -> (Cout, Cin) transpose: 64 x 64 tiles through LDS, both sides coalesced (as one element per
+    // thread with the source index computed from the destination's, every read touched its own cache line: 87 us for the 14 layers)
+    __shared__ float tile[64][65];
     int li = 0;
     while (li + 1 < a.n && blockIdx.x >= a.block_end[li]) ++li;
     const unsigned first = li == 0 ? 0u : a.block_end[li - 1];
     const int Cin = a.cin[li], Cout = a.cout[li], taps = a.taps[li];
-    const size_t total = (size_t)Cin * Cout * taps;
-    const size_t i = (size_t)(blockIdx.x - first) * 256 + threadIdx.x;
-    if (i >= total) return;
-    const int ci = (int)(i % Cin);
-    const int t = (int)((i / Cin) % taps), co = (int)(i / ((size_t)Cin * taps));
-    a.wd[li][i] = a.wp[li][((size_t)ci * taps + (taps - 1 - t)) * Cout + co];
+    const int cit = (Cin + 63) / 64, cot = (Cout + 63) / 64;
+    const unsigned u = blockIdx.x - first;                       // (tap, ci tile, co tile)
+    const int t = (int)(u / (unsigned)(cit * cot)), rem = (int)(u % (unsigned)(cit * cot));
+    const int ci0 = (rem / cot) * 64, co0 = (rem % cot) * 64;
+    const float *wp = a.wp[li];
+    float *wd = a.wd[li];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int i = ty; i < 64; i += 4) {                              // source rows: (ci, rotated tap), columns co
+        const int ci = ci0 + i, co = co0 + tx;
+        tile[i][tx] = (ci < Cin && co < Cout) ? wp[((size_t)ci * taps + (taps - 1 - t)) * Cout + co] : 0.0f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {                              // destination rows: (co, tap), columns ci
+        const int co = co0 + i, ci = ci0 + tx;
+        if (co < Cout && ci < Cin) wd[((size_t)co * taps + t) * Cin + ci] = tile[tx][i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1268,7 +1281,7 @@ int frcnn_pack_conv_dgrad_w_many(const frcnn_dgrad_pack_desc *layers, int n, voi
         const frcnn_dgrad_pack_desc &d = layers[i];
         if (!d.w_packed || !d.w_dgrad || d.Cin < 1 || d.Cout < 1 || (d.ksize != 1 && d.ksize != 3)) return FRCNN_ERR_INVALID;
         a.wp[i] = d.w_packed; a.wd[i] = d.w_dgrad; a.cin[i] = d.Cin; a.cout[i] = d.Cout; a.taps[i] = d.ksize * d.ksize;
-        blocks += (unsigned)(((size_t)d.Cin * d.Cout * d.ksize * d.ksize + 255) / 256);
+        blocks += (unsigned)(d.ksize * d.ksize * ((d.Cin + 63) / 64) * ((d.Cout + 63) / 64));
         a.block_end[i] = blocks;
     }
     a.n = n;

@@ -24,7 +24,7 @@ def main(tag="r03z"):
             if line:
                 open(os.path.join(P, n + ".json"), "w").write(line)
     for n in ("r03_hbm_traffic_pmc.json", "r03_hbm_traffic_pmc_bf16.json", "r03_mfma_pmc_summary.json", "r03_roi_pmc.txt", "r03_store_micro.txt",
-              "r03_roi_micro.txt", "r03_conv_bf16_micro.txt"):
+              "r03_roi_micro.txt", "r03_conv_bf16_micro.txt", "r03_conv_f32_micro.txt", "r03_wgrad_micro.txt", "r03_mfma_filler_micro.txt", "r03_dma_align_micro.txt"):
         if os.path.exists(os.path.join(O, n)):
             shutil.copy(os.path.join(O, n), os.path.join(P, n))
     if os.path.exists(os.path.join(O, "parity_reports.txt")):

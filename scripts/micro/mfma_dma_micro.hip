@@ -113,9 +113,24 @@ int main() {
     const uint32_t nb = 1u << 20; float *d, *sink; unsigned long long *o; const int blocks = 256;
     hipMalloc(&d, nb); hipMemset(d, 0, nb); hipMalloc(&sink, 4096); hipMalloc(&o, blocks * 16 * 8);
     const int nm = 9 * 4000;
+    printf("== a second wave on the same SIMD (polling an LDS flag, or issuing LDS-DMA pieces) next to a wave of back-to-back MFMAs:\n");
+    printf("   `DMA pieces per MFMA` = iterations / pieces the second wave got through per MFMA of the first\n");
+    run<0, 0, 0>("f32 32x32x2: alone", d, nb, nm, 0, o, sink, blocks);
+    run<4, 0, 0>("f32 32x32x2: + polling wave", d, nb, nm, 0, o, sink, blocks);
+    run<4, 0, 0>("f32 32x32x2: + polling wave at s_setprio 3", d, nb, nm, 0, o, sink, blocks, 3);
+    run<1, 0, 0>("f32 32x32x2: + DMA wave", d, nb, nm, 0, o, sink, blocks);
+    run<0, 2, 0>("f32 16x16x4: alone", d, nb, nm, 0, o, sink, blocks);
+    run<4, 2, 0>("f32 16x16x4: + polling wave", d, nb, nm, 0, o, sink, blocks);
+    run<4, 2, 0>("f32 16x16x4: + polling wave at s_setprio 3", d, nb, nm, 0, o, sink, blocks, 3);
+    run<1, 2, 0>("f32 16x16x4: + DMA wave", d, nb, nm, 0, o, sink, blocks);
+    run<0, 1, 0>("bf16 32x32x16: alone", d, nb, nm, 0, o, sink, blocks);
+    run<4, 1, 0>("bf16 32x32x16: + polling wave", d, nb, nm, 0, o, sink, blocks);
+    run<4, 1, 0>("bf16 32x32x16: + polling wave at s_setprio 3", d, nb, nm, 0, o, sink, blocks, 3);
+    run<3, 1, 0>("bf16 32x32x16: + DMA wave", d, nb, nm, 0, o, sink, blocks);
+    printf("== price of instructions in the MFMA wave's own stream (one wave per SIMD; clocks per MFMA):\n");
     run<0, 0, 0>("f32 32x32x2 + per MFMA: nothing", d, nb, nm, 0, o, sink, blocks);
     run<0, 0, 1>("f32 32x32x2 + per MFMA: 1 s_nop", d, nb, nm, 0, o, sink, blocks);
-    run<0, 0, 7>("f32 32x32x2 + per MFMA: 4 SALU (mov/add)", d, nb, nm, 0, o, sink, blocks);
+    run<0, 0, 2>("f32 32x32x2 + per MFMA: 4 s_nop", d, nb, nm, 0, o, sink, blocks);
     run<0, 0, 9>("f32 32x32x2 + per MFMA: 1 independent VALU", d, nb, nm, 0, o, sink, blocks);
     run<0, 0, 8>("f32 32x32x2 + per MFMA: 4 VALU (2 mov + 2 dependent add)", d, nb, nm, 0, o, sink, blocks);
     run<0, 0, 4>("f32 32x32x2 + per MFMA: 1 ds_read_b32", d, nb, nm, 0, o, sink, blocks);
@@ -123,7 +138,7 @@ int main() {
     run<0, 0, 6>("f32 32x32x2 + per MFMA: 1 b128 LDS-DMA", d, nb, nm, 0, o, sink, blocks);
     run<0, 1, 0>("bf16 32x32x16 + per MFMA: nothing", d, nb, nm, 0, o, sink, blocks);
     run<0, 1, 1>("bf16 32x32x16 + per MFMA: 1 s_nop", d, nb, nm, 0, o, sink, blocks);
-    run<0, 1, 7>("bf16 32x32x16 + per MFMA: 4 SALU (mov/add)", d, nb, nm, 0, o, sink, blocks);
+    run<0, 1, 2>("bf16 32x32x16 + per MFMA: 4 s_nop", d, nb, nm, 0, o, sink, blocks);
     run<0, 1, 9>("bf16 32x32x16 + per MFMA: 1 independent VALU", d, nb, nm, 0, o, sink, blocks);
     run<0, 1, 8>("bf16 32x32x16 + per MFMA: 4 VALU (2 mov + 2 dependent add)", d, nb, nm, 0, o, sink, blocks);
     run<0, 1, 4>("bf16 32x32x16 + per MFMA: 1 ds_read_b32", d, nb, nm, 0, o, sink, blocks);

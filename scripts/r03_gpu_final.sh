@@ -64,5 +64,9 @@ if has micro; then
   ./scripts/micro/_bin/store_micro > $O/r03_store_micro.txt 2>&1; head -8 $O/r03_store_micro.txt
   ROI_MICRO_BURST=50 ./scripts/micro/_bin/roi_micro DEFAULT=1 FRCNN_ROI_ST=0 FRCNN_ROI_KERNEL=cells > $O/r03_roi_micro.txt 2>&1; cat $O/r03_roi_micro.txt
   ./scripts/micro/_bin/conv_bf16_micro > $O/r03_conv_bf16_micro.txt 2>&1; tail -12 $O/r03_conv_bf16_micro.txt
+  ./scripts/micro/_bin/conv_f32_micro > $O/r03_conv_f32_micro.txt 2>&1; tail -3 $O/r03_conv_f32_micro.txt
+  { ./scripts/micro/_bin/wgrad_micro; echo "== split products"; ./scripts/micro/_bin/wgrad_micro --f32s; echo "== conv1_1, generic kernel"; FRCNN_WGRAD_CONV1=generic ./scripts/micro/_bin/wgrad_micro conv1_1; } > $O/r03_wgrad_micro.txt 2>&1; tail -14 $O/r03_wgrad_micro.txt
+  timeout 200 ./scripts/micro/_bin/mfma_dma_micro > $O/r03_mfma_filler_micro.txt 2>&1; head -8 $O/r03_mfma_filler_micro.txt
+  ./scripts/micro/_bin/dma_align_micro > $O/r03_dma_align_micro.txt 2>&1; head -4 $O/r03_dma_align_micro.txt
 fi
 echo "== done"

@@ -445,6 +445,25 @@ def check_conv_backward(rt, Cin, Cout, H, W, ksize=3, seed=0):
         assert np.abs(dx - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6)
 
 
+def check_pack_dgrad_many(rt, seed=0):
+    """one-launch re-pack of several layers' input-gradient weights (tiled transposes) == the per-layer kernel == NumPy"""
+    rs = np.random.RandomState(seed)
+    shapes = [(64, 64, 3), (3, 64, 3), (70, 130, 3), (128, 54, 1), (5, 7, 3)]
+    layers, wants = [], []
+    for cin, cout, ks in shapes:
+        wp = rs.randn(cin * ks * ks, cout).astype(np.float32)
+        w4 = wp.reshape(cin, ks * ks, cout)                                              # [ci][tap][co]
+        want = np.ascontiguousarray(w4[:, ::-1, :].transpose(2, 1, 0)).reshape(cout * ks * ks, cin)   # [co][rotated tap][ci]
+        d_wp = dev(rt, wp)
+        one = host(rt, rt.pack_conv_dgrad_w(d_wp, ks))
+        assert np.array_equal(one, want)
+        layers.append((d_wp, dev(rt, np.full((cout * ks * ks, cin), np.nan, np.float32)), ks))
+        wants.append(want)
+    rt.pack_conv_dgrad_w_many(layers)
+    for (_, wd, _), want in zip(layers, wants):
+        assert np.array_equal(host(rt, wd), want)
+
+
 def check_conv_wgrad_f32s(rt, Cin, Cout, H, W, seed=0):
     """The 3x3 weight gradient as six bf16 MFMA products of 3-way split operands: against a FLOAT64 accumulation of the same fp32
     inputs, next to the fp32 MFMA kernel (same error class)."""

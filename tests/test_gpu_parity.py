@@ -219,6 +219,10 @@ def test_conv_wgrad_forms(rt, monkeypatch, env):
     P.check_conv_backward(rt, 256, 64, 38, 63, seed=2)
 
 
+def test_pack_dgrad_many(rt):
+    P.check_pack_dgrad_many(rt)
+
+
 def test_maxpool_bwd(rt):
     P.check_maxpool_bwd(rt, 64, 75, 125)
     P.check_maxpool_bwd(rt, 8, 600, 1000)

@@ -157,6 +157,10 @@ def test_conv1_wgrad_first_layer_form(rt, monkeypatch):
     P.check_conv_backward(rt, 3, 64, 7, 33, seed=1)
 
 
+def test_pack_dgrad_many(rt):
+    P.check_pack_dgrad_many(rt)
+
+
 def test_maxpool_bwd(rt):
     P.check_maxpool_bwd(rt, 3, 7, 9)
     P.check_maxpool_bwd(rt, 2, 8, 6)
