@@ -461,8 +461,7 @@ conv_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy
 // DMA costs a handful of SALU operations and no VALU -- and no staging registers: two workgroups per CU, one's MFMAs over the
 // other's loads, plus fragment reads software-pipelined one step ahead of the MFMAs.
 // DB = double-buffered LDS images (103 KB: one workgroup per CU, one wave per SIMD): tile b+1's DMAs are issued right after the
-// barrier that hands over tile b and land under tile b's 288 MFMAs per wave.  An experiment kept behind FRCNN_WGRAD_DB=1: it measured
-// 3.6 % SLOWER per training step than the single-buffer form at two workgroups per CU (see wgrad_double_buffered()).
+// barrier that hands over tile b and land under tile b's 288 MFMAs per wave.  Picked per layer (see wgrad_double_buffered()).
 // One fence-less barrier per tile, no counted waits (a wave issues 80 DMAs per tile,
 // more than vmcnt can count: the wait for tile b+1 is the vmcnt(0) at the top of the next trip, a whole compute phase later).
 // WPS = workgroups per CU the single-buffer form is compiled for: 2 (171 VGPRs) or 3 (168 VGPRs: three dwords of the tile set-up live in
@@ -1065,12 +1064,19 @@ gather_rows_kernel(const float *__restrict__ src, const int32_t *__restrict__ id
 
 struct WgradPlan { int xtiles, nblocks, splits, ci_tiles, co_tiles; size_t slab_floats; };
 
-// FRCNN_WGRAD_DB=1 selects the double-buffered 3x3 kernel (one workgroup per CU).  Measured on MI355X (r02, bench.py --mode train):
-// 12.03 ms / step vs 11.61 ms for the single-buffer kernel at two workgroups per CU -- one wave per SIMD does not keep the fp32
-// matrix pipe fed even with its loads hidden; the second wave does more than the overlap.  So it is NOT the default.
-static bool wgrad_double_buffered() {
+// The double-buffered 3x3 kernel (one workgroup per CU, half as many slabs) against the single-buffer one (two per CU).  Round 2 measured it
+// 3.6 % slower on the training step and left it off; with the lean DMA issue and the unrolled MFMA loop of round 3 it is the faster form wherever a
+// workgroup of the single-buffer launch would get few tiles or the layer has a single (ci, co) tile (profiles/r03_wgrad_micro.txt: conv1_2
+// 433 -> 403 us, conv2_1 230 -> 217, conv3_1 220 -> 213, conv4_1 215 -> 208, the 38 x 63 layers 127 -> 118) and the slower one on the 44-GFLOP layers
+// with >= 4 (ci, co) tiles (conv3_2 375 -> 392): picked per layer.  FRCNN_WGRAD_DB=0 / 1 forces one form (A/B hook).
+static bool wgrad_double_buffered(int Cin, int Cout, int H, int W) {
     const char *e = getenv("FRCNN_WGRAD_DB");
-    return e && e[0] == '1';
+    if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
+    const int cico = frcnn_cdiv(Cin, 64) * frcnn_cdiv(Cout, 64);
+    const int nblocks = frcnn_cdiv(W, 32) * frcnn_cdiv(H, WG_ROWS);
+    int splits2 = frcnn_cdiv(2 * frcnn_cu_count(), cico);             // what the single-buffer launch would use
+    if (splits2 > nblocks) splits2 = nblocks;
+    return cico == 1 || nblocks < 14 * splits2;
 }
 
 // workgroups per CU of the single-buffer 3x3 kernel (FRCNN_WGRAD_WPS=2|3: A/B hook; the default is the measured pick)
@@ -1101,7 +1107,7 @@ static WgradPlan plan_wgrad(int Cin, int Cout, int H, int W, int ks) {
         return p;
     }
     // 3x3 double-buffered kernel: one workgroup per CU; the single-buffer forms (1x1, FRCNN_WGRAD_DB=0): about two per CU
-    int s = frcnn_cdiv((ks == 3 && wgrad_double_buffered()) ? frcnn_cu_count() : (ks == 3 ? wgrad_wgs_per_cu() : 2) * frcnn_cu_count(), p.ci_tiles * p.co_tiles);
+    int s = frcnn_cdiv((ks == 3 && wgrad_double_buffered(Cin, Cout, H, W)) ? frcnn_cu_count() : (ks == 3 ? wgrad_wgs_per_cu() : 2) * frcnn_cu_count(), p.ci_tiles * p.co_tiles);
     if (s > p.nblocks) s = p.nblocks;
     if (s < 1) s = 1;
     p.splits = s;
@@ -1312,7 +1318,7 @@ int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int 
     }
     const dim3 grid(p.ci_tiles, p.co_tiles, p.splits);
     const bool reg = getenv("FRCNN_WGRAD_REG") != nullptr;        // A/B hook: the register-staged kernel
-    if (ksize == 3 && !reg && wgrad_double_buffered()) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, 0);
+    if (ksize == 3 && !reg && wgrad_double_buffered(Cin, Cout, H, W)) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, 0);
     else if (ksize == 3 && !reg) {
 #define FRCNN_WGRAD_LAUNCH(WPS_, ABL_) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, WPS_, ABL_>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, 0)
         const bool three = wgrad_wgs_per_cu() == 3;
