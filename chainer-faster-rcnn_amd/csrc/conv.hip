@@ -48,7 +48,10 @@ namespace {
 // (__launch_bounds__'s second argument is waves per SIMD = BPC * threads / 256).
 // DMA = stage through LDS-DMA (buffer_load ... lds: no staging VGPRs, no ds_write pass, counted vmcnt wait + fence-less barrier);
 // the LDS images are the same -- they were lane-linear per 64-thread slice already.
-template <int KS, int WCO, int WPX, int ACO, int APX, int CK, bool PIPE, int BPC, int ABL = 0, bool DMA = false>
+// SOFF (DMA form): Cin is a whole number of chunks, so a chunk's offset rides in the scalar offset of its pieces.  A template parameter, not a
+// launch-time flag: with both forms in one kernel the per-chunk descriptor state of the ragged form kept the scalar registers so full that the
+// x descriptor lived in VGPR lanes and came back through four v_readlane per chunk.
+template <int KS, int WCO, int WPX, int ACO, int APX, int CK, bool PIPE, int BPC, int ABL = 0, bool DMA = false, bool SOFF = false>
 __global__ void __launch_bounds__(64 * WCO * WPX, (BPC * 64 * WCO * WPX) / 256)
 conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
                      float *__restrict__ y, int Cin, int Cout, int H, int W, int relu, int xtiles, int ytiles, int nchunks,
@@ -97,7 +100,7 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
     const long long G = gridDim.x;
     long long g = blockIdx.x;
     const bool banded = (relu & 512) != 0;
-    const bool soff_mode = (relu & 1024) != 0;
+    constexpr bool soff_mode = SOFF;
     if (relu & (256 | 512)) {
         const long long xcd = g & 7, q = G >> 3, r = G & 7;
         g = xcd * q + (xcd < r ? xcd : r) + (g >> 3);
@@ -195,7 +198,7 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
         // than the scalar-offset form, which every VGG layer uses).  Adding the chunk offset to the per-lane offsets instead puts a
         // VALU write in front of every DMA: -4 %.
         auto issue = [&](int chunk, int buf) {
-            if (soff_mode) {                 // Cin is a whole number of chunks: the chunk offset rides in the scalar offset (3 % faster)
+            if constexpr (soff_mode) {       // Cin is a whole number of chunks: the chunk offset rides in the scalar offset (3 % faster)
                 const uint32_t wb = (uint32_t)chunk * w_chunk_bytes, xb = (uint32_t)chunk * x_chunk_bytes;
 #pragma unroll
                 for (int q = 0; q < WIT; ++q)
@@ -212,8 +215,7 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
                     if ((q + 1) * NT <= HVP || wave * 64 + q * NT < HVP)
                         frcnn_buf_load_lds_b32(xbuf, &in_lds[buf][q * NT + wave * 64], hoff[q], xb);
                 }
-                return;
-            }
+            } else {
             const long long wrem = (long long)(K - chunk * KR) * Cout, xrem = (long long)(Cin - chunk * CK) * HW;
             const frcnn_buf_t wb_c = frcnn_make_buf(wp + (size_t)chunk * KR * Cout, (uint32_t)((wrem > 0 ? wrem : 0) * sizeof(float)));
             const frcnn_buf_t xb_c = frcnn_make_buf(x + (size_t)chunk * CK * HW, (uint32_t)((xrem > 0 ? xrem : 0) * sizeof(float)));
@@ -231,6 +233,7 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
             for (int q = 0; q < HIT; ++q)
                 if ((q + 1) * NT <= HVP || wave * 64 + q * NT < HVP)
                     frcnn_buf_load_lds_b32(xb_c, &in_lds[buf][q * NT + wave * 64], hoff[q], 0);
+            }
             }
         };
 
@@ -732,7 +735,7 @@ static int launch_conv(const float *x, const float *wp, const float *bias, float
         const int order = xcd_env >= 0 ? xcd_env : ((p.G == p.ntiles || w_bytes >= map_bytes) ? 1 : 0);
         relu |= 256 * order;
     }
-    if (DMA && (Cin % CK == 0 || Cin <= CK)) relu |= 1024;        // no ragged chunk past chunk 0: scalar-offset DMA form
+    const bool soff = DMA && (Cin % CK == 0 || Cin <= CK);       // no ragged chunk past chunk 0: scalar-offset DMA form
     int *counters = nullptr;
     float *partials = nullptr;
     if (p.G != p.ntiles) {
@@ -740,8 +743,15 @@ static int launch_conv(const float *x, const float *wp, const float *bias, float
         partials = (float *)((char *)workspace + p.counters_bytes);
         if (!p.self_cleaning) FRCNN_HIP_TRY(hipMemsetAsync(counters, 0, p.counters_bytes, stream));
     }
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_f32_kernel<KS, WCO, WPX, ACO, APX, CK, PIPE, BPC, ABL, DMA>), dim3(p.G), dim3(64 * WCO * WPX), 0,
-                       stream, x, wp, bias, y, Cin, Cout, H, W, relu, p.xtiles, p.ytiles, p.nchunks, p.total, partials, counters, mask);
+    if constexpr (DMA) {
+        if (soff) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_f32_kernel<KS, WCO, WPX, ACO, APX, CK, PIPE, BPC, ABL, true, true>), dim3(p.G), dim3(64 * WCO * WPX), 0,
+                                     stream, x, wp, bias, y, Cin, Cout, H, W, relu, p.xtiles, p.ytiles, p.nchunks, p.total, partials, counters, mask);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_f32_kernel<KS, WCO, WPX, ACO, APX, CK, PIPE, BPC, ABL, true, false>), dim3(p.G), dim3(64 * WCO * WPX), 0,
+                                stream, x, wp, bias, y, Cin, Cout, H, W, relu, p.xtiles, p.ytiles, p.nchunks, p.total, partials, counters, mask);
+    } else {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_f32_kernel<KS, WCO, WPX, ACO, APX, CK, PIPE, BPC, ABL, false>), dim3(p.G), dim3(64 * WCO * WPX), 0,
+                           stream, x, wp, bias, y, Cin, Cout, H, W, relu, p.xtiles, p.ytiles, p.nchunks, p.total, partials, counters, mask);
+    }
     return frcnn_launch_status();
 }
 
