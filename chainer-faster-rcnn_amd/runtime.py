@@ -84,6 +84,28 @@ class TorchDeviceMemory(object):
         if getattr(self, "_side", None) is not None:
             self.torch.cuda.current_stream(self.device).wait_stream(self._side)
 
+    def aux_stream(self, name, *arrays):
+        """Context manager: a named second stream that starts after everything already enqueued on the current one (side_stream's
+        semantics, any number of them).  The trainers put a layer's weight / bias gradient there so that it runs NEXT TO the layer's
+        input-gradient convolution on the current stream instead of in front of it: tails, ramps and the memory-bound helpers (slab
+        reductions, bias sums) of one chain fill what the other leaves idle.  join_aux_stream(name) makes the current stream wait."""
+        torch = self.torch
+        if not hasattr(self, "_aux"):
+            self._aux = {}
+        st = self._aux.get(name)
+        if st is None:
+            st = self._aux[name] = torch.cuda.Stream(device=self.device)
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        for a in arrays:
+            if a is not None and hasattr(a, "record_stream"):
+                a.record_stream(st)
+        return torch.cuda.stream(st)
+
+    def join_aux_stream(self, name):
+        st = getattr(self, "_aux", {}).get(name)
+        if st is not None:
+            self.torch.cuda.current_stream(self.device).wait_stream(st)
+
     def early_stream(self, *after):
         """Context manager: a stream that does NOT wait for the current one -- for work that depends on nothing already enqueued (the
         trainers' AnchorTargetLayer: ground truth in, labels out, with a host round trip in the middle) so that its host part overlaps

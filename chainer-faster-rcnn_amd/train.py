@@ -40,6 +40,13 @@ def trunk_forward(model, x):
     return h, inputs
 
 
+def _grad_stream(rt, *arrays):
+    import contextlib
+    if os.environ.get("FRCNN_TRAIN_STREAMS") == "1":
+        return contextlib.nullcontext()
+    return rt.mem.aux_stream("grad", *arrays)
+
+
 def trunk_backward(trainer, layer_inputs, g):
     """Backward through [(layer, input)] in reverse, starting from g = dL/d(output of the last layer) ALREADY masked by that
     layer's ReLU.  Writes weight / bias gradients into trainer.grad and re-packs the input-gradient weights."""
@@ -56,14 +63,18 @@ def trunk_backward(trainer, layer_inputs, g):
         keep = getattr(trainer, "keep_dy", None)
         if keep is not None and name in keep:                     # tests: the (input, upstream gradient) pair a weight gradient was computed from
             trainer.kept_dy[name] = (xin, g.clone() if hasattr(g, "clone") else g.copy())
-        rt.conv_wgrad(xin, g, 3, out=trainer.grad[name + "/W"])
-        rt.bias_grad(g, out=trainer.grad[name + "/b"])
-        if hasattr(trainer, "_grads_ready"):
-            trainer._grads_ready(name)                            # data parallel: a finished bucket starts its all-reduce now
+        # this layer's weight / bias gradient on the gradient stream: it needs (xin, g) only, so it runs NEXT TO the input-gradient
+        # convolution below (FRCNN_TRAIN_STREAMS=1: one stream, A/B hook)
+        with _grad_stream(rt, xin, g):
+            rt.conv_wgrad(xin, g, 3, out=trainer.grad[name + "/W"])
+            rt.bias_grad(g, out=trainer.grad[name + "/b"])
+            if hasattr(trainer, "_grads_ready"):
+                trainer._grads_ready(name)                        # data parallel: a finished bucket starts its all-reduce now
         if name != first:                                         # the image needs no gradient
             if not getattr(trainer, "_dgrad_packed", False):          # (RPNTrainer re-packs every layer in one launch per step)
                 rt.pack_conv_dgrad_w(links[name].Wp, 3, out=trainer.wd[name])
             g = rt.conv_ex(g, trainer.wd[name], trainer.zero_bias, 3, act=2, mask=xin)
+    rt.mem.join_aux_stream("grad")
     return g
 
 
@@ -118,10 +129,11 @@ def trunk_backward_split(trainer, layer_inputs, g):
         keep = getattr(trainer, "keep_dy", None)
         if keep is not None and name in keep:
             trainer.kept_dy[name] = (xin, g.clone() if hasattr(g, "clone") else g.copy())
-        rt.conv_wgrad_f32s(xin, g, out=trainer.grad[name + "/W"])  # split products too: fp32 NCHW in, the split happens in the kernel
-        rt.bias_grad(g, out=trainer.grad[name + "/b"])
-        if hasattr(trainer, "_grads_ready"):
-            trainer._grads_ready(name)
+        with _grad_stream(rt, xin, g):                               # next to the input-gradient convolution below (see trunk_backward)
+            rt.conv_wgrad_f32s(xin, g, out=trainer.grad[name + "/W"])  # split products too: fp32 NCHW in, the split happens in the kernel
+            rt.bias_grad(g, out=trainer.grad[name + "/b"])
+            if hasattr(trainer, "_grads_ready"):
+                trainer._grads_ready(name)
         if name == first:
             continue                                                  # the image needs no gradient
         cin, cout = _conv_dims(trainer, name)
@@ -132,6 +144,7 @@ def trunk_backward_split(trainer, layer_inputs, g):
         below = names[pos - 1] if pos > 0 else None                   # who consumes dL/d(input): a convolution with an input gradient of its own?
         below_conv = below is not None and below != "pool" and below != first and _conv_dims(trainer, below)[0] > 3
         gs, g = rt.conv3x3_f32s_train(gs, trainer.ws_dgrad[name], trainer.zero_bias, cout, cin, relu=False, want_split=below_conv, mask=xin)
+    rt.mem.join_aux_stream("grad")
     return g
 
 
@@ -293,7 +306,8 @@ class RPNTrainer(_BucketedAllReduce):
         else:
             # weights of every input-gradient convolution (rotated / transposed copies of the current packed weights): one launch
             if os.environ.get("FRCNN_DGRAD_PACK") != "each":          # (=each: A/B hook, one launch per layer inside the backward pass)
-                rt.pack_conv_dgrad_w_many([(l.Wp, self.wd[n], 3) for n, l in self.convs[1:]] + [(rpn._heads_packed[0], self.wd_heads, 1)])
+                with _grad_stream(rt):                                # on the gradient stream: under the forward pass, joined before the backward pass
+                    rt.pack_conv_dgrad_w_many([(l.Wp, self.wd[n], 3) for n, l in self.convs[1:]] + [(rpn._heads_packed[0], self.wd_heads, 1)])
                 self._dgrad_packed = True
             feat, inputs = trunk_forward(model, x)                     # keeps every layer's input
             mid = rpn.rpn_conv_3x3(feat, relu=True)
@@ -317,8 +331,10 @@ class RPNTrainer(_BucketedAllReduce):
         losses, _, _ = rt.rpn_loss(score[0], bbox[0], labels, targets, inds, n_in, A, H, W, rpn._delta, rpn._loss_lambda,
                                    d_score=draw[:2 * A], d_bbox=draw[2 * A:6 * A])
         # ---- backward: heads (one 1x1 convolution over the stacked cls|bbox matrix)
-        rt.conv_wgrad(mid, draw, 1, out=self.grad["heads/W"])
-        rt.bias_grad(draw, out=self.grad["heads/b"])
+        rt.mem.join_aux_stream("grad")                               # the re-packed input-gradient weights are ready
+        with _grad_stream(rt, mid, draw):
+            rt.conv_wgrad(mid, draw, 1, out=self.grad["heads/W"])
+            rt.bias_grad(draw, out=self.grad["heads/b"])
         if not getattr(self, "_dgrad_packed", False):
             rt.pack_conv_dgrad_w(rpn._heads_packed[0], 1, out=self.wd_heads)
         g = rt.conv_ex(draw.reshape(1, NP, H, W), self.wd_heads, self.zero_bias, 1, act=2, mask=mid)

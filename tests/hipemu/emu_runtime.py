@@ -61,6 +61,13 @@ class HostMemory(object):
     def join_side_stream(self):
         pass
 
+    def aux_stream(self, name, *arrays):                 # runtime.py: a second stream next to the current one; the host runs in order
+        import contextlib
+        return contextlib.nullcontext()
+
+    def join_aux_stream(self, name):
+        pass
+
     def early_stream(self, *after):                      # runtime.py: the side stream waits for the producers of `after`; the host runs in order
         import contextlib
         return contextlib.nullcontext()
