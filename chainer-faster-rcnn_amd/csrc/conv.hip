@@ -395,7 +395,47 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
         // The epilogues fetch everything they read (bias; the mask of the training / residual forms) in ONE batch before their first
         // store: written as load - use - store per element, the compiler waited for every load with vmcnt(0), i.e. also for the
         // previous element's store to be acknowledged -- 16-32 dependent memory round trips per tile.
-        if (finish && relu == 4) {
+        if (finish && relu == 5) {
+            // training form of the fused ReLU + 2x2 max-pool: the pooled map AND, per window, which cell it came from (0 .. 3 in the scan
+            // order (row, column) of maxpool2x2_bwd_kernel, first maximum wins, decided on the post-ReLU values exactly as that kernel
+            // decides on the stored map) as one byte at `mask` -- the pre-pool map, which only the pool's backward pass would read, is
+            // never written.  (Where every cell of a window is <= 0 the byte is 0 and the gradient that arrives there is 0: the
+            // input-gradient convolution above masks by pooled > 0.)
+            if constexpr (APX == 2) {
+                const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+                const int px = x0 + l31, py = y0 + b_row;
+                const bool has_row1 = py + 1 < H, has_right = px + 1 < W;
+                unsigned char *arg_map = reinterpret_cast<unsigned char *>(const_cast<float *>(mask));
+#pragma unroll
+                for (int i = 0; i < ACO; ++i) {
+                    const int cob = co0 + wco * (32 * ACO) + 32 * i + 4 * khalf;
+                    float4 bq[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) bq[g] = *reinterpret_cast<const float4 *>(&bias[cob + 8 * g]);
+                    const size_t o0 = (size_t)cob * OH * OW + (size_t)(py >> 1) * OW + (px >> 1);
+                    const bool writer = (l31 & 1) == 0 && px < W && py < H;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float b = (r & 3) == 0 ? bq[r >> 2].x : ((r & 3) == 1 ? bq[r >> 2].y : ((r & 3) == 2 ? bq[r >> 2].z : bq[r >> 2].w));
+                        const float v00 = fmaxf(acc[i][0][r] + b, 0.0f), v10 = fmaxf(acc[i][1][r] + b, 0.0f);
+                        // both right-hand neighbours in one exchange
+                        const unsigned long long both = ((unsigned long long)__float_as_uint(v10) << 32) | __float_as_uint(v00);
+                        const unsigned long long nb = __shfl_xor(both, 1);
+                        const float v01 = __uint_as_float((unsigned int)nb), v11 = __uint_as_float((unsigned int)(nb >> 32));
+                        float m = v00;
+                        int k = 0;
+                        if (has_right && v01 > m) { m = v01; k = 1; }
+                        if (has_row1 && v10 > m) { m = v10; k = 2; }
+                        if (has_right && has_row1 && v11 > m) { m = v11; k = 3; }
+                        if (writer) {
+                            const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * OH * OW;
+                            y[o] = m;
+                            arg_map[o] = (unsigned char)k;
+                        }
+                    }
+                }
+            }
+        } else if (finish && relu == 4) {
             // epilogue with F.MaxPooling2D(2, 2) (cover_all) fused behind the ReLU: the wave's two rows are one window row
             // pair (tile rows start at multiples of 4), the horizontal neighbour is the next lane.  y is (Cout, ceil(H/2), ceil(W/2)).
             if constexpr (APX == 2) {
@@ -880,10 +920,10 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
                       int H, int W, int ksize, int act, void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (Cout % 64) != 0) return FRCNN_ERR_INVALID;
-    if (act < 0 || act > 4 || ((act == 2 || act == 3) && !mask) || (ksize != 1 && ksize != 3) || (act == 4 && ksize != 3)) return FRCNN_ERR_INVALID;
+    if (act < 0 || act > 5 || ((act == 2 || act == 3 || act == 5) && !mask) || (ksize != 1 && ksize != 3) || ((act == 4 || act == 5) && ksize != 3)) return FRCNN_ERR_INVALID;
     if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cin * ksize * ksize * Cout * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;
     if (ksize == 1) return launch_conv<1, 2, 2, 1, 1, 32, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, 0, nullptr, 0, stream, mask);
-    const int cfg = pick_conv_config(Cin, Cout, H, W, act == 4);
+    const int cfg = pick_conv_config(Cin, Cout, H, W, act == 4 || act == 5);
     const int streamk = cfg / 100;
     switch (cfg % 100) {
         case 34: return launch_conv<3, 2, 2, 1, 2, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);

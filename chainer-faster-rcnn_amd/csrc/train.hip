@@ -253,6 +253,24 @@ maxpool2x2_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy,
     }
 }
 
+// the same routing from the arg-max bytes the fused conv + ReLU + pool epilogue wrote (conv.hip, act 5): no pre-pool map to read
+__global__ void __launch_bounds__(256)
+maxpool2x2_bwd_idx_kernel(const unsigned char *__restrict__ idx, const float *__restrict__ dy, float *__restrict__ dx, int C, int H, int W, int OH, int OW) {
+    const uint32_t total = (uint32_t)C * OH * OW;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t ow = i % (uint32_t)OW, t = i / (uint32_t)OW, oh = t % (uint32_t)OH, c = t / (uint32_t)OH;
+        const size_t base = ((size_t)c * H + 2 * oh) * W + 2 * ow;
+        const bool hasx = 2 * ow + 1 < (uint32_t)W, hasy = 2 * oh + 1 < (uint32_t)H;
+        const int arg = idx[i];
+        const float g = dy[i];
+        float *d = dx + base;
+        d[0] = arg == 0 ? g : 0.0f;
+        if (hasx) d[1] = arg == 1 ? g : 0.0f;
+        if (hasy) d[W] = arg == 2 ? g : 0.0f;
+        if (hasx && hasy) d[W + 1] = arg == 3 ? g : 0.0f;
+    }
+}
+
 // db[c] = sum over pixels of dy[c][:].  Two fixed-shape stages (deterministic): `parts` workgroups per channel each reduce a
 // contiguous slice (float4 loads), then one wave per channel adds the partials in order.
 __global__ void __launch_bounds__(256)
@@ -1245,6 +1263,16 @@ int frcnn_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int C, 
     if (total >= (1ull << 32)) return FRCNN_ERR_INVALID;
     const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
     hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, dy, dx, C, H, W, OH, OW);
+    return frcnn_launch_status();
+}
+
+int frcnn_maxpool2x2_bwd_idx_f32(const unsigned char *idx, const float *dy, float *dx, int C, int H, int W, void *stream) {
+    if (!idx || !dy || !dx || C < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
+    const int OH = (H + 1) / 2, OW = (W + 1) / 2;
+    const size_t total = (size_t)C * OH * OW;
+    if (total >= (1ull << 32)) return FRCNN_ERR_INVALID;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(maxpool2x2_bwd_idx_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, idx, dy, dx, C, H, W, OH, OW);
     return frcnn_launch_status();
 }
 

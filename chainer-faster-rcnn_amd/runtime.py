@@ -754,6 +754,27 @@ class Runtime(object):
         _lib.check(L.frcnn_maxpool2x2_bwd_f32(m.ptr(x), m.ptr(dy), m.ptr(dx), C, H, W, m.stream()), "frcnn_maxpool2x2_bwd_f32")
         return dx
 
+    def conv_relu_pool_train(self, x, w_packed, bias):
+        """conv3x3 + ReLU + F.MaxPooling2D(2,2) in one launch, training form: (pooled map (1,Cout,OH,OW), arg-max bytes (Cout,OH,OW) u8)
+        -- what the pool's backward pass needs instead of the pre-pool map, which is never written."""
+        m, L = self.mem, self.lib
+        ci, H, W = [int(v) for v in x.shape[-3:]]
+        co = int(w_packed.shape[1])
+        oh, ow = (H + 1) // 2, (W + 1) // 2
+        y = m.empty((1, co, oh, ow), "f32")
+        idx = m.empty((co, oh, ow), "u8")
+        ws = self._conv_workspace(ci, co, H, W)
+        _lib.check(L.frcnn_conv_f32_ex(m.ptr(x), m.ptr(w_packed), m.ptr(bias), m.ptr(idx), m.ptr(y), ci, co, H, W, 3, 5, m.ptr(ws), ws.shape[0],
+                                       m.stream()), "frcnn_conv_f32_ex")
+        return y, idx
+
+    def maxpool2x2_bwd_idx(self, idx, dy, H, W):
+        m, L = self.mem, self.lib
+        C = int(idx.shape[0])
+        dx = m.empty((1, C, int(H), int(W)), "f32")
+        _lib.check(L.frcnn_maxpool2x2_bwd_idx_f32(m.ptr(idx), m.ptr(dy), m.ptr(dx), C, int(H), int(W), m.stream()), "frcnn_maxpool2x2_bwd_idx_f32")
+        return dx
+
     def bias_grad(self, dy, out=None):
         m, L = self.mem, self.lib
         C = int(dy.shape[-3])

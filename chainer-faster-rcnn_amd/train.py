@@ -30,13 +30,39 @@ from .chainer_compat import unwrap
 from .models.anchor_target_layer import AnchorTargetLayer
 
 
-def trunk_forward(model, x):
-    """Trunk forward keeping every layer's input (the backward pass needs them) -> (feat, inputs)."""
+class _PoolArg(object):
+    """What the backward pass of a pool FUSED into its convolution needs: the arg-max byte of every window and the pre-pool size."""
+
+    def __init__(self, idx, H, W):
+        self.idx, self.H, self.W = idx, int(H), int(W)
+
+
+def trunk_forward(model, x, fuse_pools=True):
+    """Trunk forward keeping every layer's input (the backward pass needs them) -> (feat, inputs).  A convolution that is followed by a
+    pool runs conv + ReLU + pool as ONE launch (csrc/conv.hip, act 5) and keeps a byte per window instead of the pre-pool map: the
+    pool's entry in `inputs` is then a _PoolArg (fuse_pools=False / FRCNN_TRAIN_FUSE_POOL=0: two launches, the pre-pool map kept --
+    the tests that impose the device's decisions on a float64 pass read it)."""
     rt = model.rt
-    inputs, h = [], x
-    for l in model.trunk.layers:
+    layers = model.trunk.layers
+    fuse = fuse_pools and os.environ.get("FRCNN_TRAIN_FUSE_POOL") != "0"
+    inputs, h, skip = [], x, None
+    for idx, l in enumerate(layers):
+        if l == "pool":
+            if skip is not None:                                      # applied inside the previous convolution
+                inputs.append(skip)
+                skip = None
+                continue
+            inputs.append(h)
+            h = rt.maxpool2x2(h)
+            continue
         inputs.append(h)
-        h = rt.maxpool2x2(h) if l == "pool" else model.trunk.links[l[0]](h, relu=True)
+        link = model.trunk.links[l[0]]
+        if fuse and idx + 1 < len(layers) and layers[idx + 1] == "pool" and int(link.cin) > 3 and int(link.cout) % 64 == 0:
+            H, W = int(h.shape[2]), int(h.shape[3])
+            h, arg = rt.conv_relu_pool_train(h, link.Wp, link.b)
+            skip = _PoolArg(arg, H, W)
+        else:
+            h = link(h, relu=True)
     return h, inputs
 
 
@@ -55,6 +81,9 @@ def trunk_backward(trainer, layer_inputs, g):
     links = dict(trainer.convs)
     for l, xin in reversed(layer_inputs):
         if l == "pool":
+            if isinstance(xin, _PoolArg):                             # the pool ran inside its convolution: route by the kept bytes
+                g = rt.maxpool2x2_bwd_idx(xin.idx, g, xin.H, xin.W)
+                continue
             if getattr(trainer, "keep_dy", None) is not None:        # tests: the pre-pool maps (near-tie windows = where two fp32 passes may route differently)
                 trainer.kept_dy.setdefault("pool_inputs", []).append(xin)
             g = rt.maxpool2x2_bwd(xin, g)
@@ -309,7 +338,7 @@ class RPNTrainer(_BucketedAllReduce):
                 with _grad_stream(rt):                                # on the gradient stream: under the forward pass, joined before the backward pass
                     rt.pack_conv_dgrad_w_many([(l.Wp, self.wd[n], 3) for n, l in self.convs[1:]] + [(rpn._heads_packed[0], self.wd_heads, 1)])
                 self._dgrad_packed = True
-            feat, inputs = trunk_forward(model, x)                     # keeps every layer's input
+            feat, inputs = trunk_forward(model, x, fuse_pools=getattr(self, "keep_dy", None) is None)     # keeps every layer's input
             mid = rpn.rpn_conv_3x3(feat, relu=True)
         score, prob, bbox = rt.rpn_heads(mid, rpn._heads_packed)
         if getattr(self, "keep_dy", None) is not None:               # tests: every activation map a ReLU / max-pool decision was taken on

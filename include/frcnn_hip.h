@@ -203,6 +203,8 @@ int frcnn_softmax_rows(const float *scores, int R, int n, float *probs, void *st
 
 /* generic form of the convolution entry: ksize 1 or 3 (stride 1, pad ksize/2), act 0 = none, 1 = ReLU,
  * 4 = ReLU then F.MaxPooling2D(2,2) (cover_all) fused into the epilogue: y is (Cout, ceil(H/2), ceil(W/2)) (ksize 3),
+ * 5 = the training form of 4: as 4, plus the window cell every pooled value came from (0..3 = (row, column) scan order, first maximum) as one
+ *     byte per pooled value at `mask`, reinterpreted as unsigned char[Cout][ceil(H/2)][ceil(W/2)] (frcnn_maxpool2x2_bwd_idx_f32 reads it),
  * 3 = y = relu(conv + bias + mask) (residual add), 2 = y = (mask > 0) ? conv + bias : 0  -- the input-gradient convolution of the backward pass with the producing
  * ReLU's mask fused in (mask has y's shape).  Cout % 64 == 0. */
 int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, const float *mask, float *y, int Cin,
@@ -369,6 +371,8 @@ int frcnn_relu_bwd_f32(float *g, const float *out, size_t n, void *stream);
 int frcnn_gather_rows_f32(const float *src, const int32_t *idx, int n, int cols, float *dst, void *stream);
 int frcnn_scatter_rows_f32(const float *src, const int32_t *idx, int n, int cols, float *dst, int dst_rows, void *stream);
 int frcnn_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int C, int H, int W, void *stream);
+/* the same from the arg-max bytes of frcnn_conv_f32_ex(act = 5) instead of the pool's input: dx (C,H,W) = dy routed to cell idx of each window */
+int frcnn_maxpool2x2_bwd_idx_f32(const unsigned char *idx, const float *dy, float *dx, int C, int H, int W, void *stream);
 size_t frcnn_bias_grad_workspace_bytes(int C, int HW);
 int frcnn_bias_grad_f32(const float *dy, int C, int HW, float *db, void *workspace, size_t workspace_bytes, void *stream);
 int frcnn_pack_conv_dgrad_w(const float *w_packed, int Cin, int Cout, int ksize, float *w_dgrad, void *stream);

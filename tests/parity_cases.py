@@ -445,6 +445,40 @@ def check_conv_backward(rt, Cin, Cout, H, W, ksize=3, seed=0):
         assert np.abs(dx - want).max() <= 1e-4 * max(np.abs(want).max(), 1e-6)
 
 
+def check_conv_relu_pool_train(rt, Cin, Cout, H, W, seed=0):
+    """training form of the fused conv + ReLU + 2x2 max-pool (act 5) against the two-launch path (conv + ReLU, then the pool; another tile
+    shape, so sums differ in the last bits): the pooled map within 2e-6, every arg-max byte points at a cell within 2e-6 of its window's
+    maximum and is the FIRST such cell wherever the maximum is unique by that margin, and the pool's backward pass from the bytes puts
+    each gradient value into exactly that cell."""
+    rs = np.random.RandomState(seed)
+    x = np.maximum(rs.randn(1, Cin, H, W), 0).astype(np.float32)
+    w = (rs.randn(Cout, Cin, 3, 3) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    b = (rs.randn(Cout) * 0.5).astype(np.float32)             # sizeable biases: whole windows end up <= 0
+    wp = dev(rt, np.ascontiguousarray(w.reshape(Cout, Cin * 9).T))
+    full = host(rt, rt.conv_ex(dev(rt, x), wp, dev(rt, b), 3, act=1))[0]
+    pooled, idx = rt.conv_relu_pool_train(dev(rt, x), wp, dev(rt, b))
+    pooled, idx = host(rt, pooled)[0], host(rt, idx)
+    OH, OW = (H + 1) // 2, (W + 1) // 2
+    pad = np.full((Cout, 2 * OH, 2 * OW), -np.inf, np.float32)
+    pad[:, :H, :W] = full
+    cells = np.stack([pad[:, 0::2, 0::2], pad[:, 0::2, 1::2], pad[:, 1::2, 0::2], pad[:, 1::2, 1::2]], axis=-1)     # window scan order
+    wmax = cells.max(axis=-1)
+    tol = 2e-6 * max(np.abs(full).max(), 1.0)
+    assert np.abs(pooled - wmax).max() <= tol
+    chosen = np.take_along_axis(cells, idx[..., None].astype(np.int64), axis=-1)[..., 0]
+    assert np.all(chosen >= wmax - tol) and idx.max() <= 3
+    clear = (np.sort(cells, axis=-1)[..., -1] - np.sort(cells, axis=-1)[..., -2]) > 4 * tol                          # unique maximum
+    assert np.array_equal(idx[clear], cells.argmax(axis=-1)[clear])
+    zero = wmax <= 0
+    assert zero.any() and np.all(idx[zero & (np.abs(cells).max(axis=-1) == 0)] == 0)                                  # all-zero windows: cell 0
+    g = rs.randn(Cout, OH, OW).astype(np.float32)
+    dx = host(rt, rt.maxpool2x2_bwd_idx(dev(rt, idx), dev(rt, g[None]), H, W))[0]
+    want = np.zeros((Cout, 2 * OH, 2 * OW), np.float32)
+    for k, (dy_, dx_) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+        want[:, dy_::2, dx_::2] = np.where(idx == k, g, 0.0)
+    assert np.array_equal(dx, want[:, :H, :W])
+
+
 def check_pack_dgrad_many(rt, seed=0):
     """one-launch re-pack of several layers' input-gradient weights (tiled transposes) == the per-layer kernel == NumPy"""
     rs = np.random.RandomState(seed)

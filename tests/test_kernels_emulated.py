@@ -157,6 +157,11 @@ def test_conv1_wgrad_first_layer_form(rt, monkeypatch):
     P.check_conv_backward(rt, 3, 64, 7, 33, seed=1)
 
 
+def test_conv_relu_pool_train(rt):
+    P.check_conv_relu_pool_train(rt, 8, 64, 9, 37)              # odd H and W: clipped windows on both edges
+    P.check_conv_relu_pool_train(rt, 64, 128, 8, 70, seed=1)     # the 128-cout tiles (four accumulators per wave)
+
+
 def test_pack_dgrad_many(rt):
     P.check_pack_dgrad_many(rt)
 
