@@ -101,6 +101,7 @@ SIGNATURES = {
     "frcnn_scatter_rows_f32": (_I, [_P, _P, _I, _I, _P, _I, _P]),
     "frcnn_maxpool2x2_bwd_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "frcnn_maxpool2x2_bwd_idx_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "frcnn_conv_dgrad_unpool_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_bias_grad_workspace_bytes": (_S, [_I, _I]),
     "frcnn_bias_grad_f32": (_I, [_P, _I, _I, _P, _P, _S, _P]),
     "frcnn_pack_conv_dgrad_w": (_I, [_P, _I, _I, _I, _P, _P]),

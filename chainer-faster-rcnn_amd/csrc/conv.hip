@@ -106,6 +106,9 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
         g = xcd * q + (xcd < r ? xcd : r) + (g >> 3);
     }
     relu &= 255;
+    // act 6 (the input-gradient convolution in front of a fused pool, see the epilogue): bits 3 / 4 of the act byte = the pre-pool map has an odd height / width
+    const bool unpool_h_odd = (relu & 8) != 0, unpool_w_odd = (relu & 16) != 0;
+    if ((relu & 7) == 6) relu = 6;
     const long long it_begin = g * total / G, it_end = (g + 1) * total / G;
 
     float4 wreg[WIT];
@@ -430,7 +433,7 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
                         if (writer) {
                             const size_t o = o0 + (size_t)((r & 3) + 8 * (r >> 2)) * OH * OW;
                             y[o] = m;
-                            arg_map[o] = (unsigned char)k;
+                            arg_map[o] = (unsigned char)(k | (m > 0.0f ? 4 : 0));          // bit 2: the pooled value is positive (the ReLU mask of the layer above)
                         }
                     }
                 }
@@ -479,6 +482,29 @@ conv_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
                         for (int r = 0; r < 16; ++r) {
                             const float b = (r & 3) == 0 ? bq[r >> 2].x : ((r & 3) == 1 ? bq[r >> 2].y : ((r & 3) == 2 ? bq[r >> 2].z : bq[r >> 2].w));
                             v[r] = acc[i][j][r] + b;
+                        }
+                        if (relu == 6) {
+                            // input-gradient convolution whose output is the gradient of a POOLED map (the layer below ran conv + ReLU + pool
+                            // fused, act 5): masked by that layer's ReLU (bit 2 of its arg-max byte) and written straight into the
+                            // pre-pool gradient map -- the value into the window's arg-max cell, zeros into the other cells -- so the pool's
+                            // backward pass is no launch of its own.  y is (Cout, H2, W2), H2 = 2H or 2H - 1.
+                            const unsigned char *arg_map = reinterpret_cast<const unsigned char *>(mask);
+                            const int H2 = 2 * H - (unpool_h_odd ? 1 : 0), W2 = 2 * W - (unpool_w_odd ? 1 : 0);
+                            const bool hasx = 2 * px + 1 < W2, hasy = 2 * py + 1 < H2;
+                            unsigned char bt[16];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) bt[r] = arg_map[o0 + (size_t)((r & 3) + 8 * (r >> 2)) * HW];
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float g = (bt[r] & 4) ? v[r] : 0.0f;
+                                const int k = bt[r] & 3;
+                                float *d = y + ((size_t)(cob + (r & 3) + 8 * (r >> 2)) * H2 + 2 * py) * W2 + 2 * px;
+                                d[0] = k == 0 ? g : 0.0f;
+                                if (hasx) d[1] = k == 1 ? g : 0.0f;
+                                if (hasy) d[W2] = k == 2 ? g : 0.0f;
+                                if (hasx && hasy) d[W2 + 1] = k == 3 ? g : 0.0f;
+                            }
+                            continue;
                         }
                         if (relu == 2 || relu == 3) {
                             float mv[16];
@@ -931,6 +957,26 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
         case 46: return launch_conv<3, 2, 2, 1, 1, 4, true, 6, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
         case 38: return launch_conv<3, 2, 2, 2, 2, 4, true, 2, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
         default: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
+    }
+}
+
+int frcnn_conv_dgrad_unpool_f32(const float *x, const float *w_packed, const float *bias, const unsigned char *argmax, float *y, int Cin, int Cout, int H,
+                                int W, int H2, int W2, void *workspace, size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!x || !w_packed || !bias || !argmax || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (Cout % 64) != 0) return FRCNN_ERR_INVALID;
+    if ((H2 != 2 * H && H2 != 2 * H - 1) || (W2 != 2 * W && W2 != 2 * W - 1)) return FRCNN_ERR_INVALID;
+    if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cin * 9 * Cout * 4 >= (1ull << 31) || (size_t)Cout * H2 * W2 * 4 >= (1ull << 32)) return FRCNN_ERR_INVALID;
+    const float *zero_bias = bias;
+    const int act = 6 | (H2 == 2 * H - 1 ? 8 : 0) | (W2 == 2 * W - 1 ? 16 : 0);
+    const float *mask = reinterpret_cast<const float *>(argmax);
+    const int cfg = pick_conv_config(Cin, Cout, H, W, false);
+    const int streamk = cfg / 100;
+    switch (cfg % 100) {
+        case 34: return launch_conv<3, 2, 2, 1, 2, 4, true, 4, 0, true>(x, w_packed, zero_bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
+        case 36: return launch_conv<3, 2, 2, 1, 1, 4, true, 4, 0, true>(x, w_packed, zero_bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
+        case 46: return launch_conv<3, 2, 2, 1, 1, 4, true, 6, 0, true>(x, w_packed, zero_bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
+        case 38: return launch_conv<3, 2, 2, 2, 2, 4, true, 2, 0, true>(x, w_packed, zero_bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
+        default: return launch_conv<3, 2, 2, 1, 2, 8, true, 3, 0, true>(x, w_packed, zero_bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
     }
 }
 

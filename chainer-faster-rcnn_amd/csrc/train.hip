@@ -261,7 +261,7 @@ maxpool2x2_bwd_idx_kernel(const unsigned char *__restrict__ idx, const float *__
         const uint32_t ow = i % (uint32_t)OW, t = i / (uint32_t)OW, oh = t % (uint32_t)OH, c = t / (uint32_t)OH;
         const size_t base = ((size_t)c * H + 2 * oh) * W + 2 * ow;
         const bool hasx = 2 * ow + 1 < (uint32_t)W, hasy = 2 * oh + 1 < (uint32_t)H;
-        const int arg = idx[i];
+        const int arg = idx[i] & 3;                                  // (bit 2 of the byte is the ReLU mask of the layer above, read by conv.hip's act 6)
         const float g = dy[i];
         float *d = dx + base;
         d[0] = arg == 0 ? g : 0.0f;

@@ -768,6 +768,19 @@ class Runtime(object):
                                        m.stream()), "frcnn_conv_f32_ex")
         return y, idx
 
+    def conv_dgrad_unpool(self, dy, w_dgrad, zero_bias, idx, H2, W2):
+        """input-gradient convolution of the layer above a fused pool + that pool's backward pass: dy (1,Cin,H,W), idx (Cout,H,W) u8 from
+        conv_relu_pool_train of the layer below -> dL/d(pre-pool map) (1,Cout,H2,W2)."""
+        m, L = self.mem, self.lib
+        ci, H, W = [int(v) for v in dy.shape[-3:]]
+        co = int(w_dgrad.shape[1])
+        assert int(w_dgrad.shape[0]) == ci * 9 and tuple(int(v) for v in idx.shape) == (co, H, W)
+        dx = m.empty((1, co, int(H2), int(W2)), "f32")
+        ws = self._conv_workspace(ci, co, H, W)
+        _lib.check(L.frcnn_conv_dgrad_unpool_f32(m.ptr(dy), m.ptr(w_dgrad), m.ptr(zero_bias), m.ptr(idx), m.ptr(dx), ci, co, H, W, int(H2), int(W2), m.ptr(ws),
+                                                 ws.shape[0], m.stream()), "frcnn_conv_dgrad_unpool_f32")
+        return dx
+
     def maxpool2x2_bwd_idx(self, idx, dy, H, W):
         m, L = self.mem, self.lib
         C = int(idx.shape[0])

@@ -79,8 +79,14 @@ def trunk_backward(trainer, layer_inputs, g):
     rt = trainer.rt
     first = trainer.convs[0][0]
     links = dict(trainer.convs)
-    for l, xin in reversed(layer_inputs):
+    unpool = os.environ.get("FRCNN_TRAIN_FUSE_POOL") != "0"
+    skip_pool = False
+    for pos in range(len(layer_inputs) - 1, -1, -1):
+        l, xin = layer_inputs[pos]
         if l == "pool":
+            if skip_pool:                                             # done in the epilogue of the input-gradient convolution above
+                skip_pool = False
+                continue
             if isinstance(xin, _PoolArg):                             # the pool ran inside its convolution: route by the kept bytes
                 g = rt.maxpool2x2_bwd_idx(xin.idx, g, xin.H, xin.W)
                 continue
@@ -102,7 +108,15 @@ def trunk_backward(trainer, layer_inputs, g):
         if name != first:                                         # the image needs no gradient
             if not getattr(trainer, "_dgrad_packed", False):          # (RPNTrainer re-packs every layer in one launch per step)
                 rt.pack_conv_dgrad_w(links[name].Wp, 3, out=trainer.wd[name])
-            g = rt.conv_ex(g, trainer.wd[name], trainer.zero_bias, 3, act=2, mask=xin)
+            below = layer_inputs[pos - 1] if pos > 0 else None
+            if unpool and below is not None and below[0] == "pool" and isinstance(below[1], _PoolArg):
+                # the layer below ran conv + ReLU + pool as one launch: its ReLU mask (pooled > 0) and the pool's routing both sit in
+                # its arg-max bytes, and this convolution writes dL/d(pre-pool map) directly (csrc/conv.hip, act 6)
+                pa = below[1]
+                g = rt.conv_dgrad_unpool(g, trainer.wd[name], trainer.zero_bias, pa.idx, pa.H, pa.W)
+                skip_pool = True
+            else:
+                g = rt.conv_ex(g, trainer.wd[name], trainer.zero_bias, 3, act=2, mask=xin)
     rt.mem.join_aux_stream("grad")
     return g
 

@@ -371,6 +371,12 @@ int frcnn_relu_bwd_f32(float *g, const float *out, size_t n, void *stream);
 int frcnn_gather_rows_f32(const float *src, const int32_t *idx, int n, int cols, float *dst, void *stream);
 int frcnn_scatter_rows_f32(const float *src, const int32_t *idx, int n, int cols, float *dst, int dst_rows, void *stream);
 int frcnn_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int C, int H, int W, void *stream);
+/* the input-gradient convolution of the layer ABOVE a fused pool (3x3, frcnn_pack_conv_dgrad_w weights, `bias` = Cout zeros) with that pool's backward
+ * pass in its epilogue: x (Cin,H,W) = dL/d(output of the layer above), argmax = the bytes frcnn_conv_f32_ex(act = 5) wrote for the layer below
+ * (Cout,H,W: bits 0-1 the window cell, bit 2 "pooled value > 0" = the ReLU mask), y (Cout,H2,W2) = dL/d(pre-pool map): every value lands in its
+ * window's arg-max cell, the other cells are written 0.  H2 = 2H or 2H-1, W2 likewise.  Workspace: frcnn_conv3x3_workspace_bytes. */
+int frcnn_conv_dgrad_unpool_f32(const float *x, const float *w_packed, const float *bias, const unsigned char *argmax, float *y, int Cin, int Cout,
+                                int H, int W, int H2, int W2, void *workspace, size_t workspace_bytes, void *stream);
 /* the same from the arg-max bytes of frcnn_conv_f32_ex(act = 5) instead of the pool's input: dx (C,H,W) = dy routed to cell idx of each window */
 int frcnn_maxpool2x2_bwd_idx_f32(const unsigned char *idx, const float *dy, float *dx, int C, int H, int W, void *stream);
 size_t frcnn_bias_grad_workspace_bytes(int C, int HW);

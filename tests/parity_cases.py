@@ -457,7 +457,10 @@ def check_conv_relu_pool_train(rt, Cin, Cout, H, W, seed=0):
     wp = dev(rt, np.ascontiguousarray(w.reshape(Cout, Cin * 9).T))
     full = host(rt, rt.conv_ex(dev(rt, x), wp, dev(rt, b), 3, act=1))[0]
     pooled, idx = rt.conv_relu_pool_train(dev(rt, x), wp, dev(rt, b))
-    pooled, idx = host(rt, pooled)[0], host(rt, idx)
+    pooled, idx_dev = host(rt, pooled)[0], idx
+    raw = host(rt, idx_dev)
+    assert np.array_equal((raw & 4) != 0, pooled > 0) and raw.max() <= 7          # bit 2: the ReLU mask of the layer above
+    idx = raw & 3
     OH, OW = (H + 1) // 2, (W + 1) // 2
     pad = np.full((Cout, 2 * OH, 2 * OW), -np.inf, np.float32)
     pad[:, :H, :W] = full
@@ -472,11 +475,35 @@ def check_conv_relu_pool_train(rt, Cin, Cout, H, W, seed=0):
     zero = wmax <= 0
     assert zero.any() and np.all(idx[zero & (np.abs(cells).max(axis=-1) == 0)] == 0)                                  # all-zero windows: cell 0
     g = rs.randn(Cout, OH, OW).astype(np.float32)
-    dx = host(rt, rt.maxpool2x2_bwd_idx(dev(rt, idx), dev(rt, g[None]), H, W))[0]
+    dx = host(rt, rt.maxpool2x2_bwd_idx(idx_dev, dev(rt, g[None]), H, W))[0]
     want = np.zeros((Cout, 2 * OH, 2 * OW), np.float32)
     for k, (dy_, dx_) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
         want[:, dy_::2, dx_::2] = np.where(idx == k, g, 0.0)
     assert np.array_equal(dx, want[:, :H, :W])
+
+
+def check_conv_dgrad_unpool(rt, Cmid, Cout, H2, W2, seed=0):
+    """the input-gradient convolution above a fused pool with the pool's backward pass in its epilogue (act 6) against the three-launch
+    path: the same convolution masked by pooled > 0 (act 2), then the pool's backward pass from the arg-max bytes -- bit for bit."""
+    rs = np.random.RandomState(seed)
+    H, W = (H2 + 1) // 2, (W2 + 1) // 2
+    # layer below: Cout channels, pre-pool H2 x W2 -> pooled H x W with arg-max bytes (from the device, so that the bytes are the product's own)
+    x0 = np.maximum(rs.randn(1, 8, H2, W2), 0).astype(np.float32)
+    w0 = (rs.randn(Cout, 8, 3, 3) * 0.2).astype(np.float32)
+    b0 = (rs.randn(Cout) * 0.5).astype(np.float32)
+    pooled, idx = rt.conv_relu_pool_train(dev(rt, x0), dev(rt, np.ascontiguousarray(w0.reshape(Cout, 72).T)), dev(rt, b0))
+    assert tuple(int(v) for v in pooled.shape) == (1, Cout, H, W)
+    # layer above: Cout -> Cmid; its input gradient maps Cmid -> Cout
+    w1 = (rs.randn(Cmid, Cout, 3, 3) * np.sqrt(2.0 / (Cout * 9))).astype(np.float32)
+    wp1 = dev(rt, np.ascontiguousarray(w1.reshape(Cmid, Cout * 9).T))
+    wd = rt.pack_conv_dgrad_w(wp1, 3)
+    dy = rs.randn(1, Cmid, H, W).astype(np.float32)
+    zero = dev(rt, np.zeros(max(Cout, 512), np.float32))
+    g_pooled = rt.conv_ex(dev(rt, dy), wd, zero, 3, act=2, mask=pooled)
+    want = host(rt, rt.maxpool2x2_bwd_idx(idx, g_pooled, H2, W2))
+    got = host(rt, rt.conv_dgrad_unpool(dev(rt, dy), wd, zero, idx, H2, W2))
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert (want != 0).any() and (host(rt, pooled) == 0).any()
 
 
 def check_pack_dgrad_many(rt, seed=0):

@@ -15,7 +15,7 @@ def rt():
 
 
 def test_library_is_the_device_build(rt):
-    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 17
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 18
 
 
 def test_nms_golden(rt):
@@ -223,6 +223,12 @@ def test_conv_relu_pool_train(rt):
     P.check_conv_relu_pool_train(rt, 64, 64, 120, 200)
     P.check_conv_relu_pool_train(rt, 128, 128, 75, 125, seed=1)
     P.check_conv_relu_pool_train(rt, 512, 512, 37, 63, seed=2)
+
+
+def test_conv_dgrad_unpool(rt):
+    P.check_conv_dgrad_unpool(rt, 128, 64, 120, 200)
+    P.check_conv_dgrad_unpool(rt, 256, 128, 75, 125, seed=1)
+    P.check_conv_dgrad_unpool(rt, 512, 512, 37, 63, seed=2)
 
 
 def test_pack_dgrad_many(rt):

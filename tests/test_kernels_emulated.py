@@ -162,6 +162,11 @@ def test_conv_relu_pool_train(rt):
     P.check_conv_relu_pool_train(rt, 64, 128, 8, 70, seed=1)     # the 128-cout tiles (four accumulators per wave)
 
 
+def test_conv_dgrad_unpool(rt):
+    P.check_conv_dgrad_unpool(rt, 64, 64, 9, 37)                 # odd pre-pool height and width
+    P.check_conv_dgrad_unpool(rt, 64, 128, 8, 66, seed=1)         # even sizes, the 128-cout tiles
+
+
 def test_pack_dgrad_many(rt):
     P.check_pack_dgrad_many(rt)
 
