@@ -6,13 +6,14 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; O=gpurun_out/r03wg; mkdir -p $O
 B=scripts/micro/_bin
 run() { echo "## $*"; env "$@" 2>&1; }
 {
-echo "== default (2 workgroups per CU)";              $B/wgrad_micro
-echo "== FRCNN_WGRAD_WPS=3";                          FRCNN_WGRAD_WPS=3 $B/wgrad_micro
-echo "== FRCNN_WGRAD_PRIO=1 (2 per CU)";              FRCNN_WGRAD_PRIO=1 $B/wgrad_micro conv1_2 conv3_2 conv4_2 conv5_1
-echo "== FRCNN_WGRAD_PRIO=1 FRCNN_WGRAD_WPS=3";       FRCNN_WGRAD_PRIO=1 FRCNN_WGRAD_WPS=3 $B/wgrad_micro conv1_2 conv3_2 conv4_2 conv5_1
+echo "== default (per-layer pick of the single- / double-buffered form)"; $B/wgrad_micro
+echo "== FRCNN_WGRAD_DB=0 (single buffer, 2 workgroups per CU, everywhere)"; FRCNN_WGRAD_DB=0 $B/wgrad_micro
+echo "== FRCNN_WGRAD_WPS=3";                          FRCNN_WGRAD_DB=0 FRCNN_WGRAD_WPS=3 $B/wgrad_micro
+echo "== FRCNN_WGRAD_PRIO=1 (2 per CU)";              FRCNN_WGRAD_DB=0 FRCNN_WGRAD_PRIO=1 $B/wgrad_micro conv1_2 conv3_2 conv4_2 conv5_1
+echo "== FRCNN_WGRAD_PRIO=1 FRCNN_WGRAD_WPS=3";       FRCNN_WGRAD_DB=0 FRCNN_WGRAD_PRIO=1 FRCNN_WGRAD_WPS=3 $B/wgrad_micro conv1_2 conv3_2 conv4_2 conv5_1
 echo "== FRCNN_WGRAD_DB=1";                           FRCNN_WGRAD_DB=1 $B/wgrad_micro conv1_2 conv3_2 conv4_2 conv5_1
 for w in 2 3; do for a in 1 4 8 5; do
-  echo "== ablation build WPS=$w ABL=$a (1 no DMA, 4 no MFMA, 8 no slab stores, 5 = neither DMA nor MFMA)"; FRCNN_WGRAD_WPS=$w FRCNN_WGRAD_ABL=$a $B/wgrad_micro_abl conv1_2 conv3_2 conv4_2 conv5_1
+  echo "== ablation build WPS=$w ABL=$a (1 no DMA, 4 no MFMA, 8 no slab stores, 5 = neither DMA nor MFMA)"; FRCNN_WGRAD_DB=0 FRCNN_WGRAD_WPS=$w FRCNN_WGRAD_ABL=$a $B/wgrad_micro_abl conv1_2 conv3_2 conv4_2 conv5_1
 done; done
 echo "== split-product kernel"; $B/wgrad_micro --f32s conv1_2 conv3_2 conv4_2 conv5_1
 } > $O/wgrad_micro.txt 2>&1
