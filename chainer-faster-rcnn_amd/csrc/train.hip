@@ -482,15 +482,13 @@ conv_wgrad_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy
 // barrier that hands over tile b and land under tile b's 288 MFMAs per wave.  Picked per layer (see wgrad_double_buffered()).
 // One fence-less barrier per tile, no counted waits (a wave issues 80 DMAs per tile,
 // more than vmcnt can count: the wait for tile b+1 is the vmcnt(0) at the top of the next trip, a whole compute phase later).
-// WPS = workgroups per CU the single-buffer form is compiled for: 2 (171 VGPRs) or 3 (168 VGPRs: three dwords of the tile set-up live in
-// scratch and are re-read once per tile, nothing in the MFMA loop; 3 x 51.4 KB of LDS).  ABL (timing ablations, WRONG results, only in
-// -DFRCNN_TIMING_ABLATIONS builds): 1 no DMA, 4 no MFMA phase, 8 no slab stores.
-// PRIO: the workgroups that share a CU (launch order: linear id / #CUs) run their MFMA phase at different wave priorities, so that two
-// of them that reach the phase together do not split the matrix pipe evenly and then both wait for their DMAs together.
-template <int KS, bool DB = false, int WPS = 2, int ABL = 0, bool PRIO = false>
-__global__ void __launch_bounds__(256, DB ? 1 : WPS)
+// ABL (timing ablations, WRONG results, only in -DFRCNN_TIMING_ABLATIONS builds): 1 no DMA, 4 no MFMA phase, 8 no slab stores.
+// (Measured in round 3 and removed again, DESIGN 3.6 / 3.11: three single-buffer workgroups per CU at 168 VGPRs -- +-1 %; wave priorities
+// and a staggered start by hardware wave slot -- no effect: a wave with an fp32 MFMA ready blocks the SIMD's issue stage whatever the priorities.)
+template <int KS, bool DB = false, int ABL = 0>
+__global__ void __launch_bounds__(256, DB ? 1 : 2)
 conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slabs, int Cin, int Cout, int H, int W,
-                      int xtiles, int nblocks, int splits, int prio_mode) {
+                      int xtiles, int nblocks, int splits) {
     constexpr int T = KS * KS, PAD = KS / 2;
     constexpr int HP = 32 + KS - 1;
     constexpr int HR = WG_ROWS + KS - 1;
@@ -630,13 +628,6 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
             for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][t], bv[1], acc[t], 0, 0, 0);
         }
     };
-    // class of this wave among the waves that share its SIMD = its hardware wave slot (HW_ID[3:0]); FRCNN_WGRAD_PRIO=2 staggers the
-    // classes once at the start instead (class k sleeps k x 8k clocks), =3 does both
-    int prio_class = 0;
-    if constexpr (PRIO) {
-        prio_class = (int)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) % (unsigned)WPS);
-        if ((prio_mode & 2) != 0) for (int k = 0; k < prio_class; ++k) __builtin_amdgcn_s_sleep(127);
-    }
     if constexpr (DB) {
         if (b_begin < b_end) issue(b_begin, 0);
         int buf = 0;
@@ -653,9 +644,7 @@ conv_wgrad_dma_kernel(const float *__restrict__ x, const float *__restrict__ dy,
             issue(b, 0);
             frcnn_wait_vmcnt<0>();
             frcnn_barrier_nofence();
-            if constexpr (PRIO) { if ((prio_mode & 1) != 0) { if (prio_class == 0) __builtin_amdgcn_s_setprio(2); else if (prio_class == 1) __builtin_amdgcn_s_setprio(1); } }
             compute(0);
-            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
     }
     if constexpr ((ABL & 8) != 0) { if (acc[0][0] != 12345.678f) return; }
@@ -1097,13 +1086,6 @@ static bool wgrad_double_buffered(int Cin, int Cout, int H, int W) {
     return cico == 1 || nblocks < 14 * splits2;
 }
 
-// workgroups per CU of the single-buffer 3x3 kernel (FRCNN_WGRAD_WPS=2|3: A/B hook; the default is the measured pick)
-static int wgrad_wgs_per_cu() {
-    const char *e = getenv("FRCNN_WGRAD_WPS");
-    if (e && (e[0] == '2' || e[0] == '3')) return e[0] - '0';
-    return 2;
-}
-
 // conv1_1 (Cin * 9 <= 32) has its own kernel; FRCNN_WGRAD_CONV1=generic keeps the generic one on it (A/B, tests compare the two)
 static bool wgrad_first_layer_form(int Cin, int ks) {
     if (ks != 3 || Cin * 9 > 32) return false;
@@ -1125,7 +1107,7 @@ static WgradPlan plan_wgrad(int Cin, int Cout, int H, int W, int ks) {
         return p;
     }
     // 3x3 double-buffered kernel: one workgroup per CU; the single-buffer forms (1x1, FRCNN_WGRAD_DB=0): about two per CU
-    int s = frcnn_cdiv((ks == 3 && wgrad_double_buffered(Cin, Cout, H, W)) ? frcnn_cu_count() : (ks == 3 ? wgrad_wgs_per_cu() : 2) * frcnn_cu_count(), p.ci_tiles * p.co_tiles);
+    int s = frcnn_cdiv((ks == 3 && wgrad_double_buffered(Cin, Cout, H, W)) ? frcnn_cu_count() : 2 * frcnn_cu_count(), p.ci_tiles * p.co_tiles);
     if (s > p.nblocks) s = p.nblocks;
     if (s < 1) s = 1;
     p.splits = s;
@@ -1346,29 +1328,23 @@ int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int 
     }
     const dim3 grid(p.ci_tiles, p.co_tiles, p.splits);
     const bool reg = getenv("FRCNN_WGRAD_REG") != nullptr;        // A/B hook: the register-staged kernel
-    if (ksize == 3 && !reg && wgrad_double_buffered(Cin, Cout, H, W)) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, 0);
+    if (ksize == 3 && !reg && wgrad_double_buffered(Cin, Cout, H, W)) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
     else if (ksize == 3 && !reg) {
-#define FRCNN_WGRAD_LAUNCH(WPS_, ABL_) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, WPS_, ABL_>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, 0)
-        const bool three = wgrad_wgs_per_cu() == 3;
+#define FRCNN_WGRAD_LAUNCH(ABL_) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, ABL_>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits)
 #ifdef FRCNN_TIMING_ABLATIONS
         const char *ae = getenv("FRCNN_WGRAD_ABL");
         const int abl = ae ? atoi(ae) : 0;
-        if (abl == 1) { if (three) FRCNN_WGRAD_LAUNCH(3, 1); else FRCNN_WGRAD_LAUNCH(2, 1); }
-        else if (abl == 4) { if (three) FRCNN_WGRAD_LAUNCH(3, 4); else FRCNN_WGRAD_LAUNCH(2, 4); }
-        else if (abl == 8) { if (three) FRCNN_WGRAD_LAUNCH(3, 8); else FRCNN_WGRAD_LAUNCH(2, 8); }
-        else if (abl == 5) { if (three) FRCNN_WGRAD_LAUNCH(3, 5); else FRCNN_WGRAD_LAUNCH(2, 5); }
+        if (abl == 1) FRCNN_WGRAD_LAUNCH(1);
+        else if (abl == 4) FRCNN_WGRAD_LAUNCH(4);
+        else if (abl == 8) FRCNN_WGRAD_LAUNCH(8);
+        else if (abl == 5) FRCNN_WGRAD_LAUNCH(5);
         else
 #endif
-        if (const char *pe = getenv("FRCNN_WGRAD_PRIO")) {          // A/B hook: 1 priorities, 2 stagger, 3 both
-            const int pm = atoi(pe);
-            if (three) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, 3, 0, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, pm);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, 2, 0, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, pm);
-        } else
-        if (three) FRCNN_WGRAD_LAUNCH(3, 0); else FRCNN_WGRAD_LAUNCH(2, 0);
+        FRCNN_WGRAD_LAUNCH(0);
 #undef FRCNN_WGRAD_LAUNCH
     }
     else if (ksize == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<3>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
-    else if (!reg) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<1>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits, 0);
+    else if (!reg) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<1>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_mfma_kernel<1>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
     const size_t n = p.slab_floats;
     const size_t work = (n / 4 + 255) / 256 + 1;

@@ -1,6 +1,6 @@
 // wgrad_micro.cpp -- times frcnn_conv_wgrad_f32 (libfrcnn_hip.so: the weight-gradient kernel + its slab reduction) on the VGG-16 layer
 // shapes at 600 x 1000 without torch: per layer a captured graph of 5 back-to-back calls, bursts of graph launches between two events.
-// Usage: wgrad_micro [--f32s] [layer ...]; settings come from the environment (FRCNN_WGRAD_WPS, FRCNN_WGRAD_DB, FRCNN_WGRAD_ABL in the
+// Usage: wgrad_micro [--f32s] [layer ...]; settings come from the environment (FRCNN_WGRAD_DB, FRCNN_WGRAD_ABL in the
 // ablation build ...).  Values: uniform fp32 in [-1, 1); results are not checked here (tests/ do that).
 #include <hip/hip_runtime.h>
 #include <stdint.h>

@@ -137,10 +137,9 @@ def test_conv_backward(rt):
     P.check_conv_backward(rt, 64, 64, 5, 40, ksize=1, seed=2)   # the RPN heads' 1x1
 
 
-@pytest.mark.parametrize("env", [{"FRCNN_WGRAD_WPS": "3", "FRCNN_WGRAD_DB": "0"}, {"FRCNN_WGRAD_DB": "1"}, {"FRCNN_WGRAD_DB": "0"}, {"FRCNN_WGRAD_PRIO": "3", "FRCNN_WGRAD_DB": "0"}])
+@pytest.mark.parametrize("env", [{"FRCNN_WGRAD_DB": "1"}, {"FRCNN_WGRAD_DB": "0"}])
 def test_conv_wgrad_forms(rt, monkeypatch, env):
-    """A/B forms of the 3x3 weight-gradient kernel: three workgroups per CU, double-buffered images with the next tile's DMAs ahead of /
-    inside the MFMA stream, wave priorities.  Several tiles per workgroup (the emulated chip has 3 CUs) and ragged borders."""
+    """A/B forms of the 3x3 weight-gradient kernel: the single-buffer form (two workgroups per CU) and the double-buffered one (one per CU) forced on every layer.  Several tiles per workgroup (the emulated chip has 3 CUs) and ragged borders."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     P.check_conv_backward(rt, 64, 64, 9, 70)
