@@ -589,6 +589,8 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
     conv_bf16_epilogue<BROWS, 256, RW, COB>(acc, ring, bias, y, Cout, CoutP, H, W, relu, out_mode, x0, y0, co0);
 }
 
+#include "conv_bf16_strip.h"      // conv_strip_bf16_kernel: one workgroup per CU, one wave per SIMD (candidate, FRCNN_BF16_DMA=900..903)
+
 // (Cout, Cin, k, k) fp32 -> [CinP/16][tap][CoutP][16] bf16, zero padded
 __global__ void __launch_bounds__(256)
 pack_w_bf16_kernel(const float *__restrict__ w, int Cout, int Cin, int taps, int CoutP, int CinP, uint16_t *__restrict__ wp) {
@@ -736,6 +738,42 @@ rpn_heads_bf16_fused_kernel(const uint16_t *__restrict__ h, const uint16_t *__re
 
 }  // namespace
 
+// The strip forms of conv_bf16_strip.h (FRCNN_BF16_DMA=901 / 902 / 903 = form A / B / C, 900 = the cheapest applicable one by a
+// count of MFMA rounds; candidates, not default picks: see the header).  Returns 1 when the form does not apply to the launch.
+template <int COB, int RW, int RG, int CW, int KW, int NS>
+static void conv_bf16_strip_go(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int CinP, int Cout, int CoutP, int H, int W,
+                               int relu, int out_mode, hipStream_t stream) {
+    const int xtiles = frcnn_cdiv(W, 32), ytiles = frcnn_cdiv(H, RG * RW), cotiles = frcnn_cdiv(CoutP, 32 * COB * CW);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_strip_bf16_kernel<COB, RW, RG, CW, KW, NS>), dim3((unsigned)((long)xtiles * ytiles * cotiles)), dim3(256), 0, stream,
+                       x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, cotiles);
+}
+static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int CinP, int Cout, int CoutP, int H, int W,
+                           int relu, int out_mode, hipStream_t stream) {
+    const int chunks = CinP / kCK;
+    // {couts per workgroup, tile rows, K ways, MFMAs per wave and stage}
+    static const int kForm[4][4] = {{0, 0, 0, 0}, {64, 20, 1, 90}, {64, 10, 1, 45}, {32, 5, 4, 45}};
+    auto applies = [&](int f) { return chunks % kForm[f][2] == 0 && !(out_mode == 2 && (kForm[f][1] & 1)); };
+    if (form == 0) {
+        const long cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
+        long best = -1;
+        for (int f = 1; f <= 3; ++f) {
+            if (!applies(f)) continue;
+            const long wgs = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, kForm[f][1]) * frcnn_cdiv(CoutP, kForm[f][0]);
+            // MFMAs in sequence on a SIMD: rounds x (stages + two stages' worth of prologue / epilogue) x MFMAs per wave and stage
+            const long cost = ((wgs + cus - 1) / cus) * (chunks / kForm[f][2] + 2) * kForm[f][3];
+            if (best < 0 || cost < best) { best = cost; form = f; }
+        }
+        if (form == 0) return 1;
+    }
+    if (!applies(form)) return 1;
+    switch (form) {
+    case 1: conv_bf16_strip_go<2, 5, 4, 1, 1, 3>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
+    case 2: conv_bf16_strip_go<1, 5, 2, 2, 1, 4>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
+    default: conv_bf16_strip_go<1, 5, 1, 1, 4, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
+    }
+    return 0;
+}
+
 extern "C" {
 
 int frcnn_bf16_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, void *stream) {
@@ -814,6 +852,12 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
     // compiled only with FRCNN_TIMING_ABLATIONS).
     const char *dma_env = getenv("FRCNN_BF16_DMA");
     int mode = dma_env ? atoi(dma_env) : -1;
+    if (ksize == 3 && mode >= 900 && mode <= 903) {
+        const int rc = conv_bf16_strip(mode - 900, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
+        if (rc == 0) return frcnn_launch_status();
+        if (mode != 900) return FRCNN_ERR_INVALID;                // an explicitly requested form that does not apply to this launch
+        mode = -1;                                                // 900: the measured default picks below
+    }
     // tile rows / accumulators per thread of the DMA kernel's shapes (RPW = last digit of the mode): 64 couts x {4, 8, 8, 16} rows x 32 px
     static const int kRowsOf[5] = {0, 4, 8, 8, 16}, kAccOf[5] = {0, 2, 4, 4, 8};
     if (mode < 0) {

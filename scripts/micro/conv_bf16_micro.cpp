@@ -2,12 +2,15 @@
 // captured graph of 10 back-to-back launches (outputs rotating over 3 buffers), bursts of graph launches between two events.
 // Usage: conv_bf16_micro [layer ...] with settings from the environment (FRCNN_BF16_DMA, FRCNN_BF16_DMA_DEFAULT, FRCNN_BF16_SPLIT ...)
 //        or conv_bf16_micro --modes "141 231 611" [layer ...] to sweep FRCNN_BF16_DMA per layer.
-// Values: uniform bf16 in [-1, 1) (weights x 0.05); results are not checked here (tests/ do that).
+//        --check: every mode's output is also compared with the default pick's (bf16 words that differ, largest difference) -- a
+//        hardware sanity check for a new staging form in seconds, without torch; the parity tests proper are tests/.
+// Values: uniform bf16 in [-1, 1) (weights x 0.05).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #include <algorithm>
 #include <random>
 #include <sstream>
@@ -27,8 +30,10 @@ static uint16_t bf16_of(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu +
 
 int main(int argc, char **argv) {
     std::vector<std::string> modes, want;
+    bool check = false;
     for (int i = 1; i < argc; ++i) {
-        if (!strcmp(argv[i], "--modes") && i + 1 < argc) { std::istringstream ss(argv[++i]); std::string m; while (ss >> m) modes.push_back(m); }
+        if (!strcmp(argv[i], "--check")) check = true;
+        else if (!strcmp(argv[i], "--modes") && i + 1 < argc) { std::istringstream ss(argv[++i]); std::string m; while (ss >> m) modes.push_back(m); }
         else want.push_back(argv[i]);
     }
     if (modes.empty()) modes.push_back("");
@@ -52,9 +57,20 @@ int main(int argc, char **argv) {
         CK(hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dw, hw.data(), nw * 2, hipMemcpyHostToDevice));
         const double gflop = 2.0 * L.h * L.w * L.co * L.ci * 9 / 1e9;
         printf("%-8s %3d->%3d %4dx%-4d %6.1f GFLOP:", L.name, L.ci, L.co, L.h, L.w, gflop);
+        const size_t nout = L.pool ? (size_t)cop * ((L.h + 1) / 2) * ((L.w + 1) / 2) : ny;
+        std::vector<uint16_t> ref, got;
+        if (check) {                                                       // the default pick's output
+            unsetenv("FRCNN_BF16_DMA");
+            CK(hipMemsetAsync(dy[0], 0xff, ny * 2, s));
+            if (frcnn_conv_bf16_ws(dx, dw, db, dy[0], L.ci, L.co, L.h, L.w, 3, 1, L.pool ? 2 : 0, ws, wsb, s) != 0) { printf(" default launch refused\n"); return 1; }
+            ref.resize(nout); got.resize(nout);
+            CK(hipStreamSynchronize(s));
+            CK(hipMemcpy(ref.data(), dy[0], nout * 2, hipMemcpyDeviceToHost));
+        }
         double best = 1e30;
         for (const std::string &m : modes) {
-            if (!m.empty()) setenv("FRCNN_BF16_DMA", m.c_str(), 1);
+            if (m == "def") unsetenv("FRCNN_BF16_DMA");                 // "def" in a --modes list = the default pick
+            else if (!m.empty()) setenv("FRCNN_BF16_DMA", m.c_str(), 1);
             hipGraph_t gr; hipGraphExec_t ge;
             CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
             bool ok = true;
@@ -62,6 +78,20 @@ int main(int argc, char **argv) {
                 ok = ok && frcnn_conv_bf16_ws(dx, dw, db, dy[i % 3], L.ci, L.co, L.h, L.w, 3, 1, L.pool ? 2 : 0, ws, wsb, s) == 0;
             CK(hipStreamEndCapture(s, &gr));
             if (!ok) { printf("  %s: launch refused", m.c_str()); CK(hipGraphDestroy(gr)); continue; }
+            if (check) {
+                CK(hipMemsetAsync(dy[0], 0xff, ny * 2, s));
+                if (frcnn_conv_bf16_ws(dx, dw, db, dy[0], L.ci, L.co, L.h, L.w, 3, 1, L.pool ? 2 : 0, ws, wsb, s) != 0) { printf(" launch refused\n"); return 1; }
+                CK(hipStreamSynchronize(s));
+                CK(hipMemcpy(got.data(), dy[0], nout * 2, hipMemcpyDeviceToHost));
+                size_t ndiff = 0; double maxd = 0, maxv = 0;
+                for (size_t i = 0; i < nout; ++i) {
+                    uint32_t a = (uint32_t)got[i] << 16, b = (uint32_t)ref[i] << 16; float fa, fb; memcpy(&fa, &a, 4); memcpy(&fb, &b, 4);
+                    if (got[i] != ref[i]) { ++ndiff; if (!(fabs((double)fa - fb) <= maxd)) maxd = fabs((double)fa - fb); }
+                    if (fabs((double)fb) > maxv) maxv = fabs((double)fb);
+                }
+                if (ndiff == 0) printf("  [%s = default]", m.empty() ? "default" : m.c_str());
+                else printf("  [%s: %zu of %zu words differ, max |d| %.3g of %.3g]", m.c_str(), ndiff, nout, maxd, maxv);
+            }
             CK(hipGraphInstantiate(&ge, gr, nullptr, nullptr, 0));
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(ge, s));

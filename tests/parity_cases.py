@@ -840,6 +840,41 @@ def check_conv_bf16_pool(rt, Cin, Cout, H, W, seed=0):
     assert fused.shape == sep.shape and np.array_equal(fused, sep)
 
 
+def check_conv_bf16_strip(rt, form, Cin, Cout, H, W, pool=False, seed=0):
+    """Strip form `form` (FRCNN_BF16_DMA=901 / 902 / 903, csrc/conv_bf16_strip.h) of the 3x3 bf16 convolution against the default
+    kernel on the same operands: bit-identical for the forms that keep one accumulation chain per output (A, B); within fp32
+    summation-order noise of it for the K-split form C (and then the bf16 outputs may differ by one rounding step at a tie)."""
+    rs = np.random.RandomState(seed)
+    x = rs.randn(1, Cin, H, W).astype(np.float32)
+    w = (rs.randn(Cout, Cin, 3, 3) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
+    b = dev(rt, (rs.randn(Cout) * 0.1).astype(np.float32))
+    xd = rt.bf16_from_nchw(dev(rt, x))
+    wpk = rt.bf16_pack_conv_w(dev(rt, w), 3)
+
+    def run():
+        y32 = host(rt, rt.conv_bf16(xd, wpk, b, Cin, Cout, 3, relu=True, out_f32_nchw=True))
+        y16 = host(rt, rt.conv_bf16(xd, wpk, b, Cin, Cout, 3, relu=True, pool=pool))
+        return y32, y16
+    old = os.environ.pop("FRCNN_BF16_DMA", None)
+    try:
+        ref32, ref16 = run()
+        os.environ["FRCNN_BF16_DMA"] = str(form)
+        got32, got16 = run()
+    finally:
+        os.environ.pop("FRCNN_BF16_DMA", None)
+        if old is not None:
+            os.environ["FRCNN_BF16_DMA"] = old
+    assert got32.shape == ref32.shape and got16.shape == ref16.shape
+    if form in (901, 902):
+        assert np.array_equal(got32, ref32) and np.array_equal(got16, ref16)
+    else:
+        scale = max(np.abs(ref32).max(), 1e-6)
+        assert np.abs(got32 - ref32).max() <= 2e-5 * scale, np.abs(got32 - ref32).max() / scale
+        a, c = from_bf16_bits(got16), from_bf16_bits(ref16)
+        assert np.all(np.abs(a - c) <= np.abs(c) * 2.0 ** -7 + 1e-5 * scale)
+        assert np.mean(got16 != ref16) < 0.01                   # a rounding tie here and there, not a different result
+
+
 def check_maxpool_bf16(rt, C, H, W, seed=0):
     rs = np.random.RandomState(seed)
     x = rs.randn(1, C, H, W).astype(np.float32)
