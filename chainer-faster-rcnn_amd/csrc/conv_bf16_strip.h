@@ -31,7 +31,7 @@
 #pragma once
 #include <type_traits>
 
-template <int COB, int RW, int RG, int CW, int KW, int NS>
+template <int COB, int RW, int RG, int CW, int KW, int NS, bool FRONT = false>
 struct StripShape {
     static constexpr int KS = 3, TAPS = 9, PAD = 1;
     static constexpr int GW = RG * CW;                                    // waves per K way
@@ -58,7 +58,7 @@ struct StripShape {
     // DMA pieces of the next-but-(NS-2) stage go out between the MFMAs of tap groups 0 .. 7 (the hand-over sits before group 8): evenly
     // over all of them with >= 3 stages (the data has more than a whole stage to arrive); with 2 stages it has to arrive within
     // THIS stage, so as early as one piece per two MFMAs allows
-    static constexpr int SPAN = NS >= 3 ? 8 * GM : (2 * (PPW + 1) < 8 * GM ? 2 * (PPW + 1) : 8 * GM);
+    static constexpr int SPAN = (NS >= 3 && !FRONT) ? 8 * GM : (2 * (PPW + 1) < 8 * GM ? 2 * (PPW + 1) : 8 * GM);
     static_assert(GW * KW == 4, "four waves");
     static_assert(KW == 1 || KW == 2 || KW == 4, "K ways");
     static_assert(LDS_BYTES <= 160 * 1024 - 64, "LDS");
@@ -67,11 +67,17 @@ struct StripShape {
     static_assert(2 * (COB + RW) <= 15, "two tap groups of fragment reads in flight: lgkmcnt holds 15");
 };
 
-template <int COB, int RW, int RG, int CW, int KW, int NS>
+#ifdef FRCNN_TIMING_ABLATIONS
+__device__ __forceinline__ void strip_keep(const uint4 &v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
+#endif
+
+// ABL (timing ablations, WRONG results, only in -DFRCNN_TIMING_ABLATIONS builds): 1 no DMA after the prologue, 2 no fragment reads after the
+// prologue, 4 no MFMAs (their operands are still waited for), 8 no stage hand-over (wait + barrier)
+template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, bool FRONT = false>
 __global__ void __launch_bounds__(256, 1)
 conv_strip_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
                        int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles, int cotiles) {
-    using S = StripShape<COB, RW, RG, CW, KW, NS>;
+    using S = StripShape<COB, RW, RG, CW, KW, NS, FRONT>;
     constexpr int KS = 3, TAPS = 9, PAD = 1, HPX = S::HPX, BCO = S::BCO, TR = S::TR, NACC = S::NACC, PPW = S::PPW, IN_Q = S::IN_Q, OP = S::OP, GW = S::GW;
     __shared__ __attribute__((aligned(1024))) unsigned char ring[S::LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -124,6 +130,16 @@ conv_strip_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restric
         }
     };
 
+    // prologue, first half: NS-1 stages go out NOW -- their latency (the longest single wait of a one-round launch: nobody else is
+    // resident to cover it) runs under the set-up below (fragment offsets, 160 accumulator writes)
+#pragma unroll
+    for (int c = 0; c < NS - 1; ++c)
+        if (c < nsc) {
+#pragma unroll
+            for (int q = 0; q < PPW; ++q) issue_piece(q, c, c);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+
     // fragment byte offsets inside a K-way's chunk image (swizzled): A = weight row tap*BCO + (cw*COB + cb)*32 + l31, B = halo pixel
     // (rg*RW + r)*34 + l31 + kx
     const uint32_t a_off = (uint32_t)(S::IN_BYTES + (cw * COB * 32 + l31) * 32 + ((khalf ^ ((l31 >> 3) & 1)) << 4));
@@ -165,26 +181,33 @@ conv_strip_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restric
         const unsigned char *st = ring + stage * S::STAGE_BYTES + kw * S::KW_BYTES;
 #pragma unroll
         for (int g = 0; g < TAPS; ++g) {
-            if (g >= 1 && g + 1 < TAPS) {
+            if (g >= 1 && g + 1 < TAPS && (ABL & 2) == 0) {
                 read_group(st, g + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (g == TAPS - 1 && NEXT) {
-                wait_allow(allow);
-                frcnn_barrier_nofence();
-                const unsigned char *stn = ring + stage_next * S::STAGE_BYTES + kw * S::KW_BYTES;
-                read_group(stn, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                read_group(stn, 1);
-                __builtin_amdgcn_sched_barrier(0);
+                if constexpr ((ABL & 8) == 0) {
+                    wait_allow(allow);
+                    frcnn_barrier_nofence();
+                }
+                if constexpr ((ABL & 2) == 0) {
+                    const unsigned char *stn = ring + stage_next * S::STAGE_BYTES + kw * S::KW_BYTES;
+                    read_group(stn, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_group(stn, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             const int ky = g / KS, kx = g - ky * KS;
 #pragma unroll
             for (int cb = 0; cb < COB; ++cb)
 #pragma unroll
                 for (int j = 0; j < RW; ++j) {
+#ifdef FRCNN_TIMING_ABLATIONS
+                    if constexpr ((ABL & 4) != 0) { strip_keep(fa[g % 3][cb]); strip_keep(fb[ky + j][kx]); } else
+#endif
                     acc[cb * RW + j] = frcnn_mfma_32x32x16_bf16(fa[g % 3][cb], fb[ky + j][kx], acc[cb * RW + j]);
-                    if constexpr (ISSUE) {
+                    if constexpr (ISSUE && (ABL & 1) == 0) {
                         const int m = (g * COB + cb) * RW + j;                             // folds to a constant in the unrolled body
                         const int q0 = m * (PPW + 1) / S::SPAN, q1 = (m + 1) * (PPW + 1) / S::SPAN;
                         if (q1 != q0 && q1 - 1 < PPW) {
@@ -200,13 +223,8 @@ conv_strip_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restric
     using Yes = std::true_type;
     using No = std::false_type;
 
-    // prologue: NS-1 stages in flight, stage 0 landed, its first two tap groups on their way into registers
-#pragma unroll
-    for (int c = 0; c < NS - 1; ++c)
-        if (c < nsc) {
-#pragma unroll
-            for (int q = 0; q < PPW; ++q) issue_piece(q, c, c);
-        }
+    // prologue, second half (the first NS-1 stages were issued above, before the fragment offsets and the accumulators were set up): stage 0
+    // landed, its first two tap groups on their way into registers
     wait_allow(min(NS - 2, nsc - 1));
     frcnn_barrier_nofence();
     read_group(ring + kw * S::KW_BYTES, 0);

@@ -10,6 +10,7 @@ mkdir -p scripts/micro/_bin
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip scripts/micro/conv_f32_micro.cpp -I include -L chainer-faster-rcnn_amd -lfrcnn_hip -Wl,-rpath,'$ORIGIN/../../../chainer-faster-rcnn_amd' -o scripts/micro/_bin/conv_f32_micro
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-inline-asm -Wno-unused-value scripts/micro/mfma_dma_micro.hip -o scripts/micro/_bin/mfma_dma_micro
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-inline-asm -Wno-unused-value scripts/micro/dma_align_micro.hip -o scripts/micro/_bin/dma_align_micro
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scripts/micro/mfma_peak_micro.hip -o scripts/micro/_bin/mfma_peak_micro
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip scripts/micro/linear_bf16_micro.cpp -I include -L chainer-faster-rcnn_amd -lfrcnn_hip -Wl,-rpath,'$ORIGIN/../../../chainer-faster-rcnn_amd' -o scripts/micro/_bin/linear_bf16_micro
 # timing-ablation build of roi_pool.hip alone (FRCNN_ROI_DBG is honoured; WRONG results by design) + the same harness against it
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DFRCNN_TIMING_ABLATIONS -I include -I chainer-faster-rcnn_amd/csrc -shared chainer-faster-rcnn_amd/csrc/roi_pool.hip -o scripts/micro/_bin/libroi_abl.so

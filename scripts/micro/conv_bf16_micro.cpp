@@ -48,6 +48,10 @@ int main(int argc, char **argv) {
         std::vector<uint16_t> hx(nx), hw(nw);
         for (auto &e : hx) e = bf16_of(u(g));
         for (auto &e : hw) e = bf16_of(0.05f * u(g));
+        if (getenv("CONV_MICRO_ZERO")) {                                   // all-zero operands: the same instruction stream with no bits toggling in the
+            std::fill(hx.begin(), hx.end(), (uint16_t)0);                  // matrix datapath -- separates what the data costs (power -> clocks) from what
+            std::fill(hw.begin(), hw.end(), (uint16_t)0);                  // the instruction stream costs
+        }
         uint16_t *dx, *dw, *dy[3]; float *db; void *ws;
         CK(hipMalloc(&dx, nx * 2)); CK(hipMalloc(&dw, nw * 2)); CK(hipMalloc(&db, cop * 4)); CK(hipMemset(db, 0, cop * 4));
         for (auto &p : dy) CK(hipMalloc(&p, ny * 2));
