@@ -51,3 +51,23 @@ def test_loads_stay_batched(src, tmp_path):
         assert hits, "kernel %s not found in %s.hip" % (frag, src)
         for k, v in hits.items():
             assert v <= bound, "%s: %d full vmcnt waits (bound %d): a load - wait - store chain is back (scripts/isa_wait_scan.py)" % (k, v, bound)
+
+
+# the one-wave-per-SIMD strip kernels (csrc/conv_bf16_strip.h): nothing of theirs may live in scratch, and their LDS is exactly the ring.
+# (Forms B and C are compiled at 128 + 128 registers and sit at that limit: sixteen more live values across the K loop -- the bias, fetched
+# early -- made the compiler spill fragments to scratch and to LDS, 38 -> 133 us on conv4_2, with every result still correct; r03 probe 5.)
+STRIP_LDS = {"ILi2ELi5ELi4ELi1ELi1ELi3ELi0ELb0E": 3 * 42 * 1024, "ILi1ELi5ELi2ELi2ELi1ELi4ELi0ELb0E": 4 * 34 * 1024, "ILi1ELi5ELi1ELi1ELi4ELi2ELi0ELb0E": 2 * 68 * 1024}
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc (cross-compiles without a GPU)")
+def test_strip_kernels_do_not_spill(tmp_path):
+    asm = str(tmp_path / "conv_bf16.s")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"),
+                    "-I", CSRC, os.path.join(CSRC, "conv_bf16.hip"), "-o", asm], check=True, stderr=subprocess.DEVNULL)
+    text = open(asm).read()
+    for frag, lds in STRIP_LDS.items():
+        m = re.search(r"\.amdhsa_kernel \S*conv_strip_bf16_kernel" + frag + r"\S*\n(.*?)\.end_amdhsa_kernel", text, re.S)
+        assert m, frag
+        meta = m.group(1)
+        assert int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", meta).group(1)) == 0, frag + ": scratch in use"
+        assert int(re.search(r"\.amdhsa_group_segment_fixed_size\s+(\d+)", meta).group(1)) == lds, frag + ": LDS is not the ring alone"
