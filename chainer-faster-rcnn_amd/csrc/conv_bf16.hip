@@ -740,18 +740,18 @@ rpn_heads_bf16_fused_kernel(const uint16_t *__restrict__ h, const uint16_t *__re
 
 // The strip forms of conv_bf16_strip.h (FRCNN_BF16_DMA=901 / 902 / 903 = form A / B / C, 900 = the cheapest applicable one by a
 // count of MFMA rounds; candidates, not default picks: see the header).  Returns 1 when the form does not apply to the launch.
-template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, bool FRONT = false>
+template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, bool FRONT = false, int WPE = 1>
 static void conv_bf16_strip_go(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int CinP, int Cout, int CoutP, int H, int W,
                                int relu, int out_mode, hipStream_t stream) {
     const int xtiles = frcnn_cdiv(W, 32), ytiles = frcnn_cdiv(H, RG * RW), cotiles = frcnn_cdiv(CoutP, 32 * COB * CW);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_strip_bf16_kernel<COB, RW, RG, CW, KW, NS, ABL, FRONT>), dim3((unsigned)((long)xtiles * ytiles * cotiles)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_strip_bf16_kernel<COB, RW, RG, CW, KW, NS, ABL, FRONT, WPE>), dim3((unsigned)((long)xtiles * ytiles * cotiles)), dim3(256), 0, stream,
                        x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, cotiles);
 }
 static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int CinP, int Cout, int CoutP, int H, int W,
                            int relu, int out_mode, hipStream_t stream, int abl = 0) {
     const int chunks = CinP / kCK;
     // {couts per workgroup, tile rows, K ways, MFMAs per wave and stage}
-    static const int kForm[8][4] = {{0, 0, 0, 0}, {64, 20, 1, 90}, {64, 10, 1, 45}, {32, 5, 4, 45}, {64, 20, 1, 90}, {64, 20, 1, 90}, {64, 10, 1, 45}, {64, 10, 2, 90}};
+    static const int kForm[10][4] = {{0, 0, 0, 0}, {64, 20, 1, 90}, {64, 10, 1, 45}, {32, 5, 4, 45}, {64, 20, 1, 90}, {64, 20, 1, 90}, {64, 10, 1, 45}, {64, 10, 2, 90}, {64, 12, 1, 54}, {64, 10, 1, 45}};
     auto applies = [&](int f) { return chunks % kForm[f][2] == 0 && !(out_mode == 2 && (kForm[f][1] & 1)); };
     if (form == 0) {
         const long cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
@@ -786,7 +786,11 @@ static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed
     case 5: conv_bf16_strip_go<2, 5, 4, 1, 1, 3, 0, true>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
     case 6: conv_bf16_strip_go<1, 5, 2, 2, 1, 3>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
     // 907: 64 couts x 10 rows with the K loop split two ways over the waves (64 couts per wave: 0.43 fragment reads per MFMA instead of form B's 0.67)
-    default: conv_bf16_strip_go<2, 5, 2, 1, 2, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
+    case 7: conv_bf16_strip_go<2, 5, 2, 1, 2, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
+    // 908 / 909: two workgroups per CU (<= 256 registers, 68 KB of LDS each, two-stage rings) for the launches of several rounds, where the
+    // one-workgroup forms pay every tile's prologue and epilogue in the open: 64 couts x 12 rows (three rows per wave) / 64 couts x 10 rows (form B's waves)
+    case 8: conv_bf16_strip_go<2, 3, 4, 1, 1, 2, 0, false, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
+    default: conv_bf16_strip_go<1, 5, 2, 2, 1, 2, 0, false, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
     }
     return 0;
 }
@@ -869,23 +873,25 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
     // compiled only with FRCNN_TIMING_ABLATIONS).
     const char *dma_env = getenv("FRCNN_BF16_DMA");
     int mode = dma_env ? atoi(dma_env) : -1;
-    // Default pick, first rule (measured on the MI355X, profiles/r03_conv_bf16_strip_micro.txt): a launch with at least 16 K-chunks that ONE
-    // round of a strip form covers (more than half the CUs, at most all of them) runs as that strip form -- conv3_2/3 41.1 / 40.2 us
-    // (form A) vs 44.0 / 42.5, conv4_1..3 21.9 / 37.7 / 37.1 (form B) vs 26.2 / 45.7 / 45.3, the four 38 x 63 launches 15.1 (form C) vs
-    // 23.1.  Launches of several rounds (conv1_2, conv2_x: 62.7 / 35.0 / 47.3 vs 47.1 / 27.6 / 43.0) and short K loops (conv3_1: 26.0 vs
-    // 25.3) stay on conv_dma_bf16_kernel.  Forms A and B are bit-identical to it; form C sums four partial accumulators (fp32 rounding).
-    // FRCNN_BF16_STRIP=0 switches the rule off (A/B measurements); the tuning hooks that select a kernel family (FRCNN_BF16_RP,
-    // FRCNN_BF16_DMA_DEFAULT, FRCNN_BF16_SPLIT) keep their meaning.
-    if (ksize == 3 && mode < 0 && !big && CinP / kCK >= 16 && !getenv("FRCNN_BF16_DMA_DEFAULT") && !getenv("FRCNN_BF16_SPLIT")) {
+    // Default pick, first rule (measured on the MI355X, profiles/r03_conv_bf16_strip_micro.txt; same box, us, strip form vs conv_dma_bf16_kernel's
+    // best mode): a launch with at least 8 K-chunks and at least one 64-cout x 10-row x 32-px tile per CU runs as strip form D (two workgroups
+    // per CU, each one wave per SIMD with a two-stage software-pipelined ring) -- conv2_2 41.6 vs 43.5, conv3_1 24.2 vs 26.4, conv3_2/3 39.5 /
+    // 39.1 vs 44.0 / 42.5, conv4_1..3 23.2 / 39.8 / 39.1 vs 26.2 / 45.7 / 45.3; a smaller launch that ONE round of form C covers (32 couts x 5
+    // rows, the K loop split over the four waves: more than half the CUs, at most all) runs as form C -- the four 38 x 63 launches 15.1 vs
+    // 23.1.  Short K loops (conv1_2, conv2_1: 49.6 / 30.8 vs 48.4 / 28.2) and everything else stay on conv_dma_bf16_kernel.  Form D is
+    // bit-identical to it; form C sums four partial accumulators (fp32 rounding).  The one-workgroup-per-CU forms A and B (41.0 / 40.0 us on
+    // conv3_2 / conv4_2) stay selectable (901, 902).  FRCNN_BF16_STRIP=0 switches the rule off (A/B measurements); the tuning hooks that
+    // select a kernel family (FRCNN_BF16_RP, FRCNN_BF16_DMA_DEFAULT, FRCNN_BF16_SPLIT) keep their meaning.
+    if (ksize == 3 && mode < 0 && !big && CinP / kCK >= 8 && !getenv("FRCNN_BF16_DMA_DEFAULT") && !getenv("FRCNN_BF16_SPLIT")) {
         const char *se = getenv("FRCNN_BF16_STRIP");
         if (!(se && se[0] == '0')) {
             const long cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
-            static const int kTile[4][3] = {{0, 0, 0}, {64, 20, 1}, {64, 10, 1}, {32, 5, 4}};      // couts, rows, K ways of forms A, B, C
-            for (int f = 1; f <= 3; ++f) {
-                const long wgs = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, kTile[f][1]) * frcnn_cdiv(CoutP, kTile[f][0]);
-                if (2 * wgs <= cus || wgs > cus) continue;
-                if (conv_bf16_strip(f, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream) == 0) return frcnn_launch_status();
-            }
+            const long wgs_d = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 10) * frcnn_cdiv(CoutP, 64);
+            const long wgs_c = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 5) * frcnn_cdiv(CoutP, 32);
+            int form = 0;
+            if (wgs_d >= cus) form = 9;
+            else if (CinP / kCK >= 16 && 2 * wgs_c > cus && wgs_c <= cus) form = 3;
+            if (form && conv_bf16_strip(form, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream) == 0) return frcnn_launch_status();
         }
     }
     if (ksize == 3 && mode >= 9010 && mode <= 9039) {             // 90<form><ablation> (FRCNN_TIMING_ABLATIONS builds; else the plain form)
@@ -893,7 +899,7 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
         return conv_bf16_strip((mode - 9000) / 10, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream, ae ? atoi(ae) : mode % 10) == 0
                    ? frcnn_launch_status() : FRCNN_ERR_INVALID;
     }
-    if (ksize == 3 && mode >= 900 && mode <= 907) {
+    if (ksize == 3 && mode >= 900 && mode <= 909) {
         const int rc = conv_bf16_strip(mode - 900, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
         if (rc == 0) return frcnn_launch_status();
         if (mode != 900) return FRCNN_ERR_INVALID;                // an explicitly requested form that does not apply to this launch

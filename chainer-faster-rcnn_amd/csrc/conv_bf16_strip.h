@@ -61,7 +61,7 @@ struct StripShape {
     static constexpr int SPAN = (NS >= 3 && !FRONT) ? 8 * GM : (2 * (PPW + 1) < 8 * GM ? 2 * (PPW + 1) : 8 * GM);
     static_assert(GW * KW == 4, "four waves");
     static_assert(KW == 1 || KW == 2 || KW == 4, "K ways");
-    static_assert(LDS_BYTES <= 160 * 1024 - 64, "LDS");
+    static_assert(LDS_BYTES <= 160 * 1024 - 64, "LDS");                    // (the kernel checks WPE * LDS_BYTES)
     static_assert(NS >= 2 && NS <= 4 && (NS - 1) * PPW <= 63, "vmcnt holds 63");
     static_assert(PPW + 1 <= SPAN, "a piece per MFMA at most");
     static_assert(2 * (COB + RW) <= 15, "two tap groups of fragment reads in flight: lgkmcnt holds 15");
@@ -73,11 +73,13 @@ __device__ __forceinline__ void strip_keep(const uint4 &v) { asm volatile("" ::"
 
 // ABL (timing ablations, WRONG results, only in -DFRCNN_TIMING_ABLATIONS builds): 1 no DMA after the prologue, 2 no fragment reads after the
 // prologue, 4 no MFMAs (their operands are still waited for), 8 no stage hand-over (wait + barrier)
-template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, bool FRONT = false>
-__global__ void __launch_bounds__(256, 1)
+// WPE = workgroups per CU the form is compiled for (2: at most 256 registers and half the LDS -- experiments 908 / 909 on the multi-round layers)
+template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, bool FRONT = false, int WPE = 1>
+__global__ void __launch_bounds__(256, WPE)
 conv_strip_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
                        int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles, int cotiles) {
     using S = StripShape<COB, RW, RG, CW, KW, NS, FRONT>;
+    static_assert(WPE * S::LDS_BYTES <= 160 * 1024 - 64 * WPE, "LDS of WPE workgroups");
     constexpr int KS = 3, TAPS = 9, PAD = 1, HPX = S::HPX, BCO = S::BCO, TR = S::TR, NACC = S::NACC, PPW = S::PPW, IN_Q = S::IN_Q, OP = S::OP, GW = S::GW;
     __shared__ __attribute__((aligned(1024))) unsigned char ring[S::LDS_BYTES];
     const int tid = threadIdx.x, lane = tid & 63;

@@ -73,7 +73,9 @@ int main(int argc, char **argv) {
         }
         double best = 1e30;
         for (const std::string &m : modes) {
+            unsetenv("FRCNN_BF16_STRIP");
             if (m == "def") unsetenv("FRCNN_BF16_DMA");                 // "def" in a --modes list = the default pick
+            else if (m == "old") { unsetenv("FRCNN_BF16_DMA"); setenv("FRCNN_BF16_STRIP", "0", 1); }   // "old" = conv_dma_bf16_kernel's picks (no strip rule)
             else if (!m.empty()) setenv("FRCNN_BF16_DMA", m.c_str(), 1);
             hipGraph_t gr; hipGraphExec_t ge;
             CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));

@@ -841,9 +841,10 @@ def check_conv_bf16_pool(rt, Cin, Cout, H, W, seed=0):
 
 
 def check_conv_bf16_strip(rt, form, Cin, Cout, H, W, pool=False, seed=0):
-    """Strip form `form` (FRCNN_BF16_DMA=901 / 902 / 903, csrc/conv_bf16_strip.h) of the 3x3 bf16 convolution against the default
-    kernel on the same operands: bit-identical for the forms that keep one accumulation chain per output (A, B); within fp32
-    summation-order noise of it for the K-split form C (and then the bf16 outputs may differ by one rounding step at a tie)."""
+    """Strip form `form` (FRCNN_BF16_DMA=901 / 902 / 903 / 907 / 908 / 909, csrc/conv_bf16_strip.h) of the 3x3 bf16 convolution against
+    conv_dma_bf16_kernel on the same operands: bit-identical for the forms that keep one accumulation chain per output (A, B, D = 909,
+    908); within fp32 summation-order noise of it for the K-split forms (C = 903, 907: the bf16 outputs may then differ by one rounding
+    step at a tie)."""
     rs = np.random.RandomState(seed)
     x = rs.randn(1, Cin, H, W).astype(np.float32)
     w = (rs.randn(Cout, Cin, 3, 3) * np.sqrt(2.0 / (Cin * 9))).astype(np.float32)
@@ -855,17 +856,21 @@ def check_conv_bf16_strip(rt, form, Cin, Cout, H, W, pool=False, seed=0):
         y32 = host(rt, rt.conv_bf16(xd, wpk, b, Cin, Cout, 3, relu=True, out_f32_nchw=True))
         y16 = host(rt, rt.conv_bf16(xd, wpk, b, Cin, Cout, 3, relu=True, pool=pool))
         return y32, y16
-    old = os.environ.pop("FRCNN_BF16_DMA", None)
+    old = os.environ.pop("FRCNN_BF16_DMA", None), os.environ.get("FRCNN_BF16_STRIP")
     try:
+        os.environ["FRCNN_BF16_STRIP"] = "0"                    # the reference: conv_dma_bf16_kernel's pick, not a strip form by the default rule
         ref32, ref16 = run()
         os.environ["FRCNN_BF16_DMA"] = str(form)
         got32, got16 = run()
     finally:
         os.environ.pop("FRCNN_BF16_DMA", None)
-        if old is not None:
-            os.environ["FRCNN_BF16_DMA"] = old
+        os.environ.pop("FRCNN_BF16_STRIP", None)
+        if old[0] is not None:
+            os.environ["FRCNN_BF16_DMA"] = old[0]
+        if old[1] is not None:
+            os.environ["FRCNN_BF16_STRIP"] = old[1]
     assert got32.shape == ref32.shape and got16.shape == ref16.shape
-    if form in (901, 902):
+    if form in (901, 902, 908, 909):
         assert np.array_equal(got32, ref32) and np.array_equal(got16, ref16)
     else:
         scale = max(np.abs(ref32).max(), 1e-6)

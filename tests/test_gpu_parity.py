@@ -383,6 +383,16 @@ def test_conv_bf16_staging_variants_bit_identical(rt, monkeypatch, cin, cout, h,
         assert np.array_equal(full, outs["0"][0]) and np.array_equal(pooled, outs["0"][1]), mode
 
 
+@pytest.mark.parametrize("form", [901, 902, 903, 909])
+def test_conv_bf16_strip_forms(rt, form):
+    """The strip forms (csrc/conv_bf16_strip.h; D = 909 and C = 903 are default picks) against conv_dma_bf16_kernel at VGG layer sizes: bit-identical
+    where one accumulation chain per output is kept, fp32 summation-order noise for the K-split form (profiles/r03_conv_bf16_strip_micro.txt holds
+    the same comparison from the torch-free harness on all ten layer shapes)."""
+    P.check_conv_bf16_strip(rt, form, 256, 256, 150, 250, pool=form != 903)
+    P.check_conv_bf16_strip(rt, form, 512, 512, 38, 63, seed=1)
+    P.check_conv_bf16_strip(rt, form, 128, 54, 75, 125, seed=2)      # ragged: 54 couts of 64, 75 rows = 7.5 tiles of 10
+
+
 @pytest.mark.parametrize("split,mode", [("2", None), ("4", None), ("2", "224"), ("4", "223")])
 def test_conv_bf16_split_k(rt, monkeypatch, split, mode):
     monkeypatch.setenv("FRCNN_BF16_SPLIT", split)

@@ -243,24 +243,24 @@ def test_conv_bf16_lds_dma(rt, monkeypatch, mode):
     P.check_conv_bf16_pool(rt, 48, 64, 9, 37, seed=3)
 
 
-@pytest.mark.parametrize("mode", ["901", "902", "903", "900"])
+@pytest.mark.parametrize("mode", ["901", "902", "903", "900", "907", "908", "909"])
 def test_conv_bf16_strip_forms(rt, monkeypatch, mode):
     """The strip forms of the 3x3 bf16 kernel (csrc/conv_bf16_strip.h: one workgroup per CU, software-pipelined ring; candidates, no
     default pick): against the oracle like every other staging variant -- one stage, the ring wrapping (5 and 12 stages), several
     x / y / cout tiles, ragged edges, 54 couts of 64 (form C: a 32-cout tile that is half padding), the fused pool."""
     monkeypatch.setenv("FRCNN_BF16_DMA", mode)
     P.check_conv_bf16(rt, 64, 64, 9, 37)                   # forms A, B: 4 stages; C: one stage of four K ways
-    if mode == "903":                                      # one chunk cannot be split four ways: the explicit form refuses, 900 falls back
+    if mode in ("903", "907"):                             # one chunk cannot be split over K ways: the explicit form refuses, 900 falls back
         with pytest.raises(Exception):
             P.check_conv_bf16(rt, 3, 64, 7, 33, seed=1)
     else:
         P.check_conv_bf16(rt, 3, 64, 7, 33, seed=1)
     P.check_conv_bf16(rt, 192, 54, 23, 70, seed=2)         # 12 chunks: every ring wraps; two row blocks (A), three (B), five (C)
-    if mode != "903":
-        P.check_conv_bf16_pool(rt, 80, 128, 22, 37, seed=3)   # odd tile rows rule the pool out for form C
+    if mode not in ("903", "907"):
+        P.check_conv_bf16_pool(rt, 80, 128, 22, 37, seed=3)   # odd tile rows rule the pool out for form C, five chunks the two-way K split
 
 
-@pytest.mark.parametrize("form", [901, 902, 903])
+@pytest.mark.parametrize("form", [901, 902, 903, 907, 909])
 def test_conv_bf16_strip_same_as_default(rt, form):
     P.check_conv_bf16_strip(rt, form, 128, 96, 21, 45, seed=4)
     P.check_conv_bf16_strip(rt, form, 64, 64, 12, 64, pool=form != 903, seed=5)
