@@ -1,6 +1,8 @@
-// conv_bf16_strip.h -- the 3x3 bf16 convolution as ONE workgroup per CU, one wave per SIMD ("strip" form; included by conv_bf16.hip
-// inside its anonymous namespace).  ROUND-3 CANDIDATE: written and parity-tested on the host emulator after the round's GPU budget was
-// spent -- NOT yet timed on an MI355X, so no launch picks it by default (FRCNN_BF16_DMA=900..903 selects it).
+// conv_bf16_strip.h -- the 3x3 bf16 convolution with one wave per SIMD and the latency hiding INSIDE the wave ("strip" forms; included by
+// conv_bf16.hip inside its anonymous namespace).  Written late in round 3 on the host emulator, then timed and compared bit for bit with
+// conv_dma_bf16_kernel on the MI355X through the torch-free harness (scripts/micro/conv_bf16_micro --check; profiles/r03_conv_bf16_strip_*.txt,
+// DESIGN 3.8b): forms D and C are default picks of frcnn_conv_bf16_ws (conv2_2 ... conv4_3: -4 ... -15 %, the 38x63 launches 23.1 -> 15.1 us),
+// A and B stay selectable (FRCNN_BF16_DMA=901 / 902; 903 = C, 909 = D, 904 ... 908 experiments).
 //
 // Why another form (profiles/r03_conv_bf16_micro.txt): conv_dma_bf16_kernel hides latency with co-resident workgroups,
 // which ties it to small tiles (64 couts x 4..8 rows: 200..350 B of LDS-DMA and 0.75..1.2 fragment reads per MFMA), and its large
@@ -20,6 +22,8 @@
 //   form A  COB 2, RW 5, RG 4, CW 1, KW 1: 64 couts x 20 rows x 32 px, 3 stages of 42 KB   (150 x 250 maps: 256 workgroups)
 //   form B  COB 1, RW 5, RG 2, CW 2, KW 1: 64 couts x 10 rows x 32 px, 4 stages of 34 KB   ( 75 x 125 maps: 256 workgroups)
 //   form C  COB 1, RW 5, RG 1, CW 1, KW 4: 32 couts x  5 rows x 32 px, 2 stages of 68 KB   ( 38 x  63 maps: 256 workgroups)
+//   form D  form B's waves, 2 stages of 34 KB, <= 256 registers: TWO workgroups per CU -- each still one wave per SIMD with the pipeline
+//           below, and each covering the other's prologue and epilogue; the best form on every launch with >= 8 K-chunks and >= one tile per CU
 // Same operands, same LDS image (pitch 32 B, XOR swizzle on source offsets and fragment reads) and, for KW 1, the same
 // (chunk, tap) accumulation order per output as every conv_dma_bf16_kernel variant: bit-identical results; KW > 1 sums KW
 // partial accumulators in ascending K-way order (deterministic; fp32 rounding differs from the single chain).
