@@ -83,7 +83,12 @@ def pmc_traffic(dtype):
             continue
         try:
             s = json.load(open(path))["_summary"][kernel]
-            return s["hbm_bytes_per_launch"], "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % name
+            src = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)" % name
+            if dtype == "bf16" and name.startswith(("r02_", "r03_")):
+                # that pass measured conv_dma_bf16_kernel on every layer; since then eleven of the fourteen launches run as strip forms D / C
+                # (csrc/conv_bf16_strip.h, DESIGN 3.8b: larger tiles, fewer weight re-reads) -- no PMC pass of those picks exists yet
+                src += "; measured BEFORE the strip-form default picks of late round 3 (conv_dma_bf16_kernel on every layer): an upper bound for today's launches"
+            return s["hbm_bytes_per_launch"], src
         except (KeyError, ValueError):
             continue
     return None, None

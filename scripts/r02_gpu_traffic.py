@@ -46,7 +46,7 @@ def main(out_dir, dtype):
                                     "correction": "FETCH x 2 (16-byte-per-lane buffer_load ... lds; the first layer's 4-byte image reads are "
                                                   "7 MB of the total: counted twice, an upper bound)"}
     else:
-        n, fb, wb = family(lambda s: s.startswith("conv_dma_bf16_kernel") or s.startswith("conv_mfma_bf16_kernel<3") or s.startswith("conv1_f32s_kernel"))
+        n, fb, wb = family(lambda s: s.startswith("conv_dma_bf16_kernel") or s.startswith("conv_strip_bf16_kernel") or s.startswith("conv_mfma_bf16_kernel<3") or s.startswith("conv1_f32s_kernel"))
         summ["conv_bf16_kernel"] = {"launches_counted": n, "fetch_bytes_per_launch_raw": fb, "write_bytes_per_launch": wb,
                                     "hbm_bytes_per_launch": 2.0 * fb + wb,
                                     "correction": "FETCH x 2 (every global read of the kernel is a 16-byte-per-lane buffer_load ... lds)"}

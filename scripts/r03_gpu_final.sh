@@ -51,7 +51,7 @@ O = sys.argv[1]
 acc = collections.defaultdict(lambda: [0.0, set()])
 for f in glob.glob(O + "/mfma_bf16/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "conv_dma_bf16_kernel" in r["Kernel_Name"]:
+        if "conv_dma_bf16_kernel" in r["Kernel_Name"] or "conv_strip_bf16_kernel" in r["Kernel_Name"]:
             a = acc[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
 out = {k: {"per_launch_mean": v / max(len(ids), 1), "launches": len(ids)} for k, (v, ids) in acc.items()}
 out["_note"] = "conv_dma_bf16_kernel on the conv3_2 shape (256 -> 256, 150 x 250) through scripts/micro/conv_bf16_micro; rocprofv3 --pmc, one pass"
