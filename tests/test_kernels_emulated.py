@@ -266,6 +266,19 @@ def test_conv_bf16_strip_same_as_default(rt, form):
     P.check_conv_bf16_strip(rt, form, 64, 64, 12, 64, pool=form != 903, seed=5)
 
 
+def test_conv_bf16_strip_forms_on_ragged_shapes(rt):
+    """A seeded sweep of awkward launches through the strip forms that are default picks (D = 909, C = 903) and the two one-workgroup
+    forms: maps smaller than a tile, a single row / column, channel counts that fill neither a 16-channel block nor a 32- / 64-cout
+    tile, odd sizes under the fused pool -- each against conv_dma_bf16_kernel (bit-identical, or summation-order noise for the K split)."""
+    rs = np.random.RandomState(321)
+    for t in range(6):
+        form = int(rs.choice([901, 902, 903, 909]))
+        kways = 4 if form == 903 else 1
+        cin = int(rs.choice([16, 24, 40, 64, 100])) if kways == 1 else int(rs.choice([49, 64, 120, 128]))      # 903: chunks a multiple of 4
+        cout, h, w = int(rs.choice([1, 20, 33, 64, 70])), int(rs.randint(1, 24)), int(rs.randint(1, 70))
+        P.check_conv_bf16_strip(rt, form, cin, cout, h, w, pool=bool(rs.randint(2)) and form != 903, seed=t)
+
+
 @pytest.mark.parametrize("split,mode", [("2", None), ("4", None), ("2", "224"), ("4", "223")])
 def test_conv_bf16_split_k(rt, monkeypatch, split, mode):
     """Split-K form of the bf16 3x3 kernel: partial tiles through the workspace, last arriver sums in split order."""
