@@ -738,21 +738,21 @@ rpn_heads_bf16_fused_kernel(const uint16_t *__restrict__ h, const uint16_t *__re
 
 }  // namespace
 
-// The strip forms of conv_bf16_strip.h (FRCNN_BF16_DMA=901 / 902 / 903 = form A / B / C, 900 = the cheapest applicable one by a
-// count of MFMA rounds; candidates, not default picks: see the header).  Returns 1 when the form does not apply to the launch.
-template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, bool FRONT = false, int WPE = 1>
+// The strip forms of conv_bf16_strip.h (FRCNN_BF16_DMA=901 / 902 / 903 / 909 = form A / B / C / D, 900 = the cheapest applicable one of A / B / C by a
+// count of MFMA rounds, 907 / 908 two measured shapes that were not adopted).  Returns 1 when the form does not exist or does not apply to the launch.
+template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, int WPE = 1>
 static void conv_bf16_strip_go(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int CinP, int Cout, int CoutP, int H, int W,
                                int relu, int out_mode, hipStream_t stream) {
     const int xtiles = frcnn_cdiv(W, 32), ytiles = frcnn_cdiv(H, RG * RW), cotiles = frcnn_cdiv(CoutP, 32 * COB * CW);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_strip_bf16_kernel<COB, RW, RG, CW, KW, NS, ABL, FRONT, WPE>), dim3((unsigned)((long)xtiles * ytiles * cotiles)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_strip_bf16_kernel<COB, RW, RG, CW, KW, NS, ABL, WPE>), dim3((unsigned)((long)xtiles * ytiles * cotiles)), dim3(256), 0, stream,
                        x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, cotiles);
 }
 static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int CinP, int Cout, int CoutP, int H, int W,
                            int relu, int out_mode, hipStream_t stream, int abl = 0) {
     const int chunks = CinP / kCK;
     // {couts per workgroup, tile rows, K ways, MFMAs per wave and stage}
-    static const int kForm[10][4] = {{0, 0, 0, 0}, {64, 20, 1, 90}, {64, 10, 1, 45}, {32, 5, 4, 45}, {64, 20, 1, 90}, {64, 20, 1, 90}, {64, 10, 1, 45}, {64, 10, 2, 90}, {64, 12, 1, 54}, {64, 10, 1, 45}};
-    auto applies = [&](int f) { return chunks % kForm[f][2] == 0 && !(out_mode == 2 && (kForm[f][1] & 1)); };
+    static const int kForm[10][4] = {{0, 0, 0, 0}, {64, 20, 1, 90}, {64, 10, 1, 45}, {32, 5, 4, 45}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {64, 10, 2, 90}, {64, 12, 1, 54}, {64, 10, 1, 45}};
+    auto applies = [&](int f) { return kForm[f][0] != 0 && chunks % kForm[f][2] == 0 && !(out_mode == 2 && (kForm[f][1] & 1)); };
     if (form == 0) {
         const long cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
         long best = -1;
@@ -781,16 +781,15 @@ static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed
     case 1: conv_bf16_strip_go<2, 5, 4, 1, 1, 3>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
     case 2: conv_bf16_strip_go<1, 5, 2, 2, 1, 4>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
     case 3: conv_bf16_strip_go<1, 5, 1, 1, 4, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
-    // experiments (904 .. 906): form A with a two-stage ring; form A with its pieces front-loaded; form B with a three-stage ring
-    case 4: conv_bf16_strip_go<2, 5, 4, 1, 1, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
-    case 5: conv_bf16_strip_go<2, 5, 4, 1, 1, 3, 0, true>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
-    case 6: conv_bf16_strip_go<1, 5, 2, 2, 1, 3>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
-    // 907: 64 couts x 10 rows with the K loop split two ways over the waves (64 couts per wave: 0.43 fragment reads per MFMA instead of form B's 0.67)
+    // 907: 64 couts x 10 rows with the K loop split two ways over the waves (64 couts per wave: 0.43 fragment reads per MFMA instead of form B's 0.67;
+    //      40.5 vs 39.9 us on conv4_2, not adopted)
     case 7: conv_bf16_strip_go<2, 5, 2, 1, 2, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
-    // 908 / 909: two workgroups per CU (<= 256 registers, 68 KB of LDS each, two-stage rings) for the launches of several rounds, where the
-    // one-workgroup forms pay every tile's prologue and epilogue in the open: 64 couts x 12 rows (three rows per wave) / 64 couts x 10 rows (form B's waves)
-    case 8: conv_bf16_strip_go<2, 3, 4, 1, 1, 2, 0, false, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
-    default: conv_bf16_strip_go<1, 5, 2, 2, 1, 2, 0, false, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
+    // 908 / 909: TWO workgroups per CU (<= 256 registers, 68 KB of LDS each, two-stage rings): each covers the other's prologue and epilogue, which the
+    // one-workgroup forms pay in the open on every tile of a launch of several rounds.  908: 64 couts x 12 rows (three rows per wave; 2-8 % behind 909),
+    // 909 = form D: form B's waves -- the default pick of frcnn_conv_bf16_ws for launches with >= 8 K-chunks and >= one tile per CU
+    case 8: conv_bf16_strip_go<2, 3, 4, 1, 1, 2, 0, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
+    case 9: conv_bf16_strip_go<1, 5, 2, 2, 1, 2, 0, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
+    default: return 1;
     }
     return 0;
 }

@@ -2,7 +2,8 @@
 // conv_bf16.hip inside its anonymous namespace).  Written late in round 3 on the host emulator, then timed and compared bit for bit with
 // conv_dma_bf16_kernel on the MI355X through the torch-free harness (scripts/micro/conv_bf16_micro --check; profiles/r03_conv_bf16_strip_*.txt,
 // DESIGN 3.8b): forms D and C are default picks of frcnn_conv_bf16_ws (conv2_2 ... conv4_3: -4 ... -15 %, the 38x63 launches 23.1 -> 15.1 us),
-// A and B stay selectable (FRCNN_BF16_DMA=901 / 902; 903 = C, 909 = D, 904 ... 908 experiments).
+// A and B stay selectable (FRCNN_BF16_DMA=901 / 902; 903 = C, 909 = D; 907 / 908 are two measured-and-not-adopted shapes kept under test).
+// (Measured and removed again: form A with a two-stage ring, with its DMA pieces front-loaded, form B with three stages: all within 0.5 us.)
 //
 // Why another form (profiles/r03_conv_bf16_micro.txt): conv_dma_bf16_kernel hides latency with co-resident workgroups,
 // which ties it to small tiles (64 couts x 4..8 rows: 200..350 B of LDS-DMA and 0.75..1.2 fragment reads per MFMA), and its large
@@ -35,7 +36,7 @@
 #pragma once
 #include <type_traits>
 
-template <int COB, int RW, int RG, int CW, int KW, int NS, bool FRONT = false>
+template <int COB, int RW, int RG, int CW, int KW, int NS>
 struct StripShape {
     static constexpr int KS = 3, TAPS = 9, PAD = 1;
     static constexpr int GW = RG * CW;                                    // waves per K way
@@ -62,7 +63,7 @@ struct StripShape {
     // DMA pieces of the next-but-(NS-2) stage go out between the MFMAs of tap groups 0 .. 7 (the hand-over sits before group 8): evenly
     // over all of them with >= 3 stages (the data has more than a whole stage to arrive); with 2 stages it has to arrive within
     // THIS stage, so as early as one piece per two MFMAs allows
-    static constexpr int SPAN = (NS >= 3 && !FRONT) ? 8 * GM : (2 * (PPW + 1) < 8 * GM ? 2 * (PPW + 1) : 8 * GM);
+    static constexpr int SPAN = NS >= 3 ? 8 * GM : (2 * (PPW + 1) < 8 * GM ? 2 * (PPW + 1) : 8 * GM);
     static_assert(GW * KW == 4, "four waves");
     static_assert(KW == 1 || KW == 2 || KW == 4, "K ways");
     static_assert(LDS_BYTES <= 160 * 1024 - 64, "LDS");                    // (the kernel checks WPE * LDS_BYTES)
@@ -77,12 +78,12 @@ __device__ __forceinline__ void strip_keep(const uint4 &v) { asm volatile("" ::"
 
 // ABL (timing ablations, WRONG results, only in -DFRCNN_TIMING_ABLATIONS builds): 1 no DMA after the prologue, 2 no fragment reads after the
 // prologue, 4 no MFMAs (their operands are still waited for), 8 no stage hand-over (wait + barrier)
-// WPE = workgroups per CU the form is compiled for (2: at most 256 registers and half the LDS -- experiments 908 / 909 on the multi-round layers)
-template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, bool FRONT = false, int WPE = 1>
+// WPE = workgroups per CU the form is compiled for (2: at most 256 registers and half the LDS -- form D and experiment 908)
+template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, int WPE = 1>
 __global__ void __launch_bounds__(256, WPE)
 conv_strip_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
                        int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles, int cotiles) {
-    using S = StripShape<COB, RW, RG, CW, KW, NS, FRONT>;
+    using S = StripShape<COB, RW, RG, CW, KW, NS>;
     static_assert(WPE * S::LDS_BYTES <= 160 * 1024 - 64 * WPE, "LDS of WPE workgroups");
     constexpr int KS = 3, TAPS = 9, PAD = 1, HPX = S::HPX, BCO = S::BCO, TR = S::TR, NACC = S::NACC, PPW = S::PPW, IN_Q = S::IN_Q, OP = S::OP, GW = S::GW;
     __shared__ __attribute__((aligned(1024))) unsigned char ring[S::LDS_BYTES];
