@@ -32,6 +32,7 @@ import numpy as np  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: Peak BF16 MFMA, dense
+SUSTAINED_BF16_MFMA_TFLOPS_RANDOM = 1867.0   # measured, round 3: every SIMD issuing only bf16 MFMAs on random operands (profiles/r03_mfma_peak_micro.txt)
 PEAK_HBM_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E peak BW (spec)
 IM_H, IM_W = 600, 1000
 DEFAULT_STEPS = 250               # ~1 s of timed region at 3.9 ms / step: long enough for an outside observer (rocm-smi) to see it
@@ -315,9 +316,27 @@ def bf16_variant(args, torch, rt, params, x, dbg, flops_total):
         conv_ms = graph_time_us(torch, f32s_conv_chain(rt, model, x, bf16=True), 1, max(args.steps, 100)) / 1e3
         out.update(conv_ms_per_image=conv_ms, conv_tflops=flops_total / (conv_ms * 1e-3) / 1e12,
                    frac_of_bf16_mfma_peak=flops_total / (conv_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS)
+        # a second reading, not a replacement: what every SIMD of this chip sustains issuing nothing but bf16 MFMAs on RANDOM operands
+        # (scripts/micro/mfma_peak_micro.hip -> profiles/r03_mfma_peak_micro.txt: 1856-1878 TFLOP/s, against 2385-2467 on constant operands:
+        # the matrix datapath is power-limited on real data) -- a measured constant of round 3, not re-measured by this run
+        out["frac_of_sustained_bf16_mfma_rate_on_random_operands"] = out["conv_tflops"] / SUSTAINED_BF16_MFMA_TFLOPS_RANDOM
+        out["sustained_rate_source"] = "profiles/r03_mfma_peak_micro.txt (1867 TFLOP/s = the mean of 1856 and 1878; DESIGN 3.8b)"
     except Exception as e:
         print("bf16 conv-chain graph failed (%s)" % (e,), file=sys.stderr)
         torch.cuda.synchronize()
+    try:                                                     # which kernel family each 3x3 launch of the chain runs (launch-free query of the library)
+        names = {0: "conv_dma_bf16_kernel", 901: "strip A", 902: "strip B", 903: "strip C (K split over waves)", 909: "strip D"}
+        picks, h, w = {}, IM_H, IM_W
+        from chainer_faster_rcnn_amd.models.vgg16 import LAYERS as _layers
+        for l in _layers:
+            if l == "pool":
+                h, w = (h + 1) // 2, (w + 1) // 2
+            else:
+                picks[l[0]] = names.get(int(rt.lib.frcnn_conv_bf16_plan(int(l[1]), int(l[2]), h, w, 3, 0)), "?") if l[1] > 3 else "conv1_f32s_kernel (first layer)"
+        picks["rpn_conv_3x3"] = names.get(int(rt.lib.frcnn_conv_bf16_plan(512, 512, h, w, 3, 0)), "?")
+        out["conv_kernel_picks"] = picks
+    except Exception as e:
+        out["conv_kernel_picks"] = {"error": repr(e)}
     if dbg is not None:
         try:
             from oracle import parity

@@ -78,6 +78,7 @@ SIGNATURES = {
     "frcnn_bf16_to_nchw_f32": (_I, [_P, _I, _I, _I, _P, _P]),
     "frcnn_conv_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "frcnn_conv_bf16_workspace_bytes": (_S, [_I, _I, _I, _I]),
+    "frcnn_conv_bf16_plan": (_I, [_I, _I, _I, _I, _I, _I]),
     "frcnn_conv_bf16_workspace_init": (_I, [_P, _S, _P]),
     "frcnn_conv_bf16_ws": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_maxpool2x2_bf16": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -794,6 +794,22 @@ static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed
     return 0;
 }
 
+// The strip form the default rule picks for a 3x3 launch (0: none -- conv_dma_bf16_kernel's picks), environment hooks included; the
+// measurements behind it are quoted where frcnn_conv_bf16_ws applies it.
+static int conv_bf16_default_strip_form(int CinP, int CoutP, int H, int W, int out_mode) {
+    const char *rp_env = getenv("FRCNN_BF16_RP");
+    if (rp_env && atoi(rp_env) == 4) return 0;
+    if (CinP / kCK < 8 || getenv("FRCNN_BF16_DMA_DEFAULT") || getenv("FRCNN_BF16_SPLIT")) return 0;
+    const char *se = getenv("FRCNN_BF16_STRIP");
+    if (se && se[0] == '0') return 0;
+    const long cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
+    const long wgs_d = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 10) * frcnn_cdiv(CoutP, 64);
+    const long wgs_c = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 5) * frcnn_cdiv(CoutP, 32);
+    if (wgs_d >= cus) return 9;                                                       // form D: any chunk count, even tile rows (pool-capable)
+    if (CinP / kCK >= 16 && (CinP / kCK) % 4 == 0 && out_mode != 2 && 2 * wgs_c > cus && wgs_c <= cus) return 3;       // form C
+    return 0;
+}
+
 extern "C" {
 
 int frcnn_bf16_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, void *stream) {
@@ -881,17 +897,9 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
     // bit-identical to it; form C sums four partial accumulators (fp32 rounding).  The one-workgroup-per-CU forms A and B (41.0 / 40.0 us on
     // conv3_2 / conv4_2) stay selectable (901, 902).  FRCNN_BF16_STRIP=0 switches the rule off (A/B measurements); the tuning hooks that
     // select a kernel family (FRCNN_BF16_RP, FRCNN_BF16_DMA_DEFAULT, FRCNN_BF16_SPLIT) keep their meaning.
-    if (ksize == 3 && mode < 0 && !big && CinP / kCK >= 8 && !getenv("FRCNN_BF16_DMA_DEFAULT") && !getenv("FRCNN_BF16_SPLIT")) {
-        const char *se = getenv("FRCNN_BF16_STRIP");
-        if (!(se && se[0] == '0')) {
-            const long cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
-            const long wgs_d = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 10) * frcnn_cdiv(CoutP, 64);
-            const long wgs_c = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 5) * frcnn_cdiv(CoutP, 32);
-            int form = 0;
-            if (wgs_d >= cus) form = 9;
-            else if (CinP / kCK >= 16 && 2 * wgs_c > cus && wgs_c <= cus) form = 3;
-            if (form && conv_bf16_strip(form, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream) == 0) return frcnn_launch_status();
-        }
+    if (ksize == 3 && mode < 0) {
+        const int form = conv_bf16_default_strip_form(CinP, CoutP, H, W, out_mode);
+        if (form && conv_bf16_strip(form, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream) == 0) return frcnn_launch_status();
     }
     if (ksize == 3 && mode >= 9010 && mode <= 9039) {             // 90<form><ablation> (FRCNN_TIMING_ABLATIONS builds; else the plain form)
         const char *ae = getenv("FRCNN_BF16_STRIP_ABL");
@@ -1000,6 +1008,17 @@ int frcnn_rpn_heads_bf16(const uint16_t *h, int Cmid, int H, int W, int A, const
 int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H, int W, int ksize, int relu,
                     int out_mode, void *stream) {
     return frcnn_conv_bf16_ws(x, w_packed, bias, y, Cin, Cout, H, W, ksize, relu, out_mode, nullptr, 0, stream);
+}
+
+int frcnn_conv_bf16_plan(int Cin, int Cout, int H, int W, int ksize, int out_mode) {
+    if (Cin < 1 || Cout < 1 || H < 1 || W < 1 || (ksize != 1 && ksize != 3) || out_mode < 0 || out_mode > 2) return FRCNN_ERR_INVALID;
+    if (ksize != 3) return 0;
+    const char *dma_env = getenv("FRCNN_BF16_DMA");
+    const int mode = dma_env ? atoi(dma_env) : -1;
+    if (mode >= 900 && mode <= 909) return mode;
+    if (mode >= 0) return 0;
+    const int form = conv_bf16_default_strip_form(frcnn_bf16_padded_channels(Cin), frcnn_bf16_padded_channels(Cout), H, W, out_mode);
+    return form ? 900 + form : 0;
 }
 
 int frcnn_maxpool2x2_bf16(const uint16_t *x, uint16_t *y, int C, int H, int W, void *stream) {

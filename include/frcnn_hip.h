@@ -307,6 +307,11 @@ size_t frcnn_conv_bf16_workspace_bytes(int Cin, int Cout, int H, int W);
 int frcnn_conv_bf16_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
 int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
                        int W, int ksize, int relu, int out_mode, void *workspace, size_t workspace_bytes, void *stream);
+/* which kernel family frcnn_conv_bf16[_ws] launches for this shape under the current environment (A/B hooks included): 0 = conv_dma_bf16_kernel
+ * (or, for ksize 1 / FRCNN_BF16_DMA=0, the register-staged kernel), 901 / 902 / 903 / 909 = strip form A / B / C / D of csrc/conv_bf16_strip.h (one wave
+ * per SIMD, software-pipelined ring; D and C are default picks: DESIGN 3.8b).  Forms A, B, D give bit-identical results to 0; form C splits the K loop
+ * four ways over the waves of a workgroup and sums the partial accumulators in K-way order (deterministic, fp32 rounding differs).  No launch. */
+int frcnn_conv_bf16_plan(int Cin, int Cout, int H, int W, int ksize, int out_mode);
 int frcnn_maxpool2x2_bf16(const uint16_t *x, uint16_t *y, int C, int H, int W, void *stream);
 /* bf16 fully connected layer (config-3 head): y(M,N) = act(x(M,K) @ W(N,K)^T + b); x, W raw bf16 bits (frcnn_f32_to_bf16
  * converts fp32 arrays: weights once at load, activations per call), fp32 accumulation and bias; y fp32, or bf16 when

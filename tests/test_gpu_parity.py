@@ -15,7 +15,7 @@ def rt():
 
 
 def test_library_is_the_device_build(rt):
-    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 18
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 19
 
 
 def test_nms_golden(rt):
