@@ -259,8 +259,15 @@ class Runtime(object):
         H, W = int(x_blk.shape[1]), int(x_blk.shape[2])
         R = int(rois.shape[0])
         y = m.empty((R, int(C) * outh * outw), "i16") if out_bf16 else m.empty((R, int(C), outh, outw), "f32")
-        _lib.check(L.frcnn_roi_pool_fwd_blk_bf16(m.ptr(x_blk), int(C), H, W, m.ptr(rois), R, int(rois.shape[1]), outh, outw, float(scale),
-                                                 m.ptr(y), int(bool(out_bf16)), m.stream()), "frcnn_roi_pool_fwd_blk_bf16")
+        rc = L.frcnn_roi_pool_fwd_blk_bf16(m.ptr(x_blk), int(C), H, W, m.ptr(rois), R, int(rois.shape[1]), outh, outw, float(scale),
+                                           m.ptr(y), int(bool(out_bf16)), m.stream())
+        if rc == -1 and 1 <= outh <= 7 and 1 <= outw <= 7 and R > 0:
+            # the cell-major kernel declined (a map beyond its LDS image, or FRCNN_ROI_KERNEL=planes): the documented detour of
+            # include/frcnn_hip.h -- the map as fp32 NCHW, the fp32 pooling (which has its own fallbacks), one rounding-free conversion
+            # back (a maximum of bf16 values is a bf16 value) -- same device kernels, same results, no CPU path
+            y32 = self.roi_pool_fwd_chw(self.bf16_to_nchw(x_blk, int(C)), rois, outh, outw, scale)
+            return self.to_bf16(y32.reshape(R, -1)) if out_bf16 else y32
+        _lib.check(rc, "frcnn_roi_pool_fwd_blk_bf16")
         return y
 
     def roi_pool_fwd_chw_f32s(self, x, rois, outh, outw, scale):
@@ -269,8 +276,11 @@ class Runtime(object):
         C, H, W = [int(v) for v in x.shape[-3:]]
         R = int(rois.shape[0])
         y = m.empty((3, R, C * outh * outw), "i16")
-        _lib.check(L.frcnn_roi_pool_fwd_chw_f32s(m.ptr(x), C, H, W, m.ptr(rois), R, int(rois.shape[1]), outh, outw, float(scale),
-                                                 m.ptr(y), m.stream()), "frcnn_roi_pool_fwd_chw_f32s")
+        rc = L.frcnn_roi_pool_fwd_chw_f32s(m.ptr(x), C, H, W, m.ptr(rois), R, int(rois.shape[1]), outh, outw, float(scale), m.ptr(y), m.stream())
+        if rc == -1 and 1 <= outh <= 7 and 1 <= outw <= 7 and R > 0:
+            # the cell-major kernel declined (see roi_pool_fwd_blk_bf16): pool in fp32, then split -- the same three terms (the split is exact)
+            return self.f32s_split(self.roi_pool_fwd_chw(x, rois, outh, outw, scale).reshape(R, -1))
+        _lib.check(rc, "frcnn_roi_pool_fwd_chw_f32s")
         return y
 
     def chw_to_hwc(self, x):

@@ -66,6 +66,24 @@ def test_roi_pool_cells_kernel(rt):
     P.check_roi_pool_cells(rt)
 
 
+def test_roi_pool_output_forms_when_the_cell_kernel_declines(rt):
+    """frcnn_roi_pool_fwd_chw_f32s / _blk_bf16 exist on the cell-major kernel only and return FRCNN_ERR_INVALID when it declines (a map beyond its
+    76 x 64 LDS image); the runtime wrappers then take the header's documented detour -- fp32 pooling + an exact conversion -- instead of
+    raising (callers guarded on the map size only by convention).  Same bits either way."""
+    calls, orig = [], rt.roi_pool_fwd_chw
+    rt.roi_pool_fwd_chw = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        P.check_roi_pool_blk_bf16(rt, 9, 24, 20, 70)                 # 70 cells per row: beyond the image
+        rs = np.random.RandomState(7)
+        x, rois = P.roi_case(rs, 9, 11, 19, 70)
+        want = P.O.roi_pooling_2d(x, rois, 7, 7, 0.0625)
+        ysp = rt.roi_pool_fwd_chw_f32s(P.dev(rt, x[0]), P.dev(rt, np.ascontiguousarray(rois[:, 1:])), 7, 7, 0.0625)
+        assert np.array_equal(P.host(rt, rt.f32s_join(ysp)).reshape(want.shape), want)
+    finally:
+        rt.roi_pool_fwd_chw = orig
+    assert len(calls) == 3                                           # blocked map: fp32 and bf16 outputs; split tensor: once
+
+
 def test_roi_pool_cells_batches(rt):
     P.check_roi_pool_cells_batches(rt)
 
