@@ -112,7 +112,7 @@ int main(int argc, char **argv) {
             std::sort(us.begin(), us.end());
             const double med = us[us.size() / 2];
             best = std::min(best, med);
-            printf("  %s %6.1f us %5.0f TF", m.empty() ? "default" : m.c_str(), med, gflop / med);
+            printf("  %s %6.1f us %5.0f TF", m.empty() ? "default" : m.c_str(), med, gflop / med * 1e3);      // GFLOP / us = PFLOP/s
             CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(gr));
         }
         printf("\n");
