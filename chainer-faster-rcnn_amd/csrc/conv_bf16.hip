@@ -589,7 +589,7 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
     conv_bf16_epilogue<BROWS, 256, RW, COB>(acc, ring, bias, y, Cout, CoutP, H, W, relu, out_mode, x0, y0, co0);
 }
 
-#include "conv_bf16_strip.h"      // conv_strip_bf16_kernel: one workgroup per CU, one wave per SIMD (candidate, FRCNN_BF16_DMA=900..903)
+#include "conv_bf16_strip.h"      // conv_strip_bf16_kernel: one wave per SIMD, software-pipelined ring (forms D and C are default picks; FRCNN_BF16_DMA=900..909)
 
 // (Cout, Cin, k, k) fp32 -> [CinP/16][tap][CoutP][16] bf16, zero padded
 __global__ void __launch_bounds__(256)

@@ -263,9 +263,9 @@ def test_conv_bf16_lds_dma(rt, monkeypatch, mode):
 
 @pytest.mark.parametrize("mode", ["901", "902", "903", "900", "907", "908", "909"])
 def test_conv_bf16_strip_forms(rt, monkeypatch, mode):
-    """The strip forms of the 3x3 bf16 kernel (csrc/conv_bf16_strip.h: one workgroup per CU, software-pipelined ring; candidates, no
-    default pick): against the oracle like every other staging variant -- one stage, the ring wrapping (5 and 12 stages), several
-    x / y / cout tiles, ragged edges, 54 couts of 64 (form C: a 32-cout tile that is half padding), the fused pool."""
+    """The strip forms of the 3x3 bf16 kernel (csrc/conv_bf16_strip.h: one wave per SIMD, software-pipelined ring; D = 909 and C = 903 are default
+    picks, the others selectable) against the oracle like every other staging variant -- one stage, the rings wrapping (5 and 12 stages),
+    several x / y / cout tiles, ragged edges, 54 couts of 64 (form C: a 32-cout tile that is half padding), the fused pool."""
     monkeypatch.setenv("FRCNN_BF16_DMA", mode)
     P.check_conv_bf16(rt, 64, 64, 9, 37)                   # forms A, B: 4 stages; C: one stage of four K ways
     if mode in ("903", "907"):                             # one chunk cannot be split over K ways: the explicit form refuses, 900 falls back
