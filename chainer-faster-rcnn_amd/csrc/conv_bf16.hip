@@ -740,18 +740,18 @@ rpn_heads_bf16_fused_kernel(const uint16_t *__restrict__ h, const uint16_t *__re
 
 // The strip forms of conv_bf16_strip.h (FRCNN_BF16_DMA=901 / 902 / 903 / 909 = form A / B / C / D, 900 = the cheapest applicable one of A / B / C by a
 // count of MFMA rounds, 907 / 908 two measured shapes that were not adopted).  Returns 1 when the form does not exist or does not apply to the launch.
-template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, int WPE = 1>
+template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, int WPE = 1, bool DIRECT = false>
 static void conv_bf16_strip_go(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int CinP, int Cout, int CoutP, int H, int W,
                                int relu, int out_mode, hipStream_t stream) {
     const int xtiles = frcnn_cdiv(W, 32), ytiles = frcnn_cdiv(H, RG * RW), cotiles = frcnn_cdiv(CoutP, 32 * COB * CW);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_strip_bf16_kernel<COB, RW, RG, CW, KW, NS, ABL, WPE>), dim3((unsigned)((long)xtiles * ytiles * cotiles)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_strip_bf16_kernel<COB, RW, RG, CW, KW, NS, ABL, WPE, DIRECT>), dim3((unsigned)((long)xtiles * ytiles * cotiles)), dim3(256), 0, stream,
                        x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, cotiles);
 }
 static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int CinP, int Cout, int CoutP, int H, int W,
                            int relu, int out_mode, hipStream_t stream, int abl = 0) {
     const int chunks = CinP / kCK;
     // {couts per workgroup, tile rows, K ways, MFMAs per wave and stage}
-    static const int kForm[10][4] = {{0, 0, 0, 0}, {64, 20, 1, 90}, {64, 10, 1, 45}, {32, 5, 4, 45}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {64, 10, 2, 90}, {64, 12, 1, 54}, {64, 10, 1, 45}};
+    static const int kForm[11][4] = {{0, 0, 0, 0}, {64, 20, 1, 90}, {64, 10, 1, 45}, {32, 5, 4, 45}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {64, 10, 2, 90}, {64, 12, 1, 54}, {64, 10, 1, 45}, {64, 10, 1, 45}};
     auto applies = [&](int f) { return kForm[f][0] != 0 && chunks % kForm[f][2] == 0 && !(out_mode == 2 && (kForm[f][1] & 1)); };
     if (form == 0) {
         const long cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
@@ -789,6 +789,11 @@ static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed
     // 909 = form D: form B's waves -- the default pick of frcnn_conv_bf16_ws for launches with >= 8 K-chunks and >= one tile per CU
     case 8: conv_bf16_strip_go<2, 3, 4, 1, 1, 2, 0, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
     case 9: conv_bf16_strip_go<1, 5, 2, 2, 1, 2, 0, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
+    // 910: form D with the bf16 output of a launch without the fused pool stored straight from the accumulators (no LDS transpose; NOT yet timed)
+    case 10:
+        if (out_mode == 0 && (size_t)CoutP * H * W * 2 < (1ull << 31)) conv_bf16_strip_go<1, 5, 2, 2, 1, 2, 0, 2, true>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
+        else conv_bf16_strip_go<1, 5, 2, 2, 1, 2, 0, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
+        break;
     default: return 1;
     }
     return 0;
@@ -906,7 +911,7 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
         return conv_bf16_strip((mode - 9000) / 10, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream, ae ? atoi(ae) : mode % 10) == 0
                    ? frcnn_launch_status() : FRCNN_ERR_INVALID;
     }
-    if (ksize == 3 && mode >= 900 && mode <= 909) {
+    if (ksize == 3 && mode >= 900 && mode <= 910) {
         const int rc = conv_bf16_strip(mode - 900, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
         if (rc == 0) return frcnn_launch_status();
         if (mode != 900) return FRCNN_ERR_INVALID;                // an explicitly requested form that does not apply to this launch
@@ -1015,7 +1020,7 @@ int frcnn_conv_bf16_plan(int Cin, int Cout, int H, int W, int ksize, int out_mod
     if (ksize != 3) return 0;
     const char *dma_env = getenv("FRCNN_BF16_DMA");
     const int mode = dma_env ? atoi(dma_env) : -1;
-    if (mode >= 900 && mode <= 909) return mode;
+    if (mode >= 900 && mode <= 910) return mode;
     if (mode >= 0) return 0;
     const int form = conv_bf16_default_strip_form(frcnn_bf16_padded_channels(Cin), frcnn_bf16_padded_channels(Cout), H, W, out_mode);
     return form ? 900 + form : 0;

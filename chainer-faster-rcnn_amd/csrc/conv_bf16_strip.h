@@ -79,7 +79,10 @@ __device__ __forceinline__ void strip_keep(const uint4 &v) { asm volatile("" ::"
 // ABL (timing ablations, WRONG results, only in -DFRCNN_TIMING_ABLATIONS builds): 1 no DMA after the prologue, 2 no fragment reads after the
 // prologue, 4 no MFMAs (their operands are still waited for), 8 no stage hand-over (wait + barrier)
 // WPE = workgroups per CU the form is compiled for (2: at most 256 registers and half the LDS -- form D and experiment 908)
-template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, int WPE = 1>
+// DIRECT (experiment 910, NOT yet timed on the hardware): the bf16 output of a launch without the fused pool leaves straight from the accumulator quads
+// -- a quad is four consecutive couts of one pixel = one aligned 8-byte piece of the channel-blocked record, a wave's store covers 32 pixels x 16 B -- instead
+// of through the LDS transpose: no barrier, no LDS round trip, and no use of the ring by the epilogue (the condition for a persistent tile loop)
+template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, int WPE = 1, bool DIRECT = false>
 __global__ void __launch_bounds__(256, WPE)
 conv_strip_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
                        int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles, int cotiles) {
@@ -324,6 +327,35 @@ conv_strip_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restric
                 }
             }
         return;
+    }
+    if constexpr (DIRECT) {
+        if (out_mode == 0) {
+            const frcnn_buf_t ybuf = frcnn_make_buf(y, (uint32_t)((size_t)CoutP * H * W * 2));         // (the host checks < 2 GiB)
+            const int px = x0 + l31;
+#pragma unroll
+            for (int cb = 0; cb < COB; ++cb)
+#pragma unroll
+                for (int j = 0; j < RW; ++j) {
+                    const int py = y0 + rg * RW + j;
+                    const bool inside = px < W && py < H;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (g % KW != kw) continue;
+                        const int co = co0 + (cw * COB + cb) * 32 + 8 * g + 4 * khalf;                    // first of four consecutive couts: co % 4 == 0
+                        float v[4];
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            v[t] = acc[cb * RW + j][4 * g + t] + bv[cb][4 * g + t];
+                            if (relu) v[t] = fmaxf(v[t], 0.0f);
+                        }
+                        uint2 pk;
+                        pk.x = frcnn_pack_bf16x2(v[0], v[1]);
+                        pk.y = frcnn_pack_bf16x2(v[2], v[3]);
+                        frcnn_buf_store_b64(ybuf, (inside && co < CoutP) ? (uint32_t)((((co >> 4) * H + py) * W + px) * 32 + (co & 15) * 2) : kBufOob, pk);
+                    }
+                }
+            return;
+        }
     }
     // bf16 channel-blocked output: transpose through LDS so that each 16-cout block of a tile row leaves as one contiguous run
 #pragma unroll

@@ -58,6 +58,14 @@ __device__ __forceinline__ void frcnn_buf_store_f32x4_soff(frcnn_buf_t b, uint32
     __builtin_amdgcn_raw_buffer_store_b128(u, b, (int)byte_off, (int)soff, AUX);
 }
 
+// 8-byte store through a descriptor (lanes whose offset is kBufOob store nothing)
+__device__ __forceinline__ void frcnn_buf_store_b64(frcnn_buf_t b, uint32_t byte_off, uint2 v) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t u;
+    u.x = v.x; u.y = v.y;
+    __builtin_amdgcn_raw_buffer_store_b64(u, b, (int)byte_off, 0, 0);
+}
+
 __device__ __forceinline__ void frcnn_buf_store_f32(frcnn_buf_t b, uint32_t byte_off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b, (int)byte_off, 0, 0);
 }

@@ -28,6 +28,9 @@ static inline void frcnn_buf_store_b128(frcnn_buf_t b, uint32_t off, uint4 v) {
 template <int AUX> static inline void frcnn_buf_store_f32x4_soff(frcnn_buf_t b, uint32_t off, uint32_t soff, float4 v) {
     if ((uint64_t)off + 16 <= b.bytes) memcpy(const_cast<char *>(b.base) + off + soff, &v, 16);
 }
+static inline void frcnn_buf_store_b64(frcnn_buf_t b, uint32_t off, uint2 v) {
+    if ((uint64_t)off + 8 <= b.bytes) memcpy(const_cast<char *>(b.base) + off, &v, 8);
+}
 static inline void frcnn_buf_store_f32(frcnn_buf_t b, uint32_t off, float v) {
     if ((uint64_t)off + 4 <= b.bytes) memcpy(const_cast<char *>(b.base) + off, &v, 4);
 }

@@ -56,8 +56,9 @@ def test_loads_stay_batched(src, tmp_path):
 # the one-wave-per-SIMD strip kernels (csrc/conv_bf16_strip.h): nothing of theirs may live in scratch, and their LDS is exactly the ring.
 # (Forms B and C are compiled at 128 + 128 registers and sit at that limit: sixteen more live values across the K loop -- the bias, fetched
 # early -- made the compiler spill fragments to scratch and to LDS, 38 -> 133 us on conv4_2, with every result still correct; r03 probe 5.)
-STRIP_LDS = {"ILi2ELi5ELi4ELi1ELi1ELi3ELi0ELi1E": 3 * 42 * 1024, "ILi1ELi5ELi2ELi2ELi1ELi4ELi0ELi1E": 4 * 34 * 1024, "ILi1ELi5ELi1ELi1ELi4ELi2ELi0ELi1E": 2 * 68 * 1024,
-             "ILi1ELi5ELi2ELi2ELi1ELi2ELi0ELi2E": 2 * 34 * 1024}        # forms A, B, C (one workgroup per CU) and D (two)
+STRIP_LDS = {"ILi2ELi5ELi4ELi1ELi1ELi3ELi0ELi1ELb0E": 3 * 42 * 1024, "ILi1ELi5ELi2ELi2ELi1ELi4ELi0ELi1ELb0E": 4 * 34 * 1024, "ILi1ELi5ELi1ELi1ELi4ELi2ELi0ELi1ELb0E": 2 * 68 * 1024,
+             "ILi1ELi5ELi2ELi2ELi1ELi2ELi0ELi2ELb0E": 2 * 34 * 1024, "ILi1ELi5ELi2ELi2ELi1ELi2ELi0ELi2ELb1E": 2 * 34 * 1024}
+# forms A, B, C (one workgroup per CU) and D (two)
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc (cross-compiles without a GPU)")

@@ -261,7 +261,7 @@ def test_conv_bf16_lds_dma(rt, monkeypatch, mode):
     P.check_conv_bf16_pool(rt, 48, 64, 9, 37, seed=3)
 
 
-@pytest.mark.parametrize("mode", ["901", "902", "903", "900", "907", "908", "909"])
+@pytest.mark.parametrize("mode", ["901", "902", "903", "900", "907", "908", "909", "910"])
 def test_conv_bf16_strip_forms(rt, monkeypatch, mode):
     """The strip forms of the 3x3 bf16 kernel (csrc/conv_bf16_strip.h: one wave per SIMD, software-pipelined ring; D = 909 and C = 903 are default
     picks, the others selectable) against the oracle like every other staging variant -- one stage, the rings wrapping (5 and 12 stages),
@@ -278,7 +278,7 @@ def test_conv_bf16_strip_forms(rt, monkeypatch, mode):
         P.check_conv_bf16_pool(rt, 80, 128, 22, 37, seed=3)   # odd tile rows rule the pool out for form C, five chunks the two-way K split
 
 
-@pytest.mark.parametrize("form", [901, 902, 903, 907, 909])
+@pytest.mark.parametrize("form", [901, 902, 903, 907, 909, 910])
 def test_conv_bf16_strip_same_as_default(rt, form):
     P.check_conv_bf16_strip(rt, form, 128, 96, 21, 45, seed=4)
     P.check_conv_bf16_strip(rt, form, 64, 64, 12, 64, pool=form != 903, seed=5)
@@ -289,8 +289,8 @@ def test_conv_bf16_strip_forms_on_ragged_shapes(rt):
     forms: maps smaller than a tile, a single row / column, channel counts that fill neither a 16-channel block nor a 32- / 64-cout
     tile, odd sizes under the fused pool -- each against conv_dma_bf16_kernel (bit-identical, or summation-order noise for the K split)."""
     rs = np.random.RandomState(321)
-    for t in range(6):
-        form = int(rs.choice([901, 902, 903, 909]))
+    for t in range(8):
+        form = int(rs.choice([901, 902, 903, 909, 910]))
         kways = 4 if form == 903 else 1
         cin = int(rs.choice([16, 24, 40, 64, 100])) if kways == 1 else int(rs.choice([49, 64, 120, 128]))      # 903: chunks a multiple of 4
         cout, h, w = int(rs.choice([1, 20, 33, 64, 70])), int(rs.randint(1, 24)), int(rs.randint(1, 70))
