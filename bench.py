@@ -325,7 +325,7 @@ def bf16_variant(args, torch, rt, params, x, dbg, flops_total):
         print("bf16 conv-chain graph failed (%s)" % (e,), file=sys.stderr)
         torch.cuda.synchronize()
     try:                                                     # which kernel family each 3x3 launch of the chain runs (launch-free query of the library)
-        names = {0: "conv_dma_bf16_kernel", 901: "strip A", 902: "strip B", 903: "strip C (K split over waves)", 909: "strip D"}
+        names = {0: "conv_dma_bf16_kernel", 901: "strip A", 902: "strip B", 903: "strip C (K split over waves)", 909: "strip D", 910: "strip D"}
         picks, h, w = {}, IM_H, IM_W
         from chainer_faster_rcnn_amd.models.vgg16 import LAYERS as _layers
         for l in _layers:

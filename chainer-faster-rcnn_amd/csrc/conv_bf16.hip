@@ -789,7 +789,8 @@ static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed
     // 909 = form D: form B's waves -- the default pick of frcnn_conv_bf16_ws for launches with >= 8 K-chunks and >= one tile per CU
     case 8: conv_bf16_strip_go<2, 3, 4, 1, 1, 2, 0, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
     case 9: conv_bf16_strip_go<1, 5, 2, 2, 1, 2, 0, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
-    // 910: form D with the bf16 output of a launch without the fused pool stored straight from the accumulators (no LDS transpose; NOT yet timed)
+    // 910: form D with the bf16 output of a launch without the fused pool stored straight from the accumulators (no LDS transpose, no barrier: conv3_1 / conv3_2 /
+    //      conv4_2 25.4 / 41.7 / 41.7 -> 25.1 / 40.8 / 40.9 us, bit-identical; probe 9) -- what the default rule launches; pooled and fp32-NCHW launches take 909's epilogue
     case 10:
         if (out_mode == 0 && (size_t)CoutP * H * W * 2 < (1ull << 31)) conv_bf16_strip_go<1, 5, 2, 2, 1, 2, 0, 2, true>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
         else conv_bf16_strip_go<1, 5, 2, 2, 1, 2, 0, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
@@ -810,7 +811,7 @@ static int conv_bf16_default_strip_form(int CinP, int CoutP, int H, int W, int o
     const long cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
     const long wgs_d = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 10) * frcnn_cdiv(CoutP, 64);
     const long wgs_c = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 5) * frcnn_cdiv(CoutP, 32);
-    if (wgs_d >= cus) return 9;                                                       // form D: any chunk count, even tile rows (pool-capable)
+    if (wgs_d >= cus) return 10;                                                      // form D (910: its un-pooled bf16 output stored straight from the accumulators); even tile rows: pool-capable
     if (CinP / kCK >= 16 && (CinP / kCK) % 4 == 0 && out_mode != 2 && 2 * wgs_c > cus && wgs_c <= cus) return 3;       // form C
     return 0;
 }
