@@ -383,9 +383,9 @@ def test_conv_bf16_staging_variants_bit_identical(rt, monkeypatch, cin, cout, h,
         assert np.array_equal(full, outs["0"][0]) and np.array_equal(pooled, outs["0"][1]), mode
 
 
-@pytest.mark.parametrize("form", [901, 902, 903, 909])
+@pytest.mark.parametrize("form", [901, 902, 903, 909, 910])
 def test_conv_bf16_strip_forms(rt, form):
-    """The strip forms (csrc/conv_bf16_strip.h; D = 909 and C = 903 are default picks) against conv_dma_bf16_kernel at VGG layer sizes: bit-identical
+    """The strip forms (csrc/conv_bf16_strip.h; D -- 910, with 909's epilogue under the fused pool -- and C = 903 are default picks) against conv_dma_bf16_kernel at VGG layer sizes: bit-identical
     where one accumulation chain per output is kept, fp32 summation-order noise for the K-split form (profiles/r03_conv_bf16_strip_micro.txt holds
     the same comparison from the torch-free harness on all ten layer shapes)."""
     P.check_conv_bf16_strip(rt, form, 256, 256, 150, 250, pool=form != 903)
