@@ -11,6 +11,8 @@
 // other.  __syncthreads() and the wave-level collectives (ballot / shuffle / readlane / MFMA) are
 // rendezvous points; a collective that not all live lanes of a wave reach from the same call site aborts
 // with a diagnostic (catches divergent-collective bugs that real hardware would turn into garbage).
+// LDS-DMA pieces land either when they are issued (default) or at the s_waitcnt that covers them (HIPEMU_DMA_DEFER=1): the two ends of what
+// the hardware may do, so that a DMA ring's counted waits are tested and not only reasoned about (see dma_deposit / dma_wait below).
 #pragma once
 #include <ucontext.h>
 #include <sys/mman.h>
@@ -75,11 +77,16 @@ namespace hipemu {
 
 enum State { RUNNABLE = 0, WAIT_BAR = 1, WAIT_WAVE = 2, DONE = 3 };
 
+// One LDS-DMA deposit of one lane that has been issued but has not "landed" yet (HIPEMU_DMA_DEFER=1, see dma_deposit below)
+struct PendingDma { void *dst; unsigned char data[16]; int bytes; };
+
 struct Fiber {
     ucontext_t ctx;
     uint3_emu tid;
     int lin, wave, lane, state;
     char *stack;
+    std::vector<PendingDma> dma;        // in issue order; [dma_head, size) are still in flight
+    size_t dma_head = 0;
 };
 
 struct Wave {
@@ -100,8 +107,33 @@ struct Global {
     void (*body)(void *) = nullptr;
     void *body_arg = nullptr;
     size_t stack_bytes = 512 * 1024;
+    bool dma_defer = false;             // HIPEMU_DMA_DEFER=1, read at every launch
 };
 inline Global &G() { static Global g; return g; }
+
+// LDS-DMA timing model.  The hardware lands a buffer_load ... lds some time between its issue and the s_waitcnt vmcnt(N) that covers it.  By
+// default the emulator lands it AT ISSUE (the earliest legal moment: what catches a stage refilled while somebody still reads it); with
+// HIPEMU_DMA_DEFER=1 it lands AT THE WAIT THAT COVERS IT (the latest legal moment: a fragment read before its stage's counted wait sees the
+// stage's previous contents, a wait that allows one stage too many in flight leaves a stage un-landed).  A ring protocol has to pass both.
+// vmcnt is per wave and counts instructions; every lane of a wave executes every DMA instruction once, so a per-lane queue has the same length.
+// (Ordinary global loads / stores, which the hardware also counts, land at once here: that only ever makes a real wait cover MORE pieces.)
+inline void dma_deposit(void *dst, const void *src, int bytes) {
+    Global &g = G();
+    if (!g.dma_defer) { memcpy(dst, src, (size_t)bytes); return; }
+    PendingDma p;
+    p.dst = dst; p.bytes = bytes;
+    memcpy(p.data, src, (size_t)bytes);
+    g.cur->dma.push_back(p);
+}
+inline void dma_wait(int allow) {       // s_waitcnt vmcnt(allow) of the calling lane's wave
+    Fiber *f = G().cur;
+    if (!f) return;
+    while ((long)(f->dma.size() - f->dma_head) > (long)allow) {
+        const PendingDma &p = f->dma[f->dma_head++];
+        memcpy(p.dst, p.data, (size_t)p.bytes);
+    }
+    if (f->dma_head == f->dma.size()) { f->dma.clear(); f->dma_head = 0; }
+}
 
 inline void yield_to_sched() { Global &g = G(); swapcontext(&g.cur->ctx, &g.sched); }
 
@@ -118,6 +150,7 @@ inline void wave_release(Wave &w, int wave_id) {
 inline void trampoline() {
     Global &g = G();
     g.body(g.body_arg);
+    dma_wait(0);                        // (a wave does not end with loads in flight)
     Fiber *f = g.cur;
     f->state = DONE;
     g.alive--;
@@ -185,6 +218,8 @@ inline void run_block() {
         f.wave = (int)(i / 64);
         f.lane = (int)(i % 64);
         f.state = RUNNABLE;
+        f.dma.clear();
+        f.dma_head = 0;
         g.waves[f.wave].alive++;
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack;
@@ -224,6 +259,7 @@ inline void launch(dim3 grid, dim3 block, F &&f) {
     if ((size_t)block.x * block.y * block.z > 1024 || block.x * block.y * block.z == 0) { fprintf(stderr, "hipemu: bad block size\n"); abort(); }
     g.gdim = grid;
     g.bdim = block;
+    { const char *e = getenv("HIPEMU_DMA_DEFER"); g.dma_defer = e && e[0] == '1'; }
     using Fn = typename std::remove_reference<F>::type;
     Fn *fp = &f;
     g.body = [](void *p) { (*(Fn *)p)(); };
@@ -250,7 +286,7 @@ inline void hipLaunchKernelGGL(void (*kernel)(KArgs...), dim3 grid, dim3 block, 
     hipemu::launch(grid, block, [&]() { kernel(static_cast<KArgs>(args)...); });
 }
 
-static inline void __syncthreads() { hipemu::block_barrier(); }
+static inline void __syncthreads() { hipemu::dma_wait(0); hipemu::block_barrier(); }       // (its fences compile to s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier)
 static inline void __builtin_amdgcn_s_barrier() { hipemu::block_barrier(); }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}

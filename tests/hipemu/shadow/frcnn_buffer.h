@@ -40,13 +40,13 @@ static inline void frcnn_buf_load_lds_b128(frcnn_buf_t b, void *lds_wave_base, u
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < 4; ++k)
         if ((uint64_t)off + 4 * k + 4 <= b.bytes) memcpy(&v[k], b.base + off + soff + 4 * k, 4);
-    memcpy((char *)lds_wave_base + 16 * (threadIdx.x & 63), v, 16);
+    hipemu::dma_deposit((char *)lds_wave_base + 16 * (threadIdx.x & 63), v, 16);       // lands now, or at the covering wait (HIPEMU_DMA_DEFER=1)
 }
 static inline void frcnn_buf_load_lds_b32(frcnn_buf_t b, void *lds_wave_base, uint32_t off, uint32_t soff) {
     float v = 0.0f;
     if ((uint64_t)off + 4 <= b.bytes) memcpy(&v, b.base + off + soff, 4);
-    memcpy((char *)lds_wave_base + 4 * (threadIdx.x & 63), &v, 4);
+    hipemu::dma_deposit((char *)lds_wave_base + 4 * (threadIdx.x & 63), &v, 4);
 }
-template <int N> static inline void frcnn_wait_vmcnt() {}
-static inline void frcnn_barrier_nofence() { __syncthreads(); }
+template <int N> static inline void frcnn_wait_vmcnt() { hipemu::dma_wait(N); }
+static inline void frcnn_barrier_nofence() { __builtin_amdgcn_s_barrier(); }       // the barrier alone: no wait on loads in flight
 static inline void frcnn_sleep_64clk(int) {}

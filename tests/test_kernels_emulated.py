@@ -284,6 +284,28 @@ def test_conv_bf16_strip_same_as_default(rt, form):
     P.check_conv_bf16_strip(rt, form, 64, 64, 12, 64, pool=form != 903, seed=5)
 
 
+def test_lds_dma_kernels_with_late_landing(rt, monkeypatch):
+    """Every kernel family that stages through LDS-DMA (buffer_load ... lds + counted s_waitcnt vmcnt + fence-less barriers), once more with
+    the emulator landing each piece at the LATEST legal moment -- the wait that covers it (HIPEMU_DMA_DEFER=1, tests/hipemu/hip/hip_runtime.h)
+    -- instead of at issue.  By default the emulator lands a piece the moment it is issued, which catches a stage refilled too early but is
+    blind to a fragment read before its stage's wait and to a wait that allows one stage too many in flight (changing the strip kernel's
+    hand-over to `wait_allow(allow + 1)` passes every other test here and fails this one); a ring protocol has to hold at both ends."""
+    monkeypatch.setenv("HIPEMU_DMA_DEFER", "1")
+    for form in (901, 902, 903, 910):                                   # strip forms: 8 chunks, every ring wraps (3, 4, 2, 2 stages)
+        P.check_conv_bf16_strip(rt, form, 128, 96, 21, 45, seed=4)
+    P.check_conv_bf16_strip(rt, 909, 64, 64, 12, 64, pool=True, seed=5)
+    for mode in ("231", "321", "141", "224"):                           # conv_dma_bf16_kernel: two / three-stage rings, single stage, 16-row tiles
+        monkeypatch.setenv("FRCNN_BF16_DMA", mode)
+        P.check_conv_bf16(rt, 80, 128, 13, 70, seed=2)
+    monkeypatch.delenv("FRCNN_BF16_DMA")
+    P.check_conv3x3(rt, 48, 64, 9, 70, seed=1)                          # fp32 MFMA convolution (conv.hip), stream-K pieces included
+    P.check_conv_f32s(rt, 192, 64, 5, 33, seed=6)                       # split products (conv_f32s.hip)
+    P.check_conv_backward(rt, 64, 64, 9, 70)                            # weight / input gradients (train.hip)
+    P.check_linear(rt, 70, 140, 256, True)                              # fp32 FC (gemm.hip)
+    P.check_linear_bf16(rt, 100, 130, 128, True, seed=2)                # bf16 FC
+    P.check_linear_f32s(rt, 40, 96, 192, True, seed=1)                  # split-product FC
+
+
 def test_conv_bf16_strip_forms_on_ragged_shapes(rt):
     """A seeded sweep of awkward launches through the strip forms that are default picks (D = 909, C = 903) and the two one-workgroup
     forms: maps smaller than a tile, a single row / column, channel counts that fill neither a 16-channel block nor a 32- / 64-cout
