@@ -264,12 +264,16 @@ inline void launch(dim3 grid, dim3 block, F &&f) {
     Fn *fp = &f;
     g.body = [](void *p) { (*(Fn *)p)(); };
     g.body_arg = (void *)fp;
-    for (unsigned z = 0; z < grid.z; ++z)
-        for (unsigned y = 0; y < grid.y; ++y)
-            for (unsigned x = 0; x < grid.x; ++x) {
-                g.bid = uint3_emu{x, y, z};
-                run_block();
-            }
+    // Workgroups run one after the other; HIPEMU_BLOCK_ORDER=reverse runs them last to first, so that "the last workgroup to arrive" of a
+    // ticketed fix-up (stream-K / split-K pieces) is a different one: the results must not depend on it.
+    const char *oe = getenv("HIPEMU_BLOCK_ORDER");
+    const bool rev = oe && oe[0] == 'r';
+    const unsigned long total = (unsigned long)grid.x * grid.y * grid.z;
+    for (unsigned long k = 0; k < total; ++k) {
+        const unsigned long i = rev ? total - 1 - k : k;
+        g.bid = uint3_emu{(unsigned)(i % grid.x), (unsigned)((i / grid.x) % grid.y), (unsigned)(i / ((unsigned long)grid.x * grid.y))};
+        run_block();
+    }
 }
 
 }  // namespace hipemu

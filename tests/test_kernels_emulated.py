@@ -284,6 +284,30 @@ def test_conv_bf16_strip_same_as_default(rt, form):
     P.check_conv_bf16_strip(rt, form, 64, 64, 12, 64, pool=form != 903, seed=5)
 
 
+def test_ticketed_fixups_do_not_depend_on_arrival_order(rt, monkeypatch):
+    """The launches whose workgroups hand partial results to each other through a ticket (the fp32 convolution's stream-K pieces, the bf16
+    convolution's split-K, the split-K FC layers; the last arriver sums the pieces in piece order) give bit-identical results whichever
+    workgroup arrives last: the emulator runs workgroups first to last by default and last to first with HIPEMU_BLOCK_ORDER=reverse."""
+    rs = np.random.RandomState(3)
+    x = rs.randn(1, 128, 9, 70).astype(np.float32)               # 8 K-chunks: two bf16 splits of four
+    w = (rs.randn(64, 128, 3, 3) * 0.05).astype(np.float32)
+    b = (rs.randn(64) * 0.1).astype(np.float32)
+    xm, wm = rs.randn(70, 512).astype(np.float32), (rs.randn(140, 512) * 0.05).astype(np.float32)
+    bm = (rs.randn(140) * 0.1).astype(np.float32)
+
+    def run():
+        out = [P.host(rt, rt.conv3x3(P.dev(rt, x), rt.pack_conv3x3_w(P.dev(rt, w)), P.dev(rt, b), relu=True))]
+        monkeypatch.setenv("FRCNN_BF16_SPLIT", "2")
+        out.append(P.host(rt, rt.conv_bf16(rt.bf16_from_nchw(P.dev(rt, x)), rt.bf16_pack_conv_w(P.dev(rt, w), 3), P.dev(rt, b), 128, 64, 3, relu=True)))
+        monkeypatch.delenv("FRCNN_BF16_SPLIT")
+        out.append(P.host(rt, rt.linear(P.dev(rt, xm), P.dev(rt, wm), P.dev(rt, bm), relu=True)))
+        return out
+    first = run()
+    monkeypatch.setenv("HIPEMU_BLOCK_ORDER", "reverse")
+    for a, c in zip(first, run()):
+        assert a.shape == c.shape and np.array_equal(a, c)
+
+
 def test_lds_dma_kernels_with_late_landing(rt, monkeypatch):
     """Every kernel family that stages through LDS-DMA (buffer_load ... lds + counted s_waitcnt vmcnt + fence-less barriers), once more with
     the emulator landing each piece at the LATEST legal moment -- the wait that covers it (HIPEMU_DMA_DEFER=1, tests/hipemu/hip/hip_runtime.h)
