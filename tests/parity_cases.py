@@ -921,6 +921,37 @@ def check_vgg_bf16_forward(rt, im_h, im_w, seed=5):
     return err
 
 
+def check_vgg_bf16_trunk(rt, im_h, im_w, seed=5):
+    """The full-width bf16 trunk + RPN convolution and heads through the model classes at a small image (no FC head: on the emulator
+    its 25088-wide GEMM alone takes minutes): conv5_3 within 3e-2 of the fp32 oracle's feature scale, and -- the point of running it
+    on the emulator, whose three-CU chip sends ten of the thirteen layers and the RPN convolution through strip form D -- the same
+    maps bit for bit with the strip rule switched off (form D keeps conv_dma_bf16_kernel's accumulation order)."""
+    from chainer_faster_rcnn_amd import synthetic
+    from chainer_faster_rcnn_amd.models import FasterRCNN
+    params = synthetic.params(seed=1)
+    x = synthetic.image(seed=seed, h=im_h, w=im_w)
+    outs = {}
+    old = os.environ.get("FRCNN_BF16_STRIP")
+    try:
+        model = FasterRCNN(runtime=rt, conv_dtype="bf16", head_dtype="bf16")
+        model.load_params(params)
+        for strip in ("1", "0"):                                    # (the library reads the hook at every launch)
+            os.environ["FRCNN_BF16_STRIP"] = strip
+            feat = model.trunk(rt.mem.from_numpy(x))
+            h, score, prob, bbox = model.RPN.heads(feat, want_score=False, x_bf16=model.trunk.feat_bf16)
+            outs[strip] = [host(rt, t) for t in (feat, prob, bbox)]
+    finally:
+        os.environ.pop("FRCNN_BF16_STRIP", None)
+        if old is not None:
+            os.environ["FRCNN_BF16_STRIP"] = old
+    want = O.vgg16_trunk(params, x)
+    err = np.abs(outs["1"][0] - want).max() / np.abs(want).max()
+    assert err < 3e-2, err
+    for a, c in zip(outs["1"], outs["0"]):
+        assert a.shape == c.shape and np.array_equal(a, c)
+    return err
+
+
 def check_detections(rt, R=300, ncls=21, seed=0):
     """forward.py:48-58 post-processing: 20 per-class NMS problems (thresh 0.3) + conf cut, batched on the device."""
     from chainer_faster_rcnn_amd.postprocess import detections

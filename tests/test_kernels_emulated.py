@@ -284,6 +284,13 @@ def test_conv_bf16_strip_same_as_default(rt, form):
     P.check_conv_bf16_strip(rt, form, 64, 64, 12, 64, pool=form != 903, seed=5)
 
 
+def test_vgg16_bf16_trunk_through_the_strip_picks(rt):
+    """The full-width bf16 trunk + RPN heads at 22 x 37 through the model classes: on the emulated three-CU chip the default rule sends ten
+    of the thirteen trunk layers (incl. the pool-fused ones) and the RPN convolution through strip form D; same maps bit for bit with the
+    rule off, conv5_3 within the bf16 bar of the fp32 oracle."""
+    assert P.check_vgg_bf16_trunk(rt, 22, 37) < 3e-2
+
+
 def test_ticketed_fixups_do_not_depend_on_arrival_order(rt, monkeypatch):
     """The launches whose workgroups hand partial results to each other through a ticket (the fp32 convolution's stream-K pieces, the bf16
     convolution's split-K, the split-K FC layers; the last arriver sums the pieces in piece order) give bit-identical results whichever
