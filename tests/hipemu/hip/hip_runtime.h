@@ -65,7 +65,13 @@ static inline hipError_t hipGetDeviceCount(int *n) { *n = 0; return hipSuccess; 
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 0 };
 static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
 // a deliberately odd, tiny "chip" so persistent / stream-K decompositions split tiles unevenly under test
-static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 3; return hipSuccess; }
+// (HIPEMU_CUS=n gives the emulated chip another size -- read when a library first asks, i.e. once per process: tests that want the launch
+// heuristics of a bigger chip run in a subprocess)
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) {
+    const char *e = getenv("HIPEMU_CUS");
+    *v = (e && atoi(e) > 0) ? atoi(e) : 3;
+    return hipSuccess;
+}
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n); return *p ? hipSuccess : hipErrorInvalidValue; }

@@ -291,6 +291,28 @@ def test_vgg16_bf16_trunk_through_the_strip_picks(rt):
     assert P.check_vgg_bf16_trunk(rt, 22, 37) < 3e-2
 
 
+def test_default_rule_picks_form_c_on_a_chip_of_eight_cus():
+    """The default rule's second branch -- a launch too small for form D that ONE round of form C covers -- cannot trigger on the three-CU
+    emulated chip; a subprocess with HIPEMU_CUS=8 (the CU count is cached per process) runs a 256 -> 64 convolution on a 10 x 64 map:
+    the plan says form C, and the launch -- default picks, no hook -- matches the oracle like every other variant."""
+    import subprocess
+    code = ("import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from emu_runtime import emu_runtime; import parity_cases as P\n"
+            "rt = emu_runtime()\n"
+            "assert rt.lib.frcnn_conv_bf16_plan(256, 64, 10, 64, 3, 0) == 903, rt.lib.frcnn_conv_bf16_plan(256, 64, 10, 64, 3, 0)\n"
+            "assert rt.lib.frcnn_conv_bf16_plan(256, 64, 10, 64, 3, 2) == 0\n"
+            "assert rt.lib.frcnn_conv_bf16_plan(256, 256, 10, 64, 3, 0) == 910\n"
+            "P.check_conv_bf16(rt, 256, 64, 10, 64, seed=3)\n"
+            "P.check_conv_bf16_strip(rt, 903, 256, 64, 10, 64, seed=3)\n"
+            "print('ok')\n") % (os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"), os.path.dirname(os.path.abspath(__file__)),
+                                 os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = dict(os.environ, HIPEMU_CUS="8")
+    for k in ("FRCNN_BF16_DMA", "FRCNN_BF16_STRIP", "FRCNN_BF16_SPLIT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_ticketed_fixups_do_not_depend_on_arrival_order(rt, monkeypatch):
     """The launches whose workgroups hand partial results to each other through a ticket (the fp32 convolution's stream-K pieces, the bf16
     convolution's split-K, the split-K FC layers; the last arriver sums the pieces in piece order) give bit-identical results whichever
