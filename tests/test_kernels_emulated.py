@@ -285,9 +285,9 @@ def test_conv_bf16_strip_same_as_default(rt, form):
 
 
 def test_vgg16_bf16_trunk_through_the_strip_picks(rt):
-    """The full-width bf16 trunk + RPN heads at 22 x 37 through the model classes: on the emulated three-CU chip the default rule sends ten
-    of the thirteen trunk layers (incl. the pool-fused ones) and the RPN convolution through strip form D; same maps bit for bit with the
-    rule off, conv5_3 within the bf16 bar of the fp32 oracle."""
+    """The full-width bf16 trunk, conv1_1 ... conv4_1, at 22 x 37 through the model class: on the emulated three-CU chip the default rule sends
+    five of those ten layers (two of them pool-fused) through strip form D; same map bit for bit with the rule off, within the bf16 bar of
+    the fp32 oracle."""
     assert P.check_vgg_bf16_trunk(rt, 22, 37) < 3e-2
 
 
