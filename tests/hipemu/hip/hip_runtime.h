@@ -7,7 +7,7 @@
 // collectives, MFMA fragment layouts, barriers) against the oracle.  It is never loaded by the product
 // package, is not a fallback, and says nothing about performance.
 //
-// Model: each workgroup runs as cooperative fibers (ucontext) on one OS thread, blocks run one after the
+// Model: each workgroup runs as cooperative fibers (a hand-rolled x86-64 stack switch; ucontext elsewhere) on one OS thread, blocks run one after the
 // other.  __syncthreads() and the wave-level collectives (ballot / shuffle / readlane / MFMA) are
 // rendezvous points; a collective that not all live lanes of a wave reach from the same call site aborts
 // with a diagnostic (catches divergent-collective bugs that real hardware would turn into garbage).
@@ -86,8 +86,41 @@ enum State { RUNNABLE = 0, WAIT_BAR = 1, WAIT_WAVE = 2, DONE = 3 };
 // One LDS-DMA deposit of one lane that has been issued but has not "landed" yet (HIPEMU_DMA_DEFER=1, see dma_deposit below)
 struct PendingDma { void *dst; unsigned char data[16]; int bytes; };
 
+// Context switch.  swapcontext() saves and restores the signal mask -- two system calls per switch, a quarter of the emulator's run time --
+// which cooperative fibers on one thread have no use for: on x86-64 the switch is the callee-saved registers and the stack pointer.
+#if defined(__x86_64__)
+struct Ctx { void *sp; };
+__attribute__((naked, noinline)) static void ctx_switch(Ctx * /*from: rdi*/, Ctx * /*to: rsi*/) {
+    __asm__ volatile(
+        "pushq %rbp\n\tpushq %rbx\n\tpushq %r12\n\tpushq %r13\n\tpushq %r14\n\tpushq %r15\n\t"
+        "movq %rsp, (%rdi)\n\t"
+        "movq (%rsi), %rsp\n\t"
+        "popq %r15\n\tpopq %r14\n\tpopq %r13\n\tpopq %r12\n\tpopq %rbx\n\tpopq %rbp\n\t"
+        "ret");
+}
+// a fresh context that enters `entry` (which never returns) on the given stack at its first switch-in
+inline void ctx_make(Ctx &c, char *stack, size_t bytes, void (*entry)()) {
+    uintptr_t top = ((uintptr_t)stack + bytes) & ~(uintptr_t)15;
+    void **sp = (void **)top;
+    *--sp = nullptr;                    // the slot a caller's return address would occupy: keeps entry's frame 16-byte aligned as the ABI expects
+    *--sp = (void *)entry;              // popped by ctx_switch's ret
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;      // rbp, rbx, r12 .. r15
+    c.sp = (void *)sp;
+}
+#else
+struct Ctx { ucontext_t uc; };
+inline void ctx_switch(Ctx *from, Ctx *to) { swapcontext(&from->uc, &to->uc); }
+inline void ctx_make(Ctx &c, char *stack, size_t bytes, void (*entry)()) {
+    getcontext(&c.uc);
+    c.uc.uc_stack.ss_sp = stack;
+    c.uc.uc_stack.ss_size = bytes;
+    c.uc.uc_link = nullptr;
+    makecontext(&c.uc, entry, 0);
+}
+#endif
+
 struct Fiber {
-    ucontext_t ctx;
+    Ctx ctx;
     uint3_emu tid;
     int lin, wave, lane, state;
     char *stack;
@@ -103,7 +136,7 @@ struct Wave {
 };
 
 struct Global {
-    ucontext_t sched;
+    Ctx sched;
     Fiber *cur = nullptr;
     std::vector<Fiber> fibers;
     std::vector<Wave> waves;
@@ -141,7 +174,7 @@ inline void dma_wait(int allow) {       // s_waitcnt vmcnt(allow) of the calling
     if (f->dma_head == f->dma.size()) { f->dma.clear(); f->dma_head = 0; }
 }
 
-inline void yield_to_sched() { Global &g = G(); swapcontext(&g.cur->ctx, &g.sched); }
+inline void yield_to_sched() { Global &g = G(); ctx_switch(&g.cur->ctx, &g.sched); }
 
 inline void wave_release(Wave &w, int wave_id) {
     Global &g = G();
@@ -163,7 +196,7 @@ inline void trampoline() {
     Wave &w = g.waves[f->wave];
     w.alive--;
     if (w.alive > 0 && w.arrived == w.alive) wave_release(w, f->wave);
-    swapcontext(&f->ctx, &g.sched);
+    ctx_switch(&f->ctx, &g.sched);
 }
 
 // Rendezvous of all live lanes of the calling wave; returns the 64 deposits (valid until the
@@ -227,11 +260,7 @@ inline void run_block() {
         f.dma.clear();
         f.dma_head = 0;
         g.waves[f.wave].alive++;
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack;
-        f.ctx.uc_stack.ss_size = g.stack_bytes;
-        f.ctx.uc_link = nullptr;
-        makecontext(&f.ctx, (void (*)())trampoline, 0);
+        ctx_make(f.ctx, f.stack, g.stack_bytes, trampoline);
     }
     g.alive = (int)n;
     g.in_bar = 0;
@@ -241,7 +270,7 @@ inline void run_block() {
             Fiber &f = g.fibers[i];
             if (f.state != RUNNABLE) continue;
             g.cur = &f;
-            swapcontext(&g.sched, &f.ctx);
+            ctx_switch(&g.sched, &f.ctx);
             progressed = true;
         }
         if (g.alive > 0 && g.in_bar == g.alive) {
