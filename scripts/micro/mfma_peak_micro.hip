@@ -3,7 +3,8 @@
 // micro-benchmarks count shader clocks per MFMA (32.9 for bf16 32x32x16: the pipe is full); this one says what those clocks are worth
 // under a chip-wide MFMA load -- the ceiling every "fraction of the 2.5 PFLOP/s peak" in DESIGN.md has to be read against.
 // Operand DATA matters: the matrix datapath of a chip-wide MFMA load is power-limited, and constant operands toggle no bits.
-// Usage: mfma_peak_micro [waves_per_simd=1] [mfmas_per_wave=20000]
+// Usage: mfma_peak_micro [waves_per_simd=1] [mfmas_per_wave=20000] [launches_per_timed_burst=10]   (a burst of 10 lasts ~6 ms at bf16 rates; 2000 lasts over a second:
+//        does the clock sag further when the load lasts?)
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -42,6 +43,7 @@ __global__ void __launch_bounds__(256) mfma_stream(float *out, int n, const uint
     if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
+static int g_burst = 10;
 template <int KIND>
 static void run(const char *name, double flop_per_mfma, int wps, int n, int cus, bool random_data) {
     float *out; CK(hipMalloc(&out, 4096));
@@ -64,10 +66,10 @@ static void run(const char *name, double flop_per_mfma, int wps, int n, int cus,
     std::vector<double> tf;
     for (int r = 0; r < 9; ++r) {
         CK(hipEventRecord(e0, s));
-        for (int i = 0; i < 10; ++i) hipLaunchKernelGGL(mfma_stream<KIND>, grid, block, 0, s, out, n, rnd);
+        for (int i = 0; i < g_burst; ++i) hipLaunchKernelGGL(mfma_stream<KIND>, grid, block, 0, s, out, n, rnd);
         CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
         float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
-        tf.push_back(10.0 * grid.x * 4 * (double)n * flop_per_mfma / (ms * 1e-3) / 1e12);
+        tf.push_back((double)g_burst * grid.x * 4 * (double)n * flop_per_mfma / (ms * 1e-3) / 1e12);
     }
     std::sort(tf.begin(), tf.end());
     const double med = tf[tf.size() / 2];
@@ -80,6 +82,7 @@ static void run(const char *name, double flop_per_mfma, int wps, int n, int cus,
 
 int main(int argc, char **argv) {
     const int wps = argc > 1 ? atoi(argv[1]) : 1, n = argc > 2 ? atoi(argv[2]) : 20000;
+    if (argc > 3 && atoi(argv[3]) > 0) g_burst = atoi(argv[3]);
     hipDeviceProp_t p; CK(hipGetDeviceProperties(&p, 0));
     printf("%s: %d CUs, clockRate %d kHz\n", p.gcnArchName, p.multiProcessorCount, p.clockRate);
     run<0>("bf16 32x32x16, constant operands", 32768.0, wps, n, p.multiProcessorCount, false);
