@@ -747,12 +747,13 @@ static void conv_bf16_strip_go(const uint16_t *x, const uint16_t *w_packed, cons
     hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_strip_bf16_kernel<COB, RW, RG, CW, KW, NS, ABL, WPE, DIRECT>), dim3((unsigned)((long)xtiles * ytiles * cotiles)), dim3(256), 0, stream,
                        x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, cotiles);
 }
-static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int CinP, int Cout, int CoutP, int H, int W,
-                           int relu, int out_mode, hipStream_t stream, int abl = 0) {
+// Which strip form a request resolves to for a launch (0 = the request does not exist / does not apply): `form` 1..10 as requested, 0 = the cheapest
+// applicable one of A / B / C by a count of MFMA rounds.  ONE place for the launcher and for frcnn_conv_bf16_plan (the plan query had its own copy).
+static int conv_bf16_strip_resolve(int form, int CinP, int CoutP, int H, int W, int out_mode) {
     const int chunks = CinP / kCK;
     // {couts per workgroup, tile rows, K ways, MFMAs per wave and stage}
     static const int kForm[11][4] = {{0, 0, 0, 0}, {64, 20, 1, 90}, {64, 10, 1, 45}, {32, 5, 4, 45}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {64, 10, 2, 90}, {64, 12, 1, 54}, {64, 10, 1, 45}, {64, 10, 1, 45}};
-    auto applies = [&](int f) { return kForm[f][0] != 0 && chunks % kForm[f][2] == 0 && !(out_mode == 2 && (kForm[f][1] & 1)); };
+    auto applies = [&](int f) { return f >= 0 && f <= 10 && kForm[f][0] != 0 && chunks % kForm[f][2] == 0 && !(out_mode == 2 && (kForm[f][1] & 1)); };
     if (form == 0) {
         const long cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
         long best = -1;
@@ -763,9 +764,13 @@ static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed
             const long cost = ((wgs + cus - 1) / cus) * (chunks / kForm[f][2] + 2) * kForm[f][3];
             if (best < 0 || cost < best) { best = cost; form = f; }
         }
-        if (form == 0) return 1;
     }
-    if (!applies(form)) return 1;
+    return applies(form) && form != 0 ? form : 0;
+}
+static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int CinP, int Cout, int CoutP, int H, int W,
+                           int relu, int out_mode, hipStream_t stream, int abl = 0) {
+    form = conv_bf16_strip_resolve(form, CinP, CoutP, H, W, out_mode);
+    if (form == 0) return 1;
 #ifdef FRCNN_TIMING_ABLATIONS                                                                       // WRONG results: sweeps only, never shipped
 #define FRCNN_STRIP_ABL(A)                                                                                                                  \
     case A:                                                                                                                                 \
@@ -1019,12 +1024,25 @@ int frcnn_conv_bf16(const uint16_t *x, const uint16_t *w_packed, const float *bi
 int frcnn_conv_bf16_plan(int Cin, int Cout, int H, int W, int ksize, int out_mode) {
     if (Cin < 1 || Cout < 1 || H < 1 || W < 1 || (ksize != 1 && ksize != 3) || out_mode < 0 || out_mode > 2) return FRCNN_ERR_INVALID;
     if (ksize != 3) return 0;
+    const int CinP = frcnn_bf16_padded_channels(Cin), CoutP = frcnn_bf16_padded_channels(Cout);
     const char *dma_env = getenv("FRCNN_BF16_DMA");
     const int mode = dma_env ? atoi(dma_env) : -1;
-    if (mode >= 900 && mode <= 910) return mode;
-    if (mode >= 0) return 0;
-    const int form = conv_bf16_default_strip_form(frcnn_bf16_padded_channels(Cin), frcnn_bf16_padded_channels(Cout), H, W, out_mode);
-    return form ? 900 + form : 0;
+    // the same three branches as frcnn_conv_bf16_ws, through the same resolver: what is returned is the form that would be LAUNCHED
+    if (mode < 0) {
+        const int pick = conv_bf16_default_strip_form(CinP, CoutP, H, W, out_mode);
+        const int form = pick ? conv_bf16_strip_resolve(pick, CinP, CoutP, H, W, out_mode) : 0;
+        return form ? 900 + form : 0;
+    }
+    if (mode >= 9010 && mode <= 9039) {
+        const int form = conv_bf16_strip_resolve((mode - 9000) / 10, CinP, CoutP, H, W, out_mode);
+        return form ? 900 + form : FRCNN_ERR_INVALID;
+    }
+    if (mode >= 900 && mode <= 910) {
+        const int form = conv_bf16_strip_resolve(mode - 900, CinP, CoutP, H, W, out_mode);
+        if (form) return 900 + form;
+        return mode == 900 ? 0 : FRCNN_ERR_INVALID;               // 900 falls back to conv_dma_bf16_kernel's picks; an explicit form that does not apply is refused
+    }
+    return 0;
 }
 
 int frcnn_maxpool2x2_bf16(const uint16_t *x, uint16_t *y, int C, int H, int W, void *stream) {
