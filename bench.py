@@ -74,8 +74,8 @@ def pmc_traffic(dtype):
     WRITE_SIZE in separate rocprofv3 --pmc runs); counters cannot be read from inside the process, so the bench line carries
     the last measured figure and names its source, or null when no PMC pass exists for this dtype."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    cands = {"f32": ["r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"],
-             "bf16": ["r03_hbm_traffic_pmc_bf16.json", "r02_hbm_traffic_pmc_bf16.json"],
+    cands = {"f32": ["r04_hbm_traffic_pmc.json", "r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"],
+             "bf16": ["r04_hbm_traffic_pmc_bf16.json", "r03_hbm_traffic_pmc_bf16.json", "r02_hbm_traffic_pmc_bf16.json"],
              "f32s": ["r03_hbm_traffic_pmc_f32s.json", "r02_hbm_traffic_pmc_f32s.json"]}[dtype]
     kernel = {"f32": "conv_mfma_f32_kernel", "bf16": "conv_bf16_kernel", "f32s": "conv_f32s_kernel"}[dtype]
     for name in cands:
@@ -466,6 +466,68 @@ def train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_not
         dist.destroy_process_group()
 
 
+def train_rcnn_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note):
+    """Stage 2 of the reference's alternating schedule (train_rcnn.py:35-78; models/faster_rcnn.py:110-173 with rcnn_train = True): trunk -> RPN
+    proposals (no gradient) -> RoI pooling with arg-max -> fc6 / fc7 + dropout -> cls_score / bbox_pred -> ProposalTargetLayer -> losses ->
+    backward through the head, RoI pooling and the trunk -> all-reduce -> MomentumSGD + WeightDecay over trunk + head (548 MB of parameters).
+    One synthetic VOC-shaped image per GPU per step; per-stage HIP events through the trainer's stage hook."""
+    from chainer_faster_rcnn_amd.train import RCNNTrainer, TorchComm
+    model.rpn_train, model.rcnn_train = False, True
+    conv_math = "split" if args.dtype == "f32s" else "mfma"
+    tr = RCNNTrainer(model, comm=TorchComm(force_single_rank=args.dist_world1) if dist is not None else None, conv_math=conv_math)
+    rs = np.random.RandomState(rank)
+    G = 4
+    w, h = rs.uniform(32, 400, G), rs.uniform(32, 400, G)
+    x1, y1 = rs.uniform(0, IM_W - 1 - w), rs.uniform(0, IM_H - 1 - h)
+    gt = np.stack([x1, y1, x1 + w, y1 + h, rs.randint(1, 21, G)], axis=1).astype(np.float32)[None]
+    info = np.array([[IM_H, IM_W]], dtype=np.int32)
+    np.random.seed(rank)
+    ev = []
+
+    def hook(name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        ev[-1].append((name, e))
+
+    for _ in range(max(2, args.warmup)):                              # a fixed count (collectives inside): see train_mode
+        out = tr.step(x, info, gt)
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ev.append([])
+        tr.stage_hook = hook
+        out = tr.forward_backward(x, info, gt)
+        tr.stage_hook = None
+        tr.all_reduce()
+        hook("all_reduce")
+        tr.update()
+        hook("update")
+    barrier()
+    dt = time.perf_counter() - t0
+    dt, per_rank = gather_rank_times(torch, dist, dt, world)
+    if rank == 0:
+        names = [n for n, _ in ev[0]]
+        st = {names[i]: float(np.mean([s[i - 1][1].elapsed_time(s[i][1]) for s in ev])) for i in range(1, len(names))}
+        emit_json_line({"metric": "images/sec Fast R-CNN (stage 2) training step VGG16 600x1000", "value": world * args.steps / dt, "unit": "img/s",
+                        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32s" if conv_math == "split" else "f32", "data": "synthetic",
+                        "config": {"workload": "train_rcnn.py stage-2 training step (trunk + RoI head; RPN proposals without gradient), 1 image per GPU, "
+                                               "all-reduce of the flat fp32 gradient buffer in 3 buckets (SURVEY 8f-2; not a BASELINE.json config)",
+                                   "conv_math": conv_math, "grad_buffer_mb": tr.n_flat * 4 / 1e6, "global_batch": world, "n_rois_last_step": int(out["n_rois"]),
+                                   "ranks_share_gpus": shared_note,
+                                   "host_in_step": "dropout masks (2 x n_rois x 4096 floats from NumPy's global RNG, as chainer's CPU path draws them) and "
+                                                   "ProposalTargetLayer's subsample are host work inside the timed step, with one device->host read of the RoI count"},
+                        "per_rank": per_rank_block(per_rank, args.steps),
+                        "dist": {"backend": (dist.get_backend() if dist is not None else None), "world_size": world},
+                        "cpu_baseline": None if world == 1 else "not run: ranks > 1",
+                        "stages_ms": {k: round(v, 4) for k, v in st.items()}, "sum_of_stages_ms": round(sum(st.values()), 4),
+                        "losses": tr.losses_host(out)})
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -488,8 +550,8 @@ def main():
                     help="f32 = BASELINE.json configs[1] (the contract line); bf16 = configs[2]: bf16 convolutions, fp32 RoI / head")
     ap.add_argument("--dist-world1", action="store_true",
                     help="with one rank: still create the process group (nccl = RCCL) and run every collective of the N > 1 path through it")
-    ap.add_argument("--mode", choices=["infer", "train"], default="infer",
-                    help="infer = BASELINE.json configs[1] (the contract line); train = configs[4], the RPN training step")
+    ap.add_argument("--mode", choices=["infer", "train", "train-rcnn"], default="infer",
+                    help="infer = BASELINE.json configs[1] (the contract line); train = configs[4], the RPN training step; train-rcnn = the stage-2 step of train_rcnn.py (SURVEY 8f-2)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = DEFAULT_STEPS if args.mode == "infer" else 40
@@ -552,6 +614,8 @@ def main():
 
     if args.mode == "train":
         return train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note)
+    if args.mode == "train-rcnn":
+        return train_rcnn_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note)
 
     use_graph = args.graph in ("on", "auto")
     # Untimed preamble before the W warm-up steps: the first forwards of a process run at idle clocks (DVFS needs a few hundred
@@ -673,7 +737,10 @@ def main():
                                       ("VGG16 inference, data-parallel 1 img/GPU, bf16 convs + bf16 FC head (fp32 accumulate) / fp32 proposals, "
                                        "RoI pooling, decode (BASELINE.json configs[2])"),
                           "image": "1x3x600x1000", "global_batch": world, "launch": "hipGraph replay" if use_graph else "eager", "parallelism": "dp%d (images sharded, no collective)" % world,
-                          "n_rois_last_step": n_rois, "ranks_share_gpus": shared_note},
+                          "n_rois_last_step": n_rois, "ranks_share_gpus": shared_note,
+                          "timed_region": ("K replays of ONE captured hipGraph of the whole forward (image -> cls_prob / boxes) on ONE image already resident in HBM: "
+                                           "no H2D inside the region, the same pixels every step") if use_graph else
+                                          "K eager forwards on one image already resident in HBM (no H2D inside the region, the same pixels every step)"},
                "ramp_seconds": args.ramp_seconds,
                "per_rank": per_rank_block(per_rank, args.steps)}
         if world > 1:
@@ -750,6 +817,18 @@ def main():
             except Exception as e:
                 res["f32_split_products"] = {"error": repr(e)}
                 torch.cuda.synchronize()
+        # the secondary figures INSIDE `roofline` (the driver's stored record keeps `roofline` verbatim and only the names of the other blocks)
+        if "roofline" in res:
+            nr, b3, sp = res.get("nms_roi") or {}, res.get("bf16_config3") or {}, res.get("f32_split_products") or {}
+            sec = {"roi_pool_us": nr.get("roi_pool_us"), "roi_pool_frac_of_hbm_peak": nr.get("roi_pool_frac_of_hbm_peak"),
+                   "roi_pool_us_in_pipeline": nr.get("roi_pool_us_in_pipeline_stage_event"),
+                   "roi_pool_fwd_argmax_us": nr.get("roi_pool_fwd_argmax_us"), "roi_pool_fwd_argmax_frac_of_hbm_peak": nr.get("roi_pool_fwd_argmax_frac_of_hbm_peak"),
+                   "roi_pool_bwd_us": nr.get("roi_pool_bwd_us"), "roi_pool_bwd_frac_of_hbm_peak": nr.get("roi_pool_bwd_frac_of_hbm_peak"),
+                   "proposals_nms_us": nr.get("proposals_nms_us"),
+                   "bf16_img_s": b3.get("value"), "bf16_ms_per_step": b3.get("ms_per_step"), "bf16_conv_ms_per_image": b3.get("conv_ms_per_image"),
+                   "bf16_conv_frac_of_bf16_mfma_peak": b3.get("frac_of_bf16_mfma_peak"),
+                   "f32s_img_s": sp.get("value"), "f32s_ms_per_step": sp.get("ms_per_step")}
+            res["roofline"]["secondary"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in sec.items() if v is not None}
         emit_json_line(res)
     if dist is not None:
         dist.barrier()

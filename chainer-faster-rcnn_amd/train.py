@@ -557,23 +557,28 @@ class RCNNTrainer(_BucketedAllReduce):
     def forward_backward(self, x, img_info, gt_boxes, masks=None):
         """Fills self.G; returns dict(losses (3,) device [loss_cls, loss_bbox, cls_accuracy], n_rois, keep_inds)."""
         rt, model = self.rt, self.model
+        stage = getattr(self, "stage_hook", None) or (lambda name: None)      # bench.py --mode train-rcnn: a HIP event per stage boundary
         self._drain()                                              # a previous backward whose sums were never consumed
         self._ensure_adopted()
         x = rt.asarray(unwrap(x), "f32")
         im_h, im_w = model.RPN.proposal_layer._img_hw(img_info)
+        stage("start")
         if self.conv_math == "split":
             big = [(n, l) for n, l in self.convs if int(l.cin) > 3]
             if big:
                 rt.f32s_pack_many([(l.Wp, self.ws_fwd[n], self.ws_dgrad[n], l.cin, l.cout) for n, l in big])
             feat, inputs, _ = trunk_forward_split(self, x)
         else:
-            feat, inputs = trunk_forward(model, x)
+            feat, inputs = trunk_forward(model, x, fuse_pools=getattr(self, "keep_dy", None) is None)
         C, H, W = [int(v) for v in feat.shape[1:]]
+        stage("trunk_fwd")
         _, _, prob, bbox = model.RPN.heads(feat, want_score=False)
         rois, _, n_out = model.RPN.proposal_layer.forward_device(prob, bbox, im_h, im_w)      # RPN.train is False in rcnn_train mode
         n = int(rt.mem.to_numpy(n_out)[0])
         rois = rois[:n]
+        stage("rpn_proposals")
         pool5, argmax = rt.roi_pool_fwd_chw(feat, rois, 7, 7, model._spatial_scale, want_argmax=True)
+        stage("roi_pool_fwd")
         pool5 = pool5.reshape(n, -1)
         scale = 1.0 / (1.0 - self.dropout_ratio)
         a6 = model.fc6(pool5, relu=True)
@@ -588,21 +593,27 @@ class RCNNTrainer(_BucketedAllReduce):
         m7 = rt.asarray(m7, "f32")
         d7 = rt.mul(a7, m7)
         cls_score, bbox_pred = model.cls_score(d7), model.bbox_pred(d7)
+        stage("head_fwd")
         use_gt, ext, keep = self.ptl(rois, gt_boxes)
         labels = rt.mem.from_numpy(rt.mem.to_numpy(use_gt)[:, -1].astype(np.int32))        # faster_rcnn.py:153
         losses, dcs, dbp = rt.rcnn_loss(rt.gather_rows(cls_score, keep), rt.gather_rows(bbox_pred, keep), labels, ext, model._rcnn_delta)
+        stage("targets_loss")
         # ---- backward: head
         dcls, dbb = rt.scatter_rows(dcs, keep, n), rt.scatter_rows(dbp, keep, n)
         g7 = rt.add(self._linear_backward("cls_score", d7, dcls), self._linear_backward("bbox_pred", d7, dbb))
         g7 = rt.relu_bwd_(rt.mul(g7, m7, out=g7), a7)
         g6 = self._linear_backward("fc7", d6, g7)
         g6 = rt.relu_bwd_(rt.mul(g6, m6, out=g6), a6)
+        stage("head_bwd_small")
         gp = self._linear_backward("fc6", pool5, g6)
+        stage("fc6_bwd")
         for n_ in reversed(self.HEAD):                             # every head gradient is enqueued: a bucket closed by a head layer starts now
             self._grads_ready(n_)
         # ---- RoI pooling (arg-max scatter) and the trunk; feat = relu(conv5_3): mask before entering conv5_3's backward
         gfeat = rt.relu_bwd_(rt.roi_pool_bwd(gp.reshape(n, C, 7, 7), argmax, C, H, W), feat)
+        stage("roi_pool_bwd")
         (trunk_backward_split if self.conv_math == "split" else trunk_backward)(self, list(zip(self.layers, inputs)), gfeat)
+        stage("trunk_bwd")
         return dict(losses=losses, n_rois=n, keep_inds=keep)
 
     def update(self):

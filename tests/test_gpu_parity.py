@@ -382,7 +382,9 @@ def test_conv_bf16_staging_variants_bit_identical(rt, monkeypatch, cin, cout, h,
                 monkeypatch.setenv("FRCNN_BF16_DMA", m2)
                 pre[m2] = rt.mem.to_numpy(rt.conv_bf16(x, wt, b, cin, cout, 3, relu=False, out_f32_nchw=True))[0]
             P.check_ksplit_words("staging[%d-%d-%d-%d] full" % (cin, cout, h, w), full, outs["0"][0], pre["-1"], pre["0"], cout)
-            P.check_ksplit_words("staging[%d-%d-%d-%d] pooled" % (cin, cout, h, w), pooled, outs["0"][1], pre["-1"], pre["0"], cout, pooled=True)
+            # the fused-pool launch of this size is NOT form C (odd tile rows): conv_dma_bf16_kernel's pick, the register-staged kernel's chain
+            assert rt.lib.frcnn_conv_bf16_plan(cin, cout, h, w, 3, 0) == 903 and rt.lib.frcnn_conv_bf16_plan(cin, cout, h, w, 3, 2) == 0
+            assert np.array_equal(pooled, outs["0"][1])
             continue
         assert np.array_equal(full, outs["0"][0]) and np.array_equal(pooled, outs["0"][1]), mode
 
