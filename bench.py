@@ -191,6 +191,13 @@ def cpu_baseline(params, x, samples):
     return res, dbg
 
 
+def launch_command(gpus, port, argv):
+    """The command `python bench.py --gpus N` turns itself into when no launcher is around it -- exactly the driver's form: one rank per GPU of ONE node,
+    rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(gpus)), "--master-addr", "127.0.0.1",
+            "--master-port", str(int(port)), os.path.abspath(__file__)] + list(argv)
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: become `torch.distributed.run --nproc-per-node N bench.py ...`."""
     import socket
@@ -201,9 +208,28 @@ def self_launch(args):
     s.close()
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    raise SystemExit(subprocess.call(cmd, env=env))
+    raise SystemExit(subprocess.call(launch_command(args.gpus, port, sys.argv[1:]), env=env))
+
+
+def rank_placement(environ, gpus, n_dev):
+    """(rank, local_rank, world, device index, backend, shared_note) of this process from the launcher's environment.  One rank per GPU: device =
+    LOCAL_RANK over RCCL.  Fewer GPUs than ranks (a 1-GPU box): the ranks share GPUs and talk over gloo -- RCCL refuses two ranks on one device --
+    which exercises the N > 1 code path (sharding, barriers, bucketed all-reduce) but is NOT a scaling measurement."""
+    world = int(environ.get("WORLD_SIZE", "1"))
+    rank = int(environ.get("RANK", "0"))
+    local_rank = int(environ.get("LOCAL_RANK", "0"))
+    if gpus > 1 and world != gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (gpus, world))
+    backend = environ.get("FRCNN_DIST_BACKEND", "nccl")
+    n_dev = max(int(n_dev), 1)
+    shared_note = None
+    if world > n_dev:
+        backend = "gloo"
+        shared_note = "%d ranks on %d GPU(s), gloo: functional smoke of the N>1 path, not a scaling number" % (world, n_dev)
+    device = local_rank if backend == "nccl" else local_rank % n_dev
+    if device >= n_dev:
+        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, n_dev))
+    return rank, local_rank, world, device, backend, shared_note
 
 
 def graph_time_us(torch, fn, launches_per_replay, replays):
@@ -560,22 +586,9 @@ def main():
     if args.gpus > 1 and "RANK" not in os.environ:
         self_launch(args)
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, _, world, local_rank, backend, shared_note = rank_placement(os.environ, args.gpus, torch.cuda.device_count())
     if rank != 0:
         os.dup2(2, 1)                                              # only rank 0 owns stdout (the launcher merges the ranks' streams)
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    # one rank per GPU.  Fewer GPUs than ranks (a 1-GPU box): the ranks share GPUs and talk over gloo -- RCCL refuses two ranks on one
-    # device -- which exercises the N>1 code path (sharding, barriers, bucketed all-reduce) but is NOT a scaling measurement.
-    backend = os.environ.get("FRCNN_DIST_BACKEND", "nccl")
-    n_dev = max(torch.cuda.device_count(), 1)
-    shared_note = None
-    if world > n_dev:
-        backend = "gloo"
-        shared_note = "%d ranks on %d GPU(s), gloo: functional smoke of the N>1 path, not a scaling number" % (world, n_dev)
-    if backend != "nccl":
-        local_rank %= n_dev
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.dist_world1:

@@ -118,10 +118,15 @@ class FrcnnError(RuntimeError):
     pass
 
 
+ERR_UNSUPPORTED = -2            # include/frcnn_hip.h: valid arguments, but this entry's kernel form declines the shape (the header names the detour)
+
+
 def check(status, what):
     if status != 0:
         if status == -1:
             raise ValueError("%s: invalid argument (FRCNN_ERR_INVALID)" % what)
+        if status == ERR_UNSUPPORTED:
+            raise ValueError("%s: shape not covered by this kernel form (FRCNN_ERR_UNSUPPORTED)" % what)
         raise FrcnnError("%s failed: hipError_t %d" % (what, -status - 1000))
 
 

@@ -794,7 +794,7 @@ constexpr int kQuadGeoSlots = 64 * kQuadProducers;                       // RoIs
 constexpr int kQuadTabExt = 64;
 // LDS layout (one block, carved by hand: ds_append addresses its counter through M0[15:0], so the counter must sit below 64 KB --
 // the compiler put a separate __shared__ int behind the images and the hardware wrapped the address into them)
-constexpr int kQuadOffCtr = 0;                                           // int: draw counter, NaN flag
+constexpr int kQuadOffCtr = 0;                                           // int: draw counter; bytes 8 .. 23: a NaN flag per wave
 constexpr int kQuadOffGeoM = 32;                                         // uint2 [slots]: column word, row word
 constexpr int kQuadOffGeoW = kQuadOffGeoM + kQuadGeoSlots * 8;           // uint32 [slots][8]
 constexpr int kQuadOffGeoH = kQuadOffGeoW + kQuadGeoSlots * 32;          // uint2 [slots][8]
@@ -1023,7 +1023,10 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
     // ---- prologue.  Waves 0 .. 12: map rows 3 w .. 3 w + 3 (the fourth is the halo of the tile image) of four channel planes through
     //      a buffer descriptor -- rows past H, columns past W, channels past C are out-of-range offsets that load 0.  Producers: their
     //      copy of the edge rows, then their first step.  One barrier.
-    if (tid == 0) { ctr[0] = 0; ctr[1] = 0; }
+    if (tid == 0) ctr[0] = 0;
+    // NaN flag of the map: one BYTE per wave (bytes 8 .. 23 of the counter block), each written by its own wave only and unconditionally -- no
+    // initialisation another wave could overwrite (tid 0's zero raced the map waves' ones before the barrier)
+    unsigned char *const nan_of_wave = lds + kQuadOffCtr + 8;
     float4 roi_q = make_float4(0.f, 0.f, 0.f, 0.f);
     if (pk >= 0) {
         const uint4 t0 = *reinterpret_cast<const uint4 *>(&etab.row[0][lane][0]), t1 = *reinterpret_cast<const uint4 *>(&etab.row[1][lane][0]);
@@ -1032,6 +1035,7 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
         my_tab[kQuadTabExt + lane] = t1;
         frcnn_wave_sync();         // (the rows are read by other lanes of this wave: DS operations of one wave are in order)
         if (!(dbg & 256)) build_geometry(0, roi_q, false);
+        if (lane == 0) nan_of_wave[wave] = 0;
     } else {
         const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)C * HW * sizeof(float)));
         float v[4][4];
@@ -1064,7 +1068,8 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
                                                           frcnn_max_f32(t10[i][2], t10[i + 1][2]), frcnn_max_f32(t10[i][3], t10[i + 1][3]));
             }
         }
-        if (__any(nan_sum != nan_sum) && lane == 0) ctr[1] = 1;
+        const bool wave_nan = __any(nan_sum != nan_sum);
+        if (lane == 0) nan_of_wave[wave] = wave_nan ? 1 : 0;
     }
     // lane -> bin by the hardware's ds_read_b128 lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32): group g holds the bin
     // rows 2 g and 2 g + 1, eight columns each
@@ -1087,7 +1092,7 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
     const uint2 *geo_m = reinterpret_cast<const uint2 *>(lds + kQuadOffGeoM);
     stamp();
     __syncthreads();
-    const bool nan_map = __builtin_amdgcn_readfirstlane(ctr[1]) != 0;
+    const bool nan_map = __any(ctr[2 + (lane & 3)] != 0);                  // the sixteen waves' bytes
     stamp();
     if (dbg & 2) return;
 
@@ -1488,7 +1493,7 @@ int frcnn_roi_pool_fwd_chw_f32s(const float *x, int C, int H, int W, const float
     if (outh < 1 || outw < 1 || outh > 7 || outw > 7 || (roi_cols != 4 && roi_cols != 5)) return FRCNN_ERR_INVALID;
     if (R == 0) return FRCNN_OK;
     if (roi_cells_launch<2>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, reinterpret_cast<float *>(y_parts), stream)) return frcnn_launch_status();
-    return FRCNN_ERR_INVALID;                        // cell-major kernel only (maps up to 76 x 64): pool in fp32 and frcnn_f32s_split otherwise
+    return FRCNN_ERR_UNSUPPORTED;                    // cell-major kernel only (maps up to 76 x 64): pool in fp32 and frcnn_f32s_split otherwise
 }
 
 int frcnn_roi_pool_fwd_chw_bf16(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
@@ -1499,7 +1504,7 @@ int frcnn_roi_pool_fwd_chw_bf16(const float *x, int C, int H, int W, const float
     if (R == 0) return FRCNN_OK;
     if (roi_cells_launch<1>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, reinterpret_cast<float *>(y), stream)) return frcnn_launch_status();
     const int cg = roi_planes_per_group(C, H, W, outh, outw);
-    if (cg == 0) return FRCNN_ERR_INVALID;          // plane-resident kernel only: convert an fp32 result with frcnn_f32_to_bf16 instead
+    if (cg == 0) return FRCNN_ERR_UNSUPPORTED;      // plane-resident kernel only: convert an fp32 result with frcnn_f32_to_bf16 instead
     const int cgroups = frcnn_cdiv(C, cg);
     int rgroups = frcnn_cdiv(frcnn_roi_cu_count(), cgroups);
     const int max_rgroups = frcnn_cdiv(R, kPlaneWaves);
@@ -1523,7 +1528,7 @@ int frcnn_roi_pool_fwd_blk_bf16(const uint16_t *x_blk, int C, int H, int W, cons
     const float *x = reinterpret_cast<const float *>(x_blk);
     const bool ok = out_bf16 ? roi_cells_launch<1, true>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, reinterpret_cast<float *>(y), stream)
                              : roi_cells_launch<0, true>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, reinterpret_cast<float *>(y), stream);
-    return ok ? frcnn_launch_status() : FRCNN_ERR_INVALID;       // cell-major kernel only (maps up to 76 x 64): frcnn_bf16_to_nchw_f32 + frcnn_roi_pool_fwd_chw otherwise
+    return ok ? frcnn_launch_status() : FRCNN_ERR_UNSUPPORTED;   // cell-major kernel only (maps up to 76 x 64): frcnn_bf16_to_nchw_f32 + frcnn_roi_pool_fwd_chw otherwise
 }
 
 int frcnn_roi_pool_fwd(const float *x, int C, int H, int W, const float *rois, int R, int outh, int outw, float spatial_scale,

@@ -137,10 +137,23 @@ class FasterRCNN(object):
             # EVERY trainer that has updated this model holds live packed weights for its own parameter set (after an rpn -> rcnn
             # alternation the RPNTrainer still owns rpn_conv_3x3 and the RPN heads, the RCNNTrainer the trunk and the FC head):
             # remember them all, most recent last, so that later syncs win where two trainers share the trunk
-            trs = [t for t in getattr(self, "_trainers", []) if t is not trainer]
+            # A NEW trainer of a class that is already registered supersedes the old one (a script that builds a trainer per stage or
+            # epoch kept every one's W / G / V arenas alive, ~1.6 GB each for VGG-16, and re-synced them all on every snapshot): it has adopted
+            # every parameter of that set into its own arena (_ParamArena._adopt copies the links' current windows), so the old trainer's packed
+            # weights are stale copies from then on.  Not a weak reference: a trainer the caller dropped WITHOUT a successor still holds the only
+            # packed weights its links point into until they are synced -- detach_trainer() is the explicit way out.
+            trs = [t for t in getattr(self, "_trainers", []) if t is not trainer and type(t) is not type(trainer)]
             trs.append(trainer)
             self._trainers = trs
             self._last_trainer = trainer
+
+    def detach_trainer(self, trainer):
+        """Write `trainer`'s packed weights back to the links' Chainer-layout arrays and forget it (its arenas are freed with it)."""
+        trainer.sync_params()
+        self._trainers = [t for t in getattr(self, "_trainers", []) if t is not trainer]
+        if getattr(self, "_last_trainer", None) is trainer:
+            self._last_trainer = self._trainers[-1] if self._trainers else None
+        self._head_dirty = self._derived_dirty = True
 
     def sync_trainers(self):
         """Packed training weights of every trainer that has updated the model -> (co,ci,3,3) / (out,in) arrays on the links,

@@ -261,7 +261,7 @@ class Runtime(object):
         y = m.empty((R, int(C) * outh * outw), "i16") if out_bf16 else m.empty((R, int(C), outh, outw), "f32")
         rc = L.frcnn_roi_pool_fwd_blk_bf16(m.ptr(x_blk), int(C), H, W, m.ptr(rois), R, int(rois.shape[1]), outh, outw, float(scale),
                                            m.ptr(y), int(bool(out_bf16)), m.stream())
-        if rc == -1 and 1 <= outh <= 7 and 1 <= outw <= 7 and R > 0:
+        if rc == _lib.ERR_UNSUPPORTED:
             # the cell-major kernel declined (a map beyond its LDS image, or FRCNN_ROI_KERNEL=planes): the documented detour of
             # include/frcnn_hip.h -- the map as fp32 NCHW, the fp32 pooling (which has its own fallbacks), one rounding-free conversion
             # back (a maximum of bf16 values is a bf16 value) -- same device kernels, same results, no CPU path
@@ -277,7 +277,7 @@ class Runtime(object):
         R = int(rois.shape[0])
         y = m.empty((3, R, C * outh * outw), "i16")
         rc = L.frcnn_roi_pool_fwd_chw_f32s(m.ptr(x), C, H, W, m.ptr(rois), R, int(rois.shape[1]), outh, outw, float(scale), m.ptr(y), m.stream())
-        if rc == -1 and 1 <= outh <= 7 and 1 <= outw <= 7 and R > 0:
+        if rc == _lib.ERR_UNSUPPORTED:
             # the cell-major kernel declined (see roi_pool_fwd_blk_bf16): pool in fp32, then split -- the same three terms (the split is exact)
             return self.f32s_split(self.roi_pool_fwd_chw(x, rois, outh, outw, scale).reshape(R, -1))
         _lib.check(rc, "frcnn_roi_pool_fwd_chw_f32s")

@@ -545,6 +545,20 @@ class RCNNTrainer(_BucketedAllReduce):
         rt.bias_grad(dyT.reshape(1, N, 1, Mp), out=self.grad[name + "/b"])          # db = column sums of dy
         if not need_dx:
             return None
+        if N % 64 == 0 and K % 64 == 0 and M <= 4096 and os.environ.get("FRCNN_LINEAR_DX", "conv") == "conv":
+            # dx = dy W with W (N, K) READ AS STORED: a 1x1 convolution whose "image" is W itself -- N channels of K "pixels" -- and whose
+            # packed weights (Cin, Cout) are dy^T padded to 64 output channels: y[m][k] = sum_n dy[m][n] W[n][k].  No transposed copy of W
+            # (fc6: 411 MB read + written every step), and W is streamed exactly once.
+            Mc = (M + 63) // 64 * 64
+            wh = 1
+            for c in (256, 224, 128, 64):                          # a map shape for the kernel's 2-D tiles; any factorisation of K is the same sum
+                if K % c == 0:
+                    wh = c
+                    break
+            dyc = rt.mem.zeros((Mc, N), "f32")
+            dyc[:M] = dy
+            dx = rt.conv_ex(lin.W.reshape(1, N, K // wh, wh), rt.transpose(dyc), self.zero_bias[:Mc], ksize=1, act=0)
+            return dx.reshape(Mc, K)[:M]
         Np = (N + 3) // 4 * 4                                        # dx = dy W contracts over N: pad it to a multiple of 4 as well
         if Np != N:
             dyn, wn = rt.mem.zeros((M, Np), "f32"), rt.mem.zeros((Np, K), "f32")

@@ -31,6 +31,9 @@ extern "C" {
 
 #define FRCNN_OK 0
 #define FRCNN_ERR_INVALID (-1)
+/* the arguments are valid but THIS entry's kernel form does not cover the shape (documented per entry, with the detour to take): -2.
+ * Distinct from FRCNN_ERR_INVALID so that a caller's detour can never hide a genuinely bad argument. */
+#define FRCNN_ERR_UNSUPPORTED (-2)
 
 /* Library identification: returns the ABI version (bumped on any signature change). */
 int frcnn_abi_version(void);
@@ -112,13 +115,13 @@ int frcnn_roi_pool_fwd_chw_f32s(const float *x, int C, int H, int W, const float
                                 float spatial_scale, uint16_t *y_parts, void *stream);
 /* the same with the pooled values written as raw bf16 (one rounding of the fp32 maximum): the input of the bf16 FC head
  * (BASELINE config 3) without the fp32 pool5 round trip.  LDS-resident kernels only (the cell-major kernel for maps up to 76 x 64,
- * else the plane kernel while a plane fits in LDS); FRCNN_ERR_INVALID beyond that: pool in fp32 and convert with frcnn_f32_to_bf16. */
+ * else the plane kernel while a plane fits in LDS); FRCNN_ERR_UNSUPPORTED beyond that: pool in fp32 and convert with frcnn_f32_to_bf16. */
 int frcnn_roi_pool_fwd_chw_bf16(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh,
                                 int outw, float spatial_scale, uint16_t *y, void *stream);
 /* the same pooling straight from the bf16 chain's channel-blocked map x_blk = [CP/16][H][W][16] bf16 (CP = C rounded up to 16): a
  * cell's eight channels are one 16-byte load and no fp32 NCHW copy of conv5_3 has to exist.  y = (R, C, outh, outw) fp32, or raw
  * bf16 bits when out_bf16 (values are bf16 to begin with: exact).  Cell-major kernel only (maps up to 76 x 64), else
- * FRCNN_ERR_INVALID: frcnn_bf16_to_nchw_f32 + frcnn_roi_pool_fwd_chw then. */
+ * FRCNN_ERR_UNSUPPORTED: frcnn_bf16_to_nchw_f32 + frcnn_roi_pool_fwd_chw then. */
 int frcnn_roi_pool_fwd_blk_bf16(const uint16_t *x_blk, int C, int H, int W, const float *rois, int R, int roi_cols, int outh,
                                 int outw, float spatial_scale, void *y, int out_bf16, void *stream);
 int frcnn_roi_pool_fwd(const float *x, int C, int H, int W, const float *rois, int R, int outh, int outw,

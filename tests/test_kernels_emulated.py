@@ -67,7 +67,7 @@ def test_roi_pool_cells_kernel(rt):
 
 
 def test_roi_pool_output_forms_when_the_cell_kernel_declines(rt):
-    """frcnn_roi_pool_fwd_chw_f32s / _blk_bf16 exist on the cell-major kernel only and return FRCNN_ERR_INVALID when it declines (a map beyond its
+    """frcnn_roi_pool_fwd_chw_f32s / _blk_bf16 exist on the cell-major kernel only and return FRCNN_ERR_UNSUPPORTED when it declines (a map beyond its
     76 x 64 LDS image); the runtime wrappers then take the header's documented detour -- fp32 pooling + an exact conversion -- instead of
     raising (callers guarded on the map size only by convention).  Same bits either way."""
     calls, orig = [], rt.roi_pool_fwd_chw

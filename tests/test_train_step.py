@@ -110,6 +110,76 @@ def test_data_parallel_step_gloo_world2():
     assert res[0][2] == res[1][2]
 
 
+def _dp4_worker(rank, world, port, q):
+    import hashlib
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, os.path.join(HERE, "hipemu")); sys.path.insert(0, HERE)
+        from emu_runtime import emu_runtime
+        from chainer_faster_rcnn_amd.chainer_compat import Variable
+        from chainer_faster_rcnn_amd.train import RPNTrainer, TorchComm
+        import parity_cases as P
+        rt = emu_runtime()
+        params = T.small_params()
+        info = np.array([[40, 56]], dtype=np.int32)
+
+        def sample(i):
+            rs = np.random.RandomState(100 + i)
+            gt = P.gt_case(rs, 2, 40, 56)
+            gt[0, :, 2] = np.minimum(gt[0, :, 0] + 20, 55); gt[0, :, 3] = np.minimum(gt[0, :, 1] + 20, 39)
+            return rs.randn(1, 3, 40, 56).astype(np.float32), gt
+        comm = TorchComm()
+        launched = []
+        orig = comm.all_reduce_sum_async
+        comm.all_reduce_sum_async = lambda buf: (launched.append(int(buf.shape[0])), orig(buf))[1]
+        tr = RPNTrainer(T.build_small(rt, params), comm=comm)
+        x, gt = sample(rank)
+        np.random.seed(5 + rank)
+        for _ in range(2):                                         # two steps: the second reuses the bucket plan and the works list starts empty again
+            tr.step(Variable(x), Variable(info), Variable(gt))
+        w_dp = rt.mem.to_numpy(tr.W)
+        # float64 reference of the same two steps over the four images (the ring's fp32 summation order is gloo's, not ours: compare within rounding)
+        ref = RPNTrainer(T.build_small(rt, params))
+        for _ in range(2):
+            gsum = None
+            for r in range(world):
+                xr, gr = sample(r)
+                np.random.seed(5 + r)
+                ref.forward_backward(Variable(xr), Variable(info), Variable(gr))
+                g = rt.mem.to_numpy(ref.G).astype(np.float64)
+                gsum = g if gsum is None else gsum + g
+            ref.G[...] = gsum.astype(np.float32)
+            ref.update()
+        w_ref = rt.mem.to_numpy(ref.W)
+        err = float(np.abs(w_dp - w_ref).max() / max(np.abs(w_ref).max(), 1e-12))
+        sizes = [int(e - s0) for _, s0, e in tr.buckets]
+        q.put((rank, hashlib.sha1(w_dp.tobytes()).hexdigest(), err, launched == sizes * 2, len(tr.buckets), [b[0] for b in tr.buckets]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_step_gloo_world4():
+    """Four ranks (rank > 2 ordering, bucket keying): every rank launches the SAME three buckets in the same (backward) order
+    in both steps -- a collective is matched by call order, so a rank-dependent order would deadlock or mix buckets --, the weights stay bit-identical
+    on all four ranks after two steps, and equal the float64-summed single-process update within fp32 rounding of the ring's summation order."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_dp4_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert len({h for _, h, _, _, _, _ in res}) == 1, res           # bit-identical weights everywhere
+    assert all(err < 1e-6 for _, _, err, _, _, _ in res), res
+    assert all(ok for _, _, _, ok, _, _ in res), res                # bucket launch order = plan order, on every rank, in both steps
+    assert all(n == 3 for _, _, _, _, n, _ in res) and len({tuple(names) for *_, names in res}) == 1, res
+
+
 def test_snapshot_roundtrip_after_training(rt, tmp_path):
     """save_npz / load_npz in chainer's link-path key scheme (forward.py:29): after one training step the packed weights are
     synced back, written, and a fresh model loaded from the file reproduces the trained model's RPN outputs bit for bit."""
@@ -274,6 +344,35 @@ def test_two_trainers_on_one_model_keep_training_it(rt):
     # inference sees the trained weights: the link's arrays ARE the windows
     seg = t1.seg["conv2_1/W"]
     assert np.array_equal(live.ravel(), rt.mem.to_numpy(t1.W)[seg.offset:seg.offset + seg.size])
+
+
+def test_a_new_trainer_supersedes_the_old_one_of_its_class(rt):
+    """A trainer per stage / epoch must not pile up arenas on the model: a second RPNTrainer replaces the first in the model's registry (it adopted
+    every parameter of the set, starting from the first one's trained values), an RCNNTrainer registers next to it, detach_trainer() syncs and forgets."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.train import RCNNTrainer, RPNTrainer
+    model, _ = _small_full_model(rt)
+    x, gt, info = _step_inputs()
+    model.rpn_train = True
+    t1 = RPNTrainer(model)
+    np.random.seed(0)
+    t1.step(Variable(x), Variable(info), Variable(gt))
+    trained = rt.mem.to_numpy(model.trunk.links["conv2_1"].Wp).copy()
+    t1b = RPNTrainer(model)                                           # e.g. the next epoch's trainer
+    assert np.array_equal(rt.mem.to_numpy(model.trunk.links["conv2_1"].Wp), trained)          # adopted the trained values, not the initial ones
+    np.random.seed(1)
+    t1b.step(Variable(x), Variable(info), Variable(gt))
+    assert model._trainers == [t1b]
+    model.rcnn_train = True
+    t2 = RCNNTrainer(model)
+    np.random.seed(2)
+    t2.step(Variable(x), Variable(info), Variable(gt))
+    assert model._trainers == [t1b, t2] and model._last_trainer is t2
+    live = rt.mem.to_numpy(model.trunk.links["conv2_1"].Wp).copy()
+    model.detach_trainer(t2)
+    assert model._trainers == [t1b] and model._last_trainer is t1b
+    link = model.trunk.links["conv2_1"]
+    assert np.array_equal(rt.mem.to_numpy(link.W).reshape(link.cout, -1), live.T)             # synced to Chainer's layout on the way out
 
 
 def test_load_npz_writes_through_adopted_links(rt, tmp_path):
