@@ -497,16 +497,18 @@ def train_rcnn_mode(args, torch, dist, rt, model, x, rank, world, barrier, share
     proposals (no gradient) -> RoI pooling with arg-max -> fc6 / fc7 + dropout -> cls_score / bbox_pred -> ProposalTargetLayer -> losses ->
     backward through the head, RoI pooling and the trunk -> all-reduce -> MomentumSGD + WeightDecay over trunk + head (548 MB of parameters).
     One synthetic VOC-shaped image per GPU per step; per-stage HIP events through the trainer's stage hook."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
     from chainer_faster_rcnn_amd.train import RCNNTrainer, TorchComm
     model.rpn_train, model.rcnn_train = False, True
     conv_math = "split" if args.dtype == "f32s" else "mfma"
-    tr = RCNNTrainer(model, comm=TorchComm(force_single_rank=args.dist_world1) if dist is not None else None, conv_math=conv_math)
+    tr = RCNNTrainer(model, comm=TorchComm(force_single_rank=args.dist_world1) if dist is not None else None, conv_math=conv_math,
+                     dropout_rng=args.dropout_rng, dropout_seed=rank)
     rs = np.random.RandomState(rank)
     G = 4
     w, h = rs.uniform(32, 400, G), rs.uniform(32, 400, G)
     x1, y1 = rs.uniform(0, IM_W - 1 - w), rs.uniform(0, IM_H - 1 - h)
     gt = np.stack([x1, y1, x1 + w, y1 + h, rs.randint(1, 21, G)], axis=1).astype(np.float32)[None]
-    info = np.array([[IM_H, IM_W]], dtype=np.int32)
+    gt, info = Variable(gt), Variable(np.array([[IM_H, IM_W]], dtype=np.int32))       # ProposalTargetLayer keeps the reference's type checks
     np.random.seed(rank)
     ev = []
 
@@ -542,8 +544,10 @@ def train_rcnn_mode(args, torch, dist, rt, model, x, rank, world, barrier, share
                                                "all-reduce of the flat fp32 gradient buffer in 3 buckets (SURVEY 8f-2; not a BASELINE.json config)",
                                    "conv_math": conv_math, "grad_buffer_mb": tr.n_flat * 4 / 1e6, "global_batch": world, "n_rois_last_step": int(out["n_rois"]),
                                    "ranks_share_gpus": shared_note,
-                                   "host_in_step": "dropout masks (2 x n_rois x 4096 floats from NumPy's global RNG, as chainer's CPU path draws them) and "
-                                                   "ProposalTargetLayer's subsample are host work inside the timed step, with one device->host read of the RoI count"},
+                                   "dropout_rng": args.dropout_rng,
+                                   "host_in_step": ("dropout masks (2 x n_rois x 4096 floats from NumPy's global RNG, as chainer's CPU path draws them: ~7 ms) and "
+                                                    if args.dropout_rng == "numpy" else "dropout masks drawn by the dropout kernel (counter-based hash; no host work); ") +
+                                                   "ProposalTargetLayer's subsample is host work inside the timed step, with one device->host read of the RoI count"},
                         "per_rank": per_rank_block(per_rank, args.steps),
                         "dist": {"backend": (dist.get_backend() if dist is not None else None), "world_size": world},
                         "cpu_baseline": None if world == 1 else "not run: ranks > 1",
@@ -576,6 +580,8 @@ def main():
                     help="f32 = BASELINE.json configs[1] (the contract line); bf16 = configs[2]: bf16 convolutions, fp32 RoI / head")
     ap.add_argument("--dist-world1", action="store_true",
                     help="with one rank: still create the process group (nccl = RCCL) and run every collective of the N > 1 path through it")
+    ap.add_argument("--dropout-rng", choices=["device", "numpy"], default="device",
+                    help="--mode train-rcnn: where F.dropout's masks are drawn (numpy = the reference CPU path's random stream, on the host)")
     ap.add_argument("--mode", choices=["infer", "train", "train-rcnn"], default="infer",
                     help="infer = BASELINE.json configs[1] (the contract line); train = configs[4], the RPN training step; train-rcnn = the stage-2 step of train_rcnn.py (SURVEY 8f-2)")
     args = ap.parse_args()

@@ -97,6 +97,7 @@ SIGNATURES = {
     "frcnn_rcnn_loss": (_I, [_P, _P, _P, _P, _I, _I, _F, _P, _P, _P, _P]),
     "frcnn_mul_f32": (_I, [_P, _P, _S, _P, _P]),
     "frcnn_add_f32": (_I, [_P, _P, _S, _P, _P]),
+    "frcnn_dropout_f32": (_I, [_P, _S, _F, ctypes.c_ulonglong, _P, _P, _P]),
     "frcnn_relu_bwd_f32": (_I, [_P, _P, _S, _P]),
     "frcnn_gather_rows_f32": (_I, [_P, _P, _I, _I, _P, _P]),
     "frcnn_scatter_rows_f32": (_I, [_P, _P, _I, _I, _P, _I, _P]),

@@ -1047,6 +1047,24 @@ mul_kernel(const float *__restrict__ a, const float *__restrict__ b, size_t n, f
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = a[i] * b[i];
 }
 
+// F.dropout with the mask drawn ON THE DEVICE: element i keeps its value (scaled by 1 / (1 - ratio)) iff u(seed, i) >= ratio, u = the top 24 bits of a
+// splitmix64 finaliser over (seed, i) -- a counter-based generator: stateless, order-free, reproducible for a given seed.  Writes the mask as well
+// (0 or 1 / (1 - ratio)): the backward pass multiplies by it.  The reference's CPU path draws numpy.random.rand (chainer F.dropout); its GPU path
+// draws from cupy's generator, so no bit-level claim exists there -- the NumPy-stream form stays the default of RCNNTrainer for the parity tests.
+__global__ void __launch_bounds__(256)
+dropout_kernel(const float *__restrict__ x, size_t n, float ratio, unsigned long long seed, float scale, float *__restrict__ mask, float *__restrict__ y) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned long long z = seed + 0x9e3779b97f4a7c15ull * (unsigned long long)(i + 1);
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        z ^= z >> 31;
+        const float u = (float)(unsigned)(z >> 40) * (1.0f / 16777216.0f);          // [0, 1), 24 bits: exact in fp32
+        const float m = u >= ratio ? scale : 0.0f;
+        mask[i] = m;
+        y[i] = x[i] * m;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 add_kernel(const float *__restrict__ a, const float *__restrict__ b, size_t n, float *__restrict__ y) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = a[i] + b[i];
@@ -1205,6 +1223,13 @@ int frcnn_mul_f32(const float *a, const float *b, size_t n, float *y, void *stre
     if (n == 0) return FRCNN_OK;
     if (!a || !b || !y) return FRCNN_ERR_INVALID;
     hipLaunchKernelGGL(mul_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, n, y);
+    return frcnn_launch_status();
+}
+
+int frcnn_dropout_f32(const float *x, size_t n, float ratio, unsigned long long seed, float *mask, float *y, void *stream) {
+    if (n == 0) return FRCNN_OK;
+    if (!x || !mask || !y || !(ratio >= 0.0f) || !(ratio < 1.0f)) return FRCNN_ERR_INVALID;
+    hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, n, ratio, seed, 1.0f / (1.0f - ratio), mask, y);
     return frcnn_launch_status();
 }
 

@@ -732,6 +732,15 @@ class Runtime(object):
         _lib.check(L.frcnn_mul_f32(m.ptr(a), m.ptr(b), int(np.prod(a.shape)), m.ptr(y), m.stream()), "frcnn_mul_f32")
         return y
 
+    def dropout(self, x, ratio, seed):
+        """F.dropout with a device-drawn mask -> (y, mask); mask holds 0 or 1/(1-ratio) (the backward pass multiplies by it)."""
+        m, L = self.mem, self.lib
+        shape = tuple(int(v) for v in x.shape)
+        y, mask = m.empty(shape, "f32"), m.empty(shape, "f32")
+        _lib.check(L.frcnn_dropout_f32(m.ptr(x), int(np.prod(shape)), float(ratio), int(seed) & (2 ** 64 - 1), m.ptr(mask), m.ptr(y), m.stream()),
+                   "frcnn_dropout_f32")
+        return y, mask
+
     def add(self, a, b, out=None):
         m, L = self.mem, self.lib
         y = out if out is not None else m.empty(tuple(int(v) for v in a.shape), "f32")

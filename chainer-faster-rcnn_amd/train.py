@@ -479,14 +479,20 @@ class RCNNTrainer(_BucketedAllReduce):
 
     HEAD = ("fc6", "fc7", "cls_score", "bbox_pred")
 
-    def __init__(self, model, lr=0.001, momentum=0.9, weight_decay=0.0005, dropout_ratio=0.5, comm=None, conv_math="mfma"):
-        """conv_math: as in RPNTrainer -- "mfma" = the trunk's forward / input-gradient / weight-gradient convolutions on the fp32 MFMA
+    def __init__(self, model, lr=0.001, momentum=0.9, weight_decay=0.0005, dropout_ratio=0.5, comm=None, conv_math="mfma", dropout_rng="numpy",
+                 dropout_seed=0):
+        """dropout_rng: "numpy" (default) draws both masks on the host from NumPy's global stream exactly as chainer's CPU F.dropout does (two
+        np.random.rand calls of n_rois x 4096 values per step: ~7 ms of host time at 300 RoIs, bench.py --mode train-rcnn); "device" draws them
+        in the dropout kernel from a counter-based hash of (dropout_seed, step, layer) -- the throughput form, no host work, no H2D.
+        conv_math: as in RPNTrainer -- "mfma" = the trunk's forward / input-gradient / weight-gradient convolutions on the fp32 MFMA
         kernels, "split" = the same fp32 convolutions as six bf16 MFMA products of 3-way split operands (csrc/conv_f32s.hip)."""
         from .models.proposal_target_layer import ProposalTargetLayer
         assert conv_math in ("mfma", "split")
         self.conv_math = conv_math
         self.model, self.rt = model, model.rt
         self.lr, self.momentum, self.weight_decay, self.dropout_ratio, self.comm = lr, momentum, weight_decay, dropout_ratio, comm
+        assert dropout_rng in ("numpy", "device")
+        self.dropout_rng, self.dropout_seed = dropout_rng, int(dropout_seed)
         rt = self.rt
         self.ptl = ProposalTargetLayer(model._feat_stride, num_classes=model._num_classes, runtime=rt)
         self.layers = model.trunk.layers
@@ -596,16 +602,23 @@ class RCNNTrainer(_BucketedAllReduce):
         pool5 = pool5.reshape(n, -1)
         scale = 1.0 / (1.0 - self.dropout_ratio)
         a6 = model.fc6(pool5, relu=True)
-        if masks is None:                                            # F.dropout [chainer-ext]: mask = (rand >= ratio) * 1/(1-ratio)
-            m6 = ((np.random.rand(*a6.shape) >= self.dropout_ratio) * scale).astype(np.float32)
+        on_device = masks is None and self.dropout_rng == "device"
+        if on_device:                                                # one launch: mask drawn, stored and applied
+            d6, m6 = rt.dropout(a6, self.dropout_ratio, self.dropout_seed * 0x100000001b3 + 2 * self.iteration)
         else:
-            m6 = masks[0]
-        m6 = rt.asarray(m6, "f32")
-        d6 = rt.mul(a6, m6)
+            if masks is None:                                        # F.dropout [chainer-ext]: mask = (rand >= ratio) * 1/(1-ratio)
+                m6 = ((np.random.rand(*a6.shape) >= self.dropout_ratio) * scale).astype(np.float32)
+            else:
+                m6 = masks[0]
+            m6 = rt.asarray(m6, "f32")
+            d6 = rt.mul(a6, m6)
         a7 = model.fc7(d6, relu=True)
-        m7 = ((np.random.rand(*a7.shape) >= self.dropout_ratio) * scale).astype(np.float32) if masks is None else masks[1]
-        m7 = rt.asarray(m7, "f32")
-        d7 = rt.mul(a7, m7)
+        if on_device:
+            d7, m7 = rt.dropout(a7, self.dropout_ratio, self.dropout_seed * 0x100000001b3 + 2 * self.iteration + 1)
+        else:
+            m7 = ((np.random.rand(*a7.shape) >= self.dropout_ratio) * scale).astype(np.float32) if masks is None else masks[1]
+            m7 = rt.asarray(m7, "f32")
+            d7 = rt.mul(a7, m7)
         cls_score, bbox_pred = model.cls_score(d7), model.bbox_pred(d7)
         stage("head_fwd")
         use_gt, ext, keep = self.ptl(rois, gt_boxes)
@@ -628,7 +641,7 @@ class RCNNTrainer(_BucketedAllReduce):
         stage("roi_pool_bwd")
         (trunk_backward_split if self.conv_math == "split" else trunk_backward)(self, list(zip(self.layers, inputs)), gfeat)
         stage("trunk_bwd")
-        return dict(losses=losses, n_rois=n, keep_inds=keep)
+        return dict(losses=losses, n_rois=n, keep_inds=keep, masks=(m6, m7))
 
     def update(self):
         self._ensure_adopted()

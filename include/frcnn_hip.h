@@ -375,6 +375,10 @@ int frcnn_rcnn_loss(const float *cls_score, const float *bbox_pred, const int32_
                     int ncls, float delta, float *losses, float *d_cls_score, float *d_bbox_pred, void *stream);
 int frcnn_mul_f32(const float *a, const float *b, size_t n, float *y, void *stream);
 int frcnn_add_f32(const float *a, const float *b, size_t n, float *y, void *stream);      /* y = a + b (y may alias a or b) */
+/* F.dropout (models/faster_rcnn.py:128,131, train = True) with the mask drawn on the device: y[i] = x[i] * mask[i], mask[i] = 1/(1-ratio) iff
+ * u(seed, i) >= ratio else 0, u = 24 bits of a splitmix64 hash of (seed, i) -- stateless and reproducible per seed.  The trainer's default keeps
+ * the reference CPU path's numpy.random stream (host masks + frcnn_mul_f32); this entry is the throughput form (ABI v20). */
+int frcnn_dropout_f32(const float *x, size_t n, float ratio, unsigned long long seed, float *mask, float *y, void *stream);
 int frcnn_relu_bwd_f32(float *g, const float *out, size_t n, void *stream);
 int frcnn_gather_rows_f32(const float *src, const int32_t *idx, int n, int cols, float *dst, void *stream);
 int frcnn_scatter_rows_f32(const float *src, const int32_t *idx, int n, int cols, float *dst, int dst_rows, void *stream);

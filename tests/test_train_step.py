@@ -238,6 +238,38 @@ def test_rcnn_train_step_small_split_products(rt):
     T.check_small_rcnn_step(rt, conv_math="split")
 
 
+def test_device_dropout_kernel_and_step(rt):
+    """frcnn_dropout_f32: mask values are exactly 0 or 1/(1-ratio), y = x * mask, the keep rate is 1 - ratio, the draw is a pure function of
+    (seed, index) -- and a stage-2 step that draws its masks on the device equals, bit for bit, the step that is handed those masks."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.train import RCNNTrainer
+    rs = np.random.RandomState(0)
+    x = rs.randn(300, 4096).astype(np.float32)
+    y, m = rt.dropout(rt.mem.from_numpy(x), 0.5, 1234)
+    y, m = rt.mem.to_numpy(y), rt.mem.to_numpy(m)
+    assert set(np.unique(m)) == {0.0, 2.0} and np.array_equal(y, x * m)
+    assert abs((m > 0).mean() - 0.5) < 0.004                                                  # 1.2 M draws: sigma = 4.5e-4
+    assert abs((m.reshape(300, 4096) > 0).mean(axis=0) - 0.5).max() < 0.15 and abs((m[:, ::2] > 0).mean() - (m[:, 1::2] > 0).mean()) < 0.004
+    y2, m2 = rt.dropout(rt.mem.from_numpy(x), 0.5, 1234)
+    assert np.array_equal(rt.mem.to_numpy(m2), m)
+    _, m3 = rt.dropout(rt.mem.from_numpy(x), 0.5, 1235)
+    assert abs((rt.mem.to_numpy(m3) == m).mean() - 0.5) < 0.004                               # another seed: independent
+    _, m4 = rt.dropout(rt.mem.from_numpy(x), 0.25, 7)
+    m4 = rt.mem.to_numpy(m4)
+    assert set(np.unique(m4)) == {0.0, np.float32(1.0 / 0.75)} and abs((m4 > 0).mean() - 0.75) < 0.004
+    xg, gt, info = _step_inputs()
+    grads = []
+    for rng in ("device", "given"):
+        model, _ = _small_full_model(rt)
+        model.rcnn_train = True
+        tr = RCNNTrainer(model, dropout_rng="device" if rng == "device" else "numpy", dropout_seed=3)
+        np.random.seed(11)                                                                    # ProposalTargetLayer's subsample
+        out = tr.forward_backward(Variable(xg), Variable(info), Variable(gt), masks=None if rng == "device" else masks)
+        masks = tuple(rt.mem.to_numpy(v) for v in out["masks"])
+        grads.append(rt.mem.to_numpy(tr.G).copy())
+    assert np.array_equal(grads[0], grads[1]) and np.abs(grads[0]).max() > 0
+
+
 def test_gradient_buckets_tile_the_flat_buffer(rt):
     """Data-parallel buckets: contiguous tail ranges of the flat gradient buffer in backward order, together covering it exactly
     once, each closed by a layer whose gradients are the last of the bucket to be produced."""
