@@ -256,7 +256,13 @@ def f32s_conv_chain(rt, model, x, bf16=False):
     def chain():
         tr_ = model.trunk
         h, n_l = None, len(tr_.layers)
+        pair = bf16 and tr_.conv1_pair_applies()
         for idx, l in enumerate(tr_.layers):
+            if pair and idx < 3:                                  # conv1_1 + conv1_2 + pool1 as one launch (csrc/conv_bf16_pair.hip): 13 launches then
+                if idx == 0:
+                    l1, l2 = tr_.links[tr_.layers[0][0]], tr_.links[tr_.layers[1][0]]
+                    h = rt.conv1_pair_bf16(x, l1.W, l1.b, l2.Wb, l2.b)
+                continue
             if l == "pool":
                 continue
             link = tr_.links[l[0]]

@@ -82,6 +82,7 @@ SIGNATURES = {
     "frcnn_conv_bf16_workspace_init": (_I, [_P, _S, _P]),
     "frcnn_conv_bf16_ws": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_maxpool2x2_bf16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "frcnn_conv1_pair_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "frcnn_f32_to_bf16": (_I, [_P, _S, _P, _P]),
     "frcnn_linear_bf16_workspace_bytes": (_S, [_I, _I, _I]),
     "frcnn_linear_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),

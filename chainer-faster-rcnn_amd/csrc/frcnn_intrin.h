@@ -76,6 +76,11 @@ __device__ __forceinline__ void frcnn_split3_pair(float v0, float v1, uint32_t &
 }
 
 
+// DPP quad_perm [1,0,3,2]: every lane receives the value of lane ^ 1 -- one VALU instruction (a __shfl_xor may go through the LDS crossbar)
+__device__ __forceinline__ float frcnn_lane_xor1_f32(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
+}
+
 // ds_append: ONE wave-level LDS operation that adds the number of active lanes to a counter and hands every lane the old value.  The
 // hardware addresses the counter through M0[15:0]: it must sit in the first 64 KB of the workgroup's LDS.
 __device__ __forceinline__ int frcnn_lds_append(int *ctr) {

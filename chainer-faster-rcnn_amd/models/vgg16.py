@@ -116,12 +116,32 @@ class VGG16Prev(object):
         return h
 
 
+    def conv1_pair_applies(self):
+        """conv1_1 (<= 3 -> 64), conv1_2 (64 -> 64), pool -- VGG-16's first three entries -- run as one launch on the bf16 chain
+        (FRCNN_BF16_CONV1_PAIR=0: the two-launch form, for A/B measurements)."""
+        import os
+        L = self.layers
+        return (self.conv_dtype == "bf16" and self.fuse_pool and os.environ.get("FRCNN_BF16_CONV1_PAIR", "1") != "0" and len(L) >= 3 and L[0] != "pool"
+                and L[1] != "pool" and L[2] == "pool" and L[0][1] <= 3 and L[0][2] == 64 and L[1][1] == 64 and L[1][2] == 64
+                and not getattr(self, "generic_first_layer", False))
+
     def _call_bf16(self, x, timer, collect=None):
         """bf16 chain: fp32 NCHW image -> channel-blocked bf16 -> 13 bf16 convs / 4 pools -> conv5_3 back as fp32 NCHW."""
         rt = self.rt
         h = None                             # converted lazily: a first layer with <= 3 input channels reads the fp32 NCHW image itself
         n_pool, cout, skip = 0, int(x.shape[1]), False
+        pair = self.conv1_pair_applies() and collect is None            # (a per-layer collection wants conv1_1's map: the two-launch form then)
         for idx, l in enumerate(self.layers):
+            if pair and idx < 3:
+                # conv1_1 + ReLU + conv1_2 + ReLU + pool1 as ONE launch (csrc/conv_bf16_pair.hip): the 64-channel map between them stays in LDS
+                if idx == 0:
+                    l1, l2 = self.links[self.layers[0][0]], self.links[self.layers[1][0]]
+                    h = rt.conv1_pair_bf16(x, l1.W, l1.b, l2.Wb, l2.b)
+                    n_pool, cout = 1, int(self.layers[1][2])
+                    if timer:
+                        timer.mark(self.layers[0][0])                   # (the whole launch is booked on conv1_2: conv1_1 has no launch of its own)
+                        timer.mark(self.layers[1][0])
+                continue
             if l == "pool":
                 n_pool += 1
                 if skip:

@@ -552,6 +552,17 @@ class Runtime(object):
         _lib.check(L.frcnn_conv1_bf16(m.ptr(x), m.ptr(w), m.ptr(bias), m.ptr(y), cin, cout, H, W, int(bool(relu)), m.stream()), "frcnn_conv1_bf16")
         return y
 
+    def conv1_pair_bf16(self, x, w1, b1, w2_packed, b2):
+        """conv1_1 + ReLU + conv1_2 + ReLU + 2x2 max-pool of the bf16 chain in one launch: x (1,Cin<=3,H,W) fp32 NCHW, w1 (64,Cin,3,3) fp32,
+        w2_packed [4][9][64][16] bf16 -> [4][ceil(H/2)][ceil(W/2)][16] bf16."""
+        m, L = self.mem, self.lib
+        cin, H, W = [int(v) for v in x.shape[-3:]]
+        assert int(w1.shape[0]) == 64 and int(w1.shape[1]) == cin and tuple(int(v) for v in w2_packed.shape) == (4, 9, 64, 16)
+        y = m.empty((4, (H + 1) // 2, (W + 1) // 2, 16), "i16")
+        _lib.check(L.frcnn_conv1_pair_bf16(m.ptr(x), m.ptr(w1), m.ptr(b1), m.ptr(w2_packed), m.ptr(b2), m.ptr(y), cin, H, W, m.stream()),
+                   "frcnn_conv1_pair_bf16")
+        return y
+
     def conv3x3_f32s(self, x, w_packed, bias, cin, cout, relu=True, out_f32_nchw=False, pool=False):
         """x split tensor [3][CinP/16][H][W][16] -> split tensor (optionally ReLU + 2x2 max-pooled), or (1,Cout,H,W) fp32."""
         m, L = self.mem, self.lib

@@ -316,6 +316,13 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
  * four ways over the waves of a workgroup and sums the partial accumulators in K-way order (deterministic, fp32 rounding differs).  No launch. */
 int frcnn_conv_bf16_plan(int Cin, int Cout, int H, int W, int ksize, int out_mode);
 int frcnn_maxpool2x2_bf16(const uint16_t *x, uint16_t *y, int C, int H, int W, void *stream);
+/* The first two layers of the bf16 chain as ONE launch (ABI v21): conv1_1 (Cin <= 3 -> 64, 3x3, pad 1) + ReLU + conv1_2 (64 -> 64) + ReLU +
+ * F.max_pooling_2d(2, stride 2) -- /root/reference/models/vgg16.py:38-44 (conv1_1, conv1_2, pool1 of VGG16Prev / VGG16).  The 64-channel map
+ * between the two convolutions lives in LDS only.  x (Cin, H, W) fp32 NCHW; w1 (64, Cin, 3, 3) fp32 as Chainer stores it, b1 (64);
+ * w2_packed = frcnn_bf16_pack_conv_w of the (64, 64, 3, 3) weights, b2 (64); y [4][ceil(H/2)][ceil(W/2)][16] bf16 (channel-blocked).
+ * Bit-identical to frcnn_conv1_bf16 followed by frcnn_conv_bf16 with out_mode 2 (same operand rounding, same accumulation order). */
+int frcnn_conv1_pair_bf16(const float *x, const float *w1, const float *b1, const uint16_t *w2_packed, const float *b2,
+                          uint16_t *y, int Cin, int H, int W, void *stream);
 /* bf16 fully connected layer (config-3 head): y(M,N) = act(x(M,K) @ W(N,K)^T + b); x, W raw bf16 bits (frcnn_f32_to_bf16
  * converts fp32 arrays: weights once at load, activations per call), fp32 accumulation and bias; y fp32, or bf16 when
  * out_bf16 (feeding the next bf16 layer).  K % 8 == 0. */

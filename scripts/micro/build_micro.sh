@@ -6,6 +6,7 @@ mkdir -p scripts/micro/_bin
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 scripts/micro/store_micro.hip -o scripts/micro/_bin/store_micro
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip scripts/micro/roi_micro.cpp -I include -L chainer-faster-rcnn_amd -lfrcnn_hip -Wl,-rpath,'$ORIGIN/../../../chainer-faster-rcnn_amd' -o scripts/micro/_bin/roi_micro
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip scripts/micro/conv_bf16_micro.cpp -I include -L chainer-faster-rcnn_amd -lfrcnn_hip -Wl,-rpath,'$ORIGIN/../../../chainer-faster-rcnn_amd' -o scripts/micro/_bin/conv_bf16_micro
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip scripts/micro/conv_pair_micro.cpp -I include -L chainer-faster-rcnn_amd -lfrcnn_hip -Wl,-rpath,'$ORIGIN/../../../chainer-faster-rcnn_amd' -o scripts/micro/_bin/conv_pair_micro
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip scripts/micro/wgrad_micro.cpp -I include -L chainer-faster-rcnn_amd -lfrcnn_hip -Wl,-rpath,'$ORIGIN/../../../chainer-faster-rcnn_amd' -o scripts/micro/_bin/wgrad_micro
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip scripts/micro/conv_f32_micro.cpp -I include -L chainer-faster-rcnn_amd -lfrcnn_hip -Wl,-rpath,'$ORIGIN/../../../chainer-faster-rcnn_amd' -o scripts/micro/_bin/conv_f32_micro
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -Wno-inline-asm -Wno-unused-value scripts/micro/mfma_dma_micro.hip -o scripts/micro/_bin/mfma_dma_micro

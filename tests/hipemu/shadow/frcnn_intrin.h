@@ -64,3 +64,4 @@ __attribute__((noinline)) static float frcnn_wave_shl1_f32(float v) {
     if (s < 64 && ((e.present >> s) & 1)) memcpy(&r, e.vals[s], sizeof(r));
     return r;
 }
+static inline float frcnn_lane_xor1_f32(float v) { return __shfl_xor(v, 1); }

@@ -877,6 +877,43 @@ def check_conv_bf16_default_pick(rt, Cin, Cout, H, W, expect, expect_pooled, see
     print("PARITY conv_bf16 default pick %d/%d (%d->%d @ %dx%d) vs oracle: fp32 %.2e of scale, bf16 within one rounding" % (expect, expect_pooled, Cin, Cout, H, W, e32))
 
 
+def check_conv1_pair_bf16(rt, H, W, Cin=3, seed=0, rw=None):
+    """frcnn_conv1_pair_bf16 (conv1_1 + ReLU + conv1_2 + ReLU + 2x2 ceil-mode pool in one launch, csrc/conv_bf16_pair.hip): (1) bit for bit the
+    two-launch chain frcnn_conv1_bf16 -> frcnn_conv_bf16(out_mode 2) on the same operands; (2) against the ORACLE: conv1_1 of the bf16-rounded
+    image and weights (fp32 accumulation), rounded to bf16 once, conv1_2 of that with bf16-rounded weights, ReLU, ceil-mode pool, one rounding."""
+    rs = np.random.RandomState(seed)
+    x = (rs.randn(1, Cin, H, W) * 50.0).astype(np.float32)               # image-like magnitudes (mean-subtracted pixels)
+    w1 = (rs.randn(64, Cin, 3, 3) * np.sqrt(2.0 / (Cin * 9)) / 50.0).astype(np.float32)
+    b1 = (rs.randn(64) * 0.1).astype(np.float32)
+    w2 = (rs.randn(64, 64, 3, 3) * np.sqrt(2.0 / (64 * 9))).astype(np.float32)
+    b2 = (rs.randn(64) * 0.1).astype(np.float32)
+    xd, w1d, b1d, b2d = dev(rt, x), dev(rt, w1), dev(rt, b1), dev(rt, b2)
+    w2p = rt.bf16_pack_conv_w(dev(rt, w2), 3)
+    old = os.environ.get("FRCNN_BF16_PAIR_RW")
+    try:
+        if rw is not None:
+            os.environ["FRCNN_BF16_PAIR_RW"] = str(rw)
+        got = host(rt, rt.conv1_pair_bf16(xd, w1d, b1d, w2p, b2d))
+    finally:
+        os.environ.pop("FRCNN_BF16_PAIR_RW", None)
+        if old is not None:
+            os.environ["FRCNN_BF16_PAIR_RW"] = old
+    h1 = rt.conv1_bf16(xd, w1d, b1d, relu=True)
+    two = host(rt, rt.conv_bf16(h1, w2p, b2d, 64, 64, 3, relu=True, pool=True))
+    assert got.shape == two.shape == (4, (H + 1) // 2, (W + 1) // 2, 16)
+    assert np.array_equal(got, two), "%d of %d words differ from the two-launch chain" % (int((got != two).sum()), got.size)
+    xb, w1b, w2b = to_bf16(x)[0], to_bf16(w1)[0], to_bf16(w2)[0]
+    m1 = to_bf16(O.relu(O.conv2d(xb, w1b, b1, 1)))[0]
+    dev1 = from_bf16_bits(blocked_to_hwc(host(rt, h1))).transpose(2, 0, 1)[None]
+    s1 = max(np.abs(m1).max(), 1e-6)
+    assert np.all(np.abs(dev1 - m1) <= np.abs(m1) * 2.0 ** -7 + 2e-5 * s1)                      # conv1_1: one rounding of fp32-order noise
+    want = O.max_pool_2x2(O.relu(O.conv2d(dev1, w2b, b2, 1)))[0].transpose(1, 2, 0)               # conv1_2 of the DEVICE's conv1_1 map: fp32-order noise + one rounding
+    s2 = max(np.abs(want).max(), 1e-6)
+    g = from_bf16_bits(blocked_to_hwc(got))
+    assert np.all(np.abs(g - want) <= np.abs(want) * 2.0 ** -8 + 2e-5 * s2)
+    print("PARITY conv1 pair (%dx%d, Cin %d%s): == two-launch chain bit for bit; vs oracle within one rounding" % (H, W, Cin, "" if rw is None else ", RW %d" % rw))
+
+
 def check_conv_bf16_strip(rt, form, Cin, Cout, H, W, pool=False, seed=0):
     """Strip form `form` (FRCNN_BF16_DMA=901 / 902 / 903 / 907 / 908 / 909, csrc/conv_bf16_strip.h) of the 3x3 bf16 convolution against
     conv_dma_bf16_kernel on the same operands: bit-identical for the forms that keep one accumulation chain per output (A, B, D = 909,

@@ -15,7 +15,7 @@ def rt():
 
 
 def test_library_is_the_device_build(rt):
-    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 19
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 21
 
 
 def test_nms_golden(rt):
@@ -397,6 +397,13 @@ def test_conv_bf16_staging_variants_bit_identical(rt, monkeypatch, cin, cout, h,
 def test_conv_bf16_default_picks_vs_oracle(rt, cin, cout, h, w, expect, expect_pooled):
     """The strip forms at the VGG layer sizes where the default rule really launches them, against the oracle (not against another HIP kernel)."""
     P.check_conv_bf16_default_pick(rt, cin, cout, h, w, expect, expect_pooled)
+
+
+@pytest.mark.parametrize("h,w,cin,rw", [(600, 1000, 3, None), (600, 1000, 3, 4), (75, 101, 3, None), (24, 64, 1, 4)])
+def test_conv1_pair_bf16(rt, h, w, cin, rw):
+    """conv1_1 + conv1_2 + pool1 as one launch (csrc/conv_bf16_pair.hip; the bf16 chain's default first launch): bit for bit the two-launch chain, and
+    within one rounding of the oracle -- at the real 600 x 1000 image (1600 tiles on 256 persistent workgroups) and on ragged / odd sizes."""
+    P.check_conv1_pair_bf16(rt, h, w, Cin=cin, rw=rw)
 
 
 @pytest.mark.parametrize("form", [901, 902, 903, 909, 910])

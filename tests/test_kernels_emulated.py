@@ -484,3 +484,31 @@ def test_f32s_weight_packs(rt):
 def test_conv_wgrad_f32s(rt):
     P.check_conv_wgrad_f32s(rt, 64, 64, 5, 37)               # two x tiles, three row tiles (ragged), one (ci, co) tile
     P.check_conv_wgrad_f32s(rt, 3, 80, 4, 33, seed=1)         # conv1_1's 3 input channels; 80 couts: a ragged second co tile
+
+
+@pytest.mark.parametrize("h,w,cin,rw", [(24, 64, 3, 6), (13, 37, 3, 6), (30, 33, 1, 4), (17, 70, 3, 4)])
+def test_conv1_pair_bf16(rt, h, w, cin, rw):
+    """conv1_1 + conv1_2 + pool as one launch (csrc/conv_bf16_pair.hip): whole tiles, ragged rows / columns, odd sizes (ceil-mode windows with one row /
+    column), one input channel, both tile heights, several tiles per workgroup (the emulator seats few workgroups: the persistent loop wraps)."""
+    P.check_conv1_pair_bf16(rt, h, w, Cin=cin, rw=rw)
+
+
+def test_vgg16_bf16_trunk_with_the_conv1_pair_launch(rt, monkeypatch):
+    """The bf16 trunk's default first launch (conv1_1 + conv1_2 + pool1 fused, csrc/conv_bf16_pair.hip) leaves conv5_3 bit-identical to the
+    three-entry form it replaces, and a per-layer collection still sees conv1_1's own map."""
+    from chainer_faster_rcnn_amd import synthetic
+    from chainer_faster_rcnn_amd.models.vgg16 import VGG16
+    params = synthetic.params(seed=1)
+    x = rt.mem.from_numpy(synthetic.image(seed=2, h=40, w=72))
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("FRCNN_BF16_CONV1_PAIR", flag)
+        trunk = VGG16(runtime=rt, conv_dtype="bf16")
+        trunk.load_params(params)
+        assert trunk.conv1_pair_applies() == (flag == "1")
+        outs[flag] = rt.mem.to_numpy(trunk(x)).copy()
+    assert np.array_equal(outs["1"], outs["0"]) and np.abs(outs["1"]).max() > 0
+    monkeypatch.setenv("FRCNN_BF16_CONV1_PAIR", "1")
+    col = {}
+    trunk(x, collect=col)
+    assert "conv1_1" in col and "pool1" in col
