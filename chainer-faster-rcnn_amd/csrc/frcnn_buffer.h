@@ -19,6 +19,10 @@ __device__ __forceinline__ frcnn_buf_t frcnn_make_buf(const void *base, uint32_t
 __device__ __forceinline__ float frcnn_buf_load_f32(frcnn_buf_t b, uint32_t byte_off) {
     return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b, (int)byte_off, 0, 0));
 }
+// 4-byte load at (per-lane offset, range-checked) + (wave-uniform scalar offset, added after the check): the scalar rides in the instruction
+__device__ __forceinline__ float frcnn_buf_load_f32_soff(frcnn_buf_t b, uint32_t byte_off, uint32_t soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b, (int)byte_off, (int)soff, 0));
+}
 __device__ __forceinline__ float4 frcnn_buf_load_f32x4(frcnn_buf_t b, uint32_t byte_off) {
     const frcnn_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)byte_off, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));

@@ -81,6 +81,13 @@ __device__ __forceinline__ float frcnn_lane_xor1_f32(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
 }
 
+// max(v, value of lane ^ 1) as ONE instruction: v_max_f32 with the DPP modifier on its first source (quad_perm [1,0,3,2])
+__device__ __forceinline__ float frcnn_max_lane_xor1_f32(float v) {
+    float r;
+    asm("v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
+
 // ds_append: ONE wave-level LDS operation that adds the number of active lanes to a counter and hands every lane the old value.  The
 // hardware addresses the counter through M0[15:0]: it must sit in the first 64 KB of the workgroup's LDS.
 __device__ __forceinline__ int frcnn_lds_append(int *ctr) {

@@ -11,6 +11,11 @@ static inline float frcnn_buf_load_f32(frcnn_buf_t b, uint32_t off) {
     if ((uint64_t)off + 4 <= b.bytes) memcpy(&v, b.base + off, 4);
     return v;
 }
+static inline float frcnn_buf_load_f32_soff(frcnn_buf_t b, uint32_t off, uint32_t soff) {
+    float v = 0.0f;
+    if ((uint64_t)off + 4 <= b.bytes) memcpy(&v, b.base + off + soff, 4);
+    return v;
+}
 static inline float4 frcnn_buf_load_f32x4(frcnn_buf_t b, uint32_t off) {
     return make_float4(frcnn_buf_load_f32(b, off), frcnn_buf_load_f32(b, off + 4), frcnn_buf_load_f32(b, off + 8), frcnn_buf_load_f32(b, off + 12));
 }

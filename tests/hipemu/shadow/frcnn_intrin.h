@@ -65,3 +65,4 @@ __attribute__((noinline)) static float frcnn_wave_shl1_f32(float v) {
     return r;
 }
 static inline float frcnn_lane_xor1_f32(float v) { return __shfl_xor(v, 1); }
+static inline float frcnn_max_lane_xor1_f32(float v) { return frcnn_max_f32(v, __shfl_xor(v, 1)); }

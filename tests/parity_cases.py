@@ -877,7 +877,7 @@ def check_conv_bf16_default_pick(rt, Cin, Cout, H, W, expect, expect_pooled, see
     print("PARITY conv_bf16 default pick %d/%d (%d->%d @ %dx%d) vs oracle: fp32 %.2e of scale, bf16 within one rounding" % (expect, expect_pooled, Cin, Cout, H, W, e32))
 
 
-def check_conv1_pair_bf16(rt, H, W, Cin=3, seed=0, rw=None):
+def check_conv1_pair_bf16(rt, H, W, Cin=3, seed=0, rw=None, form=None):
     """frcnn_conv1_pair_bf16 (conv1_1 + ReLU + conv1_2 + ReLU + 2x2 ceil-mode pool in one launch, csrc/conv_bf16_pair.hip): (1) bit for bit the
     two-launch chain frcnn_conv1_bf16 -> frcnn_conv_bf16(out_mode 2) on the same operands; (2) against the ORACLE: conv1_1 of the bf16-rounded
     image and weights (fp32 accumulation), rounded to bf16 once, conv1_2 of that with bf16-rounded weights, ReLU, ceil-mode pool, one rounding."""
@@ -889,15 +889,20 @@ def check_conv1_pair_bf16(rt, H, W, Cin=3, seed=0, rw=None):
     b2 = (rs.randn(64) * 0.1).astype(np.float32)
     xd, w1d, b1d, b2d = dev(rt, x), dev(rt, w1), dev(rt, b1), dev(rt, b2)
     w2p = rt.bf16_pack_conv_w(dev(rt, w2), 3)
-    old = os.environ.get("FRCNN_BF16_PAIR_RW")
+    old = os.environ.get("FRCNN_BF16_PAIR_RW"), os.environ.get("FRCNN_BF16_PAIR_FORM")
     try:
-        if rw is not None:
-            os.environ["FRCNN_BF16_PAIR_RW"] = str(rw)
+        if rw is not None:                                              # form 1 (one wave per SIMD, weights in registers): rows per wave
+            os.environ["FRCNN_BF16_PAIR_RW"], os.environ["FRCNN_BF16_PAIR_FORM"] = str(rw), "1"
+        elif form is not None:
+            os.environ["FRCNN_BF16_PAIR_FORM"] = str(form)
         got = host(rt, rt.conv1_pair_bf16(xd, w1d, b1d, w2p, b2d))
     finally:
         os.environ.pop("FRCNN_BF16_PAIR_RW", None)
-        if old is not None:
-            os.environ["FRCNN_BF16_PAIR_RW"] = old
+        os.environ.pop("FRCNN_BF16_PAIR_FORM", None)
+        if old[0] is not None:
+            os.environ["FRCNN_BF16_PAIR_RW"] = old[0]
+        if old[1] is not None:
+            os.environ["FRCNN_BF16_PAIR_FORM"] = old[1]
     h1 = rt.conv1_bf16(xd, w1d, b1d, relu=True)
     two = host(rt, rt.conv_bf16(h1, w2p, b2d, 64, 64, 3, relu=True, pool=True))
     assert got.shape == two.shape == (4, (H + 1) // 2, (W + 1) // 2, 16)

@@ -399,7 +399,7 @@ def test_conv_bf16_default_picks_vs_oracle(rt, cin, cout, h, w, expect, expect_p
     P.check_conv_bf16_default_pick(rt, cin, cout, h, w, expect, expect_pooled)
 
 
-@pytest.mark.parametrize("h,w,cin,rw", [(600, 1000, 3, None), (600, 1000, 3, 4), (75, 101, 3, None), (24, 64, 1, 4)])
+@pytest.mark.parametrize("h,w,cin,rw", [(600, 1000, 3, None), (600, 1000, 3, 4), (600, 1000, 3, 6), (75, 101, 3, None), (24, 64, 1, None), (24, 64, 1, 4)])
 def test_conv1_pair_bf16(rt, h, w, cin, rw):
     """conv1_1 + conv1_2 + pool1 as one launch (csrc/conv_bf16_pair.hip; the bf16 chain's default first launch): bit for bit the two-launch chain, and
     within one rounding of the oracle -- at the real 600 x 1000 image (1600 tiles on 256 persistent workgroups) and on ragged / odd sizes."""

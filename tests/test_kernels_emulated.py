@@ -486,10 +486,12 @@ def test_conv_wgrad_f32s(rt):
     P.check_conv_wgrad_f32s(rt, 3, 80, 4, 33, seed=1)         # conv1_1's 3 input channels; 80 couts: a ragged second co tile
 
 
-@pytest.mark.parametrize("h,w,cin,rw", [(24, 64, 3, 6), (13, 37, 3, 6), (30, 33, 1, 4), (17, 70, 3, 4)])
+@pytest.mark.parametrize("h,w,cin,rw", [(24, 64, 3, None), (13, 37, 3, None), (30, 33, 1, None), (17, 70, 2, None), (41, 100, 3, None),
+                                        (24, 64, 3, 6), (13, 37, 3, 6), (30, 33, 1, 4), (17, 70, 3, 4)])
 def test_conv1_pair_bf16(rt, h, w, cin, rw):
     """conv1_1 + conv1_2 + pool as one launch (csrc/conv_bf16_pair.hip): whole tiles, ragged rows / columns, odd sizes (ceil-mode windows with one row /
-    column), one input channel, both tile heights, several tiles per workgroup (the emulator seats few workgroups: the persistent loop wraps)."""
+    column), one input channel, several tiles per workgroup (the emulator seats few workgroups: the persistent loop wraps) -- for the default
+    producer / consumer form (rw None) and for the one-wave-per-SIMD form at both tile heights."""
     P.check_conv1_pair_bf16(rt, h, w, Cin=cin, rw=rw)
 
 
