@@ -589,6 +589,7 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
     conv_bf16_epilogue<BROWS, 256, RW, COB>(acc, ring, bias, y, Cout, CoutP, H, W, relu, out_mode, x0, y0, co0);
 }
 
+#include "conv_bf16_res.h"        // conv_res_bf16_kernel: resident weight slab, producer / consumer waves (FRCNN_BF16_DMA=921 / 922; round 4)
 #include "conv_bf16_strip.h"      // conv_strip_bf16_kernel: one wave per SIMD, software-pipelined ring (forms D and C are default picks; FRCNN_BF16_DMA=900..909)
 
 // (Cout, Cin, k, k) fp32 -> [CinP/16][tap][CoutP][16] bf16, zero padded
@@ -807,6 +808,21 @@ static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed
 
 // The strip form the default rule picks for a 3x3 launch (0: none -- conv_dma_bf16_kernel's picks), environment hooks included; the
 // measurements behind it are quoted where frcnn_conv_bf16_ws applies it.
+// The resident forms (csrc/conv_bf16_res.h: weight slab in LDS, producer / consumer waves; Cin 64 -> 21 = form R, Cin 128 -> 22 = form R2) are NOT default
+// picks: measured on the MI355X (profiles/r04_conv_res_micro.txt, bit-identical to the other kernels) they lose to the strip forms / conv_dma_bf16_kernel
+// on all four layers they fit -- conv1_2 52.2 vs 48.5 us, conv2_1 31.1 vs 28.3, conv2_2 49.3 vs 41.7, conv3_1 31.0 vs 23.8 -- with any ring depth and
+// either wave priority: with ONE multiplying wave per SIMD nothing covers that wave's own stalls at a chunk boundary (barrier, first fragments of the
+// next chunk), which two symmetric workgroups per CU (strip form D) cover for each other.  FRCNN_BF16_RES=1 opts in (A/B), FRCNN_BF16_DMA=921 / 922 selects one.
+static int conv_bf16_default_res_form(int CinP, int CoutP, int H, int W, int out_mode) {
+    const char *re = getenv("FRCNN_BF16_RES");
+    if (!re || re[0] != '1' || getenv("FRCNN_BF16_RP") || getenv("FRCNN_BF16_DMA_DEFAULT") || getenv("FRCNN_BF16_SPLIT")) return 0;
+    if (out_mode != 0 && out_mode != 2) return 0;
+    const long cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
+    if (CinP == 64 && (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 8) * frcnn_cdiv(CoutP, 64) >= 2 * cus) return 21;
+    if (CinP == 128 && (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 16) * frcnn_cdiv(CoutP, 32) >= 2 * cus) return 22;
+    return 0;
+}
+
 static int conv_bf16_default_strip_form(int CinP, int CoutP, int H, int W, int out_mode) {
     const char *rp_env = getenv("FRCNN_BF16_RP");
     if (rp_env && atoi(rp_env) == 4) return 0;
@@ -909,8 +925,15 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
     // conv3_2 / conv4_2) stay selectable (901, 902).  FRCNN_BF16_STRIP=0 switches the rule off (A/B measurements); the tuning hooks that
     // select a kernel family (FRCNN_BF16_RP, FRCNN_BF16_DMA_DEFAULT, FRCNN_BF16_SPLIT) keep their meaning.
     if (ksize == 3 && mode < 0) {
+        const int rform = conv_bf16_default_res_form(CinP, CoutP, H, W, out_mode);
+        if (rform && conv_bf16_res(rform, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream) == 0) return frcnn_launch_status();
         const int form = conv_bf16_default_strip_form(CinP, CoutP, H, W, out_mode);
         if (form && conv_bf16_strip(form, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream) == 0) return frcnn_launch_status();
+    }
+    if (ksize == 3 && (mode == 921 || mode == 922)) {              // an explicitly requested resident form (its fp32-NCHW output: conv_dma_bf16_kernel's picks)
+        if (conv_bf16_res(mode - 900, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream) == 0) return frcnn_launch_status();
+        if (out_mode != 1) return FRCNN_ERR_INVALID;
+        mode = -1;
     }
     if (ksize == 3 && mode >= 9010 && mode <= 9039) {             // 90<form><ablation> (FRCNN_TIMING_ABLATIONS builds; else the plain form)
         const char *ae = getenv("FRCNN_BF16_STRIP_ABL");
@@ -1028,7 +1051,13 @@ int frcnn_conv_bf16_plan(int Cin, int Cout, int H, int W, int ksize, int out_mod
     const char *dma_env = getenv("FRCNN_BF16_DMA");
     const int mode = dma_env ? atoi(dma_env) : -1;
     // the same three branches as frcnn_conv_bf16_ws, through the same resolver: what is returned is the form that would be LAUNCHED
+    if (mode == 921 || mode == 922) {
+        const bool shape = (mode == 921 && CinP == 64) || (mode == 922 && CinP == 128);
+        return (shape && out_mode != 1) ? mode : ((shape || out_mode == 1) && out_mode == 1 ? 0 : FRCNN_ERR_INVALID);
+    }
     if (mode < 0) {
+        const int rform = conv_bf16_default_res_form(CinP, CoutP, H, W, out_mode);
+        if (rform) return 900 + rform;
         const int pick = conv_bf16_default_strip_form(CinP, CoutP, H, W, out_mode);
         const int form = pick ? conv_bf16_strip_resolve(pick, CinP, CoutP, H, W, out_mode) : 0;
         return form ? 900 + form : 0;

@@ -416,6 +416,13 @@ def test_conv_bf16_strip_forms(rt, form):
     P.check_conv_bf16_strip(rt, form, 128, 54, 75, 125, seed=2)      # ragged: 54 couts of 64, 75 rows = 7.5 tiles of 10
 
 
+@pytest.mark.parametrize("form,cin,cout,h,w,pool", [(921, 64, 128, 300, 500, False), (921, 64, 64, 150, 250, True), (922, 128, 128, 300, 500, True), (922, 128, 256, 150, 250, False)])
+def test_conv_bf16_resident_forms(rt, form, cin, cout, h, w, pool):
+    """csrc/conv_bf16_res.h (weight slab resident in LDS, producer / consumer waves; measured and not adopted, kept selectable): bit-identical to
+    conv_dma_bf16_kernel at the VGG layer sizes it fits."""
+    P.check_conv_bf16_strip(rt, form, cin, cout, h, w, pool=pool, seed=form)
+
+
 @pytest.mark.parametrize("split,mode", [("2", None), ("4", None), ("2", "224"), ("4", "223")])
 def test_conv_bf16_split_k(rt, monkeypatch, split, mode):
     monkeypatch.setenv("FRCNN_BF16_SPLIT", split)

@@ -514,3 +514,11 @@ def test_vgg16_bf16_trunk_with_the_conv1_pair_launch(rt, monkeypatch):
     col = {}
     trunk(x, collect=col)
     assert "conv1_1" in col and "pool1" in col
+
+
+@pytest.mark.parametrize("form,cin,cout,h,w,pool", [(921, 64, 64, 24, 64, True), (921, 64, 128, 19, 70, False), (921, 64, 128, 40, 100, False), (921, 64, 54, 9, 33, True),
+                                                    (922, 128, 128, 32, 64, True), (922, 128, 256, 35, 70, False), (922, 128, 80, 50, 100, False)])
+def test_conv_bf16_resident_forms(rt, form, cin, cout, h, w, pool):
+    """csrc/conv_bf16_res.h (weight slab resident in LDS, producer / consumer waves, the input ring running across the tiles of a persistent workgroup):
+    bit-identical to conv_dma_bf16_kernel -- whole and ragged tiles, ragged couts, several tiles and several cout tiles per workgroup, both outputs."""
+    P.check_conv_bf16_strip(rt, form, cin, cout, h, w, pool=pool, seed=form)
