@@ -74,7 +74,16 @@ class TorchDeviceMemory(object):
         current stream wait for it."""
         torch = self.torch
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            # the side stream carries work nobody waits for soon (the discarded train-mode ProposalLayer of an RPN step: 1.2 ms of NMS launches under a
+            # 7 ms backward pass): the LOWEST priority the device offers, so that its workgroups take what the main and gradient streams leave
+            # (FRCNN_SIDE_STREAM_PRIO overrides; priorities outside the device's range are clamped by the runtime)
+            import os
+            try:
+                lo = torch.cuda.Stream.priority_range()[0]
+            except Exception:
+                lo = 0
+            pr = int(os.environ.get("FRCNN_SIDE_STREAM_PRIO", lo))
+            self._side = torch.cuda.Stream(device=self.device, priority=pr)
         self._side.wait_stream(torch.cuda.current_stream(self.device))
         for a in arrays:
             a.record_stream(self._side)

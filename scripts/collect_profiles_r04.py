@@ -17,14 +17,14 @@ def last_json_line(path):
 def main(tag="r04z"):
     O, P = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
     for n in ("r04_bench", "r04_bench_bf16", "r04_bench_f32s", "r04_bench_train", "r04_bench_train_f32s", "r04_bench_nccl_w1_train",
-              "r04_bench_2rank_gloo_train", "r04_bench_2rank_gloo_infer"):
+              "r04_bench_2rank_gloo_train", "r04_bench_2rank_gloo_infer", "r04_bench_train_rcnn_device", "r04_bench_train_rcnn_numpy", "r04_bench_bf16_pair1", "r04_bench_bf16_pair0"):
         src = os.path.join(O, n + ".json")
         if os.path.exists(src):
             line = last_json_line(src)
             if line:
                 open(os.path.join(P, n + ".json"), "w").write(line)
     for n in ("r04_hbm_traffic_pmc.json", "r04_hbm_traffic_pmc_bf16.json", "r04_mfma_pmc_summary.json", "r04_roi_pmc.txt", "r04_store_micro.txt",
-              "r04_roi_micro.txt", "r04_conv_bf16_micro.txt", "r04_conv_f32_micro.txt", "r04_wgrad_micro.txt", "r04_mfma_filler_micro.txt", "r04_dma_align_micro.txt"):
+              "r04_roi_micro.txt", "r04_conv_bf16_micro.txt", "r04_conv_f32_micro.txt", "r04_wgrad_micro.txt", "r04_mfma_filler_micro.txt", "r04_dma_align_micro.txt", "r04_conv_pair_micro.txt", "r04_mfma_peak_micro.txt"):
         if os.path.exists(os.path.join(O, n)):
             shutil.copy(os.path.join(O, n), os.path.join(P, n))
     if os.path.exists(os.path.join(O, "parity_reports.txt")):
