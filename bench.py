@@ -357,7 +357,7 @@ def bf16_variant(args, torch, rt, params, x, dbg, flops_total):
         print("bf16 conv-chain graph failed (%s)" % (e,), file=sys.stderr)
         torch.cuda.synchronize()
     try:                                                     # which kernel family each 3x3 launch of the chain runs (launch-free query of the library)
-        names = {0: "conv_dma_bf16_kernel", 901: "strip A", 902: "strip B", 903: "strip C (K split over waves)", 909: "strip D", 910: "strip D"}
+        names = {0: "conv_dma_bf16_kernel", 901: "strip A", 902: "strip B", 903: "strip C (K split over waves)", 909: "strip D", 910: "strip D", 921: "resident R", 922: "resident R2"}
         picks, h, w = {}, IM_H, IM_W
         from chainer_faster_rcnn_amd.models.vgg16 import LAYERS as _layers
         for l in _layers:
@@ -366,6 +366,8 @@ def bf16_variant(args, torch, rt, params, x, dbg, flops_total):
             else:
                 picks[l[0]] = names.get(int(rt.lib.frcnn_conv_bf16_plan(int(l[1]), int(l[2]), h, w, 3, 0)), "?") if l[1] > 3 else "conv1_f32s_kernel (first layer)"
         picks["rpn_conv_3x3"] = names.get(int(rt.lib.frcnn_conv_bf16_plan(512, 512, h, w, 3, 0)), "?")
+        if model.trunk.conv1_pair_applies():                  # conv1_1 + conv1_2 + pool1 are ONE launch (csrc/conv_bf16_pair.hip): 13 conv launches per image
+            picks[_layers[0][0]] = picks[_layers[1][0]] = "conv1_pair_pc_bf16_kernel (conv1_1 + conv1_2 + pool1 in one launch)"
         out["conv_kernel_picks"] = picks
     except Exception as e:
         out["conv_kernel_picks"] = {"error": repr(e)}
@@ -786,7 +788,11 @@ def main():
             traffic, traffic_src = pmc_traffic(args.dtype)
             res["roofline"] = {"bound": "mfma", "achieved": conv_tf, "peak": peak, "unit": "TFLOP/s",
                                "frac": conv_tf / peak, "traffic": traffic, "traffic_source": traffic_src,
-                               "kernel": ("conv_f32s_kernel" if args.dtype == "f32s" else "conv_mfma_%s_kernel" % args.dtype) + " (14 launches/image: 13 VGG-16 convs + rpn_conv_3x3)",
+                               "kernel": ("conv_f32s_kernel (14 launches/image: 13 VGG-16 convs + rpn_conv_3x3)" if args.dtype == "f32s" else
+                                          "conv_mfma_f32_kernel (14 launches/image: 13 VGG-16 convs + rpn_conv_3x3)" if args.dtype == "f32" else
+                                          ("bf16 conv chain: conv1_pair_pc_bf16_kernel (conv1_1 + conv1_2 + pool1) + conv_dma_bf16_kernel / conv_strip_bf16_kernel, 13 launches/image"
+                                           if model.trunk.conv1_pair_applies() else
+                                           "bf16 conv chain: conv1_f32s_kernel + conv_dma_bf16_kernel / conv_strip_bf16_kernel, 14 launches/image")),
                                "algorithmic_tflops": alg_tf,
                                "algorithmic_gflop_per_image": sum(flops.values()) / 1e9, "conv_ms_per_image": conv_ms, "conv_ms_source": conv_src,
                                "algorithmic_bytes_per_launch": sum(conv_algorithmic_bytes(LAYERS, IM_H, IM_W, {"f32": 4, "f32s": 6, "bf16": 2}[args.dtype]).values()) / 14.0}

@@ -54,7 +54,7 @@ for f in glob.glob(O + "/mfma_bf16/**/*counter_collection.csv", recursive=True):
         if "conv_dma_bf16_kernel" in r["Kernel_Name"] or "conv_strip_bf16_kernel" in r["Kernel_Name"]:
             a = acc[r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
 out = {k: {"per_launch_mean": v / max(len(ids), 1), "launches": len(ids)} for k, (v, ids) in acc.items()}
-out["_note"] = "conv_dma_bf16_kernel on the conv3_2 shape (256 -> 256, 150 x 250) through scripts/micro/conv_bf16_micro; rocprofv3 --pmc, one pass"
+out["_note"] = "the default pick for the conv3_2 shape (256 -> 256, 150 x 250: conv_strip_bf16_kernel, form D with direct stores) through scripts/micro/conv_bf16_micro; rocprofv3 --pmc, one pass.  MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)"
 json.dump(out, open(O + "/r04_mfma_pmc_summary.json", "w"), indent=1, sort_keys=True)
 print({k: v["per_launch_mean"] for k, v in out.items() if k != "_note"})
 PY
