@@ -34,9 +34,6 @@ SIGNATURES = {
     "frcnn_roi_pool_fwd_chw_f32s": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _F, _P, _P]),
     "frcnn_roi_pool_fwd": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _F, _P, _P, _P, _S, _P]),
     "frcnn_roi_pool_bwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P]),
-    "frcnn_roi_pool_bwd_workspace_bytes": (_S, [_I, _I, _I]),
-    "frcnn_roi_pool_bwd_workspace_init": (_I, [_P, _S, _P]),
-    "frcnn_roi_pool_bwd_ws": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P, _P, _S, _P]),
     "frcnn_pack_conv3x3_w": (_I, [_P, _I, _I, _P, _P]),
     "frcnn_conv3x3_workspace_bytes": (_S, [_I, _I, _I, _I]),
     "frcnn_conv3x3_workspace_init": (_I, [_P, _S, _P]),

@@ -3,7 +3,7 @@
 
 extern "C" {
 
-int frcnn_abi_version(void) { return 22; }
+int frcnn_abi_version(void) { return 21; }
 
 int frcnn_device_count(void) {
     int n = 0;

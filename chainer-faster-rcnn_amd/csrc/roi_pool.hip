@@ -19,7 +19,6 @@
 // tests/test_oracle_pinned.py::test_roi_bin_edges_need_double_arithmetic).  Empty bins give 0 / argmax -1.
 #include "frcnn_common.h"
 #include <frcnn_intrin.h>   // angle brackets: shadowed by the test emulator
-#include <frcnn_sync.h>
 #include <frcnn_buffer.h>
 #include <math.h>
 #include <algorithm>
@@ -1230,7 +1229,7 @@ constexpr int kBwdWaves = 16;
 constexpr int kBwdMaxPlane = 38 * 64;      // floats per channel plane the LDS image holds (4 planes: 38.9 KB)
 __global__ void __launch_bounds__(64 * kBwdWaves)
 roi_pool_bwd_planes_kernel(const float *__restrict__ dy, const int32_t *__restrict__ argmax, int R, int C, int HW, int bins,
-                           float *__restrict__ dx, int dbg_arg, int *__restrict__ tickets, float *__restrict__ slab) {
+                           float *__restrict__ dx, int dbg_arg) {
 #ifdef FRCNN_TIMING_ABLATIONS                    // tuning builds only: 1 plain read-modify-write, 2 integer atomics, 4 no LDS update (WRONG results), 8 ds_add_f32
     const int dbg = dbg_arg;
 #else
@@ -1253,16 +1252,11 @@ roi_pool_bwd_planes_kernel(const float *__restrict__ dy, const int32_t *__restri
     const frcnn_buf_t abuf = frcnn_make_buf(argmax, (uint32_t)((size_t)R * C * bins * sizeof(float)));
     const uint32_t voff = lane < n4 ? (uint32_t)(lane * 16) : kBufOob;
     const uint32_t roi_bytes = (uint32_t)(C * bins) * 4u, c0_bytes = (uint32_t)(c0 * bins) * 4u;
-    // gridDim.y = 2 (round 4: with a workspace): the channel quad's RoIs are shared by TWO workgroups -- a launch of C / 4 = 128 workgroups left half
-    // the chip idle, and the kernel is bound by what ONE CU can load (13 B / clock: the 60 MB took 18 us on 128 CUs) -- each accumulating its half into
-    // its own LDS planes; the halves meet through a ticket (below).
-    const int half_r = gridDim.y > 1 ? ((R + 3) / 4) * 2 : R;                // RoIs of the first half (even: pairs)
-    const int r_begin = blockIdx.y ? half_r : 0, r_end = blockIdx.y ? R : min(half_r, R);
     // two RoIs per step: four 16-byte loads in flight per lane before the first atomic
 #pragma unroll 1
-    for (int r = r_begin + 2 * wave; r < r_end; r += 2 * kBwdWaves) {
+    for (int r = 2 * wave; r < R; r += 2 * kBwdWaves) {
         const uint32_t s0 = (uint32_t)r * roi_bytes + c0_bytes, s1 = s0 + roi_bytes;
-        const bool two = r + 1 < r_end;
+        const bool two = r + 1 < R;
         const float4 g0 = frcnn_buf_load_f32x4_soff(dbuf, voff, s0), a0 = frcnn_buf_load_f32x4_soff(abuf, voff, s0);
         const float4 g1 = frcnn_buf_load_f32x4_soff(dbuf, two ? voff : kBufOob, s1), a1 = frcnn_buf_load_f32x4_soff(abuf, two ? voff : kBufOob, s1);
         const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -1293,27 +1287,6 @@ roi_pool_bwd_planes_kernel(const float *__restrict__ dy, const int32_t *__restri
     __syncthreads();
     // (c0 .. c0 + 3, :, :) is one contiguous run of 4 HW floats of dx
     float *dst = dx + (size_t)c0 * HW;
-    if (gridDim.y > 1) {
-        // Two halves: each deposits its planes in its own place (half 0: dx itself, half 1: the workspace slab), publishes them (every wave drains its
-        // stores, one lane releases at agent scope) and draws a ticket; the SECOND arriver -- whichever half it is -- acquires, adds the other half's
-        // planes to its own LDS planes and writes dx.  a + b == b + a: the result does not depend on who arrives last.  No spin, no second launch; the
-        // ticket counter is left at zero for the next launch.
-        float *mine = blockIdx.y ? slab + (size_t)c0 * HW : dst;
-        const float *other = blockIdx.y ? dst : slab + (size_t)c0 * HW;
-        for (int i = tid; i < 4 * HW; i += 64 * kBwdWaves) mine[i] = planes[i];
-        frcnn_drain_vmem();
-        __syncthreads();
-        __shared__ int s_ticket;
-        if (tid == 0) {
-            frcnn_release_agent();
-            s_ticket = frcnn_ticket(&tickets[blockIdx.x]);
-            if (s_ticket == 1) { frcnn_acquire_agent(); frcnn_counter_reset(&tickets[blockIdx.x]); }
-        }
-        __syncthreads();
-        if (s_ticket != 1) return;
-        for (int i = tid; i < 4 * HW; i += 64 * kBwdWaves) dst[i] = planes[i] + other[i];
-        return;
-    }
     if ((HW & 3) == 0) {
         for (int i = tid; i < HW; i += 64 * kBwdWaves) reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(planes)[i];
     } else {
@@ -1563,26 +1536,8 @@ int frcnn_roi_pool_fwd(const float *x, int C, int H, int W, const float *rois, i
     return frcnn_roi_pool_fwd_chw(x, C, H, W, rois, R, 5, outh, outw, spatial_scale, y, argmax, workspace, workspace_bytes, stream);
 }
 
-// workspace of the two-half backward launch: a 64 KB page of ticket counters (zero them ONCE with frcnn_roi_pool_bwd_workspace_init; every launch leaves
-// them zeroed) + one (C, H, W) fp32 slab for the second half's planes
-constexpr size_t kRoiBwdCounterBytes = 64 * 1024;
-size_t frcnn_roi_pool_bwd_workspace_bytes(int C, int H, int W) {
-    if (C < 1 || H < 1 || W < 1) return 0;
-    return kRoiBwdCounterBytes + frcnn_align256((size_t)C * H * W * sizeof(float));
-}
-int frcnn_roi_pool_bwd_workspace_init(void *workspace, size_t workspace_bytes, void *stream) {
-    if (!workspace || workspace_bytes < kRoiBwdCounterBytes) return FRCNN_ERR_INVALID;
-    FRCNN_HIP_TRY(hipMemsetAsync(workspace, 0, kRoiBwdCounterBytes, (hipStream_t)stream));
-    return FRCNN_OK;
-}
-
 int frcnn_roi_pool_bwd(const float *dy, const int32_t *argmax, int R, int C, int H, int W, int outh, int outw, float *dx,
                        void *stream_) {
-    return frcnn_roi_pool_bwd_ws(dy, argmax, R, C, H, W, outh, outw, dx, nullptr, 0, stream_);
-}
-
-int frcnn_roi_pool_bwd_ws(const float *dy, const int32_t *argmax, int R, int C, int H, int W, int outh, int outw, float *dx,
-                          void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!dy || !argmax || !dx || R < 0 || C < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
     {
@@ -1596,15 +1551,7 @@ int frcnn_roi_pool_bwd_ws(const float *dy, const int32_t *argmax, int R, int C, 
             const char *bdbg_s = getenv("FRCNN_ROI_BWD_DBG");
             bdbg = bdbg_s ? atoi(bdbg_s) : 0;
 #endif
-            // two workgroups per channel quad when the caller lent a workspace, the quads alone do not fill the chip and there are RoIs to share
-            // (FRCNN_ROI_BWD_SPLIT=0: one workgroup per quad, A/B)
-            const char *sp = getenv("FRCNN_ROI_BWD_SPLIT");
-            const bool split = workspace && workspace_bytes >= frcnn_roi_pool_bwd_workspace_bytes(C, H, W) && C / 4 <= 16384 && R >= 8 &&
-                               ((sp && sp[0] == '1') || C / 4 <= frcnn_roi_cu_count()) && !(sp && sp[0] == '0');     // (=1: forced -- the emulator seats few CUs)
-            int *tickets = split ? reinterpret_cast<int *>(workspace) : nullptr;
-            float *slab = split ? reinterpret_cast<float *>(reinterpret_cast<char *>(workspace) + kRoiBwdCounterBytes) : nullptr;
-            hipLaunchKernelGGL(roi_pool_bwd_planes_kernel, dim3(C / 4, split ? 2 : 1), dim3(64 * kBwdWaves), 0, stream, dy, argmax, R, C, H * W, bins, dx, bdbg,
-                               tickets, slab);
+            hipLaunchKernelGGL(roi_pool_bwd_planes_kernel, dim3(C / 4), dim3(64 * kBwdWaves), 0, stream, dy, argmax, R, C, H * W, bins, dx, bdbg);
             return frcnn_launch_status();
         }
     }

@@ -312,11 +312,8 @@ class Runtime(object):
         m, L = self.mem, self.lib
         R, _, outh, outw = [int(v) for v in dy.shape]
         dx = out if out is not None else m.empty((1, C, H, W), "f32")
-        # with a workspace the RoIs of a channel quad are shared by two workgroups (csrc/roi_pool.hip; 128 workgroups alone leave half the chip idle)
-        ws = self.workspace("roi_bwd", L.frcnn_roi_pool_bwd_workspace_bytes(int(C), int(H), int(W)),
-                            init=lambda w: _lib.check(L.frcnn_roi_pool_bwd_workspace_init(m.ptr(w), w.shape[0], m.stream()), "frcnn_roi_pool_bwd_workspace_init"))
-        _lib.check(L.frcnn_roi_pool_bwd_ws(m.ptr(dy), m.ptr(argmax), R, C, H, W, outh, outw, m.ptr(dx), m.ptr(ws), ws.shape[0], m.stream()),
-                   "frcnn_roi_pool_bwd_ws")
+        _lib.check(L.frcnn_roi_pool_bwd(m.ptr(dy), m.ptr(argmax), R, C, H, W, outh, outw, m.ptr(dx), m.stream()),
+                   "frcnn_roi_pool_bwd")
         return dx
 
     # ------------------------------------------------------------------ convolution stack

@@ -129,14 +129,6 @@ int frcnn_roi_pool_fwd(const float *x, int C, int H, int W, const float *rois, i
                        size_t workspace_bytes, void *stream);
 int frcnn_roi_pool_bwd(const float *dy, const int32_t *argmax, int R, int C, int H, int W, int outh,
                        int outw, float *dx, void *stream);
-/* the same with a workspace (ABI v22): the RoIs of a channel quad are shared by TWO workgroups -- C / 4 = 128 workgroups alone leave half of the
- * MI355X idle and the kernel is bound by what one CU can load -- whose plane sums meet through a ticket (no second launch).  The first 64 KB of
- * the workspace are ticket counters: zero them ONCE (frcnn_roi_pool_bwd_workspace_init); every launch leaves them zeroed.  One workspace per stream.
- * workspace NULL = frcnn_roi_pool_bwd.  Same sums as the one-workgroup form up to the order of the fp32 additions (as between any two runs of it). */
-size_t frcnn_roi_pool_bwd_workspace_bytes(int C, int H, int W);
-int frcnn_roi_pool_bwd_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
-int frcnn_roi_pool_bwd_ws(const float *dy, const int32_t *argmax, int R, int C, int H, int W, int outh, int outw,
-                          float *dx, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- convolution stack -----------------------------------------------------------------------------
  * Replaces L.Convolution2D(ci,co,3,1,1)+F.ReLU (models/vgg16.py:39-68, region_proposal_network.py:53,117)

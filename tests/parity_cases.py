@@ -218,33 +218,6 @@ def check_roi_pool(rt, R=12, C=128, H=38, W=63, seed=0):
     assert np.allclose(host(rt, dx), want_dx, rtol=1e-4, atol=1e-4)    # atomics: summation order differs
 
 
-def check_roi_pool_bwd_split(rt, R=37, C=16, H=12, W=17, seed=0, force=True):
-    """RoI pooling backward with the RoIs of a channel quad shared by two workgroups (frcnn_roi_pool_bwd_ws: planes meet through a ticket): against the
-    oracle, against the one-workgroup form (same sums up to the order of the fp32 additions), and twice in a row (the ticket counters are left at zero)."""
-    rs = np.random.RandomState(seed)
-    x, rois = roi_case(rs, R, C, H, W)
-    want_y, want_am = O.roi_pooling_2d(x, rois, 7, 7, 0.0625, return_argmax=True)
-    dy = rs.randn(*want_y.shape).astype(np.float32)
-    want_dx = O.roi_pooling_2d_backward(dy, want_am, rois, x.shape)
-    dyd, amd = dev(rt, dy), dev(rt, want_am)
-    old = os.environ.get("FRCNN_ROI_BWD_SPLIT")
-    try:
-        os.environ["FRCNN_ROI_BWD_SPLIT"] = "0"
-        one = host(rt, rt.roi_pool_bwd(dyd, amd, C, H, W)).copy()
-        if force:
-            os.environ["FRCNN_ROI_BWD_SPLIT"] = "1"                  # (the emulator seats few CUs: the rule would not split there)
-        else:
-            os.environ.pop("FRCNN_ROI_BWD_SPLIT")
-        for _ in range(3):
-            two = host(rt, rt.roi_pool_bwd(dyd, amd, C, H, W)).copy()
-            assert np.allclose(two, want_dx, rtol=1e-4, atol=1e-4)
-            assert np.allclose(two, one, rtol=1e-5, atol=1e-5)
-    finally:
-        os.environ.pop("FRCNN_ROI_BWD_SPLIT", None)
-        if old is not None:
-            os.environ["FRCNN_ROI_BWD_SPLIT"] = old
-
-
 def check_roi_pool_cells(rt):
     """The cell-major inference kernel (maps up to 76 x 64): ragged channel counts, non-7x7 outputs, the tall-map instantiation,
     RoIs larger than the bin tables, and the oracle's NaN rule -- a NaN in a bin's FIRST cell stays, NaNs elsewhere never win."""

@@ -15,7 +15,7 @@ def rt():
 
 
 def test_library_is_the_device_build(rt):
-    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 22
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 21
 
 
 def test_nms_golden(rt):
@@ -397,12 +397,6 @@ def test_conv_bf16_staging_variants_bit_identical(rt, monkeypatch, cin, cout, h,
 def test_conv_bf16_default_picks_vs_oracle(rt, cin, cout, h, w, expect, expect_pooled):
     """The strip forms at the VGG layer sizes where the default rule really launches them, against the oracle (not against another HIP kernel)."""
     P.check_conv_bf16_default_pick(rt, cin, cout, h, w, expect, expect_pooled)
-
-
-def test_roi_pool_bwd_two_halves(rt):
-    """RoI pooling backward at the benchmark size with the default rule (two workgroups per channel quad: 256 instead of 128 on 256 CUs) and on a small case."""
-    P.check_roi_pool_bwd_split(rt, R=300, C=512, H=38, W=63, force=False)
-    P.check_roi_pool_bwd_split(rt, R=37, C=16, H=12, W=17, seed=3)
 
 
 @pytest.mark.parametrize("h,w,cin,rw", [(600, 1000, 3, None), (600, 1000, 3, 4), (600, 1000, 3, 6), (75, 101, 3, None), (24, 64, 1, None), (24, 64, 1, 4)])

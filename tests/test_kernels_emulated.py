@@ -522,10 +522,3 @@ def test_conv_bf16_resident_forms(rt, form, cin, cout, h, w, pool):
     """csrc/conv_bf16_res.h (weight slab resident in LDS, producer / consumer waves, the input ring running across the tiles of a persistent workgroup):
     bit-identical to conv_dma_bf16_kernel -- whole and ragged tiles, ragged couts, several tiles and several cout tiles per workgroup, both outputs."""
     P.check_conv_bf16_strip(rt, form, cin, cout, h, w, pool=pool, seed=form)
-
-
-def test_roi_pool_bwd_two_halves(rt):
-    """frcnn_roi_pool_bwd_ws: two workgroups per channel quad, halves combined by the second arriver (either order: the emulator runs workgroups in
-    launch order and -- HIPEMU_REVERSE -- in reverse), odd RoI counts, several quads."""
-    P.check_roi_pool_bwd_split(rt, R=37, C=16, H=12, W=17)
-    P.check_roi_pool_bwd_split(rt, R=8, C=4, H=38, W=63, seed=1)
