@@ -745,6 +745,18 @@ def main():
                 for _ in range(8):
                     model.RPN.proposal_layer.forward_device(prob, bbox, IM_H, IM_W)
             iso["proposals_nms_us"] = graph_time_us(torch, prop_seq, 8, max(iso_replays // 4, 25))
+
+            # RoI pooling IN the pipeline: eight times (proposal pipeline -> RoI pooling of ITS OWN rois) in one graph, minus the proposal pipeline's own
+            # figure = what the RoI launch costs behind the NMS scan it depends on (launch latency + prologue are not hidden by anything there)
+            outs2 = [rt.mem.empty((int(rois.shape[0]), 512, 7, 7), "f32") for _ in range(4)]
+
+            def prop_roi_seq():
+                for _ in range(8):
+                    r_, _, _ = model.RPN.proposal_layer.forward_device(prob, bbox, IM_H, IM_W)
+                    rt.roi_pool_fwd_chw(feat, r_, 7, 7, 1.0 / 16, out=outs2[state["i"] % 4])
+                    state["i"] += 1
+            iso["proposals_plus_roi_us"] = graph_time_us(torch, prop_roi_seq, 8, max(iso_replays // 4, 25))
+            del outs2
         except Exception as e:
             print("isolated RoI / proposal graphs failed (%s)" % (e,), file=sys.stderr)
             torch.cuda.synchronize()
@@ -810,6 +822,7 @@ def main():
             res["nms_roi"] = {"proposals_nms_us": iso.get("proposals_nms_us", avg["proposals"] * 1e3), "roi_pool_us": roi_us,
                               "source": ("HIP events around hipGraphs of 8 back-to-back launches (kernel time; RoI outputs rotate over 10 buffers = 301 MB)"
                                          if "roi_pool_us" in iso else "per-stage HIP events of eager launches"),
+                              "roi_pool_us_behind_nms_in_one_graph": (iso["proposals_plus_roi_us"] - iso["proposals_nms_us"]) if "proposals_plus_roi_us" in iso and "proposals_nms_us" in iso else None,
                               "proposals_nms_us_in_pipeline_stage_event": avg["proposals"] * 1e3,
                               "roi_pool_us_in_pipeline_stage_event": avg["roi_pool"] * 1e3,
                               "roi_pool_algorithmic_mb": roi_bytes / 1e6,
@@ -853,6 +866,7 @@ def main():
             nr, b3, sp = res.get("nms_roi") or {}, res.get("bf16_config3") or {}, res.get("f32_split_products") or {}
             sec = {"roi_pool_us": nr.get("roi_pool_us"), "roi_pool_frac_of_hbm_peak": nr.get("roi_pool_frac_of_hbm_peak"),
                    "roi_pool_us_in_pipeline": nr.get("roi_pool_us_in_pipeline_stage_event"),
+                   "roi_pool_us_behind_nms_in_one_graph": nr.get("roi_pool_us_behind_nms_in_one_graph"),
                    "roi_pool_fwd_argmax_us": nr.get("roi_pool_fwd_argmax_us"), "roi_pool_fwd_argmax_frac_of_hbm_peak": nr.get("roi_pool_fwd_argmax_frac_of_hbm_peak"),
                    "roi_pool_bwd_us": nr.get("roi_pool_bwd_us"), "roi_pool_bwd_frac_of_hbm_peak": nr.get("roi_pool_bwd_frac_of_hbm_peak"),
                    "proposals_nms_us": nr.get("proposals_nms_us"),
