@@ -741,11 +741,11 @@ rpn_heads_bf16_fused_kernel(const uint16_t *__restrict__ h, const uint16_t *__re
 
 // The strip forms of conv_bf16_strip.h (FRCNN_BF16_DMA=901 / 902 / 903 / 909 = form A / B / C / D, 900 = the cheapest applicable one of A / B / C by a
 // count of MFMA rounds, 907 / 908 two measured shapes that were not adopted).  Returns 1 when the form does not exist or does not apply to the launch.
-template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, int WPE = 1, bool DIRECT = false>
+template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, int WPE = 1, bool DIRECT = false, int NW = 4>
 static void conv_bf16_strip_go(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int CinP, int Cout, int CoutP, int H, int W,
                                int relu, int out_mode, hipStream_t stream) {
     const int xtiles = frcnn_cdiv(W, 32), ytiles = frcnn_cdiv(H, RG * RW), cotiles = frcnn_cdiv(CoutP, 32 * COB * CW);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_strip_bf16_kernel<COB, RW, RG, CW, KW, NS, ABL, WPE, DIRECT>), dim3((unsigned)((long)xtiles * ytiles * cotiles)), dim3(256), 0, stream,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_strip_bf16_kernel<COB, RW, RG, CW, KW, NS, ABL, WPE, DIRECT, NW>), dim3((unsigned)((long)xtiles * ytiles * cotiles)), dim3(64 * NW), 0, stream,
                        x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, cotiles);
 }
 // Which strip form a request resolves to for a launch (0 = the request does not exist / does not apply): `form` 1..10 as requested, 0 = the cheapest
@@ -753,8 +753,9 @@ static void conv_bf16_strip_go(const uint16_t *x, const uint16_t *w_packed, cons
 static int conv_bf16_strip_resolve(int form, int CinP, int CoutP, int H, int W, int out_mode) {
     const int chunks = CinP / kCK;
     // {couts per workgroup, tile rows, K ways, MFMAs per wave and stage}
-    static const int kForm[11][4] = {{0, 0, 0, 0}, {64, 20, 1, 90}, {64, 10, 1, 45}, {32, 5, 4, 45}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {64, 10, 2, 90}, {64, 12, 1, 54}, {64, 10, 1, 45}, {64, 10, 1, 45}};
-    auto applies = [&](int f) { return f >= 0 && f <= 10 && kForm[f][0] != 0 && chunks % kForm[f][2] == 0 && !(out_mode == 2 && (kForm[f][1] & 1)); };
+    static const int kForm[12][4] = {{0, 0, 0, 0}, {64, 20, 1, 90}, {64, 10, 1, 45}, {32, 5, 4, 45}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {64, 10, 2, 90}, {64, 12, 1, 54}, {64, 10, 1, 45}, {64, 10, 1, 45},
+                                     {64, 20, 1, 45}};
+    auto applies = [&](int f) { return f >= 0 && f <= 11 && kForm[f][0] != 0 && chunks % kForm[f][2] == 0 && !(out_mode == 2 && (kForm[f][1] & 1)); };
     if (form == 0) {
         const long cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
         long best = -1;
@@ -800,6 +801,12 @@ static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed
     case 10:
         if (out_mode == 0 && (size_t)CoutP * H * W * 2 < (1ull << 31)) conv_bf16_strip_go<1, 5, 2, 2, 1, 2, 0, 2, true>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
         else conv_bf16_strip_go<1, 5, 2, 2, 1, 2, 0, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
+        break;
+    // 911 = form E (round 4): form A's tile -- 64 couts x 20 rows x 32 px -- on EIGHT of form D's waves (two per SIMD, one workgroup per CU, three 42 KB stages):
+    //       the two waves of a SIMD share a stage's weight panel; 6 LDS-DMA pieces per wave and stage instead of 8.5
+    case 11:
+        if (out_mode == 0 && (size_t)CoutP * H * W * 2 < (1ull << 31)) conv_bf16_strip_go<1, 5, 4, 2, 1, 3, 0, 1, true, 8>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
+        else conv_bf16_strip_go<1, 5, 4, 2, 1, 3, 0, 1, false, 8>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
         break;
     default: return 1;
     }
@@ -940,7 +947,7 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
         return conv_bf16_strip((mode - 9000) / 10, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream, ae ? atoi(ae) : mode % 10) == 0
                    ? frcnn_launch_status() : FRCNN_ERR_INVALID;
     }
-    if (ksize == 3 && mode >= 900 && mode <= 910) {
+    if (ksize == 3 && mode >= 900 && mode <= 911) {
         const int rc = conv_bf16_strip(mode - 900, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
         if (rc == 0) return frcnn_launch_status();
         if (mode != 900) return FRCNN_ERR_INVALID;                // an explicitly requested form that does not apply to this launch
@@ -1066,7 +1073,7 @@ int frcnn_conv_bf16_plan(int Cin, int Cout, int H, int W, int ksize, int out_mod
         const int form = conv_bf16_strip_resolve((mode - 9000) / 10, CinP, CoutP, H, W, out_mode);
         return form ? 900 + form : FRCNN_ERR_INVALID;
     }
-    if (mode >= 900 && mode <= 910) {
+    if (mode >= 900 && mode <= 911) {
         const int form = conv_bf16_strip_resolve(mode - 900, CinP, CoutP, H, W, out_mode);
         if (form) return 900 + form;
         return mode == 900 ? 0 : FRCNN_ERR_INVALID;               // 900 falls back to conv_dma_bf16_kernel's picks; an explicit form that does not apply is refused

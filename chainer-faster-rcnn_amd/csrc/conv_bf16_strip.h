@@ -36,7 +36,7 @@
 #pragma once
 #include <type_traits>
 
-template <int COB, int RW, int RG, int CW, int KW, int NS>
+template <int COB, int RW, int RG, int CW, int KW, int NS, int NW = 4>
 struct StripShape {
     static constexpr int KS = 3, TAPS = 9, PAD = 1;
     static constexpr int GW = RG * CW;                                    // waves per K way
@@ -64,7 +64,7 @@ struct StripShape {
     // over all of them with >= 3 stages (the data has more than a whole stage to arrive); with 2 stages it has to arrive within
     // THIS stage, so as early as one piece per two MFMAs allows
     static constexpr int SPAN = NS >= 3 ? 8 * GM : (2 * (PPW + 1) < 8 * GM ? 2 * (PPW + 1) : 8 * GM);
-    static_assert(GW * KW == 4, "four waves");
+    static_assert(GW * KW == NW && (NW == 4 || NW == 8), "waves");
     static_assert(KW == 1 || KW == 2 || KW == 4, "K ways");
     static_assert(LDS_BYTES <= 160 * 1024 - 64, "LDS");                    // (the kernel checks WPE * LDS_BYTES)
     static_assert(NS >= 2 && NS <= 4 && (NS - 1) * PPW <= 63, "vmcnt holds 63");
@@ -82,11 +82,13 @@ __device__ __forceinline__ void strip_keep(const uint4 &v) { asm volatile("" ::"
 // DIRECT (910; the default rule's form D: -0.3 ... -0.9 us per launch, bit-identical on the MI355X, r03 probe 9): the bf16 output of a launch without the fused pool leaves straight from the accumulator quads
 // -- a quad is four consecutive couts of one pixel = one aligned 8-byte piece of the channel-blocked record, a wave's store covers 32 pixels x 16 B -- instead
 // of through the LDS transpose: no barrier, no LDS round trip, and no use of the ring by the epilogue (the condition for a persistent tile loop)
-template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, int WPE = 1, bool DIRECT = false>
-__global__ void __launch_bounds__(256, WPE)
+// NW = waves per workgroup: 4 (one per SIMD) or 8 (form E, round 4: two per SIMD in ONE workgroup -- form A's 64-cout x 20-row tile on form D's waves; the
+// two waves of a SIMD share one stage's weight panel instead of each workgroup fetching its own: 42 KB of DMA per 360 MFMAs where form D moves 2 x 31 KB)
+template <int COB, int RW, int RG, int CW, int KW, int NS, int ABL = 0, int WPE = 1, bool DIRECT = false, int NW = 4>
+__global__ void __launch_bounds__(64 * NW, WPE)
 conv_strip_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wp, const float *__restrict__ bias, void *__restrict__ y,
                        int CinP, int Cout, int CoutP, int H, int W, int relu, int out_mode, int xtiles, int ytiles, int cotiles) {
-    using S = StripShape<COB, RW, RG, CW, KW, NS>;
+    using S = StripShape<COB, RW, RG, CW, KW, NS, NW>;
     static_assert(WPE * S::LDS_BYTES <= 160 * 1024 - 64 * WPE, "LDS of WPE workgroups");
     constexpr int KS = 3, TAPS = 9, PAD = 1, HPX = S::HPX, BCO = S::BCO, TR = S::TR, NACC = S::NACC, PPW = S::PPW, IN_Q = S::IN_Q, OP = S::OP, GW = S::GW;
     __shared__ __attribute__((aligned(1024))) unsigned char ring[S::LDS_BYTES];
@@ -383,7 +385,7 @@ conv_strip_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restric
         // F.MaxPooling2D(2, 2) (cover_all) fused: TR is even and tiles start at even rows / columns, so every 2x2 window lies inside
         // the tile; y is [CoutP/16][ceil(H/2)][ceil(W/2)][16]
         const int OH = (H + 1) / 2, OW = (W + 1) / 2;
-        for (int v = tid; v < (TR / 2) * 16 * CB16 * 2; v += 256) {
+        for (int v = tid; v < (TR / 2) * 16 * CB16 * 2; v += 64 * NW) {
             const int cbl = v / ((TR / 2) * 16 * 2), rem = v - cbl * ((TR / 2) * 16 * 2);
             const int opix = rem >> 1, half = rem & 1;
             const int orow = opix >> 4, ocol = opix & 15;
@@ -400,7 +402,7 @@ conv_strip_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restric
         }
         return;
     }
-    for (int v = tid; v < TR * 32 * CB16 * 2; v += 256) {                 // 16-byte vectors: (cout block of 16, pixel, half)
+    for (int v = tid; v < TR * 32 * CB16 * 2; v += 64 * NW) {             // 16-byte vectors: (cout block of 16, pixel, half)
         const int cbl = v / (TR * 32 * 2), rem = v - cbl * (TR * 32 * 2);
         const int pix = rem >> 1, half = rem & 1;
         const int py = y0 + (pix >> 5), qx = x0 + (pix & 31), co = co0 + cbl * 16;

@@ -311,7 +311,7 @@ int frcnn_conv_bf16_workspace_init(void *workspace, size_t workspace_bytes, void
 int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
                        int W, int ksize, int relu, int out_mode, void *workspace, size_t workspace_bytes, void *stream);
 /* which kernel family frcnn_conv_bf16[_ws] launches for this shape under the current environment (A/B hooks included): 0 = conv_dma_bf16_kernel
- * (or, for ksize 1 / FRCNN_BF16_DMA=0, the register-staged kernel), 901 / 902 / 903 / 909 / 910 = strip form A / B / C / D / D with direct stores of csrc/conv_bf16_strip.h (one wave
+ * (or, for ksize 1 / FRCNN_BF16_DMA=0, the register-staged kernel), 901 / 902 / 903 / 909 / 910 / 911 = strip form A / B / C / D / D with direct stores / E of csrc/conv_bf16_strip.h (one wave
  * per SIMD, software-pipelined ring; D and C are default picks: DESIGN 3.8b).  Forms A, B, D give bit-identical results to 0; form C splits the K loop
  * four ways over the waves of a workgroup and sums the partial accumulators in K-way order (deterministic, fp32 rounding differs).  No launch. */
 int frcnn_conv_bf16_plan(int Cin, int Cout, int H, int W, int ksize, int out_mode);

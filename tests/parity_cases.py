@@ -949,7 +949,7 @@ def check_conv_bf16_strip(rt, form, Cin, Cout, H, W, pool=False, seed=0):
         if old[1] is not None:
             os.environ["FRCNN_BF16_STRIP"] = old[1]
     assert got32.shape == ref32.shape and got16.shape == ref16.shape
-    if form in (901, 902, 908, 909, 910, 921, 922):
+    if form in (901, 902, 908, 909, 910, 911, 921, 922):
         assert np.array_equal(got32, ref32) and np.array_equal(got16, ref16)
     else:
         scale = max(np.abs(ref32).max(), 1e-6)

@@ -406,7 +406,7 @@ def test_conv1_pair_bf16(rt, h, w, cin, rw):
     P.check_conv1_pair_bf16(rt, h, w, Cin=cin, rw=rw)
 
 
-@pytest.mark.parametrize("form", [901, 902, 903, 909, 910])
+@pytest.mark.parametrize("form", [901, 902, 903, 909, 910, 911])
 def test_conv_bf16_strip_forms(rt, form):
     """The strip forms (csrc/conv_bf16_strip.h; D -- 910, with 909's epilogue under the fused pool -- and C = 903 are default picks) against conv_dma_bf16_kernel at VGG layer sizes: bit-identical
     where one accumulation chain per output is kept, fp32 summation-order noise for the K-split form (profiles/r03_conv_bf16_strip_micro.txt holds

@@ -278,10 +278,12 @@ def test_conv_bf16_strip_forms(rt, monkeypatch, mode):
         P.check_conv_bf16_pool(rt, 80, 128, 22, 37, seed=3)   # odd tile rows rule the pool out for form C, five chunks the two-way K split
 
 
-@pytest.mark.parametrize("form", [901, 902, 903, 907, 909, 910])
+@pytest.mark.parametrize("form", [901, 902, 903, 907, 909, 910, 911])
 def test_conv_bf16_strip_same_as_default(rt, form):
     P.check_conv_bf16_strip(rt, form, 128, 96, 21, 45, seed=4)
     P.check_conv_bf16_strip(rt, form, 64, 64, 12, 64, pool=form != 903, seed=5)
+    if form == 911:                                           # form E: eight waves, 20-row tiles: two row blocks + a ragged third, 12 chunks (the ring wraps)
+        P.check_conv_bf16_strip(rt, form, 192, 128, 45, 70, pool=True, seed=6)
 
 
 def test_vgg16_bf16_trunk_through_the_strip_picks(rt):
