@@ -73,3 +73,27 @@ def test_strip_kernels_do_not_spill(tmp_path):
         meta = m.group(1)
         assert int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", meta).group(1)) == 0, frag + ": scratch in use"
         assert int(re.search(r"\.amdhsa_group_segment_fixed_size\s+(\d+)", meta).group(1)) == lds, frag + ": LDS is not the ring alone"
+
+
+# round 4: the producer / consumer kernels (csrc/conv_bf16_pair.hip form 2, csrc/conv_bf16_res.h) are compiled for TWO waves per SIMD -- at most 256 registers --
+# and the one-wave-per-SIMD pair form keeps 36 weight fragments in registers: none of them may touch scratch (a `cond ? pk[2 + h] : pk[h]` on a register array
+# once did: 48 bytes per lane), and form E of the strip kernel (eight waves) keeps form D's register budget.
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc (cross-compiles without a GPU)")
+def test_round4_kernels_do_not_spill(tmp_path):
+    wants = {"conv_bf16_pair": [("conv1_pair_pc_bf16_kernel", 256, None), ("conv1_pair_bf16_kernelILi6E", 512, None), ("conv1_pair_bf16_kernelILi4E", 512, None)],
+             "conv_bf16": [("conv_res_bf16_kernelILi2ELi4ELi4ELi6E", 256, None), ("conv_res_bf16_kernelILi1ELi8ELi4ELi4E", 256, None),
+                           ("conv_strip_bf16_kernelILi1ELi5ELi4ELi2ELi1ELi3ELi0ELi1ELb1ELi8E", 256, 3 * 42 * 1024)]}
+    for src, kernels in wants.items():
+        asm = str(tmp_path / (src + ".s"))
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"),
+                        "-I", CSRC, os.path.join(CSRC, src + ".hip"), "-o", asm], check=True, stderr=subprocess.DEVNULL)
+        text = open(asm).read()
+        for frag, max_regs, lds in kernels:
+            m = re.search(r"\.amdhsa_kernel \S*" + frag + r"\S*\n(.*?)\.end_amdhsa_kernel", text, re.S)
+            assert m, frag
+            meta = m.group(1)
+            assert int(re.search(r"\.amdhsa_private_segment_fixed_size\s+(\d+)", meta).group(1)) == 0, frag + ": scratch in use"
+            regs = int(re.search(r"\.amdhsa_next_free_vgpr\s+(\d+)", meta).group(1))
+            assert regs <= max_regs, "%s: %d registers" % (frag, regs)
+            if lds is not None:
+                assert int(re.search(r"\.amdhsa_group_segment_fixed_size\s+(\d+)", meta).group(1)) == lds, frag + ": LDS is not the ring alone"
