@@ -62,6 +62,20 @@ __device__ __forceinline__ void frcnn_buf_store_f32x4_soff(frcnn_buf_t b, uint32
     __builtin_amdgcn_raw_buffer_store_b128(u, b, (int)byte_off, (int)soff, AUX);
 }
 
+// 8-byte load through a descriptor (out-of-range lanes read 0)
+__device__ __forceinline__ uint2 frcnn_buf_load_b64(frcnn_buf_t b, uint32_t byte_off) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(b, (int)byte_off, 0, 0);
+    return make_uint2(v.x, v.y);
+}
+// 8-byte store at (per-lane offset, range-checked) + (wave-uniform scalar offset), cache policy AUX (16 = sc1 write-through) as a template argument
+template <int AUX>
+__device__ __forceinline__ void frcnn_buf_store_b64_soff(frcnn_buf_t b, uint32_t byte_off, uint32_t soff, uint2 v) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t u;
+    u.x = v.x; u.y = v.y;
+    __builtin_amdgcn_raw_buffer_store_b64(u, b, (int)byte_off, (int)soff, AUX);
+}
 // 8-byte store through a descriptor (lanes whose offset is kBufOob store nothing)
 __device__ __forceinline__ void frcnn_buf_store_b64(frcnn_buf_t b, uint32_t byte_off, uint2 v) {
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));

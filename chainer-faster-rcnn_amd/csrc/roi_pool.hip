@@ -904,7 +904,10 @@ __device__ __forceinline__ void quad_scan_slot_argmax(const unsigned char *img, 
 // BINS: outh * outw as a compile-time constant (49 for the 7 x 7 head: the staging stores get immediate offsets and pair up as
 // ds_write2_b32), or 0 = any shape up to 7 x 7
 // ARGMAX: the training form -- also writes argmax_data (int32, same shape as y); every RoI takes the plain-cell scan above.
-template <int ST, int BINS, bool ARGMAX = false>
+// IN16 (round 4): the map is the bf16 chain's channel-blocked tensor [CP/16][H][W][16] -- a cell's four channels are ONE 8-byte load, widened to fp32 on
+// the way into the LDS images (exact), everything after that is the fp32 kernel; OUT16: the output is raw bf16 bits (R, C * bins) -- the staged fp32 maxima
+// are rounded once (v_cvt_pk_bf16_f32; of bf16 inputs: exact) and leave as 8-byte stores.  The bf16 line's RoI stage used the round-2 cell-major kernel (13.9 us).
+template <int ST, int BINS, bool ARGMAX = false, bool IN16 = false, bool OUT16 = false>
 __global__ void __launch_bounds__(64 * kQuadWaves)
 roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const float *__restrict__ rois, int roi_cols, int R,
                       int outh, int outw, float scale, float *__restrict__ y, int32_t *__restrict__ argmax, int rsplit, const RoiEdgeTable etab,
@@ -1037,14 +1040,27 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
         if (!(dbg & 256)) build_geometry(0, roi_q, false);
         if (lane == 0) nan_of_wave[wave] = 0;
     } else {
-        const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)C * HW * sizeof(float)));
         float v[4][4];
+        if constexpr (IN16) {
+            const int CP16 = (C + 15) / 16 * 16;                                  // the blocked tensor is zero-padded to whole 16-channel blocks
+            const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)CP16 * HW * 2));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int h = 3 * wave + i;
-            const uint32_t base = (h < H && lane < W) ? (uint32_t)((c0 * HW + h * W + lane) * 4) : kBufOob;
+            for (int i = 0; i < 4; ++i) {
+                const int h = 3 * wave + i;
+                const uint32_t off = (h < H && lane < W) ? (uint32_t)((((c0 >> 4) * HW + h * W + lane) * 16 + (c0 & 15)) * 2) : kBufOob;
+                const uint2 q = frcnn_buf_load_b64(xbuf, off);                    // channels c0 .. c0 + 3 of the cell: 4 x bf16
+                v[i][0] = __uint_as_float(q.x << 16); v[i][1] = __uint_as_float(q.x & 0xffff0000u);
+                v[i][2] = __uint_as_float(q.y << 16); v[i][3] = __uint_as_float(q.y & 0xffff0000u);
+            }
+        } else {
+            const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)C * HW * sizeof(float)));
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[i][c] = frcnn_buf_load_f32(xbuf, base + (uint32_t)(c * HW * 4));   // c0 + c >= C: past the end -> 0
+            for (int i = 0; i < 4; ++i) {
+                const int h = 3 * wave + i;
+                const uint32_t base = (h < H && lane < W) ? (uint32_t)((c0 * HW + h * W + lane) * 4) : kBufOob;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[i][c] = frcnn_buf_load_f32(xbuf, base + (uint32_t)(c * HW * 4));   // c0 + c >= C: past the end -> 0
+            }
         }
         float4 *img0 = reinterpret_cast<float4 *>(lds + kQuadOffImg), *img1 = reinterpret_cast<float4 *>(lds + kQuadOffImg + kQuadImgBytes);
         float t10[4][4];
@@ -1080,12 +1096,14 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
     const bool lane_on = ph < outh && pw < outw;
     const int cg = min(4, C - c0), run = cg * bins;
     const bool vec_ok = (run & 3) == 0 && ((C * bins) & 3) == 0 && ((c0 * bins) & 3) == 0;
-    const frcnn_buf_t ybuf = frcnn_make_buf(y, (uint32_t)((size_t)R * C * bins * sizeof(float)));
+    static_assert(!(ARGMAX && OUT16), "the training form is fp32");
+    constexpr uint32_t kOutBytes = OUT16 ? 2u : 4u;                               // bytes per output value
+    const frcnn_buf_t ybuf = frcnn_make_buf(y, (uint32_t)((size_t)R * C * bins * kOutBytes));
     const frcnn_buf_t abuf = frcnn_make_buf(ARGMAX ? (const void *)argmax : (const void *)y, (uint32_t)((size_t)R * C * bins * sizeof(float)));
     float *sv = reinterpret_cast<float *>(lds + kQuadOffStage) + wave * ((ARGMAX ? 4 : 2) * kQuadStageFloats);
     float *sv_lane = sv + min(ph, outh - 1) * outw + min(pw, outw - 1);
-    const uint32_t st_off = (vec_ok && lane < run / 4 && !(dbg & 16)) ? (uint32_t)(lane * 16) : kBufOob;
-    const uint32_t run_bytes = (uint32_t)(C * bins) * 4u, c0_bytes = (uint32_t)(c0 * bins) * 4u;
+    const uint32_t st_off = (vec_ok && lane < run / 4 && !(dbg & 16)) ? (uint32_t)(lane * 4) * kOutBytes : kBufOob;     // four values per lane
+    const uint32_t run_bytes = (uint32_t)(C * bins) * kOutBytes, c0_bytes = (uint32_t)(c0 * bins) * kOutBytes;
     const unsigned char *img = lds + kQuadOffImg;
     const uint32_t *geo_w_lane = reinterpret_cast<const uint32_t *>(lds + kQuadOffGeoW) + pw;
     const uint2 *geo_h_lane = reinterpret_cast<const uint2 *>(lds + kQuadOffGeoH) + ph;
@@ -1182,8 +1200,13 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
         if (vec_ok) {
             const int li = min(lane, kQuadStageFloats / 4 - 1);
             const float4 o0 = reinterpret_cast<const float4 *>(sv)[li], o1 = reinterpret_cast<const float4 *>(sv + kQuadStageFloats)[li];
-            frcnn_buf_store_f32x4_soff<ST>(ybuf, st_off, dst0, o0);
-            if (second) frcnn_buf_store_f32x4_soff<ST>(ybuf, st_off, dst1, o1);
+            if constexpr (OUT16) {
+                frcnn_buf_store_b64_soff<ST>(ybuf, st_off, dst0, make_uint2(frcnn_pack_bf16x2(o0.x, o0.y), frcnn_pack_bf16x2(o0.z, o0.w)));
+                if (second) frcnn_buf_store_b64_soff<ST>(ybuf, st_off, dst1, make_uint2(frcnn_pack_bf16x2(o1.x, o1.y), frcnn_pack_bf16x2(o1.z, o1.w)));
+            } else {
+                frcnn_buf_store_f32x4_soff<ST>(ybuf, st_off, dst0, o0);
+                if (second) frcnn_buf_store_f32x4_soff<ST>(ybuf, st_off, dst1, o1);
+            }
             if constexpr (ARGMAX) {
                 const float4 j0 = reinterpret_cast<const float4 *>(sv + 2 * kQuadStageFloats)[li], j1 = reinterpret_cast<const float4 *>(sv + 3 * kQuadStageFloats)[li];
                 frcnn_buf_store_f32x4_soff<ST>(abuf, st_off, dst0, j0);
@@ -1191,6 +1214,12 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
             }
         } else {
             for (int i = lane; i < run; i += 64) {
+                if constexpr (OUT16) {
+                    uint16_t *y16 = reinterpret_cast<uint16_t *>(y);
+                    y16[(size_t)(dst0 / 2) + i] = (uint16_t)frcnn_pack_bf16x2(sv[i], 0.0f);
+                    if (second) y16[(size_t)(dst1 / 2) + i] = (uint16_t)frcnn_pack_bf16x2(sv[kQuadStageFloats + i], 0.0f);
+                    continue;
+                }
                 y[(size_t)(dst0 / 4) + i] = sv[i];
                 if (second) y[(size_t)(dst1 / 4) + i] = sv[kQuadStageFloats + i];
                 if constexpr (ARGMAX) {
@@ -1334,11 +1363,27 @@ static void roi_fill_edge_table(RoiEdgeTable &t, int outh, int outw) {
 
 // Launch the quad-cell kernel (fp32 NCHW in, fp32 out; argmax != nullptr: the training form) wherever its 38-row image and its
 // 32-bit output offsets fit.  Returns false when it does not apply.
+template <bool IN16 = false, bool OUT16 = false>
 static bool roi_quads_launch(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
                              float scale, float *y, int32_t *argmax, hipStream_t stream) {
     if (H > kQuadRows || W > 64) return false;
     if ((size_t)C * H * W * sizeof(float) >= (1ull << 31)) return false;      // the map is read through a 32-bit buffer descriptor
     if ((size_t)R * C * outh * outw * sizeof(float) >= (1ull << 32)) return false;
+    if constexpr (IN16 || OUT16) {                                            // the bf16 forms: one instantiation each (write-through stores, any bin count)
+        if (argmax) return false;
+        RoiEdgeTable qk16;
+        roi_fill_edge_table(qk16, outh, outw);
+        const int cq = frcnn_cdiv(C, 4);
+        int rs = frcnn_cdiv(frcnn_roi_cu_count(), cq);
+        const int ms = frcnn_cdiv(R, 2 * kQuadWaves);
+        if (rs > ms) rs = ms;
+        if (rs < 1) rs = 1;
+        const char *fx = getenv("FRCNN_ROI_RSPLIT");
+        if (fx && atoi(fx) > 0) rs = atoi(fx);
+        if (outh * outw == 49) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<16, 49, false, IN16, OUT16>), dim3(cq, rs), dim3(64 * kQuadWaves), 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, nullptr, rs, qk16, 0);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<16, 0, false, IN16, OUT16>), dim3(cq, rs), dim3(64 * kQuadWaves), 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, nullptr, rs, qk16, 0);
+        return true;
+    }
     RoiEdgeTable qk;
     roi_fill_edge_table(qk, outh, outw);
     const int cquads = frcnn_cdiv(C, 4);
@@ -1376,6 +1421,9 @@ static bool roi_cells_launch(const float *x, int C, int H, int W, const float *r
     if ((size_t)C * H * W * sizeof(float) >= (1ull << 31)) return false;      // the map is read through a 32-bit buffer descriptor
     if constexpr (OUT16 == 0 && !IN16) {
         if (!(sel && sel[0] == 'c') && roi_quads_launch(x, C, H, W, rois, R, roi_cols, outh, outw, scale, y, nullptr, stream)) return true;
+    }
+    if constexpr (IN16 && OUT16 != 2) {                                       // round 4: the quad kernel reads the blocked bf16 map itself (FRCNN_ROI_KERNEL=cells: the round-2 kernel, A/B)
+        if (!(sel && sel[0] == 'c') && roi_quads_launch<true, OUT16 == 1>(x, C, H, W, rois, R, roi_cols, outh, outw, scale, y, nullptr, stream)) return true;
     }
     const int cgroups = frcnn_cdiv(C, 8);
     const int waves = H <= 38 ? 16 : 8;

@@ -33,6 +33,14 @@ static inline void frcnn_buf_store_b128(frcnn_buf_t b, uint32_t off, uint4 v) {
 template <int AUX> static inline void frcnn_buf_store_f32x4_soff(frcnn_buf_t b, uint32_t off, uint32_t soff, float4 v) {
     if ((uint64_t)off + 16 <= b.bytes) memcpy(const_cast<char *>(b.base) + off + soff, &v, 16);
 }
+static inline uint2 frcnn_buf_load_b64(frcnn_buf_t b, uint32_t off) {
+    uint2 v = make_uint2(0u, 0u);
+    if ((uint64_t)off + 8 <= b.bytes) memcpy(&v, b.base + off, 8);
+    return v;
+}
+template <int AUX> static inline void frcnn_buf_store_b64_soff(frcnn_buf_t b, uint32_t off, uint32_t soff, uint2 v) {
+    if ((uint64_t)off + 8 <= b.bytes) memcpy(const_cast<char *>(b.base) + off + soff, &v, 8);
+}
 static inline void frcnn_buf_store_b64(frcnn_buf_t b, uint32_t off, uint2 v) {
     if ((uint64_t)off + 8 <= b.bytes) memcpy(const_cast<char *>(b.base) + off, &v, 8);
 }
