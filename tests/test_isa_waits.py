@@ -25,6 +25,24 @@ BOUNDS = {
 }
 
 
+_ASM = {}
+
+
+def asm_of(src, tmp_root):
+    """gfx950 assembly of csrc/<src>.hip, compiled ONCE per test session (three tests read conv_bf16.hip's: ~30 s of hipcc each)."""
+    if src not in _ASM:
+        path = os.path.join(str(tmp_root), src + ".s")
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"),
+                        "-I", CSRC, os.path.join(CSRC, src + ".hip"), "-o", path], check=True, stderr=subprocess.DEVNULL)
+        _ASM[src] = path
+    return _ASM[src]
+
+
+@pytest.fixture(scope="module")
+def asm_dir(tmp_path_factory):
+    return tmp_path_factory.mktemp("isa")
+
+
 def full_waits(asm_path):
     counts, name = {}, None
     for ln in open(asm_path):
@@ -41,10 +59,8 @@ def full_waits(asm_path):
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc (cross-compiles without a GPU)")
 @pytest.mark.parametrize("src", sorted(BOUNDS))
-def test_loads_stay_batched(src, tmp_path):
-    asm = str(tmp_path / (src + ".s"))
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-I", CSRC,
-                    os.path.join(CSRC, src + ".hip"), "-o", asm], check=True, stderr=subprocess.DEVNULL)
+def test_loads_stay_batched(src, asm_dir):
+    asm = asm_of(src, asm_dir)
     counts = full_waits(asm)
     for frag, bound in BOUNDS[src]:
         hits = {k: v for k, v in counts.items() if frag in k}
@@ -62,11 +78,8 @@ STRIP_LDS = {"ILi2ELi5ELi4ELi1ELi1ELi3ELi0ELi1ELb0E": 3 * 42 * 1024, "ILi1ELi5EL
 
 
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc (cross-compiles without a GPU)")
-def test_strip_kernels_do_not_spill(tmp_path):
-    asm = str(tmp_path / "conv_bf16.s")
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"),
-                    "-I", CSRC, os.path.join(CSRC, "conv_bf16.hip"), "-o", asm], check=True, stderr=subprocess.DEVNULL)
-    text = open(asm).read()
+def test_strip_kernels_do_not_spill(asm_dir):
+    text = open(asm_of("conv_bf16", asm_dir)).read()
     for frag, lds in STRIP_LDS.items():
         m = re.search(r"\.amdhsa_kernel \S*conv_strip_bf16_kernel" + frag + r"\S*\n(.*?)\.end_amdhsa_kernel", text, re.S)
         assert m, frag
@@ -79,15 +92,12 @@ def test_strip_kernels_do_not_spill(tmp_path):
 # and the one-wave-per-SIMD pair form keeps 36 weight fragments in registers: none of them may touch scratch (a `cond ? pk[2 + h] : pk[h]` on a register array
 # once did: 48 bytes per lane), and form E of the strip kernel (eight waves) keeps form D's register budget.
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="needs hipcc (cross-compiles without a GPU)")
-def test_round4_kernels_do_not_spill(tmp_path):
+def test_round4_kernels_do_not_spill(asm_dir):
     wants = {"conv_bf16_pair": [("conv1_pair_pc_bf16_kernel", 256, None), ("conv1_pair_bf16_kernelILi6E", 512, None), ("conv1_pair_bf16_kernelILi4E", 512, None)],
              "conv_bf16": [("conv_res_bf16_kernelILi2ELi4ELi4ELi6E", 256, None), ("conv_res_bf16_kernelILi1ELi8ELi4ELi4E", 256, None),
                            ("conv_strip_bf16_kernelILi1ELi5ELi4ELi2ELi1ELi3ELi0ELi1ELb1ELi8E", 256, 3 * 42 * 1024)]}
     for src, kernels in wants.items():
-        asm = str(tmp_path / (src + ".s"))
-        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"),
-                        "-I", CSRC, os.path.join(CSRC, src + ".hip"), "-o", asm], check=True, stderr=subprocess.DEVNULL)
-        text = open(asm).read()
+        text = open(asm_of(src, asm_dir)).read()
         for frag, max_regs, lds in kernels:
             m = re.search(r"\.amdhsa_kernel \S*" + frag + r"\S*\n(.*?)\.end_amdhsa_kernel", text, re.S)
             assert m, frag
