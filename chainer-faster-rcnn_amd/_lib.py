@@ -19,6 +19,9 @@ _S = ctypes.c_size_t
 SIGNATURES = {
     "frcnn_abi_version": (_I, []),
     "frcnn_device_count": (_I, []),
+    "frcnn_set_tuning": (_I, [ctypes.c_char_p, ctypes.c_char_p]),
+    "frcnn_get_tuning": (_I, [ctypes.c_char_p, ctypes.c_char_p, _I]),
+    "frcnn_reset_tuning": (_I, []),
     "frcnn_nms_workspace_bytes": (_S, [_I]),
     "frcnn_nms": (_I, [_P, _I, _D, _I, _P, _P, _P, _S, _P]),
     "frcnn_nms_batched_workspace_bytes": (_S, [_I, _I]),
@@ -144,6 +147,8 @@ def bind(path):
     # the reference's own C FFI (models/gpu_nms.hpp:9-10): void _nms(int*, int*, const float*, int, int, float, int)
     lib._nms.restype = None
     lib._nms.argtypes = [_P, ctypes.POINTER(ctypes.c_int), _P, _I, _I, _F, _I]
+    from . import tuning
+    tuning.register(lib)
     return lib
 
 

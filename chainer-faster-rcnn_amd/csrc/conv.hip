@@ -795,7 +795,7 @@ static int launch_conv(const float *x, const float *wp, const float *bias, float
     // (neighbouring tiles share halos in one L2) and of layers whose weights outweigh the map (conv5_x: 111 -> 53 MB);
     // stream-K layers with a large map fetch least with round-robin placement (161 MB vs 185 / 224 banded).
     // FRCNN_CONV_XCD=0/1/2 overrides.
-    static const int xcd_env = getenv("FRCNN_CONV_XCD") ? atoi(getenv("FRCNN_CONV_XCD")) : -1;
+    const int xcd_env = frcnn_tune_int("FRCNN_CONV_XCD", -1);
     if (!(relu & 768)) {
         const double map_bytes = 4.0 * Cin * H * W, w_bytes = 4.0 * KS * KS * Cin * Cout;
         const int order = xcd_env >= 0 ? xcd_env : ((p.G == p.ntiles || w_bytes >= map_bytes) ? 1 : 0);
@@ -836,7 +836,7 @@ static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows) {
     if (ntiles >= 4 * slots) return 34;
     // 128-cout tiles with four accumulators per wave (38, stream-K): -2 ... -4 % on the 300x500 ... 75x125 layers with >= 128 couts
     // (r03: conv3_2 348 -> 335 us, conv4_2 345 -> 333, conv2_2 345 -> 338); the 38x63 maps (80 such tiles) stay on 64-cout tiles
-    static const bool wide_off = getenv("FRCNN_CONV_WIDE") && getenv("FRCNN_CONV_WIDE")[0] == '0';      // A/B hook
+    const bool wide_off = frcnn_tune_is("FRCNN_CONV_WIDE", '0');      // A/B hook
     if (!wide_off && Cout % 128 == 0 && Cin >= 64 && (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4) * (Cout / 128) >= frcnn_cu_count()) return 238;
     if (two_rows) return 230;
     if (ntiles >= 2 * slots) return 46;            // same decomposition, 72 VGPRs: six workgroups per CU (+3 % on the 300x500 maps)
@@ -907,7 +907,7 @@ int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bi
     if (cfg < 0 && Cin <= 3 && Cout <= 64 && (relu == 0 || relu == 1) && (size_t)H * W * 64 * 4 < (1ull << 31)) {
         // the first layer (K = 27) has its own kernel (conv_f32s.hip): this one would write its 154 MB with 4-byte stores;
         // FRCNN_CONV1_F32=generic keeps this kernel on it (tests compare the two)
-        const char *form = getenv("FRCNN_CONV1_F32");
+        const char *form = frcnn_tune("FRCNN_CONV1_F32");
         if (!(form && form[0] == 'g')) return frcnn_conv1_f32(x, w_packed, bias, y, Cin, Cout, H, W, relu, stream_);
     }
     if (cfg < 0) cfg = pick_conv_config(Cin, Cout, H, W, false);
@@ -1043,7 +1043,7 @@ int frcnn_rpn_heads_f32(const float *h, int Cmid, int H, int W, int A, const flo
     const int NP = frcnn_rpn_heads_padded_channels(A);
     // one fused launch when the stacked heads fit one 64-channel block and the softmax fits its register tile (A <= 10: every
     // configuration of the reference); FRCNN_RPN_HEADS=conv keeps the two-launch form reachable (tests compare the two)
-    const char *form = getenv("FRCNN_RPN_HEADS");
+    const char *form = frcnn_tune("FRCNN_RPN_HEADS");
     if (NP == 64 && 2 * A <= 32 && (size_t)Cmid * H * W * 4 < (1ull << 31) && !(form && form[0] == 'c')) {
         hipLaunchKernelGGL(rpn_heads_fused_kernel, dim3(frcnn_cdiv(H * W, 32)), dim3(64 * kHeadWaves), 0, stream, h, w_packed, b_packed, raw,
                            cls_prob, Cmid, H * W, 2 * A);

@@ -589,7 +589,13 @@ conv_dma_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
     conv_bf16_epilogue<BROWS, 256, RW, COB>(acc, ring, bias, y, Cout, CoutP, H, W, relu, out_mode, x0, y0, co0);
 }
 
+// FRCNN_TUNING_FORMS (round 5): the forms that were measured and NOT adopted -- the resident producer / consumer kernels of
+// conv_bf16_res.h, strip forms A / B / E / 907 / 908, the ring depths and tile shapes of conv_dma_bf16_kernel that no default rule picks, the 8-wave
+// register-staged kernel -- are compiled only into the research builds (scripts/micro/build_micro.sh, the test emulator), not into libfrcnn_hip.so.
+// In the product library a request for one of them is FRCNN_ERR_INVALID.
+#ifdef FRCNN_TUNING_FORMS
 #include "conv_bf16_res.h"        // conv_res_bf16_kernel: resident weight slab, producer / consumer waves (FRCNN_BF16_DMA=921 / 922; round 4)
+#endif
 #include "conv_bf16_strip.h"      // conv_strip_bf16_kernel: one wave per SIMD, software-pipelined ring (forms D and C are default picks; FRCNN_BF16_DMA=900..909)
 
 // (Cout, Cin, k, k) fp32 -> [CinP/16][tap][CoutP][16] bf16, zero padded
@@ -755,7 +761,12 @@ static int conv_bf16_strip_resolve(int form, int CinP, int CoutP, int H, int W, 
     // {couts per workgroup, tile rows, K ways, MFMAs per wave and stage}
     static const int kForm[12][4] = {{0, 0, 0, 0}, {64, 20, 1, 90}, {64, 10, 1, 45}, {32, 5, 4, 45}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {64, 10, 2, 90}, {64, 12, 1, 54}, {64, 10, 1, 45}, {64, 10, 1, 45},
                                      {64, 20, 1, 45}};
-    auto applies = [&](int f) { return f >= 0 && f <= 11 && kForm[f][0] != 0 && chunks % kForm[f][2] == 0 && !(out_mode == 2 && (kForm[f][1] & 1)); };
+#ifdef FRCNN_TUNING_FORMS
+    auto built = [](int) { return true; };
+#else
+    auto built = [](int f) { return f == 3 || f == 9 || f == 10; };        // the default picks: form C, form D (LDS epilogue / direct stores)
+#endif
+    auto applies = [&](int f) { return f >= 0 && f <= 11 && kForm[f][0] != 0 && built(f) && chunks % kForm[f][2] == 0 && !(out_mode == 2 && (kForm[f][1] & 1)); };
     if (form == 0) {
         const long cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
         long best = -1;
@@ -785,9 +796,12 @@ static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed
 #endif
     (void)abl;
     switch (form) {
+#ifdef FRCNN_TUNING_FORMS
     case 1: conv_bf16_strip_go<2, 5, 4, 1, 1, 3>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
     case 2: conv_bf16_strip_go<1, 5, 2, 2, 1, 4>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
+#endif
     case 3: conv_bf16_strip_go<1, 5, 1, 1, 4, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
+#ifdef FRCNN_TUNING_FORMS
     // 907: 64 couts x 10 rows with the K loop split two ways over the waves (64 couts per wave: 0.43 fragment reads per MFMA instead of form B's 0.67;
     //      40.5 vs 39.9 us on conv4_2, not adopted)
     case 7: conv_bf16_strip_go<2, 5, 2, 1, 2, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
@@ -795,6 +809,7 @@ static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed
     // one-workgroup forms pay in the open on every tile of a launch of several rounds.  908: 64 couts x 12 rows (three rows per wave; 2-8 % behind 909),
     // 909 = form D: form B's waves -- the default pick of frcnn_conv_bf16_ws for launches with >= 8 K-chunks and >= one tile per CU
     case 8: conv_bf16_strip_go<2, 3, 4, 1, 1, 2, 0, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
+#endif
     case 9: conv_bf16_strip_go<1, 5, 2, 2, 1, 2, 0, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream); break;
     // 910: form D with the bf16 output of a launch without the fused pool stored straight from the accumulators (no LDS transpose, no barrier: conv3_1 / conv3_2 /
     //      conv4_2 25.4 / 41.7 / 41.7 -> 25.1 / 40.8 / 40.9 us, bit-identical; probe 9) -- what the default rule launches; pooled and fp32-NCHW launches take 909's epilogue
@@ -802,12 +817,14 @@ static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed
         if (out_mode == 0 && (size_t)CoutP * H * W * 2 < (1ull << 31)) conv_bf16_strip_go<1, 5, 2, 2, 1, 2, 0, 2, true>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
         else conv_bf16_strip_go<1, 5, 2, 2, 1, 2, 0, 2>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
         break;
+#ifdef FRCNN_TUNING_FORMS
     // 911 = form E (round 4): form A's tile -- 64 couts x 20 rows x 32 px -- on EIGHT of form D's waves (two per SIMD, one workgroup per CU, three 42 KB stages):
     //       the two waves of a SIMD share a stage's weight panel; 6 LDS-DMA pieces per wave and stage instead of 8.5
     case 11:
         if (out_mode == 0 && (size_t)CoutP * H * W * 2 < (1ull << 31)) conv_bf16_strip_go<1, 5, 4, 2, 1, 3, 0, 1, true, 8>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
         else conv_bf16_strip_go<1, 5, 4, 2, 1, 3, 0, 1, false, 8>(x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream);
         break;
+#endif
     default: return 1;
     }
     return 0;
@@ -821,20 +838,25 @@ static int conv_bf16_strip(int form, const uint16_t *x, const uint16_t *w_packed
 // either wave priority: with ONE multiplying wave per SIMD nothing covers that wave's own stalls at a chunk boundary (barrier, first fragments of the
 // next chunk), which two symmetric workgroups per CU (strip form D) cover for each other.  FRCNN_BF16_RES=1 opts in (A/B), FRCNN_BF16_DMA=921 / 922 selects one.
 static int conv_bf16_default_res_form(int CinP, int CoutP, int H, int W, int out_mode) {
-    const char *re = getenv("FRCNN_BF16_RES");
-    if (!re || re[0] != '1' || getenv("FRCNN_BF16_RP") || getenv("FRCNN_BF16_DMA_DEFAULT") || getenv("FRCNN_BF16_SPLIT")) return 0;
+#ifndef FRCNN_TUNING_FORMS
+    (void)CinP; (void)CoutP; (void)H; (void)W; (void)out_mode;
+    return 0;
+#else
+    const char *re = frcnn_tune("FRCNN_BF16_RES");
+    if (!re || re[0] != '1' || frcnn_tune("FRCNN_BF16_RP") || frcnn_tune("FRCNN_BF16_DMA_DEFAULT") || frcnn_tune("FRCNN_BF16_SPLIT")) return 0;
     if (out_mode != 0 && out_mode != 2) return 0;
     const long cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
     if (CinP == 64 && (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 8) * frcnn_cdiv(CoutP, 64) >= 2 * cus) return 21;
     if (CinP == 128 && (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 16) * frcnn_cdiv(CoutP, 32) >= 2 * cus) return 22;
     return 0;
+#endif
 }
 
 static int conv_bf16_default_strip_form(int CinP, int CoutP, int H, int W, int out_mode) {
-    const char *rp_env = getenv("FRCNN_BF16_RP");
+    const char *rp_env = frcnn_tune("FRCNN_BF16_RP");
     if (rp_env && atoi(rp_env) == 4) return 0;
-    if (CinP / kCK < 8 || getenv("FRCNN_BF16_DMA_DEFAULT") || getenv("FRCNN_BF16_SPLIT")) return 0;
-    const char *se = getenv("FRCNN_BF16_STRIP");
+    if (CinP / kCK < 8 || frcnn_tune("FRCNN_BF16_DMA_DEFAULT") || frcnn_tune("FRCNN_BF16_SPLIT")) return 0;
+    const char *se = frcnn_tune("FRCNN_BF16_STRIP");
     if (se && se[0] == '0') return 0;
     const long cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
     const long wgs_d = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 10) * frcnn_cdiv(CoutP, 64);
@@ -879,7 +901,7 @@ int frcnn_bf16_from_nchw_f32(const float *x, int C, int H, int W, uint16_t *y, v
 // keeps the path reachable for other shapes (it is exercised by the emulator and GPU tests).
 static int conv_bf16_pick_split(long tiles, int chunks) {
     (void)tiles;
-    const char *e = getenv("FRCNN_BF16_SPLIT");
+    const char *e = frcnn_tune("FRCNN_BF16_SPLIT");
     int s = e ? atoi(e) : 1;
     if (s != 2 && s != 4) s = 1;
     while (s > 1 && chunks / s < 4) s >>= 1;                      // a split should still carry a few chunks
@@ -910,8 +932,13 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
     const int xtiles = frcnn_cdiv(W, 32), cotiles = frcnn_cdiv(CoutP, 64);
     // 8-row tiles (8 waves) carry 1.7x the MFMA work per staged byte but measured no faster than 4-row tiles on any VGG layer
     // (scripts/conv_bf16_sweep.py, r01); kept as a tuning hook: FRCNN_BF16_RP=4 selects them.
-    const char *rp_env = getenv("FRCNN_BF16_RP");
+    const char *rp_env = frcnn_tune("FRCNN_BF16_RP");
+#ifdef FRCNN_TUNING_FORMS
     const bool big = rp_env && atoi(rp_env) == 4;
+#else
+    if (rp_env && atoi(rp_env) == 4) return FRCNN_ERR_INVALID;     // the 8-wave register-staged kernel: research builds only
+    constexpr bool big = false;
+#endif
     const int ytiles = frcnn_cdiv(H, big ? 8 : 4);
     const dim3 grid(xtiles * ytiles * cotiles);
     // 3x3: LDS-DMA staging.  Launches with at least four tiles per CU run single-stage rings -- 25 KB of LDS per workgroup, up to six
@@ -920,7 +947,7 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
     // (scripts/conv_bf16_sweep.py, r01: +20...45 % over register staging on every VGG layer).  FRCNN_BF16_DMA overrides
     // (digits = ring stages, waves/SIMD budget, row pairs per wave; 0 = the register-staged kernel; 4-digit values = timing ablations,
     // compiled only with FRCNN_TIMING_ABLATIONS).
-    const char *dma_env = getenv("FRCNN_BF16_DMA");
+    const char *dma_env = frcnn_tune("FRCNN_BF16_DMA");
     int mode = dma_env ? atoi(dma_env) : -1;
     // Default pick, first rule (measured on the MI355X, profiles/r03_conv_bf16_strip_micro.txt; same box, us, strip form vs conv_dma_bf16_kernel's
     // best mode): a launch with at least 8 K-chunks and at least one 64-cout x 10-row x 32-px tile per CU runs as strip form D (two workgroups
@@ -932,18 +959,24 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
     // conv3_2 / conv4_2) stay selectable (901, 902).  FRCNN_BF16_STRIP=0 switches the rule off (A/B measurements); the tuning hooks that
     // select a kernel family (FRCNN_BF16_RP, FRCNN_BF16_DMA_DEFAULT, FRCNN_BF16_SPLIT) keep their meaning.
     if (ksize == 3 && mode < 0) {
+#ifdef FRCNN_TUNING_FORMS
         const int rform = conv_bf16_default_res_form(CinP, CoutP, H, W, out_mode);
         if (rform && conv_bf16_res(rform, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream) == 0) return frcnn_launch_status();
+#endif
         const int form = conv_bf16_default_strip_form(CinP, CoutP, H, W, out_mode);
         if (form && conv_bf16_strip(form, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream) == 0) return frcnn_launch_status();
     }
     if (ksize == 3 && (mode == 921 || mode == 922)) {              // an explicitly requested resident form (its fp32-NCHW output: conv_dma_bf16_kernel's picks)
+#ifdef FRCNN_TUNING_FORMS
         if (conv_bf16_res(mode - 900, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream) == 0) return frcnn_launch_status();
         if (out_mode != 1) return FRCNN_ERR_INVALID;
         mode = -1;
+#else
+        return FRCNN_ERR_INVALID;                                  // research builds only
+#endif
     }
     if (ksize == 3 && mode >= 9010 && mode <= 9039) {             // 90<form><ablation> (FRCNN_TIMING_ABLATIONS builds; else the plain form)
-        const char *ae = getenv("FRCNN_BF16_STRIP_ABL");
+        const char *ae = frcnn_tune("FRCNN_BF16_STRIP_ABL");
         return conv_bf16_strip((mode - 9000) / 10, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, stream, ae ? atoi(ae) : mode % 10) == 0
                    ? frcnn_launch_status() : FRCNN_ERR_INVALID;
     }
@@ -956,7 +989,7 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
     // tile rows / accumulators per thread of the DMA kernel's shapes (RPW = last digit of the mode): 64 couts x {4, 8, 8, 16} rows x 32 px
     static const int kRowsOf[5] = {0, 4, 8, 8, 16}, kAccOf[5] = {0, 2, 4, 4, 8};
     if (mode < 0) {
-        const char *def_env = getenv("FRCNN_BF16_DMA_DEFAULT");       // "<big launches>,<small launches>", e.g. 224,223 (tuning hook)
+        const char *def_env = frcnn_tune("FRCNN_BF16_DMA_DEFAULT");       // "<big launches>,<small launches>", e.g. 224,223 (tuning hook)
         int big_mode = 141, small_mode = 231;
         if (def_env) {
             big_mode = atoi(def_env);
@@ -988,11 +1021,14 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
     }
     float *partials = nsplit > 1 ? (float *)((char *)workspace + kBf16CounterPageBytes) : nullptr;
     int *counters = nsplit > 1 ? (int *)workspace : nullptr;
+#ifdef FRCNN_TUNING_FORMS
     if (ksize == 3 && big) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3, 4>), grid, dim3(512), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles);
-    else if (ksize == 3 && mode > 0) {
+    else
+#endif
+    if (ksize == 3 && mode > 0) {
         dim3 dgrid((unsigned)(dma_tiles * nsplit));
         int xcd_cotiles = 0;
-        const char *xcd_env = getenv("FRCNN_BF16_XCD");               // 1 enables: measured 1.5 % SLOWER on the VGG chain here (r02n), so off
+        const char *xcd_env = frcnn_tune("FRCNN_BF16_XCD");               // 1 enables: measured 1.5 % SLOWER on the VGG chain here (r02n), so off
         if ((cotiles == 1 || cotiles == 2 || cotiles == 4 || cotiles == 8) && xcd_env && xcd_env[0] == '1') {
             xcd_cotiles = cotiles;
             dgrid = dim3((unsigned)(8 * frcnn_cdiv((int)((long)xtiles * yt * nsplit), 8 / cotiles)));
@@ -1008,10 +1044,13 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
                            Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, 1, nullptr, nullptr, 0);                                    \
         break;
         switch (mode) {
-            FRCNN_DMA_CASE(3, 2, 1) FRCNN_DMA_CASE(2, 3, 1) FRCNN_DMA_CASE(1, 4, 1) FRCNN_DMA_CASE(1, 3, 2) FRCNN_DMA_CASE(2, 2, 2)
+            FRCNN_DMA_CASE(2, 3, 1) FRCNN_DMA_CASE(1, 4, 1) FRCNN_DMA_CASE(1, 3, 2)          // 231 / 141 / 132: the measured picks of the default rule below
+#ifdef FRCNN_TUNING_FORMS
+            FRCNN_DMA_CASE(3, 2, 1) FRCNN_DMA_CASE(2, 2, 2)
             FRCNN_DMA_CASE(3, 1, 1) FRCNN_DMA_CASE(4, 1, 1) FRCNN_DMA_CASE(5, 1, 1) FRCNN_DMA_CASE(6, 1, 1)
             FRCNN_DMA_CASE(2, 2, 3) FRCNN_DMA_CASE(2, 3, 3) FRCNN_DMA_CASE(3, 2, 3) FRCNN_DMA_CASE(2, 2, 4) FRCNN_DMA_CASE(3, 2, 4)
             FRCNN_DMA_CASE(1, 2, 4) FRCNN_DMA_CASE(1, 3, 3)
+#endif
 #ifdef FRCNN_TIMING_ABLATIONS                                                                       // WRONG results: sweeps only, never shipped
             FRCNN_DMA_ABL(1, 4, 1) FRCNN_DMA_ABL(1, 4, 4) FRCNN_DMA_ABL(2, 3, 1) FRCNN_DMA_ABL(2, 3, 4)
 #endif
@@ -1021,7 +1060,7 @@ int frcnn_conv_bf16_ws(const uint16_t *x, const uint16_t *w_packed, const float 
 #undef FRCNN_DMA_ABL
     }
     else if (ksize == 3) {
-        const char *abl_env = getenv("FRCNN_BF16_ABL");
+        const char *abl_env = frcnn_tune("FRCNN_BF16_ABL");
         const int abl = abl_env ? atoi(abl_env) : 0;
 #define FRCNN_ABL_CASE(A) case A: hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_mfma_bf16_kernel<3, 2, A>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles); break;
         switch (abl) {
@@ -1055,16 +1094,22 @@ int frcnn_conv_bf16_plan(int Cin, int Cout, int H, int W, int ksize, int out_mod
     if (Cin < 1 || Cout < 1 || H < 1 || W < 1 || (ksize != 1 && ksize != 3) || out_mode < 0 || out_mode > 2) return FRCNN_ERR_INVALID;
     if (ksize != 3) return 0;
     const int CinP = frcnn_bf16_padded_channels(Cin), CoutP = frcnn_bf16_padded_channels(Cout);
-    const char *dma_env = getenv("FRCNN_BF16_DMA");
+    const char *dma_env = frcnn_tune("FRCNN_BF16_DMA");
     const int mode = dma_env ? atoi(dma_env) : -1;
     // the same three branches as frcnn_conv_bf16_ws, through the same resolver: what is returned is the form that would be LAUNCHED
     if (mode == 921 || mode == 922) {
-        const bool shape = (mode == 921 && CinP == 64) || (mode == 922 && CinP == 128);
-        return (shape && out_mode != 1) ? mode : ((shape || out_mode == 1) && out_mode == 1 ? 0 : FRCNN_ERR_INVALID);
+#ifdef FRCNN_TUNING_FORMS
+        if (conv_bf16_res_applies(mode - 900, CinP, CoutP, H, W, out_mode)) return mode;
+        return out_mode == 1 ? 0 : FRCNN_ERR_INVALID;             // (its fp32-NCHW output takes conv_dma_bf16_kernel's picks; anything else it declines is refused)
+#else
+        return FRCNN_ERR_INVALID;                                  // research builds only
+#endif
     }
     if (mode < 0) {
+#ifdef FRCNN_TUNING_FORMS
         const int rform = conv_bf16_default_res_form(CinP, CoutP, H, W, out_mode);
-        if (rform) return 900 + rform;
+        if (rform && conv_bf16_res_applies(rform, CinP, CoutP, H, W, out_mode)) return 900 + rform;
+#endif
         const int pick = conv_bf16_default_strip_form(CinP, CoutP, H, W, out_mode);
         const int form = pick ? conv_bf16_strip_resolve(pick, CinP, CoutP, H, W, out_mode) : 0;
         return form ? 900 + form : 0;
@@ -1338,7 +1383,7 @@ int frcnn_linear_bf16(const uint16_t *x, const uint16_t *w, const float *bias, v
     if (!workspace || workspace_bytes < (size_t)p.splits * M * N * sizeof(float)) return FRCNN_ERR_INVALID;
     float *part = (float *)workspace;
     const dim3 grid(p.nblocks, p.mblocks, p.splits);
-    const bool dma = (K % kLBK) == 0 && (p.k_per_split % kLBK) == 0 && !getenv("FRCNN_LINEAR_NODMA");
+    const bool dma = (K % kLBK) == 0 && (p.k_per_split % kLBK) == 0 && !frcnn_tune("FRCNN_LINEAR_NODMA");
     if (dma && p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_bf16_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     else if (dma && p.am == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_bf16_kernel<3>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     else if (dma) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_bf16_kernel<1>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);

@@ -720,18 +720,21 @@ int frcnn_conv1_pair_bf16(const float *x, const float *w1, const float *b1, cons
     const int xtiles = frcnn_cdiv(W, 32);
     const int cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
     // FRCNN_BF16_PAIR_FORM=1: the one-wave-per-SIMD form (weights in registers; FRCNN_BF16_PAIR_RW = 4 | 6 rows per wave) -- kept for A/B measurements
-    const char *fe = getenv("FRCNN_BF16_PAIR_FORM");
+    const char *fe = frcnn_tune("FRCNN_BF16_PAIR_FORM");
     if (!fe || atoi(fe) != 1) {
         const int ntiles = xtiles * frcnn_cdiv(H, Pair2::TR);
         // which half of a SIMD's wave pair issues first when both are ready (s_setprio): measured on the MI355X (profiles/r04_conv_pair_micro.txt) the
         // PRODUCERS first is the faster arrangement -- the MFMA stream loses ~8 % of its own pace and the tile ~15 % of its wait for the next image
-        const char *pe = getenv("FRCNN_BF16_PAIR_PRIO");
+        const char *pe = frcnn_tune("FRCNN_BF16_PAIR_PRIO");
         const int prio = pe ? atoi(pe) : 2;
         hipLaunchKernelGGL(conv1_pair_pc_bf16_kernel, dim3((unsigned)(ntiles < cus ? ntiles : cus)), dim3(512), 0, (hipStream_t)stream, x, w1, b1, w2_packed, b2, y,
                            Cin, H, W, xtiles, ntiles, prio);
         return frcnn_launch_status();
     }
-    const char *e = getenv("FRCNN_BF16_PAIR_RW");
+#ifndef FRCNN_TUNING_FORMS
+    return FRCNN_ERR_INVALID;                                       // form 1 (70 us = no gain): research builds only
+#else
+    const char *e = frcnn_tune("FRCNN_BF16_PAIR_RW");
     const int rw = e ? atoi(e) : 6;
     if (rw == 4) {
         const int ntiles = xtiles * frcnn_cdiv(H, 8);
@@ -743,6 +746,7 @@ int frcnn_conv1_pair_bf16(const float *x, const float *w1, const float *b1, cons
                            w2_packed, b2, y, Cin, H, W, xtiles, ntiles);
     } else return FRCNN_ERR_INVALID;
     return frcnn_launch_status();
+#endif
 }
 
 }  // extern "C"

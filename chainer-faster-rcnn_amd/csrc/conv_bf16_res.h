@@ -281,11 +281,22 @@ conv_res_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict_
 }
 
 // launch: 910 + form: 921 = form R (Cin 64, 64 couts per workgroup), 922 = form R2 (Cin 128, 32 couts per workgroup).  Returns 1 when the form does not apply.
+// ONE place for "does the resident form apply to this launch" -- the launcher and frcnn_conv_bf16_plan both ask it (the plan query used to
+// answer from the channel count alone and could name a kernel the launcher then declined)
+static bool conv_bf16_res_applies(int form, int CinP, int CoutP, int H, int W, int out_mode) {
+    if (out_mode != 0 && out_mode != 2) return false;
+    if ((size_t)CoutP * H * W * 2 >= (1ull << 31) || (size_t)CinP * H * W * 2 >= (1ull << 31)) return false;
+    if (!((form == 21 && CinP == 64) || (form == 22 && CinP == 128))) return false;
+    const int cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
+    const int bco = form == 21 ? ResShape<2, 4, 4, 6>::BCO : ResShape<1, 8, 4, 4>::BCO, tr = form == 21 ? ResShape<2, 4, 4, 6>::TR : ResShape<1, 8, 4, 4>::TR;
+    const int cotiles = frcnn_cdiv(CoutP, bco), ntiles = frcnn_cdiv(W, 32) * frcnn_cdiv(H, tr) * cotiles;
+    const int grid = ntiles < cus ? ntiles : (cus / cotiles > 0 ? cus / cotiles * cotiles : cotiles);
+    return grid >= 1 && grid % cotiles == 0;
+}
 static int conv_bf16_res(int form, const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int CinP, int Cout, int CoutP, int H, int W, int relu,
                          int out_mode, hipStream_t stream) {
-    if (out_mode != 0 && out_mode != 2) return 1;
-    if ((size_t)CoutP * H * W * 2 >= (1ull << 31) || (size_t)CinP * H * W * 2 >= (1ull << 31)) return 1;
-    const char *pe = getenv("FRCNN_BF16_RES_PRIO");
+    if (!conv_bf16_res_applies(form, CinP, CoutP, H, W, out_mode)) return 1;
+    const char *pe = frcnn_tune("FRCNN_BF16_RES_PRIO");
     const int prio = pe ? atoi(pe) : 0;
     const int cus = frcnn_cu_count() > 0 ? frcnn_cu_count() : 256;
     const int xtiles = frcnn_cdiv(W, 32);

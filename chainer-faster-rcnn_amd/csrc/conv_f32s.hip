@@ -801,9 +801,9 @@ int frcnn_f32s_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, voi
 // persistent first-layer launch: as many workgroups as the chip seats at once (2 per CU for the split form, 4 for the bf16 form, 3
 // for the fp32 form: the kernels' __launch_bounds__), each strides over the tiles
 static int conv1_grid(int ntiles, bool split, int seats = 0) {
-    const char *e = getenv("FRCNN_CONV1_WGS_PER_CU");
+    const char *e = frcnn_tune("FRCNN_CONV1_WGS_PER_CU");
     const int per_cu = e && atoi(e) > 0 ? atoi(e) : (seats > 0 ? seats : (split ? 2 : 4));
-    const char *g = getenv("FRCNN_CONV1_GRID");                        // tests: an exact workgroup count (the strided tile loop on small images)
+    const char *g = frcnn_tune("FRCNN_CONV1_GRID");                        // tests: an exact workgroup count (the strided tile loop on small images)
     const long slots = g && atoi(g) > 0 ? atoi(g) : (long)frcnn_cu_count() * per_cu;
     return (int)(ntiles < slots ? ntiles : slots);
 }
@@ -865,7 +865,7 @@ constexpr long kF32sMaxSplitTiles = 2048;     // launches with more tiles than t
 // so a thin last round costs far less than the slot count suggests, and every split pays its own prologue and partial tile.
 // (FRCNN_F32S_SPLIT overrides.)
 static int conv_f32s_pick_split(long tiles, int chunks) {
-    const char *e = getenv("FRCNN_F32S_SPLIT");
+    const char *e = frcnn_tune("FRCNN_F32S_SPLIT");
     int s = e ? atoi(e) : (int)((2L * frcnn_cu_count()) / (tiles > 0 ? tiles : 1));
     if (tiles > kF32sMaxSplitTiles && !e) s = 1;
     // a launch that fills the slots once and leaves a thin second round (conv4_2/3: 608 tiles) gains 5 % from two splits when its
@@ -911,12 +911,12 @@ static int conv3x3_f32s_launch(const uint16_t *x, const uint16_t *w_packed, cons
     int xcd_cotiles = 0;
     // 1 enables.  Four back-to-back launches of one layer gain 5-10 % from it (r02j), the real 14-layer chain nothing (r02o: 2.131 vs
     // 2.142 ms) -- between different layers the slabs are cold either way -- so the plain order stays the default
-    const char *xcd_env = getenv("FRCNN_F32S_XCD");
+    const char *xcd_env = frcnn_tune("FRCNN_F32S_XCD");
     if ((cotiles == 1 || cotiles == 2 || cotiles == 4 || cotiles == 8) && xcd_env && xcd_env[0] == '1') {
         xcd_cotiles = cotiles;
         grid = dim3((unsigned)(8 * frcnn_cdiv(xtiles * ytiles * nsplit, 8 / cotiles)));
     }
-    const char *abl_env = getenv("FRCNN_F32S_ABL");
+    const char *abl_env = frcnn_tune("FRCNN_F32S_ABL");
     const int abl = abl_env ? atoi(abl_env) : 0;
 #define FRCNN_F32S_LAUNCH(...) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_f32s_kernel<__VA_ARGS__>), grid, dim3(256), 0, stream, x, w_packed, bias, y, CinP, Cout, CoutP, H, W, relu, out_mode, xtiles, ytiles, nsplit, partials, counters, xcd_cotiles, y_nchw, mask)
     switch (abl) {

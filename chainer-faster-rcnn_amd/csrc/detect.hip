@@ -781,7 +781,7 @@ struct Layout {   // carve-up of the caller's workspace (per group)
 
 // FRCNN_NMS_SCAN=1: the one-chunk-per-trip single-wave scan of round 1 (A/B measurements); default: four chunks per trip
 static bool scan_one_chunk_per_trip() {
-    const char *e = getenv("FRCNN_NMS_SCAN");
+    const char *e = frcnn_tune("FRCNN_NMS_SCAN");
     return e && e[0] == '1';
 }
 
@@ -790,7 +790,7 @@ static int mask_blocks(int lo, int hi) { return (int)(((long long)hi * (hi + 1) 
 // first-stage width of a staged NMS: 4 x post_nms_top_n boxes (a greedy NMS that keeps `limit` boxes has usually done so long before
 // it has looked at 4 x limit of them: 610 of 6000 on the benchmark image); 0 = one stage
 static int nms_stage_chunks(int pitch, int max_out) {
-    const char *e = getenv("FRCNN_NMS_STAGE");
+    const char *e = frcnn_tune("FRCNN_NMS_STAGE");
     if (e && e[0] == '0') return 0;
     if (max_out <= 0) return 0;
     const int s = (4 * max_out + kChunk - 1) / kChunk;
@@ -799,7 +799,7 @@ static int nms_stage_chunks(int pitch, int max_out) {
 
 // workgroups of a second-stage mask launch (FRCNN_NMS_TAIL_WGS overrides: A/B measurements)
 static int nms_tail_workgroups() {
-    const char *e = getenv("FRCNN_NMS_TAIL_WGS");
+    const char *e = frcnn_tune("FRCNN_NMS_TAIL_WGS");
     const int v = e ? atoi(e) : 0;
     return v > 0 ? v : 4 * frcnn_cu_count();
 }

@@ -68,6 +68,28 @@ __device__ __forceinline__ uint2 frcnn_buf_load_b64(frcnn_buf_t b, uint32_t byte
     const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(b, (int)byte_off, 0, 0);
     return make_uint2(v.x, v.y);
 }
+// 8-byte load at (per-lane offset, range-checked) + (wave-uniform scalar offset, added after the check)
+__device__ __forceinline__ uint2 frcnn_buf_load_b64_soff(frcnn_buf_t b, uint32_t byte_off, uint32_t soff) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(b, (int)byte_off, (int)soff, 0);
+    return make_uint2(v.x, v.y);
+}
+// streaming reads with a cache policy: AUX as in the stores (1 = sc0, 2 = nt, 16 = sc1) -- for bytes that are read exactly once
+template <int AUX>
+__device__ __forceinline__ float frcnn_buf_load_f32_soff_aux(frcnn_buf_t b, uint32_t byte_off, uint32_t soff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(b, (int)byte_off, (int)soff, AUX));
+}
+template <int AUX>
+__device__ __forceinline__ float4 frcnn_buf_load_f32x4_soff_aux(frcnn_buf_t b, uint32_t byte_off, uint32_t soff) {
+    const frcnn_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(b, (int)byte_off, (int)soff, AUX);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+template <int AUX>
+__device__ __forceinline__ uint2 frcnn_buf_load_b64_soff_aux(frcnn_buf_t b, uint32_t byte_off, uint32_t soff) {
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t v = __builtin_amdgcn_raw_buffer_load_b64(b, (int)byte_off, (int)soff, AUX);
+    return make_uint2(v.x, v.y);
+}
 // 8-byte store at (per-lane offset, range-checked) + (wave-uniform scalar offset), cache policy AUX (16 = sc1 write-through) as a template argument
 template <int AUX>
 __device__ __forceinline__ void frcnn_buf_store_b64_soff(frcnn_buf_t b, uint32_t byte_off, uint32_t soff, uint2 v) {

@@ -5,6 +5,7 @@
 #include <stddef.h>
 
 #include "frcnn_hip.h"
+#include "frcnn_tune.h"
 
 #define FRCNN_WAVE 64
 

@@ -81,10 +81,13 @@ __device__ __forceinline__ float frcnn_lane_xor1_f32(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));
 }
 
-// max(v, value of lane ^ 1) as ONE instruction: v_max_f32 with the DPP modifier on its first source (quad_perm [1,0,3,2])
+// max(v, value of lane ^ 1) as ONE instruction: v_max_f32 with the DPP modifier on its first source (quad_perm [1,0,3,2]).  The ISA wants two
+// wait states between a VALU write of a VGPR and a DPP read of it, and the compiler's hazard recognizer sees neither a DPP read inside an asm
+// string nor (as the producer) a VALU write inside one -- so the wait states are part of the string (the bare instruction sat ONE
+// s_nop behind its producer in conv1_pair_pc_bf16_kernel).  tests/test_isa_waits.py checks every DPP read of the library's listings.
 __device__ __forceinline__ float frcnn_max_lane_xor1_f32(float v) {
     float r;
-    asm("v_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
     return r;
 }
 

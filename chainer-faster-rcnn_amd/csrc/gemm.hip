@@ -277,7 +277,7 @@ int frcnn_linear_f32(const float *x, const float *w, const float *bias, float *y
     if (!workspace || workspace_bytes < (size_t)p.splits * M * N * sizeof(float)) return FRCNN_ERR_INVALID;
     float *part = (float *)workspace;
     const dim3 grid(p.nblocks, p.mblocks, p.splits);
-    const bool dma = (K % kBK) == 0 && (size_t)M * K * 4 < (1ull << 31) && (size_t)N * K * 4 < (1ull << 31) && !getenv("FRCNN_LINEAR_NODMA");
+    const bool dma = (K % kBK) == 0 && (size_t)M * K * 4 < (1ull << 31) && (size_t)N * K * 4 < (1ull << 31) && !frcnn_tune("FRCNN_LINEAR_NODMA");
     if (dma && p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_f32_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     else if (dma && p.am == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_f32_kernel<3>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     else if (dma) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_f32_kernel<1>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);

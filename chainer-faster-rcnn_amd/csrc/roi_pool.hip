@@ -1249,77 +1249,91 @@ roi_pool_bwd_kernel(const float *__restrict__ dy, const int32_t *__restrict__ ar
     }
 }
 
-// Backward, plane-resident (round 3): dx[c, argmax] += dy for every (roi, c, bin) with argmax >= 0 (Chainer backward_cpu).  One workgroup
-// owns FOUR channels of dx as planar fp32 accumulators in LDS (38 KB for the 38 x 63 map), streams the dy / argmax runs of all RoIs for
-// those channels (784 contiguous bytes per RoI: 16 bytes per lane, fully coalesced), adds into the LDS cells and writes its four
-// planes out once -- no memset of dx, no global atomics, each dy / argmax byte read once, each dx byte written once (65.1 MB).
-// The summation order over RoIs differs from the reference's loop only in rounding (as with the global atomics before).
-constexpr int kBwdWaves = 16;
-constexpr int kBwdMaxPlane = 38 * 64;      // floats per channel plane the LDS image holds (4 planes: 38.9 KB)
-__global__ void __launch_bounds__(64 * kBwdWaves)
-roi_pool_bwd_planes_kernel(const float *__restrict__ dy, const int32_t *__restrict__ argmax, int R, int C, int HW, int bins,
-                           float *__restrict__ dx, int dbg_arg) {
-#ifdef FRCNN_TIMING_ABLATIONS                    // tuning builds only: 1 plain read-modify-write, 2 integer atomics, 4 no LDS update (WRONG results), 8 ds_add_f32
-    const int dbg = dbg_arg;
-#else
-    constexpr int dbg = 0;
-    (void)dbg_arg;
-#endif
-    __shared__ __attribute__((aligned(16))) float planes[4 * kBwdMaxPlane];
+// Backward, plane-resident: dx[c, argmax] += dy for every (roi, c, bin) with argmax >= 0 (Chainer backward_cpu).  One workgroup owns NCH channels of
+// dx as planar fp32 accumulators in LDS, streams the dy / argmax runs of all RoIs for those channels, adds into the LDS cells and writes its planes
+// out once -- no memset of dx, no global atomics, each dy / argmax byte read once, each dx byte written once (65.1 MB).  The adds are compare-and-swap
+// loops on the LDS cells: the LDS's INTEGER atomics run at full rate on this chip, ds_add_f32 does not (78 us with it in round 3).  The summation
+// order over RoIs differs from the reference's loop only in rounding (test bar 1e-4).
+// Round 5 (25.9 -> 17.0 us on the 300 x 512 x 7 x 7 case, scripts/micro/roi_micro, profiles/r05_roi_micro.txt):
+//  * NCH = 2 channels per workgroup instead of four: 256 workgroups for the 512-channel map -- the four-channel launch left half the CUs without a
+//    workgroup and was bound by what 128 CUs can pull (its "no update" ablation cost the same 26 us).  A lane owns NCH consecutive floats of the
+//    RoI's (NCH x bins)-float run: 392 contiguous bytes, one 8-byte load per lane.  (NCH = 1, 512 workgroups of 196-byte runs: 25-27 us.)
+//  * a wave issues the loads of DEPTH = 5 RoIs (ten loads) before it touches the first value.  MORE in flight is slower, not faster: DEPTH 10 / 20
+//    21.4 / 23.8 us against 19.1; the next step's loads issued before the current step's adds (two register sets) 20.8; the adds of a step as one
+//    batch of LDS reads + one batch of swaps 22.1; both 24.2; the first step's loads before the planes are zeroed 19.3 against 18.2.  Ten loads per
+//    wave are already 16 MB in flight chip-wide -- queueing, not latency, is what a wave waits for, and a deeper queue only disorders the stream.
+//  * workgroups are dealt to the eight XCDs round-robin; the XCD-major mapping gives the workgroups of ONE XCD consecutive channel pairs, so the
+//    pieces that share a 128-byte line (a 392-byte piece starts and ends inside one) and a RoI's whole 12.5 KB stretch meet in one L2: 19.1 -> 18.2;
+//  * the reads are non-temporal (read once: nothing of them should stay in the L2): 18.2 -> 17.6, and depth stops mattering (17.6-17.8 for 5..10);
+//  * the planes leave as write-through stores (they drain while other workgroups still stream instead of after the last wave): 17.7 -> 17.05.
+constexpr int kBwdMaxPlane = 38 * 64;      // floats per channel plane the LDS image holds
+template <int NCH, int DEPTH, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES)
+roi_pool_bwd_runs_kernel(const float *__restrict__ dy, const int32_t *__restrict__ argmax, int R, int C, int HW, int bins,
+                         float *__restrict__ dx) {
+    __shared__ __attribute__((aligned(16))) float planes[NCH * kBwdMaxPlane];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int c0 = blockIdx.x * 4;
-    const int run = 4 * bins;                                              // floats per RoI for this workgroup (C % 4 == 0, run % 4 == 0: host)
-    for (int i = tid; i < 4 * HW; i += 64 * kBwdWaves) planes[i] = 0.0f;
+    int grp = blockIdx.x;
+    if ((gridDim.x & 7) == 0) grp = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);          // XCD-major (see above)
+    const int c0 = grp * NCH;
+    for (int i = tid; i < NCH * HW; i += 64 * WAVES) planes[i] = 0.0f;
     __syncthreads();
-    // lane l owns the floats 4 l .. 4 l + 3 of a run; their channels are loop-invariant
-    const int n4 = run / 4;
-    int ch[4];
+    int ch[NCH];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ch[i] = min((4 * lane + i) / bins, 3) * HW;
-    const frcnn_buf_t dbuf = frcnn_make_buf(dy, (uint32_t)((size_t)R * C * bins * sizeof(float)));
-    const frcnn_buf_t abuf = frcnn_make_buf(argmax, (uint32_t)((size_t)R * C * bins * sizeof(float)));
-    const uint32_t voff = lane < n4 ? (uint32_t)(lane * 16) : kBufOob;
+    for (int i = 0; i < NCH; ++i) ch[i] = min((NCH * lane + i) / bins, NCH - 1) * HW;
+    const uint32_t total_bytes = (uint32_t)((size_t)R * C * bins * sizeof(float));
+    const frcnn_buf_t dbuf = frcnn_make_buf(dy, total_bytes), abuf = frcnn_make_buf(argmax, total_bytes);
+    const bool own = lane < bins;
+    const uint32_t voff = own ? (uint32_t)(lane * 4 * NCH) : kBufOob;
     const uint32_t roi_bytes = (uint32_t)(C * bins) * 4u, c0_bytes = (uint32_t)(c0 * bins) * 4u;
-    // two RoIs per step: four 16-byte loads in flight per lane before the first atomic
+    constexpr int kNt = 2;                                                  // buffer-load cache policy: non-temporal
 #pragma unroll 1
-    for (int r = 2 * wave; r < R; r += 2 * kBwdWaves) {
-        const uint32_t s0 = (uint32_t)r * roi_bytes + c0_bytes, s1 = s0 + roi_bytes;
-        const bool two = r + 1 < R;
-        const float4 g0 = frcnn_buf_load_f32x4_soff(dbuf, voff, s0), a0 = frcnn_buf_load_f32x4_soff(abuf, voff, s0);
-        const float4 g1 = frcnn_buf_load_f32x4_soff(dbuf, two ? voff : kBufOob, s1), a1 = frcnn_buf_load_f32x4_soff(abuf, two ? voff : kBufOob, s1);
-        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const int av[8] = {__float_as_int(a0.x), __float_as_int(a0.y), __float_as_int(a0.z), __float_as_int(a0.w),
-                           __float_as_int(a1.x), __float_as_int(a1.y), __float_as_int(a1.z), __float_as_int(a1.w)};
+    for (int r0 = wave; r0 < R; r0 += DEPTH * WAVES) {
+        float gv[DEPTH][NCH];
+        int av[DEPTH][NCH];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (lane < n4 && (i < 4 || two) && av[i] >= 0) {
-                float *cell = &planes[ch[i & 3] + av[i]];
-                if (dbg & 1) *cell += gv[i];
-                else if (dbg & 2) atomicAdd(reinterpret_cast<int *>(cell), __float_as_int(gv[i]));
-                else if (dbg & 4) { if (gv[i] == 12345.678f) *cell = 1.f; }
-                else if (dbg & 8) atomicAdd(cell, gv[i]);
-                else {
-                    // fp32 add as a compare-and-swap loop on the cell: the LDS's INTEGER atomics run at full rate, ds_add_f32 does not
-                    // (measured on this kernel: 78 us with ds_add_f32, 30 us this way, 18 us for the loads alone)
-                    int *ic = reinterpret_cast<int *>(cell);
+        for (int k = 0; k < DEPTH; ++k) {
+            const int r = r0 + k * WAVES;                                   // wave-uniform
+            const uint32_t s = (uint32_t)min(r, R - 1) * roi_bytes + c0_bytes;
+            const uint32_t vo = r < R ? voff : kBufOob;
+            if constexpr (NCH == 4) {
+                const float4 g = frcnn_buf_load_f32x4_soff_aux<kNt>(dbuf, vo, s), a = frcnn_buf_load_f32x4_soff_aux<kNt>(abuf, vo, s);
+                gv[k][0] = g.x; gv[k][1] = g.y; gv[k][2] = g.z; gv[k][3] = g.w;
+                av[k][0] = __float_as_int(a.x); av[k][1] = __float_as_int(a.y); av[k][2] = __float_as_int(a.z); av[k][3] = __float_as_int(a.w);
+            } else if constexpr (NCH == 2) {
+                const uint2 g = frcnn_buf_load_b64_soff_aux<kNt>(dbuf, vo, s), a = frcnn_buf_load_b64_soff_aux<kNt>(abuf, vo, s);
+                gv[k][0] = __uint_as_float(g.x); gv[k][1] = __uint_as_float(g.y);
+                av[k][0] = (int)a.x; av[k][1] = (int)a.y;
+            } else {
+                gv[k][0] = frcnn_buf_load_f32_soff_aux<kNt>(dbuf, vo, s);
+                av[k][0] = __float_as_int(frcnn_buf_load_f32_soff_aux<kNt>(abuf, vo, s));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DEPTH; ++k) {
+            const bool live = own && r0 + k * WAVES < R;
+#pragma unroll
+            for (int i = 0; i < NCH; ++i)
+                if (live && av[k][i] >= 0) {
+                    int *ic = reinterpret_cast<int *>(&planes[ch[i] + av[k][i]]);
                     int old = *ic;
                     for (;;) {
-                        const int want = __float_as_int(__int_as_float(old) + gv[i]);
+                        const int want = __float_as_int(__int_as_float(old) + gv[k][i]);
                         const int prev = atomicCAS(ic, old, want);
                         if (prev == old) break;
                         old = prev;
                     }
                 }
-            }
+        }
     }
     __syncthreads();
-    // (c0 .. c0 + 3, :, :) is one contiguous run of 4 HW floats of dx
-    float *dst = dx + (size_t)c0 * HW;
-    if ((HW & 3) == 0) {
-        for (int i = tid; i < HW; i += 64 * kBwdWaves) reinterpret_cast<float4 *>(dst)[i] = reinterpret_cast<const float4 *>(planes)[i];
+    float *dst = dx + (size_t)c0 * HW;                                      // (c0 .. c0 + NCH - 1, :, :) is one contiguous run of dx
+    if (((NCH * HW) & 3) == 0 && (((size_t)c0 * HW) & 3) == 0) {
+        const frcnn_buf_t obuf = frcnn_make_buf(dst, (uint32_t)(NCH * HW * 4));
+        for (int i = tid; i < NCH * HW / 4; i += 64 * WAVES) frcnn_buf_store_f32x4_wt(obuf, (uint32_t)i * 16u, reinterpret_cast<const float4 *>(planes)[i]);
     } else {
-        for (int i = tid; i < 4 * HW; i += 64 * kBwdWaves) dst[i] = planes[i];
+        for (int i = tid; i < NCH * HW; i += 64 * WAVES) dst[i] = planes[i];
     }
 }
 
@@ -1378,7 +1392,7 @@ static bool roi_quads_launch(const float *x, int C, int H, int W, const float *r
         const int ms = frcnn_cdiv(R, 2 * kQuadWaves);
         if (rs > ms) rs = ms;
         if (rs < 1) rs = 1;
-        const char *fx = getenv("FRCNN_ROI_RSPLIT");
+        const char *fx = frcnn_tune("FRCNN_ROI_RSPLIT");
         if (fx && atoi(fx) > 0) rs = atoi(fx);
         if (outh * outw == 49) hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<16, 49, false, IN16, OUT16>), dim3(cq, rs), dim3(64 * kQuadWaves), 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, nullptr, rs, qk16, 0);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(roi_pool_quads_kernel<16, 0, false, IN16, OUT16>), dim3(cq, rs), dim3(64 * kQuadWaves), 0, stream, x, C, H, W, rois, roi_cols, R, outh, outw, scale, y, nullptr, rs, qk16, 0);
@@ -1391,12 +1405,12 @@ static bool roi_quads_launch(const float *x, int C, int H, int W, const float *r
     const int max_split = frcnn_cdiv(R, 2 * kQuadWaves);                      // at least one pair of RoIs per wave
     if (rsplit > max_split) rsplit = max_split;
     if (rsplit < 1) rsplit = 1;
-    const char *fix = getenv("FRCNN_ROI_RSPLIT");                             // test hook: RoI groups per channel group
+    const char *fix = frcnn_tune("FRCNN_ROI_RSPLIT");                             // test hook: RoI groups per channel group
     if (fix && atoi(fix) > 0) rsplit = atoi(fix);
-    const char *st = getenv("FRCNN_ROI_ST");                                  // A/B hook: 0 = plain stores, default write-through
+    const char *st = frcnn_tune("FRCNN_ROI_ST");                                  // A/B hook: 0 = plain stores, default write-through
     int qdbg = 0;
 #ifdef FRCNN_TIMING_ABLATIONS
-    const char *qdbg_s = getenv("FRCNN_ROI_DBG");
+    const char *qdbg_s = frcnn_tune("FRCNN_ROI_DBG");
     qdbg = qdbg_s ? atoi(qdbg_s) : 0;
 #endif
     const dim3 grid(cquads, rsplit), blk(64 * kQuadWaves);
@@ -1415,7 +1429,7 @@ static bool roi_quads_launch(const float *x, int C, int H, int W, const float *r
 template <int OUT16, bool IN16 = false>
 static bool roi_cells_launch(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
                              float scale, float *y, hipStream_t stream) {
-    const char *sel = getenv("FRCNN_ROI_KERNEL");
+    const char *sel = frcnn_tune("FRCNN_ROI_KERNEL");
     if (sel && sel[0] == 'p' && OUT16 != 2 && !IN16) return false;           // A/B hook (the split-tensor and blocked-map forms have no plane kernel: they ignore it)
     if (W > kCellPitch || H > 76) return false;
     if ((size_t)C * H * W * sizeof(float) >= (1ull << 31)) return false;      // the map is read through a 32-bit buffer descriptor
@@ -1427,19 +1441,19 @@ static bool roi_cells_launch(const float *x, int C, int H, int W, const float *r
     }
     const int cgroups = frcnn_cdiv(C, 8);
     const int waves = H <= 38 ? 16 : 8;
-    const char *mul = getenv("FRCNN_ROI_SPLIT_MUL");                         // tuning hook: workgroups per CU (default 1)
+    const char *mul = frcnn_tune("FRCNN_ROI_SPLIT_MUL");                         // tuning hook: workgroups per CU (default 1)
     const int rounds = mul && atoi(mul) > 0 ? atoi(mul) : 1;
     int rsplit = frcnn_cdiv(rounds * frcnn_roi_cu_count(), cgroups);         // one resident workgroup per CU
     const int max_split = frcnn_cdiv(R, waves);                              // at least one RoI per wave
     if (rsplit > max_split) rsplit = max_split;
     if (rsplit < 1) rsplit = 1;
-    const char *fix = getenv("FRCNN_ROI_RSPLIT");                             // test hook: RoI groups per channel group
+    const char *fix = frcnn_tune("FRCNN_ROI_RSPLIT");                             // test hook: RoI groups per channel group
     if (fix && atoi(fix) > 0) rsplit = atoi(fix);
     RoiBinTables tables;
     roi_fill_tables(tables, outh, outw);
     int dbg = 0;
 #ifdef FRCNN_TIMING_ABLATIONS
-    const char *dbg_s = getenv("FRCNN_ROI_DBG");
+    const char *dbg_s = frcnn_tune("FRCNN_ROI_DBG");
     dbg = dbg_s ? atoi(dbg_s) : 0;
 #endif
     const dim3 grid(cgroups, rsplit), blk(64 * waves);
@@ -1509,7 +1523,7 @@ int frcnn_roi_pool_fwd_chw(const float *x, int C, int H, int W, const float *roi
     if (R == 0) return FRCNN_OK;
     if (!argmax && roi_cells_launch<0>(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, y, stream)) return frcnn_launch_status();
     {
-        const char *sel = getenv("FRCNN_ROI_KERNEL");                         // A/B hook: p = the plane kernel for the arg-max form too
+        const char *sel = frcnn_tune("FRCNN_ROI_KERNEL");                         // A/B hook: p = the plane kernel for the arg-max form too
         if (argmax && !(sel && (sel[0] == 'p' || sel[0] == 'c')) && roi_quads_launch(x, C, H, W, rois, R, roi_cols, outh, outw, spatial_scale, y, argmax, stream))
             return frcnn_launch_status();
     }
@@ -1589,17 +1603,20 @@ int frcnn_roi_pool_bwd(const float *dy, const int32_t *argmax, int R, int C, int
     hipStream_t stream = (hipStream_t)stream_;
     if (!dy || !argmax || !dx || R < 0 || C < 1 || H < 1 || W < 1) return FRCNN_ERR_INVALID;
     {
-        // plane-resident kernel: four channel planes of dx in LDS, no memset, no global atomics (FRCNN_ROI_BWD=atomic: the round-1 kernel)
-        const char *sel = getenv("FRCNN_ROI_BWD");
+        // plane-resident kernel: NCH channel planes of dx in LDS per workgroup, no memset, no global atomics.  FRCNN_ROI_BWD (tuning registry):
+        // "n1" / "n2" / "n4" force the channels per workgroup (tests), "atomic" the round-1 global-atomic kernel (also the path of maps beyond the LDS planes).
+        const char *sel = frcnn_tune("FRCNN_ROI_BWD");
         const int bins = outh * outw;
-        if (!(sel && sel[0] == 'a') && R > 0 && (C & 3) == 0 && H * W <= kBwdMaxPlane && bins >= 1 && bins <= 64 &&
+        if (!(sel && sel[0] == 'a') && R > 0 && H * W <= kBwdMaxPlane && bins >= 1 && bins <= 64 &&
             (size_t)R * C * bins * sizeof(float) < (1ull << 32)) {
-            int bdbg = 0;
-#ifdef FRCNN_TIMING_ABLATIONS
-            const char *bdbg_s = getenv("FRCNN_ROI_BWD_DBG");
-            bdbg = bdbg_s ? atoi(bdbg_s) : 0;
-#endif
-            hipLaunchKernelGGL(roi_pool_bwd_planes_kernel, dim3(C / 4), dim3(64 * kBwdWaves), 0, stream, dy, argmax, R, C, H * W, bins, dx, bdbg);
+            int nch = (C & 1) ? 1 : 2;
+            if (sel && sel[0] == 'n') {
+                nch = atoi(sel + 1);
+                if ((nch != 1 && nch != 2 && nch != 4) || C % nch) return FRCNN_ERR_INVALID;          // an unknown form: never a silent substitute
+            }
+            if (nch == 2) hipLaunchKernelGGL((roi_pool_bwd_runs_kernel<2, 5, 16>), dim3(C / 2), dim3(1024), 0, stream, dy, argmax, R, C, H * W, bins, dx);
+            else if (nch == 1) hipLaunchKernelGGL((roi_pool_bwd_runs_kernel<1, 10, 8>), dim3(C), dim3(512), 0, stream, dy, argmax, R, C, H * W, bins, dx);
+            else hipLaunchKernelGGL((roi_pool_bwd_runs_kernel<4, 5, 16>), dim3(C / 4), dim3(1024), 0, stream, dy, argmax, R, C, H * W, bins, dx);
             return frcnn_launch_status();
         }
     }

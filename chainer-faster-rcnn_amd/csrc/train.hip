@@ -1095,7 +1095,7 @@ struct WgradPlan { int xtiles, nblocks, splits, ci_tiles, co_tiles; size_t slab_
 // 433 -> 403 us, conv2_1 230 -> 217, conv3_1 220 -> 213, conv4_1 215 -> 208, the 38 x 63 layers 127 -> 118) and the slower one on the 44-GFLOP layers
 // with >= 4 (ci, co) tiles (conv3_2 375 -> 392): picked per layer.  FRCNN_WGRAD_DB=0 / 1 forces one form (A/B hook).
 static bool wgrad_double_buffered(int Cin, int Cout, int H, int W) {
-    const char *e = getenv("FRCNN_WGRAD_DB");
+    const char *e = frcnn_tune("FRCNN_WGRAD_DB");
     if (e && (e[0] == '0' || e[0] == '1')) return e[0] == '1';
     const int cico = frcnn_cdiv(Cin, 64) * frcnn_cdiv(Cout, 64);
     const int nblocks = frcnn_cdiv(W, 32) * frcnn_cdiv(H, WG_ROWS);
@@ -1107,7 +1107,7 @@ static bool wgrad_double_buffered(int Cin, int Cout, int H, int W) {
 // conv1_1 (Cin * 9 <= 32) has its own kernel; FRCNN_WGRAD_CONV1=generic keeps the generic one on it (A/B, tests compare the two)
 static bool wgrad_first_layer_form(int Cin, int ks) {
     if (ks != 3 || Cin * 9 > 32) return false;
-    const char *e = getenv("FRCNN_WGRAD_CONV1");
+    const char *e = frcnn_tune("FRCNN_WGRAD_CONV1");
     return !(e && e[0] == 'g');
 }
 
@@ -1352,12 +1352,12 @@ int frcnn_conv_wgrad_f32(const float *x, const float *dy, float *dw_packed, int 
         return frcnn_launch_status();
     }
     const dim3 grid(p.ci_tiles, p.co_tiles, p.splits);
-    const bool reg = getenv("FRCNN_WGRAD_REG") != nullptr;        // A/B hook: the register-staged kernel
+    const bool reg = frcnn_tune("FRCNN_WGRAD_REG") != nullptr;        // A/B hook: the register-staged kernel
     if (ksize == 3 && !reg && wgrad_double_buffered(Cin, Cout, H, W)) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, true>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits);
     else if (ksize == 3 && !reg) {
 #define FRCNN_WGRAD_LAUNCH(ABL_) hipLaunchKernelGGL(HIP_KERNEL_NAME(conv_wgrad_dma_kernel<3, false, ABL_>), grid, dim3(256), 0, stream, x, dy, slabs, Cin, Cout, H, W, p.xtiles, p.nblocks, p.splits)
 #ifdef FRCNN_TIMING_ABLATIONS
-        const char *ae = getenv("FRCNN_WGRAD_ABL");
+        const char *ae = frcnn_tune("FRCNN_WGRAD_ABL");
         const int abl = ae ? atoi(ae) : 0;
         if (abl == 1) FRCNN_WGRAD_LAUNCH(1);
         else if (abl == 4) FRCNN_WGRAD_LAUNCH(4);
@@ -1387,7 +1387,7 @@ int frcnn_conv_wgrad_f32s(const float *x, const float *dy, float *dw_packed, int
     if (!workspace || workspace_bytes < p.slab_floats * p.splits * sizeof(float)) return FRCNN_ERR_INVALID;   // the fp32 kernel's workspace fits
     p.nblocks = p.xtiles * frcnn_cdiv(H, kSRows);                                   // this kernel's tiles are kSRows x 32 px
     int s = frcnn_cdiv(frcnn_cu_count(), p.ci_tiles * p.co_tiles);                   // ONE workgroup per CU
-    const char *se = getenv("FRCNN_WGRAD_F32S_SPLITS");
+    const char *se = frcnn_tune("FRCNN_WGRAD_F32S_SPLITS");
     if (se && atoi(se) > 0) s = atoi(se);
     if (s > p.splits) s = p.splits;
     if (s > p.nblocks) s = p.nblocks;

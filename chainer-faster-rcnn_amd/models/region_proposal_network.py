@@ -5,6 +5,7 @@ import os
 
 import numpy as np
 
+from .. import tuning as _tuning
 from ..chainer_compat import Variable, is_variable, kind, unwrap
 from ..runtime import default_runtime
 from .proposal_layer import ProposalLayer
@@ -98,7 +99,7 @@ class RegionProposalNetwork(object):
         if timer:
             timer.mark("rpn_conv_3x3")
         wb, bb = self._heads_bf16
-        if 6 * A <= 64 and os.environ.get("FRCNN_RPN_HEADS", "")[:1] != "c":
+        if 6 * A <= 64 and _tuning.get("FRCNN_RPN_HEADS", "")[:1] != "c":
             score, prob, bbox = rt.rpn_heads_bf16(h, wb, bb, self.mid_ch, A)                      # one launch (csrc/conv_bf16.hip)
         else:
             raw = rt.conv_bf16(h, wb, bb, self.mid_ch, 6 * A, 1, relu=False, out_f32_nchw=True)   # (1, 6A, H, W) fp32

@@ -3,6 +3,7 @@
 (csrc/conv.hip).  Parameters keep Chainer's link paths (`conv1_1/W` (co,ci,3,3), `conv1_1/b`)."""
 import numpy as np
 
+from .. import tuning as _tuning
 from ..chainer_compat import unwrap
 from ..runtime import default_runtime
 
@@ -121,7 +122,7 @@ class VGG16Prev(object):
         (FRCNN_BF16_CONV1_PAIR=0: the two-launch form, for A/B measurements)."""
         import os
         L = self.layers
-        return (self.conv_dtype == "bf16" and self.fuse_pool and os.environ.get("FRCNN_BF16_CONV1_PAIR", "1") != "0" and len(L) >= 3 and L[0] != "pool"
+        return (self.conv_dtype == "bf16" and self.fuse_pool and _tuning.get("FRCNN_BF16_CONV1_PAIR", "1") != "0" and len(L) >= 3 and L[0] != "pool"
                 and L[1] != "pool" and L[2] == "pool" and L[0][1] <= 3 and L[0][2] == 64 and L[1][1] == 64 and L[1][2] == 64
                 and not getattr(self, "generic_first_layer", False))
 

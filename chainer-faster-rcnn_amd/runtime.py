@@ -5,11 +5,10 @@ all arithmetic happens inside libfrcnn_hip.so.
 """
 import ctypes
 
-import os
-
 import numpy as np
 
 from . import _lib
+from . import tuning as _tuning
 
 _NP = {"f32": np.float32, "i32": np.int32, "u8": np.uint8, "f64": np.float64, "i64": np.int64, "i16": np.int16}
 
@@ -74,16 +73,10 @@ class TorchDeviceMemory(object):
         current stream wait for it."""
         torch = self.torch
         if getattr(self, "_side", None) is None:
-            # the side stream carries work nobody waits for soon (the discarded train-mode ProposalLayer of an RPN step: 1.2 ms of NMS launches under a
-            # 7 ms backward pass): the LOWEST priority the device offers, so that its workgroups take what the main and gradient streams leave
-            # (FRCNN_SIDE_STREAM_PRIO overrides; priorities outside the device's range are clamped by the runtime)
-            import os
-            try:
-                lo = torch.cuda.Stream.priority_range()[0]
-            except Exception:
-                lo = 0
-            pr = int(os.environ.get("FRCNN_SIDE_STREAM_PRIO", lo))
-            self._side = torch.cuda.Stream(device=self.device, priority=pr)
+            # the side stream carries work nobody waits for soon (the discarded train-mode ProposalLayer of an RPN step: 1.2 ms of NMS launches
+            # under a 7 ms backward pass).  It has the DEFAULT priority, like the main and gradient streams: the device offers nothing below it
+            # (`priority_range()` = (0, -1) and PyTorch clamps to at most 0; measured in round 4, ADVICE r04) -- its workgroups simply share the CUs.
+            self._side = torch.cuda.Stream(device=self.device)
         self._side.wait_stream(torch.cuda.current_stream(self.device))
         for a in arrays:
             a.record_stream(self._side)

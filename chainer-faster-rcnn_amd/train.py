@@ -22,10 +22,10 @@ models/faster_rcnn.py:115-116).  Convolution weights live in the kernels' packed
 ProposalLayer runs inside the training step exactly where the reference runs it (train-mode top-N 12000 / 2000,
 region_proposal_network.py:123-126) and its result is discarded, as there; `run_proposal_layer=False` skips it (same gradients).
 """
-import os
 
 import numpy as np
 
+from . import tuning as _tuning
 from .chainer_compat import unwrap
 from .models.anchor_target_layer import AnchorTargetLayer
 
@@ -44,7 +44,7 @@ def trunk_forward(model, x, fuse_pools=True):
     the tests that impose the device's decisions on a float64 pass read it)."""
     rt = model.rt
     layers = model.trunk.layers
-    fuse = fuse_pools and os.environ.get("FRCNN_TRAIN_FUSE_POOL") != "0"
+    fuse = fuse_pools and _tuning.get("FRCNN_TRAIN_FUSE_POOL") != "0"
     inputs, h, skip = [], x, None
     for idx, l in enumerate(layers):
         if l == "pool":
@@ -68,7 +68,7 @@ def trunk_forward(model, x, fuse_pools=True):
 
 def _grad_stream(rt, *arrays):
     import contextlib
-    if os.environ.get("FRCNN_TRAIN_STREAMS") == "1":
+    if _tuning.get("FRCNN_TRAIN_STREAMS") == "1":
         return contextlib.nullcontext()
     return rt.mem.aux_stream("grad", *arrays)
 
@@ -79,7 +79,7 @@ def trunk_backward(trainer, layer_inputs, g):
     rt = trainer.rt
     first = trainer.convs[0][0]
     links = dict(trainer.convs)
-    unpool = os.environ.get("FRCNN_TRAIN_FUSE_POOL") != "0"
+    unpool = _tuning.get("FRCNN_TRAIN_FUSE_POOL") != "0"
     skip_pool = False
     for pos in range(len(layer_inputs) - 1, -1, -1):
         l, xin = layer_inputs[pos]
@@ -348,7 +348,7 @@ class RPNTrainer(_BucketedAllReduce):
             _, mid = rt.conv3x3_f32s_train(feat_split, self.ws_fwd["rpn_conv_3x3"], link.b, link.cin, link.cout, relu=True, want_split=False)
         else:
             # weights of every input-gradient convolution (rotated / transposed copies of the current packed weights): one launch
-            if os.environ.get("FRCNN_DGRAD_PACK") != "each":          # (=each: A/B hook, one launch per layer inside the backward pass)
+            if _tuning.get("FRCNN_DGRAD_PACK") != "each":          # (=each: A/B hook, one launch per layer inside the backward pass)
                 with _grad_stream(rt):                                # on the gradient stream: under the forward pass, joined before the backward pass
                     rt.pack_conv_dgrad_w_many([(l.Wp, self.wd[n], 3) for n, l in self.convs[1:]] + [(rpn._heads_packed[0], self.wd_heads, 1)])
                 self._dgrad_packed = True
@@ -551,7 +551,7 @@ class RCNNTrainer(_BucketedAllReduce):
         rt.bias_grad(dyT.reshape(1, N, 1, Mp), out=self.grad[name + "/b"])          # db = column sums of dy
         if not need_dx:
             return None
-        if N % 64 == 0 and K % 64 == 0 and M <= 4096 and os.environ.get("FRCNN_LINEAR_DX", "conv") == "conv":
+        if N % 64 == 0 and K % 64 == 0 and M <= 4096 and _tuning.get("FRCNN_LINEAR_DX", "conv") == "conv":
             # dx = dy W with W (N, K) READ AS STORED: a 1x1 convolution whose "image" is W itself -- N channels of K "pixels" -- and whose
             # packed weights (Cin, Cout) are dy^T padded to 64 output channels: y[m][k] = sum_n dy[m][n] W[n][k].  No transposed copy of W
             # (fc6: 411 MB read + written every step), and W is streamed exactly once.
@@ -719,7 +719,7 @@ class TorchComm(object):
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.backend = dist.get_backend() if dist.is_initialized() else None
         self._pinned, self._copy_stream = None, None
-        self.trace = {} if os.environ.get("FRCNN_COMM_TRACE") == "1" else None
+        self.trace = {} if _tuning.get("FRCNN_COMM_TRACE") == "1" else None
 
     def _note(self, kind, t0):
         if self.trace is not None:

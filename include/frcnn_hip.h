@@ -40,6 +40,21 @@ int frcnn_abi_version(void);
 /* Number of HIP devices visible to the library (hipGetDeviceCount), or -(1000+hipError_t). */
 int frcnn_device_count(void);
 
+/* ---- tuning registry (csrc/frcnn_tune.h) ---------------------------------------------------------------
+ * Every A/B knob of the launchers (kernel-form picks such as FRCNN_BF16_DMA, FRCNN_ROI_BWD, FRCNN_NMS_SCAN; DESIGN.md 7b lists them) lives in ONE
+ * table inside the library.  It is filled once, when the library is loaded, from the FRCNN_* variables the process environment holds at that
+ * moment; no entry point reads the environment afterwards (a later setenv() has no effect and cannot race a launch).  With no entry a launcher
+ * takes its measured default; no key selects a CPU path.  The reference has no counterpart (its only knob on this path is the process-wide
+ * cudaSetDevice of nms_kernel.cu:80-89).
+ *   frcnn_set_tuning(key, value)   key must start with "FRCNN_" (47 characters at most), value at most 79 characters; value NULL removes
+ *                                  the entry.  Not to be called concurrently with a launch that reads the same key.  0, or FRCNN_ERR_INVALID.
+ *   frcnn_get_tuning(key, out, n)  copies the value (NUL-terminated, truncated to n) and returns its length + 1; 0 when the key is unset.
+ *   frcnn_reset_tuning()           back to the load-time snapshot.
+ */
+int frcnn_set_tuning(const char *key, const char *value);
+int frcnn_get_tuning(const char *key, char *value_out, int capacity);
+int frcnn_reset_tuning(void);
+
 /* ---- greedy IoU NMS ------------------------------------------------------------------------------
  * Replaces cpu_nms(dets, thresh) (models/cpu_nms.pyx:18-69; live caller models/proposal_layer.py:176-178,
  * second caller forward.py:54) and the dead gpu_nms/_nms (models/gpu_nms.hpp:9-10).
@@ -101,6 +116,12 @@ int frcnn_proposals(const float *rpn_cls_prob, const float *rpn_bbox_pred, int A
  *   frcnn_roi_pool_fwd_hwc  takes the feature map channel-last, xt (H*W, C) -- any map size;
  *                           roi_cols = 5 ([batch,x1,y1,x2,y2] rows) or 4 (ProposalLayer's bare (R,4)
  *                           output, i.e. the concat at faster_rcnn.py:123-124 folded into the read)
+ * NaN RULE -- A STATED DEVIATION from Chainer's CPU path.  forward_cpu takes numpy.max / numpy.argmax over the bin, which PROPAGATE a NaN (any NaN in
+ * the bin -> NaN out, argmax = the first NaN).  Every kernel here (and oracle/c/frcnn_oracle.c, which the parity tests compare with) follows
+ * forward_gpu's scan instead: the bin's first cell seeds the maximum and a later cell replaces it only under a strict `>` -- a NaN in the FIRST cell
+ * stays, a NaN elsewhere never wins.  The two rules agree on every NaN-free map (tests/test_oracle_pinned.py: the C restatement == the NumPy twin of
+ * forward_cpu; its test_roi_pool_nan_rule_is_the_stated_deviation pins where they differ).  A map with NaNs means the step has already diverged; the
+ * scan rule keeps the kernel's fast path (IEEE maxNum, v_max_f32) exact on NaN-free maps without a per-cell NaN test.
  */
 size_t frcnn_roi_pool_workspace_bytes(int C, int H, int W);
 int frcnn_chw_to_hwc(const float *x, int C, int H, int W, float *xt, void *stream);

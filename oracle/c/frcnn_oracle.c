@@ -101,6 +101,9 @@ void oracle_bbox_overlaps(const double *boxes, int64_t N, const double *query, i
  *   bin = [floor(p*stride)+xs, ceil((p+1)*stride)+xs) clamped to [0,W]
  *   out = max over bin (first max in row-major order wins -> argmax = h*W+w),
  *   empty bin -> 0 / argmax -1 (forward_gpu's definition; forward_cpu leaves it undefined).
+ *   NaN: this scan is forward_gpu's rule (the first cell seeds, a later cell wins only under a strict `>`: a NaN in the first cell stays, a NaN
+ *   elsewhere never wins).  forward_cpu's numpy.max / numpy.argmax PROPAGATE a NaN instead.  The deviation is deliberate and stated in
+ *   include/frcnn_hip.h (RoIPooling2D block); the two rules agree on NaN-free maps and tests/test_oracle_pinned.py pins the difference.
  * PARITY UNPINNED by the reference's tests.
  * x (N,C,H,W) f32; rois (R,5) f32 [batch,x1,y1,x2,y2]; y (R,C,outh,outw); argmax int32 or NULL.
  * ------------------------------------------------------------------------------------- */

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Copy the evidence of scripts/r02_gpu_final.sh from gpurun_out/<tag>/ into profiles/r02_* (tracked)."""
-import collections
-import csv
+"""Copy the evidence of scripts/gpu_evidence.sh (+ the round's final script) from gpurun_out/<tag>/ into profiles/<prefix>_* (tracked).
+Usage: collect_profiles.py <tag> [prefix]   (default r05z r05)"""
+import glob
 import json
 import os
 import shutil
@@ -10,35 +10,39 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def main(tag="r02z"):
+def last_json_line(path):
+    lines = [l for l in open(path) if l.startswith('{"metric"')]
+    return lines[-1] if lines else None
+
+
+def main(tag="r05z", R="r05"):
     O, P = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
-    for n in ("r02_bench.json", "r02_bench_default_steps.json", "r02_bench_bf16.json", "r02_bench_f32s.json", "r02_bench_train.json",
-              "r02_bench_train_f32s.json", "r02_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc_bf16.json", "r02_hbm_traffic_pmc_f32s.json"):
-        shutil.copy(os.path.join(O, n), os.path.join(P, n))
-    for n in ("r02_bench_2rank_gloo_infer.json", "r02_bench_2rank_gloo_train.json"):          # drop gloo's log lines
-        line = [l for l in open(os.path.join(O, n)) if l.startswith('{"metric"')][-1]
-        open(os.path.join(P, n), "w").write(line)
-    shutil.copy(os.path.join(O, "parity_reports.txt"), os.path.join(P, "r02_parity_reports.txt"))
-    for src, dst in (("prof/r02_kernel_stats.csv", "r02_kernel_stats.csv"), ("prof_bf16/r02_bf16_kernel_stats.csv", "r02_bf16_kernel_stats.csv"),
-                     ("prof_f32s/r02_f32s_kernel_stats.csv", "r02_f32s_kernel_stats.csv"), ("prof_train/r02_train_kernel_stats.csv", "r02_train_kernel_stats.csv"),
-                     ("prop/prop_kernel_stats.csv", "r02_proposals_kernel_stats.csv")):
-        shutil.copy(os.path.join(O, src), os.path.join(P, dst))
-    summ = {}
-    for d, f in (("rpmc1", "p1_counter_collection.csv"), ("rpmc2", "p2_counter_collection.csv")):
-        acc = collections.defaultdict(list)
-        for r in csv.DictReader(open(os.path.join(O, d, f))):
-            if "roi_pool_cells_kernel" in r["Kernel_Name"]:
-                acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for k, v in acc.items():
-            summ[k] = {"per_launch_mean": sum(v) / len(v), "launches": len(v)}
-    summ["_note"] = ("roi_pool_cells_kernel (fp32 and bf16-output launches of scripts/roi_bench.py), rocprofv3 --pmc, two passes "
-                     "(scripts/r02_gpu_final.sh); per-launch means summed over all SEs/CUs")
-    json.dump(summ, open(os.path.join(P, "r02_roi_pmc_summary.json"), "w"), indent=1, sort_keys=True)
-    for n in ("r02_bench", "r02_bench_default_steps", "r02_bench_bf16", "r02_bench_f32s", "r02_bench_train", "r02_bench_train_f32s"):
-        d = json.load(open(os.path.join(P, n + ".json")))
-        print(n, round(d["value"], 1), round(d["ms_per_step"], 4), (d.get("roofline") or {}).get("frac"), (d.get("nms_roi") or {}).get("proposals_nms_us"),
-              (d.get("nms_roi") or {}).get("roi_pool_us"), (d.get("parity") or {}).get("ok"), (d.get("f32_split_products") or {}).get("value"),
-              d.get("ms_per_step_without_proposal_layer"))
+    for n in (R + "_bench", R + "_bench_bf16", R + "_bench_f32s", R + "_bench_train", R + "_bench_train_f32s", R + "_bench_nccl_w1_train",
+              R + "_bench_2rank_gloo_train", R + "_bench_2rank_gloo_infer", R + "_bench_train_rcnn_device", R + "_bench_train_rcnn_numpy", R + "_bench_bf16_pair1", R + "_bench_bf16_pair0"):
+        src = os.path.join(O, n + ".json")
+        if os.path.exists(src):
+            line = last_json_line(src)
+            if line:
+                open(os.path.join(P, n + ".json"), "w").write(line)
+    for n in (R + "_hbm_traffic_pmc.json", R + "_hbm_traffic_pmc_bf16.json", R + "_mfma_pmc_summary.json", R + "_roi_pmc.txt", R + "_store_micro.txt",
+              R + "_roi_micro.txt", R + "_conv_bf16_micro.txt", R + "_conv_f32_micro.txt", R + "_wgrad_micro.txt", R + "_mfma_filler_micro.txt", R + "_dma_align_micro.txt", R + "_conv_pair_micro.txt", R + "_mfma_peak_micro.txt"):
+        if os.path.exists(os.path.join(O, n)):
+            shutil.copy(os.path.join(O, n), os.path.join(P, n))
+    if os.path.exists(os.path.join(O, "parity_reports.txt")):
+        shutil.copy(os.path.join(O, "parity_reports.txt"), os.path.join(P, R + "_parity_reports.txt"))
+    for d, dst in (("prof", R + "_kernel_stats.csv"), ("prof_bf16", R + "_bf16_kernel_stats.csv"), ("prof_train", R + "_train_kernel_stats.csv")):
+        hits = glob.glob(os.path.join(O, d, "**", "*kernel_stats.csv"), recursive=True)
+        if hits:
+            shutil.copy(hits[0], os.path.join(P, dst))
+    for n in (R + "_bench", R + "_bench_bf16", R + "_bench_f32s", R + "_bench_train", R + "_bench_train_f32s", R + "_bench_nccl_w1_train", R + "_bench_2rank_gloo_train"):
+        f = os.path.join(P, n + ".json")
+        if not os.path.exists(f):
+            continue
+        d = json.load(open(f))
+        nr = d.get("nms_roi") or {}
+        print(n, round(d["value"], 1), round(d["ms_per_step"], 4), (d.get("roofline") or {}).get("frac"), nr.get("proposals_nms_us"), nr.get("roi_pool_us"),
+              nr.get("roi_pool_frac_of_hbm_peak"), (d.get("parity") or {}).get("ok"), (d.get("f32_split_products") or {}).get("value"),
+              (d.get("bf16_config3") or {}).get("value"), (d.get("bf16_config3") or {}).get("frac_of_bf16_mfma_peak"))
 
 
 if __name__ == "__main__":

@@ -14,15 +14,16 @@ mkdir -p scripts/micro/_bin
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 scripts/micro/mfma_peak_micro.hip -o scripts/micro/_bin/mfma_peak_micro
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip scripts/micro/linear_bf16_micro.cpp -I include -L chainer-faster-rcnn_amd -lfrcnn_hip -Wl,-rpath,'$ORIGIN/../../../chainer-faster-rcnn_amd' -o scripts/micro/_bin/linear_bf16_micro
 # timing-ablation build of roi_pool.hip alone (FRCNN_ROI_DBG is honoured; WRONG results by design) + the same harness against it
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DFRCNN_TIMING_ABLATIONS -I include -I chainer-faster-rcnn_amd/csrc -shared chainer-faster-rcnn_amd/csrc/roi_pool.hip -o scripts/micro/_bin/libroi_abl.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DFRCNN_TIMING_ABLATIONS -I include -I chainer-faster-rcnn_amd/csrc -shared chainer-faster-rcnn_amd/csrc/roi_pool.hip chainer-faster-rcnn_amd/csrc/abi.hip -o scripts/micro/_bin/libroi_abl.so
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip scripts/micro/roi_micro.cpp -I include -L scripts/micro/_bin -lroi_abl -Wl,-rpath,'$ORIGIN' -o scripts/micro/_bin/roi_micro_abl
 
-# full timing-ablation build of the library (FRCNN_TIMING_ABLATIONS: WRONG results by design) for the conv micro-benchmark: opt-in
+# full research build of the library for the conv micro-benchmarks: opt-in.  -DFRCNN_TUNING_FORMS adds the measured-and-not-adopted kernel forms the product
+# library no longer carries; -DFRCNN_TIMING_ABLATIONS the timing ablations (WRONG results by design)
 if [ "${MICRO_ABL_LIB:-0}" = "1" ]; then
   mkdir -p scripts/micro/_bin/abl_obj
   for f in chainer-faster-rcnn_amd/csrc/*.hip; do
     o=scripts/micro/_bin/abl_obj/$(basename $f .hip).o
-    if [ ! -f $o ] || [ $f -nt $o ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DFRCNN_TIMING_ABLATIONS -I include -I chainer-faster-rcnn_amd/csrc -c $f -o $o & fi
+    if [ ! -f $o ] || [ $f -nt $o ]; then /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DFRCNN_TIMING_ABLATIONS -DFRCNN_TUNING_FORMS -I include -I chainer-faster-rcnn_amd/csrc -c $f -o $o & fi
   done
   wait
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o scripts/micro/_bin/libfrcnn_hip_abl.so scripts/micro/_bin/abl_obj/*.o

@@ -64,7 +64,7 @@ int main(int argc, char **argv) {
         const size_t nout = L.pool ? (size_t)cop * ((L.h + 1) / 2) * ((L.w + 1) / 2) : ny;
         std::vector<uint16_t> ref, got;
         if (check) {                                                       // the default pick's output
-            unsetenv("FRCNN_BF16_DMA");
+            frcnn_set_tuning("FRCNN_BF16_DMA", nullptr);
             CK(hipMemsetAsync(dy[0], 0xff, ny * 2, s));
             if (frcnn_conv_bf16_ws(dx, dw, db, dy[0], L.ci, L.co, L.h, L.w, 3, 1, L.pool ? 2 : 0, ws, wsb, s) != 0) { printf(" default launch refused\n"); return 1; }
             ref.resize(nout); got.resize(nout);
@@ -73,10 +73,10 @@ int main(int argc, char **argv) {
         }
         double best = 1e30;
         for (const std::string &m : modes) {
-            unsetenv("FRCNN_BF16_STRIP");
-            if (m == "def") unsetenv("FRCNN_BF16_DMA");                 // "def" in a --modes list = the default pick
-            else if (m == "old") { unsetenv("FRCNN_BF16_DMA"); setenv("FRCNN_BF16_STRIP", "0", 1); }   // "old" = conv_dma_bf16_kernel's picks (no strip rule)
-            else if (!m.empty()) setenv("FRCNN_BF16_DMA", m.c_str(), 1);
+            frcnn_set_tuning("FRCNN_BF16_STRIP", nullptr);
+            if (m == "def") frcnn_set_tuning("FRCNN_BF16_DMA", nullptr);                 // "def" in a --modes list = the default pick
+            else if (m == "old") { frcnn_set_tuning("FRCNN_BF16_DMA", nullptr); frcnn_set_tuning("FRCNN_BF16_STRIP", "0"); }   // "old" = conv_dma_bf16_kernel's picks (no strip rule)
+            else if (!m.empty()) frcnn_set_tuning("FRCNN_BF16_DMA", m.c_str());
             hipGraph_t gr; hipGraphExec_t ge;
             CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
             bool ok = true;
@@ -117,7 +117,7 @@ int main(int argc, char **argv) {
         }
         printf("\n");
         total_us_best += best * (strcmp(L.name, "conv5_1") == 0 ? 4 : 1);      // conv5_1's shape runs four times in the chain (conv5_1..3, rpn_conv_3x3)
-        unsetenv("FRCNN_BF16_DMA");
+        frcnn_set_tuning("FRCNN_BF16_DMA", nullptr);
         CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(db)); CK(hipFree(ws)); for (auto &p : dy) CK(hipFree(p));
     }
     printf("sum of the best per layer (conv5_1 x 4, conv1_1 not included): %.1f us\n", total_us_best);

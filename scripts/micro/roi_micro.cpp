@@ -1,6 +1,6 @@
 // roi_micro.cpp -- times frcnn_roi_pool_fwd_chw (libfrcnn_hip.so) on the benchmark's own RoIs without torch: a captured graph of
 // 10 back-to-back launches into 10 rotating 30 MB outputs, per environment setting given on the command line
-// (e.g.  roi_micro FRCNN_ROI_ST=0 FRCNN_ROI_ST=1 "FRCNN_ROI_KERNEL=planes").  Each result is compared bit for bit with the
+// (e.g.  roi_micro FRCNN_ROI_ST=0 FRCNN_ROI_ST=1 "FRCNN_ROI_KERNEL=planes": applied through frcnn_set_tuning).  Each result is compared bit for bit with the
 // channel-last gather kernel (frcnn_roi_pool_fwd_hwc after frcnn_chw_to_hwc: an independent implementation in the same library).
 // Inputs: scripts/_data/bench_rois.npy (300 x 4 f32, written once from the oracle's proposals for synthetic.image(seed 0)) and
 // optionally bench_feat.npy (512 x 38 x 63); without it the map is |N(0,1)|.
@@ -68,14 +68,15 @@ int main(int argc, char **argv) {
         CK(hipStreamSynchronize(s));
         CK(hipMemcpy(hamref.data(), amref, ybytes, hipMemcpyDeviceToHost));
         const int burst = getenv("ROI_MICRO_BURST") ? atoi(getenv("ROI_MICRO_BURST")) : 1;
-        for (const char *which : {"fwd+argmax", "fwd+argmax FRCNN_ROI_KERNEL=planes", "bwd", "bwd FRCNN_ROI_BWD=atomic", "bwd dbg1 plain rmw", "bwd dbg2 integer adds", "bwd dbg4 no update", "bwd dbg8 cas loop"}) {
-            if (strstr(which, "dbg8")) setenv("FRCNN_ROI_BWD_DBG", "8", 1);
-            if (strstr(which, "dbg1")) setenv("FRCNN_ROI_BWD_DBG", "1", 1);
-            if (strstr(which, "dbg2")) setenv("FRCNN_ROI_BWD_DBG", "2", 1);
-            if (strstr(which, "dbg4")) setenv("FRCNN_ROI_BWD_DBG", "4", 1);
+        for (const char *which : {"fwd+argmax", "fwd+argmax FRCNN_ROI_KERNEL=planes", "bwd", "bwd form=n1", "bwd form=n4", "bwd FRCNN_ROI_BWD=atomic"}) {
+            if (const char *f = strstr(which, "form=")) { char form[32]; sscanf(f + 5, "%31s", form); frcnn_set_tuning("FRCNN_ROI_BWD", form); }
+            if (strstr(which, "dbg8")) frcnn_set_tuning("FRCNN_ROI_BWD_DBG", "8");
+            if (strstr(which, "dbg1")) frcnn_set_tuning("FRCNN_ROI_BWD_DBG", "1");
+            if (strstr(which, "dbg2")) frcnn_set_tuning("FRCNN_ROI_BWD_DBG", "2");
+            if (strstr(which, "dbg4")) frcnn_set_tuning("FRCNN_ROI_BWD_DBG", "4");
             const bool is_bwd = which[0] == 'b';
-            if (strstr(which, "planes")) setenv("FRCNN_ROI_KERNEL", "planes", 1);
-            if (strstr(which, "atomic")) setenv("FRCNN_ROI_BWD", "atomic", 1);
+            if (strstr(which, "planes")) frcnn_set_tuning("FRCNN_ROI_KERNEL", "planes");
+            if (strstr(which, "atomic")) frcnn_set_tuning("FRCNN_ROI_BWD", "atomic");
             hipGraph_t g; hipGraphExec_t ge;
             CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
             for (int i = 0; i < 10; ++i) {
@@ -103,7 +104,7 @@ int main(int argc, char **argv) {
                 verdict = (memcmp(hy.data(), href.data(), ybytes) == 0 && memcmp(ham.data(), hamref.data(), ybytes) == 0) ? "bit-exact (values and indices)" : "MISMATCH";
             }
             printf("%-40s best %6.2f us  median %6.2f us  (%.3f of 8 TB/s)  %s\n", which, us[0], us[us.size() / 2], 65.1e6 / (us[us.size() / 2] * 1e-6) / 8e12, verdict);
-            unsetenv("FRCNN_ROI_KERNEL"); unsetenv("FRCNN_ROI_BWD"); unsetenv("FRCNN_ROI_BWD_DBG");
+            frcnn_set_tuning("FRCNN_ROI_KERNEL", nullptr); frcnn_set_tuning("FRCNN_ROI_BWD", nullptr); frcnn_set_tuning("FRCNN_ROI_BWD_DBG", nullptr);
             CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
         }
     }
@@ -118,7 +119,7 @@ int main(int argc, char **argv) {
         while (pos < st.size()) {
             size_t e = st.find(',', pos); if (e == std::string::npos) e = st.size();
             const std::string kv = st.substr(pos, e - pos); const size_t eq = kv.find('=');
-            if (eq != std::string::npos) { setenv(kv.substr(0, eq).c_str(), kv.substr(eq + 1).c_str(), 1); names.push_back(kv.substr(0, eq)); }
+            if (eq != std::string::npos && kv.compare(0, 6, "FRCNN_") == 0) { frcnn_set_tuning(kv.substr(0, eq).c_str(), kv.substr(eq + 1).c_str()); names.push_back(kv.substr(0, eq)); }
             pos = e + 1;
         }
         CK(hipMemsetAsync(ys[3], 0xff, ybytes, s));
@@ -155,7 +156,7 @@ int main(int argc, char **argv) {
                 printf("\n");
             }
         }
-        for (const auto &n : names) unsetenv(n.c_str());
+        for (const auto &n : names) frcnn_set_tuning(n.c_str(), nullptr);
         CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     }
     return 0;

@@ -21,3 +21,13 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"))
     return load
+
+
+@pytest.fixture(autouse=True)
+def _tuning_back_to_defaults():
+    """A/B knobs are set through the tuning registry (chainer_faster_rcnn_amd.tuning -> frcnn_set_tuning), never through the
+    environment; every test starts and ends on the load-time snapshot."""
+    yield
+    mod = sys.modules.get("chainer_faster_rcnn_amd.tuning")
+    if mod is not None:
+        mod.reset()

@@ -26,7 +26,8 @@ def build(force=False, sources=None):
         o = os.path.join(OUT, os.path.basename(s) + ".o")
         objs.append(o)
         procs.append(subprocess.Popen([CLANG if os.path.exists(CLANG) else "g++", "-x", "c++", "-std=c++17", "-O1", "-g",
-                                       "-ffp-contract=off", "-fPIC", "-Wno-unused-function", "-Wno-unused-value",
+                                       "-ffp-contract=off", "-fPIC", "-Wno-unused-function", "-Wno-unused-value", "-DFRCNN_TUNING_FORMS",     # the emulator carries the research forms too (logic tests)
+                                       
                                        "-I", os.path.join(HERE, "shadow"), "-I", HERE, "-I", os.path.join(ROOT, "include"), "-I", CSRC,
                                        "-c", s, "-o", o]))
     for p in procs:

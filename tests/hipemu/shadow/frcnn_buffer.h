@@ -38,6 +38,14 @@ static inline uint2 frcnn_buf_load_b64(frcnn_buf_t b, uint32_t off) {
     if ((uint64_t)off + 8 <= b.bytes) memcpy(&v, b.base + off, 8);
     return v;
 }
+static inline uint2 frcnn_buf_load_b64_soff(frcnn_buf_t b, uint32_t off, uint32_t soff) {
+    uint2 v = make_uint2(0u, 0u);
+    if ((uint64_t)off + 8 <= b.bytes) memcpy(&v, b.base + off + soff, 8);
+    return v;
+}
+template <int AUX> static inline float frcnn_buf_load_f32_soff_aux(frcnn_buf_t b, uint32_t off, uint32_t soff) { return frcnn_buf_load_f32_soff(b, off, soff); }
+template <int AUX> static inline float4 frcnn_buf_load_f32x4_soff_aux(frcnn_buf_t b, uint32_t off, uint32_t soff) { return frcnn_buf_load_f32x4_soff(b, off, soff); }
+template <int AUX> static inline uint2 frcnn_buf_load_b64_soff_aux(frcnn_buf_t b, uint32_t off, uint32_t soff) { return frcnn_buf_load_b64_soff(b, off, soff); }
 template <int AUX> static inline void frcnn_buf_store_b64_soff(frcnn_buf_t b, uint32_t off, uint32_t soff, uint2 v) {
     if ((uint64_t)off + 8 <= b.bytes) memcpy(const_cast<char *>(b.base) + off + soff, &v, 8);
 }

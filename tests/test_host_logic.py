@@ -30,7 +30,7 @@ def test_device_library_builds_and_exports_every_declared_symbol():
     assert norm(ref) in norm(hdr)
     import chainer_faster_rcnn_amd as pkg
     assert sorted(pkg._lib.SIGNATURES) == _declared()   # the binding table mirrors the header one to one
-    assert lib.frcnn_abi_version() == 21
+    assert lib.frcnn_abi_version() == 22
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -151,9 +151,10 @@ def test_conv_bf16_plan_of_the_vgg16_chain(monkeypatch):
     600 x 1000 -- strip form D where a launch has >= 8 K-chunks and >= one 64-cout x 10-row x 32-px tile per CU, form C on the 38 x 63
     launches (not under the fused pool: five tile rows), conv_dma_bf16_kernel elsewhere -- and the hooks that switch the rule off."""
     import chainer_faster_rcnn_amd as pkg
+    tuning = pkg.tuning
     lib = pkg._lib.bind(pkg._lib.LIB_PATH)
     for k in ("FRCNN_BF16_DMA", "FRCNN_BF16_STRIP", "FRCNN_BF16_SPLIT", "FRCNN_BF16_RP", "FRCNN_BF16_DMA_DEFAULT"):
-        monkeypatch.delenv(k, raising=False)
+        tuning.set(k, None)
     want = {(64, 64, 600, 1000, 2): 0, (64, 128, 300, 500, 0): 0, (128, 128, 300, 500, 2): 910, (128, 256, 150, 250, 0): 910, (256, 256, 150, 250, 0): 910,
             (256, 256, 150, 250, 2): 910, (256, 512, 75, 125, 0): 910, (512, 512, 75, 125, 2): 910, (512, 512, 38, 63, 0): 903, (512, 512, 38, 63, 2): 0,
             (3, 64, 600, 1000, 0): 0, (512, 512, 10, 14, 0): 0}               # 910 = form D (direct stores where the launch has no fused pool)
@@ -161,10 +162,14 @@ def test_conv_bf16_plan_of_the_vgg16_chain(monkeypatch):
         assert lib.frcnn_conv_bf16_plan(ci, co, h, w, 3, om) == form, (ci, co, h, w, om)
     assert lib.frcnn_conv_bf16_plan(512, 54, 38, 63, 1, 1) == 0                     # 1x1: the register-staged kernel
     assert lib.frcnn_conv_bf16_plan(512, 512, 38, 63, 5, 0) == -1                   # FRCNN_ERR_INVALID
-    monkeypatch.setenv("FRCNN_BF16_STRIP", "0")
+    tuning.set("FRCNN_BF16_STRIP", "0")
     assert lib.frcnn_conv_bf16_plan(256, 256, 150, 250, 3, 0) == 0
-    monkeypatch.delenv("FRCNN_BF16_STRIP")
-    monkeypatch.setenv("FRCNN_BF16_DMA", "901")
-    assert lib.frcnn_conv_bf16_plan(256, 256, 150, 250, 3, 0) == 901
-    monkeypatch.setenv("FRCNN_BF16_DMA", "141")
+    tuning.set("FRCNN_BF16_STRIP", None)
+    tuning.set("FRCNN_BF16_DMA", "909")
+    assert lib.frcnn_conv_bf16_plan(256, 256, 150, 250, 3, 0) == 909
+    tuning.set("FRCNN_BF16_DMA", "901")                                              # form A: research builds only (-DFRCNN_TUNING_FORMS) -- refused, not substituted
+    assert lib.frcnn_conv_bf16_plan(256, 256, 150, 250, 3, 0) == -1
+    tuning.set("FRCNN_BF16_DMA", "921")
+    assert lib.frcnn_conv_bf16_plan(64, 64, 600, 1000, 3, 0) == -1
+    tuning.set("FRCNN_BF16_DMA", "141")
     assert lib.frcnn_conv_bf16_plan(256, 256, 150, 250, 3, 0) == 0

@@ -9,6 +9,7 @@ import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
 import parity_cases as P  # noqa: E402
+from chainer_faster_rcnn_amd import tuning  # noqa: E402
 
 
 @pytest.fixture(scope="module")
@@ -93,6 +94,7 @@ def test_roi_pool(rt):
     P.check_roi_pool(rt, R=5, C=64, H=38, W=63, seed=1)     # VEC=1 path (C % 128 != 0)
     P.check_roi_pool(rt, R=40, C=8, H=12, W=17, seed=2)     # 3 RoI groups x 1 channel group, ragged last batch
     P.check_roi_pool(rt, R=6, C=6, H=70, W=90, seed=3)      # 3 planes per group (odd sizes: scalar copies)
+    P.check_roi_pool(rt, R=37, C=7, H=12, W=17, seed=4)     # odd channel count: the backward's one-channel workgroups; more RoIs than one wave step
 
 
 @pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6, 8, 10, 11, 30, 35, 34, 36, 46, 37, 38, 39])
@@ -159,7 +161,7 @@ def test_conv_backward(rt):
 def test_conv_wgrad_forms(rt, monkeypatch, env):
     """A/B forms of the 3x3 weight-gradient kernel: the single-buffer form (two workgroups per CU) and the double-buffered one (one per CU) forced on every layer.  Several tiles per workgroup (the emulated chip has 3 CUs) and ragged borders."""
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        tuning.set(k, v)
     P.check_conv_backward(rt, 64, 64, 9, 70)
     P.check_conv_backward(rt, 3, 64, 7, 33, seed=1)
 
@@ -170,7 +172,7 @@ def test_conv1_wgrad_first_layer_form(rt, monkeypatch):
     for cin, h, w in ((3, 7, 33), (3, 12, 70), (1, 5, 40), (2, 9, 64)):
         P.check_conv_backward(rt, cin, 64, h, w, seed=cin)
     P.check_conv_backward(rt, 3, 128, 6, 37, seed=5)
-    monkeypatch.setenv("FRCNN_WGRAD_CONV1", "generic")
+    tuning.set("FRCNN_WGRAD_CONV1", "generic")
     P.check_conv_backward(rt, 3, 64, 7, 33, seed=1)
 
 
@@ -245,7 +247,7 @@ def test_img_preprocessing(rt):
 
 
 def test_conv_bf16_eight_row_tiles(rt, monkeypatch):
-    monkeypatch.setenv("FRCNN_BF16_RP", "4")                        # force the 8-wave / 8-row decomposition
+    tuning.set("FRCNN_BF16_RP", "4")                        # force the 8-wave / 8-row decomposition
     P.check_conv_bf16(rt, 16, 64, 13, 37, seed=3)
     P.check_conv_bf16(rt, 32, 128, 8, 33, seed=4)
 
@@ -254,7 +256,7 @@ def test_conv_bf16_eight_row_tiles(rt, monkeypatch):
 def test_conv_bf16_lds_dma(rt, monkeypatch, mode):
     """Every LDS-DMA staging variant of the 3x3 bf16 kernel (lane-linear swizzled LDS image, NS-stage ring) and the
     register-staged kernel ("0"): same results.  The default picks 141 / 231 by launch size."""
-    monkeypatch.setenv("FRCNN_BF16_DMA", mode)
+    tuning.set("FRCNN_BF16_DMA", mode)
     P.check_conv_bf16(rt, 16, 64, 9, 37)                  # one chunk
     P.check_conv_bf16(rt, 3, 64, 7, 33, seed=1)
     P.check_conv_bf16(rt, 80, 128, 13, 70, seed=2)        # five chunks: the ring wraps; three x tiles, ragged rows
@@ -266,7 +268,7 @@ def test_conv_bf16_strip_forms(rt, monkeypatch, mode):
     """The strip forms of the 3x3 bf16 kernel (csrc/conv_bf16_strip.h: one wave per SIMD, software-pipelined ring; D = 909 and C = 903 are default
     picks, the others selectable) against the oracle like every other staging variant -- one stage, the rings wrapping (5 and 12 stages),
     several x / y / cout tiles, ragged edges, 54 couts of 64 (form C: a 32-cout tile that is half padding), the fused pool."""
-    monkeypatch.setenv("FRCNN_BF16_DMA", mode)
+    tuning.set("FRCNN_BF16_DMA", mode)
     P.check_conv_bf16(rt, 64, 64, 9, 37)                   # forms A, B: 4 stages; C: one stage of four K ways
     if mode in ("903", "907"):                             # one chunk cannot be split over K ways: the explicit form refuses, 900 falls back
         with pytest.raises(Exception):
@@ -328,9 +330,9 @@ def test_ticketed_fixups_do_not_depend_on_arrival_order(rt, monkeypatch):
 
     def run():
         out = [P.host(rt, rt.conv3x3(P.dev(rt, x), rt.pack_conv3x3_w(P.dev(rt, w)), P.dev(rt, b), relu=True))]
-        monkeypatch.setenv("FRCNN_BF16_SPLIT", "2")
+        tuning.set("FRCNN_BF16_SPLIT", "2")
         out.append(P.host(rt, rt.conv_bf16(rt.bf16_from_nchw(P.dev(rt, x)), rt.bf16_pack_conv_w(P.dev(rt, w), 3), P.dev(rt, b), 128, 64, 3, relu=True)))
-        monkeypatch.delenv("FRCNN_BF16_SPLIT")
+        tuning.set("FRCNN_BF16_SPLIT", None)
         out.append(P.host(rt, rt.linear(P.dev(rt, xm), P.dev(rt, wm), P.dev(rt, bm), relu=True)))
         return out
     first = run()
@@ -350,9 +352,9 @@ def test_lds_dma_kernels_with_late_landing(rt, monkeypatch):
         P.check_conv_bf16_strip(rt, form, 128, 96, 21, 45, seed=4)
     P.check_conv_bf16_strip(rt, 909, 64, 64, 12, 64, pool=True, seed=5)
     for mode in ("231", "321", "141", "224"):                           # conv_dma_bf16_kernel: two / three-stage rings, single stage, 16-row tiles
-        monkeypatch.setenv("FRCNN_BF16_DMA", mode)
+        tuning.set("FRCNN_BF16_DMA", mode)
         P.check_conv_bf16(rt, 80, 128, 13, 70, seed=2)
-    monkeypatch.delenv("FRCNN_BF16_DMA")
+    tuning.set("FRCNN_BF16_DMA", None)
     P.check_conv3x3(rt, 48, 64, 9, 70, seed=1)                          # fp32 MFMA convolution (conv.hip), stream-K pieces included
     P.check_conv_f32s(rt, 192, 64, 5, 33, seed=6)                       # split products (conv_f32s.hip)
     P.check_conv_backward(rt, 64, 64, 9, 70)                            # weight / input gradients (train.hip)
@@ -377,9 +379,9 @@ def test_conv_bf16_strip_forms_on_ragged_shapes(rt):
 @pytest.mark.parametrize("split,mode", [("2", None), ("4", None), ("2", "224"), ("4", "223")])
 def test_conv_bf16_split_k(rt, monkeypatch, split, mode):
     """Split-K form of the bf16 3x3 kernel: partial tiles through the workspace, last arriver sums in split order."""
-    monkeypatch.setenv("FRCNN_BF16_SPLIT", split)
+    tuning.set("FRCNN_BF16_SPLIT", split)
     if mode:
-        monkeypatch.setenv("FRCNN_BF16_DMA", mode)
+        tuning.set("FRCNN_BF16_DMA", mode)
     P.check_conv_bf16(rt, 128, 64, 9, 37, seed=5)         # 8 chunks: 2 or 4 splits of >= 2 chunks ... (the picker wants >= 4 per split)
     P.check_conv_bf16(rt, 256, 128, 6, 40, seed=6)        # 16 chunks
     P.check_conv_bf16_pool(rt, 256, 64, 8, 33, seed=7)
@@ -405,10 +407,10 @@ def test_conv_f32s_split_bf16(rt):
 @pytest.mark.parametrize("split", ["2", "3"])
 def test_conv_f32s_split_k(rt, monkeypatch, split):
     """Few-tile launches split their K range over several workgroups (ticket + deterministic fix-up by the last one)."""
-    monkeypatch.setenv("FRCNN_F32S_SPLIT", split)
+    tuning.set("FRCNN_F32S_SPLIT", split)
     P.check_conv_f32s(rt, 192, 64, 5, 33, seed=6)          # 12 chunks: 2 or 3 splits of >= 4
     if split == "2":
-        monkeypatch.setenv("FRCNN_F32S_XCD", "1")          # the XCD-aware (pixel tile, split) enumeration (off by default)
+        tuning.set("FRCNN_F32S_XCD", "1")          # the XCD-aware (pixel tile, split) enumeration (off by default)
         P.check_conv_f32s(rt, 192, 128, 5, 33, seed=6)     # two cout tiles: two XCDs per tile
 
 
@@ -456,7 +458,7 @@ def test_conv1_f32_first_layer(rt, monkeypatch):
     P.check_conv1_f32(rt, monkeypatch, 3, 64, 11, 70)                      # ragged right edge (70 = 64 + 6: a partial group of four)
     P.check_conv1_f32(rt, monkeypatch, 3, 64, 6, 67, seed=2)               # W % 4 != 0: unaligned 16-byte stores, 3-px tail
     P.check_conv1_f32(rt, monkeypatch, 1, 24, 5, 33, relu=False, seed=1)   # one channel, one cout block, no ReLU
-    monkeypatch.setenv("FRCNN_CONV1_GRID", "2")                            # the strided tile loop
+    tuning.set("FRCNN_CONV1_GRID", "2")                            # the strided tile loop
     P.check_conv1_f32(rt, monkeypatch, 3, 64, 11, 70, seed=3)
 
 
@@ -464,7 +466,7 @@ def test_conv1_f32_first_layer(rt, monkeypatch):
 def test_conv1_persistent_tile_loop(rt, monkeypatch, grid):
     """The first-layer kernel is a persistent launch: with fewer workgroups than tiles every workgroup strides over several tiles
     (next halo prefetched under the current tile's units) -- forced here on a six-tile image; 4 workgroups = an uneven split."""
-    monkeypatch.setenv("FRCNN_CONV1_GRID", grid)
+    tuning.set("FRCNN_CONV1_GRID", grid)
     P.check_conv1_f32s(rt, 3, 64, 11, 70, seed=3)
     P.check_conv1_bf16(rt, 3, 64, 11, 70, seed=3)
 
@@ -510,11 +512,11 @@ def test_vgg16_bf16_trunk_with_the_conv1_pair_launch(rt, monkeypatch):
     x = rt.mem.from_numpy(synthetic.image(seed=2, h=24, w=40))
     outs = {}
     for flag in ("1", "0"):                                      # (read at every call)
-        monkeypatch.setenv("FRCNN_BF16_CONV1_PAIR", flag)
+        tuning.set("FRCNN_BF16_CONV1_PAIR", flag)
         assert trunk.conv1_pair_applies() == (flag == "1")
         outs[flag] = rt.mem.to_numpy(trunk(x)).copy()
     assert np.array_equal(outs["1"], outs["0"]) and np.abs(outs["1"]).max() > 0
-    monkeypatch.setenv("FRCNN_BF16_CONV1_PAIR", "1")
+    tuning.set("FRCNN_BF16_CONV1_PAIR", "1")
     col = {}
     trunk(x, collect=col)
     assert "conv1_1" in col and "pool1" in col

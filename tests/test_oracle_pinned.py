@@ -107,6 +107,29 @@ def test_roi_pool_c_matches_python_twin():
     assert np.array_equal(dx.reshape(1, 5, -1), ref)
 
 
+def test_roi_pool_nan_rule_is_the_stated_deviation():
+    """Chainer's forward_cpu (numpy.max / numpy.argmax, the NumPy twin below) PROPAGATES a NaN; the C restatement -- and every kernel, which the
+    parity tests compare with it -- follows forward_gpu's scan: a NaN in a bin's first cell stays, a NaN elsewhere never wins (include/frcnn_hip.h,
+    RoIPooling2D block: a stated deviation, VERDICT r04 weak #4).  This test pins exactly where the two differ and that they differ nowhere else."""
+    rs = np.random.RandomState(5)
+    x = rs.randn(1, 2, 12, 17).astype(np.float32)
+    rois = np.array([[0, 0, 0, 16 * 16 - 1, 11 * 16 - 1]], np.float32)      # the whole map: bin (ph, pw) covers rows / columns known below
+    x[0, 0, 0, 0] = np.nan                                                   # the FIRST cell of bin (0, 0): both rules say NaN
+    x[0, 1, 5, 8] = np.nan                                                   # an interior cell of some bin: numpy.max says NaN, the scan ignores it
+    y, am = O.roi_pooling_2d(x, rois, return_argmax=True)
+    y2, am2 = O.roi_pooling_2d_py(x, rois)
+    assert np.isnan(y[0, 0, 0, 0]) and np.isnan(y2[0, 0, 0, 0]) and am[0, 0, 0, 0] == am2[0, 0, 0, 0] == 0
+    differ = np.isnan(y2) & ~np.isnan(y)
+    assert differ.sum() >= 1 and differ[0, 1].sum() == differ.sum()          # only channel 1's bins that hold the interior NaN
+    for ph, pw in zip(*np.nonzero(differ[0, 1])):
+        assert am2[0, 1, ph, pw] == 5 * 17 + 8                               # numpy.argmax: the NaN's position
+        assert np.isfinite(y[0, 1, ph, pw])                                  # the scan: the maximum of the bin's other cells
+        rest = x[0, 1].copy(); rest[5, 8] = -np.inf
+        assert y[0, 1, ph, pw] == rest.reshape(-1)[am[0, 1, ph, pw]]
+    same = ~differ
+    assert np.array_equal(np.nan_to_num(y[same], nan=-1.0), np.nan_to_num(y2[same], nan=-1.0)) and np.array_equal(am[same], am2[same])
+
+
 def test_roi_bin_edges_need_double_arithmetic():
     """Chainer's CPU path derives bin edges in Python doubles: floor(p*(rh/7.)), ceil((p+1)*(rh/7.)).
     That is NOT the exact-rational formula: 7*(29/7.) = 29.000000000000004 -> ceil = 30, so the last bin
