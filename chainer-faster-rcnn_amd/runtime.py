@@ -390,12 +390,15 @@ class Runtime(object):
                                                m.ptr(pred), m.ptr(prob), m.stream()), "frcnn_head_decode_stacked")
         return pred, prob
 
-    def preprocess_u8(self, img, means, im_scale, out_hw):
-        """img (H,W,C) uint8 device array -> (1,C,OH,OW) float32 (forward.py:33-45 on the device)."""
+    def preprocess_u8(self, img, means, im_scale, out_hw, out=None):
+        """img (H,W,C) uint8 device array -> (1,C,OH,OW) float32 (forward.py:33-45 on the device); `out`: an existing array of that shape (a captured
+        graph's input buffer) to write into."""
         m, L = self.mem, self.lib
         H, W, C = [int(v) for v in img.shape]
         OH, OW = int(out_hw[0]), int(out_hw[1])
-        out = m.empty((1, C, OH, OW), "f32")
+        if out is None:
+            out = m.empty((1, C, OH, OW), "f32")
+        assert tuple(int(v) for v in out.shape) == (1, C, OH, OW)
         mh = np.ascontiguousarray(means, dtype=np.float64).ravel()
         _lib.check(L.frcnn_preprocess_u8(m.ptr(img), H, W, C, mh.ctypes.data_as(ctypes.c_void_p), float(im_scale), OH, OW, m.ptr(out),
                                          m.stream()), "frcnn_preprocess_u8")

@@ -752,7 +752,7 @@ def _torch_rcnn_losses(cls_score, bbox_pred, labels, targets, delta):
     the number of RoIs (F.huber_loss returns one value per row [chainer-ext]; loss_bbox.size is the row count)."""
     import torch
     loss_cls = torch.nn.functional.cross_entropy(cls_score, torch.from_numpy(np.asarray(labels, dtype=np.int64)))
-    d = bbox_pred - torch.from_numpy(np.ascontiguousarray(targets, dtype=np.float32))
+    d = bbox_pred - torch.from_numpy(np.ascontiguousarray(targets, dtype=np.float32)).to(bbox_pred.dtype)
     a = d.abs()
     loss_bbox = torch.where(a < delta, 0.5 * d * d, delta * (a - 0.5 * delta)).sum() / bbox_pred.shape[0]
     return loss_cls, loss_bbox
@@ -768,40 +768,81 @@ def rcnn_loss_grads(cls_score, bbox_pred, labels, targets, delta=1.0):
     return np.float32(lc.item()), np.float32(lb.item()), np.float32(acc), s.grad.numpy(), b.grad.numpy()
 
 
-def rcnn_train_grads(p, x, rois, keep_inds, labels, targets, mask6, mask7, layers=None, spatial_scale=1.0 / 16, delta=1.0):
+def rcnn_train_grads(p, x, rois, keep_inds, labels, targets, mask6, mask7, layers=None, spatial_scale=1.0 / 16, delta=1.0, float64=False):
     """One rcnn_train-mode forward/backward of FasterRCNN (faster_rcnn.py:110-173) given the proposals (rois (R,4)), the
     ProposalTargetLayer output (keep_inds, labels = use_gt_boxes[:, -1], class-wise targets) and the two dropout masks
     (values 0 or 1/(1-ratio) [chainer-ext F.dropout]).  RoI pooling is a custom autograd function over the C oracle.
-    -> (loss_rcnn, {link path: gradient}) for the trunk and the four head layers (the RPN receives no gradient)."""
+    -> (loss_rcnn, {link path: gradient}) for the trunk and the four head layers (the RPN receives no gradient).
+    float64: the same fp32 parameters / image / sample evaluated in float64 -- the arbiter of the full-size test (two fp32 passes through
+    17 layers take a handful of different ReLU / max-pool / arg-max decisions; how far that moves a gradient is measured against this pass).
+    RoI pooling then picks its arg-max cells on the float64 map itself (same scan rule) and gathers / scatters in float64."""
     import torch
     F = torch.nn.functional
+    dt = torch.float64 if float64 else torch.float32
 
     class RoiPool(torch.autograd.Function):
         @staticmethod
         def forward(ctx, feat, brois):
-            y, am = roi_pooling_2d(feat.detach().numpy(), brois, 7, 7, spatial_scale, return_argmax=True)
-            ctx.am, ctx.shape, ctx.brois = am, tuple(feat.shape), brois
+            if not float64:
+                y, am = roi_pooling_2d(feat.detach().numpy(), brois, 7, 7, spatial_scale, return_argmax=True)
+                ctx.am, ctx.shape, ctx.brois = am, tuple(feat.shape), brois
+                return torch.from_numpy(y)
+            # float64: bin edges from the fp32 restatement (they do not depend on the map), maxima / first arg-max per bin on the float64 map
+            f = feat.detach().numpy()[0]
+            C, H, W = f.shape
+            _, am32 = roi_pooling_2d(f.astype(np.float32)[None], brois, 7, 7, spatial_scale, return_argmax=True)
+            R = len(brois)
+            y = np.zeros((R, C, 7, 7), np.float64)
+            am = -np.ones((R, C, 7, 7), np.int64)
+            sc = np.float32(spatial_scale)
+            for r in range(R):
+                xs, ys = int(np.rint(np.float32(brois[r, 1]) * sc)), int(np.rint(np.float32(brois[r, 2]) * sc))
+                xe, ye = int(np.rint(np.float32(brois[r, 3]) * sc)), int(np.rint(np.float32(brois[r, 4]) * sc))
+                rw, rh = max(xe - xs + 1, 1), max(ye - ys + 1, 1)
+                sh, sw = rh / 7.0, rw / 7.0
+                for ph in range(7):
+                    hs, he = min(max(int(np.floor(ph * sh)) + ys, 0), H), min(max(int(np.ceil((ph + 1) * sh)) + ys, 0), H)
+                    for pw in range(7):
+                        ws, we = min(max(int(np.floor(pw * sw)) + xs, 0), W), min(max(int(np.ceil((pw + 1) * sw)) + xs, 0), W)
+                        if he <= hs or we <= ws:
+                            continue
+                        d = f[:, hs:he, ws:we].reshape(C, -1)
+                        a = d.argmax(axis=1)
+                        y[r, :, ph, pw] = d[np.arange(C), a]
+                        am[r, :, ph, pw] = (a // (we - ws) + hs) * W + (a % (we - ws) + ws)
+            assert ((am32 < 0) == (am < 0)).all()
+            ctx.am, ctx.shape = am, tuple(feat.shape)
             return torch.from_numpy(y)
 
         @staticmethod
         def backward(ctx, gy):
-            return torch.from_numpy(roi_pooling_2d_backward(np.ascontiguousarray(gy.numpy()), ctx.am, ctx.brois, ctx.shape)), None
+            if not float64:
+                return torch.from_numpy(roi_pooling_2d_backward(np.ascontiguousarray(gy.numpy()), ctx.am, ctx.brois, ctx.shape)), None
+            _, C, H, W = ctx.shape
+            g = np.zeros((C, H * W), np.float64)
+            gyn, am = gy.numpy(), ctx.am
+            cidx = np.broadcast_to(np.arange(C)[None, :, None, None], am.shape)
+            ok = am >= 0
+            np.add.at(g, (cidx[ok], am[ok]), gyn[ok])
+            return torch.from_numpy(g.reshape(1, C, H, W)), None
 
     names = [k for k in p if k.startswith("trunk/") or k.split("/")[0] in ("fc6", "fc7", "cls_score", "bbox_pred")]
-    tp = {k: _t(p[k]).clone().requires_grad_(True) for k in names}
-    h = _t(x)
+    tp = {k: _t(p[k]).to(dt).clone().requires_grad_(True) for k in names}
+    h = _t(x).to(dt)
     layers = layers or ["conv1_1", "conv1_2", "pool", "conv2_1", "conv2_2", "pool", "conv3_1", "conv3_2", "conv3_3", "pool",
                         "conv4_1", "conv4_2", "conv4_3", "pool", "conv5_1", "conv5_2", "conv5_3"]
     for l in layers:
         h = F.max_pool2d(h, 2, 2, ceil_mode=True) if l == "pool" else F.relu(F.conv2d(h, tp["trunk/%s/W" % l], tp["trunk/%s/b" % l], padding=1))
     brois = np.concatenate([np.zeros((len(rois), 1), np.float32), np.asarray(rois, np.float32)], axis=1)
     pool5 = RoiPool.apply(h, brois)
-    fc6 = F.relu(F.linear(pool5.reshape(len(rois), -1), tp["fc6/W"], tp["fc6/b"])) * _t(mask6)
-    fc7 = F.relu(F.linear(fc6, tp["fc7/W"], tp["fc7/b"])) * _t(mask7)
+    fc6 = F.relu(F.linear(pool5.reshape(len(rois), -1), tp["fc6/W"], tp["fc6/b"])) * _t(mask6).to(dt)
+    fc7 = F.relu(F.linear(fc6, tp["fc7/W"], tp["fc7/b"])) * _t(mask7).to(dt)
     cls_score = F.linear(fc7, tp["cls_score/W"], tp["cls_score/b"])
     bbox_pred = F.linear(fc7, tp["bbox_pred/W"], tp["bbox_pred/b"])
     idx = torch.from_numpy(np.asarray(keep_inds, dtype=np.int64))
     lc, lb = _torch_rcnn_losses(cls_score[idx], bbox_pred[idx], labels, targets, delta)
     total = lc + lb
     total.backward()
+    if float64:
+        return float(total.item()), {k: v.grad.numpy() for k, v in tp.items()}
     return np.float32(total.item()), {k: v.grad.numpy() for k, v in tp.items()}

@@ -10,6 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np  # noqa: E402
 
 import chainer_faster_rcnn_amd as pkg  # noqa: E402
+from chainer_faster_rcnn_amd import tuning as _tuning  # noqa: E402  (knobs go through frcnn_set_tuning, not the environment)
 from prop_bench import graph_us  # noqa: E402
 
 
@@ -27,16 +28,16 @@ def main():
     for name, (fn, nbytes) in forms.items():
         for per_cu in os.environ.get("PER_CU", "0,1,2,3,4,6,8").split(","):
             if per_cu == "0":
-                os.environ.pop("FRCNN_CONV1_WGS_PER_CU", None)
+                _tuning.set("FRCNN_CONV1_WGS_PER_CU", None)
             else:
-                os.environ["FRCNN_CONV1_WGS_PER_CU"] = per_cu
+                _tuning.set("FRCNN_CONV1_WGS_PER_CU", per_cu)
 
             def f():
                 for _ in range(8):
                     fn()
             us = graph_us(f, 8, replays=10)
             print("%-32s workgroups/CU %-8s %7.1f us  %5.2f TB/s" % (name, per_cu if per_cu != "0" else "default", us, nbytes / us / 1e6), flush=True)
-    os.environ.pop("FRCNN_CONV1_WGS_PER_CU", None)
+    _tuning.set("FRCNN_CONV1_WGS_PER_CU", None)
 
 
 if __name__ == "__main__":

@@ -8,6 +8,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import chainer_faster_rcnn_amd as pkg  # noqa: E402
+from chainer_faster_rcnn_amd import tuning as _tuning  # noqa: E402  (knobs go through frcnn_set_tuning, not the environment)
 
 SHAPES = [("conv1_1", 3, 64, 600, 1000), ("conv1_2", 64, 64, 600, 1000), ("conv2_1", 64, 128, 300, 500),
           ("conv2_2", 128, 128, 300, 500), ("conv3_1", 128, 256, 150, 250), ("conv3_2", 256, 256, 150, 250),
@@ -18,8 +19,8 @@ def main():
     """FRCNN_BF16_ABLS="0 1 2 3 4 7": repeat the sweep with each timing ablation of the 3x3 kernel (see conv_bf16.hip)."""
     for abl in os.environ.get("FRCNN_BF16_ABLS", "0").split():
         for dma in os.environ.get("FRCNN_BF16_DMAS", "").split() or [os.environ.get("FRCNN_BF16_DMA", "-1")]:
-            os.environ["FRCNN_BF16_ABL"] = abl
-            os.environ["FRCNN_BF16_DMA"] = dma
+            _tuning.set("FRCNN_BF16_ABL", abl)
+            _tuning.set("FRCNN_BF16_DMA", dma)
             print("abl", abl, "dma", dma, end="  ")
             sweep()
 

@@ -10,6 +10,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import chainer_faster_rcnn_amd as pkg  # noqa: E402
+from chainer_faster_rcnn_amd import tuning as _tuning  # noqa: E402  (knobs go through frcnn_set_tuning, not the environment)
 from prop_bench import graph_us  # noqa: E402
 
 SHAPES = [("conv1_1", 3, 64, 600, 1000, False), ("conv1_2", 64, 64, 600, 1000, True), ("conv2_1", 64, 128, 300, 500, False),
@@ -45,13 +46,13 @@ def main():
                     rt.conv3x3(x, wn, b, relu=True)
         for abl in os.environ.get("ABLS", "").split(","):
             if abl:
-                os.environ["FRCNN_F32S_ABL"] = abl
+                _tuning.set("FRCNN_F32S_ABL", abl)
                 print("   ablation %s: %.1f us" % (abl, graph_us(f_split, 4, replays=10)))
-        os.environ["FRCNN_F32S_ABL"] = "0"
+        _tuning.set("FRCNN_F32S_ABL", "0")
         if os.environ.get("XCD_AB"):
-            os.environ["FRCNN_F32S_XCD"] = "0"
+            _tuning.set("FRCNN_F32S_XCD", "0")
             print("   linear tile order: %.1f us" % graph_us(f_split, 4, replays=10))
-            os.environ.pop("FRCNN_F32S_XCD", None)
+            _tuning.set("FRCNN_F32S_XCD", None)
         us_s = graph_us(f_split, 4, replays=10)
         us_n = graph_us(f_native, 4, replays=10)
         gf = 2.0 * ci * co * 9 * h * w / 1e9

@@ -8,6 +8,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import chainer_faster_rcnn_amd as pkg  # noqa: E402
+from chainer_faster_rcnn_amd import tuning as _tuning  # noqa: E402  (knobs go through frcnn_set_tuning, not the environment)
 
 
 def main():
@@ -16,9 +17,9 @@ def main():
     blk_b = torch.empty_like(blk_a)
     for variant in ("dma", "reg", "dma", "reg"):
         if variant == "reg":
-            os.environ["FRCNN_LINEAR_NODMA"] = "1"
+            _tuning.set("FRCNN_LINEAR_NODMA", "1")
         else:
-            os.environ.pop("FRCNN_LINEAR_NODMA", None)
+            _tuning.set("FRCNN_LINEAR_NODMA", None)
         out = []
         for name, M, N, K in [("fc6", 300, 4096, 25088), ("fc7", 300, 4096, 4096), ("bbox", 300, 84, 4096)]:
             rs = np.random.RandomState(0)

@@ -10,6 +10,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import chainer_faster_rcnn_amd as pkg  # noqa: E402
+from chainer_faster_rcnn_amd import tuning as _tuning  # noqa: E402  (knobs go through frcnn_set_tuning, not the environment)
 from chainer_faster_rcnn_amd import synthetic  # noqa: E402
 from chainer_faster_rcnn_amd.models import FasterRCNN  # noqa: E402
 
@@ -51,9 +52,9 @@ def main():
         for _ in range(8):
             pl.forward_device(prob, bbox, 600, 1000)
     for scan in ("0", "1"):
-        os.environ["FRCNN_NMS_SCAN"] = scan
+        _tuning.set("FRCNN_NMS_SCAN", scan)
         print("FRCNN_NMS_SCAN=%s: %.1f us per proposals call (test mode 6000 -> 300)" % (scan, graph_us(seq, 8)))
-    os.environ["FRCNN_NMS_SCAN"] = "0"
+    _tuning.set("FRCNN_NMS_SCAN", "0")
     pl.train = True
 
     def seq_train():

@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
 import chainer_faster_rcnn_amd as pkg  # noqa: E402
+from chainer_faster_rcnn_amd import tuning as _tuning  # noqa: E402  (knobs go through frcnn_set_tuning, not the environment)
 from chainer_faster_rcnn_amd import synthetic  # noqa: E402
 from chainer_faster_rcnn_amd.models import FasterRCNN  # noqa: E402
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -42,7 +43,7 @@ def main():
         if old is not None:
             print("previous revision: %.2f us" % graph_us(seq_old, 10))
         for dbg in (0, 1, 2, 4, 8, 12):
-            os.environ["FRCNN_ROI_DBG"] = str(dbg)
+            _tuning.set("FRCNN_ROI_DBG", str(dbg))
             print("FRCNN_ROI_DBG=%2d: %.2f us" % (dbg, graph_us(seq, 10)))
 
 

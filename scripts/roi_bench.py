@@ -9,6 +9,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import chainer_faster_rcnn_amd as pkg  # noqa: E402
+from chainer_faster_rcnn_amd import tuning as _tuning  # noqa: E402  (knobs go through frcnn_set_tuning, not the environment)
 from chainer_faster_rcnn_amd import synthetic  # noqa: E402
 from chainer_faster_rcnn_amd.models import FasterRCNN  # noqa: E402
 
@@ -45,16 +46,16 @@ def main():
     R = int(rois.shape[0])
     y = rt.mem.empty((R, C, 7, 7), "f32")
     nbytes = (C * H * W + R * C * 49) * 4 + R * 16
-    os.environ["FRCNN_ROI_KERNEL"] = "cells"
+    _tuning.set("FRCNN_ROI_KERNEL", "cells")
     us = timeit(lambda: rt.roi_pool_fwd_chw(feat, rois, 7, 7, 1 / 16., out=y))
     print("cells (NCHW, b128) %.1f us  %.0f GB/s  (%.1f %% of 8 TB/s)" % (us, nbytes / us / 1e3, nbytes / us / 1e3 / 80))
     yb = rt.roi_pool_fwd_chw_bf16(feat, rois, 7, 7, 1 / 16.)
     us = timeit(lambda: rt.roi_pool_fwd_chw_bf16(feat, rois, 7, 7, 1 / 16.))
     print("cells, bf16 out    %.1f us" % us)
-    os.environ["FRCNN_ROI_KERNEL"] = "planes"
+    _tuning.set("FRCNN_ROI_KERNEL", "planes")
     us = timeit(lambda: rt.roi_pool_fwd_chw(feat, rois, 7, 7, 1 / 16., out=y))
     print("planes (NCHW)      %.1f us  %.0f GB/s  (%.1f %% of 8 TB/s)" % (us, nbytes / us / 1e3, nbytes / us / 1e3 / 80))
-    os.environ["FRCNN_ROI_KERNEL"] = "cells"
+    _tuning.set("FRCNN_ROI_KERNEL", "cells")
     us = timeit(lambda: rt.roi_pool_fwd_chw(feat, rois, 7, 7, 1 / 16., want_argmax=True, out=y))
     print("planes + argmax    %.1f us" % us)
     xt = rt.chw_to_hwc(feat)

@@ -10,6 +10,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import chainer_faster_rcnn_amd as pkg  # noqa: E402
+from chainer_faster_rcnn_amd import tuning as _tuning  # noqa: E402  (knobs go through frcnn_set_tuning, not the environment)
 from prop_bench import graph_us  # noqa: E402
 
 SHAPES = [("conv1_1", 3, 64, 600, 1000), ("conv1_2", 64, 64, 600, 1000), ("conv2_1", 64, 128, 300, 500), ("conv2_2", 128, 128, 300, 500),
@@ -30,9 +31,9 @@ def main():
         res = {}
         for sp in os.environ.get("SPLITS", "0").split(","):
             if sp != "0":
-                os.environ["FRCNN_WGRAD_F32S_SPLITS"] = sp
+                _tuning.set("FRCNN_WGRAD_F32S_SPLITS", sp)
             else:
-                os.environ.pop("FRCNN_WGRAD_F32S_SPLITS", None)
+                _tuning.set("FRCNN_WGRAD_F32S_SPLITS", None)
             res[sp] = graph_us(lambda: [rt.conv_wgrad_f32s(x, dy, out=out) for _ in range(4)], 4, replays=8)
         us_n = graph_us(lambda: [rt.conv_wgrad(x, dy, 3, out=out) for _ in range(4)], 4, replays=8)
         gf = 2.0 * ci * co * 9 * h * w / 1e9

