@@ -641,7 +641,7 @@ class RCNNTrainer(_BucketedAllReduce):
         stage("roi_pool_bwd")
         (trunk_backward_split if self.conv_math == "split" else trunk_backward)(self, list(zip(self.layers, inputs)), gfeat)
         stage("trunk_bwd")
-        return dict(losses=losses, n_rois=n, keep_inds=keep, masks=(m6, m7))
+        return dict(losses=losses, n_rois=n, keep_inds=keep, masks=(m6, m7), head_acts=(a6, a7))       # head_acts: relu(fc6), relu(fc7) before dropout (the parity tests read the device's ReLU decisions off them)
 
     def update(self):
         self._ensure_adopted()

@@ -768,14 +768,17 @@ def rcnn_loss_grads(cls_score, bbox_pred, labels, targets, delta=1.0):
     return np.float32(lc.item()), np.float32(lb.item()), np.float32(acc), s.grad.numpy(), b.grad.numpy()
 
 
-def rcnn_train_grads(p, x, rois, keep_inds, labels, targets, mask6, mask7, layers=None, spatial_scale=1.0 / 16, delta=1.0, float64=False):
+def rcnn_train_grads(p, x, rois, keep_inds, labels, targets, mask6, mask7, layers=None, spatial_scale=1.0 / 16, delta=1.0, float64=False, head_relu=None):
     """One rcnn_train-mode forward/backward of FasterRCNN (faster_rcnn.py:110-173) given the proposals (rois (R,4)), the
     ProposalTargetLayer output (keep_inds, labels = use_gt_boxes[:, -1], class-wise targets) and the two dropout masks
     (values 0 or 1/(1-ratio) [chainer-ext F.dropout]).  RoI pooling is a custom autograd function over the C oracle.
     -> (loss_rcnn, {link path: gradient}) for the trunk and the four head layers (the RPN receives no gradient).
     float64: the same fp32 parameters / image / sample evaluated in float64 -- the arbiter of the full-size test (two fp32 passes through
     17 layers take a handful of different ReLU / max-pool / arg-max decisions; how far that moves a gradient is measured against this pass).
-    RoI pooling then picks its arg-max cells on the float64 map itself (same scan rule) and gathers / scatters in float64."""
+    RoI pooling then picks its arg-max cells on the float64 map itself (same scan rule) and gathers / scatters in float64.
+    head_relu = (r6, r7) boolean (R, hidden) arrays: IMPOSE these ReLU decisions on fc6 / fc7 instead of taking the pass's own (the device's, read off
+    its activations: a pre-activation within summation noise of zero may take the other branch there -- one flipped unit moves fc6's bias gradient by
+    that unit's whole upstream gradient); the number of imposed decisions that differ from the pass's own is returned as a third value."""
     import torch
     F = torch.nn.functional
     dt = torch.float64 if float64 else torch.float32
@@ -835,14 +838,29 @@ def rcnn_train_grads(p, x, rois, keep_inds, labels, targets, mask6, mask7, layer
         h = F.max_pool2d(h, 2, 2, ceil_mode=True) if l == "pool" else F.relu(F.conv2d(h, tp["trunk/%s/W" % l], tp["trunk/%s/b" % l], padding=1))
     brois = np.concatenate([np.zeros((len(rois), 1), np.float32), np.asarray(rois, np.float32)], axis=1)
     pool5 = RoiPool.apply(h, brois)
-    fc6 = F.relu(F.linear(pool5.reshape(len(rois), -1), tp["fc6/W"], tp["fc6/b"])) * _t(mask6).to(dt)
-    fc7 = F.relu(F.linear(fc6, tp["fc7/W"], tp["fc7/b"])) * _t(mask7).to(dt)
+    flips = 0
+    pre6 = F.linear(pool5.reshape(len(rois), -1), tp["fc6/W"], tp["fc6/b"])
+    if head_relu is None:
+        fc6 = F.relu(pre6) * _t(mask6).to(dt)
+    else:
+        r6 = torch.from_numpy(np.ascontiguousarray(head_relu[0], dtype=bool))
+        flips += int(((pre6.detach() > 0) != r6).sum())
+        fc6 = pre6 * r6.to(dt) * _t(mask6).to(dt)
+    pre7 = F.linear(fc6, tp["fc7/W"], tp["fc7/b"])
+    if head_relu is None:
+        fc7 = F.relu(pre7) * _t(mask7).to(dt)
+    else:
+        r7 = torch.from_numpy(np.ascontiguousarray(head_relu[1], dtype=bool))
+        flips += int(((pre7.detach() > 0) != r7).sum())
+        fc7 = pre7 * r7.to(dt) * _t(mask7).to(dt)
     cls_score = F.linear(fc7, tp["cls_score/W"], tp["cls_score/b"])
     bbox_pred = F.linear(fc7, tp["bbox_pred/W"], tp["bbox_pred/b"])
     idx = torch.from_numpy(np.asarray(keep_inds, dtype=np.int64))
     lc, lb = _torch_rcnn_losses(cls_score[idx], bbox_pred[idx], labels, targets, delta)
     total = lc + lb
     total.backward()
+    if head_relu is not None:
+        return float(total.item()), {k: v.grad.numpy() for k, v in tp.items()}, flips
     if float64:
         return float(total.item()), {k: v.grad.numpy() for k, v in tp.items()}
     return np.float32(total.item()), {k: v.grad.numpy() for k, v in tp.items()}

@@ -291,19 +291,36 @@ def check_rcnn_step(rt, model, params, layers, x, gt, info, feat_stride, seed=0,
         loss64, want64 = O.rcnn_train_grads(params, x, rois, keep, use_gt[:, -1].astype(np.int64), ext, masks[0], masks[1], layers=names,
                                             spatial_scale=1.0 / feat_stride, float64=True)
         assert abs(l["loss_rcnn"] - loss64) <= 1e-4 * abs(loss64), (l, loss64)
+        # ... and once more in float64 with the DEVICE's fc6 / fc7 ReLU decisions imposed (read off its activations): of 1.2 M fc6 pre-activations a
+        # couple sit within fp32 summation noise (K = 25088) of zero, and ONE unit taking the other branch moves fc6's bias gradient by that unit's whole
+        # upstream gradient (measured: 1.6e-2 of the largest entry) -- decision noise, not arithmetic.  The flips are counted and must be a handful.
+        a6, a7 = [rt.mem.to_numpy(a) for a in out["head_acts"]]
+        _, want64h, flips = O.rcnn_train_grads(params, x, rois, keep, use_gt[:, -1].astype(np.int64), ext, masks[0], masks[1], layers=names,
+                                               spatial_scale=1.0 / feat_stride, float64=True, head_relu=(a6 > 0, a7 > 0))
         table = {}
         for k in sorted(want):
             w64 = want64[k]
             scale = max(float(np.abs(w64).max()), 1e-12)
             e_dev = float(np.abs(got[k].astype(np.float64) - w64).max() / scale)
             e_t32 = float(np.abs(want[k].astype(np.float64) - w64).max() / scale)
-            table[k] = {"device_vs_f64": float("%.3g" % e_dev), "torch_fp32_vs_f64": float("%.3g" % e_t32)}
-            worst = max(worst, e_dev)
-        print("\nPARITY_TABLE rcnn_train_600x1000%s %s" % ("_split_products" if conv_math == "split" else "", json_dumps(table)))
+            e_giv = float(np.abs(got[k].astype(np.float64) - want64h[k]).max() / max(float(np.abs(want64h[k]).max()), 1e-12))
+            table[k] = {"device_vs_f64": float("%.3g" % e_dev), "torch_fp32_vs_f64": float("%.3g" % e_t32), "device_vs_f64_given_device_head_relu": float("%.3g" % e_giv)}
+            worst = max(worst, e_giv)
+        tag = "rcnn_train_600x1000%s" % ("_split_products" if conv_math == "split" else "")
+        print("\nPARITY_TABLE %s %s" % (tag, json_dumps(table)))
+        print("PARITY_FLIPS %s %s" % (tag, json_dumps({"fc6_fc7_relu_decisions_that_differ_from_the_float64_pass": int(flips), "of": int(a6.size + a7.size)})))
+        assert flips <= 16, flips
+        beyond = []
         for k, row in sorted(table.items()):
-            assert row["device_vs_f64"] <= max(1e-3, 2.0 * row["torch_fp32_vs_f64"]) or row["device_vs_f64"] <= 5e-3, (k, row)
-        beyond = [(k, r["device_vs_f64"], r["torch_fp32_vs_f64"]) for k, r in sorted(table.items()) if r["device_vs_f64"] > max(1e-3, 2.0 * r["torch_fp32_vs_f64"])]
-        print("PARITY_EXCEED rcnn_train_600x1000 %s" % json_dumps({"gradients_beyond_max(1e-3, 2 x torch_fp32_vs_f64)_but_within_5e-3": beyond}))
+            # under the device's own head decisions: max(1e-3, 2 x torch's own fp32 distance), 5e-3 at most (the trunk's ReLU / max-pool / arg-max decisions
+            # stay free, as in the RPN step's end-to-end column)
+            e = row["device_vs_f64_given_device_head_relu"]
+            assert e <= 5e-3, (k, row)
+            if e > max(1e-3, 2.0 * row["torch_fp32_vs_f64"]):
+                beyond.append((k, e, row["torch_fp32_vs_f64"]))
+            if flips == 0:
+                assert row["device_vs_f64"] <= 5e-3, (k, row)
+        print("PARITY_EXCEED %s %s" % (tag, json_dumps({"gradients_beyond_max(1e-3, 2 x torch_fp32_vs_f64)_but_within_5e-3": beyond})))
     else:
         for k in sorted(want):
             scale = max(np.abs(want[k]).max(), 1e-8)
