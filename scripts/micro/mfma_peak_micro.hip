@@ -14,8 +14,32 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// round 5: the same stream with v_mfma_f32_16x16x32_bf16 (KIND 2: half the accumulator rows per instruction, twice the k -- the same flops per instruction
+// and per operand byte; does the datapath draw the same power for them?), and with HALF of the B operand's values zero (zero_b: what a post-ReLU activation
+// map looks like to the multipliers)
+template <int KIND>
+__global__ void __launch_bounds__(256) mfma_stream16(float *out, int n, const uint4 *rnd, int zero_b) {
+    f32x4 acc[10];
+    for (int a = 0; a < 10; ++a) for (int r = 0; r < 4; ++r) acc[a][r] = 0.f;
+    bf16x8 va[5], vb[5];
+    for (int k = 0; k < 5; ++k) {
+        const uint4 ra = rnd[(k * 2) * 256 + threadIdx.x];
+        uint4 rb = rnd[(k * 2 + 1) * 256 + threadIdx.x];
+        if (zero_b) { rb.x &= 0xffff0000u; rb.y &= 0x0000ffffu; rb.z &= 0xffff0000u; rb.w &= 0x0000ffffu; }
+        va[k] = __builtin_bit_cast(bf16x8, ra); vb[k] = __builtin_bit_cast(bf16x8, rb);
+    }
+    for (int i = 0; i < n; i += 10) {
+#pragma unroll
+        for (int a = 0; a < 10; ++a) acc[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(va[a % 5], vb[a / 2], acc[a], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int a = 0; a < 10; ++a) for (int r = 0; r < 4; ++r) s += acc[a][r];
+    if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
 template <int KIND>   // 0: v_mfma_f32_32x32x16_bf16, 1: v_mfma_f32_32x32x2_f32
-__global__ void __launch_bounds__(256) mfma_stream(float *out, int n, const uint4 *rnd) {
+__global__ void __launch_bounds__(256) mfma_stream(float *out, int n, const uint4 *rnd, int zero_b = 0) {
     f32x16 acc[10];
     for (int a = 0; a < 10; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
     // operands: small constants (rnd == nullptr: almost no bits toggle between MFMAs) or random bf16 / fp32 values in [-1, 1), a different
@@ -27,7 +51,9 @@ __global__ void __launch_bounds__(256) mfma_stream(float *out, int n, const uint
         fa[k] = (float)(threadIdx.x & 3); fb[k] = 1.0f;
         if (rnd) {
             const uint4 ra = rnd[(k * 2) * 256 + threadIdx.x], rb = rnd[(k * 2 + 1) * 256 + threadIdx.x];
-            va[k] = __builtin_bit_cast(bf16x8, ra); vb[k] = __builtin_bit_cast(bf16x8, rb);
+            uint4 rbz = rb;
+            if (zero_b) { rbz.x &= 0xffff0000u; rbz.y &= 0x0000ffffu; rbz.z &= 0xffff0000u; rbz.w &= 0x0000ffffu; }
+            va[k] = __builtin_bit_cast(bf16x8, ra); vb[k] = __builtin_bit_cast(bf16x8, rbz);
             fa[k] = __uint_as_float((ra.x & 0x007fffffu) | 0x3f000000u) - 0.75f; fb[k] = __uint_as_float((rb.x & 0x007fffffu) | 0x3f000000u) - 0.75f;
         }
     }
@@ -45,7 +71,7 @@ __global__ void __launch_bounds__(256) mfma_stream(float *out, int n, const uint
 
 static int g_burst = 10;
 template <int KIND>
-static void run(const char *name, double flop_per_mfma, int wps, int n, int cus, bool random_data) {
+static void run(const char *name, double flop_per_mfma, int wps, int n, int cus, bool random_data, int zero_b = 0) {
     float *out; CK(hipMalloc(&out, 4096));
     uint4 *rnd = nullptr;
     if (random_data) {                                                    // bf16 pairs with exponents around 2^-2 .. 2^0, random signs and mantissas
@@ -61,12 +87,16 @@ static void run(const char *name, double flop_per_mfma, int wps, int n, int cus,
     hipStream_t s; CK(hipStreamCreate(&s));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const dim3 grid(cus * wps), block(256);
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(mfma_stream<KIND>, grid, block, 0, s, out, n, rnd);      // warm-up: let the clocks settle under load
+    auto launch = [&]() {
+        if (KIND == 2) hipLaunchKernelGGL(mfma_stream16<2>, grid, block, 0, s, out, n, rnd, zero_b);
+        else hipLaunchKernelGGL(mfma_stream<(KIND == 2 ? 0 : KIND)>, grid, block, 0, s, out, n, rnd, zero_b);
+    };
+    for (int i = 0; i < 20; ++i) launch();      // warm-up: let the clocks settle under load
     CK(hipStreamSynchronize(s));
     std::vector<double> tf;
     for (int r = 0; r < 9; ++r) {
         CK(hipEventRecord(e0, s));
-        for (int i = 0; i < g_burst; ++i) hipLaunchKernelGGL(mfma_stream<KIND>, grid, block, 0, s, out, n, rnd);
+        for (int i = 0; i < g_burst; ++i) launch();
         CK(hipEventRecord(e1, s)); CK(hipEventSynchronize(e1));
         float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
         tf.push_back((double)g_burst * grid.x * 4 * (double)n * flop_per_mfma / (ms * 1e-3) / 1e12);
@@ -74,7 +104,7 @@ static void run(const char *name, double flop_per_mfma, int wps, int n, int cus,
     std::sort(tf.begin(), tf.end());
     const double med = tf[tf.size() / 2];
     // clocks per MFMA are known (32.9 / 64.0, profiles/r03_mfma_filler_micro.txt): the implied shader clock under this load
-    const double clk_per = KIND == 0 ? 32.9 : 64.04, mfma_per_s_per_simd = med * 1e12 / flop_per_mfma / (cus * 4.0);
+    const double clk_per = KIND == 0 ? 32.9 : (KIND == 2 ? 16.45 : 64.04), mfma_per_s_per_simd = med * 1e12 / flop_per_mfma / (cus * 4.0);
     printf("%-40s %d wave(s)/SIMD, %d MFMAs/wave: median %8.1f TFLOP/s (min %.1f max %.1f)  -> implied shader clock %.2f GHz\n", name, wps, n, med, tf.front(), tf.back(),
            mfma_per_s_per_simd * clk_per / wps / 1e9 * wps);
     CK(hipFree(out)); if (rnd) CK(hipFree(rnd));
@@ -90,5 +120,9 @@ int main(int argc, char **argv) {
     run<1>("f32 32x32x2, constant operands", 4096.0, wps, n, p.multiProcessorCount, false);
     run<1>("f32 32x32x2, random operands", 4096.0, wps, n, p.multiProcessorCount, true);
     run<0>("bf16 32x32x16, random operands again", 32768.0, wps, n, p.multiProcessorCount, true);
+    run<0>("bf16 32x32x16, random, half of B zero", 32768.0, wps, n, p.multiProcessorCount, true, 1);
+    run<2>("bf16 16x16x32, random operands", 16384.0, wps, 2 * n, p.multiProcessorCount, true);
+    run<2>("bf16 16x16x32, random, half of B zero", 16384.0, wps, 2 * n, p.multiProcessorCount, true, 1);
+    run<0>("bf16 32x32x16, random operands once more", 32768.0, wps, n, p.multiProcessorCount, true);
     return 0;
 }
