@@ -70,12 +70,12 @@ class EventTimer(object):
 
 
 def pmc_traffic(dtype):
-    """HBM bytes per conv launch from the committed PMC passes of this same command (scripts/gpu_traffic.sh: FETCH_SIZE and
+    """HBM bytes per conv launch from the committed PMC passes of this same command (scripts/gpu_evidence.sh + scripts/gpu_traffic.py: FETCH_SIZE and
     WRITE_SIZE in separate rocprofv3 --pmc runs); counters cannot be read from inside the process, so the bench line carries
     the last measured figure and names its source, or null when no PMC pass exists for this dtype."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    cands = {"f32": ["r04_hbm_traffic_pmc.json", "r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"],
-             "bf16": ["r04_hbm_traffic_pmc_bf16.json", "r03_hbm_traffic_pmc_bf16.json", "r02_hbm_traffic_pmc_bf16.json"],
+    cands = {"f32": ["r05_hbm_traffic_pmc.json", "r04_hbm_traffic_pmc.json", "r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"],
+             "bf16": ["r05_hbm_traffic_pmc_bf16.json", "r04_hbm_traffic_pmc_bf16.json", "r03_hbm_traffic_pmc_bf16.json", "r02_hbm_traffic_pmc_bf16.json"],
              "f32s": ["r03_hbm_traffic_pmc_f32s.json", "r02_hbm_traffic_pmc_f32s.json"]}[dtype]
     kernel = {"f32": "conv_mfma_f32_kernel", "bf16": "conv_bf16_kernel", "f32s": "conv_f32s_kernel"}[dtype]
     for name in cands:
@@ -331,7 +331,9 @@ def feed_variant(torch, rt, graph, steps, n_images=8, check_oracle=True):
     host = [torch.from_numpy(rs.randint(0, 256, size=(IM_H, IM_W, 3), dtype=np.uint8)).pin_memory() for _ in range(n_images)]
     u8 = torch.empty((IM_H, IM_W, 3), dtype=torch.uint8, device=dev)
     means = np.asarray(PIXEL_MEANS, dtype=np.float64).ravel()
-    main, copy = torch.cuda.current_stream(dev), torch.cuda.Stream(device=dev)
+    main = torch.cuda.current_stream(dev)
+    copies = [torch.cuda.Stream(device=dev) for _ in range(4)]        # candidates: a copy stream that shares a hardware queue with the compute stream serialises with it
+    copy = copies[0]
     consumed, landed = torch.cuda.Event(), torch.cuda.Event()
     report = {}
     if check_oracle:                                          # the fed tensor is the oracle's img_preprocessing of the same pixels
@@ -343,6 +345,10 @@ def feed_variant(torch, rt, graph, steps, n_images=8, check_oracle=True):
         got = rt.mem.to_numpy(graph.x)[0]
         report["fed_image_vs_oracle_img_preprocessing_max_abs"] = float(np.abs(got - want).max()) if got.shape == want.shape else "shape %r vs %r" % (got.shape, want.shape)
         report["im_scale"] = float(scale)
+
+    # the host stays at most four images ahead of the device (a serving loop reads its results anyway): with unbounded run-ahead -- hundreds of graph launches,
+    # copies and cross-stream events queued -- the same loop measured 1420 instead of 1553-1567 img/s on the bf16 line (sync every 1 ... 16 images: all the same)
+    sync_every = 4
 
     def run(k_steps):
         with torch.cuda.stream(copy):
@@ -357,16 +363,59 @@ def feed_variant(torch, rt, graph, steps, n_images=8, check_oracle=True):
                 u8.copy_(host[(k + 1) % n_images], non_blocking=True)
                 landed.record(copy)
             graph.graph.replay()
+            if sync_every and k % sync_every == sync_every - 1:
+                consumed.synchronize()                        # the host stays at most `sync_every` images ahead of the device
         main.wait_event(landed)
+    probe = []
+    for cand in copies:                                       # (ForwardsInFlight's lesson: which streams share one of the runtime's hardware queues is not knowable up front)
+        copy = cand
+        run(5)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(30)
+        torch.cuda.synchronize()
+        probe.append(30 / (time.perf_counter() - t0))
+    copy = copies[int(np.argmax(probe))]
     run(5)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    report["copy_stream_probe_img_s"] = [round(v, 1) for v in probe]
     report.update({"img_s_with_feed": steps / dt, "ms_per_step_with_feed": dt / steps * 1e3, "steps": steps, "distinct_images": n_images,
+                   "host_runs_ahead_by_at_most": sync_every,
                    "what": "per step: pinned uint8 HWC image (1.8 MB) -> H2D on a copy stream under the previous forward -> frcnn_preprocess_u8 into the graph's input -> graph replay"})
     return report
+
+
+def two_streams_variant(torch, pkg, rt, params, dtype, x, steps, graph_a):
+    """TWO images in flight per GPU (chainer_faster_rcnn_amd.graph.ForwardsInFlight: two model instances with their own workspaces and captured graphs on two HIP
+    streams, image k on slot k % 2): image k's proposal / RoI / head stages overlap image k + 1's convolutions.  Throughput of a serving loop, not the latency of
+    one image; a secondary figure next to the one-image-at-a-time contract line.  The outputs of the concurrent replays are compared with the serial graph's."""
+    from chainer_faster_rcnn_amd.graph import ForwardsInFlight
+    from chainer_faster_rcnn_amd.models import FasterRCNN
+
+    def make_model(rt_i):
+        m = FasterRCNN(runtime=rt_i, conv_dtype=dtype, head_dtype=dtype)
+        m.load_params(params)
+        return m
+    fl = ForwardsInFlight(make_model, lambda: pkg.runtime.Runtime(rt.lib, pkg.runtime.TorchDeviceMemory(str(rt.mem.device))), x, IM_H, IM_W, n=2)
+    for _ in range(20):
+        fl.submit()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fl.submit()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ref = graph_a.replay(x)
+    torch.cuda.synchronize()
+    same = all(bool(torch.equal(g.out[k], ref[k])) for g in fl.slots for k in ("rois", "cls_prob", "pred_boxes", "n_out"))
+    return {"img_s_two_images_in_flight": steps / dt, "ms_per_image": dt / steps * 1e3, "steps": steps, "outputs_identical_to_the_serial_graph": same,
+            "stream_set_probe_img_s": {"best": round(max(fl.probe.values()), 1), "worst": round(min(fl.probe.values()), 1), "sets": len(fl.probe),
+                                       "why": "streams that share one of the runtime's hardware queues run one after the other: the constructor keeps the pair that overlaps"},
+            "what": "two model instances (own workspaces + captured graphs, same weights), image k on HIP stream k % 2: image k's proposal / RoI / head stages overlap image k + 1's convolutions"}
 
 
 def bf16_variant(args, torch, rt, params, x, dbg, flops_total):
@@ -403,6 +452,14 @@ def bf16_variant(args, torch, rt, params, x, dbg, flops_total):
            "value": steps / dt, "unit": "img/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "launch": "hipGraph replay"}
     if feed is not None:
         out["with_feed"] = feed
+    if not args.no_two_streams_variant:
+        try:
+            import chainer_faster_rcnn_amd as _pkg
+            graph.replay(x)
+            out["two_images_in_flight"] = two_streams_variant(torch, _pkg, rt, params, "bf16", x, 2 * steps, graph)
+        except Exception as e:
+            out["two_images_in_flight"] = {"error": repr(e)}
+            torch.cuda.synchronize()
     try:
         conv_ms = graph_time_us(torch, f32s_conv_chain(rt, model, x, bf16=True), 1, max(args.steps, 100)) / 1e3
         out.update(conv_ms_per_image=conv_ms, conv_tflops=flops_total / (conv_ms * 1e-3) / 1e12,
@@ -635,6 +692,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16-variant", action="store_true", help="skip the bf16_config3 block (BASELINE configs[2] per GPU) of the default line")
     ap.add_argument("--no-stage-events", action="store_true")
+    ap.add_argument("--no-two-streams-variant", action="store_true",
+                    help="skip the secondary measurement with two images in flight per GPU (a second model instance replaying its graph on a second stream)")
     ap.add_argument("--no-feed-variant", action="store_true",
                     help="skip the secondary measurement with the input inside the timed region (uint8 image -> H2D -> frcnn_preprocess_u8 -> forward, a different image per step)")
     ap.add_argument("--no-split-variant", action="store_true",
@@ -761,6 +820,15 @@ def main():
             feed_main = {"error": repr(e)}
             torch.cuda.synchronize()
         graph.replay(x)                                           # the resident image back in the graph's input (parity below reads its outputs)
+    two_main = None
+    if rank == 0 and world == 1 and use_graph and not args.no_two_streams_variant:
+        try:
+            graph.replay(x)
+            torch.cuda.synchronize()
+            two_main = two_streams_variant(torch, pkg, rt, params, args.dtype, x, max(args.steps, 50), graph)
+        except Exception as e:
+            two_main = {"error": repr(e)}
+            torch.cuda.synchronize()
     # roofline of the dominant kernel: the 14 conv launches (13 trunk convs with their fused pools + rpn_conv_3x3) as their own
     # hipGraph, replays bracketed by HIP events on the launch stream -- kernel time only, whatever the host is doing
     conv_chain_ms, iso = None, {}
@@ -906,6 +974,8 @@ def main():
                     res["nms_roi"][tag + "_frac_of_hbm_peak"] = train_bytes / (iso[key] * 1e-6) / 1e9 / PEAK_HBM_GBPS
         if feed_main is not None:
             res["with_feed"] = feed_main
+        if two_main is not None:
+            res["two_images_in_flight"] = two_main
         dbg = None
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"], dbg = cpu_baseline(params, x_host, args.cpu_samples)
@@ -945,7 +1015,9 @@ def main():
                    "bf16_conv_frac_of_bf16_mfma_peak": b3.get("frac_of_bf16_mfma_peak"),
                    "f32s_img_s": sp.get("value"), "f32s_ms_per_step": sp.get("ms_per_step"),
                    "img_s_with_feed": (res.get("with_feed") or {}).get("img_s_with_feed"),
-                   "bf16_img_s_with_feed": (b3.get("with_feed") or {}).get("img_s_with_feed")}
+                   "bf16_img_s_with_feed": (b3.get("with_feed") or {}).get("img_s_with_feed"),
+                   "img_s_two_images_in_flight": (res.get("two_images_in_flight") or {}).get("img_s_two_images_in_flight"),
+                   "bf16_img_s_two_images_in_flight": (b3.get("two_images_in_flight") or {}).get("img_s_two_images_in_flight")}
             res["roofline"]["secondary"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in sec.items() if v is not None}
         emit_json_line(res)
     if dist is not None:

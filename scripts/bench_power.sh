@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 4: package power and shader clock while the bench's timed regions run (hipGraph replays of the whole forward): the fp32 contract line and the bf16 line.
+# Package power and shader clock while the bench's timed regions run (hipGraph replays of the whole forward): the fp32 contract line and the bf16 line.
 set -u
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; O=gpurun_out/r04b2; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; O=${O:-gpurun_out/power}; mkdir -p $O
 poll() { for i in $(seq 1 $1); do echo "t=$(date +%s.%N) $(/opt/rocm/bin/rocm-smi --showclocks --showpower 2>/dev/null | grep -E 'sclk|Current Socket' | tr -s ' ' | tr '\n' '|')"; sleep 0.1; done; }
 for dt in f32 bf16; do
   steps=2500; [ $dt = bf16 ] && steps=12000

@@ -72,9 +72,9 @@ def main(out_dir, dtype):
         n, fb, wb = family(lambda s, pred=pred: quad_args(s) is not None and pred(quad_args(s)))
         summ[key] = {"launches_counted": n, "fetch_bytes_per_launch": fb, "write_bytes_per_launch": wb, "note": note}
     n, fb, wb = family(lambda s: s.startswith("roi_pool_bwd_runs_kernel"))
-    summ["roi_pool_bwd_runs_kernel"] = {"launches_counted": n, "fetch_bytes_per_launch_raw": fb, "write_bytes_per_launch": wb,
-                                        "note": "8-byte-per-lane non-temporal reads of dy and argmax_data (counted 1:1 here; the guide's x2 correction is stated for "
-                                                "16-byte-per-lane loads); algorithmic 60.2 MB read + 4.90 MB written"}
+    summ["roi_pool_bwd_runs_kernel"] = {"launches_counted": n, "fetch_bytes_per_launch_raw": fb, "fetch_bytes_per_launch_x2": 2 * fb, "write_bytes_per_launch": wb,
+                                        "note": "8-byte-per-lane non-temporal reads of dy and argmax_data: FETCH_SIZE reports HALF of them, as it does for the 16-byte-per-lane "
+                                                "loads the guide's correction names (raw 31.5 MB for 60.2 MB that are certainly read once: x2); algorithmic 60.2 MB read + 4.90 MB written"}
     # only the forms this run launched (a block with zero launches is noise, not evidence)
     summ = {k: v for k, v in summ.items() if not isinstance(v, dict) or v.get("launches_counted", 1) > 0}
     out["_summary"] = summ

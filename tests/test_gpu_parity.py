@@ -544,6 +544,40 @@ def test_conv_workspace_self_cleaning(rt):
     P.check_conv_workspace_self_cleaning(rt)
 
 
+def test_forwards_in_flight_match_serial(rt):
+    """graph.ForwardsInFlight: two captured forwards on two HIP streams, four DIFFERENT images submitted back to back -- every image's outputs equal the serial
+    captured forward's for that image bit for bit (separate workspaces per instance: nothing is shared but the read-only weights)."""
+    import torch
+    import chainer_faster_rcnn_amd as pkg
+    from chainer_faster_rcnn_amd import synthetic
+    from chainer_faster_rcnn_amd.graph import CapturedForward, ForwardsInFlight
+    from chainer_faster_rcnn_amd.models import FasterRCNN
+    params = synthetic.params(seed=1)
+    h, w = 160, 224
+    imgs = [rt.mem.from_numpy(synthetic.image(seed=10 + i, h=h, w=w)) for i in range(4)]
+
+    def make_model(r):
+        m = FasterRCNN(runtime=r)
+        m.load_params(params)
+        return m
+    serial = CapturedForward(make_model(rt), imgs[0], h, w)
+    want = []
+    for x in imgs:
+        o = serial.replay(x)
+        torch.cuda.synchronize()
+        want.append({k: o[k].clone() for k in ("rois", "cls_prob", "pred_boxes", "n_out")})
+    fl = ForwardsInFlight(make_model, lambda: pkg.runtime.Runtime(rt.lib, pkg.runtime.TorchDeviceMemory(str(rt.mem.device))), imgs[0], h, w, n=2, probe_steps=4)
+    got = []
+    for rnd in range(2):                              # two images in flight, then the next two
+        handles = [fl.submit(imgs[2 * rnd + i]) for i in range(2)]
+        for slot, out in handles:
+            fl.wait(slot)
+            got.append({k: out[k].clone() for k in ("rois", "cls_prob", "pred_boxes", "n_out")})
+    for i in range(4):
+        for k in want[i]:
+            assert torch.equal(got[i][k], want[i][k]), (i, k)
+
+
 def test_captured_forward_matches_eager(rt):
     """hipGraph replay (graph.CapturedForward) == eager launches, bit for bit, also after the input buffer is replaced."""
     from chainer_faster_rcnn_amd import synthetic
