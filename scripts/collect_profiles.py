@@ -25,7 +25,7 @@ def main(tag="r05z", R="r05"):
             if line:
                 open(os.path.join(P, n + ".json"), "w").write(line)
     for n in (R + "_hbm_traffic_pmc.json", R + "_hbm_traffic_pmc_bf16.json", R + "_mfma_pmc_summary.json", R + "_roi_pmc.txt", R + "_store_micro.txt",
-              R + "_roi_micro.txt", R + "_conv_bf16_micro.txt", R + "_conv_f32_micro.txt", R + "_wgrad_micro.txt", R + "_mfma_filler_micro.txt", R + "_dma_align_micro.txt", R + "_conv_pair_micro.txt", R + "_mfma_peak_micro.txt", R + "_roi_bwd_pmc.txt", R + "_bench_power.txt"):
+              R + "_roi_micro.txt", R + "_conv_bf16_micro.txt", R + "_conv_f32_micro.txt", R + "_wgrad_micro.txt", R + "_mfma_filler_micro.txt", R + "_dma_align_micro.txt", R + "_conv_pair_micro.txt", R + "_mfma_peak_micro.txt", R + "_roi_bwd_pmc.txt", R + "_bench_power.txt", R + "_two_streams_probe.txt"):
         if os.path.exists(os.path.join(O, n)):
             shutil.copy(os.path.join(O, n), os.path.join(P, n))
     if os.path.exists(os.path.join(O, "parity_reports.txt")):

@@ -15,6 +15,8 @@ done
 { echo "=== chain: default picks vs conv_dma_bf16_kernel's (old)"; timeout 120 $B/conv_bf16_micro --check --modes "def old"; } > $O/r05_conv_bf16_micro.txt 2>&1; tail -3 $O/r05_conv_bf16_micro.txt
 { timeout 60 $B/mfma_peak_micro 1 20000 10; } > $O/r05_mfma_peak_micro.txt 2>&1
 for f in 1 0; do FRCNN_BF16_CONV1_PAIR=$f timeout 600 python bench.py --dtype bf16 --steps 100 --warmup 5 --no-cpu-baseline > $O/r05_bench_bf16_pair$f.json 2>> $O/bench.err; echo "bench bf16, conv1 pair launch = $f: rc=$?"; cut -c1-140 $O/r05_bench_bf16_pair$f.json | tail -1; done
+# two images in flight per GPU (graph.ForwardsInFlight's mechanism, torch-level probe): serial vs two / three instances, outputs compared
+{ for a in "bf16 2" "bf16 3" "f32 2" "f32s 2"; do timeout 300 python scripts/two_streams_probe.py $a; done; } 2>&1 | grep -v amdgpu.ids > $O/r05_two_streams_probe.txt; cat $O/r05_two_streams_probe.txt
 # the backward RoI kernel's counters (torch-free harness; the bwd launches of roi_micro)
 scripts/micro/roi_pmc.sh 'roi_pool_bwd_runs_kernel<2' DEFAULT=1 > $O/r05_roi_bwd_pmc.txt 2>&1; tail -12 $O/r05_roi_bwd_pmc.txt
 # package power / clocks beside the bench lines (rocm-smi polled every 0.25 s)
