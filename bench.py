@@ -412,7 +412,32 @@ def two_streams_variant(torch, pkg, rt, params, dtype, x, steps, graph_a):
     ref = graph_a.replay(x)
     torch.cuda.synchronize()
     same = all(bool(torch.equal(g.out[k], ref[k])) for g in fl.slots for k in ("rois", "cls_prob", "pred_boxes", "n_out"))
-    return {"img_s_two_images_in_flight": steps / dt, "ms_per_image": dt / steps * 1e3, "steps": steps, "outputs_identical_to_the_serial_graph": same,
+    # ... and the serving loop whole: two in flight AND the input inside the timed region (a different pinned uint8 image per step -> H2D -> frcnn_preprocess_u8 ->
+    # forward, all on the slot's stream, stream-ordered behind the slot's previous image; the host stays at most eight images ahead)
+    fed, fed_probe = None, None
+    try:
+        from chainer_faster_rcnn_amd.postprocess import PIXEL_MEANS
+        rs = np.random.RandomState(321)
+        host = [torch.from_numpy(rs.randint(0, 256, size=(IM_H, IM_W, 3), dtype=np.uint8)).pin_memory() for _ in range(8)]
+        means = np.asarray(PIXEL_MEANS, dtype=np.float64).ravel()
+
+        def run_fed(k_steps):
+            for k in range(k_steps):
+                fl.submit_u8(host[k % len(host)], means, 1.0)     # (a slot's copy / preprocess / replay are stream-ordered behind its previous image: no hazard)
+                if k % 8 == 7:
+                    fl.wait()                                     # the host stays at most eight images ahead
+        fed_probe = fl.reprobe(lambda k: fl.submit_u8(host[k % len(host)], means, 1.0))          # the copies bring other queues into play: pick the stream pair again
+        run_fed(10)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_fed(steps)
+        torch.cuda.synchronize()
+        fed = steps / (time.perf_counter() - t1)
+    except Exception as e:
+        fed = repr(e)
+        torch.cuda.synchronize()
+    return {"img_s_two_images_in_flight": steps / dt, "img_s_two_images_in_flight_with_feed": fed,
+            "fed_stream_set_probe_img_s": (sorted((round(v, 1) for v in fed_probe.values()), reverse=True) if isinstance(fed, float) and fed_probe else None), "ms_per_image": dt / steps * 1e3, "steps": steps, "outputs_identical_to_the_serial_graph": same,
             "stream_set_probe_img_s": {"best": round(max(fl.probe.values()), 1), "worst": round(min(fl.probe.values()), 1), "sets": len(fl.probe),
                                        "why": "streams that share one of the runtime's hardware queues run one after the other: the constructor keeps the pair that overlaps"},
             "what": "two model instances (own workspaces + captured graphs, same weights), image k on HIP stream k % 2: image k's proposal / RoI / head stages overlap image k + 1's convolutions"}
@@ -1017,7 +1042,9 @@ def main():
                    "img_s_with_feed": (res.get("with_feed") or {}).get("img_s_with_feed"),
                    "bf16_img_s_with_feed": (b3.get("with_feed") or {}).get("img_s_with_feed"),
                    "img_s_two_images_in_flight": (res.get("two_images_in_flight") or {}).get("img_s_two_images_in_flight"),
-                   "bf16_img_s_two_images_in_flight": (b3.get("two_images_in_flight") or {}).get("img_s_two_images_in_flight")}
+                   "bf16_img_s_two_images_in_flight": (b3.get("two_images_in_flight") or {}).get("img_s_two_images_in_flight"),
+                   "img_s_two_images_in_flight_with_feed": (res.get("two_images_in_flight") or {}).get("img_s_two_images_in_flight_with_feed"),
+                   "bf16_img_s_two_images_in_flight_with_feed": (b3.get("two_images_in_flight") or {}).get("img_s_two_images_in_flight_with_feed")}
             res["roofline"]["secondary"] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in sec.items() if v is not None}
         emit_json_line(res)
     if dist is not None:

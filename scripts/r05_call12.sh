@@ -9,7 +9,7 @@ import json, sys
 d = json.loads([l for l in open(sys.argv[1]) if l.startswith('{"metric"')][-1])
 print("  value %.1f img/s (%.4f ms)" % (d["value"], d["ms_per_step"]))
 print("  with_feed", {k: v for k, v in (d.get("with_feed") or {}).items() if k != "what"})
-print("  two_images_in_flight", {k: v for k, v in (d.get("two_images_in_flight") or {}).items() if k != "what"})
+print("  two_images_in_flight", {k: v for k, v in (d.get("two_images_in_flight") or {}).items() if k not in ("what", "stream_set_probe_img_s")})
 b = d.get("bf16_config3") or {}
 if b:
     print("  bf16_config3 value %.1f" % b["value"], "with_feed", (b.get("with_feed") or {}).get("img_s_with_feed"), "two", {k: v for k, v in (b.get("two_images_in_flight") or {}).items() if k != "what"})
