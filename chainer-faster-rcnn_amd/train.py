@@ -604,7 +604,12 @@ class RCNNTrainer(_BucketedAllReduce):
         a6 = model.fc6(pool5, relu=True)
         on_device = masks is None and self.dropout_rng == "device"
         if on_device:                                                # one launch: mask drawn, stored and applied
-            d6, m6 = rt.dropout(a6, self.dropout_ratio, self.dropout_seed * 0x100000001b3 + 2 * self.iteration)
+            # one counter per FORWARD (two draws each) -- not per update: forward_backward twice without update() must not reuse its masks -- and the
+            # data-parallel rank folded in: every rank draws its own masks from one dropout_seed
+            self._dropout_calls = getattr(self, "_dropout_calls", 0) + 1
+            rank = int(getattr(getattr(self, "comm", None), "rank", 0) or 0)
+            base = (self.dropout_seed * 0x100000001b3 + rank * 0x9E3779B97F4A7C15 + 2 * (self._dropout_calls - 1)) & 0xFFFFFFFFFFFFFFFF
+            d6, m6 = rt.dropout(a6, self.dropout_ratio, base)
         else:
             if masks is None:                                        # F.dropout [chainer-ext]: mask = (rand >= ratio) * 1/(1-ratio)
                 m6 = ((np.random.rand(*a6.shape) >= self.dropout_ratio) * scale).astype(np.float32)
@@ -614,7 +619,7 @@ class RCNNTrainer(_BucketedAllReduce):
             d6 = rt.mul(a6, m6)
         a7 = model.fc7(d6, relu=True)
         if on_device:
-            d7, m7 = rt.dropout(a7, self.dropout_ratio, self.dropout_seed * 0x100000001b3 + 2 * self.iteration + 1)
+            d7, m7 = rt.dropout(a7, self.dropout_ratio, (base + 1) & 0xFFFFFFFFFFFFFFFF)
         else:
             m7 = ((np.random.rand(*a7.shape) >= self.dropout_ratio) * scale).astype(np.float32) if masks is None else masks[1]
             m7 = rt.asarray(m7, "f32")
