@@ -30,7 +30,7 @@ def main(tag="r05z", R="r05"):
             shutil.copy(os.path.join(O, n), os.path.join(P, n))
     if os.path.exists(os.path.join(O, "parity_reports.txt")):
         shutil.copy(os.path.join(O, "parity_reports.txt"), os.path.join(P, R + "_parity_reports.txt"))
-    for d, dst in (("prof", R + "_kernel_stats.csv"), ("prof_bf16", R + "_bf16_kernel_stats.csv"), ("prof_train", R + "_train_kernel_stats.csv")):
+    for d, dst in (("prof", R + "_kernel_stats.csv"), ("prof_bf16", R + "_bf16_kernel_stats.csv"), ("prof_train", R + "_train_kernel_stats.csv"), ("prof_two", R + "_bf16_two_in_flight_kernel_stats.csv")):
         hits = glob.glob(os.path.join(O, d, "**", "*kernel_stats.csv"), recursive=True)
         if hits:
             shutil.copy(hits[0], os.path.join(P, dst))

@@ -16,7 +16,7 @@ if has tests; then
   grep -E "^PARITY|full-size weight" $O/pytest_gpu.log > $O/parity_reports.txt
 fi
 if has bench; then
-  echo "== bench f32 (contract line)"; timeout 900 python bench.py > $O/${P}_bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-300 $O/${P}_bench.json
+  echo "== bench f32 (contract line)"; T0=$(date +%s); timeout 900 python bench.py > $O/${P}_bench.json 2> $O/bench.err; echo "bench rc=$? wall $(( $(date +%s) - T0 )) s"; cut -c1-300 $O/${P}_bench.json
   echo "== bench bf16"; timeout 600 python bench.py --dtype bf16 --steps 100 --warmup 5 > $O/${P}_bench_bf16.json 2>> $O/bench.err; echo "rc=$?"; cut -c1-200 $O/${P}_bench_bf16.json
   echo "== bench f32s"; timeout 600 python bench.py --dtype f32s --steps 100 --warmup 5 > $O/${P}_bench_f32s.json 2>> $O/bench.err; echo "rc=$?"; cut -c1-200 $O/${P}_bench_f32s.json
   echo "== bench train"; timeout 600 python bench.py --mode train --steps 40 --warmup 3 > $O/${P}_bench_train.json 2>> $O/bench.err; echo "rc=$?"; cut -c1-200 $O/${P}_bench_train.json

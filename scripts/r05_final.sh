@@ -6,7 +6,7 @@
 # Outputs under gpurun_out/r05z/; scripts/collect_profiles.py r05z r05 copies what is judged into profiles/r05_*.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
-STAGES="${STAGES:-tests bench prof pmc dist micro}" TAG=r05z P=r05 bash scripts/gpu_evidence.sh
+START=$(date +%s); STAGES="${STAGES:-tests bench prof pmc dist micro}" TAG=r05z P=r05 bash scripts/gpu_evidence.sh
 O=gpurun_out/r05z; B=scripts/micro/_bin
 for rng in device numpy; do
   timeout 600 python bench.py --mode train-rcnn --dropout-rng $rng --steps 20 --warmup 3 > $O/r05_bench_train_rcnn_$rng.json 2>> $O/bench.err; echo "train-rcnn ($rng masks) rc=$?"; cut -c1-160 $O/r05_bench_train_rcnn_$rng.json | tail -1
@@ -17,8 +17,11 @@ done
 for f in 1 0; do FRCNN_BF16_CONV1_PAIR=$f timeout 600 python bench.py --dtype bf16 --steps 100 --warmup 5 --no-cpu-baseline > $O/r05_bench_bf16_pair$f.json 2>> $O/bench.err; echo "bench bf16, conv1 pair launch = $f: rc=$?"; cut -c1-140 $O/r05_bench_bf16_pair$f.json | tail -1; done
 # two images in flight per GPU (graph.ForwardsInFlight's mechanism, torch-level probe): serial vs two / three instances, outputs compared
 { for a in "bf16 2" "bf16 3" "f32 2" "f32s 2"; do timeout 300 python scripts/two_streams_probe.py $a; done; } 2>&1 | grep -v amdgpu.ids > $O/r05_two_streams_probe.txt; cat $O/r05_two_streams_probe.txt
+# ... and what the kernels look like under it: rocprofv3 kernel statistics of the two-instance run (durations stretch where two images share the chip)
+( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_two" -o r05_two -- python "$R/scripts/two_streams_probe.py" bf16 2 > "$R/$O/prof_two.log" 2>&1; echo "rocprof two-in-flight rc=$?" )
 # the backward RoI kernel's counters (torch-free harness; the bwd launches of roi_micro)
 scripts/micro/roi_pmc.sh 'roi_pool_bwd_runs_kernel<2' DEFAULT=1 > $O/r05_roi_bwd_pmc.txt 2>&1; tail -12 $O/r05_roi_bwd_pmc.txt
 # package power / clocks beside the bench lines (rocm-smi polled every 0.25 s)
 O=$O/power bash scripts/bench_power.sh > $O/r05_bench_power.txt 2>&1; tail -12 $O/r05_bench_power.txt
 grep -E "^(FAILED|ERROR)" $O/pytest_gpu.log | head -20
+echo "whole evidence run: $(( $(date +%s) - START )) s"
