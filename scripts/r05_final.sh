@@ -3,11 +3,11 @@
 # line now carries `with_feed` --, RCCL at world size 1 / gloo with two ranks, rocprofv3 kernel statistics, HBM-traffic and MFMA / RoI PMC passes, the micro
 # harnesses) plus: the stage-2 training step (device-drawn and NumPy-stream dropout masks), the conv1 pair launch against its two-launch chain, the bf16 line with /
 # without it, the RoI backward kernel's PMC pass, the sustained MFMA rates, package power beside the bench lines.
-# Outputs under gpurun_out/r05z/; scripts/collect_profiles.py r05z r05 copies what is judged into profiles/r05_*.
+# Outputs under gpurun_out/$TAG/ (default r05z; gpurun does not overwrite files of an earlier call: a re-run takes a fresh TAG); scripts/collect_profiles.py <TAG> r05 copies what is judged into profiles/r05_*.
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"
-START=$(date +%s); STAGES="${STAGES:-tests bench prof pmc dist micro}" TAG=r05z P=r05 bash scripts/gpu_evidence.sh
-O=gpurun_out/r05z; B=scripts/micro/_bin
+START=$(date +%s); STAGES="${STAGES:-tests bench prof pmc dist micro}" TAG=${TAG:=r05z} P=r05 bash scripts/gpu_evidence.sh
+O=gpurun_out/$TAG; B=scripts/micro/_bin
 for rng in device numpy; do
   timeout 600 python bench.py --mode train-rcnn --dropout-rng $rng --steps 20 --warmup 3 > $O/r05_bench_train_rcnn_$rng.json 2>> $O/bench.err; echo "train-rcnn ($rng masks) rc=$?"; cut -c1-160 $O/r05_bench_train_rcnn_$rng.json | tail -1
 done
