@@ -8,7 +8,7 @@ for dt in f32 bf16; do
   poll 150 > $O/smi_$dt.txt 2>&1 &
   P=$!
   echo "start $(date +%s.%N)" > $O/marks_$dt.txt
-  timeout 300 python bench.py --dtype $dt --steps $steps --warmup 5 --no-cpu-baseline --no-split-variant --no-bf16-variant --no-stage-events > $O/bench_$dt.json 2> $O/err_$dt.txt
+  timeout 300 python bench.py --dtype $dt --steps $steps --warmup 5 --no-cpu-baseline --no-split-variant --no-bf16-variant --no-stage-events --no-feed-variant --no-two-streams-variant > $O/bench_$dt.json 2> $O/err_$dt.txt
   echo "end $(date +%s.%N)" >> $O/marks_$dt.txt
   wait $P
   python - "$O" "$dt" <<'PY'

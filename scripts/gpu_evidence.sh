@@ -30,17 +30,19 @@ if has dist; then
 fi
 if has prof; then
   echo "== rocprof kernel stats"; cd /tmp && export TMPDIR=/tmp
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof" -o ${P} -- python "$R/bench.py" --steps 100 --warmup 5 --no-cpu-baseline --no-split-variant --no-bf16-variant > "$R/$O/prof.log" 2>&1; echo "rocprof f32 rc=$?"
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_bf16" -o ${P}_bf16 -- python "$R/bench.py" --dtype bf16 --steps 100 --warmup 5 --no-cpu-baseline > "$R/$O/prof_bf16.log" 2>&1; echo "rocprof bf16 rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof" -o ${P} -- python "$R/bench.py" --steps 100 --warmup 5 --no-cpu-baseline --no-split-variant --no-bf16-variant --no-feed-variant --no-two-streams-variant > "$R/$O/prof.log" 2>&1; echo "rocprof f32 rc=$?"
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_bf16" -o ${P}_bf16 -- python "$R/bench.py" --dtype bf16 --steps 100 --warmup 5 --no-cpu-baseline --no-feed-variant --no-two-streams-variant > "$R/$O/prof_bf16.log" 2>&1; echo "rocprof bf16 rc=$?"
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_train" -o ${P}_train -- python "$R/bench.py" --mode train --steps 10 --warmup 2 > "$R/$O/prof_train.log" 2>&1; echo "rocprof train rc=$?"
   cd "$R"
+  for d in prof prof_bf16 prof_train; do find $O/$d -type f ! -name "*kernel_stats.csv" -delete 2>/dev/null; done       # keep the per-kernel statistics, drop the raw traces
 fi
 if has pmc; then
   echo "== hbm traffic PMC"; cd /tmp && export TMPDIR=/tmp
   for dt in f32 bf16; do for c in FETCH_SIZE WRITE_SIZE; do
-    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$R/$O/traffic_${dt}_$c" -o t -- python "$R/bench.py" --dtype $dt --steps 3 --warmup 2 --no-cpu-baseline --no-split-variant --no-bf16-variant > "$R/$O/traffic_${dt}_$c.log" 2>&1; echo "$dt $c rc=$?"
+    timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$R/$O/traffic_${dt}_$c" -o t -- python "$R/bench.py" --dtype $dt --steps 3 --warmup 2 --no-cpu-baseline --no-split-variant --no-bf16-variant --no-feed-variant --no-two-streams-variant > "$R/$O/traffic_${dt}_$c.log" 2>&1; echo "$dt $c rc=$?"
   done; done
   cd "$R"; for dt in f32 bf16; do python scripts/gpu_traffic.py $O $dt ${P} > $O/traffic_${dt}_summary.txt 2>&1; done; tail -8 $O/traffic_f32_summary.txt
+  rm -rf $O/traffic_f32_FETCH_SIZE $O/traffic_f32_WRITE_SIZE $O/traffic_bf16_FETCH_SIZE $O/traffic_bf16_WRITE_SIZE        # raw counter csvs: tens of MB (gpurun copies back at most 64 MiB); the summaries stay
   echo "== RoI SQ counters (torch-free harness)"
   scripts/micro/roi_pmc.sh quads DEFAULT=1 > $O/${P}_roi_pmc.txt 2>&1; tail -20 $O/${P}_roi_pmc.txt
   echo "== bf16 conv3_2 MFMA counters"; cd /tmp
@@ -59,6 +61,7 @@ out["_note"] = "the default pick for the conv3_2 shape (256 -> 256, 150 x 250: c
 json.dump(out, open(O + "/" + P + "_mfma_pmc_summary.json", "w"), indent=1, sort_keys=True)
 print({k: v["per_launch_mean"] for k, v in out.items() if k != "_note"})
 PY
+  rm -rf $O/mfma_bf16
 fi
 if has micro; then
   echo "== store / launch micro-measurements"

@@ -18,7 +18,7 @@ for f in 1 0; do FRCNN_BF16_CONV1_PAIR=$f timeout 600 python bench.py --dtype bf
 # two images in flight per GPU (graph.ForwardsInFlight's mechanism, torch-level probe): serial vs two / three instances, outputs compared
 { for a in "bf16 2" "bf16 3" "f32 2" "f32s 2"; do timeout 300 python scripts/two_streams_probe.py $a; done; } 2>&1 | grep -v amdgpu.ids > $O/r05_two_streams_probe.txt; cat $O/r05_two_streams_probe.txt
 # ... and what the kernels look like under it: rocprofv3 kernel statistics of the two-instance run (durations stretch where two images share the chip)
-( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_two" -o r05_two -- python "$R/scripts/two_streams_probe.py" bf16 2 > "$R/$O/prof_two.log" 2>&1; echo "rocprof two-in-flight rc=$?" )
+( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_two" -o r05_two -- python "$R/scripts/two_streams_probe.py" bf16 2 > "$R/$O/prof_two.log" 2>&1; echo "rocprof two-in-flight rc=$?" ); find $O/prof_two -type f ! -name "*kernel_stats.csv" -delete 2>/dev/null
 # the backward RoI kernel's counters (torch-free harness; the bwd launches of roi_micro)
 scripts/micro/roi_pmc.sh 'roi_pool_bwd_runs_kernel<2' DEFAULT=1 > $O/r05_roi_bwd_pmc.txt 2>&1; tail -12 $O/r05_roi_bwd_pmc.txt
 # package power / clocks beside the bench lines (rocm-smi polled every 0.25 s)

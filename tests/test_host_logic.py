@@ -146,6 +146,44 @@ def test_split_tensor_entry_points_reject_bad_arguments():
     assert all(rc != 0 for rc in bad), bad
 
 
+def test_tuning_registry_abi():
+    """frcnn_set_tuning / frcnn_get_tuning / frcnn_reset_tuning (ABI v22): the library's knobs live in one table filled from the FRCNN_* environment when the
+    library is loaded; the environment is never read again (a later os.environ change has no effect), keys must start with FRCNN_, values are bounded, reset goes
+    back to the load-time snapshot; the Python registry (chainer_faster_rcnn_amd.tuning) keeps its own copy in step."""
+    import ctypes
+    import chainer_faster_rcnn_amd as pkg
+    tuning = pkg.tuning
+    lib = pkg._lib.bind(pkg._lib.LIB_PATH)
+
+    def get(key):
+        buf = ctypes.create_string_buffer(96)
+        n = lib.frcnn_get_tuning(key.encode(), buf, 96)
+        return None if n == 0 else buf.value.decode()
+    assert get("FRCNN_TEST_KNOB") is None
+    os.environ["FRCNN_TEST_KNOB"] = "from-the-environment-after-load"
+    try:
+        assert get("FRCNN_TEST_KNOB") is None                                   # no entry point reads the environment after load
+        assert lib.frcnn_conv_bf16_plan(256, 256, 150, 250, 3, 0) == 910
+    finally:
+        del os.environ["FRCNN_TEST_KNOB"]
+    tuning.set("FRCNN_TEST_KNOB", "7")
+    assert get("FRCNN_TEST_KNOB") == "7" and tuning.get("FRCNN_TEST_KNOB") == "7"
+    with tuning.override(FRCNN_TEST_KNOB="8", FRCNN_BF16_STRIP="0"):
+        assert get("FRCNN_TEST_KNOB") == "8" and lib.frcnn_conv_bf16_plan(256, 256, 150, 250, 3, 0) == 0
+    assert get("FRCNN_TEST_KNOB") == "7" and lib.frcnn_conv_bf16_plan(256, 256, 150, 250, 3, 0) == 910
+    assert lib.frcnn_set_tuning(b"NOT_OURS", b"1") == -1 and lib.frcnn_set_tuning(b"FRCNN_" + b"K" * 60, b"1") == -1
+    assert lib.frcnn_set_tuning(b"FRCNN_TEST_KNOB", b"v" * 200) == -1 and get("FRCNN_TEST_KNOB") == "7"
+    buf = ctypes.create_string_buffer(2)
+    assert lib.frcnn_get_tuning(b"FRCNN_TEST_KNOB", buf, 2) == 2 and buf.value == b"7"
+    tuning.set("FRCNN_TEST_KNOB", None)
+    assert get("FRCNN_TEST_KNOB") is None
+    tuning.set("FRCNN_TEST_KNOB", "9")
+    tuning.reset()
+    assert get("FRCNN_TEST_KNOB") is None and tuning.get("FRCNN_TEST_KNOB") is None
+    with pytest.raises(ValueError):
+        tuning.set("PATH", "x")
+
+
 def test_conv_bf16_plan_of_the_vgg16_chain(monkeypatch):
     """frcnn_conv_bf16_plan (launch-free; a CU count of 256 is assumed where no device is visible): the default picks of the bf16 chain at
     600 x 1000 -- strip form D where a launch has >= 8 K-chunks and >= one 64-cout x 10-row x 32-px tile per CU, form C on the 38 x 63
