@@ -85,6 +85,33 @@ def main():
         out = cap.replay()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+    # two images in flight per GPU (graph.ForwardsInFlight): the ResNet trunk is 104 small launches, many of them far from filling the chip
+    two = None
+    try:
+        from chainer_faster_rcnn_amd.graph import ForwardsInFlight
+
+        def make_model(rt_i):
+            m_ = FasterRCNN(trunk_class=ResNet101, rpn_in_ch=2048, rpn_mid_ch=512, feat_stride=32, runtime=rt_i)
+            m_.load_params(params)
+            m_.RPN.proposal_layer._pre_nms_top_n, m_.RPN.proposal_layer._post_nms_top_n = 1000, 300
+            return m_
+        fl = ForwardsInFlight(make_model, lambda: pkg.runtime.Runtime(rt.lib, pkg.runtime.TorchDeviceMemory(str(rt.mem.device))), x, h, w, n=2)
+        for _ in range(10):
+            fl.submit()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2 * steps):
+            fl.submit()
+        torch.cuda.synchronize()
+        two_rate = 2 * steps / (time.perf_counter() - t1)
+        ref = cap.replay()
+        torch.cuda.synchronize()
+        same = all(bool(torch.equal(g.out[k], ref[k])) for g in fl.slots for k in ("rois", "cls_prob", "pred_boxes", "n_out"))
+        two = {"img_s_two_images_in_flight": two_rate, "outputs_identical_to_the_serial_graph": same,
+               "stream_set_probe_img_s": {"best": round(max(fl.probe.values()), 1), "worst": round(min(fl.probe.values()), 1)}}
+    except Exception as e:
+        two = {"error": repr(e)}
+        torch.cuda.synchronize()
     per, (fh, fw) = resnet_trunk_flops(h, w)
     trunk_flops = sum(per.values())
     rpn_flops = 2.0 * 2048 * 9 * 512 * fh * fw
@@ -103,7 +130,7 @@ def main():
            "stages_ms": {k: round(v, 4) for k, v in stages.items()},
            "fc6": {"shape": "300 x 100352 x 4096", "ms": stages.get("fc6"), "tflops": fc6_flops / (stages["fc6"] * 1e-3) / 1e12 if stages.get("fc6") else None,
                    "weight_mb": 100352 * 4096 * 4 / 1e6},
-           "rpn_conv_3x3": {"gflop": rpn_flops / 1e9}}
+           "rpn_conv_3x3": {"gflop": rpn_flops / 1e9}, "two_images_in_flight": two}
     bench.emit_json_line(rec)
 
 
