@@ -664,7 +664,7 @@ def train_rcnn_mode(args, torch, dist, rt, model, x, rank, world, barrier, share
     def hook(name):
         e = torch.cuda.Event(enable_timing=True)
         e.record()
-        ev[-1].append((name, e))
+        ev[-1].append((name, e, time.perf_counter()))
 
     for _ in range(max(2, args.warmup)):                              # a fixed count (collectives inside): see train_mode
         out = tr.step(x, info, gt)
@@ -684,23 +684,31 @@ def train_rcnn_mode(args, torch, dist, rt, model, x, rank, world, barrier, share
     dt = time.perf_counter() - t0
     dt, per_rank = gather_rank_times(torch, dist, dt, world)
     if rank == 0:
-        names = [n for n, _ in ev[0]]
+        names = [n for n, _, _ in ev[0]]
         st = {names[i]: float(np.mean([s[i - 1][1].elapsed_time(s[i][1]) for s in ev])) for i in range(1, len(names))}
+        # the host's side of the same boundaries: how long the Python thread took to ENQUEUE each stage (a stage whose GPU time equals its enqueue
+        # time is bound by the launch rate of the un-captured step, not by its kernels)
+        st_host = {names[i]: float(np.mean([(s[i][2] - s[i - 1][2]) * 1e3 for s in ev])) for i in range(1, len(names))}
         emit_json_line({"metric": "images/sec Fast R-CNN (stage 2) training step VGG16 600x1000", "value": world * args.steps / dt, "unit": "img/s",
                         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32s" if conv_math == "split" else "f32", "data": "synthetic",
                         "config": {"workload": "train_rcnn.py stage-2 training step (trunk + RoI head; RPN proposals without gradient), 1 image per GPU, "
                                                "all-reduce of the flat fp32 gradient buffer in 3 buckets (SURVEY 8f-2; not a BASELINE.json config)",
                                    "conv_math": conv_math, "grad_buffer_mb": tr.n_flat * 4 / 1e6, "global_batch": world, "n_rois_last_step": int(out["n_rois"]),
+                                   "head_backward_rows_last_step": int(out["keep_inds"].shape[0]),
+                                   "head_backward": "on ProposalTargetLayer's kept rows only (every other row of the head's output gradient is exactly zero: "
+                                                    "faster_rcnn.py:155-160); FRCNN_RCNN_BWD_ROWS=all is the zero-padded form over all n_rois rows",
                                    "ranks_share_gpus": shared_note,
                                    "dropout_rng": args.dropout_rng,
                                    "host_in_step": ("dropout masks (2 x n_rois x 4096 floats from NumPy's global RNG, as chainer's CPU path draws them: ~7 ms) and "
                                                     if args.dropout_rng == "numpy" else "dropout masks drawn by the dropout kernel (counter-based hash; no host work); ") +
-                                                   "ProposalTargetLayer's subsample is host work inside the timed step, with one device->host read of the RoI count"},
+                                                   "ProposalTargetLayer's subsample is host work inside the timed step (under the head's forward pass), after one device->host read of "
+                                                   "the RoI count, the RoIs and their float64 IoU matrix"},
                         "per_rank": per_rank_block(per_rank, args.steps),
                         "dist": {"backend": (dist.get_backend() if dist is not None else None), "world_size": world},
                         "cpu_baseline": None if world == 1 else "not run: ranks > 1",
                         "stages_ms": {k: round(v, 4) for k, v in st.items()}, "sum_of_stages_ms": round(sum(st.values()), 4),
+                        "host_enqueue_ms": {k: round(v, 4) for k, v in st_host.items()},
                         "losses": tr.losses_host(out)})
     if dist is not None:
         dist.barrier()

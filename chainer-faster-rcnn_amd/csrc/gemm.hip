@@ -232,7 +232,7 @@ linear_reduce_kernel(const float *__restrict__ part, const float *__restrict__ b
                      int relu) {
     const size_t total = (size_t)M * N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const float b = bias[i % N];                         // issued ahead of the slab loads: it is used last
+        const float b = bias ? bias[i % N] : 0.0f;           // issued ahead of the slab loads: it is used last
         float v = frcnn_sum_splits(part, total, i, splits);
         v += b;
         if (relu) v = fmaxf(v, 0.0f);
@@ -272,10 +272,13 @@ size_t frcnn_linear_workspace_bytes(int M, int N, int K) {
 int frcnn_linear_f32(const float *x, const float *w, const float *bias, float *y, int M, int N, int K, int relu, void *workspace,
                      size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!x || !w || !bias || !y || M < 1 || N < 1 || K < 1 || (K % 4) != 0) return FRCNN_ERR_INVALID;
+    if (!x || !w || !y || M < 1 || N < 1 || K < 1 || (K % 4) != 0) return FRCNN_ERR_INVALID;
     const LinearPlan p = plan_linear(M, N, K);
-    if (!workspace || workspace_bytes < (size_t)p.splits * M * N * sizeof(float)) return FRCNN_ERR_INVALID;
-    float *part = (float *)workspace;
+    // one K slab, no bias, no activation: the slab IS the result -- the GEMM writes y and the combine pass (for fc6's weight gradient: 411 MB
+    // written, read and written again) is not launched
+    const bool direct = p.splits == 1 && !bias && !relu;
+    if (!direct && (!workspace || workspace_bytes < (size_t)p.splits * M * N * sizeof(float))) return FRCNN_ERR_INVALID;
+    float *part = direct ? y : (float *)workspace;
     const dim3 grid(p.nblocks, p.mblocks, p.splits);
     const bool dma = (K % kBK) == 0 && (size_t)M * K * 4 < (1ull << 31) && (size_t)N * K * 4 < (1ull << 31) && !frcnn_tune("FRCNN_LINEAR_NODMA");
     if (dma && p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_f32_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
@@ -284,6 +287,7 @@ int frcnn_linear_f32(const float *x, const float *w, const float *bias, float *y
     else if (p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_f32_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     else if (p.am == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_f32_kernel<3>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_f32_kernel<1>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    if (direct) return frcnn_launch_status();
     const size_t total = (size_t)M * N;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(linear_reduce_kernel, dim3(blocks), dim3(256), 0, stream, part, bias, y, M, N, p.splits, relu);

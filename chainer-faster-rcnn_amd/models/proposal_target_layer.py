@@ -37,11 +37,22 @@ class ProposalTargetLayer(AnchorTargetLayer):
         assert kind(gt_boxes) == 'f'
         assert is_variable(gt_boxes)
 
-    def sample(self, proposals, gt):
-        """Host part (:84-148) on NumPy arrays: proposals (n,4) f32, gt (G,5) f32 -> (use_gt_boxes, ext_targets, keep_inds)."""
+    def overlaps_device(self, proposals_dev, gt):
+        """The float64 IoU matrix of DEVICE proposals (n,4) f32 against gt -- host (G,5), or (G,4) float64 already on the device -- (:88-91), enqueued on the current stream and left on the
+        device: RCNNTrainer issues it right behind the ProposalLayer and reads it back together with the RoI count, so the sampling below runs on
+        the host while the head's forward pass runs on the GPU."""
         rt = self.rt
-        ov = rt.mem.to_numpy(rt.bbox_overlaps(rt.asarray(np.ascontiguousarray(proposals, dtype=np.float64), "f64"),
-                                              rt.asarray(np.ascontiguousarray(gt[:, :4], dtype=np.float64), "f64")))
+        if not rt.mem.is_array(gt):                                  # (a caller that uploaded the (G,4) float64 boxes ahead of time passes them as they are)
+            gt = rt.asarray(np.ascontiguousarray(gt[:, :4], dtype=np.float64), "f64")
+        return rt.bbox_overlaps(rt.mem.astype(proposals_dev, "f64"), gt)
+
+    def sample(self, proposals, gt, overlaps=None):
+        """Host part (:84-148) on NumPy arrays: proposals (n,4) f32, gt (G,5) f32 -> (use_gt_boxes, ext_targets, keep_inds).
+        overlaps: the (n,G) float64 IoU matrix when the caller has already fetched it (overlaps_device)."""
+        rt = self.rt
+        ov = overlaps if overlaps is not None else rt.mem.to_numpy(
+            rt.bbox_overlaps(rt.asarray(np.ascontiguousarray(proposals, dtype=np.float64), "f64"),
+                             rt.asarray(np.ascontiguousarray(gt[:, :4], dtype=np.float64), "f64")))
         argmax = ov.argmax(axis=1)
         max_ov = ov[np.arange(len(proposals)), argmax]
         fg_inds = np.where(max_ov >= self.FG_THRESH)[0]
@@ -62,9 +73,10 @@ class ProposalTargetLayer(AnchorTargetLayer):
         gcx = use_gt[:, 0] + 0.5 * gw; gcy = use_gt[:, 1] + 0.5 * gh
         t = np.vstack(((gcx - ecx) / ew, (gcy - ecy) / eh, np.log(gw / ew), np.log(gh / eh))).transpose()
         ext = np.zeros((len(keep), 4 * self._num_classes), dtype=np.float32)
-        for ind in np.where(use_gt[:, 4] > 0)[0]:
-            pos = int(4 * use_gt[ind, -1])
-            ext[ind, pos:pos + 4] = t[ind]
+        ind = np.where(use_gt[:, 4] > 0)[0]                           # :136-142, the loop over the rows as one indexed assignment
+        if ind.size:
+            pos = (4 * use_gt[ind, -1]).astype(np.int64)
+            ext[ind[:, None], pos[:, None] + np.arange(4)] = t[ind]
         return use_gt, ext, keep
 
     def __call__(self, proposals, gt_boxes):

@@ -34,14 +34,48 @@ class TorchDeviceMemory(object):
     def from_numpy(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
+    def from_numpy_async(self, a):
+        """Host -> device through a pinned staging buffer, enqueued on the current stream WITHOUT blocking the host (a pageable copy waits for
+        everything the stream still has queued: RCNNTrainer's targets would stall the host behind the head's forward pass).  The pinned block
+        returns to torch's host allocator only after the copy has run (it records the stream)."""
+        return self.torch.from_numpy(np.ascontiguousarray(a)).pin_memory().to(self.device, non_blocking=True)
+
     def to_numpy(self, t):
         return t.detach().cpu().numpy()
+
+    def to_numpy_many(self, arrays):
+        """Several small device arrays through ONE device -> host copy (one host round trip instead of one per array): their bytes are
+        concatenated on the device; pass the widest element type first so the host views stay aligned."""
+        torch = self.torch
+        dev = torch.cat([self.contiguous(a).reshape(-1).view(torch.uint8) for a in arrays])
+        # into a pinned staging buffer kept for the purpose + a stream synchronize: `.cpu()` goes through a pageable destination (a bounce copy and a
+        # longer host wake-up), and the GPU idles for exactly that long in RCNNTrainer's step
+        pin = getattr(self, "_pin", None)
+        if pin is None or pin.numel() < dev.numel():
+            pin = self._pin = torch.empty((max(int(dev.numel()), 1 << 16),), dtype=torch.uint8, pin_memory=True)
+        pin[:dev.numel()].copy_(dev, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        host = pin[:dev.numel()].numpy().copy()
+        out, off = [], 0
+        for a in arrays:
+            nb = a.numel() * a.element_size()
+            out.append(host[off:off + nb].view(_NP[self.dtype_of(a)]).reshape(tuple(a.shape)))
+            off += nb
+        return out
 
     def is_array(self, a):
         return isinstance(a, self.torch.Tensor) and a.is_cuda
 
     def contiguous(self, t):
         return t if t.is_contiguous() else t.contiguous()
+
+    def bitcast(self, t, dtype):
+        """The same bytes as another element type of the same size (no copy)."""
+        return t.view(self._dt[dtype])
+
+    def astype(self, t, dtype):
+        """A contiguous copy in another element type (a device-side cast on the current stream)."""
+        return t.to(self._dt[dtype]).contiguous()
 
     def view(self, flat, offset, shape):
         """A contiguous window of a flat buffer, reshaped (shares memory)."""
@@ -360,6 +394,7 @@ class Runtime(object):
 
     # ------------------------------------------------------------------ head
     def linear(self, x, w, bias, relu=False, out=None):
+        """bias None: no bias term (include/frcnn_hip.h)."""
         m, L = self.mem, self.lib
         M, K = int(x.shape[0]), int(np.prod(x.shape[1:]))
         N = int(w.shape[0])
@@ -769,9 +804,12 @@ class Runtime(object):
         return g
 
     def gather_rows(self, src, idx):
+        """dst[i] = src[idx[i]]: rows of 4-byte elements moved as they are (fp32, or the int32 arg-max rows of the RoI pooling)."""
         m, L = self.mem, self.lib
         n, cols = int(idx.shape[0]), int(np.prod(src.shape[1:]))
-        dst = m.empty((n,) + tuple(int(v) for v in src.shape[1:]), "f32")
+        dt = m.dtype_of(src)
+        assert dt in ("f32", "i32")
+        dst = m.empty((n,) + tuple(int(v) for v in src.shape[1:]), dt)
         _lib.check(L.frcnn_gather_rows_f32(m.ptr(src), m.ptr(idx), n, cols, m.ptr(dst), m.stream()), "frcnn_gather_rows_f32")
         return dst
 

@@ -543,11 +543,14 @@ class RCNNTrainer(_BucketedAllReduce):
         M, K = int(x.shape[0]), int(np.prod(x.shape[1:]))
         N = int(dy.shape[1])
         Mp = (M + 3) // 4 * 4                                        # the GEMM contracts over M here: pad it to a multiple of 4
-        xpad, dpad = rt.mem.zeros((Mp, K), "f32"), rt.mem.zeros((Mp, N), "f32")
-        xpad[:M] = x.reshape(M, K)
-        dpad[:M] = dy
+        if Mp == M:                                                  # (the 128 kept rows of a full sample: nothing to pad, four launches fewer)
+            xpad, dpad = x.reshape(M, K), dy
+        else:
+            xpad, dpad = rt.mem.zeros((Mp, K), "f32"), rt.mem.zeros((Mp, N), "f32")
+            xpad[:M] = x.reshape(M, K)
+            dpad[:M] = dy
         dyT, xT = rt.transpose(dpad), rt.transpose(xpad)             # (N, Mp), (K, Mp)
-        rt.linear(dyT, xT, self.zero_bias[:K], out=self.grad[name + "/W"])          # dW = dy^T x
+        rt.linear(dyT, xT, None, out=self.grad[name + "/W"])                        # dW = dy^T x (no bias term: a single K slab goes straight into the gradient)
         rt.bias_grad(dyT.reshape(1, N, 1, Mp), out=self.grad[name + "/b"])          # db = column sums of dy
         if not need_dx:
             return None
@@ -561,9 +564,13 @@ class RCNNTrainer(_BucketedAllReduce):
                 if K % c == 0:
                     wh = c
                     break
-            dyc = rt.mem.zeros((Mc, N), "f32")
-            dyc[:M] = dy
-            dx = rt.conv_ex(lin.W.reshape(1, N, K // wh, wh), rt.transpose(dyc), self.zero_bias[:Mc], ksize=1, act=0)
+            if Mc == Mp:
+                dycT = dyT                                           # already (N, Mc)
+            else:
+                dyc = rt.mem.zeros((Mc, N), "f32")
+                dyc[:M] = dy
+                dycT = rt.transpose(dyc)
+            dx = rt.conv_ex(lin.W.reshape(1, N, K // wh, wh), dycT, self.zero_bias[:Mc], ksize=1, act=0)
             return dx.reshape(Mc, K)[:M]
         Np = (N + 3) // 4 * 4                                        # dx = dy W contracts over N: pad it to a multiple of 4 as well
         if Np != N:
@@ -572,7 +579,7 @@ class RCNNTrainer(_BucketedAllReduce):
             wn[:N] = lin.W
         else:
             dyn, wn = dy, lin.W
-        return rt.linear(dyn, rt.transpose(wn), self.zero_bias[:K])                 # W^T is (K, Np)
+        return rt.linear(dyn, rt.transpose(wn), None)                               # W^T is (K, Np)
 
     def forward_backward(self, x, img_info, gt_boxes, masks=None):
         """Fills self.G; returns dict(losses (3,) device [loss_cls, loss_bbox, cls_accuracy], n_rois, keep_inds)."""
@@ -582,6 +589,11 @@ class RCNNTrainer(_BucketedAllReduce):
         self._ensure_adopted()
         x = rt.asarray(unwrap(x), "f32")
         im_h, im_w = model.RPN.proposal_layer._img_hw(img_info)
+        # the gt boxes go up FIRST and without blocking the host: everything up to the one host read behind the ProposalLayer is then enqueued while
+        # the trunk still runs (a pageable copy issued where the boxes are needed stalled the host -- and, behind it, the GPU -- in the middle of the step)
+        gt_host = unwrap(gt_boxes)
+        gt_host = np.ascontiguousarray(rt.mem.to_numpy(gt_host) if rt.mem.is_array(gt_host) else np.asarray(gt_host), dtype=np.float32)
+        gt_dev64 = rt.mem.from_numpy_async(np.ascontiguousarray(gt_host[0][:, :4], dtype=np.float64))
         stage("start")
         if self.conv_math == "split":
             big = [(n, l) for n, l in self.convs if int(l.cin) > 3]
@@ -594,7 +606,15 @@ class RCNNTrainer(_BucketedAllReduce):
         stage("trunk_fwd")
         _, _, prob, bbox = model.RPN.heads(feat, want_score=False)
         rois, _, n_out = model.RPN.proposal_layer.forward_device(prob, bbox, im_h, im_w)      # RPN.train is False in rcnn_train mode
-        n = int(rt.mem.to_numpy(n_out)[0])
+        # ProposalTargetLayer needs the RoIs and the gt boxes only: its float64 IoU matrix is enqueued here and comes back with the RoI count (the
+        # one host read the step needs anyway), so the host-side sampling further down overlaps the head's forward pass instead of waiting for it
+        if self.ptl.type_check_enable:
+            self.ptl._check_data_type_forward(rois, gt_boxes)
+        ov_dev = self.ptl.overlaps_device(rois, gt_dev64)
+        ov_host, rois_host, n_host = rt.mem.to_numpy_many([ov_dev, rois, n_out])             # one device -> host copy, one host round trip
+        n = int(n_host[0])
+        assert n > 0, "the ProposalLayer returned no RoI (proposal_target_layer.py:52 asserts the same)"
+        rois_host, ov_host = rois_host[:n], ov_host[:n]
         rois = rois[:n]
         stage("rpn_proposals")
         pool5, argmax = rt.roi_pool_fwd_chw(feat, rois, 7, 7, model._spatial_scale, want_argmax=True)
@@ -626,23 +646,45 @@ class RCNNTrainer(_BucketedAllReduce):
             d7 = rt.mul(a7, m7)
         cls_score, bbox_pred = model.cls_score(d7), model.bbox_pred(d7)
         stage("head_fwd")
-        use_gt, ext, keep = self.ptl(rois, gt_boxes)
-        labels = rt.mem.from_numpy(rt.mem.to_numpy(use_gt)[:, -1].astype(np.int32))        # faster_rcnn.py:153
+        # host work under the head's forward pass: np.random.choice in the reference's call order (after the two dropout draws)
+        use_gt, ext, keep = self.ptl.sample(np.ascontiguousarray(rois_host, dtype=np.float32), gt_host[0], overlaps=ov_host)
+        k = int(keep.shape[0])
+        blob = np.empty((k * (2 + ext.shape[1]),), dtype=np.float32)                         # keep | labels | targets: ONE host -> device copy
+        blob[:k] = np.ascontiguousarray(keep, dtype=np.int32).view(np.float32)
+        blob[k:2 * k] = use_gt[:, -1].astype(np.int32).view(np.float32)                      # faster_rcnn.py:153
+        blob[2 * k:] = ext.reshape(-1)
+        blob = rt.mem.from_numpy_async(blob)                                                 # the host keeps running ahead of the head's forward pass
+        keep, labels = rt.mem.bitcast(blob[:k], "i32"), rt.mem.bitcast(blob[k:2 * k], "i32")
+        ext = blob[2 * k:].reshape(k, -1)
         losses, dcs, dbp = rt.rcnn_loss(rt.gather_rows(cls_score, keep), rt.gather_rows(bbox_pred, keep), labels, ext, model._rcnn_delta)
         stage("targets_loss")
-        # ---- backward: head
-        dcls, dbb = rt.scatter_rows(dcs, keep, n), rt.scatter_rows(dbp, keep, n)
-        g7 = rt.add(self._linear_backward("cls_score", d7, dcls), self._linear_backward("bbox_pred", d7, dbb))
-        g7 = rt.relu_bwd_(rt.mul(g7, m7, out=g7), a7)
-        g6 = self._linear_backward("fc7", d6, g7)
-        g6 = rt.relu_bwd_(rt.mul(g6, m6, out=g6), a6)
+        # ---- backward: head.  Only the sampled rows carry a gradient (faster_rcnn.py:155-160: the losses see cls_score[keep_inds] and
+        # bbox_pred[keep_inds]; get_item's adjoint leaves every other row of the 300 EXACTLY zero), so the four L.Linear backward passes, the
+        # dropout / ReLU adjoints and the RoI-pooling scatter run on the k <= 128 kept rows: the same sums without their zero terms
+        # (fc6's two 61.7-GFLOP GEMMs become two of 26.3).  FRCNN_RCNN_BWD_ROWS=all runs them over all n rows (A/B; the zero-padded form).
+        if 0 < k < n and _tuning.get("FRCNN_RCNN_BWD_ROWS", "kept") != "all":
+            rows = k
+            dcls, dbb = dcs, dbp
+            d7b, m7b = rt.gather_rows(d7, keep), rt.gather_rows(m7, keep)
+            d6b, m6b = rt.gather_rows(d6, keep), rt.gather_rows(m6, keep)
+            pool5b, argmaxb = rt.gather_rows(pool5, keep), rt.gather_rows(argmax.reshape(n, -1), keep)
+        else:
+            rows = n
+            dcls, dbb = rt.scatter_rows(dcs, keep, n), rt.scatter_rows(dbp, keep, n)
+            d7b, m7b, d6b, m6b, pool5b, argmaxb = d7, m7, d6, m6, pool5, argmax
+        # dropout then ReLU, backwards: g * mask where relu(.) > 0.  d = relu(.) * mask is positive exactly where both are, and where the mask is zero
+        # the product already is (for finite g): the ReLU test reads d (no third row set to gather)
+        g7 = rt.add(self._linear_backward("cls_score", d7b, dcls), self._linear_backward("bbox_pred", d7b, dbb))
+        g7 = rt.relu_bwd_(rt.mul(g7, m7b, out=g7), d7b)
+        g6 = self._linear_backward("fc7", d6b, g7)
+        g6 = rt.relu_bwd_(rt.mul(g6, m6b, out=g6), d6b)
         stage("head_bwd_small")
-        gp = self._linear_backward("fc6", pool5, g6)
+        gp = self._linear_backward("fc6", pool5b, g6)
         stage("fc6_bwd")
         for n_ in reversed(self.HEAD):                             # every head gradient is enqueued: a bucket closed by a head layer starts now
             self._grads_ready(n_)
         # ---- RoI pooling (arg-max scatter) and the trunk; feat = relu(conv5_3): mask before entering conv5_3's backward
-        gfeat = rt.relu_bwd_(rt.roi_pool_bwd(gp.reshape(n, C, 7, 7), argmax, C, H, W), feat)
+        gfeat = rt.relu_bwd_(rt.roi_pool_bwd(gp.reshape(rows, C, 7, 7), argmaxb.reshape(rows, C, 7, 7), C, H, W), feat)
         stage("roi_pool_bwd")
         (trunk_backward_split if self.conv_math == "split" else trunk_backward)(self, list(zip(self.layers, inputs)), gfeat)
         stage("trunk_bwd")

@@ -197,6 +197,8 @@ int frcnn_rpn_heads_f32(const float *h, int Cmid, int H, int W, int A, const flo
 
 /* ---- fully connected head --------------------------------------------------------------------------
  * Replaces L.Linear + F.relu (models/faster_rcnn.py:33-36,127-134): y(M,N) = act(x(M,K) @ W(N,K)^T + b).
+ * bias (N) or NULL = no bias term (the training step's dW = dy^T x and dx = dy W).  Split-K partial slabs live in the caller's workspace; it is not
+ * touched (and may be NULL) when bias == NULL, relu == 0 and the plan has a single slab: the GEMM then writes y itself and no combine pass runs.
  */
 size_t frcnn_linear_workspace_bytes(int M, int N, int K);
 int frcnn_linear_f32(const float *x, const float *w, const float *bias, float *y, int M, int N, int K,

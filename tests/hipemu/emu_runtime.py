@@ -25,14 +25,26 @@ class HostMemory(object):
     def from_numpy(self, a):
         return np.array(a, order="C", copy=True)
 
+    def from_numpy_async(self, a):
+        return np.array(a, order="C", copy=True)
+
     def to_numpy(self, a):
         return np.array(a, copy=True)
+
+    def to_numpy_many(self, arrays):
+        return [np.array(a, copy=True) for a in arrays]
 
     def is_array(self, a):
         return isinstance(a, np.ndarray)
 
     def contiguous(self, a):
         return np.ascontiguousarray(a)
+
+    def astype(self, a, dtype):
+        return np.ascontiguousarray(a, dtype=_NP[dtype])
+
+    def bitcast(self, a, dtype):
+        return a.view(_NP[dtype])
 
     def view(self, flat, offset, shape):
         n = int(np.prod(shape))

@@ -339,15 +339,16 @@ def check_rpn_heads_forms(rt, monkeypatch, **kw):
     assert np.abs(fused[1] - e / e.sum(axis=1, keepdims=True, dtype=np.float32)).max() <= 1e-6
 
 
-def check_linear(rt, M, N, K, relu, seed=0):
+def check_linear(rt, M, N, K, relu, seed=0, bias=True):
+    """bias=False: the NULL-bias form of the ABI (the training step's dW / dx products; a single-slab plan then writes y directly)."""
     rs = np.random.RandomState(seed)
     x = rs.randn(M, K).astype(np.float32)
     w = (rs.randn(N, K) / np.sqrt(K)).astype(np.float32)
-    b = rs.randn(N).astype(np.float32) * 0.1
+    b = rs.randn(N).astype(np.float32) * 0.1 if bias else np.zeros((N,), dtype=np.float32)
     want = O.linear(x, w, b)
     if relu:
         want = O.relu(want)
-    got = host(rt, rt.linear(dev(rt, x), dev(rt, w), dev(rt, b), relu=relu))
+    got = host(rt, rt.linear(dev(rt, x), dev(rt, w), dev(rt, b) if bias else None, relu=relu))
     err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-6)
     assert got.shape == want.shape and err < 1e-4, (M, N, K, err)
 

@@ -143,6 +143,10 @@ def test_linear(rt):
     P.check_linear(rt, 300, 21, 4096, False)         # cls_score
     P.check_linear(rt, 300, 84, 4096, False)         # bbox_pred
     P.check_linear(rt, 17, 33, 100, False)
+    P.check_linear(rt, 512, 1024, 128, False, bias=False)     # the weight-gradient shape (short contraction, one slab: written straight to y)
+    P.check_linear(rt, 84, 416, 128, False, bias=False)
+    P.check_linear(rt, 128, 256, 4096, False, bias=False)     # NULL bias with split-K slabs (the combine pass without a bias term)
+    P.check_linear(rt, 40, 64, 256, True, bias=False)
 
 
 def test_head_decode(rt):

@@ -131,6 +131,8 @@ def test_linear(rt):
     P.check_linear(rt, 130, 84, 128, False)
     P.check_linear(rt, 9, 21, 72, False, seed=3)          # K % 32 != 0: the register-staged kernel (odd-pitch LDS image)
     P.check_linear(rt, 100, 130, 96, True, seed=4)        # AM = 5, ragged M and N, three panels
+    P.check_linear(rt, 130, 84, 128, False, bias=False)   # NULL bias, one slab: the GEMM writes y itself (the weight-gradient product)
+    P.check_linear(rt, 40, 64, 512, True, seed=5, bias=False)     # NULL bias through the combine pass
 
 
 def test_head_decode(rt):

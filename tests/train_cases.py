@@ -282,6 +282,20 @@ def check_rcnn_step(rt, model, params, layers, x, gt, info, feat_stride, seed=0,
     l = tr.losses_host(out)
     assert abs(l["loss_rcnn"] - want_loss) <= 1e-4 * abs(want_loss), (l, want_loss)
     got = tr.grads_chainer_layout()
+    # The head's backward runs on the kept rows only (their gradient rows are the only non-zero ones): the same step with every one of the n rows
+    # (FRCNN_RCNN_BWD_ROWS=all, the zero-padded form) must give the same gradients up to the grouping of the sums.
+    if 0 < len(keep) < n:
+        from chainer_faster_rcnn_amd import tuning
+        g_kept = rt.mem.to_numpy(tr.G).copy()
+        with tuning.override(FRCNN_RCNN_BWD_ROWS="all"):
+            np.random.seed(seed + 1)
+            out_all = tr.forward_backward(Variable(x), Variable(info), Variable(gt), masks=masks)
+        assert np.array_equal(rt.mem.to_numpy(out_all["keep_inds"]), keep)
+        g_all = rt.mem.to_numpy(tr.G)
+        for name, sg in sorted(tr.seg.items()):
+            a, b = g_kept[sg.offset:sg.offset + sg.size], g_all[sg.offset:sg.offset + sg.size]
+            assert np.abs(a - b).max() <= 2e-5 * max(float(np.abs(b).max()), 1e-12), (name, float(np.abs(a - b).max()), float(np.abs(b).max()))
+        print("RCNN_BWD_ROWS kept %d of %d rows: gradients equal to the all-rows form within 2e-5" % (len(keep), n))
     worst = 0.0
     if x.shape[2] * x.shape[3] >= 300000:
         # Full size (600 x 1000), as for the RPN step (check_vgg_step): a float64 arbiter instead of a relaxed bar.  The oracle's autograd runs once more
