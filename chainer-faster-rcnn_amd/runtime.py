@@ -46,22 +46,31 @@ class TorchDeviceMemory(object):
     def to_numpy_many(self, arrays):
         """Several small device arrays through ONE device -> host copy (one host round trip instead of one per array): their bytes are
         concatenated on the device; pass the widest element type first so the host views stay aligned."""
+        return self.to_numpy_many_async(arrays)()
+
+    def to_numpy_many_async(self, arrays):
+        """The same copy, enqueued now on the current stream; returns a function that waits for THAT COPY (an event behind it, not the stream: work
+        enqueued afterwards keeps running) and hands out the NumPy arrays.  One staging buffer: collect a copy before starting the next."""
         torch = self.torch
         dev = torch.cat([self.contiguous(a).reshape(-1).view(torch.uint8) for a in arrays])
-        # into a pinned staging buffer kept for the purpose + a stream synchronize: `.cpu()` goes through a pageable destination (a bounce copy and a
-        # longer host wake-up), and the GPU idles for exactly that long in RCNNTrainer's step
-        pin = getattr(self, "_pin", None)
+        pin = getattr(self, "_pin", None)                            # pinned: a pageable destination goes through a bounce copy
         if pin is None or pin.numel() < dev.numel():
             pin = self._pin = torch.empty((max(int(dev.numel()), 1 << 16),), dtype=torch.uint8, pin_memory=True)
-        pin[:dev.numel()].copy_(dev, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
-        host = pin[:dev.numel()].numpy().copy()
-        out, off = [], 0
-        for a in arrays:
-            nb = a.numel() * a.element_size()
-            out.append(host[off:off + nb].view(_NP[self.dtype_of(a)]).reshape(tuple(a.shape)))
-            off += nb
-        return out
+        nbytes = int(dev.numel())
+        pin[:nbytes].copy_(dev, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        shapes = [(tuple(a.shape), a.numel() * a.element_size(), _NP[self.dtype_of(a)]) for a in arrays]
+
+        def collect():
+            done.synchronize()
+            host = pin[:nbytes].numpy().copy()
+            out, off = [], 0
+            for shape, nb, dt in shapes:
+                out.append(host[off:off + nb].view(dt).reshape(shape))
+                off += nb
+            return out
+        return collect
 
     def is_array(self, a):
         return isinstance(a, self.torch.Tensor) and a.is_cuda

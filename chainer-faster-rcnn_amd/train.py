@@ -611,41 +611,66 @@ class RCNNTrainer(_BucketedAllReduce):
         if self.ptl.type_check_enable:
             self.ptl._check_data_type_forward(rois, gt_boxes)
         ov_dev = self.ptl.overlaps_device(rois, gt_dev64)
-        ov_host, rois_host, n_host = rt.mem.to_numpy_many([ov_dev, rois, n_out])             # one device -> host copy, one host round trip
-        n = int(n_host[0])
-        assert n > 0, "the ProposalLayer returned no RoI (proposal_target_layer.py:52 asserts the same)"
-        rois_host, ov_host = rois_host[:n], ov_host[:n]
-        rois = rois[:n]
-        stage("rpn_proposals")
-        pool5, argmax = rt.roi_pool_fwd_chw(feat, rois, 7, 7, model._spatial_scale, want_argmax=True)
-        stage("roi_pool_fwd")
-        pool5 = pool5.reshape(n, -1)
+        fetch = rt.mem.to_numpy_many_async([ov_dev, rois, n_out])                            # one device -> host copy, one host round trip
         scale = 1.0 / (1.0 - self.dropout_ratio)
-        a6 = model.fc6(pool5, relu=True)
         on_device = masks is None and self.dropout_rng == "device"
-        if on_device:                                                # one launch: mask drawn, stored and applied
-            # one counter per FORWARD (two draws each) -- not per update: forward_backward twice without update() must not reuse its masks -- and the
-            # data-parallel rank folded in: every rank draws its own masks from one dropout_seed
-            self._dropout_calls = getattr(self, "_dropout_calls", 0) + 1
-            rank = int(getattr(getattr(self, "comm", None), "rank", 0) or 0)
-            base = (self.dropout_seed * 0x100000001b3 + rank * 0x9E3779B97F4A7C15 + 2 * (self._dropout_calls - 1)) & 0xFFFFFFFFFFFFFFFF
-            d6, m6 = rt.dropout(a6, self.dropout_ratio, base)
-        else:
-            if masks is None:                                        # F.dropout [chainer-ext]: mask = (rand >= ratio) * 1/(1-ratio)
-                m6 = ((np.random.rand(*a6.shape) >= self.dropout_ratio) * scale).astype(np.float32)
+
+        def collect():
+            ov_host, rois_host, n_host = fetch()
+            n = int(n_host[0])
+            assert n > 0, "the ProposalLayer returned no RoI (proposal_target_layer.py:52 asserts the same)"
+            return n, rois_host[:n], ov_host[:n]
+
+        def head_forward(rois, n):
+            """RoI pooling -> fc6 -> dropout -> fc7 -> dropout -> cls_score / bbox_pred on n rows."""
+            pool5, argmax = rt.roi_pool_fwd_chw(feat, rois, 7, 7, model._spatial_scale, want_argmax=True)
+            stage("roi_pool_fwd")
+            pool5 = pool5.reshape(n, -1)
+            a6 = model.fc6(pool5, relu=True)
+            if on_device:                                            # one launch: mask drawn, stored and applied
+                # one counter per FORWARD (two draws each) -- not per update: forward_backward twice without update() must not reuse its masks -- and
+                # the data-parallel rank folded in: every rank draws its own masks from one dropout_seed (ADVICE r04)
+                self._dropout_calls = getattr(self, "_dropout_calls", 0) + 1
+                rank = int(getattr(getattr(self, "comm", None), "rank", 0) or 0)
+                base = (self.dropout_seed * 0x100000001b3 + rank * 0x9E3779B97F4A7C15 + 2 * (self._dropout_calls - 1)) & 0xFFFFFFFFFFFFFFFF
+                d6, m6 = rt.dropout(a6, self.dropout_ratio, base)
             else:
-                m6 = masks[0]
-            m6 = rt.asarray(m6, "f32")
-            d6 = rt.mul(a6, m6)
-        a7 = model.fc7(d6, relu=True)
-        if on_device:
-            d7, m7 = rt.dropout(a7, self.dropout_ratio, (base + 1) & 0xFFFFFFFFFFFFFFFF)
+                if masks is None:                                    # F.dropout [chainer-ext]: mask = (rand >= ratio) * 1/(1-ratio)
+                    m6 = ((np.random.rand(*a6.shape) >= self.dropout_ratio) * scale).astype(np.float32)
+                else:
+                    m6 = masks[0]
+                m6 = rt.asarray(m6, "f32")
+                d6 = rt.mul(a6, m6)
+            a7 = model.fc7(d6, relu=True)
+            if on_device:
+                d7, m7 = rt.dropout(a7, self.dropout_ratio, (base + 1) & 0xFFFFFFFFFFFFFFFF)
+            else:
+                m7 = ((np.random.rand(*a7.shape) >= self.dropout_ratio) * scale).astype(np.float32) if masks is None else masks[1]
+                m7 = rt.asarray(m7, "f32")
+                d7 = rt.mul(a7, m7)
+            cls_score, bbox_pred = model.cls_score(d7), model.bbox_pred(d7)
+            stage("head_fwd")
+            return pool5, argmax, a6, d6, m6, a7, d7, m7, cls_score, bbox_pred
+
+        if on_device and _tuning.get("FRCNN_RCNN_HEAD_FWD", "early") == "early":
+            # Device-drawn masks: nothing on the host has to know the RoI count before the head's forward pass, so it is enqueued at the
+            # ProposalLayer's CAPACITY (rows past the count are zero boxes -- detect.hip defines them -- and a row's results, its mask included,
+            # do not depend on the row count) BEFORE the host waits for its copy: the round trip, the sampling and the enqueueing of the losses
+            # and the head's backward pass all run under 0.65 ms of GPU work instead of in front of it.  (The NumPy-stream masks are
+            # (n, 4096) draws in the reference's order: that form reads the count first.)
+            stage("rpn_proposals")
+            cap = int(rois.shape[0])
+            fw = head_forward(rois, cap)
+            n, rois_host, ov_host = collect()
+            if n < cap:
+                fw = tuple(t[:n] for t in fw)
+            rois = rois[:n]
         else:
-            m7 = ((np.random.rand(*a7.shape) >= self.dropout_ratio) * scale).astype(np.float32) if masks is None else masks[1]
-            m7 = rt.asarray(m7, "f32")
-            d7 = rt.mul(a7, m7)
-        cls_score, bbox_pred = model.cls_score(d7), model.bbox_pred(d7)
-        stage("head_fwd")
+            n, rois_host, ov_host = collect()
+            rois = rois[:n]
+            stage("rpn_proposals")
+            fw = head_forward(rois, n)
+        pool5, argmax, a6, d6, m6, a7, d7, m7, cls_score, bbox_pred = fw
         # host work under the head's forward pass: np.random.choice in the reference's call order (after the two dropout draws)
         use_gt, ext, keep = self.ptl.sample(np.ascontiguousarray(rois_host, dtype=np.float32), gt_host[0], overlaps=ov_host)
         k = int(keep.shape[0])

@@ -18,7 +18,7 @@ def last_json_line(path):
 def main(tag="r05z", R="r05"):
     O, P = os.path.join(ROOT, "gpurun_out", tag), os.path.join(ROOT, "profiles")
     for n in (R + "_bench", R + "_bench_bf16", R + "_bench_f32s", R + "_bench_train", R + "_bench_train_f32s", R + "_bench_nccl_w1_train",
-              R + "_bench_2rank_gloo_train", R + "_bench_2rank_gloo_infer", R + "_bench_train_rcnn_device", R + "_bench_train_rcnn_numpy", R + "_bench_bf16_pair1", R + "_bench_bf16_pair0"):
+              R + "_bench_2rank_gloo_train", R + "_bench_2rank_gloo_infer", R + "_bench_train_rcnn_device", R + "_bench_train_rcnn_numpy", R + "_bench_train_rcnn_f32s", R + "_bench_train_rcnn_allrows_late", R + "_bench_bf16_pair1", R + "_bench_bf16_pair0"):
         src = os.path.join(O, n + ".json")
         if os.path.exists(src):
             line = last_json_line(src)
@@ -30,7 +30,8 @@ def main(tag="r05z", R="r05"):
             shutil.copy(os.path.join(O, n), os.path.join(P, n))
     if os.path.exists(os.path.join(O, "parity_reports.txt")):
         shutil.copy(os.path.join(O, "parity_reports.txt"), os.path.join(P, R + "_parity_reports.txt"))
-    for d, dst in (("prof", R + "_kernel_stats.csv"), ("prof_bf16", R + "_bf16_kernel_stats.csv"), ("prof_train", R + "_train_kernel_stats.csv"), ("prof_two", R + "_bf16_two_in_flight_kernel_stats.csv")):
+    for d, dst in (("prof", R + "_kernel_stats.csv"), ("prof_bf16", R + "_bf16_kernel_stats.csv"), ("prof_train", R + "_train_kernel_stats.csv"), ("prof_two", R + "_bf16_two_in_flight_kernel_stats.csv"),
+                   ("prof_rcnn", R + "_train_rcnn_kernel_stats.csv")):
         hits = glob.glob(os.path.join(O, d, "**", "*kernel_stats.csv"), recursive=True)
         if hits:
             shutil.copy(hits[0], os.path.join(P, dst))

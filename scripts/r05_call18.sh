@@ -1,7 +1,7 @@
 #!/bin/bash
 set -u
-R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; O=gpurun_out/r05s7; mkdir -p $O
-timeout 900 python -m pytest tests -m gpu -q -k "rcnn_train_step_small or rcnn_train_step_vgg16 or linear or dropout" > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -1 $O/pytest.log
+R=${GRAFT_REPO_ROOT:-/root/repo}; cd "$R"; O=gpurun_out/r05s8; mkdir -p $O
+timeout 900 python -m pytest tests -m gpu -q -k "rcnn or dropout" > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -1 $O/pytest.log
 timeout 300 python bench.py --mode train-rcnn --dropout-rng device --steps 20 --warmup 3 > $O/train_rcnn.json 2>> $O/err.log
 python - <<PY
 import json

@@ -14,6 +14,11 @@ done
 { for pr in 2 1 0; do echo "== FRCNN_BF16_PAIR_PRIO=$pr (0 none, 1 consumers first, 2 producers first)"; FRCNN_BF16_PAIR_PRIO=$pr timeout 60 $B/conv_pair_micro; done; } > $O/r05_conv_pair_micro.txt 2>&1; grep "^pair" $O/r05_conv_pair_micro.txt
 { echo "=== chain: default picks vs conv_dma_bf16_kernel's (old)"; timeout 120 $B/conv_bf16_micro --check --modes "def old"; } > $O/r05_conv_bf16_micro.txt 2>&1; tail -3 $O/r05_conv_bf16_micro.txt
 { timeout 60 $B/mfma_peak_micro 1 20000 10; } > $O/r05_mfma_peak_micro.txt 2>&1
+# the stage-2 step's other forms: split-product convolutions; the zero-padded head backward over all RoI rows and the count-first order (the A/B of the round's changes)
+timeout 600 python bench.py --mode train-rcnn --dtype f32s --dropout-rng device --steps 20 --warmup 3 > $O/r05_bench_train_rcnn_f32s.json 2>> $O/bench.err; echo "train-rcnn f32s rc=$?"; cut -c1-160 $O/r05_bench_train_rcnn_f32s.json | tail -1
+FRCNN_RCNN_BWD_ROWS=all FRCNN_RCNN_HEAD_FWD=late timeout 600 python bench.py --mode train-rcnn --dropout-rng device --steps 20 --warmup 3 > $O/r05_bench_train_rcnn_allrows_late.json 2>> $O/bench.err; echo "train-rcnn all rows, count first rc=$?"; cut -c1-160 $O/r05_bench_train_rcnn_allrows_late.json | tail -1
+# ... and its kernels
+( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/$O/prof_rcnn" -o r05_train_rcnn -- python "$R/bench.py" --mode train-rcnn --dropout-rng device --steps 10 --warmup 2 > "$R/$O/prof_rcnn.log" 2>&1; echo "rocprof train-rcnn rc=$?" ); find $O/prof_rcnn -type f ! -name "*kernel_stats.csv" -delete 2>/dev/null
 for f in 1 0; do FRCNN_BF16_CONV1_PAIR=$f timeout 600 python bench.py --dtype bf16 --steps 100 --warmup 5 --no-cpu-baseline > $O/r05_bench_bf16_pair$f.json 2>> $O/bench.err; echo "bench bf16, conv1 pair launch = $f: rc=$?"; cut -c1-140 $O/r05_bench_bf16_pair$f.json | tail -1; done
 # two images in flight per GPU (graph.ForwardsInFlight's mechanism, torch-level probe): serial vs two / three instances, outputs compared
 { for a in "bf16 2" "bf16 3" "f32 2" "f32s 2"; do timeout 300 python scripts/two_streams_probe.py $a; done; } 2>&1 | grep -v amdgpu.ids > $O/r05_two_streams_probe.txt; cat $O/r05_two_streams_probe.txt

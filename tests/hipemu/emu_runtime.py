@@ -34,6 +34,10 @@ class HostMemory(object):
     def to_numpy_many(self, arrays):
         return [np.array(a, copy=True) for a in arrays]
 
+    def to_numpy_many_async(self, arrays):
+        out = [np.array(a, copy=True) for a in arrays]
+        return lambda: out
+
     def is_array(self, a):
         return isinstance(a, np.ndarray)
 
