@@ -601,6 +601,12 @@ class RCNNTrainer(_BucketedAllReduce):
                 rt.f32s_pack_many([(l.Wp, self.ws_fwd[n], self.ws_dgrad[n], l.cin, l.cout) for n, l in big])
             feat, inputs, _ = trunk_forward_split(self, x)
         else:
+            # weights of every input-gradient convolution (rotated / transposed copies of the current packed weights): ONE launch on the gradient
+            # stream, under the forward pass -- as in RPNTrainer (one launch per layer inside the backward pass was 12 x 17 us on its critical path)
+            if _tuning.get("FRCNN_DGRAD_PACK") != "each":
+                with _grad_stream(rt):
+                    rt.pack_conv_dgrad_w_many([(l.Wp, self.wd[n], 3) for n, l in self.convs[1:]])
+                self._dgrad_packed = True
             feat, inputs = trunk_forward(model, x, fuse_pools=getattr(self, "keep_dy", None) is None)
         C, H, W = [int(v) for v in feat.shape[1:]]
         stage("trunk_fwd")
@@ -711,7 +717,9 @@ class RCNNTrainer(_BucketedAllReduce):
         # ---- RoI pooling (arg-max scatter) and the trunk; feat = relu(conv5_3): mask before entering conv5_3's backward
         gfeat = rt.relu_bwd_(rt.roi_pool_bwd(gp.reshape(rows, C, 7, 7), argmaxb.reshape(rows, C, 7, 7), C, H, W), feat)
         stage("roi_pool_bwd")
+        rt.mem.join_aux_stream("grad")                               # the re-packed input-gradient weights are ready
         (trunk_backward_split if self.conv_math == "split" else trunk_backward)(self, list(zip(self.layers, inputs)), gfeat)
+        self._dgrad_packed = False
         stage("trunk_bwd")
         return dict(losses=losses, n_rois=n, keep_inds=keep, masks=(m6, m7), head_acts=(a6, a7))       # head_acts: relu(fc6), relu(fc7) before dropout (the parity tests read the device's ReLU decisions off them)
 
