@@ -50,21 +50,20 @@ class TorchDeviceMemory(object):
 
     def to_numpy_many_async(self, arrays):
         """The same copy, enqueued now on the current stream; returns a function that waits for THAT COPY (an event behind it, not the stream: work
-        enqueued afterwards keeps running) and hands out the NumPy arrays.  One staging buffer: collect a copy before starting the next."""
+        enqueued afterwards keeps running) and hands out the NumPy arrays.  Every call stages through its own pinned block (torch's host allocator
+        recycles them), so several copies may be outstanding."""
         torch = self.torch
         dev = torch.cat([self.contiguous(a).reshape(-1).view(torch.uint8) for a in arrays])
-        pin = getattr(self, "_pin", None)                            # pinned: a pageable destination goes through a bounce copy
-        if pin is None or pin.numel() < dev.numel():
-            pin = self._pin = torch.empty((max(int(dev.numel()), 1 << 16),), dtype=torch.uint8, pin_memory=True)
         nbytes = int(dev.numel())
-        pin[:nbytes].copy_(dev, non_blocking=True)
+        pin = torch.empty((nbytes,), dtype=torch.uint8, pin_memory=True)      # pinned: a pageable destination goes through a bounce copy
+        pin.copy_(dev, non_blocking=True)
         done = torch.cuda.Event()
         done.record()
         shapes = [(tuple(a.shape), a.numel() * a.element_size(), _NP[self.dtype_of(a)]) for a in arrays]
 
         def collect():
             done.synchronize()
-            host = pin[:nbytes].numpy().copy()
+            host = pin.numpy().copy()
             out, off = [], 0
             for shape, nb, dt in shapes:
                 out.append(host[off:off + nb].view(dt).reshape(shape))
