@@ -37,9 +37,13 @@ constexpr int kSortThreads = 256;
 constexpr int kRankTiles = 4;     // tiles searched together (8 = 128 KB of LDS, one workgroup per CU: measured slower) by rank_scatter_kernel (independent binary searches in flight)
 constexpr int kChunk = 64;        // NMS chunk = wave width
 
+// unsigned order == float order; EVERY NaN -- either sign bit, any payload -- takes the one top key: NumPy's argsort()[::-1]
+// (proposal_layer.py:156-157, cpu_nms.pyx:26) sorts all NaNs to the end and the reversal puts them first.  0xFFC00000 (sign set) is
+// what x86 makes of inf - inf, i.e. what a host-computed softmax hands over.  Several NaNs are ties: ascending index, like all ties.
 __device__ __forceinline__ uint32_t ordered_bits(float f) {
     uint32_t b = __float_as_uint(f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // unsigned order == float order, +NaN on top
+    if ((b & 0x7fffffffu) > 0x7f800000u) return 0xffffffffu;
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 __device__ __forceinline__ unsigned long long make_key(float score, uint32_t index) {
     return ((unsigned long long)ordered_bits(score) << 32) | (uint32_t)(~index);

@@ -7,7 +7,8 @@
 #pragma once
 #include <stdlib.h>
 
-// value of `key` or nullptr when unset.  The pointer stays valid until the same key is set again.
+// value of `key` or nullptr when unset.  The string is immutable and stays valid for the life of the library (a later set / reset swaps
+// the slot to another interned string; it never rewrites this one).
 const char *frcnn_tune(const char *key);
 static inline int frcnn_tune_int(const char *key, int dflt) {
     const char *v = frcnn_tune(key);

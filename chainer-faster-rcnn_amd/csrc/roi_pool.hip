@@ -961,24 +961,29 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
     auto build_geometry = [&](int base, const float4 q, bool force_general) __attribute__((always_inline)) {
         const int sl = pk * 64 + lane;
         if (base + sl >= n_slots) return;
-        const int xs = (int)rintf(q.x * scale), ys = (int)rintf(q.y * scale);      // roi_geometry(): round-half-even of the fp32 product
+        int xs = (int)rintf(q.x * scale), ys = (int)rintf(q.y * scale);            // roi_geometry(): round-half-even of the fp32 product
         const int rw = max((int)rintf(q.z * scale) - xs + 1, 1), rh = max((int)rintf(q.w * scale) - ys + 1, 1);
         uint32_t rwq[4], rhq[4];                                             // the two edge rows: seven bins lo | hi << 8, then the meta word
         if (rw < kQuadTabExt && rh < kQuadTabExt) {
             const uint4 a = my_tab[rw], b = my_tab[kQuadTabExt + rh];
             rwq[0] = a.x; rwq[1] = a.y; rwq[2] = a.z; rwq[3] = a.w; rhq[0] = b.x; rhq[1] = b.y; rhq[2] = b.z; rhq[3] = b.w;
-        } else {                                                           // a RoI larger than the map: bin_range()'s arithmetic itself
+        } else {                                                           // a RoI larger than the map: bin_range()'s arithmetic itself.
+            // The row's eight bits per edge cannot hold an offset from a far-away origin (round 5 clamped the OFFSET at 255 and then added
+            // xs: a RoI reaching from -10^4 px lost every bin), so the edges are clamped into the map HERE -- 64-bit sums, exact for every
+            // RoI in the header's stated domain -- and stored relative to the origin 0.
             const double sw = (double)rw / (double)outw, sh = (double)rh / (double)outh;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { rwq[i] = 0u; rhq[i] = 0u; }
 #pragma unroll
             for (int p = 0; p < 7; ++p) {
                 const int pw = min(p, outw - 1), ph = min(p, outh - 1);
-                const int lw = min((int)floor((double)pw * sw), 255), hw = min((int)ceil((double)(pw + 1) * sw), 255);   // far past the map either way:
-                const int lh = min((int)floor((double)ph * sh), 255), hh = min((int)ceil((double)(ph + 1) * sh), 255);   // the clamps below see to it
+                const long long LW = W, LH = H;
+                const int lw = (int)min(max((long long)floor((double)pw * sw) + xs, 0ll), LW), hw = (int)min(max((long long)ceil((double)(pw + 1) * sw) + xs, 0ll), LW);
+                const int lh = (int)min(max((long long)floor((double)ph * sh) + ys, 0ll), LH), hh = (int)min(max((long long)ceil((double)(ph + 1) * sh) + ys, 0ll), LH);
                 rwq[p >> 1] |= (uint32_t)(lw | (hw << 8)) << (16 * (p & 1));
                 rhq[p >> 1] |= (uint32_t)(lh | (hh << 8)) << (16 * (p & 1));
             }
+            xs = 0; ys = 0;
             rwq[3] |= 0xffffu << 16; rhq[3] |= 0xffffu << 16;                // meta: largest bin 255, last hi 255 -> never "fast"; bounds only
         }
         const int mbw = (int)((rwq[3] >> 16) & 255u), hlw = (int)(rwq[3] >> 24), mbh = (int)((rhq[3] >> 16) & 255u), hlh = (int)(rhq[3] >> 24);

@@ -9,26 +9,45 @@ selects a CPU path.
 import contextlib
 import os
 
-_snapshot = {k: v for k, v in os.environ.items() if k.startswith("FRCNN_")}      # taken at import, like the library's at load
+_KEY_MAX, _VAL_MAX, _SLOTS = 47, 79, 96          # csrc/abi.hip: kTuneKey - 1, kTuneVal - 1, kTuneSlots
+
+
+def _holdable(k, v):
+    """What the library's own load-time snapshot keeps (abi.hip tune_snapshot_env skips the rest silently): an FRCNN_* variable with
+    an over-long name or value -- a path, a space-separated sweep list for scripts/ -- is not a knob of the library."""
+    return len(k.encode()) <= _KEY_MAX and len(str(v).encode()) <= _VAL_MAX
+
+
+_snapshot = {}
+for _k, _v in os.environ.items():                # taken at import, like the library's at load
+    if _k.startswith("FRCNN_") and _holdable(_k, _v) and len(_snapshot) < _SLOTS:
+        _snapshot[_k] = _v
 _table = dict(_snapshot)
 _libs = []
 
 
-def _push(lib, key, value):
+def _push(lib, key, value, strict=True):
     rc = lib.frcnn_set_tuning(key.encode(), None if value is None else str(value).encode())
     if rc != 0:
-        raise ValueError("frcnn_set_tuning(%r, %r) -> %d" % (key, value, rc))
+        if strict:
+            raise ValueError("frcnn_set_tuning(%r, %r) -> %d" % (key, value, rc))
+        import warnings
+        warnings.warn("tuning: the library does not hold %s=%r (frcnn_set_tuning -> %d); entry skipped" % (key, value, rc))
+        _table.pop(key, None)
+        _snapshot.pop(key, None)
 
 
 def register(lib):
     """Called by _lib.bind(): bring a freshly opened library to this table's state.  The library took its own snapshot of the
     environment when it was loaded (possibly later than this module's): every entry of the table is pushed, and FRCNN_* variables
-    that are in the environment now but not in the table are cleared, so both sides hold the same picture."""
+    that are in the environment now but not in the table are cleared, so both sides hold the same picture.  Never raises on an
+    environment entry the library rejects (an unrelated FRCNN_* variable must not make the import fail) -- only an
+    explicit set() does."""
     for k in os.environ:
-        if k.startswith("FRCNN_") and k not in _table:
-            _push(lib, k, None)
-    for k, v in _table.items():
-        _push(lib, k, v)
+        if k.startswith("FRCNN_") and k not in _table and _holdable(k, ""):
+            _push(lib, k, None, strict=False)
+    for k, v in list(_table.items()):
+        _push(lib, k, v, strict=False)
     _libs.append(lib)
 
 

@@ -47,7 +47,9 @@ int frcnn_device_count(void);
  * takes its measured default; no key selects a CPU path.  The reference has no counterpart (its only knob on this path is the process-wide
  * cudaSetDevice of nms_kernel.cu:80-89).
  *   frcnn_set_tuning(key, value)   key must start with "FRCNN_" (47 characters at most), value at most 79 characters; value NULL removes
- *                                  the entry.  Not to be called concurrently with a launch that reads the same key.  0, or FRCNN_ERR_INVALID.
+ *                                  the entry.  0, or FRCNN_ERR_INVALID (key / value too long, a 97th key).  Thread-safe: values are immutable
+ *                                  interned strings and a set swaps a pointer, so a launch on another thread reads the old or the new value,
+ *                                  never a torn one.  FRCNN_* environment entries the table cannot hold are skipped at load, not an error.
  *   frcnn_get_tuning(key, out, n)  copies the value (NUL-terminated, truncated to n) and returns its length + 1; 0 when the key is unset.
  *   frcnn_reset_tuning()           back to the load-time snapshot.
  */
@@ -109,6 +111,12 @@ int frcnn_proposals(const float *rpn_cls_prob, const float *rpn_bbox_pred, int A
  * Chainer v1 ROIPooling2D forward / backward).  x (C,H,W) f32 NCHW batch 1 (the batch index in rois is
  * ignored: the reference asserts batch==1); rois (R,5) f32 [batch,x1,y1,x2,y2]; y (R,C,outh,outw) f32;
  * argmax same shape int32 (flat h*W+w, -1 for an empty bin) or NULL (inference).  outh,outw <= 7.
+ * RoI COORDINATE DOMAIN: every finite RoI with |v * spatial_scale| <= 2^24 for its four coordinates is pooled exactly as the reference's
+ * arithmetic pools it -- negative corners, reversed corners (extent max(., 1)), one-point RoIs, RoIs wholly outside the map (all bins empty:
+ * 0 / -1) and RoIs far larger than the map (e.g. [-1e4, -1e4, 2e4, 2e4]) included; tests/parity_cases.py roi_case holds one of each.  Beyond
+ * 2^24 cells (or NaN / inf coordinates) the float -> int conversion saturates; the call still returns 0 and writes finite in-range output,
+ * but which bins count as empty is unspecified (the reference's Python integers do not saturate).  The device forms cannot validate device
+ * rois without a host round trip, so nothing is rejected.
  *   frcnn_roi_pool_fwd_chw  the fast path: NCHW in, channel planes resident in LDS, no transpose (falls back to
  *                           frcnn_chw_to_hwc into `workspace` + frcnn_roi_pool_fwd_hwc when one H*W plane exceeds
  *                           the LDS budget; workspace may be NULL otherwise)

@@ -155,6 +155,80 @@ def main():
           (at["b_labels"] == 1).sum(), (at["b_labels"] == 0).sum())
 
 
+def edge_cases(ns):
+    """Inputs SURVEY 8a-9 / 8a-11 name and the reference's own tests never feed: NaN scores of either sign bit, +-inf scores,
+    NaN / +-inf deltas, an exp() overflow (dw = 100), and for cpu_nms a NaN score of either sign and a NaN coordinate.  Outputs are
+    the reference's (ProposalLayer under the stub chainer, cpu_nms.pyx compiled in place).  One special value of a kind per case, so
+    NumPy's implementation-defined order among equal keys (all NaNs compare equal) cannot leak into the fixture.  -> edge_cases.npz"""
+    import warnings
+    warnings.simplefilter("ignore", RuntimeWarning)
+    out = {}
+    fh = fw = 14
+    info = np.array([[224, 224]], dtype=np.int32)
+    NEG_NAN = np.array([0xFFC00000], np.uint32).view(np.float32)[0]      # what x86 makes of inf - inf
+    POS_NAN = np.array([0x7FC00000], np.uint32).view(np.float32)[0]
+
+    def base(seed):
+        rs = np.random.RandomState(seed)
+        return unique_scores_softmax(rs, (1, 18, fh, fw)), (rs.randn(1, 36, fh, fw) * 0.2).astype(np.float32)
+
+    def run(tag, prob, pred, train=False):
+        pl = ns.ProposalLayer()
+        pl.train = train
+        props, probs = pl(ns.Variable(prob.copy()), ns.Variable(pred.copy()), ns.Variable(info))
+        all_bbox = pl._generate_all_bbox_use_array_info(pred[0])
+        trans = pred[0].transpose(1, 2, 0).reshape(-1, 4)
+        dec = ns.clip_boxes(ns.bbox_transform_inv(all_bbox, trans), info[0])
+        keep0 = ns.filter_boxes(dec, pl._min_size)
+        fg = prob[0, 9:].transpose(1, 2, 0).reshape(-1, 1)[keep0]
+        order = fg.ravel().argsort()[::-1][:pl._pre_nms_top_n]
+        keep = np.asarray(ns.cpu_nms(np.hstack((dec[keep0][order], fg[order])), pl._nms_thresh), dtype=np.int64)
+        src = keep0[order][keep[:len(props)]]
+        assert np.array_equal(dec[src], props), tag                   # the index chain reproduces the layer's own output
+        out.update({"p_%s_prob" % tag: prob, "p_%s_pred" % tag: pred, "p_%s_train" % tag: np.array(train), "p_%s_proposals" % tag: props,
+                    "p_%s_probs" % tag: probs, "p_%s_src" % tag: src.astype(np.int64), "p_%s_nvalid" % tag: np.array(len(keep0))})
+        print("edge", tag, props.shape, "n_valid", len(keep0), "first src", src[:4])
+
+    # ---- scores: one NaN of each sign, +-inf (fg channel 9 + a at (h, w); a mid-map anchor so that the box survives filter_boxes)
+    for tag, vals in (("posnan", [POS_NAN]), ("negnan", [NEG_NAN]), ("infs", [np.float32(np.inf), np.float32(-np.inf)]),
+                      ("negnan_inf", [NEG_NAN, np.float32(np.inf)])):
+        prob, pred = base(41)
+        for k, v in enumerate(vals):
+            prob[0, 9 + 4 + k, 6 + k, 7] = v
+        run(tag, prob, pred)
+    prob, pred = base(42)
+    prob[0, 9 + 1, 5, 5] = NEG_NAN
+    run("negnan_train", prob, pred, train=True)
+    # ---- deltas: (anchor a, h, w, coordinate, value); the touched anchors get the top scores so a wrongly kept box would show
+    prob, pred = base(43)
+    cases = [(4, 3, 3, 0, np.nan), (4, 3, 6, 1, np.inf), (4, 3, 9, 2, 100.0), (4, 6, 3, 3, -np.inf), (4, 6, 6, 2, np.inf),
+             (4, 6, 9, 0, -np.inf), (4, 9, 3, 2, np.nan), (4, 9, 6, 3, 100.0), (4, 9, 9, 2, 88.0), (1, 7, 7, 3, -100.0), (7, 7, 7, 2, 87.0)]
+    top = np.sort(prob[0, 9:].ravel())[::-1]
+    for k, (a, h, w, c, v) in enumerate(cases):
+        pred[0, a * 4 + c, h, w] = v
+        prob[0, 9 + a, h, w] = np.nextafter(np.float32(1.0), np.float32(0)) - np.float32(k * 1e-6)
+    pred[0, 4 * 4 + 0, 9, 6] = np.inf                                # dx = inf together with dh = 100: inf - inf = NaN corner
+    assert len(np.unique(prob[0, 9:])) == prob[0, 9:].size
+    run("deltas", prob, pred)
+    # ---- cpu_nms (cpu_nms.pyx:18-69): a NaN score of either sign is ordered first by argsort()[::-1]; a NaN coordinate poisons
+    # the IoU of every pair it enters through max / min helpers that are NOT symmetric in NaN (cpu_nms.pyx:12-16)
+    rs = np.random.RandomState(44)
+    n = 200
+    x1 = rs.uniform(0, 300, n); y1 = rs.uniform(0, 300, n)
+    d = np.stack([x1, y1, x1 + rs.uniform(20, 200, n), y1 + rs.uniform(20, 200, n), rs.permutation(n) / float(n)], 1).astype(np.float32)
+    for tag, fn in (("negnan_score", lambda a: a.__setitem__((57, 4), NEG_NAN)), ("posnan_score", lambda a: a.__setitem__((57, 4), POS_NAN)),
+                    ("nan_x1", lambda a: a.__setitem__((31, 0), np.nan)), ("nan_y2", lambda a: a.__setitem__((140, 3), np.nan)),
+                    ("inf_score", lambda a: a.__setitem__((99, 4), np.inf)), ("inf_x2", lambda a: a.__setitem__((12, 2), np.inf))):
+        a = d.copy()
+        fn(a)
+        for thr in (0.7, 0.3):
+            keep = np.asarray(ns.cpu_nms(a, thr), dtype=np.int64)
+            out["n_%s_dets" % tag] = a
+            out["n_%s_keep_%02d" % (tag, int(thr * 10))] = keep
+            print("edge nms", tag, thr, len(keep), keep[:5])
+    np.savez_compressed(os.path.join(OUT, "edge_cases.npz"), **out)
+
+
 def proposal_target_cases(ns):
     """ProposalTargetLayer (proposal_target_layer.py:84-150): three proposal sets built around the gt boxes (fg / bg / far)."""
     from oracle import frcnn_oracle as O
@@ -183,5 +257,9 @@ def proposal_target_cases(ns):
 
 
 if __name__ == "__main__":
-    main()
-    proposal_target_cases(rh.load())
+    if "--edges" in sys.argv:          # only the edge fixture (the others regenerate identically; this avoids the churn)
+        edge_cases(rh.load())
+    else:
+        main()
+        proposal_target_cases(rh.load())
+        edge_cases(rh.load())

@@ -174,6 +174,48 @@ def check_proposals_golden(rt, case):
     return n
 
 
+PROPOSAL_EDGE_TAGS = ("posnan", "negnan", "infs", "negnan_inf", "negnan_train", "deltas")
+NMS_EDGE_TAGS = ("negnan_score", "posnan_score", "nan_x1", "nan_y2", "inf_score", "inf_x2")
+
+
+def check_proposals_edge_goldens(rt, tags=PROPOSAL_EDGE_TAGS):
+    """SURVEY 8a-9 / 8a-11's named inputs, fixtures made by the reference's own ProposalLayer (tests/make_golden.py edge_cases):
+    a NaN score of EITHER sign bit is ordered first (NumPy's argsort()[::-1]; 0xFFC00000 is what x86 makes of inf - inf), +-inf
+    scores, NaN / +-inf deltas, exp() overflow.  Source indices bit-exact, scores bit-exact (NaN payload included)."""
+    G = g("edge_cases")
+    anchors = O.generate_anchors()
+    for tag in tags:
+        train = bool(G["p_%s_train" % tag])
+        pre, post = (12000, 2000) if train else (6000, 300)
+        rois, probs, n_out, src = rt.proposals(dev(rt, G["p_%s_prob" % tag][0]), dev(rt, G["p_%s_pred" % tag][0]), anchors, 16, 224, 224,
+                                               16.0, pre, post, 0.7, want_index=True)
+        n = int(host(rt, n_out)[0])
+        want_p, want_s, want_src = G["p_%s_proposals" % tag], G["p_%s_probs" % tag].ravel(), G["p_%s_src" % tag]
+        assert n == len(want_p), (tag, n, len(want_p))
+        assert np.array_equal(host(rt, src)[:n], want_src.astype(np.int32)), (tag, host(rt, src)[:8], want_src[:8])
+        assert np.array_equal(host(rt, probs)[:n].view(np.uint32), want_s.view(np.uint32)), tag
+        got = host(rt, rois)[:n]
+        assert np.isfinite(got).all() and np.allclose(got, want_p, rtol=5e-7, atol=1e-4), (tag, np.abs(got - want_p).max())
+
+
+def check_nms_edge_goldens(rt, tags=NMS_EDGE_TAGS, ffi=True):
+    """cpu_nms.pyx on a NaN score of either sign, an infinite score, a NaN / infinite coordinate (the reference's max / min helpers
+    are not symmetric in NaN: cpu_nms.pyx:12-16) -- frcnn_nms, the batched form and `_nms` give the reference's keep list."""
+    G = g("edge_cases")
+    for tag in tags:
+        dets = G["n_%s_dets" % tag]
+        for thr in (0.7, 0.3):
+            want = G["n_%s_keep_%02d" % (tag, int(thr * 10))]
+            keep, n = rt.nms(dev(rt, dets), thr)
+            n = int(host(rt, n)[0])
+            assert n == len(want) and np.array_equal(host(rt, keep)[:n], want.astype(np.int32)), (tag, thr, n, len(want))
+            kb, nb = rt.nms_batched(dev(rt, np.stack([dets, dets[::-1].copy()])), thr)
+            assert int(host(rt, nb)[0]) == len(want) and np.array_equal(host(rt, kb)[0, :len(want)], want.astype(np.int32)), (tag, thr)
+            if ffi:
+                from chainer_faster_rcnn_amd.models import gpu_nms
+                assert [int(v) for v in gpu_nms(dets, thr, 0, lib=rt.lib)] == want.tolist(), (tag, thr)
+
+
 # ------------------------------------------------------------------------------------------- RoI pooling
 def roi_case(rs, R, C=512, H=38, W=63):
     x = np.abs(rs.randn(1, C, H, W)).astype(np.float32)
@@ -188,6 +230,13 @@ def roi_case(rs, R, C=512, H=38, W=63):
         rois[k] = [0, (W - 1) * 16, (H - 1) * 16, W * 16 - 9, H * 16 - 9]   # tiny
         rois[k + 1] = [0, W * 16 + 200, H * 16 + 100, W * 16 + 300, H * 16 + 200]   # outside: empty bins
         rois[k + 2] = [0, 0, 0, W * 16 - 9, H * 16 - 9]                      # whole map
+    if R >= 12:     # what ProposalLayer's clipped output never holds but the public ABI accepts
+        rois[k + 3] = [0, -1e4, -1e4, 2e4, 2e4]                             # far larger than the map on every side
+        rois[k + 4] = [0, W * 12, H * 12, W * 4, H * 4]                      # reversed corners: extent max(., 1)
+        rois[k + 5] = [0, -50, -70, W * 8, H * 8]                            # negative corner
+        rois[k + 6] = [0, W * 8, H * 8, W * 8, H * 8]                        # a one-point RoI
+        rois[k + 7] = [0, -3e6, 100, 1e6, 200]                               # huge one way only
+        rois[k + 8] = [0, -50, -70, -10, -20]                                # wholly outside, negative side
     return x, rois
 
 

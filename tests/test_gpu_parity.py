@@ -66,6 +66,15 @@ def test_proposals_golden(rt, case):
     P.check_proposals_golden(rt, case)
 
 
+def test_proposals_edge_goldens(rt):
+    """NaN scores of either sign, +-inf scores, NaN / +-inf deltas, exp overflow: reference-generated fixtures."""
+    P.check_proposals_edge_goldens(rt)
+
+
+def test_nms_edge_goldens(rt):
+    P.check_nms_edge_goldens(rt)
+
+
 def test_proposals_repeatable(rt):
     """idempotence: the same inputs give the same RoIs on every call (workspace reuse, no stale state)."""
     G = P.g("proposal_38x63_test")

@@ -184,6 +184,29 @@ def test_tuning_registry_abi():
         tuning.set("PATH", "x")
 
 
+def test_import_survives_frcnn_variables_the_library_cannot_hold():
+    """an unrelated FRCNN_* variable -- a long path, the space-separated sweep lists scripts/conv_bf16_sweep.py reads, a
+    60-character name -- is skipped by the library's load-time snapshot and must be skipped, not raised on, by tuning.register(); a knob that
+    fits still arrives.  A fresh interpreter, because the snapshot is taken at import."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env["FRCNN_BF16_DMAS"] = " ".join(str(900 + i) for i in range(40))            # 199 characters
+    env["FRCNN_SOME_OUTPUT_DIRECTORY"] = "/tmp/" + "x" * 300
+    env["FRCNN_" + "K" * 60] = "1"
+    env["FRCNN_BF16_STRIP"] = "0"
+    code = ("import ctypes, chainer_faster_rcnn_amd as pkg\n"
+            "lib = pkg._lib.bind(pkg._lib.LIB_PATH)\n"
+            "buf = ctypes.create_string_buffer(96)\n"
+            "assert lib.frcnn_get_tuning(b'FRCNN_BF16_STRIP', buf, 96) == 2 and buf.value == b'0'\n"
+            "assert lib.frcnn_get_tuning(b'FRCNN_BF16_DMAS', buf, 96) == 0 and pkg.tuning.get('FRCNN_BF16_DMAS') is None\n"
+            "pkg.tuning.reset()\n"
+            "assert pkg.tuning.get('FRCNN_BF16_STRIP') == '0'\n"
+            "print('ok')\n")
+    out = subprocess.run([sys.executable, "-W", "error", "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-2000:]
+
+
 def test_conv_bf16_plan_of_the_vgg16_chain(monkeypatch):
     """frcnn_conv_bf16_plan (launch-free; a CU count of 256 is assumed where no device is visible): the default picks of the bf16 chain at
     600 x 1000 -- strip form D where a launch has >= 8 K-chunks and >= one 64-cout x 10-row x 32-px tile per CU, form C on the 38 x 63

@@ -63,6 +63,14 @@ def test_proposals_14x14(rt):
     P.check_proposals_golden(rt, "proposal_14x14_train_rand")
 
 
+def test_proposals_edge_goldens(rt):
+    P.check_proposals_edge_goldens(rt)
+
+
+def test_nms_edge_goldens(rt):
+    P.check_nms_edge_goldens(rt)
+
+
 def test_roi_pool_cells_kernel(rt):
     P.check_roi_pool_cells(rt)
 

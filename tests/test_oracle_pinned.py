@@ -51,6 +51,26 @@ def test_cpu_nms(golden):
         O.cpu_nms(g["edge_dets"], 1)
 
 
+def test_edge_cases(golden):
+    """The oracle on the reference-generated edge fixtures: NaN scores of either sign, +-inf scores, NaN / +-inf deltas, exp overflow,
+    NaN / inf coordinates into cpu_nms (tests/make_golden.py edge_cases)."""
+    import warnings
+    g = golden("edge_cases")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        for tag in ("posnan", "negnan", "infs", "negnan_inf", "negnan_train", "deltas"):
+            p, s, d = O.proposal_layer(g["p_%s_prob" % tag], g["p_%s_pred" % tag], np.array([[224, 224]], np.int32),
+                                       train=bool(g["p_%s_train" % tag]), return_debug=True)
+            assert np.array_equal(p, g["p_%s_proposals" % tag]), tag
+            assert np.array_equal(s.view(np.uint32), g["p_%s_probs" % tag].view(np.uint32)), tag
+            assert np.array_equal(d["keep0"][d["order"]][d["keep"]], g["p_%s_src" % tag]), tag
+        for tag in ("negnan_score", "posnan_score", "nan_x1", "nan_y2", "inf_score", "inf_x2"):
+            for thr in (0.7, 0.3):
+                want = g["n_%s_keep_%02d" % (tag, int(thr * 10))].tolist()
+                assert O.cpu_nms(g["n_%s_dets" % tag], thr) == want, (tag, thr)
+                assert O.cpu_nms_py(g["n_%s_dets" % tag], thr) == want, (tag, thr)
+
+
 def test_bbox_overlaps(golden):
     g = golden("bbox_overlaps")
     assert np.array_equal(O.bbox_overlaps(g["boxes"], g["query"]), g["overlaps"])
