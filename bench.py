@@ -125,6 +125,143 @@ def conv_flops(model_layers, h, w):
     return out, (h, w)
 
 
+def pick_cpu_threads(torch, O, params):
+    """batch-1 convs do not scale to hundreds of threads: pick the thread count that is fastest on one mid-size layer (conv3_2 at
+    150x250) -- reported as `cores` by the CPU baselines."""
+    xs = np.random.RandomState(0).randn(1, 256, 150, 250).astype(np.float32)
+    best = None
+    for nt in sorted(set([8, 16, 32, 64, os.cpu_count() or 1])):
+        if nt > (os.cpu_count() or 1):
+            continue
+        torch.set_num_threads(nt)
+        O.conv2d(xs, params["trunk/conv3_2/W"], params["trunk/conv3_2/b"], 1)
+        t0 = time.perf_counter()
+        O.conv2d(xs, params["trunk/conv3_2/W"], params["trunk/conv3_2/b"], 1)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, nt)
+    torch.set_num_threads(best[1])
+    return best[1]
+
+
+def train_flops(model_layers, h, w, stage2=False, n_rois=300, bwd_rows=128):
+    """Algorithmic FLOPs (2 per MAC) of one training step at h x w: every 3x3 convolution forward, its input gradient (conv1_1 has none: the image
+    needs no gradient) and its weight gradient.  RPN mode (train_rpn.py): trunk + rpn_conv_3x3 in all three passes (the two 1x1 heads, 0.6 GFLOP,
+    are left out).  Stage 2 (train_rcnn.py): the trunk in all three passes, rpn_conv_3x3 forward only (proposals carry no gradient), fc6 / fc7
+    forward over n_rois rows and backward (input + weight gradients) over ProposalTargetLayer's bwd_rows kept rows."""
+    fl, _ = conv_flops(model_layers, h, w)
+    total = sum(fl.values())
+    rpn = fl["rpn_conv_3x3"]
+    first = fl[model_layers[0][0]]
+    if not stage2:
+        return {"forward": total, "input_gradients": total - first, "weight_gradients": total}
+    trunk = total - rpn
+    fc = lambda rows: 2.0 * rows * (512 * 49 * 4096 + 4096 * 4096)
+    return {"forward": trunk + rpn + fc(n_rois), "input_gradients": trunk - first + fc(bwd_rows), "weight_gradients": trunk + fc(bwd_rows)}
+
+
+def cpu_train_baseline(params, x, gt, stage2, samples=3, warmups=1, rank_seed=0):
+    """The reference's training step on this box's host cores, bounded: `warmups` untimed + `samples` timed steps (seconds each), median.
+    RPN mode (train_rpn.py:140-182): AnchorTargetLayer + the train-mode ProposalLayer the reference runs and discards + forward / losses / backward
+    (torch-CPU autograd standing in for Chainer's) + WeightDecay / MomentumSGD over every parameter.  Stage 2 (train_rcnn.py:35-78): trunk + RPN +
+    ProposalLayer without gradient, ProposalTargetLayer, RoI pooling (C restatement) + head with dropout + losses + backward + update.
+    The detection glue is the oracle's pinned restatement (bit-for-bit the reference's classes on the golden vectors: tests/test_oracle_pinned.py);
+    cpu_nms / bbox_overlaps are the reference's own Cython, compiled in place into oracle/_ref, where loadable."""
+    import torch
+    from oracle import frcnn_oracle as O
+    O.build_c()
+    nms_fn, native = None, False
+    try:
+        from oracle import ref_harness
+        nms_fn = ref_harness.native("cpu_nms").cpu_nms
+        native = True
+    except Exception as e:
+        print("oracle/_ref cpu_nms not loadable (%s): timing the C restatement" % (e,), file=sys.stderr)
+    cores = pick_cpu_threads(torch, O, params)
+    info = np.array([[IM_H, IM_W]], dtype=np.int32)
+    rng = np.random.RandomState(rank_seed)
+    names = [k for k in params if k.startswith("trunk/") or (k.split("/")[0] in ("fc6", "fc7", "cls_score", "bbox_pred") if stage2 else k.startswith("RPN/"))]
+    P = {k: params[k].copy() for k in params}
+    V = {k: np.zeros_like(P[k]) for k in names}
+    times, stages = [], {}
+    for it in range(warmups + samples):
+        st = {}
+        t0 = time.perf_counter()
+        dup = 0.0
+        if not stage2:
+            fh, fw = (IM_H + 15) // 16, (IM_W + 15) // 16
+            labels, targets, inds, n_all = O.anchor_target_layer(fh, fw, gt, info, rng=rng)
+            st["anchor_targets"] = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            loss, grads = O.rpn_train_grads(P, x, labels, targets, inds, n_all)
+            st["forward_backward"] = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            # the train-mode ProposalLayer (12000 / 2000) the reference runs inside the step and discards (region_proposal_network.py:121-124)
+            with torch.no_grad():
+                feat = O.vgg16_trunk(P, x)
+                dup = time.perf_counter() - t1                        # a second trunk forward this composition needs and the reference does not
+                _, _, prob, bbox = O.rpn_head(P, feat)
+            t2 = time.perf_counter()
+            O.proposal_layer(prob, bbox, info, train=True, nms_fn=nms_fn)
+            st["proposal_layer_train_mode"] = time.perf_counter() - t2
+        else:
+            with torch.no_grad():
+                feat = O.vgg16_trunk(P, x)
+                dup = time.perf_counter() - t0
+                _, _, prob, bbox = O.rpn_head(P, feat)
+            t1 = time.perf_counter()
+            proposals, _ = O.proposal_layer(prob, bbox, info, train=True, nms_fn=nms_fn)
+            st["proposal_layer"] = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            use_gt, ext, keep = O.proposal_target_layer(proposals, gt, rng=rng)
+            st["proposal_target_layer"] = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            m6 = (rng.rand(len(proposals), 4096) >= 0.5).astype(np.float32) * 2.0     # F.dropout's masks, drawn on the host as chainer's CPU path does
+            m7 = (rng.rand(len(proposals), 4096) >= 0.5).astype(np.float32) * 2.0
+            st["dropout_masks"] = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            loss, grads = O.rcnn_train_grads(P, x, proposals, keep, use_gt[:, -1].astype(np.int32), ext, m6, m7)
+            st["forward_backward"] = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        for k in names:       # O.momentum_sgd_wd's arithmetic, in place as chainer's CPU update rule does it (NumPy, single-threaded: g += wd * W; v = m v - lr g; W += v)
+            g = np.array(grads[k], dtype=np.float32)
+            g += np.float32(0.0005) * P[k]
+            V[k] *= np.float32(0.9)
+            g *= np.float32(0.001)
+            V[k] -= g
+            P[k] += V[k]
+        st["update"] = time.perf_counter() - t1
+        total = time.perf_counter() - t0 - dup
+        if it >= warmups:
+            times.append(total)
+            for k, v in st.items():
+                stages.setdefault(k, []).append(v * 1e3)
+            stages.setdefault("second_trunk_forward_not_counted", []).append(dup * 1e3)
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "img/s", "cores": cores, "kind": "reference-native" if native else "port",
+            "sample": "%d %s training steps at 600x1000 after %d warm-up, median (seconds per step: bounded on purpose); torch-CPU fp32 autograd on `cores` "
+                      "threads standing in for Chainer's CPU convolutions / linears, the pinned NumPy restatements of AnchorTargetLayer / ProposalLayer / "
+                      "ProposalTargetLayer, cpu_nms + bbox_overlaps = %s; this composition evaluates the trunk forward twice (once without autograd, for the "
+                      "proposals) where the reference evaluates it once: the second one is timed and NOT counted"
+                      % (samples, "stage-2 (train_rcnn.py)" if stage2 else "RPN (train_rpn.py)", warmups,
+                         "the reference's own Cython compiled in place (oracle/_ref)" if native else "the C restatement"),
+            "ms_per_step": med * 1e3, "stages_ms": {k: round(float(np.median(v)), 2) for k, v in stages.items()}, "loss_last_step": float(loss)}
+
+
+def train_roofline(flops, step_ms, fwd_bwd_ms, profile):
+    """`roofline` of a training line: the step's convolution (+ FC) FLOPs over the step time against the fp32 MFMA peak.  The kernels are many (forward,
+    input-gradient, weight-gradient forms on two streams), so `achieved` is priced on the WHOLE step (a lower bound of the kernels' own fraction);
+    the same FLOPs over the forward + backward stage alone (HIP events) and the rocprofv3 per-kernel sums of the same command are beside it."""
+    total = sum(flops.values())
+    ach = total / (step_ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv_mfma_f32_kernel + conv_wgrad_* + conv_dgrad forms + linear_dma_f32_kernel: every MFMA launch of the step, priced together",
+            "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "algorithmic_gflop_per_step": total / 1e9, "algorithmic_gflop": {k: v / 1e9 for k, v in flops.items()},
+            "basis": "whole step (ms_per_step): forward + backward + all-reduce + update; the MFMA kernels' own fraction is higher",
+            "frac_of_forward_backward_stage": (total / (fwd_bwd_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS) if fwd_bwd_ms else None,
+            "rocprof_kernel_sums": profile}
+
+
 def cpu_baseline(params, x, samples):
     """forward.py's CPU path on this box (SURVEY 8(d) / BASELINE.md 4): warm-up 2, then `samples` (>= 5) full 600x1000 images,
     per-stage medians.  Returns (the bench-line object, the oracle's debug dict of the LAST image for the parity block)."""
@@ -139,21 +276,7 @@ def cpu_baseline(params, x, samples):
         nms_kind = "the reference's own models/cpu_nms.pyx, compiled in place into oracle/_ref (single-threaded, as in the reference)"
     except Exception as e:                                          # oracle/_ref absent: the restatement is the baseline, and says so
         print("oracle/_ref cpu_nms not loadable (%s): timing the C restatement" % (e,), file=sys.stderr)
-    # batch-1 convs do not scale to hundreds of threads: pick the thread count that is fastest on one mid-size
-    # layer (conv3_2 at 150x250) and report it as `cores`
-    xs = np.random.RandomState(0).randn(1, 256, 150, 250).astype(np.float32)
-    best = None
-    for nt in sorted(set([8, 16, 32, 64, os.cpu_count() or 1])):
-        if nt > (os.cpu_count() or 1):
-            continue
-        torch.set_num_threads(nt)
-        O.conv2d(xs, params["trunk/conv3_2/W"], params["trunk/conv3_2/b"], 1)
-        t0 = time.perf_counter()
-        O.conv2d(xs, params["trunk/conv3_2/W"], params["trunk/conv3_2/b"], 1)
-        dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
-            best = (dt, nt)
-    torch.set_num_threads(best[1])
+    pick_cpu_threads(torch, O, params)
     samples = max(int(samples), 5)
     stages, totals, dbg = {}, [], None
     for it in range(2 + samples):
@@ -557,7 +680,7 @@ def per_rank_block(per_rank, steps):
     return {"ms_per_step": [round(v, 4) for v in ms], "min_ms": round(min(ms), 4), "max_ms": round(max(ms), 4), "spread_ms": round(max(ms) - min(ms), 4)}
 
 
-def train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note):
+def train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note, params=None, x_host=None):
     """BASELINE.json configs[4]: train_rpn.py's step -- forward, ProposalLayer (train top-N, discarded, as the reference runs it),
     anchor targets, losses, backward, the all-reduce of the flat gradient buffer (RCCL), fused MomentumSGD+WD -- one synthetic
     VOC-shaped image per GPU per step."""
@@ -618,6 +741,18 @@ def train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_not
     if rank == 0:
         st = {k: float(np.mean([a.elapsed_time(b) for a, b in zip(ev[p], ev[k])])) for p, k in
               (("start", "fwd_bwd"), ("fwd_bwd", "all_reduce"), ("all_reduce", "update"))}
+        from chainer_faster_rcnn_amd.models.vgg16 import LAYERS
+        step_ms = dt / args.steps * 1e3
+        roof = train_roofline(train_flops(LAYERS, IM_H, IM_W), step_ms, st["fwd_bwd"],
+                              "profiles/r06_train_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --mode train`)")
+        if conv_math == "split":
+            roof["basis"] += "; the forward / input-gradient products run on the bf16 pipes (six per fp32 product): the fraction is of the fp32 MFMA peak and may exceed what fp32 MFMAs could do"
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline and params is not None:
+            try:
+                cpu = cpu_train_baseline(params, x_host, gt, stage2=False, samples=3, warmups=1, rank_seed=rank)
+            except Exception as e:
+                cpu = {"error": repr(e)}
         emit_json_line({"metric": "images/sec RPN training step VGG16 600x1000", "value": world * args.steps / dt, "unit": "img/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32s" if conv_math == "split" else "f32", "data": "synthetic",
@@ -634,14 +769,15 @@ def train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_not
                                    "single_rank_process_group": bool(args.dist_world1 and world == 1),
                                    "comm_host_ms_per_step": ({k: round(v[1] / max(args.steps, 1), 4) for k, v in tr.comm.trace.items()}
                                                              if getattr(getattr(tr, "comm", None), "trace", None) else None)},
-                          "cpu_baseline": None if world == 1 else "not run: ranks > 1 (the N = 1 line carries it)",
+                          "roofline": roof,
+                          "cpu_baseline": cpu if world == 1 else "not run: ranks > 1 (the N = 1 line carries it)",
                           "stages_ms": st, "losses": tr.losses_host(out)})
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def train_rcnn_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note):
+def train_rcnn_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note, params=None, x_host=None):
     """Stage 2 of the reference's alternating schedule (train_rcnn.py:35-78; models/faster_rcnn.py:110-173 with rcnn_train = True): trunk -> RPN
     proposals (no gradient) -> RoI pooling with arg-max -> fc6 / fc7 + dropout -> cls_score / bbox_pred -> ProposalTargetLayer -> losses ->
     backward through the head, RoI pooling and the trunk -> all-reduce -> MomentumSGD + WeightDecay over trunk + head (548 MB of parameters).
@@ -689,6 +825,17 @@ def train_rcnn_mode(args, torch, dist, rt, model, x, rank, world, barrier, share
         # the host's side of the same boundaries: how long the Python thread took to ENQUEUE each stage (a stage whose GPU time equals its enqueue
         # time is bound by the launch rate of the un-captured step, not by its kernels)
         st_host = {names[i]: float(np.mean([(s[i][2] - s[i - 1][2]) * 1e3 for s in ev])) for i in range(1, len(names))}
+        from chainer_faster_rcnn_amd.models.vgg16 import LAYERS
+        step_ms = dt / args.steps * 1e3
+        roof = train_roofline(train_flops(LAYERS, IM_H, IM_W, stage2=True, n_rois=int(out["n_rois"]), bwd_rows=int(out["keep_inds"].shape[0])), step_ms,
+                              sum(v for k, v in st.items() if k not in ("all_reduce", "update")),
+                              "profiles/r06_train_rcnn_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `bench.py --mode train-rcnn`)")
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline and params is not None:
+            try:
+                cpu = cpu_train_baseline(params, x_host, gt.data, stage2=True, samples=3, warmups=1, rank_seed=rank)
+            except Exception as e:
+                cpu = {"error": repr(e)}
         emit_json_line({"metric": "images/sec Fast R-CNN (stage 2) training step VGG16 600x1000", "value": world * args.steps / dt, "unit": "img/s",
                         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32s" if conv_math == "split" else "f32", "data": "synthetic",
@@ -706,7 +853,8 @@ def train_rcnn_mode(args, torch, dist, rt, model, x, rank, world, barrier, share
                                                    "the RoI count, the RoIs and their float64 IoU matrix"},
                         "per_rank": per_rank_block(per_rank, args.steps),
                         "dist": {"backend": (dist.get_backend() if dist is not None else None), "world_size": world},
-                        "cpu_baseline": None if world == 1 else "not run: ranks > 1",
+                        "roofline": roof,
+                        "cpu_baseline": cpu if world == 1 else "not run: ranks > 1",
                         "stages_ms": {k: round(v, 4) for k, v in st.items()}, "sum_of_stages_ms": round(sum(st.values()), 4),
                         "host_enqueue_ms": {k: round(v, 4) for k, v in st_host.items()},
                         "losses": tr.losses_host(out)})
@@ -793,9 +941,9 @@ def main():
         torch.cuda.synchronize()
 
     if args.mode == "train":
-        return train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note)
+        return train_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note, params, x_host)
     if args.mode == "train-rcnn":
-        return train_rcnn_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note)
+        return train_rcnn_mode(args, torch, dist, rt, model, x, rank, world, barrier, shared_note, params, x_host)
 
     use_graph = args.graph in ("on", "auto")
     # Untimed preamble before the W warm-up steps: the first forwards of a process run at idle clocks (DVFS needs a few hundred

@@ -248,6 +248,34 @@ __device__ __forceinline__ void roi_scan_lane(const float *pc, int ws, int bw, i
     }
 }
 
+// The same for a RoI whose widest bin exceeds kMaxBinW columns -- only a RoI LARGER THAN THE MAP has such bins (an in-map RoI's are at most
+// ceil(W / outw) + 1 wide, which the host checks against kMaxBinW) -- the oracle's scan itself, cell by cell with per-lane trip counts: the bin's
+// first cell seeds the maximum, a later cell replaces it only under a strict `>`.  Rare and slow on purpose (round 5 sent these bins through the
+// 12-column form, which read 12 of their columns: wrong maxima for e.g. [-1e4, -1e4, 2e4, 2e4]).
+template <bool ARGMAX>
+__device__ __attribute__((noinline)) void roi_scan_lane_wide(const float *plane, int ws, int bw, int W, const int *hr, int outh, int outw, bool lane_on,
+                                                float *sv_lane, int32_t *si_lane) {
+    for (int ph = 0; ph < outh; ++ph) {
+        const int hrv = hr[ph];
+        const int hs = hrv & 0xffff, he = hrv >> 16;
+        float m = 0.0f;
+        int mi = -1;
+        if (lane_on && he > hs && bw > 0) {
+            m = plane[hs * kRowPitch + ws];
+            mi = hs * W + ws;
+            for (int h = hs; h < he; ++h)
+                for (int w = ws; w < ws + bw; ++w) {
+                    const float v = plane[h * kRowPitch + w];
+                    if (v > m) { m = v; mi = h * W + w; }
+                }
+        }
+        if (lane_on) {
+            sv_lane[ph * outw] = m;
+            if (ARGMAX) si_lane[ph * outw] = mi;
+        }
+    }
+}
+
 __device__ __forceinline__ uint32_t roi_f32_to_bf16(float f) { return frcnn_pack_bf16x2(f, 0.0f) & 0xffffu; }   // nearest even (v_cvt_pk_bf16_f32)
 
 // OUT16: y is raw bf16 (uint16) -- what the bf16 FC head consumes; pooling itself stays fp32 (a max of fp32 values, then ONE rounding:
@@ -342,7 +370,8 @@ roi_pool_planes_kernel(const float *__restrict__ x, int C, int H, int W, const f
             int32_t *sil = si + ((ARGMAX && lane_on) ? c * bins + pw : 0);
             if (bwm <= 4) roi_scan_lane<ARGMAX, 4>(pc, ws, bw, W, hrange[rl], outh, outw, lane_on, svl, sil);
             else if (bwm <= 8) roi_scan_lane<ARGMAX, 8>(pc, ws, bw, W, hrange[rl], outh, outw, lane_on, svl, sil);
-            else roi_scan_lane<ARGMAX, 12>(pc, ws, bw, W, hrange[rl], outh, outw, lane_on, svl, sil);
+            else if (bwm <= kMaxBinW) roi_scan_lane<ARGMAX, 12>(pc, ws, bw, W, hrange[rl], outh, outw, lane_on, svl, sil);
+            else roi_scan_lane_wide<ARGMAX>(planes + (lane_on ? c : 0) * pstride, ws, bw, W, hrange[rl], outh, outw, lane_on, svl, sil);
         }
         frcnn_wave_sync();     // the wave's own LDS writes above are read by other lanes below (DS ops of a wave are in order)
         // ---- (r, c0 .. c0 + cg, :, :) is one contiguous run of cg*bins floats of y

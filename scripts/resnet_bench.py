@@ -47,6 +47,46 @@ def resnet_trunk_flops(h, w, blocks=(3, 4, 23, 3)):
     return per, (hh, ww)
 
 
+def cpu_baseline_resnet(params, x, samples=3, warmups=1):
+    """configs[3] on this box's host cores, bounded (seconds per image): the oracle's ResNet-101 trunk (torch-CPU fp32, BatchNormalization in test mode,
+    models/resnet.py:11-45) -> RPN head -> the pinned ProposalLayer restatement at 1000 / 300 with the reference's own cpu_nms where loadable -> RoI
+    pooling at 1/32 (C restatement) -> fc6 (300 x 100352 x 4096) / fc7 / cls / bbox.  `warmups` untimed + `samples` timed forwards, median."""
+    from oracle import frcnn_oracle as O
+    O.build_c()
+    nms_fn = None
+    try:
+        from oracle import ref_harness
+        nms_fn = ref_harness.native("cpu_nms").cpu_nms
+    except Exception as e:
+        print("oracle/_ref cpu_nms not loadable (%s): timing the C restatement" % (e,), file=sys.stderr)
+    vgg = synthetic.params(seed=1)
+    cores = bench.pick_cpu_threads(torch, O, vgg)
+    info = np.array([[600, 1000]], dtype=np.int32)
+    times, stages = [], {}
+    for it in range(warmups + samples):
+        t0 = time.perf_counter()
+        feat = O.resnet_forward(params, x)
+        t1 = time.perf_counter()
+        _, _, prob, bbox = O.rpn_head(params, feat)
+        t2 = time.perf_counter()
+        proposals, _ = O.proposal_layer(prob, bbox, info, train=False, feat_stride=32, pre_nms_top_n=1000, post_nms_top_n=300, nms_fn=nms_fn)
+        t3 = time.perf_counter()
+        pool5 = O.roi_pooling_2d(feat, np.concatenate([np.zeros((len(proposals), 1), np.float32), proposals], 1), 7, 7, 1 / 32.)
+        t4 = time.perf_counter()
+        O.rcnn_head(params, pool5, proposals, info)
+        t5 = time.perf_counter()
+        if it >= warmups:
+            times.append(t5 - t0)
+            for k, v in (("trunk", t1 - t0), ("rpn_head", t2 - t1), ("proposals", t3 - t2), ("roi_pool", t4 - t3), ("head", t5 - t4)):
+                stages.setdefault(k, []).append(v * 1e3)
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "img/s", "cores": cores, "kind": "reference-native" if nms_fn is not None else "port",
+            "sample": "%d full 600x1000 ResNet-101 forwards after %d warm-up, median; torch-CPU fp32 on `cores` threads standing in for Chainer's CPU "
+                      "convolutions / linears, pinned NumPy ProposalLayer (1000 / 300), NMS = %s, C restatement of RoI pooling"
+                      % (samples, warmups, "the reference's own cpu_nms.pyx (oracle/_ref)" if nms_fn is not None else "the C restatement"),
+            "ms_per_image": med * 1e3, "stages_ms": {k: round(float(np.median(v)), 2) for k, v in stages.items()}}
+
+
 def main():
     rt = pkg.runtime.default_runtime()
     h, w = 600, 1000
@@ -62,7 +102,8 @@ def main():
     model = FasterRCNN(trunk_class=ResNet101, rpn_in_ch=2048, rpn_mid_ch=512, feat_stride=32, runtime=rt)
     model.load_params(params)
     model.RPN.proposal_layer._pre_nms_top_n, model.RPN.proposal_layer._post_nms_top_n = 1000, 300
-    x = rt.mem.from_numpy(synthetic.image(seed=6, h=h, w=w) / 64.0)
+    x_host = synthetic.image(seed=6, h=h, w=w) / 64.0
+    x = rt.mem.from_numpy(x_host)
     t_ramp = time.perf_counter()
     while time.perf_counter() - t_ramp < 1.0:                                          # clock ramp, untimed
         model.forward_device(x, h, w)
@@ -131,6 +172,13 @@ def main():
            "fc6": {"shape": "300 x 100352 x 4096", "ms": stages.get("fc6"), "tflops": fc6_flops / (stages["fc6"] * 1e-3) / 1e12 if stages.get("fc6") else None,
                    "weight_mb": 100352 * 4096 * 4 / 1e6},
            "rpn_conv_3x3": {"gflop": rpn_flops / 1e9}, "two_images_in_flight": two}
+    if "--no-cpu-baseline" not in sys.argv:
+        try:
+            rec["cpu_baseline"] = cpu_baseline_resnet(params, x_host)
+        except Exception as e:
+            rec["cpu_baseline"] = {"error": repr(e)}
+    else:
+        rec["cpu_baseline"] = None
     bench.emit_json_line(rec)
 
 

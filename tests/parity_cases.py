@@ -271,6 +271,36 @@ def check_roi_pool(rt, R=12, C=128, H=38, W=63, seed=0):
         assert np.allclose(host(rt, dx2), want_dx, rtol=1e-4, atol=1e-4), form
 
 
+def check_roi_pool_extreme_rois(rt):
+    """the public ABI takes any RoI, not only ProposalLayer's clipped output.  RoIs far larger than the map (round 5's quad kernel
+    clamped the bin OFFSET at 255 cells before adding a far-away origin and lost every bin of [-1e4, -1e4, 2e4, 2e4]; the plane kernel read 12 columns
+    of a 63-column bin), reversed, negative, one-point, wholly outside, up to the header's stated domain |v * scale| <= 2^24 -- on every forward kernel:
+    quads (38 x 63, both forms), cells, planes (forced, and as the arg-max default of a 45-row map), the channel-last gather (90 x 70)."""
+    rois = np.array([[0, -1e4, -1e4, 2e4, 2e4], [0, -1e5, -1e5, 1e5, 1e5], [0, -3e6, -2e6, 1e6, 4e6], [0, 500, 300, 100, 50], [0, -50, -70, -10, -20],
+                     [0, -50, -70, 60, 80], [0, 100, 100, 100, 100], [0, 5e3, 5e3, 6e3, 6e3], [0, -1e4, 100, 2e4, 200], [0, 100, -1e4, 300, 2e4],
+                     [0, 0, 0, 1e6, 1e6], [0, -2.6e8, -2.6e8, 2.6e8, 2.6e8], [0, -1023 * 16, -1023 * 16, 16 * 40, 16 * 30], [0, 37, 41, 333, 222]], np.float32)
+    rs = np.random.RandomState(11)
+    for (C, H, W) in [(16, 38, 63), (8, 45, 40), (8, 90, 70)]:
+        x = np.abs(rs.randn(1, C, H, W)).astype(np.float32)
+        want, wam = O.roi_pooling_2d(x, rois, 7, 7, 0.0625, return_argmax=True)
+        assert (want[0, :, 2, 2] == x[0].reshape(C, -1).max(axis=1)).all() and (wam[0, :, 0, 0] == -1).all()   # the whole map lies in bin (2, 2) of the first RoI
+        for sel in (None, "planes", "cells"):
+            with tuning.override(FRCNN_ROI_KERNEL=sel):
+                y, am = rt.roi_pool_fwd(dev(rt, x[0]), dev(rt, rois), 7, 7, 0.0625, want_argmax=True)
+                assert np.array_equal(host(rt, y), want) and np.array_equal(host(rt, am), wam), (C, H, W, sel, "argmax form")
+                y2 = rt.roi_pool_fwd(dev(rt, x[0]), dev(rt, rois), 7, 7, 0.0625)
+                assert np.array_equal(host(rt, y2), want), (C, H, W, sel)
+        y4, am4 = rt.roi_pool_fwd_hwc(rt.chw_to_hwc(dev(rt, x[0])), C, H, W, dev(rt, rois), 7, 7, 0.0625, want_argmax=True)
+        assert np.array_equal(host(rt, y4), want) and np.array_equal(host(rt, am4), wam)
+        if W <= 64 and hasattr(rt, "roi_pool_fwd_chw_bf16"):
+            _, want_bits = to_bf16(want.reshape(len(rois), -1))
+            y5 = host(rt, rt.roi_pool_fwd_chw_bf16(dev(rt, x[0]), dev(rt, np.ascontiguousarray(rois[:, 1:])), 7, 7, 0.0625))
+            assert np.array_equal(y5.view(np.uint16), want_bits.view(np.uint16).reshape(y5.shape))
+            xb = to_bf16(x)[0]
+            got = host(rt, rt.roi_pool_fwd_blk_bf16(rt.bf16_from_nchw(dev(rt, xb)), C, dev(rt, rois[:, 1:].copy()), 7, 7, 0.0625))
+            assert np.array_equal(got, O.roi_pooling_2d(xb, rois, 7, 7, 0.0625))
+
+
 def check_roi_pool_cells(rt):
     """The cell-major inference kernel (maps up to 76 x 64): ragged channel counts, non-7x7 outputs, the tall-map instantiation,
     RoIs larger than the bin tables, and the oracle's NaN rule -- a NaN in a bin's FIRST cell stays, NaNs elsewhere never win."""

@@ -87,6 +87,10 @@ def test_proposals_repeatable(rt):
         assert all(np.array_equal(u, v) for u, v in zip(a, b))
 
 
+def test_roi_pool_extreme_rois(rt):
+    P.check_roi_pool_extreme_rois(rt)
+
+
 def test_roi_pool_cells_kernel(rt):
     P.check_roi_pool_cells(rt)
 

@@ -71,6 +71,10 @@ def test_nms_edge_goldens(rt):
     P.check_nms_edge_goldens(rt)
 
 
+def test_roi_pool_extreme_rois(rt):
+    P.check_roi_pool_extreme_rois(rt)
+
+
 def test_roi_pool_cells_kernel(rt):
     P.check_roi_pool_cells(rt)
 
