@@ -89,6 +89,10 @@ SIGNATURES = {
     "frcnn_f32_to_bf16": (_I, [_P, _S, _P, _P]),
     "frcnn_linear_bf16_workspace_bytes": (_S, [_I, _I, _I]),
     "frcnn_linear_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),
+    "frcnn_linear_bf16_tiled_bytes": (_S, [_I, _I]),
+    "frcnn_linear_bf16_tile_w": (_I, [_P, _I, _I, _P, _P]),
+    "frcnn_linear_bf16_tiled_workspace_bytes": (_S, [_I, _I, _I]),
+    "frcnn_linear_bf16_tiled": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_softmax_channels_f32": (_I, [_P, _I, _I, _P, _P]),
     "frcnn_rpn_heads_bf16": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "frcnn_im2col7x7s2_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),

@@ -132,6 +132,21 @@ __device__ __forceinline__ void frcnn_buf_load_lds_b128(frcnn_buf_t b, void *lds
                  : "memory", "m0");
 #endif
 }
+// same with the non-temporal policy (`nt`) on the read: for a stream that ONE workgroup reads ONCE (the FC weight tiles of linear_bf16.hip) -- the lines
+// are not kept in the L2 for a second reader that never comes (MI355X_MICROARCH.md row "nt-weights": issued -> landed -18 %); never for operands other
+// workgroups re-read from the L2
+__device__ __forceinline__ void frcnn_buf_load_lds_b128_nt(frcnn_buf_t b, void *lds_wave_base, uint32_t byte_off, uint32_t soff) {
+    const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_wave_base;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen nt lds"
+                 :
+                 : "s"(la), "v"(byte_off), "s"(b), "s"(soff)
+                 : "memory", "m0");
+}
+// 4-byte store with a cache policy (16 = sc1: write-through -- a split-K slab drains while the other workgroups are still multiplying, not after the last wave)
+template <int AUX>
+__device__ __forceinline__ void frcnn_buf_store_f32_aux(frcnn_buf_t b, uint32_t byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), b, (int)byte_off, 0, AUX);
+}
 // same, 4 bytes per lane: 256 B per wave-instruction at lds_wave_base + 4 * lane
 __device__ __forceinline__ void frcnn_buf_load_lds_b32(frcnn_buf_t b, void *lds_wave_base, uint32_t byte_off, uint32_t soff) {
     const uint32_t la = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)lds_wave_base;

@@ -12,6 +12,7 @@ import os
 import numpy as np
 
 from ..chainer_compat import Variable, is_variable, kind, unwrap
+from .. import tuning
 from ..runtime import default_runtime
 from .region_proposal_network import RegionProposalNetwork
 from .vgg16 import VGG16Prev
@@ -37,6 +38,10 @@ class Linear(object):
     def refresh_bf16(self):
         if self.dtype == "bf16":
             self.Wb = self.rt.to_bf16(self.W)              # raw bf16 bits, (out, in): K-contiguous for the MFMA B operand
+            # the weight-stream layout of csrc/linear_bf16.hip (8 KB tiles = the kernel's LDS image), once per load; FRCNN_LINEAR_BF16=dma keeps the
+            # round-5 kernel on the row-major bits (A/B)
+            K = int(np.prod(self.W.shape[1:]))
+            self.Wt = self.rt.linear_bf16_tile_w(self.Wb) if (K % 32 == 0 and tuning.get("FRCNN_LINEAR_BF16") != "dma") else None
         elif self.dtype == "f32s":
             self.Ws = self.rt.f32s_split(self.W)           # the three bf16 terms of every fp32 weight, (3, out, in)
 
@@ -44,6 +49,8 @@ class Linear(object):
         return self.rt.linear(x, self.W, self.b, relu=relu)
 
     def bf16(self, x_bits, relu=False, out_bf16=False):
+        if getattr(self, "Wt", None) is not None:
+            return self.rt.linear_bf16_tiled(x_bits, self.Wt, int(self.W.shape[0]), self.b, relu=relu, out_bf16=out_bf16)
         return self.rt.linear_bf16(x_bits, self.Wb, self.b, relu=relu, out_bf16=out_bf16)
 
     def f32s(self, x_parts, relu=False, out_split=False):

@@ -697,6 +697,28 @@ class Runtime(object):
                                        ws.shape[0], m.stream()), "frcnn_linear_bf16")
         return y
 
+    def linear_bf16_tile_w(self, w_bits):
+        """(N, K) bf16 bits -> the weight-stream layout of frcnn_linear_bf16_tiled (8 KB tiles [ceil(N/128)][K/32], the kernel's swizzled LDS image);
+        once, at load time.  K % 32 == 0."""
+        m, L = self.mem, self.lib
+        N, K = int(w_bits.shape[0]), int(np.prod(w_bits.shape[1:]))
+        nbytes = L.frcnn_linear_bf16_tiled_bytes(N, K)
+        if nbytes == 0:
+            raise ValueError("frcnn_linear_bf16_tile_w: K = %d is not a multiple of 32" % K)
+        wt = m.empty((nbytes // 2,), "i16")
+        _lib.check(L.frcnn_linear_bf16_tile_w(m.ptr(w_bits), N, K, m.ptr(wt), m.stream()), "frcnn_linear_bf16_tile_w")
+        return wt
+
+    def linear_bf16_tiled(self, x, w_tiled, N, bias, relu=False, out_bf16=False):
+        """x (M,K) bf16 bits, w_tiled = linear_bf16_tile_w of the (N,K) weights, bias (N,) fp32 -> (M,N) fp32 (or bf16 bits)."""
+        m, L = self.mem, self.lib
+        M, K = int(x.shape[0]), int(np.prod(x.shape[1:]))
+        y = m.empty((M, N), "i16" if out_bf16 else "f32")
+        ws = self.workspace("linear", L.frcnn_linear_bf16_tiled_workspace_bytes(M, N, K))
+        _lib.check(L.frcnn_linear_bf16_tiled(m.ptr(x), m.ptr(w_tiled), m.ptr(bias), m.ptr(y), M, N, K, int(bool(relu)), int(bool(out_bf16)), m.ptr(ws),
+                                             ws.shape[0], m.stream()), "frcnn_linear_bf16_tiled")
+        return y
+
     def rpn_heads_bf16(self, h_blk, w_packed, bias, cmid, A):
         """h_blk [CmidP/16][H][W][16] bf16, stacked bf16-packed 1x1 weights, (6A,) fp32 bias -> (rpn_cls_score (1,2A,H,W),
         rpn_cls_prob (1,2A,H,W), rpn_bbox_pred (1,4A,H,W)) fp32: both heads and the softmax in one launch."""

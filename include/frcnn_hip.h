@@ -361,6 +361,17 @@ int frcnn_f32_to_bf16(const float *x, size_t n, uint16_t *y, void *stream);
 size_t frcnn_linear_bf16_workspace_bytes(int M, int N, int K);
 int frcnn_linear_bf16(const uint16_t *x, const uint16_t *w, const float *bias, void *y, int M, int N, int K, int relu,
                       int out_bf16, void *workspace, size_t workspace_bytes, void *stream);
+/* The same layer as a WEIGHT STREAM (ABI v23; csrc/linear_bf16.hip) -- L.Linear of /root/reference/models/faster_rcnn.py:33-36,127-134 on the bf16 line:
+ * the (N, K) bf16 weight matrix is re-tiled ONCE at load time (frcnn_linear_bf16_tile_w) into 8 KB tiles [ceil(N/128)][K/32] that are the kernel's
+ * swizzled LDS image of a 128-row x 32-k weight panel (rows past N zero), so the GEMM reads each weight byte once, as contiguous 8 KB runs, through a
+ * five-stage LDS-DMA ring; all M <= 320 rows of x sit in one workgroup.  K % 32 == 0 (FRCNN_ERR_INVALID otherwise); tensors behind a 32-bit buffer
+ * descriptor: M*K*2 and the tiled bytes below 2 GiB (FRCNN_ERR_UNSUPPORTED beyond).  Same products, fp32 accumulation, bias / ReLU / output forms as
+ * frcnn_linear_bf16; split-K partial sums are added in split order (deterministic). */
+size_t frcnn_linear_bf16_tiled_bytes(int N, int K);
+int frcnn_linear_bf16_tile_w(const uint16_t *w, int N, int K, uint16_t *w_tiled, void *stream);
+size_t frcnn_linear_bf16_tiled_workspace_bytes(int M, int N, int K);
+int frcnn_linear_bf16_tiled(const uint16_t *x, const uint16_t *w_tiled, const float *bias, void *y, int M, int N, int K, int relu,
+                            int out_bf16, void *workspace, size_t workspace_bytes, void *stream);
 /* softmax over the channel axis of a (n_ch, H*W) fp32 map: the reference's F.softmax(rpn_cls_score) (region_proposal_network.py:119) */
 int frcnn_softmax_channels_f32(const float *score, int n_ch, int HW, float *prob, void *stream);
 

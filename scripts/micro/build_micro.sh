@@ -17,6 +17,10 @@ mkdir -p scripts/micro/_bin
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DFRCNN_TIMING_ABLATIONS -I include -I chainer-faster-rcnn_amd/csrc -shared chainer-faster-rcnn_amd/csrc/roi_pool.hip chainer-faster-rcnn_amd/csrc/abi.hip -o scripts/micro/_bin/libroi_abl.so
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip scripts/micro/roi_micro.cpp -I include -L scripts/micro/_bin -lroi_abl -Wl,-rpath,'$ORIGIN' -o scripts/micro/_bin/roi_micro_abl
 
+# timing-ablation build of linear_bf16.hip alone (FRCNN_LINEAR_RING_ABL is honoured; WRONG results by design) + the same harness against it ("new" only)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -w -DFRCNN_TIMING_ABLATIONS -I include -I chainer-faster-rcnn_amd/csrc -shared chainer-faster-rcnn_amd/csrc/linear_bf16.hip chainer-faster-rcnn_amd/csrc/abi.hip -o scripts/micro/_bin/liblinear_abl.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip -DLINEAR_MICRO_NEW_ONLY scripts/micro/linear_bf16_micro.cpp -I include -L scripts/micro/_bin -llinear_abl -Wl,-rpath,'$ORIGIN' -o scripts/micro/_bin/linear_bf16_micro_abl
+
 # full research build of the library for the conv micro-benchmarks: opt-in.  -DFRCNN_TUNING_FORMS adds the measured-and-not-adopted kernel forms the product
 # library no longer carries; -DFRCNN_TIMING_ABLATIONS the timing ablations (WRONG results by design)
 if [ "${MICRO_ABL_LIB:-0}" = "1" ]; then

@@ -63,6 +63,8 @@ static inline void frcnn_buf_load_lds_b128(frcnn_buf_t b, void *lds_wave_base, u
         if ((uint64_t)off + 4 * k + 4 <= b.bytes) memcpy(&v[k], b.base + off + soff + 4 * k, 4);
     hipemu::dma_deposit((char *)lds_wave_base + 16 * (threadIdx.x & 63), v, 16);       // lands now, or at the covering wait (HIPEMU_DMA_DEFER=1)
 }
+static inline void frcnn_buf_load_lds_b128_nt(frcnn_buf_t b, void *lds_wave_base, uint32_t off, uint32_t soff) { frcnn_buf_load_lds_b128(b, lds_wave_base, off, soff); }
+template <int AUX> static inline void frcnn_buf_store_f32_aux(frcnn_buf_t b, uint32_t off, float v) { frcnn_buf_store_f32(b, off, v); }
 static inline void frcnn_buf_load_lds_b32(frcnn_buf_t b, void *lds_wave_base, uint32_t off, uint32_t soff) {
     float v = 0.0f;
     if ((uint64_t)off + 4 <= b.bytes) memcpy(&v, b.base + off + soff, 4);

@@ -1164,6 +1164,33 @@ def check_linear_bf16(rt, M, N, K, relu, seed=0):
     assert np.all(np.abs(y16 - want) <= np.abs(want) * 2.0 ** -8 + 3e-5 * np.abs(want).max())
 
 
+def check_linear_bf16_tiled(rt, M, N, K, relu, seed=0):
+    """frcnn_linear_bf16_tiled (csrc/linear_bf16.hip: the weight-stream kernel on pre-tiled weights) against the oracle fed the same bf16 operands, and
+    against frcnn_linear_bf16 on the row-major weights (same products, fp32 accumulation; the split boundaries differ, so not bit for bit)."""
+    rs = np.random.RandomState(seed)
+    x = rs.randn(M, K).astype(np.float32)
+    w = (rs.randn(N, K) / np.sqrt(K)).astype(np.float32)
+    b = rs.randn(N).astype(np.float32) * 0.1
+    xb, _ = to_bf16(x)
+    wb, wbits = to_bf16(w)
+    want = O.linear(xb, wb, b)
+    if relu:
+        want = O.relu(want)
+    wt = rt.linear_bf16_tile_w(rt.to_bf16(dev(rt, w)))
+    # the tile layout itself: tile (nb, kc), 16-byte slot row * 4 + (g ^ ((row >> 2) & 3)) = w[nb * 128 + row][kc * 32 + 8 g ..]
+    t = host(rt, wt).view(np.uint16).reshape(-1, K // 32, 128, 4, 8)
+    nb, kc, row, g = (N - 1) // 128, (K // 32) - 1, (N - 1) % 128, 2
+    assert np.array_equal(t[nb, kc, row, g ^ ((row >> 2) & 3)], wbits.view(np.uint16)[N - 1, kc * 32 + 8 * g: kc * 32 + 8 * g + 8])
+    if N % 128:
+        assert not t[nb, :, N % 128:].any()                                 # rows past N are zero
+    y = host(rt, rt.linear_bf16_tiled(rt.to_bf16(dev(rt, x)), wt, N, dev(rt, b), relu=relu))
+    assert y.shape == want.shape and np.abs(y - want).max() <= 3e-5 * max(np.abs(want).max(), 1e-6), np.abs(y - want).max()
+    y0 = host(rt, rt.linear_bf16(rt.to_bf16(dev(rt, x)), rt.to_bf16(dev(rt, w)), dev(rt, b), relu=relu))
+    assert np.abs(y - y0).max() <= 2e-5 * max(np.abs(want).max(), 1e-6)
+    y16 = from_bf16_bits(host(rt, rt.linear_bf16_tiled(rt.to_bf16(dev(rt, x)), wt, N, dev(rt, b), relu=relu, out_bf16=True)))
+    assert np.all(np.abs(y16 - want) <= np.abs(want) * 2.0 ** -8 + 3e-5 * np.abs(want).max())
+
+
 def check_linear_f32s(rt, M, N, K, relu, seed=0):
     """fp32 L.Linear on split tensors: against a float64 product (next to the native fp32 kernel), the split output form, and the
     split / join conversions."""

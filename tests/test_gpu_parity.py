@@ -16,7 +16,7 @@ def rt():
 
 
 def test_library_is_the_device_build(rt):
-    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 22
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 23
 
 
 def test_nms_golden(rt):
@@ -477,6 +477,16 @@ def test_linear_bf16(rt):
     P.check_linear_bf16(rt, 300, 4096, 4096, True)       # fc7
     P.check_linear_bf16(rt, 300, 84, 4096, False)        # bbox_pred
     P.check_linear_bf16(rt, 17, 33, 104, False)
+
+
+def test_linear_bf16_tiled(rt):
+    """The weight-stream kernel on pre-tiled weights (csrc/linear_bf16.hip), the bf16 line's default head."""
+    P.check_linear_bf16_tiled(rt, 300, 4096, 25088, True)      # fc6
+    P.check_linear_bf16_tiled(rt, 300, 4096, 4096, True)       # fc7
+    P.check_linear_bf16_tiled(rt, 300, 116, 4096, False)       # cls_score || bbox_pred, stacked
+    P.check_linear_bf16_tiled(rt, 128, 4096, 4096, True, seed=2)   # the stage-2 backward's row count: MT 3
+    P.check_linear_bf16_tiled(rt, 17, 33, 96, False)
+    P.check_linear_bf16_tiled(rt, 700, 256, 32 * 40, False, seed=3)  # three row blocks
 
 
 @pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 120, 200), (128, 128, 60, 100), (256, 256, 150, 250), (512, 512, 75, 125)])
