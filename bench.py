@@ -76,8 +76,8 @@ def pmc_traffic(dtype):
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     cands = {"f32": ["r05_hbm_traffic_pmc.json", "r04_hbm_traffic_pmc.json", "r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"],
              "bf16": ["r05_hbm_traffic_pmc_bf16.json", "r04_hbm_traffic_pmc_bf16.json", "r03_hbm_traffic_pmc_bf16.json", "r02_hbm_traffic_pmc_bf16.json"],
-             "f32s": ["r03_hbm_traffic_pmc_f32s.json", "r02_hbm_traffic_pmc_f32s.json"]}[dtype]
-    kernel = {"f32": "conv_mfma_f32_kernel", "bf16": "conv_bf16_kernel", "f32s": "conv_f32s_kernel"}[dtype]
+             "f32s": ["r03_hbm_traffic_pmc_f32s.json", "r02_hbm_traffic_pmc_f32s.json"], "f16": []}[dtype]      # (no PMC pass of the fp16 twins: same kernels, same bytes as bf16)
+    kernel = {"f32": "conv_mfma_f32_kernel", "bf16": "conv_bf16_kernel", "f32s": "conv_f32s_kernel", "f16": "conv_bf16_kernel"}[dtype]
     for name in cands:
         path = os.path.join(prof, name)
         if not os.path.exists(path):
@@ -375,7 +375,8 @@ def graph_time_us(torch, fn, launches_per_replay, replays):
 
 
 def f32s_conv_chain(rt, model, x, bf16=False):
-    """The 14 convolution launches of the f32s (or bf16) model: first layer straight from the fp32 image, fused pools, rpn_conv_3x3."""
+    """The 14 convolution launches of the f32s (or bf16 / f16) model: first layer straight from the fp32 image, fused pools, rpn_conv_3x3."""
+    rt = model.rt                                  # the model's own runtime: an fp16 model computes its 16-bit chain through the *_f16* entry points
     def chain():
         tr_ = model.trunk
         h, n_l = None, len(tr_.layers)
@@ -885,8 +886,9 @@ def main():
                     help="replay the forward as ONE captured hipGraph in the timed region (auto = on: the ~45 launches of a bf16 step are "
                          "shorter than the host can issue them, and the f32 step, GPU-bound in eager mode on a quiet host, lost up to "
                          "10 % of wall clock to host jitter on some boxes; off = eager launches)")
-    ap.add_argument("--dtype", choices=["f32", "f32s", "bf16"], default="f32",
-                    help="f32 = BASELINE.json configs[1] (the contract line); bf16 = configs[2]: bf16 convolutions, fp32 RoI / head")
+    ap.add_argument("--dtype", choices=["f32", "f32s", "bf16", "f16"], default="f32",
+                    help="f32 = BASELINE.json configs[1] (the contract line); bf16 = configs[2]: bf16 convolutions, fp32 RoI / head; f16 = the fp16 instantiation of the "
+                         "same 16-bit chain (north_star: fp16/bf16 accumulate fp32): same kernels and rate, 10 mantissa bits")
     ap.add_argument("--dist-world1", action="store_true",
                     help="with one rank: still create the process group (nccl = RCCL) and run every collective of the N > 1 path through it")
     ap.add_argument("--dropout-rng", choices=["device", "numpy"], default="device",
@@ -1031,7 +1033,7 @@ def main():
         # (301 MB > the 256 MB Infinity Cache, so the writes cannot all be absorbed on-die)
         try:
             feat = model.trunk(x)
-            _, _, prob, bbox = model.RPN.heads(feat, want_score=False, x_bf16=getattr(model.trunk, "feat_bf16", None) if args.dtype == "bf16" else None,
+            _, _, prob, bbox = model.RPN.heads(feat, want_score=False, x_bf16=getattr(model.trunk, "feat_bf16", None) if args.dtype in ("bf16", "f16") else None,
                                                x_split=getattr(model.trunk, "feat_split", None) if args.dtype == "f32s" else None)
             rois, _, _ = model.RPN.proposal_layer.forward_device(prob, bbox, IM_H, IM_W)
             outs = [rt.mem.empty((int(rois.shape[0]), 512, 7, 7), "f32") for _ in range(10)]
@@ -1092,7 +1094,10 @@ def main():
                                        "(BASELINE.json configs[1]); the 14 3x3 convolutions and the 4 fully connected layers run as six bf16 MFMA products of "
                                        "3-way split fp32 operands with fp32 accumulation (dropped terms < 2^-24 of a product)") if args.dtype == "f32s" else
                                       ("VGG16 inference, data-parallel 1 img/GPU, bf16 convs + bf16 FC head (fp32 accumulate) / fp32 proposals, "
-                                       "RoI pooling, decode (BASELINE.json configs[2])"),
+                                       "RoI pooling, decode (BASELINE.json configs[2])") if args.dtype == "bf16" else
+                                      ("VGG16 inference, data-parallel 1 img/GPU, fp16 convs + fp16 FC head (fp32 accumulate) / fp32 proposals, RoI pooling, decode: "
+                                       "BASELINE.json configs[2]'s 16-bit chain in its fp16 instantiation (north_star: fp16/bf16 accumulate fp32; the same kernels compiled "
+                                       "with v_mfma_f32_32x32x16_f16: csrc/conv_f16.hip)"),
                           "image": "1x3x600x1000", "global_batch": world, "launch": "hipGraph replay" if use_graph else "eager", "parallelism": "dp%d (images sharded, no collective)" % world,
                           "n_rois_last_step": n_rois, "ranks_share_gpus": shared_note,
                           "timed_region": ("K replays of ONE captured hipGraph of the whole forward (image -> cls_prob / boxes) on ONE image already resident in HBM: "
@@ -1125,7 +1130,7 @@ def main():
                                            "bf16 conv chain: conv1_f32s_kernel + conv_dma_bf16_kernel / conv_strip_bf16_kernel, 14 launches/image")),
                                "algorithmic_tflops": alg_tf,
                                "algorithmic_gflop_per_image": sum(flops.values()) / 1e9, "conv_ms_per_image": conv_ms, "conv_ms_source": conv_src,
-                               "algorithmic_bytes_per_launch": sum(conv_algorithmic_bytes(LAYERS, IM_H, IM_W, {"f32": 4, "f32s": 6, "bf16": 2}[args.dtype]).values()) / 14.0}
+                               "algorithmic_bytes_per_launch": sum(conv_algorithmic_bytes(LAYERS, IM_H, IM_W, {"f32": 4, "f32s": 6, "bf16": 2, "f16": 2}[args.dtype]).values()) / 14.0}
             if args.dtype == "f32s":
                 res["roofline"]["note"] = ("achieved / peak count the bf16 MFMA flops executed (6 per algorithmic product) against the dense bf16 peak; "
                                            "algorithmic_tflops is the fp32 convolution work per second (fp32 MFMA peak: %.1f)" % PEAK_F32_MFMA_TFLOPS)
@@ -1163,7 +1168,7 @@ def main():
             try:
                 from oracle import parity
                 info = np.array([[IM_H, IM_W]], dtype=np.int32)
-                tol = 3e-2 if args.dtype == "bf16" else 1e-3
+                tol = 3e-2 if args.dtype == "bf16" else (4e-3 if args.dtype == "f16" else 1e-3)
                 rep = parity.compare_forward(params, info, dbg, parity.device_forward_host(rt, model, x, IM_H, IM_W), layer_tol=tol, head_tol=tol)
                 rep["against"] = "the cpu_baseline forward of this run (same image, same weights); /root/reference/forward.py:92-94"
                 res["parity"] = rep

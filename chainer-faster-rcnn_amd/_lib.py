@@ -95,6 +95,26 @@ SIGNATURES = {
     "frcnn_linear_bf16_tiled": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_softmax_channels_f32": (_I, [_P, _I, _I, _P, _P]),
     "frcnn_rpn_heads_bf16": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    # the fp16 twins of the 16-bit chain (csrc/conv_f16.hip ...): same signatures
+    "frcnn_f16_to_nchw_f32": (_I, [_P, _I, _I, _I, _P, _P]),
+    "frcnn_f16_padded_channels": (_I, [_I]),
+    "frcnn_f16_pack_conv_w": (_I, [_P, _I, _I, _I, _P, _P]),
+    "frcnn_f16_from_nchw_f32": (_I, [_P, _I, _I, _I, _P, _P]),
+    "frcnn_conv_f16_workspace_bytes": (_S, [_I, _I, _I, _I]),
+    "frcnn_conv_f16_workspace_init": (_I, [_P, _S, _P]),
+    "frcnn_conv_f16_ws": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _S, _P]),
+    "frcnn_rpn_heads_f16": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "frcnn_conv_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "frcnn_conv_f16_plan": (_I, [_I, _I, _I, _I, _I, _I]),
+    "frcnn_maxpool2x2_f16": (_I, [_P, _P, _I, _I, _I, _P]),
+    "frcnn_f32_to_f16": (_I, [_P, _S, _P, _P]),
+    "frcnn_linear_f16_workspace_bytes": (_S, [_I, _I, _I]),
+    "frcnn_linear_f16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),
+    "frcnn_conv1_pair_f16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "frcnn_linear_f16_tiled_bytes": (_S, [_I, _I]),
+    "frcnn_linear_f16_tile_w": (_I, [_P, _I, _I, _P, _P]),
+    "frcnn_linear_f16_tiled_workspace_bytes": (_S, [_I, _I, _I]),
+    "frcnn_linear_f16_tiled": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_im2col7x7s2_f32": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "frcnn_maxpool3x3s2_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "frcnn_subsample2_f32": (_I, [_P, _P, _I, _I, _I, _P]),

@@ -78,7 +78,7 @@ const char *frcnn_tune(const char *key) {
 
 extern "C" {
 
-int frcnn_abi_version(void) { return 23; }
+int frcnn_abi_version(void) { return 24; }
 
 int frcnn_device_count(void) {
     int n = 0;

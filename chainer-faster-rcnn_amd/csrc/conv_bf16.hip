@@ -42,9 +42,9 @@ __device__ __forceinline__ uint32_t bf16x2_max4(uint32_t a, uint32_t b, uint32_t
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
         const int sh = 16 * hh;
-        const float fa = __uint_as_float((a >> sh) << 16), fb = __uint_as_float((b >> sh) << 16);
-        const float fc = __uint_as_float((c >> sh) << 16), fd = __uint_as_float((d >> sh) << 16);
-        r |= ((__float_as_uint(fmaxf(fmaxf(fa, fb), fmaxf(fc, fd))) >> 16) & 0xffffu) << sh;
+        const float fa = frcnn_h16_to_f32((uint16_t)(a >> sh)), fb = frcnn_h16_to_f32((uint16_t)(b >> sh));
+        const float fc = frcnn_h16_to_f32((uint16_t)(c >> sh)), fd = frcnn_h16_to_f32((uint16_t)(d >> sh));
+        r |= frcnn_f32_to_h16_exact(fmaxf(fmaxf(fa, fb), fmaxf(fc, fd))) << sh;
     }
     return r;
 }
@@ -621,7 +621,7 @@ nchw_to_nhwc_bf16_kernel(const float *__restrict__ x, int C, int HW, int CP, uin
     }
 }
 
-__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return frcnn_h16_to_f32(h); }
 
 // F.MaxPooling2D(2, 2), cover_all, channel-blocked bf16 [C/16][H][W][16]: one thread = one output pixel x 8 channels (16 bytes)
 __global__ void __launch_bounds__(256)

@@ -29,6 +29,20 @@ __device__ __forceinline__ uint32_t frcnn_wave_or_u32(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
 
+// The 16-bit operand format of the translation unit.  Default: bf16.  A TU compiled with FRCNN_HALF_F16 (conv_f16.hip, conv_f16_pair.hip, linear_f16.hip: the SAME
+// kernel sources included under frcnn_f16_names.h, which renames their entry points *_bf16* -> *_f16*) is the fp16 instantiation of the 16-bit chain that
+// north_star allows ("fp16/bf16 accumulate fp32"): same layouts, same LDS-DMA, same MFMA rate (v_mfma_f32_32x32x16_f16), 10 mantissa bits instead of 7.  In such a
+// TU the three helpers below -- pack, widen, MFMA -- are the fp16 ones; "bf16" in their names (and in the kernels' names) then reads "the TU's 16-bit format".
+// This is a dtype instantiation of one gfx950 code path, not a platform switch.  fp16 has 5 exponent bits: |v| > 65504 rounds to Inf (bf16 keeps fp32's range).
+#ifdef FRCNN_HALF_F16
+__device__ __forceinline__ uint32_t frcnn_pack_bf16x2(float lo, float hi) {            // two fp32 -> two fp16, round to nearest even (v_cvt_pk_f16_f32); `lo` in bits 0-15
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ float frcnn_h16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }     // exact (v_cvt_f32_f16)
+#else
 // v_cvt_pk_bf16_f32: two fp32 -> two bf16 (round to nearest even) in ONE instruction; `lo` lands in bits 0-15.  (The software
 // form -- add 0x7fff + lsb, shift -- is ~8 VALU instructions per value: 2 M of the 6.7 M VALU instructions of the bf16-output RoI
 // kernel, r02 counters.)
@@ -38,6 +52,10 @@ __device__ __forceinline__ uint32_t frcnn_pack_bf16x2(float lo, float hi) {
     const f32x2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ float frcnn_h16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }          // bf16 is the top half of an fp32
+#endif
+// the 16 bits of a value that IS representable in the TU's 16-bit format (a maximum of such values): no rounding happens
+__device__ __forceinline__ uint32_t frcnn_f32_to_h16_exact(float v) { return frcnn_pack_bf16x2(v, 0.0f) & 0xffffu; }
 
 // v_max3_f32: max(max(a, b), c) with the same NaN rule, one instruction for two updates of a running maximum
 __device__ __forceinline__ float frcnn_max3_f32(float a, float b, float c) {
@@ -51,8 +69,13 @@ __device__ __forceinline__ float frcnn_max3_f32(float a, float b, float c) {
 // 32x32 map (register r of lane l = row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31).
 typedef float frcnn_f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ frcnn_f32x16 frcnn_mfma_32x32x16_bf16(uint4 a, uint4 b, frcnn_f32x16 c) {
+#ifdef FRCNN_HALF_F16
+    typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));                       // v_mfma_f32_32x32x16_f16: same shape, same rate, fp16 operands
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, a), __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+#else
     typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+#endif
 }
 
 // v_alignbit_b32: bits [sh+31 : sh] of the 64-bit value hi:lo
@@ -63,6 +86,7 @@ __device__ __forceinline__ void frcnn_pin(float4 &v) { asm volatile("" : "+v"(v.
 __device__ __forceinline__ void frcnn_pin(float &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ uint32_t frcnn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 
+#ifndef FRCNN_HALF_F16      // (the split tensors of conv_f32s.hip are bf16 by construction)
 // (v0, v1) -> the three packed bf16 pairs (h, m, l) with h + m + l == v exactly (round to nearest even at every step; the
 // differences are exact in fp32): the "split tensors" of conv_f32s.hip.  PRECONDITION: |v| finite and below the largest bf16
 // (3.39e38): for +-Inf, or a value whose bf16 rounding overflows, h is Inf and the lower terms are NaN (Inf - Inf), i.e. an overflowed
@@ -74,6 +98,7 @@ __device__ __forceinline__ void frcnn_split3_pair(float v0, float v1, uint32_t &
     m = frcnn_pack_bf16x2(d0, d1);
     l = frcnn_pack_bf16x2(d0 - __uint_as_float(m << 16), d1 - __uint_as_float(m & 0xffff0000u));
 }
+#endif
 
 
 // DPP quad_perm [1,0,3,2]: every lane receives the value of lane ^ 1 -- one VALU instruction (a __shfl_xor may go through the LDS crossbar)

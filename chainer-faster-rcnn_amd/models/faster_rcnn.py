@@ -70,6 +70,15 @@ class FasterRCNN(object):
         fp32 layers computed as six bf16 MFMA products of 3-way split fp32 operands, fp32 accumulation (csrc/conv_f32s.hip) -- fp32
         tensors and fp32-class results on the bf16 matrix cores."""
         self.rt = runtime or default_runtime()
+        # "f16" (either): the 16-bit chain's fp16 instantiation (north_star: "fp16/bf16 accumulate fp32"; csrc/conv_f16.hip ...) -- the same layouts, kernels and
+        # schedule as "bf16" with 10-bit-mantissa operands: the model runs its bf16 code path on a runtime whose *_bf16 methods resolve to the *_f16* entry points.
+        self.half = "f16" if "f16" in (conv_dtype, head_dtype) else "bf16"
+        if self.half == "f16":
+            if "bf16" in (conv_dtype, head_dtype):
+                raise ValueError("conv_dtype / head_dtype: one 16-bit format per model (bf16 or f16)")
+            self.rt = self.rt.with_half("f16")
+            conv_dtype = "bf16" if conv_dtype == "f16" else conv_dtype
+            head_dtype = "bf16" if head_dtype == "f16" else head_dtype
         self.conv_dtype, self.head_dtype = conv_dtype, head_dtype
         self.trunk = trunk_class(runtime=self.rt, conv_dtype=conv_dtype) if conv_dtype != "f32" else trunk_class(runtime=self.rt)
         self.RPN = RegionProposalNetwork(rpn_in_ch, rpn_mid_ch, feat_stride, anchor_ratios, anchor_scales, num_classes,

@@ -177,11 +177,38 @@ class TorchDeviceMemory(object):
         return {v: k for k, v in self._dt.items()}[t.dtype]
 
 
+class _HalfLib(object):
+    """The library seen through a 16-bit operand format: with half == "f16" every *_bf16* entry point resolves to its *_f16* twin (csrc/conv_f16.hip,
+    conv_f16_pair.hip, linear_f16.hip: the same kernel sources compiled with fp16 pack / widen / MFMA; include/frcnn_hip.h).  The RoI-pooling and first-layer
+    entries have no fp16 twin: asking for one raises AttributeError, and the Runtime methods that use them compose the documented detour instead."""
+
+    def __init__(self, lib, half):
+        self._lib, self._half = lib, half
+
+    def __getattr__(self, name):
+        if self._half == "f16" and "bf16" in name:
+            return getattr(self._lib, name.replace("bf16", "f16"))
+        return getattr(self._lib, name)
+
+
 class Runtime(object):
-    def __init__(self, lib, mem):
+    def __init__(self, lib, mem, half="bf16"):
         self.lib = lib
         self.mem = mem
         self._ws = {}
+        assert half in ("bf16", "f16")
+        self.half = half                       # the 16-bit operand format the *_bf16 methods below compute in
+        self.hlib = _HalfLib(lib, half)
+
+    def with_half(self, half):
+        """The same runtime (library, memory, workspaces) computing its 16-bit chain in `half` ("bf16" or "f16"): the *_bf16 methods of the returned object
+        call the *_f16* entry points when half == "f16"; arrays of raw 16-bit values then hold IEEE binary16 bits."""
+        if half == self.half:
+            return self
+        r = Runtime.__new__(type(self))
+        r.__dict__.update(self.__dict__)
+        r.half, r.hlib = half, _HalfLib(self.lib, half)
+        return r
 
     # ------------------------------------------------------------------ helpers
     def workspace(self, tag, nbytes, init=None):
@@ -288,6 +315,8 @@ class Runtime(object):
 
     def roi_pool_fwd_chw_bf16(self, x, rois, outh, outw, scale):
         """The same pooling with the result written as raw bf16 bits, flattened (R, C*outh*outw): the bf16 FC head's input."""
+        if self.half == "f16":                 # include/frcnn_hip.h: pool in fp32, one rounding to fp16
+            return self.to_bf16(self.roi_pool_fwd_chw(x, rois, outh, outw, scale).reshape(int(rois.shape[0]), -1))
         m, L = self.mem, self.lib
         C, H, W = [int(v) for v in x.shape[-3:]]
         R = int(rois.shape[0])
@@ -299,6 +328,9 @@ class Runtime(object):
     def roi_pool_fwd_blk_bf16(self, x_blk, C, rois, outh, outw, scale, out_bf16=False):
         """RoI pooling straight from the bf16 chain's channel-blocked map [CP/16][H][W][16] -> (R, C, outh, outw) fp32, or raw bf16
         bits (R, C*outh*outw) for the bf16 FC head.  Maps up to 76 x 64 (the cell-major kernel's LDS image)."""
+        if self.half == "f16":                 # the fp16 chain takes the documented detour: map as fp32 NCHW (exact), fp32 pooling, rounding-free conversion back
+            y32 = self.roi_pool_fwd_chw(self.bf16_to_nchw(x_blk, int(C)), rois, outh, outw, scale)
+            return self.to_bf16(y32.reshape(int(rois.shape[0]), -1)) if out_bf16 else y32
         m, L = self.mem, self.lib
         H, W = int(x_blk.shape[1]), int(x_blk.shape[2])
         R = int(rois.shape[0])
@@ -593,6 +625,8 @@ class Runtime(object):
 
     def conv1_bf16(self, x, w, bias, relu=True):
         """First layer of the bf16 chain: x (1,Cin<=3,H,W) fp32 NCHW, w (Cout<=64,Cin,3,3) fp32 -> [CoutP/16][H][W][16] bf16."""
+        if self.half == "f16":                 # no fp16 twin of the first-layer kernel (csrc/conv_f32s.hip): the generic convolution on the blocked image, Cin padded to 16
+            return self.conv_bf16(self.bf16_from_nchw(x), self.bf16_pack_conv_w(w, 3), bias, int(x.shape[-3]), int(w.shape[0]), 3, relu=relu)
         m, L = self.mem, self.lib
         cin, H, W = [int(v) for v in x.shape[-3:]]
         cout = int(w.shape[0])
@@ -603,7 +637,7 @@ class Runtime(object):
     def conv1_pair_bf16(self, x, w1, b1, w2_packed, b2):
         """conv1_1 + ReLU + conv1_2 + ReLU + 2x2 max-pool of the bf16 chain in one launch: x (1,Cin<=3,H,W) fp32 NCHW, w1 (64,Cin,3,3) fp32,
         w2_packed [4][9][64][16] bf16 -> [4][ceil(H/2)][ceil(W/2)][16] bf16."""
-        m, L = self.mem, self.lib
+        m, L = self.mem, self.hlib
         cin, H, W = [int(v) for v in x.shape[-3:]]
         assert int(w1.shape[0]) == 64 and int(w1.shape[1]) == cin and tuple(int(v) for v in w2_packed.shape) == (4, 9, 64, 16)
         y = m.empty((4, (H + 1) // 2, (W + 1) // 2, 16), "i16")
@@ -633,21 +667,21 @@ class Runtime(object):
         return (int(c) + 15) // 16 * 16
 
     def bf16_pack_conv_w(self, w, ksize=3):
-        m, L = self.mem, self.lib
+        m, L = self.mem, self.hlib
         co, ci = int(w.shape[0]), int(w.shape[1])
         wp = m.empty((self.bf16_pad(ci) // 16, ksize * ksize, self.bf16_pad(co), 16), "i16")
         _lib.check(L.frcnn_bf16_pack_conv_w(m.ptr(w), co, ci, int(ksize), m.ptr(wp), m.stream()), "frcnn_bf16_pack_conv_w")
         return wp
 
     def bf16_from_nchw(self, x):
-        m, L = self.mem, self.lib
+        m, L = self.mem, self.hlib
         C, H, W = [int(v) for v in x.shape[-3:]]
         y = m.empty((self.bf16_pad(C) // 16, H, W, 16), "i16")          # channel-blocked: [C/16][H][W][16]
         _lib.check(L.frcnn_bf16_from_nchw_f32(m.ptr(x), C, H, W, m.ptr(y), m.stream()), "frcnn_bf16_from_nchw_f32")
         return y
 
     def bf16_to_nchw(self, x, C):
-        m, L = self.mem, self.lib
+        m, L = self.mem, self.hlib
         H, W = int(x.shape[1]), int(x.shape[2])
         y = m.empty((1, int(C), H, W), "f32")
         _lib.check(L.frcnn_bf16_to_nchw_f32(m.ptr(x), int(C), H, W, m.ptr(y), m.stream()), "frcnn_bf16_to_nchw_f32")
@@ -655,7 +689,7 @@ class Runtime(object):
 
     def conv_bf16(self, x, w_packed, bias, cin, cout, ksize=3, relu=True, out_f32_nchw=False, pool=False):
         """x [CinP/16][H][W][16] bf16 -> [CoutP/16][H][W][16] bf16, or (1,Cout,H,W) fp32 when out_f32_nchw."""
-        m, L = self.mem, self.lib
+        m, L = self.mem, self.hlib
         H, W = int(x.shape[1]), int(x.shape[2])
         assert int(x.shape[0]) * 16 == self.bf16_pad(cin) and int(w_packed.shape[0]) * 16 == self.bf16_pad(cin)
         if pool:                                         # ReLU + 2x2 ceil-mode max-pool fused into the epilogue (out_mode 2)
@@ -671,7 +705,7 @@ class Runtime(object):
         return y
 
     def maxpool2x2_bf16(self, x):
-        m, L = self.mem, self.lib
+        m, L = self.mem, self.hlib
         CB, H, W = int(x.shape[0]), int(x.shape[1]), int(x.shape[2])
         C = CB * 16
         y = m.empty((CB, (H + 1) // 2, (W + 1) // 2, 16), "i16")
@@ -680,14 +714,14 @@ class Runtime(object):
 
     def to_bf16(self, x):
         """fp32 array -> raw bf16 bits (int16 array of the same shape), round to nearest even."""
-        m, L = self.mem, self.lib
+        m, L = self.mem, self.hlib
         y = m.empty(tuple(int(v) for v in x.shape), "i16")
         _lib.check(L.frcnn_f32_to_bf16(m.ptr(x), int(np.prod(x.shape)), m.ptr(y), m.stream()), "frcnn_f32_to_bf16")
         return y
 
     def linear_bf16(self, x, w, bias, relu=False, out_bf16=False):
         """x (M,K) bf16 bits, w (N,K) bf16 bits, bias (N,) fp32 -> (M,N) fp32 (or bf16 bits)."""
-        m, L = self.mem, self.lib
+        m, L = self.mem, self.hlib
         M, K = int(x.shape[0]), int(np.prod(x.shape[1:]))
         N = int(w.shape[0])
         assert int(np.prod(w.shape[1:])) == K
@@ -700,7 +734,7 @@ class Runtime(object):
     def linear_bf16_tile_w(self, w_bits):
         """(N, K) bf16 bits -> the weight-stream layout of frcnn_linear_bf16_tiled (8 KB tiles [ceil(N/128)][K/32], the kernel's swizzled LDS image);
         once, at load time.  K % 32 == 0."""
-        m, L = self.mem, self.lib
+        m, L = self.mem, self.hlib
         N, K = int(w_bits.shape[0]), int(np.prod(w_bits.shape[1:]))
         nbytes = L.frcnn_linear_bf16_tiled_bytes(N, K)
         if nbytes == 0:
@@ -711,7 +745,7 @@ class Runtime(object):
 
     def linear_bf16_tiled(self, x, w_tiled, N, bias, relu=False, out_bf16=False):
         """x (M,K) bf16 bits, w_tiled = linear_bf16_tile_w of the (N,K) weights, bias (N,) fp32 -> (M,N) fp32 (or bf16 bits)."""
-        m, L = self.mem, self.lib
+        m, L = self.mem, self.hlib
         M, K = int(x.shape[0]), int(np.prod(x.shape[1:]))
         y = m.empty((M, N), "i16" if out_bf16 else "f32")
         ws = self.workspace("linear", L.frcnn_linear_bf16_tiled_workspace_bytes(M, N, K))
@@ -722,7 +756,7 @@ class Runtime(object):
     def rpn_heads_bf16(self, h_blk, w_packed, bias, cmid, A):
         """h_blk [CmidP/16][H][W][16] bf16, stacked bf16-packed 1x1 weights, (6A,) fp32 bias -> (rpn_cls_score (1,2A,H,W),
         rpn_cls_prob (1,2A,H,W), rpn_bbox_pred (1,4A,H,W)) fp32: both heads and the softmax in one launch."""
-        m, L = self.mem, self.lib
+        m, L = self.mem, self.hlib
         H, W = int(h_blk.shape[1]), int(h_blk.shape[2])
         raw = m.empty((1, 6 * A, H, W), "f32")
         prob = m.empty((1, 2 * A, H, W), "f32")

@@ -372,6 +372,39 @@ int frcnn_linear_bf16_tile_w(const uint16_t *w, int N, int K, uint16_t *w_tiled,
 size_t frcnn_linear_bf16_tiled_workspace_bytes(int M, int N, int K);
 int frcnn_linear_bf16_tiled(const uint16_t *x, const uint16_t *w_tiled, const float *bias, void *y, int M, int N, int K, int relu,
                             int out_bf16, void *workspace, size_t workspace_bytes, void *stream);
+/* ---- the fp16 instantiation of the 16-bit chain (ABI v24; csrc/conv_f16.hip, conv_f16_pair.hip, linear_f16.hip) ---------------------
+ * north_star: "MFMA-tiled ... conv stack (fp16/bf16 accumulate fp32)".  Every entry below is the twin of the *_bf16* entry of the same name: the SAME kernel
+ * source compiled with fp16 pack / widen / v_mfma_f32_32x32x16_f16 (csrc/frcnn_intrin.h), same signature, layouts ([C/16][H][W][16] channel-blocked maps,
+ * [CinP/16][tap][CoutP][16] weights, 8 KB FC tiles), workspaces, tuning keys and error codes; uint16_t arrays hold raw IEEE binary16 bits.  fp16 carries
+ * 10 mantissa bits (bf16: 7) and 5 exponent bits: |v| > 65504 rounds to Inf, |v| < 6e-8 to 0 -- VGG-16's activations on mean-subtracted 8-bit images stay
+ * inside that range; a caller whose maps do not must use the bf16 entries.  Replaces what the bf16 twins replace: models/vgg16.py:38-82,
+ * region_proposal_network.py:53,117-120, faster_rcnn.py:33-36,127-134.  RoI pooling has no fp16 form of its own: frcnn_f16_to_nchw_f32 +
+ * frcnn_roi_pool_fwd_chw + frcnn_f32_to_f16 (the maximum of fp16 values is an fp16 value: no rounding happens). */
+int frcnn_f16_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, void *stream);
+int frcnn_f16_padded_channels(int c);
+int frcnn_f16_pack_conv_w(const float *w, int Cout, int Cin, int ksize, uint16_t *w_packed, void *stream);
+int frcnn_f16_from_nchw_f32(const float *x, int C, int H, int W, uint16_t *y, void *stream);
+size_t frcnn_conv_f16_workspace_bytes(int Cin, int Cout, int H, int W);
+int frcnn_conv_f16_workspace_init(void *workspace, size_t workspace_bytes, void *stream);
+int frcnn_conv_f16_ws(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
+                       int W, int ksize, int relu, int out_mode, void *workspace, size_t workspace_bytes, void *stream);
+int frcnn_rpn_heads_f16(const uint16_t *h, int Cmid, int H, int W, int A, const uint16_t *w_packed, const float *bias, float *raw,
+                         float *cls_prob, void *stream);
+int frcnn_conv_f16(const uint16_t *x, const uint16_t *w_packed, const float *bias, void *y, int Cin, int Cout, int H,
+                    int W, int ksize, int relu, int out_mode, void *stream);
+int frcnn_conv_f16_plan(int Cin, int Cout, int H, int W, int ksize, int out_mode);
+int frcnn_maxpool2x2_f16(const uint16_t *x, uint16_t *y, int C, int H, int W, void *stream);
+int frcnn_f32_to_f16(const float *x, size_t n, uint16_t *y, void *stream);
+size_t frcnn_linear_f16_workspace_bytes(int M, int N, int K);
+int frcnn_linear_f16(const uint16_t *x, const uint16_t *w, const float *bias, void *y, int M, int N, int K, int relu,
+                      int out_f16, void *workspace, size_t workspace_bytes, void *stream);
+int frcnn_conv1_pair_f16(const float *x, const float *w1, const float *b1, const uint16_t *w2_packed, const float *b2,
+                          uint16_t *y, int Cin, int H, int W, void *stream);
+size_t frcnn_linear_f16_tiled_bytes(int N, int K);
+int frcnn_linear_f16_tile_w(const uint16_t *w, int N, int K, uint16_t *w_tiled, void *stream);
+size_t frcnn_linear_f16_tiled_workspace_bytes(int M, int N, int K);
+int frcnn_linear_f16_tiled(const uint16_t *x, const uint16_t *w_tiled, const float *bias, void *y, int M, int N, int K, int relu,
+                            int out_f16, void *workspace, size_t workspace_bytes, void *stream);
 /* softmax over the channel axis of a (n_ch, H*W) fp32 map: the reference's F.softmax(rpn_cls_score) (region_proposal_network.py:119) */
 int frcnn_softmax_channels_f32(const float *score, int n_ch, int HW, float *prob, void *stream);
 

@@ -126,13 +126,15 @@ def device_forward_host(rt, model, x_dev, im_h, im_w):
     int16 arrays, channel-blocked for feature maps -- come back as float32 NCHW / (R, N))."""
     collect = {}
     out = model.forward_device(x_dev, im_h, im_w, keep=True, collect=collect)
+    rt = getattr(model, "rt", rt)                                     # an fp16 model's runtime decodes its 16-bit arrays as IEEE binary16
+    f16 = getattr(rt, "half", "bf16") == "f16"
     rt.mem.synchronize()
     dev = {}
     for k, v in out.items():
         if v is None or not rt.mem.is_array(v):
             continue
         if rt.mem.dtype_of(v) == "i16":
-            dev[k] = rt.mem.to_numpy(rt.bf16_to_nchw(v, model.RPN.mid_ch)) if v.ndim == 4 else _bf16_bits_to_f32(rt.mem.to_numpy(v))
+            dev[k] = rt.mem.to_numpy(rt.bf16_to_nchw(v, model.RPN.mid_ch)) if v.ndim == 4 else (rt.mem.to_numpy(v).view(np.float16).astype(np.float32) if f16 else _bf16_bits_to_f32(rt.mem.to_numpy(v)))
         else:
             dev[k] = rt.mem.to_numpy(v)
     layers = {}

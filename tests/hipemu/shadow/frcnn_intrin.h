@@ -8,7 +8,15 @@ static inline uint32_t hipemu_f32_to_bf16_rne(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
+#ifdef FRCNN_HALF_F16        // the fp16 instantiation of the 16-bit chain (csrc/frcnn_intrin.h): pack / widen / MFMA operate on IEEE half
+static inline uint32_t hipemu_f32_to_f16_rne(float f) { const _Float16 h = (_Float16)f; unsigned short u; memcpy(&u, &h, 2); return u; }
+static inline uint32_t frcnn_pack_bf16x2(float lo, float hi) { return (hipemu_f32_to_f16_rne(lo) & 0xffffu) | (hipemu_f32_to_f16_rne(hi) << 16); }
+static inline float frcnn_h16_to_f32(uint16_t h) { _Float16 v; memcpy(&v, &h, 2); return (float)v; }
+#else
 static inline uint32_t frcnn_pack_bf16x2(float lo, float hi) { return (hipemu_f32_to_bf16_rne(lo) & 0xffffu) | (hipemu_f32_to_bf16_rne(hi) << 16); }
+static inline float frcnn_h16_to_f32(uint16_t h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+#endif
+static inline uint32_t frcnn_f32_to_h16_exact(float v) { return frcnn_pack_bf16x2(v, 0.0f) & 0xffffu; }
 static inline uint32_t frcnn_wave_or_u32(uint32_t v) {
     int x = (int)v;
     for (int d = 32; d > 0; d >>= 1) x |= __shfl_xor(x, d);
@@ -33,7 +41,7 @@ __attribute__((noinline)) static frcnn_f32x16 frcnn_mfma_32x32x16_bf16(uint4 a, 
             unsigned short av, bv;
             memcpy(&av, e.vals[i + 32 * (k >> 3)] + 2 * (k & 7), 2);
             memcpy(&bv, e.vals[j + 32 * (k >> 3)] + 16 + 2 * (k & 7), 2);
-            acc += hipemu_bf16_to_f32(av) * hipemu_bf16_to_f32(bv);
+            acc += frcnn_h16_to_f32(av) * frcnn_h16_to_f32(bv);
         }
         c[r] = acc;
     }
@@ -42,12 +50,14 @@ __attribute__((noinline)) static frcnn_f32x16 frcnn_mfma_32x32x16_bf16(uint4 a, 
 static inline void frcnn_pin(float4 &) {}       // (a scheduling constraint on the device; nothing to do on the host)
 static inline void frcnn_pin(float &) {}
 static inline uint32_t frcnn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
+#ifndef FRCNN_HALF_F16
 static inline void frcnn_split3_pair(float v0, float v1, uint32_t &h, uint32_t &m, uint32_t &l) {
     h = frcnn_pack_bf16x2(v0, v1);
     const float d0 = v0 - __uint_as_float(h << 16), d1 = v1 - __uint_as_float(h & 0xffff0000u);
     m = frcnn_pack_bf16x2(d0, d1);
     l = frcnn_pack_bf16x2(d0 - __uint_as_float(m << 16), d1 - __uint_as_float(m & 0xffff0000u));
 }
+#endif
 
 __attribute__((noinline)) static int frcnn_lds_append(int *ctr) {
     int z = 0;

@@ -16,7 +16,7 @@ def rt():
 
 
 def test_library_is_the_device_build(rt):
-    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 23
+    assert rt.lib.frcnn_device_count() >= 1 and rt.lib.frcnn_abi_version() == 24
 
 
 def test_nms_golden(rt):
@@ -477,6 +477,31 @@ def test_linear_bf16(rt):
     P.check_linear_bf16(rt, 300, 4096, 4096, True)       # fc7
     P.check_linear_bf16(rt, 300, 84, 4096, False)        # bbox_pred
     P.check_linear_bf16(rt, 17, 33, 104, False)
+
+
+def test_f16_instantiation_of_the_16_bit_chain(rt):
+    """The fp16 twins of the 16-bit chain (csrc/conv_f16.hip, conv_f16_pair.hip, linear_f16.hip) at the layer sizes where the default rule launches each kernel
+    form -- the bf16 parity checks on a runtime in fp16 mode, the oracle fed fp16-rounded operands."""
+    r16 = rt.with_half("f16")
+    with P.half_format("f16"):
+        P.check_conv_bf16(r16, 256, 256, 150, 250)                 # conv3_2: strip form D
+        P.check_conv_bf16(r16, 512, 512, 38, 63)                   # conv5_x: strip form C (K split over the waves)
+        P.check_conv_bf16(r16, 64, 128, 300, 500)                  # conv2_1: conv_dma_bf16_kernel
+        P.check_conv_bf16(r16, 512, 54, 38, 63, ksize=1, relu=False)
+        P.check_conv_bf16_pool(r16, 128, 128, 60, 100)
+        P.check_maxpool_bf16(r16, 64, 75, 125)
+        P.check_conv1_pair_bf16(r16, 120, 200)
+        P.check_rpn_heads_bf16(r16, 512, 38, 63)
+        P.check_linear_bf16_tiled(r16, 300, 4096, 25088, True)     # fc6
+        P.check_linear_bf16_tiled(r16, 300, 116, 4096, False)
+        P.check_linear_bf16(r16, 300, 4096, 4096, True)
+
+
+def test_vgg16_f16_forward(rt):
+    """The whole forward pass with fp16 convolutions and head at 224 x 320: trunk within 4e-3 of the fp32 oracle's feature scale (bf16: 3e-2)."""
+    with P.half_format("f16"):
+        err = P.check_vgg_bf16_forward(rt, 224, 320, dtype="f16", feat_tol=4e-3, head_tol=3e-3)
+    print("PARITY vgg16 f16 forward 224x320: conv5_3 rel err %.2e" % err)
 
 
 def test_linear_bf16_tiled(rt):

@@ -30,7 +30,7 @@ def test_device_library_builds_and_exports_every_declared_symbol():
     assert norm(ref) in norm(hdr)
     import chainer_faster_rcnn_amd as pkg
     assert sorted(pkg._lib.SIGNATURES) == _declared()   # the binding table mirrors the header one to one
-    assert lib.frcnn_abi_version() == 23
+    assert lib.frcnn_abi_version() == 24
 
 
 def test_no_cpu_fallback_without_gpu():

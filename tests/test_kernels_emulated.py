@@ -266,6 +266,25 @@ def test_linear_bf16_tiled_with_late_landing(rt, monkeypatch):
     P.check_linear_bf16_tiled(rt, 70, 128, 32 * 9, False, seed=5)
 
 
+def test_f16_instantiation_of_the_16_bit_chain(rt):
+    """csrc/conv_f16.hip, conv_f16_pair.hip, linear_f16.hip: the bf16 kernel sources compiled with fp16 pack / widen / MFMA (north_star: "fp16/bf16 accumulate
+    fp32").  The bf16 parity checks, run on a runtime whose *_bf16 methods resolve to the *_f16* entry points and an oracle fed fp16-rounded operands."""
+    r16 = rt.with_half("f16")
+    assert r16.half == "f16" and rt.half == "bf16" and r16.lib is rt.lib
+    with P.half_format("f16"):
+        x = np.array([1.0, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, 65504.0, 70000.0, 6e-8, -2.5], np.float32)     # ties to even; overflow -> Inf; the smallest subnormal
+        assert np.array_equal(P.host(rt, r16.to_bf16(P.dev(rt, x))), x.astype(np.float16).view(np.int16))
+        P.check_conv_bf16(r16, 19, 70, 9, 37)                     # ragged channels, conv_dma kernel
+        P.check_conv_bf16(r16, 32, 64, 7, 11, ksize=1, relu=False)
+        P.check_conv_bf16_pool(r16, 16, 64, 9, 37)
+        P.check_maxpool_bf16(r16, 32, 9, 13)
+        P.check_linear_bf16(r16, 70, 140, 256, True)
+        P.check_linear_bf16_tiled(r16, 100, 130, 32 * 9, True, seed=2)
+        P.check_rpn_heads_bf16(r16, 64, 7, 9)
+        P.check_conv1_pair_bf16(r16, 12, 40)
+        P.check_conv_bf16_strip(r16, 910, 128, 64, 20, 64)        # form D, direct stores
+
+
 def test_conv_relu_pool_fused(rt):
     P.check_conv_relu_pool(rt, 8, 64, 9, 37)          # odd H and W: clipped windows on both edges
     P.check_conv_relu_pool(rt, 16, 128, 8, 64, seed=1)
