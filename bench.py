@@ -365,13 +365,18 @@ def graph_time_us(torch, fn, launches_per_replay, replays):
         fn()
     for _ in range(2):
         g.replay()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(replays):
-        g.replay()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / (replays * launches_per_replay)
+    # three batches of `replays`, the median batch: one transient (a clock dip, another process's burst) inside a single interval once turned the 8 us RoI
+    # figure behind the NMS scan into 49 us (round 6, gpurun_out/r06h) while every other line of the same call read 8.0
+    batches = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(replays):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        batches.append(e0.elapsed_time(e1) * 1e3 / (replays * launches_per_replay))
+    return sorted(batches)[1]
 
 
 def f32s_conv_chain(rt, model, x, bf16=False):
@@ -567,14 +572,16 @@ def two_streams_variant(torch, pkg, rt, params, dtype, x, steps, graph_a):
             "what": "two model instances (own workspaces + captured graphs, same weights), image k on HIP stream k % 2: image k's proposal / RoI / head stages overlap image k + 1's convolutions"}
 
 
-def bf16_variant(args, torch, rt, params, x, dbg, flops_total):
+def bf16_variant(args, torch, rt, params, x, dbg, flops_total, half="bf16"):
     """BASELINE.json configs[2] on this GPU ("bf16 convs / fp32 RoI", 1 image per GPU): the bf16 chain (csrc/conv_bf16.hip: operands
     rounded to bf16, fp32 accumulation on v_mfma_f32_32x32x16_bf16, bf16 FC head; proposals, RoI pooling, decode in fp32), timed like
     the contract line (K hipGraph replays), its conv chain priced against the dense bf16 MFMA peak, and compared with the same oracle
-    forward.  Bit-exact proposal indices FROM THE IMAGE are claimed for the fp32 lines only: a bf16 trunk moves conv5_3 by ~1e-2."""
+    forward.  Bit-exact proposal indices FROM THE IMAGE are claimed for the fp32 lines only: a bf16 trunk moves conv5_3 by ~1e-2.
+    half = "f16": the same chain in its fp16 instantiation (csrc/conv_f16.hip: v_mfma_f32_32x32x16_f16, 10 mantissa bits; north_star's "fp16/bf16 accumulate
+    fp32"): timing and parity only (no feed / two-in-flight repeats)."""
     from chainer_faster_rcnn_amd.graph import CapturedForward
     from chainer_faster_rcnn_amd.models import FasterRCNN
-    model = FasterRCNN(runtime=rt, conv_dtype="bf16", head_dtype="bf16")
+    model = FasterRCNN(runtime=rt, conv_dtype=half, head_dtype=half)
     model.load_params(params)
     for _ in range(max(args.warmup, 3)):
         model.forward_device(x, IM_H, IM_W)
@@ -589,7 +596,7 @@ def bf16_variant(args, torch, rt, params, x, dbg, flops_total):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     feed = None
-    if not args.no_feed_variant:
+    if not args.no_feed_variant and half == "bf16":
         try:
             feed = feed_variant(torch, rt, graph, steps, check_oracle=False)
         except Exception as e:
@@ -599,9 +606,13 @@ def bf16_variant(args, torch, rt, params, x, dbg, flops_total):
                     "and fp32 accumulation (v_mfma_f32_32x32x16_bf16); proposals / RoI pooling / decode in fp32.  `python bench.py --dtype bf16` "
                     "prints this configuration as its own line."),
            "value": steps / dt, "unit": "img/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "launch": "hipGraph replay"}
+    if half == "f16":
+        out["what"] = ("the 16-bit chain of BASELINE.json configs[2] in its fp16 instantiation (north_star: fp16/bf16 accumulate fp32): the same kernel sources compiled "
+                       "with fp16 pack / widen / v_mfma_f32_32x32x16_f16 (csrc/conv_f16.hip, conv_f16_pair.hip, linear_f16.hip), same layouts and schedule; RoI pooling takes "
+                       "the fp32 kernel between two conversions.  `python bench.py --dtype f16` prints this configuration as its own line.")
     if feed is not None:
         out["with_feed"] = feed
-    if not args.no_two_streams_variant:
+    if not args.no_two_streams_variant and half == "bf16":
         try:
             import chainer_faster_rcnn_amd as _pkg
             graph.replay(x)
@@ -640,12 +651,17 @@ def bf16_variant(args, torch, rt, params, x, dbg, flops_total):
         try:
             from oracle import parity
             info = np.array([[IM_H, IM_W]], dtype=np.int32)
-            rep = parity.compare_forward(params, info, dbg, parity.device_forward_host(rt, model, x, IM_H, IM_W), layer_tol=3e-2, head_tol=3e-2)
+            tol = 3e-2 if half == "bf16" else 4e-3
+            rep = parity.compare_forward(params, info, dbg, parity.device_forward_host(rt, model, x, IM_H, IM_W), layer_tol=tol, head_tol=tol)
             out["parity"] = {k: rep.get(k) for k in ("ok", "layers_worst", "conv5_3_rel_err", "rpn_cls_prob_rel_err", "rpn_bbox_pred_rel_err",
                                                      "proposals_index_exact_given_device_maps", "from_image_index_match_positional",
                                                      "from_image_index_match_set", "pool5_exact", "cls_prob_rel_err", "pred_boxes_rel_err", "tolerances")}
             out["parity"]["claim"] = ("stage by stage, given the device's own maps: proposal indices and pool5 exact; from the IMAGE a bf16 trunk does not "
-                                      "reproduce the fp32 oracle's proposal indices (see from_image_index_match_*): that claim is made for the fp32 lines only")
+                                      "reproduce the fp32 oracle's proposal indices (see from_image_index_match_*): that claim is made for the fp32 lines only"
+                                      if half == "bf16" else
+                                      "stage by stage, given the device's own maps: proposal indices and pool5 exact; from the IMAGE the fp16 trunk stays within ~1.5e-3 of the "
+                                      "fp32 oracle's conv5_3 (bf16: 1.1e-2) and reproduces its proposal SET up to a box or two, but not every position (north_star's 1e-3 / "
+                                      "bit-exact-from-image bar is met by the fp32 lines only)")
         except Exception as e:
             out["parity"] = {"ok": False, "error": repr(e)}
     return out
@@ -1151,6 +1167,10 @@ def main():
                               "roi_pool_algorithmic_mb": roi_bytes / 1e6,
                               "roi_pool_gbps": roi_bytes / (roi_us * 1e-6) / 1e9,
                               "roi_pool_frac_of_hbm_peak": roi_bytes / (roi_us * 1e-6) / 1e9 / PEAK_HBM_GBPS}
+            # the RoI launch where it actually runs -- behind the NMS scan inside one graph (its 2.7 us launch latency overlaps the scan's tail): the same
+            # algorithmic bytes over (graph of [proposal pipeline -> RoI pooling of its own RoIs] - graph of the pipeline alone); the isolated figure stays beside it
+            ing = res["nms_roi"]["roi_pool_us_behind_nms_in_one_graph"]
+            res["nms_roi"]["roi_pool_frac_of_hbm_peak_behind_nms_in_one_graph"] = (roi_bytes / (ing * 1e-6) / 1e9 / PEAK_HBM_GBPS) if ing else None
             # training forms: map read + y AND argmax_data written (forward), dy and argmax_data read + dx written (backward)
             train_bytes = (512 * fh * fw + 2 * 300 * 512 * 49) * 4 + 300 * 16
             for key, tag in (("roi_pool_argmax_us", "roi_pool_fwd_argmax"), ("roi_pool_bwd_us", "roi_pool_bwd")):
@@ -1180,6 +1200,10 @@ def main():
                 res["bf16_config3"] = bf16_variant(args, torch, rt, params, x, dbg, sum(conv_flops(_L3, IM_H, IM_W)[0].values()))
             except Exception as e:
                 res["bf16_config3"] = {"error": repr(e)}
+            try:
+                res["f16_config3"] = bf16_variant(args, torch, rt, params, x, dbg, sum(conv_flops(_L3, IM_H, IM_W)[0].values()), half="f16")
+            except Exception as e:
+                res["f16_config3"] = {"error": repr(e)}
                 torch.cuda.synchronize()
         if world == 1 and args.dtype == "f32" and not args.no_split_variant:
             try:
@@ -1191,12 +1215,19 @@ def main():
         # the secondary figures INSIDE `roofline` (the driver's stored record keeps `roofline` verbatim and only the names of the other blocks)
         if "roofline" in res:
             nr, b3, sp = res.get("nms_roi") or {}, res.get("bf16_config3") or {}, res.get("f32_split_products") or {}
+            h3 = res.get("f16_config3") or {}
             sec = {"roi_pool_us": nr.get("roi_pool_us"), "roi_pool_frac_of_hbm_peak": nr.get("roi_pool_frac_of_hbm_peak"),
                    "roi_pool_us_in_pipeline": nr.get("roi_pool_us_in_pipeline_stage_event"),
                    "roi_pool_us_behind_nms_in_one_graph": nr.get("roi_pool_us_behind_nms_in_one_graph"),
+                   "roi_pool_frac_of_hbm_peak_behind_nms_in_one_graph": nr.get("roi_pool_frac_of_hbm_peak_behind_nms_in_one_graph"),
                    "roi_pool_fwd_argmax_us": nr.get("roi_pool_fwd_argmax_us"), "roi_pool_fwd_argmax_frac_of_hbm_peak": nr.get("roi_pool_fwd_argmax_frac_of_hbm_peak"),
                    "roi_pool_bwd_us": nr.get("roi_pool_bwd_us"), "roi_pool_bwd_frac_of_hbm_peak": nr.get("roi_pool_bwd_frac_of_hbm_peak"),
                    "proposals_nms_us": nr.get("proposals_nms_us"),
+                   "f16_img_s": h3.get("value"), "f16_conv5_3_rel_err": (h3.get("parity") or {}).get("conv5_3_rel_err"),
+                   "f16_from_image_index_match_set": (h3.get("parity") or {}).get("from_image_index_match_set"),
+                   "f16_from_image_index_match_positional": (h3.get("parity") or {}).get("from_image_index_match_positional"),
+                   "bf16_conv5_3_rel_err": (b3.get("parity") or {}).get("conv5_3_rel_err"),
+                   "bf16_from_image_index_match_set": (b3.get("parity") or {}).get("from_image_index_match_set"),
                    "bf16_img_s": b3.get("value"), "bf16_ms_per_step": b3.get("ms_per_step"), "bf16_conv_ms_per_image": b3.get("conv_ms_per_image"),
                    "bf16_conv_frac_of_bf16_mfma_peak": b3.get("frac_of_bf16_mfma_peak"),
                    "f32s_img_s": sp.get("value"), "f32s_ms_per_step": sp.get("ms_per_step"),

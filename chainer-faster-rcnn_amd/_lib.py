@@ -95,6 +95,8 @@ SIGNATURES = {
     "frcnn_linear_bf16_tiled": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _S, _P]),
     "frcnn_softmax_channels_f32": (_I, [_P, _I, _I, _P, _P]),
     "frcnn_rpn_heads_bf16": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "frcnn_roi_pool_fwd_chw_f16": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _F, _P, _P]),
+    "frcnn_roi_pool_fwd_blk_f16": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _F, _P, _I, _P]),
     # the fp16 twins of the 16-bit chain (csrc/conv_f16.hip ...): same signatures
     "frcnn_f16_to_nchw_f32": (_I, [_P, _I, _I, _I, _P, _P]),
     "frcnn_f16_padded_channels": (_I, [_I]),

@@ -1,5 +1,5 @@
-// frcnn_f16_names.h -- the entry points of the 16-bit chain under their fp16 names: included (before anything else) by the three fp16 translation units
-// conv_f16.hip, conv_f16_pair.hip, linear_f16.hip, which then include the bf16 sources unchanged with FRCNN_HALF_F16 defined (frcnn_intrin.h: pack / widen / MFMA
+// frcnn_f16_names.h -- the entry points of the 16-bit chain under their fp16 names: included (before anything else) by the four fp16 translation units
+// conv_f16.hip, conv_f16_pair.hip, linear_f16.hip, roi_f16.hip, which then include the bf16 sources unchanged with FRCNN_HALF_F16 defined (frcnn_intrin.h: pack / widen / MFMA
 // become the fp16 instructions).  Every declaration include/frcnn_hip.h makes for a name below is thereby also the declaration of its fp16 twin: same signature,
 // same layouts, same workspaces, same error codes.  Longest names first is not needed: the preprocessor matches whole identifiers.
 #pragma once
@@ -25,3 +25,5 @@
 #define frcnn_linear_bf16_tile_w frcnn_linear_f16_tile_w
 #define frcnn_linear_bf16_tiled_workspace_bytes frcnn_linear_f16_tiled_workspace_bytes
 #define frcnn_linear_bf16_tiled frcnn_linear_f16_tiled
+#define frcnn_roi_pool_fwd_chw_bf16 frcnn_roi_pool_fwd_chw_f16
+#define frcnn_roi_pool_fwd_blk_bf16 frcnn_roi_pool_fwd_blk_f16

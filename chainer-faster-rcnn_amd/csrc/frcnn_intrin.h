@@ -86,7 +86,8 @@ __device__ __forceinline__ void frcnn_pin(float4 &v) { asm volatile("" : "+v"(v.
 __device__ __forceinline__ void frcnn_pin(float &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ uint32_t frcnn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
 
-#ifndef FRCNN_HALF_F16      // (the split tensors of conv_f32s.hip are bf16 by construction)
+// (the split tensors of conv_f32s.hip are bf16 by construction: in an fp16 translation unit this helper still parses -- roi_pool.hip names it in a template
+// branch the fp16 twins never instantiate -- but must not be called)
 // (v0, v1) -> the three packed bf16 pairs (h, m, l) with h + m + l == v exactly (round to nearest even at every step; the
 // differences are exact in fp32): the "split tensors" of conv_f32s.hip.  PRECONDITION: |v| finite and below the largest bf16
 // (3.39e38): for +-Inf, or a value whose bf16 rounding overflows, h is Inf and the lower terms are NaN (Inf - Inf), i.e. an overflowed
@@ -98,7 +99,6 @@ __device__ __forceinline__ void frcnn_split3_pair(float v0, float v1, uint32_t &
     m = frcnn_pack_bf16x2(d0, d1);
     l = frcnn_pack_bf16x2(d0 - __uint_as_float(m << 16), d1 - __uint_as_float(m & 0xffff0000u));
 }
-#endif
 
 
 // DPP quad_perm [1,0,3,2]: every lane receives the value of lane ^ 1 -- one VALU instruction (a __shfl_xor may go through the LDS crossbar)

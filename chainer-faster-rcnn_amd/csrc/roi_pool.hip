@@ -592,8 +592,8 @@ roi_pool_cells_kernel(const float *__restrict__ x, int C, int H, int W, const fl
             const uint32_t u[4] = {__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z), __float_as_uint(q.w)};
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                v[i][2 * c] = __uint_as_float(u[c] << 16);
-                v[i][2 * c + 1] = __uint_as_float(u[c] & 0xffff0000u);
+                v[i][2 * c] = frcnn_h16_to_f32((uint16_t)u[c]);               // (bf16: u << 16 and u & 0xffff0000 -- the compiler folds the casts; fp16 twin: v_cvt_f32_f16)
+                v[i][2 * c + 1] = frcnn_h16_to_f32((uint16_t)(u[c] >> 16));
             }
         } else {
             const uint32_t base = (h < H && lane < W) ? (uint32_t)((c0 * HW + h * W + lane) * 4) : kBufOob;
@@ -1083,8 +1083,8 @@ roi_pool_quads_kernel(const float *__restrict__ x, int C, int H, int W, const fl
                 const int h = 3 * wave + i;
                 const uint32_t off = (h < H && lane < W) ? (uint32_t)((((c0 >> 4) * HW + h * W + lane) * 16 + (c0 & 15)) * 2) : kBufOob;
                 const uint2 q = frcnn_buf_load_b64(xbuf, off);                    // channels c0 .. c0 + 3 of the cell: 4 x bf16
-                v[i][0] = __uint_as_float(q.x << 16); v[i][1] = __uint_as_float(q.x & 0xffff0000u);
-                v[i][2] = __uint_as_float(q.y << 16); v[i][3] = __uint_as_float(q.y & 0xffff0000u);
+                v[i][0] = frcnn_h16_to_f32((uint16_t)q.x); v[i][1] = frcnn_h16_to_f32((uint16_t)(q.x >> 16));
+                v[i][2] = frcnn_h16_to_f32((uint16_t)q.y); v[i][3] = frcnn_h16_to_f32((uint16_t)(q.y >> 16));
             }
         } else {
             const frcnn_buf_t xbuf = frcnn_make_buf(x, (uint32_t)((size_t)C * HW * sizeof(float)));
@@ -1510,6 +1510,7 @@ static int frcnn_roi_cu_count() {
 
 extern "C" {
 
+#ifndef FRCNN_HALF_F16      // roi_f16.hip compiles this file a second time for the two 16-bit entry points only (their fp16 twins)
 size_t frcnn_roi_pool_workspace_bytes(int C, int H, int W) {
     if (C < 1 || H < 1 || W < 1) return 0;
     return frcnn_align256((size_t)C * H * W * sizeof(float));
@@ -1541,6 +1542,7 @@ int frcnn_roi_pool_fwd_hwc(const float *xt, int C, int H, int W, const float *ro
     return frcnn_launch_status();
 }
 
+#endif
 // Channel planes per workgroup for the plane-resident kernel, or 0 when a plane does not fit in LDS.
 static int roi_planes_per_group(int C, int H, int W, int outh, int outw) {
     if (W > kRowPitch || frcnn_cdiv(W, outw) + 1 > kMaxBinW || frcnn_cdiv(H, outh) + 1 > kMaxBinH) return 0;
@@ -1549,6 +1551,7 @@ static int roi_planes_per_group(int C, int H, int W, int outh, int outw) {
     return 0;
 }
 
+#ifndef FRCNN_HALF_F16
 int frcnn_roi_pool_fwd_chw(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
                            float spatial_scale, float *y, int32_t *argmax, void *workspace, size_t workspace_bytes, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -1592,6 +1595,8 @@ int frcnn_roi_pool_fwd_chw_f32s(const float *x, int C, int H, int W, const float
     return FRCNN_ERR_UNSUPPORTED;                    // cell-major kernel only (maps up to 76 x 64): pool in fp32 and frcnn_f32s_split otherwise
 }
 
+#endif
+
 int frcnn_roi_pool_fwd_chw_bf16(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh, int outw,
                                 float spatial_scale, uint16_t *y, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -1627,6 +1632,7 @@ int frcnn_roi_pool_fwd_blk_bf16(const uint16_t *x_blk, int C, int H, int W, cons
     return ok ? frcnn_launch_status() : FRCNN_ERR_UNSUPPORTED;   // cell-major kernel only (maps up to 76 x 64): frcnn_bf16_to_nchw_f32 + frcnn_roi_pool_fwd_chw otherwise
 }
 
+#ifndef FRCNN_HALF_F16
 int frcnn_roi_pool_fwd(const float *x, int C, int H, int W, const float *rois, int R, int outh, int outw, float spatial_scale,
                        float *y, int32_t *argmax, void *workspace, size_t workspace_bytes, void *stream) {
     return frcnn_roi_pool_fwd_chw(x, C, H, W, rois, R, 5, outh, outw, spatial_scale, y, argmax, workspace, workspace_bytes, stream);
@@ -1661,5 +1667,7 @@ int frcnn_roi_pool_bwd(const float *dy, const int32_t *argmax, int R, int C, int
     hipLaunchKernelGGL(roi_pool_bwd_kernel, dim3(blocks), dim3(256), 0, stream, dy, argmax, C, H * W, outh * outw, total, dx);
     return frcnn_launch_status();
 }
+
+#endif
 
 }  // extern "C"

@@ -41,7 +41,10 @@ class Linear(object):
             # the weight-stream layout of csrc/linear_bf16.hip (8 KB tiles = the kernel's LDS image), once per load; FRCNN_LINEAR_BF16=dma keeps the
             # round-5 kernel on the row-major bits (A/B)
             K = int(np.prod(self.W.shape[1:]))
-            self.Wt = self.rt.linear_bf16_tile_w(self.Wb) if (K % 32 == 0 and tuning.get("FRCNN_LINEAR_BF16") != "dma") else None
+            # (a layer with fewer than 256 outputs -- the stacked cls_score || bbox_pred GEMM -- is ONE column block of the stream kernel: 12 workgroups; the
+            # round-5 kernel's 32 are faster there: 11.8 vs 13.9 us, profiles/r06_linear_bf16_micro.txt)
+            N = int(self.W.shape[0])
+            self.Wt = self.rt.linear_bf16_tile_w(self.Wb) if (K % 32 == 0 and N >= 256 and tuning.get("FRCNN_LINEAR_BF16") != "dma") else None
         elif self.dtype == "f32s":
             self.Ws = self.rt.f32s_split(self.W)           # the three bf16 terms of every fp32 weight, (3, out, in)
 

@@ -179,8 +179,8 @@ class TorchDeviceMemory(object):
 
 class _HalfLib(object):
     """The library seen through a 16-bit operand format: with half == "f16" every *_bf16* entry point resolves to its *_f16* twin (csrc/conv_f16.hip,
-    conv_f16_pair.hip, linear_f16.hip: the same kernel sources compiled with fp16 pack / widen / MFMA; include/frcnn_hip.h).  The RoI-pooling and first-layer
-    entries have no fp16 twin: asking for one raises AttributeError, and the Runtime methods that use them compose the documented detour instead."""
+    conv_f16_pair.hip, linear_f16.hip, roi_f16.hip: the same kernel sources compiled with fp16 pack / widen / MFMA; include/frcnn_hip.h).  The
+    first-layer entry (frcnn_conv1_bf16) has no fp16 twin: Runtime.conv1_bf16 composes it from the generic kernel instead."""
 
     def __init__(self, lib, half):
         self._lib, self._half = lib, half
@@ -315,9 +315,7 @@ class Runtime(object):
 
     def roi_pool_fwd_chw_bf16(self, x, rois, outh, outw, scale):
         """The same pooling with the result written as raw bf16 bits, flattened (R, C*outh*outw): the bf16 FC head's input."""
-        if self.half == "f16":                 # include/frcnn_hip.h: pool in fp32, one rounding to fp16
-            return self.to_bf16(self.roi_pool_fwd_chw(x, rois, outh, outw, scale).reshape(int(rois.shape[0]), -1))
-        m, L = self.mem, self.lib
+        m, L = self.mem, self.hlib
         C, H, W = [int(v) for v in x.shape[-3:]]
         R = int(rois.shape[0])
         y = m.empty((R, C * outh * outw), "i16")
@@ -328,10 +326,7 @@ class Runtime(object):
     def roi_pool_fwd_blk_bf16(self, x_blk, C, rois, outh, outw, scale, out_bf16=False):
         """RoI pooling straight from the bf16 chain's channel-blocked map [CP/16][H][W][16] -> (R, C, outh, outw) fp32, or raw bf16
         bits (R, C*outh*outw) for the bf16 FC head.  Maps up to 76 x 64 (the cell-major kernel's LDS image)."""
-        if self.half == "f16":                 # the fp16 chain takes the documented detour: map as fp32 NCHW (exact), fp32 pooling, rounding-free conversion back
-            y32 = self.roi_pool_fwd_chw(self.bf16_to_nchw(x_blk, int(C)), rois, outh, outw, scale)
-            return self.to_bf16(y32.reshape(int(rois.shape[0]), -1)) if out_bf16 else y32
-        m, L = self.mem, self.lib
+        m, L = self.mem, self.hlib
         H, W = int(x_blk.shape[1]), int(x_blk.shape[2])
         R = int(rois.shape[0])
         y = m.empty((R, int(C) * outh * outw), "i16") if out_bf16 else m.empty((R, int(C), outh, outw), "f32")

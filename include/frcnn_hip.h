@@ -378,8 +378,12 @@ int frcnn_linear_bf16_tiled(const uint16_t *x, const uint16_t *w_tiled, const fl
  * [CinP/16][tap][CoutP][16] weights, 8 KB FC tiles), workspaces, tuning keys and error codes; uint16_t arrays hold raw IEEE binary16 bits.  fp16 carries
  * 10 mantissa bits (bf16: 7) and 5 exponent bits: |v| > 65504 rounds to Inf, |v| < 6e-8 to 0 -- VGG-16's activations on mean-subtracted 8-bit images stay
  * inside that range; a caller whose maps do not must use the bf16 entries.  Replaces what the bf16 twins replace: models/vgg16.py:38-82,
- * region_proposal_network.py:53,117-120, faster_rcnn.py:33-36,127-134.  RoI pooling has no fp16 form of its own: frcnn_f16_to_nchw_f32 +
- * frcnn_roi_pool_fwd_chw + frcnn_f32_to_f16 (the maximum of fp16 values is an fp16 value: no rounding happens). */
+ * region_proposal_network.py:53,117-120, faster_rcnn.py:33-36,125-134.  The two RoI-pooling twins (csrc/roi_f16.hip) pool into / from fp16: a maximum of fp16
+ * values is an fp16 value, so pooling from the blocked fp16 map rounds nothing. */
+int frcnn_roi_pool_fwd_chw_f16(const float *x, int C, int H, int W, const float *rois, int R, int roi_cols, int outh,
+                                int outw, float spatial_scale, uint16_t *y, void *stream);
+int frcnn_roi_pool_fwd_blk_f16(const uint16_t *x_blk, int C, int H, int W, const float *rois, int R, int roi_cols, int outh,
+                                int outw, float spatial_scale, void *y, int out_f16, void *stream);
 int frcnn_f16_to_nchw_f32(const uint16_t *x, int C, int H, int W, float *y, void *stream);
 int frcnn_f16_padded_channels(int c);
 int frcnn_f16_pack_conv_w(const float *w, int Cout, int Cin, int ksize, uint16_t *w_packed, void *stream);

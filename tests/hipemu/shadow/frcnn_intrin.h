@@ -50,14 +50,12 @@ __attribute__((noinline)) static frcnn_f32x16 frcnn_mfma_32x32x16_bf16(uint4 a, 
 static inline void frcnn_pin(float4 &) {}       // (a scheduling constraint on the device; nothing to do on the host)
 static inline void frcnn_pin(float &) {}
 static inline uint32_t frcnn_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
-#ifndef FRCNN_HALF_F16
 static inline void frcnn_split3_pair(float v0, float v1, uint32_t &h, uint32_t &m, uint32_t &l) {
     h = frcnn_pack_bf16x2(v0, v1);
     const float d0 = v0 - __uint_as_float(h << 16), d1 = v1 - __uint_as_float(h & 0xffff0000u);
     m = frcnn_pack_bf16x2(d0, d1);
     l = frcnn_pack_bf16x2(d0 - __uint_as_float(m << 16), d1 - __uint_as_float(m & 0xffff0000u));
 }
-#endif
 
 __attribute__((noinline)) static int frcnn_lds_append(int *ctr) {
     int z = 0;

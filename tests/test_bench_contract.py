@@ -47,7 +47,7 @@ def test_split_product_variant_is_reported_next_to_the_contract_line_not_instead
     b = _bench()
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert 'res["f32_split_products"] = split_variant(' in src and "--no-split-variant" in src
-    assert 'ap.add_argument("--dtype", choices=["f32", "f32s", "bf16"], default="f32"' in src          # the contract line stays on f32
+    assert 'ap.add_argument("--dtype", choices=["f32", "f32s", "bf16", "f16"], default="f32"' in src          # the contract line stays on f32
     traffic, tsrc = b.pmc_traffic("f32s")
     s3 = json.load(open(os.path.join(ROOT, "profiles", "r02_hbm_traffic_pmc_f32s.json")))["_summary"]["conv_f32s_kernel"]
     assert traffic == s3["hbm_bytes_per_launch"] and "f32s" in tsrc

@@ -495,6 +495,8 @@ def test_f16_instantiation_of_the_16_bit_chain(rt):
         P.check_linear_bf16_tiled(r16, 300, 4096, 25088, True)     # fc6
         P.check_linear_bf16_tiled(r16, 300, 116, 4096, False)
         P.check_linear_bf16(r16, 300, 4096, 4096, True)
+        P.check_roi_pool_blk_bf16(r16, 300, 512, 38, 63)           # roi_f16.hip at the benchmark size
+        P.check_roi_pool(r16, R=40, C=64, H=38, W=63)
 
 
 def test_vgg16_f16_forward(rt):

@@ -273,7 +273,9 @@ def test_f16_instantiation_of_the_16_bit_chain(rt):
     assert r16.half == "f16" and rt.half == "bf16" and r16.lib is rt.lib
     with P.half_format("f16"):
         x = np.array([1.0, 1.0 + 2.0 ** -11, 1.0 + 3 * 2.0 ** -11, 65504.0, 70000.0, 6e-8, -2.5], np.float32)     # ties to even; overflow -> Inf; the smallest subnormal
-        assert np.array_equal(P.host(rt, r16.to_bf16(P.dev(rt, x))), x.astype(np.float16).view(np.int16))
+        with np.errstate(over="ignore"):
+            want_bits = x.astype(np.float16).view(np.int16)
+        assert np.array_equal(P.host(rt, r16.to_bf16(P.dev(rt, x))), want_bits)
         P.check_conv_bf16(r16, 19, 70, 9, 37)                     # ragged channels, conv_dma kernel
         P.check_conv_bf16(r16, 32, 64, 7, 11, ksize=1, relu=False)
         P.check_conv_bf16_pool(r16, 16, 64, 9, 37)
@@ -283,6 +285,8 @@ def test_f16_instantiation_of_the_16_bit_chain(rt):
         P.check_rpn_heads_bf16(r16, 64, 7, 9)
         P.check_conv1_pair_bf16(r16, 12, 40)
         P.check_conv_bf16_strip(r16, 910, 128, 64, 20, 64)        # form D, direct stores
+        P.check_roi_pool_blk_bf16(r16, 9, 16, 12, 17)             # csrc/roi_f16.hip: pooling straight from the blocked fp16 map (fp32 and fp16 outputs)
+        P.check_roi_pool(r16, R=12, C=16, H=12, W=17)             # ... and the fp32-in / fp16-out form among check_roi_pool's output forms
 
 
 def test_conv_relu_pool_fused(rt):
