@@ -74,8 +74,8 @@ def pmc_traffic(dtype):
     WRITE_SIZE in separate rocprofv3 --pmc runs); counters cannot be read from inside the process, so the bench line carries
     the last measured figure and names its source, or null when no PMC pass exists for this dtype."""
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    cands = {"f32": ["r05_hbm_traffic_pmc.json", "r04_hbm_traffic_pmc.json", "r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"],
-             "bf16": ["r05_hbm_traffic_pmc_bf16.json", "r04_hbm_traffic_pmc_bf16.json", "r03_hbm_traffic_pmc_bf16.json", "r02_hbm_traffic_pmc_bf16.json"],
+    cands = {"f32": ["r06_hbm_traffic_pmc.json", "r05_hbm_traffic_pmc.json", "r04_hbm_traffic_pmc.json", "r03_hbm_traffic_pmc.json", "r02_hbm_traffic_pmc.json", "r01_hbm_traffic_pmc.json"],
+             "bf16": ["r06_hbm_traffic_pmc_bf16.json", "r05_hbm_traffic_pmc_bf16.json", "r04_hbm_traffic_pmc_bf16.json", "r03_hbm_traffic_pmc_bf16.json", "r02_hbm_traffic_pmc_bf16.json"],
              "f32s": ["r03_hbm_traffic_pmc_f32s.json", "r02_hbm_traffic_pmc_f32s.json"], "f16": []}[dtype]      # (no PMC pass of the fp16 twins: same kernels, same bytes as bf16)
     kernel = {"f32": "conv_mfma_f32_kernel", "bf16": "conv_bf16_kernel", "f32s": "conv_f32s_kernel", "f16": "conv_bf16_kernel"}[dtype]
     for name in cands:
@@ -1140,7 +1140,7 @@ def main():
             res["roofline"] = {"bound": "mfma", "achieved": conv_tf, "peak": peak, "unit": "TFLOP/s",
                                "frac": conv_tf / peak, "traffic": traffic, "traffic_source": traffic_src,
                                "kernel": ("conv_f32s_kernel (14 launches/image: 13 VGG-16 convs + rpn_conv_3x3)" if args.dtype == "f32s" else
-                                          "conv_mfma_f32_kernel (14 launches/image: 13 VGG-16 convs + rpn_conv_3x3)" if args.dtype == "f32" else
+                                          "conv1_f32s_kernel<..F32> (conv1_1, native fp32) + conv_mfma_f32_kernel (13 launches: conv1_2 ... conv5_3 + rpn_conv_3x3): 14 launches/image" if args.dtype == "f32" else
                                           ("bf16 conv chain: conv1_pair_pc_bf16_kernel (conv1_1 + conv1_2 + pool1) + conv_dma_bf16_kernel / conv_strip_bf16_kernel, 13 launches/image"
                                            if model.trunk.conv1_pair_applies() else
                                            "bf16 conv chain: conv1_f32s_kernel + conv_dma_bf16_kernel / conv_strip_bf16_kernel, 14 launches/image")),

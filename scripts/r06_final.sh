@@ -27,13 +27,14 @@ if has mfma; then
   # torch-free harness, one rocprofv3 --pmc pass; busy fraction = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), written into the file
   ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_INSTS_LDS GRBM_GUI_ACTIVE --output-format csv -d "$R/$O/mfma_f32" -o m -- bash -c "cd $R && ./scripts/micro/_bin/conv_f32_micro conv3_2 conv4_2 conv5_1" > "$R/$O/mfma_f32.log" 2>&1; echo "mfma f32 pmc rc=$?" )
   python - "$O" <<'PY'
-import csv, glob, sys, collections, json
+import csv, glob, re, sys, collections, json
 O = sys.argv[1]
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, set()]))
 for f in glob.glob(O + "/mfma_f32/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if "conv_mfma_f32_kernel" in r["Kernel_Name"]:
-            key = r["Kernel_Name"].split("(")[0][-60:] + " grid " + r.get("Grid_Size", "?")
+            m = re.search(r"conv_mfma_f32_kernel<[^>]*>", r["Kernel_Name"])
+            key = (m.group(0) if m else "conv_mfma_f32_kernel") + " grid " + r.get("Grid_Size", "?") + " lds " + r.get("LDS_Block_Size", "?")
             a = acc[key][r["Counter_Name"]]; a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
 out = {}
 for key, ctrs in acc.items():

@@ -31,13 +31,13 @@ def test_algorithmic_work_matches_design():
 def test_pmc_traffic_comes_from_the_committed_profile():
     b = _bench()
     traffic, src = b.pmc_traffic("f32")
-    summary = json.load(open(os.path.join(ROOT, "profiles", "r05_hbm_traffic_pmc.json")))["_summary"]           # the newest committed pass wins
-    assert traffic == summary["conv_mfma_f32_kernel"]["hbm_bytes_per_launch"] and "profiles/r05_hbm_traffic_pmc.json" in src
+    summary = json.load(open(os.path.join(ROOT, "profiles", "r06_hbm_traffic_pmc.json")))["_summary"]           # the newest committed pass wins
+    assert traffic == summary["conv_mfma_f32_kernel"]["hbm_bytes_per_launch"] and "profiles/r06_hbm_traffic_pmc.json" in src
     # the guide's gfx950 correction (FETCH_SIZE halves 16-byte-per-lane reads) is applied: corrected = 2 * fetch + write
     c = summary["conv_mfma_f32_kernel"]
     assert abs(c["hbm_bytes_per_launch"] - (2 * c["fetch_bytes_per_launch_raw"] + c["write_bytes_per_launch"])) < 1.0
     traffic16, src16 = b.pmc_traffic("bf16")
-    s16 = json.load(open(os.path.join(ROOT, "profiles", "r05_hbm_traffic_pmc_bf16.json")))["_summary"]["conv_bf16_kernel"]
+    s16 = json.load(open(os.path.join(ROOT, "profiles", "r06_hbm_traffic_pmc_bf16.json")))["_summary"]["conv_bf16_kernel"]
     assert traffic16 == s16["hbm_bytes_per_launch"] and "bf16" in src16 and "BEFORE the strip-form" not in src16        # this pass measured the shipped picks
 
 
