@@ -98,8 +98,18 @@ linear_ring_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restri
 #pragma unroll
     for (int q = 0; q < WQ; ++q)
         woff[q] = (uint32_t)(((size_t)nb * KC + c_begin) * kRWBytes + (wave + 4 * q) * 1024 + lane * 16);
+#ifdef FRCNN_TIMING_ABLATIONS
+    float4 xr[XQ];                                                          // (ablation 16: the x pieces as plain 16-byte loads into registers instead of LDS-DMA -- the rate of that path)
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) xr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
     auto issue_piece = [&](int q, int chunk, int stage) {
         unsigned char *dst = ring + stage * STAGE + wave * 1024;
+#ifdef FRCNN_TIMING_ABLATIONS
+        if constexpr ((ABL & 16) != 0) {
+            if (q < XQ) { xr[q] = frcnn_buf_load_f32x4_soff(xbuf, xoff[q], (uint32_t)chunk * (kRK * 2)); return; }
+        }
+#endif
         if (q < XQ) frcnn_buf_load_lds_b128(xbuf, dst + q * 4096, xoff[q], (uint32_t)chunk * (kRK * 2));
         else if (wnt) frcnn_buf_load_lds_b128_nt(wbuf, dst + XBYTES + (q - XQ) * 4096, woff[q - XQ], (uint32_t)chunk * kRWBytes);
         else frcnn_buf_load_lds_b128(wbuf, dst + XBYTES + (q - XQ) * 4096, woff[q - XQ], (uint32_t)chunk * kRWBytes);
@@ -202,6 +212,12 @@ linear_ring_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restri
         read_frags(st, 1);
         __builtin_amdgcn_sched_barrier(0);
         kstep(0, QB, QA, c - 1 + NS, s_prev);
+#ifdef FRCNN_TIMING_ABLATIONS
+        if constexpr ((ABL & 16) != 0) {                                    // the registers loaded one iteration ago are "used" here (their wait is the compiler's)
+#pragma unroll
+            for (int q = 0; q < XQ; ++q) asm volatile("" ::"v"(xr[q].x), "v"(xr[q].y), "v"(xr[q].z), "v"(xr[q].w));
+        }
+#endif
         if constexpr ((ABL & 8) == 0) {
             if constexpr ((ABL & 1) == 0) frcnn_wait_vmcnt<(NS - 2) * PPW>();
             frcnn_barrier_nofence();
@@ -330,7 +346,7 @@ int frcnn_linear_bf16_tiled(const uint16_t *x, const uint16_t *w_tiled, const fl
     if (p.mt == 5 && abl) {
         switch (abl) {
 #define RING_ABL(A) case A: hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_ring_bf16_kernel<5, 5, A>), grid, dim3(256), 0, stream, x, w_tiled, part, M, N, K, p.splits, p.cps, flags); break;
-        RING_ABL(1) RING_ABL(2) RING_ABL(3) RING_ABL(4) RING_ABL(5) RING_ABL(6) RING_ABL(7) RING_ABL(8) RING_ABL(9) RING_ABL(12) RING_ABL(15)
+        RING_ABL(1) RING_ABL(2) RING_ABL(3) RING_ABL(4) RING_ABL(5) RING_ABL(6) RING_ABL(7) RING_ABL(8) RING_ABL(9) RING_ABL(12) RING_ABL(15) RING_ABL(16) RING_ABL(22) RING_ABL(18) RING_ABL(20)
 #undef RING_ABL
         default: return FRCNN_ERR_INVALID;
         }
