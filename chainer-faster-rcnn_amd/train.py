@@ -636,9 +636,15 @@ class RCNNTrainer(_BucketedAllReduce):
             if on_device:                                            # one launch: mask drawn, stored and applied
                 # one counter per FORWARD (two draws each) -- not per update: forward_backward twice without update() must not reuse its masks -- and
                 # the data-parallel rank folded in: every rank draws its own masks from one dropout_seed
-                self._dropout_calls = getattr(self, "_dropout_calls", 0) + 1
+                # the stream is a function of (dropout_seed, rank, iteration, forward-within-iteration) -- a trainer rebuilt mid-run (resume: `iteration`
+                # comes back from the snapshot) continues the mask sequence instead of replaying step 0's; the within-iteration index resets when update() advances
+                # `iteration`
+                if getattr(self, "_dropout_iter", None) != self.iteration:
+                    self._dropout_iter, self._dropout_fwd = self.iteration, 0
+                fwd = self._dropout_fwd
+                self._dropout_fwd += 1
                 rank = int(getattr(getattr(self, "comm", None), "rank", 0) or 0)
-                base = (self.dropout_seed * 0x100000001b3 + rank * 0x9E3779B97F4A7C15 + 2 * (self._dropout_calls - 1)) & 0xFFFFFFFFFFFFFFFF
+                base = (self.dropout_seed * 0x100000001b3 + rank * 0x9E3779B97F4A7C15 + (int(self.iteration) << 20) + 2 * fwd) & 0xFFFFFFFFFFFFFFFF
                 d6, m6 = rt.dropout(a6, self.dropout_ratio, base)
             else:
                 if masks is None:                                    # F.dropout [chainer-ext]: mask = (rand >= ratio) * 1/(1-ratio)

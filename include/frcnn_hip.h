@@ -466,6 +466,8 @@ int frcnn_add_f32(const float *a, const float *b, size_t n, float *y, void *stre
  * the reference CPU path's numpy.random stream (host masks + frcnn_mul_f32); this entry is the throughput form (ABI v20). */
 int frcnn_dropout_f32(const float *x, size_t n, float ratio, unsigned long long seed, float *mask, float *y, void *stream);
 int frcnn_relu_bwd_f32(float *g, const float *out, size_t n, void *stream);
+/* frcnn_gather_rows_f32 MOVES 4-byte words (plain loads and stores, no arithmetic, no canonicalisation): any 32-bit payload survives bit for bit -- the stage-2 trainer
+ * carries int32 arg-max rows and packed keep / label blobs through it (an arg-max of -1 is a NaN bit pattern as a float).  This is part of the contract. */
 int frcnn_gather_rows_f32(const float *src, const int32_t *idx, int n, int cols, float *dst, void *stream);
 int frcnn_scatter_rows_f32(const float *src, const int32_t *idx, int n, int cols, float *dst, int dst_rows, void *stream);
 int frcnn_maxpool2x2_bwd_f32(const float *x, const float *dy, float *dx, int C, int H, int W, void *stream);

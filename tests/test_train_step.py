@@ -268,6 +268,23 @@ def test_device_dropout_kernel_and_step(rt):
         masks = tuple(rt.mem.to_numpy(v) for v in out["masks"])
         grads.append(rt.mem.to_numpy(tr.G).copy())
     assert np.array_equal(grads[0], grads[1]) and np.abs(grads[0]).max() > 0
+    # the device stream is keyed on (seed, rank, iteration, forward within the iteration) -- a second forward of the same iteration draws fresh masks,
+    # and a trainer REBUILT at iteration k (resume) draws what the original drew at iteration k
+    model, _ = _small_full_model(rt)
+    model.rcnn_train = True
+    tr = RCNNTrainer(model, dropout_rng="device", dropout_seed=3)
+    draws = []
+    for it in (0, 0, 1):
+        tr.iteration = it
+        np.random.seed(11)
+        draws.append(rt.mem.to_numpy(tr.forward_backward(Variable(xg), Variable(info), Variable(gt))["masks"][0]))
+    assert not np.array_equal(draws[0], draws[1]) and not np.array_equal(draws[0], draws[2])
+    model2, _ = _small_full_model(rt)
+    model2.rcnn_train = True
+    tr2 = RCNNTrainer(model2, dropout_rng="device", dropout_seed=3)
+    tr2.iteration = 1
+    np.random.seed(11)
+    assert np.array_equal(rt.mem.to_numpy(tr2.forward_backward(Variable(xg), Variable(info), Variable(gt))["masks"][0]), draws[2])
 
 
 def test_gradient_buckets_tile_the_flat_buffer(rt):

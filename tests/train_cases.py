@@ -335,6 +335,9 @@ def check_rcnn_step(rt, model, params, layers, x, gt, info, feat_stride, seed=0,
             if flips == 0:
                 assert row["device_vs_f64"] <= 5e-3, (k, row)
         print("PARITY_EXCEED %s %s" % (tag, json_dumps({"gradients_beyond_max(1e-3, 2 x torch_fp32_vs_f64)_but_within_5e-3": beyond})))
+        # the stated bar is asserted, not only printed -- at most TWO of the ~34 gradients may sit between it and the 5e-3 cap (measured: conv4_1's weight
+        # gradient, 1.6e-3 against torch's own 3.5e-4: the trunk's ReLU / max-pool / arg-max decisions stay free in this column)
+        assert len(beyond) <= 2, beyond
     else:
         for k in sorted(want):
             scale = max(np.abs(want[k]).max(), 1e-8)
