@@ -1147,6 +1147,9 @@ def main():
                                "algorithmic_tflops": alg_tf,
                                "algorithmic_gflop_per_image": sum(flops.values()) / 1e9, "conv_ms_per_image": conv_ms, "conv_ms_source": conv_src,
                                "algorithmic_bytes_per_launch": sum(conv_algorithmic_bytes(LAYERS, IM_H, IM_W, {"f32": 4, "f32s": 6, "bf16": 2, "f16": 2}[args.dtype]).values()) / 14.0}
+            if args.dtype == "f16":
+                res["roofline"]["kernel"] += (" -- the fp16 instantiation (csrc/conv_f16.hip / conv_f16_pair.hip: the same kernel sources and names compiled with "
+                                              "v_mfma_f32_32x32x16_f16)")
             if args.dtype == "f32s":
                 res["roofline"]["note"] = ("achieved / peak count the bf16 MFMA flops executed (6 per algorithmic product) against the dense bf16 peak; "
                                            "algorithmic_tflops is the fp32 convolution work per second (fp32 MFMA peak: %.1f)" % PEAK_F32_MFMA_TFLOPS)
