@@ -829,7 +829,7 @@ static int launch_conv(const float *x, const float *wp, const float *bias, float
 //       six-workgroup register budget), stream-K (236) below
 //       that (150x250, 75x125, 38x63: the fix-up costs less than a ragged last round; 80 % of the SIMDs would idle at 0.2 rounds).
 //   `two_rows` (the fused ReLU + pool epilogue needs a wave to own a window row pair): 34 / stream-K 230 (8-channel chunks).
-static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows) {
+static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows, bool training = false) {
     if (Cin < 8) return 34;
     const long ntiles = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4) * (Cout / 64);
     const long slots = (long)frcnn_cu_count() * 3;
@@ -837,9 +837,23 @@ static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows) {
     // 128-cout tiles with four accumulators per wave (38, stream-K): -2 ... -4 % on the 300x500 ... 75x125 layers with >= 128 couts
     // (r03: conv3_2 348 -> 335 us, conv4_2 345 -> 333, conv2_2 345 -> 338); the 38x63 maps (80 such tiles) stay on 64-cout tiles
     const bool wide_off = frcnn_tune_is("FRCNN_CONV_WIDE", '0');      // A/B hook
-    if (!wide_off && Cout % 128 == 0 && Cin >= 64 && (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4) * (Cout / 128) >= frcnn_cu_count()) return 238;
-    if (two_rows) return 230;
-    if (ntiles >= 2 * slots) return 46;            // same decomposition, 72 VGPRs: six workgroups per CU (+3 % on the 300x500 maps)
+    const bool big_map = Cout % 128 == 0 && Cin >= 64 && (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4) * (Cout / 128) >= frcnn_cu_count();
+    // `training`: the launch is one of the training step's forms (masked input gradient, fused ReLU + pool with arg-max, un-pooling input gradient): those run NEXT TO the
+    // weight-gradient kernels on a second stream, where round 5's picks (fewer, larger workgroups) stay faster -- RPN step 10.07 vs 10.24 ms, stage 2 11.45 vs 11.74 with the
+    // inference rule applied to them (gpurun_out/r06s)
+    if (frcnn_tune_is("FRCNN_CONV_PICK", '5') || (training && !frcnn_tune_is("FRCNN_CONV_PICK", '6'))) {                       // A/B hook: 5 = round 5's rule everywhere, 6 = round 6's everywhere
+        if (!wide_off && big_map) return 238;
+        if (two_rows) return 230;
+        if (ntiles >= 2 * slots) return 46;
+        return 236;
+    }
+    // Round 6 re-sweep on the shipped (LDS-DMA) kernel, three interleaved repeats per point (profiles/r06_conv_f32_sweep.txt): on the layers the 128-cout rule took,
+    // decomposition 30 with forced stream-K (64 couts x 4 rows, 8-channel chunks, three workgroups per CU: 230) is 2 % faster than 238 (conv3_2 329.5 vs 336.2 us,
+    // conv4_1 182.2 vs 186.7, conv4_2 328.1 vs 334.4, conv3_1 185.4 vs 188.9), and whole 2-row tiles at six workgroups per CU (46) 4.5 % faster on conv2_1
+    // (185.6 vs 194.5: 4.7 rounds of tiles, nothing to balance).  The 38x63 maps keep 236.
+    if (ntiles >= 2 * slots && !two_rows) return 46;
+    if (two_rows) return (!wide_off && big_map && frcnn_tune_is("FRCNN_CONV_PICK", 'w')) ? 238 : 230;
+    if (big_map) return 230;
     return 236;
 }
 
@@ -949,7 +963,7 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
     if (act < 0 || act > 5 || ((act == 2 || act == 3 || act == 5) && !mask) || (ksize != 1 && ksize != 3) || ((act == 4 || act == 5) && ksize != 3)) return FRCNN_ERR_INVALID;
     if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cin * ksize * ksize * Cout * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;
     if (ksize == 1) return launch_conv<1, 2, 2, 1, 1, 32, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, 0, nullptr, 0, stream, mask);
-    const int cfg = pick_conv_config(Cin, Cout, H, W, act == 4 || act == 5);
+    const int cfg = pick_conv_config(Cin, Cout, H, W, act == 4 || act == 5, act == 2 || act == 5);
     const int streamk = cfg / 100;
     switch (cfg % 100) {
         case 34: return launch_conv<3, 2, 2, 1, 2, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
@@ -969,7 +983,7 @@ int frcnn_conv_dgrad_unpool_f32(const float *x, const float *w_packed, const flo
     const float *zero_bias = bias;
     const int act = 6 | (H2 == 2 * H - 1 ? 8 : 0) | (W2 == 2 * W - 1 ? 16 : 0);
     const float *mask = reinterpret_cast<const float *>(argmax);
-    const int cfg = pick_conv_config(Cin, Cout, H, W, false);
+    const int cfg = pick_conv_config(Cin, Cout, H, W, false, true);
     const int streamk = cfg / 100;
     switch (cfg % 100) {
         case 34: return launch_conv<3, 2, 2, 1, 2, 4, true, 4, 0, true>(x, w_packed, zero_bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);

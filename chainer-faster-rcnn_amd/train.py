@@ -727,7 +727,10 @@ class RCNNTrainer(_BucketedAllReduce):
         (trunk_backward_split if self.conv_math == "split" else trunk_backward)(self, list(zip(self.layers, inputs)), gfeat)
         self._dgrad_packed = False
         stage("trunk_bwd")
-        return dict(losses=losses, n_rois=n, keep_inds=keep, masks=(m6, m7), head_acts=(a6, a7))       # head_acts: relu(fc6), relu(fc7) before dropout (the parity tests read the device's ReLU decisions off them)
+        # rois: the (n, 4) proposals THIS step pooled -- a parity test must hand the oracle these, not the proposals of a second, inference-form forward: the
+        # fused conv + ReLU + pool launches of the training forward (act 5) and of the inference forward (act 4) may run different decompositions (round 6:
+        # pick_conv_config), i.e. conv5_3 agrees to the last bits but one, and near-tied proposals can then differ
+        return dict(losses=losses, n_rois=n, keep_inds=keep, masks=(m6, m7), rois=rois, head_acts=(a6, a7))       # head_acts: relu(fc6), relu(fc7) before dropout (the parity tests read the device's ReLU decisions off them)
 
     def update(self):
         self._ensure_adopted()

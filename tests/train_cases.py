@@ -272,7 +272,9 @@ def check_rcnn_step(rt, model, params, layers, x, gt, info, feat_stride, seed=0,
     out = tr.forward_backward(Variable(x), Variable(info), Variable(gt), masks=masks)
     assert out["n_rois"] == n
     keep = rt.mem.to_numpy(out["keep_inds"])
-    rois = rt.mem.to_numpy(model.RPN.proposal_layer.forward_device(prob, bbox, int(info[0][0]), int(info[0][1]))[0])[:n]
+    # the proposals the STEP pooled (not those of the inference-form forward above: the two forwards' fused conv + pool launches may run different decompositions,
+    # so conv5_3 -- and with it a near-tied proposal -- can differ in the last bits; round 6 found 1431 head-ReLU "flips" that were RoIs of another forward)
+    rois = rt.mem.to_numpy(out["rois"])[:n]
     np.random.seed(seed + 1)
     use_gt, ext, keep2 = O.proposal_target_layer(rois, gt)
     assert np.array_equal(keep, keep2)
