@@ -854,7 +854,8 @@ static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows, bool
     if (ntiles >= 2 * slots && !two_rows) return 46;
     if (two_rows) return (!wide_off && big_map && frcnn_tune_is("FRCNN_CONV_PICK", 'w')) ? 238 : 230;
     if (big_map) return 230;
-    return 236;
+    // the 38x63 launches (conv5_x, rpn_conv_3x3): 8-channel chunks on the same 64-cout x 2-row tiles, three workgroups per CU (235): 101.9-103.6 vs 103.2-105.6 us (236)
+    return (Cin % 8 == 0) ? 235 : 236;
 }
 
 }  // namespace
@@ -967,6 +968,7 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
     const int streamk = cfg / 100;
     switch (cfg % 100) {
         case 34: return launch_conv<3, 2, 2, 1, 2, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
+        case 35: return launch_conv<3, 2, 2, 1, 1, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
         case 36: return launch_conv<3, 2, 2, 1, 1, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
         case 46: return launch_conv<3, 2, 2, 1, 1, 4, true, 6, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
         case 38: return launch_conv<3, 2, 2, 2, 2, 4, true, 2, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);

@@ -251,6 +251,8 @@ static LinearPlan plan_linear(int M, int N, int K) {
     const int tiles = p.mblocks * p.nblocks;
     const int kchunks = frcnn_cdiv(K, kBK);
     int splits = frcnn_cdiv(512, tiles);
+    const int forced = frcnn_tune_int("FRCNN_LINEAR_F32_SPLITS", 0);        // A/B hook (scripts/fc_bench.py --splits)
+    if (forced > 0) splits = forced;
     if (splits > kchunks / 4) splits = kchunks / 4;
     if (splits < 1) splits = 1;
     if (splits > 64) splits = 64;

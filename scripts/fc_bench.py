@@ -15,8 +15,15 @@ def main():
     rt = pkg.runtime.default_runtime()
     blk_a = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
     blk_b = torch.empty_like(blk_a)
-    for variant in ("dma", "reg", "dma", "reg"):
-        if variant == "reg":
+    variants = ("dma", "reg", "dma", "reg")
+    if "--splits" in sys.argv:                 # round 6: split-K factor sweep of the LDS-DMA kernel (FRCNN_LINEAR_F32_SPLITS)
+        variants = tuple("s%s" % v for v in sys.argv[sys.argv.index("--splits") + 1].split(",")) * 2
+    for variant in variants:
+        if variant.startswith("s"):
+            _tuning.set("FRCNN_LINEAR_NODMA", None)
+            _tuning.set("FRCNN_LINEAR_F32_SPLITS", None if variant == "s0" else variant[1:])
+            rt._ws.pop("linear", None)
+        elif variant == "reg":
             _tuning.set("FRCNN_LINEAR_NODMA", "1")
         else:
             _tuning.set("FRCNN_LINEAR_NODMA", None)
