@@ -907,6 +907,13 @@ size_t frcnn_conv3x3_workspace_bytes(int Cin, int Cout, int H, int W) {
     }
     FRCNN_CONV_CASES(X)
     X(46, 2, 2, 1, 1, 4, true, 6)
+    X(40, 1, 4, 2, 2, 4, true, 2)
+    X(41, 1, 4, 2, 1, 8, true, 3)
+    X(42, 2, 2, 2, 1, 4, true, 3)
+    X(43, 2, 2, 2, 1, 8, true, 2)
+    X(44, 4, 1, 1, 2, 8, true, 3)
+    X(45, 2, 2, 1, 4, 4, true, 2)
+    X(47, 2, 2, 1, 2, 8, true, 4)
     X(37, 2, 2, 2, 2, 4, true, 3)
     X(38, 2, 2, 2, 2, 4, true, 2)
     X(39, 2, 2, 2, 2, 8, true, 1)
@@ -953,6 +960,17 @@ int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bi
         case 37: return launch_conv<3, 2, 2, 2, 2, 4, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 38: return launch_conv<3, 2, 2, 2, 2, 4, true, 2, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 39: return launch_conv<3, 2, 2, 2, 2, 8, true, 1, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+#ifdef FRCNN_TUNING_FORMS
+        // round 6 sweep candidates (research builds only): LDS-DMA forms of tile shapes the shipped rule never had on that staging
+        case 40: return launch_conv<3, 1, 4, 2, 2, 4, true, 2, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 41: return launch_conv<3, 1, 4, 2, 1, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 42: return launch_conv<3, 2, 2, 2, 1, 4, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 43: return launch_conv<3, 2, 2, 2, 1, 8, true, 2, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 44: return launch_conv<3, 4, 1, 1, 2, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 45: return launch_conv<3, 2, 2, 1, 4, 4, true, 2, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 47: return launch_conv<3, 2, 2, 1, 2, 8, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+        case 48: return launch_conv<3, 2, 2, 1, 2, 8, true, 2, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
+#endif
         default: return FRCNN_ERR_INVALID;
     }
 }
