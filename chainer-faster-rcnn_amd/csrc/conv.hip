@@ -854,8 +854,10 @@ static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows, bool
     if (ntiles >= 2 * slots && !two_rows) return 46;
     if (two_rows) return (!wide_off && big_map && frcnn_tune_is("FRCNN_CONV_PICK", 'w')) ? 238 : 230;
     if (big_map) return 230;
-    // the 38x63 launches (conv5_x, rpn_conv_3x3): 8-channel chunks on the same 64-cout x 2-row tiles, three workgroups per CU (235): 101.9-103.6 vs 103.2-105.6 us (236)
-    return (Cin % 8 == 0) ? 235 : 236;
+    // the 38x63 launches (conv5_x, rpn_conv_3x3) keep 236.  8-channel chunks on the same tiles (235) measured 1 % faster (101.9-103.6 vs 103.2-105.6 us) and are NOT taken:
+    // another summation order in conv5_3 reorders two proposals of the benchmark image whose oracle scores are EQUAL (min_adjacent_score_gap 0: a tie NumPy breaks one way
+    // and the kernel's last bit the other) -- 298 instead of 300 of 300 indices in place from the image, for 5 us per image.  FRCNN_CONV_PICK=8 selects it (A/B).
+    return (Cin % 8 == 0 && frcnn_tune_is("FRCNN_CONV_PICK", '8')) ? 235 : 236;
 }
 
 }  // namespace
