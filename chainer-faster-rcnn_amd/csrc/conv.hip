@@ -829,7 +829,7 @@ static int launch_conv(const float *x, const float *wp, const float *bias, float
 //       six-workgroup register budget), stream-K (236) below
 //       that (150x250, 75x125, 38x63: the fix-up costs less than a ragged last round; 80 % of the SIMDs would idle at 0.2 rounds).
 //   `two_rows` (the fused ReLU + pool epilogue needs a wave to own a window row pair): 34 / stream-K 230 (8-channel chunks).
-static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows, bool training = false) {
+static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows, int training = 0) {       // training: 0 inference form, 1 fused ReLU + pool with arg-max (act 5), 2 input gradient (act 2 / un-pooling)
     if (Cin < 8) return 34;
     const long ntiles = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 4) * (Cout / 64);
     const long slots = (long)frcnn_cu_count() * 3;
@@ -841,7 +841,17 @@ static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows, bool
     // `training`: the launch is one of the training step's forms (masked input gradient, fused ReLU + pool with arg-max, un-pooling input gradient): those run NEXT TO the
     // weight-gradient kernels on a second stream, where round 5's picks (fewer, larger workgroups) stay faster -- RPN step 10.07 vs 10.24 ms, stage 2 11.45 vs 11.74 with the
     // inference rule applied to them (gpurun_out/r06s)
-    if (frcnn_tune_is("FRCNN_CONV_PICK", '5') || (training && !frcnn_tune_is("FRCNN_CONV_PICK", '6'))) {                       // A/B hook: 5 = round 5's rule everywhere, 6 = round 6's everywhere
+    if (training == 2) {                                               // A/B hook: one decomposition (64-cout tiles: 30 / 34 / 35 / 36 / 46, + 100 x stream-K mode) on every input-gradient launch
+        const int forced = frcnn_tune_int("FRCNN_CONV_DGRAD_CFG", 0);
+        const int id = forced % 100;
+        if (forced > 0 && (id == 30 || id == 34 || id == 35 || id == 36 || id == 46)) return forced;
+        // Round 6: the input-gradient launches run NEXT TO the weight-gradient kernels (second stream).  Swept there, inside the step (gpurun_out/r06u): 64-cout x 2-row
+        // tiles at SIX workgroups per CU with forced stream-K (246) -- RPN step 9.83-9.87 ms against 10.03-10.10 with round 5's picks (238 / 236), stage 2 11.28 against 11.48;
+        // 236 / 234 / 230 / 235 / 136 / 146 / 46 all at or above round 5's.  Small workgroups interleave with the other stream's.
+        if (!frcnn_tune_is("FRCNN_CONV_PICK", '5')) return 246;
+    }
+    if (frcnn_tune_is("FRCNN_CONV_PICK", '5') || (training && !frcnn_tune_is("FRCNN_CONV_PICK", '6') &&
+                                                   !(training == 1 && frcnn_tune_is("FRCNN_CONV_PICK", 'a')) && !(training == 2 && frcnn_tune_is("FRCNN_CONV_PICK", 'b')))) {   // (a / b: A/B hooks, one training form on the new rule)                       // A/B hook: 5 = round 5's rule everywhere, 6 = round 6's everywhere
         if (!wide_off && big_map) return 238;
         if (two_rows) return 230;
         if (ntiles >= 2 * slots) return 46;
@@ -984,7 +994,7 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
     if (act < 0 || act > 5 || ((act == 2 || act == 3 || act == 5) && !mask) || (ksize != 1 && ksize != 3) || ((act == 4 || act == 5) && ksize != 3)) return FRCNN_ERR_INVALID;
     if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cin * ksize * ksize * Cout * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;
     if (ksize == 1) return launch_conv<1, 2, 2, 1, 1, 32, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, 0, nullptr, 0, stream, mask);
-    const int cfg = pick_conv_config(Cin, Cout, H, W, act == 4 || act == 5, act == 2 || act == 5);
+    const int cfg = pick_conv_config(Cin, Cout, H, W, act == 4 || act == 5, act == 5 ? 1 : (act == 2 ? 2 : 0));
     const int streamk = cfg / 100;
     switch (cfg % 100) {
         case 34: return launch_conv<3, 2, 2, 1, 2, 4, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
@@ -1005,7 +1015,7 @@ int frcnn_conv_dgrad_unpool_f32(const float *x, const float *w_packed, const flo
     const float *zero_bias = bias;
     const int act = 6 | (H2 == 2 * H - 1 ? 8 : 0) | (W2 == 2 * W - 1 ? 16 : 0);
     const float *mask = reinterpret_cast<const float *>(argmax);
-    const int cfg = pick_conv_config(Cin, Cout, H, W, false, true);
+    const int cfg = pick_conv_config(Cin, Cout, H, W, false, 2);
     const int streamk = cfg / 100;
     switch (cfg % 100) {
         case 34: return launch_conv<3, 2, 2, 1, 2, 4, true, 4, 0, true>(x, w_packed, zero_bias, y, Cin, Cout, H, W, act, streamk, workspace, workspace_bytes, stream, mask);
