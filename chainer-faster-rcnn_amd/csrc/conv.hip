@@ -861,8 +861,15 @@ static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows, int 
     // decomposition 30 with forced stream-K (64 couts x 4 rows, 8-channel chunks, three workgroups per CU: 230) is 2 % faster than 238 (conv3_2 329.5 vs 336.2 us,
     // conv4_1 182.2 vs 186.7, conv4_2 328.1 vs 334.4, conv3_1 185.4 vs 188.9), and whole 2-row tiles at six workgroups per CU (46) 4.5 % faster on conv2_1
     // (185.6 vs 194.5: 4.7 rounds of tiles, nothing to balance).  The 38x63 maps keep 236.
+    if (two_rows && !training) {                                       // A/B hook: one decomposition with two-row waves (30 / 34 / 38, + 100 x stream-K mode) on every fused ReLU + pool inference launch
+        const int forced = frcnn_tune_int("FRCNN_CONV_POOL_CFG", 0);
+        const int id = forced % 100;
+        if (forced > 0 && (id == 30 || id == 34 || (id == 38 && Cout % 128 == 0))) return forced;
+    }
     if (ntiles >= 2 * slots && !two_rows) return 46;
-    if (two_rows) return (!wide_off && big_map && frcnn_tune_is("FRCNN_CONV_PICK", 'w')) ? 238 : 230;
+    // fused ReLU + pool inference launches (conv2_2, conv3_3, conv4_3): 4-channel chunks at four workgroups per CU (234) against 230: 971-972 vs 979-981 us for the three
+    // (238: 1002; whole tiles or stream-K-when-ragged lose 20 % on conv4_3) -- swept through FRCNN_CONV_POOL_CFG
+    if (two_rows) return (!wide_off && big_map && frcnn_tune_is("FRCNN_CONV_PICK", 'w')) ? 238 : (frcnn_tune_is("FRCNN_CONV_PICK", 'p') ? 230 : 234);
     if (big_map) return 230;
     // the 38x63 launches (conv5_x, rpn_conv_3x3) keep 236.  8-channel chunks on the same tiles (235) measured 1 % faster (101.9-103.6 vs 103.2-105.6 us) and are NOT taken:
     // another summation order in conv5_3 reorders two proposals of the benchmark image whose oracle scores are EQUAL (min_adjacent_score_gap 0: a tie NumPy breaks one way
