@@ -874,6 +874,9 @@ static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows, int 
     // the 38x63 launches (conv5_x, rpn_conv_3x3) keep 236.  8-channel chunks on the same tiles (235) measured 1 % faster (101.9-103.6 vs 103.2-105.6 us) and are NOT taken:
     // another summation order in conv5_3 reorders two proposals of the benchmark image whose oracle scores are EQUAL (min_adjacent_score_gap 0: a tie NumPy breaks one way
     // and the kernel's last bit the other) -- 298 instead of 300 of 300 indices in place from the image, for 5 us per image.  FRCNN_CONV_PICK=8 selects it (A/B).
+    // Launches with at most 256 input channels on such small grids (the ResNet bottlenecks' 3x3 convolutions: 64 -> 64 at 150x250, 128 -> 128 at 75x125, 256 -> 256 at 38x63)
+    // do take 235: ResNet-101 +2.4 % (196.4 -> 201.2 img/s in the evidence run that had it everywhere); FRCNN_CONV_PICK=7 keeps 236 on them (A/B).
+    if (Cin % 8 == 0 && Cin <= 256 && !frcnn_tune_is("FRCNN_CONV_PICK", '7')) return 235;
     return (Cin % 8 == 0 && frcnn_tune_is("FRCNN_CONV_PICK", '8')) ? 235 : 236;
 }
 
@@ -1000,7 +1003,26 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
     if (!x || !w_packed || !bias || !y || Cin < 1 || Cout < 1 || H < 1 || W < 1 || (Cout % 64) != 0) return FRCNN_ERR_INVALID;
     if (act < 0 || act > 5 || ((act == 2 || act == 3 || act == 5) && !mask) || (ksize != 1 && ksize != 3) || ((act == 4 || act == 5) && ksize != 3)) return FRCNN_ERR_INVALID;
     if ((size_t)Cin * H * W * 4 >= (1ull << 31) || (size_t)Cin * ksize * ksize * Cout * 4 >= (1ull << 31)) return FRCNN_ERR_INVALID;
-    if (ksize == 1) return launch_conv<1, 2, 2, 1, 1, 32, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, 0, nullptr, 0, stream, mask);
+    if (ksize == 1) {
+        // 1x1 convolutions (the ResNet bottlenecks' 70 launches, the FC input gradient of the stage-2 trainer): 64 couts x 2 rows x 32 px, 32-channel chunks, whole tiles.
+        // FRCNN_CONV1X1_CFG = id + 100 x stream-K mode (A/B hook, round 6): 1 = 4-row tiles, 2 = 128 couts x 4 rows, 3 = 16-channel chunks at four workgroups per CU
+        // Round 6 (swept on the ResNet-101 line, gpurun_out/r06v): whole tiles are the best form wherever the grid fills the chip (4-row tiles, 128-cout tiles, 16-channel
+        // chunks: -8 ... -29 %; stream-K everywhere: -1.5 ... -2.5 %), but a launch with FEWER tiles than CUs (1024 -> 256 at 38x63: 152 tiles; res5's 2048 -> 512: 80) is
+        // split over K by forced stream-K: res4 1.917 -> 1.810 ms, res5 0.330 -> 0.273, ResNet-101 196.6 -> 204.1 img/s.  f >= 1000: the threshold in percent of the CU count (A/B).
+        int f = frcnn_tune_int("FRCNN_CONV1X1_CFG", 1100);
+        if (f >= 1000) {
+            const long nt = (long)frcnn_cdiv(W, 32) * frcnn_cdiv(H, 2) * (Cout / 64);
+            f = (nt * 100 <= (long)frcnn_cu_count() * (f - 1000) && workspace) ? 200 : 0;
+        }
+        const int sk = f / 100;
+        switch (f % 100) {
+            case 1: return launch_conv<1, 2, 2, 1, 2, 32, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, sk, workspace, workspace_bytes, stream, mask);
+            case 2: if (Cout % 128 == 0) return launch_conv<1, 2, 2, 2, 2, 32, true, 2, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, sk, workspace, workspace_bytes, stream, mask); break;
+            case 3: return launch_conv<1, 2, 2, 1, 1, 16, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, sk, workspace, workspace_bytes, stream, mask);
+            default: break;
+        }
+        return launch_conv<1, 2, 2, 1, 1, 32, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, sk, sk ? workspace : nullptr, sk ? workspace_bytes : 0, stream, mask);
+    }
     const int cfg = pick_conv_config(Cin, Cout, H, W, act == 4 || act == 5, act == 5 ? 1 : (act == 2 ? 2 : 0));
     const int streamk = cfg / 100;
     switch (cfg % 100) {
