@@ -876,6 +876,11 @@ static int pick_conv_config(int Cin, int Cout, int H, int W, bool two_rows, int 
     // and the kernel's last bit the other) -- 298 instead of 300 of 300 indices in place from the image, for 5 us per image.  FRCNN_CONV_PICK=8 selects it (A/B).
     // Launches with at most 256 input channels on such small grids (the ResNet bottlenecks' 3x3 convolutions: 64 -> 64 at 150x250, 128 -> 128 at 75x125, 256 -> 256 at 38x63)
     // do take 235: ResNet-101 +2.4 % (196.4 -> 201.2 img/s in the evidence run that had it everywhere); FRCNN_CONV_PICK=7 keeps 236 on them (A/B).
+    if (Cin <= 256) {                                                  // A/B hook: one 64-cout decomposition on these launches
+        const int forced = frcnn_tune_int("FRCNN_CONV_SMALL_CFG", 0);
+        const int id = forced % 100;
+        if (forced > 0 && (id == 30 || id == 34 || id == 35 || id == 36 || id == 46) && (Cin % 8 == 0 || (id != 30 && id != 35))) return forced;
+    }
     if (Cin % 8 == 0 && Cin <= 256 && !frcnn_tune_is("FRCNN_CONV_PICK", '7')) return 235;
     return (Cin % 8 == 0 && frcnn_tune_is("FRCNN_CONV_PICK", '8')) ? 235 : 236;
 }
