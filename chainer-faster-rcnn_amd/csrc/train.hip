@@ -1144,7 +1144,10 @@ static WgradPlan plan_wgrad(int Cin, int Cout, int H, int W, int ks) {
         return p;
     }
     // 3x3 double-buffered kernel: one workgroup per CU; the single-buffer forms (1x1, FRCNN_WGRAD_DB=0): about two per CU
-    int s = frcnn_cdiv((ks == 3 && wgrad_double_buffered(Cin, Cout, H, W)) ? frcnn_cu_count() : 2 * frcnn_cu_count(), p.ci_tiles * p.co_tiles);
+    int target = (ks == 3 && wgrad_double_buffered(Cin, Cout, H, W)) ? frcnn_cu_count() : 2 * frcnn_cu_count();
+    const int mul10 = frcnn_tune_int("FRCNN_WGRAD_MUL10", 0);            // A/B hook (round 6): workgroups of the launch = CUs x mul10 / 10 instead of the 1 x / 2 x rule
+    if (mul10 > 0) target = frcnn_cu_count() * mul10 / 10;
+    int s = frcnn_cdiv(target, p.ci_tiles * p.co_tiles);
     if (s > p.nblocks) s = p.nblocks;
     if (s < 1) s = 1;
     p.splits = s;
