@@ -766,7 +766,11 @@ static ConvPlan plan_conv(int Cin, int Cout, int H, int W, int blocks_per_cu, in
     p.nchunks = frcnn_cdiv(Cin, CK);
     p.ntiles = p.xtiles * p.ytiles * p.cotiles;
     p.total = (long long)p.ntiles * p.nchunks;
-    const int slots = frcnn_cu_count() * blocks_per_cu;
+    int slots = frcnn_cu_count() * blocks_per_cu;
+    {
+        const int pct = frcnn_tune_int("FRCNN_CONV_SK_SLOTS_PCT", 0);    // A/B hook (round 6): workgroups of a stream-K launch = pct % of (CUs x resident workgroups per CU)
+        if (pct > 0 && streamk) slots = slots * pct / 100 > 0 ? slots * pct / 100 : 1;
+    }
     // stream-K only pays when whole-tile scheduling would leave a ragged last round
     p.G = (streamk && p.ntiles > slots && p.total >= slots) ? slots : p.ntiles;
     if (streamk == 2 && p.total >= slots) p.G = slots;          // forced (tests / tuning)
