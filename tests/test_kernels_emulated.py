@@ -253,7 +253,7 @@ def test_linear_bf16(rt):
 def test_linear_bf16_tiled(rt):
     """The weight-stream kernel (csrc/linear_bf16.hip) on the host emulator: splits shorter and longer than the ring (prologue / steady state / tail
     each taken), ragged M and N, all three row-tile forms, two row blocks."""
-    P.check_linear_bf16_tiled(rt, 300, 140, 32 * 23, True)         # MT 5 (320 rows), 23 chunks: prologue + steady state + tail; N ragged (two column blocks)
+    P.check_linear_bf16_tiled(rt, 300, 140, 32 * 12, True)         # MT 5 (320 rows), 12 chunks: prologue + seven steady-state iterations + tail; N ragged (two column blocks)
     P.check_linear_bf16_tiled(rt, 100, 130, 32 * 3, False, seed=2)  # MT 3, three chunks: shorter than the ring
     P.check_linear_bf16_tiled(rt, 20, 40, 32, True, seed=3)         # MT 1, ONE chunk
     P.check_linear_bf16_tiled(rt, 330, 128, 32 * 6, False, seed=4)  # two row blocks, exactly NS + 1 chunks
@@ -262,7 +262,7 @@ def test_linear_bf16_tiled(rt):
 def test_linear_bf16_tiled_with_late_landing(rt, monkeypatch):
     """The same with every LDS-DMA piece landing only at the wait that covers it (HIPEMU_DMA_DEFER): a miscounted vmcnt reads a stage before it has arrived."""
     monkeypatch.setenv("HIPEMU_DMA_DEFER", "1")
-    P.check_linear_bf16_tiled(rt, 300, 140, 32 * 23, True)
+    P.check_linear_bf16_tiled(rt, 300, 128, 32 * 8, True)
     P.check_linear_bf16_tiled(rt, 70, 128, 32 * 9, False, seed=5)
 
 
