@@ -991,8 +991,9 @@ int frcnn_conv3x3_f32_cfg(const float *x, const float *w_packed, const float *bi
         case 37: return launch_conv<3, 2, 2, 2, 2, 4, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 38: return launch_conv<3, 2, 2, 2, 2, 4, true, 2, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 39: return launch_conv<3, 2, 2, 2, 2, 8, true, 1, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
-#ifdef FRCNN_TUNING_FORMS
-        // round 6 sweep candidates (research builds only): LDS-DMA forms of tile shapes the shipped rule never had on that staging
+#ifdef FRCNN_SWEEP_FORMS
+        // round 6 sweep candidates (MICRO_CONV_F32_FORMS=1 scripts/micro/build_micro.sh only -- not the product, not the emulator / ISA listings): LDS-DMA forms of tile
+        // shapes the shipped rule never had on that staging; all measured at or behind the shipped picks (profiles/r06_conv_f32_sweep.txt)
         case 40: return launch_conv<3, 1, 4, 2, 2, 4, true, 2, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 41: return launch_conv<3, 1, 4, 2, 1, 8, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
         case 42: return launch_conv<3, 2, 2, 2, 1, 4, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, relu, streamk, workspace, workspace_bytes, stream);
@@ -1024,12 +1025,16 @@ int frcnn_conv_f32_ex(const float *x, const float *w_packed, const float *bias, 
             f = (nt * 100 <= (long)frcnn_cu_count() * (f - 1000) && workspace) ? 200 : 0;
         }
         const int sk = f / 100;
+#ifdef FRCNN_SWEEP_FORMS                                                       // the three losing tile forms of the round-6 sweep (-8 ... -29 % on the ResNet-101 line): sweep builds only
         switch (f % 100) {
             case 1: return launch_conv<1, 2, 2, 1, 2, 32, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, sk, workspace, workspace_bytes, stream, mask);
             case 2: if (Cout % 128 == 0) return launch_conv<1, 2, 2, 2, 2, 32, true, 2, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, sk, workspace, workspace_bytes, stream, mask); break;
             case 3: return launch_conv<1, 2, 2, 1, 1, 16, true, 4, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, sk, workspace, workspace_bytes, stream, mask);
             default: break;
         }
+#else
+        if (f % 100 != 0) return FRCNN_ERR_INVALID;                          // a form this build does not carry: refused, never substituted
+#endif
         return launch_conv<1, 2, 2, 1, 1, 32, true, 3, 0, true>(x, w_packed, bias, y, Cin, Cout, H, W, act, sk, sk ? workspace : nullptr, sk ? workspace_bytes : 0, stream, mask);
     }
     const int cfg = pick_conv_config(Cin, Cout, H, W, act == 4 || act == 5, act == 5 ? 1 : (act == 2 ? 2 : 0));

@@ -36,9 +36,9 @@ if [ "${MICRO_ABL_LIB:-0}" = "1" ]; then
   echo built-abl
 fi
 echo built
-# research build of the fp32 convolution alone (-DFRCNN_TUNING_FORMS: the round-6 sweep candidates 40..48 of frcnn_conv3x3_f32_cfg) + the same harness against it: opt-in
+# research build of the fp32 convolution alone (-DFRCNN_SWEEP_FORMS: the round-6 sweep candidates 40..48 of frcnn_conv3x3_f32_cfg and the 1x1 tile forms of FRCNN_CONV1X1_CFG) + the same harness against it: opt-in
 if [ "${MICRO_CONV_F32_FORMS:-0}" = "1" ]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -w -DFRCNN_TUNING_FORMS -I include -I chainer-faster-rcnn_amd/csrc -shared chainer-faster-rcnn_amd/csrc/conv.hip chainer-faster-rcnn_amd/csrc/conv_f32s.hip chainer-faster-rcnn_amd/csrc/abi.hip -o scripts/micro/_bin/libconv_forms.so
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -w -DFRCNN_TUNING_FORMS -DFRCNN_SWEEP_FORMS -I include -I chainer-faster-rcnn_amd/csrc -shared chainer-faster-rcnn_amd/csrc/conv.hip chainer-faster-rcnn_amd/csrc/conv_f32s.hip chainer-faster-rcnn_amd/csrc/abi.hip -o scripts/micro/_bin/libconv_forms.so
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip scripts/micro/conv_f32_micro.cpp -I include -L scripts/micro/_bin -lconv_forms -Wl,-rpath,'$ORIGIN' -o scripts/micro/_bin/conv_f32_micro_forms
   echo built-conv-forms
 fi
