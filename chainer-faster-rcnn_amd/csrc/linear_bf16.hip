@@ -60,7 +60,11 @@ linear_tile_w_bf16_kernel(const uint16_t *__restrict__ w, int N, int K, uint16_t
 #ifdef FRCNN_TIMING_ABLATIONS
 __device__ __forceinline__ void ring_keep(const uint4 &v) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); }
 #endif
-template <int MT, int NS, int ABL = 0>
+// TRN (round 6, the default where N % 4 == 0): the MFMA's operands swapped -- A = the weight fragment, B = the x fragment: the accumulator tile is the
+// TRANSPOSE (register r of lane l = output COLUMN (r & 3) + 8 (r >> 2) + 4 khalf of output ROW l31), the same sixteen products per element summed by the same
+// instruction, so four consecutive registers are four consecutive floats of one slab row and the partial tile leaves as 40 sixteen-byte stores per lane
+// instead of 160 four-byte ones.
+template <int MT, int NS, int ABL = 0, bool TRN = false>
 __global__ void __launch_bounds__(256)
 linear_ring_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restrict__ wt, float *__restrict__ part, int M, int N, int K, int splits, int cps, int flags) {
     constexpr int BM = 64 * MT, XQ = MT, WQ = 2, PPW = XQ + WQ;
@@ -181,7 +185,7 @@ linear_ring_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restri
 #ifdef FRCNN_TIMING_ABLATIONS
                 if constexpr ((ABL & 4) != 0) { ring_keep(fa[ks][i]); ring_keep(fb[ks][j]); } else
 #endif
-                acc[i * 2 + j] = frcnn_mfma_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i * 2 + j]);
+                acc[i * 2 + j] = TRN ? frcnn_mfma_32x32x16_bf16(fb[ks][j], fa[ks][i], acc[i * 2 + j]) : frcnn_mfma_32x32x16_bf16(fa[ks][i], fb[ks][j], acc[i * 2 + j]);
                 const int m = i * 2 + j;
                 if (npieces > 0 && (ABL & 1) == 0) {
                     const int p0 = m * npieces / NM, p1 = (m + 1) * npieces / NM;          // folds: m and npieces are compile-time at every call site
@@ -261,6 +265,26 @@ linear_ring_bf16_kernel(const uint16_t *__restrict__ x, const uint16_t *__restri
     // partial tile -> this split's slab (register r of lane l = row (r & 3) + 8 (r >> 2) + 4 khalf, column l31: 128-byte runs of a row); straight-line
     // buffer stores, rows past M / columns past N get an out-of-range offset and store nothing
     const frcnn_buf_t pbuf = frcnn_make_buf(part + (size_t)split * M * N, (uint32_t)((size_t)M * N * 4));
+    if constexpr (TRN) {
+        // transposed accumulators: lane = slab row m, registers 4 g .. 4 g + 3 = columns n0 + 8 g + 4 khalf .. + 3 (N % 4 == 0: a quad is inside N or outside)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = m0 + (wm * MT + i) * 32 + l31;
+                const int n0 = nb * kRBN + (wn * 2 + j) * 32 + 4 * khalf;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + 8 * g;
+                    const uint32_t off = (m < M && n < N) ? (uint32_t)(m * N + n) * 4u : kBufOob;
+                    const frcnn_f32x16 &a = acc[i * 2 + j];
+                    const float4 v = make_float4(a[4 * g], a[4 * g + 1], a[4 * g + 2], a[4 * g + 3]);
+                    if (flags & 2) frcnn_buf_store_f32x4_soff<16>(pbuf, off, 0u, v);
+                    else frcnn_buf_store_f32x4_soff<0>(pbuf, off, 0u, v);
+                }
+            }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -352,9 +376,16 @@ int frcnn_linear_bf16_tiled(const uint16_t *x, const uint16_t *w_tiled, const fl
         }
     } else
 #endif
-    if (p.mt == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_ring_bf16_kernel<5, 5>), grid, dim3(256), 0, stream, x, w_tiled, part, M, N, K, p.splits, p.cps, flags);
-    else if (p.mt == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_ring_bf16_kernel<3, 6>), grid, dim3(256), 0, stream, x, w_tiled, part, M, N, K, p.splits, p.cps, flags);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_ring_bf16_kernel<1, 6>), grid, dim3(256), 0, stream, x, w_tiled, part, M, N, K, p.splits, p.cps, flags);
+    {
+        const bool trn = (N & 3) == 0 && !(flags & 4);                       // (bit 2 of FRCNN_LINEAR_RING_FLAGS: round 6's first form, 4-byte slab stores -- A/B)
+#define RING_LAUNCH(MT_, NS_) do { \
+            if (trn) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_ring_bf16_kernel<MT_, NS_, 0, true>), grid, dim3(256), 0, stream, x, w_tiled, part, M, N, K, p.splits, p.cps, flags); \
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_ring_bf16_kernel<MT_, NS_, 0, false>), grid, dim3(256), 0, stream, x, w_tiled, part, M, N, K, p.splits, p.cps, flags); } while (0)
+        if (p.mt == 5) RING_LAUNCH(5, 5);
+        else if (p.mt == 3) RING_LAUNCH(3, 6);
+        else RING_LAUNCH(1, 6);
+#undef RING_LAUNCH
+    }
     const size_t total = (size_t)M * N;
     const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(linear_ring_reduce_kernel, dim3(blocks), dim3(256), 0, stream, part, bias, y, M, N, p.splits, relu, out_bf16);

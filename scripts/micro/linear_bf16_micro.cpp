@@ -79,6 +79,21 @@ int main(int argc, char **argv) {
             const double us = time_graph(s, [&](int i) { if (frcnn_linear_bf16_tiled(x, wt, b, y[i % 3], L.M, L.N, L.K, 1, 1, ws2, wsb2, s) != 0) { printf("refused\n"); exit(1); } }, 4);
             printf("[ring] %-14s %4d x %6d x %5d  %7.1f us  %6.0f TFLOP/s  weights %.0f MB at %.2f TB/s\n", L.name, L.M, L.K, L.N, us, gf / us * 1e3, mb, mb / us);
         }
+        if (do_new && getenv("LINEAR_MICRO_REALLOC")) {
+            // which buffer's PLACEMENT decides the kernel's two speeds (round 6: fc6 runs at ~75 or ~84 us from process to process)?  Re-allocate one of
+            // x / tiled weights / slabs behind a pad of a varying size and time again: LINEAR_MICRO_REALLOC = "x" | "w" | "s" | "a" (all three), eight rounds
+            const char *what = getenv("LINEAR_MICRO_REALLOC");
+            std::vector<void *> pads;
+            for (int round = 0; round < 8; ++round) {
+                void *pad; CK(hipMalloc(&pad, (size_t)(round + 1) * 3 * 1024 * 1024 + 4096 * round)); pads.push_back(pad);
+                if (strchr(what, 'x') || strchr(what, 'a')) { uint16_t *x2; CK(hipMalloc(&x2, nx * 2)); CK(hipMemcpy(x2, x, nx * 2, hipMemcpyDeviceToDevice)); CK(hipFree(x)); x = x2; }
+                if (strchr(what, 'w') || strchr(what, 'a')) { uint16_t *w2; CK(hipMalloc(&w2, tb)); CK(hipMemcpy(w2, wt, tb, hipMemcpyDeviceToDevice)); CK(hipFree(wt)); wt = w2; }
+                if (strchr(what, 's') || strchr(what, 'a')) { void *s2; CK(hipMalloc(&s2, wsb2)); CK(hipFree(ws2)); ws2 = s2; }
+                const double us = time_graph(s, [&](int i) { if (frcnn_linear_bf16_tiled(x, wt, b, y[i % 3], L.M, L.N, L.K, 1, 1, ws2, wsb2, s) != 0) { printf("refused\n"); exit(1); } }, 4);
+                printf("[ring realloc %s #%d] %-8s %7.1f us   x %p wt %p slabs %p\n", what, round, L.name, us, (void *)x, (void *)wt, ws2);
+            }
+            for (void *q : pads) CK(hipFree(q));
+        }
         if (do_old && do_new) {                                  // fp32 outputs of both (no ReLU), compared
             frcnn_linear_bf16(x, w, b, yf[0], L.M, L.N, L.K, 0, 0, ws, wsb, s);
             frcnn_linear_bf16_tiled(x, wt, b, yf[1], L.M, L.N, L.K, 0, 0, ws2, wsb2, s);
