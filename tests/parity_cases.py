@@ -1224,6 +1224,12 @@ def check_linear_bf16_tiled(rt, M, N, K, relu, seed=0):
     assert np.abs(y - y0).max() <= 2e-5 * max(np.abs(want).max(), 1e-6)
     y16 = from_bf16_bits(host(rt, rt.linear_bf16_tiled(rt.to_bf16(dev(rt, x)), wt, N, dev(rt, b), relu=relu, out_bf16=True)))
     assert np.all(np.abs(y16 - want) <= np.abs(want) * 2.0 ** -8 + 3e-5 * np.abs(want).max())
+    # the two accumulator orientations of the kernel (default where N % 4 == 0: MFMA operands swapped, 16-byte slab stores; FRCNN_LINEAR_RING_FLAGS bit 2:
+    # round 6's first form, 4-byte stores): the same products summed by the same instruction -- bit for bit
+    from chainer_faster_rcnn_amd import tuning
+    with tuning.override(FRCNN_LINEAR_RING_FLAGS="4"):
+        y4 = host(rt, rt.linear_bf16_tiled(rt.to_bf16(dev(rt, x)), wt, N, dev(rt, b), relu=relu))
+    assert np.array_equal(y4, y)
 
 
 def check_linear_f32s(rt, M, N, K, relu, seed=0):
