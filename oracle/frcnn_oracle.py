@@ -15,7 +15,9 @@ the two native routines (cpu_nms, bbox_overlaps) and RoI pooling are restated in
     Chainer, an un-vendored and un-pinned dependency (README.md:13 "1.22.0+"); the
     reference's tests pin no value at that boundary -> PARITY UNPINNED.  They restate
     Chainer v1's published semantics with torch-CPU fp32 (conv2d / max_pool2d(ceil_mode) /
-    linear) and explicit loops.
+    linear) and explicit loops.  tests/test_oracle_second_witness.py holds a second,
+    torch-free restatement of each (NumPy float64 loops from the same definitions) that has
+    to agree with this one -- a cross-check of the restatement, not a pin to Chainer.
 """
 import ctypes
 import os
