@@ -98,6 +98,10 @@ void _nms(int *keep_out, int *num_out, const float *boxes_host, int boxes_num, i
  *   rois (cap,4) f32 out; probs (cap) f32 out; n_out (1) int32 out; cap = post_nms_top_n if >0 else
  *   min(A*H*W, pre_nms_top_n); rows past n_out are zero-filled so fixed-capacity consumers stay defined
  *   src_index (cap) int32 out or NULL: index of each RoI in the (H*W*A) anchor enumeration (-1 past n_out)
+ * Arithmetic: the reference's operation by operation in float32 (separate multiply and add), with exp(dw), exp(dh) CORRECTLY ROUNDED (double exp, rounded
+ * once).  bbox_transform.py:63-64 calls np.exp on float32, whose value depends on the NumPy build and CPU (a SIMD polynomial of up to 2.5 ulp since 1.17;
+ * libm's expf before): against a correctly rounded exp the RoIs are the reference's bit for bit, against a given host's NumPy they sit within 4 ulp and an
+ * NMS decision whose IoU lies within ~1e-6 of the threshold may fall the other way (tests/test_coord_margins.py).
  */
 size_t frcnn_proposals_workspace_bytes(int A, int H, int W, int pre_nms_top_n);
 int frcnn_proposals(const float *rpn_cls_prob, const float *rpn_bbox_pred, int A, int H, int W,

@@ -77,6 +77,20 @@ def compare_forward(params, info, dbg, dev, layer_tol=1e-3, head_tol=1e-3):
     rep["proposals_index_exact_given_device_maps"] = bool(n == len(p2) and np.array_equal(dev["src_index"][:n], d2["src_index"].astype(np.int32)))
     rep["proposals_scores_exact_given_device_maps"] = bool(n == len(p2) and np.array_equal(dev["probs"][:n], s2.ravel()))
     rep["rois_max_abs_diff_given_device_maps"] = float(np.abs(dev["rois"][:n] - p2).max()) if n == len(p2) and n else None
+    # ... the same with a CORRECTLY ROUNDED float32 exp in bbox_transform_inv (bbox_transform.py:63-64 calls np.exp on float32: NumPy >= 1.17 evaluates it with
+    # a SIMD polynomial of up to 2.5 ulp that differs between CPUs and builds -- a third of the values differ from the rounded double result on this container's
+    # AVX-512 path; the NumPy of the reference's time called libm's expf, which is correctly rounded but for rare cases).  The device computes exp in double and
+    # rounds once, so HERE everything is bit for bit: indices, scores and the RoIs themselves.  Under NumPy's own exp the RoIs sit within 4 ulp and an NMS
+    # decision can flip where |IoU - thresh| is below that noise (tests/test_coord_margins.py measures how far the fixtures are from it).
+    exp_was = O.EXP
+    O.EXP = lambda v: np.exp(np.asarray(v, np.float64)).astype(np.float32)
+    try:
+        p3, s3, d3 = O.proposal_layer(dev["rpn_cls_prob"], dev["rpn_bbox_pred"], info, train=False, return_debug=True)
+    finally:
+        O.EXP = exp_was
+    rep["proposals_index_exact_given_device_maps_rounded_exp"] = bool(n == len(p3) and np.array_equal(dev["src_index"][:n], d3["src_index"].astype(np.int32)))
+    rep["rois_bit_exact_given_device_maps_rounded_exp"] = bool(n == len(p3) and np.array_equal(dev["rois"][:n], p3) and np.array_equal(dev["probs"][:n].ravel(), s3.ravel()))
+    rep["min_abs_iou_minus_thresh_given_device_maps"] = nms_margins(d3["sorted_boxes"], d3["sorted_scores"])[0]
     # ... and from the IMAGE: how many of the device's RoIs are the oracle's own, position by position and as a set
     want_src = dbg["proposal_debug"]["src_index"].astype(np.int64)
     got_src = dev["src_index"][:n].astype(np.int64)
@@ -106,7 +120,10 @@ def compare_forward(params, info, dbg, dev, layer_tol=1e-3, head_tol=1e-3):
     else:
         rep["end_to_end_cls_prob_rel_err"] = None
     worst_feat = max(v for v in (rep["layers_worst"], rep["conv5_3_rel_err"], rep["rpn_cls_prob_rel_err"], rep["rpn_bbox_pred_rel_err"]) if v is not None)
-    rep["ok"] = bool(worst_feat <= layer_tol and rep["proposals_index_exact_given_device_maps"] and rep["pool5_exact"]
+    # (index-exact under the platform-independent exp; under this host's NumPy exp too unless an IoU sits inside the exp's 4-ulp noise of the threshold)
+    exact = rep["proposals_index_exact_given_device_maps_rounded_exp"] and rep["rois_bit_exact_given_device_maps_rounded_exp"] and (
+        rep["proposals_index_exact_given_device_maps"] or rep["min_abs_iou_minus_thresh_given_device_maps"] <= 4e-6)
+    rep["ok"] = bool(worst_feat <= layer_tol and exact and rep["pool5_exact"]
                      and rep["cls_prob_rel_err"] <= head_tol and rep["pred_boxes_rel_err"] <= head_tol)
     rep["tolerances"] = {"features_rel": layer_tol, "head_rel": head_tol, "indices": "bit-exact", "pool5": "bit-exact"}
     return rep
