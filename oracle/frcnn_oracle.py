@@ -217,8 +217,12 @@ class ProposalParams(object):
 def proposal_layer(rpn_cls_prob, rpn_bbox_pred, img_info, train=False, feat_stride=16,
                    anchor_ratios=(0.5, 1, 2), anchor_scales=(8, 16, 32),
                    pre_nms_top_n=None, post_nms_top_n=None, nms_thresh=0.7, min_size=16,
-                   return_debug=False, nms_fn=None, stage_times=None):
+                   return_debug=False, nms_fn=None, stage_times=None, tie_rule=None):
     """models/proposal_layer.py:102-198.  Inputs (1,2A,H,W), (1,4A,H,W) float32, img_info (1,2) int.
+
+    tie_rule: None = the reference's own `argsort()[::-1]` (here and again inside cpu_nms: NumPy's introsort leaves the order of EQUAL scores
+    implementation-defined); "ascending_index" = the one platform-independent refinement of it, which is the HIP path's documented rule -- descending
+    score, every NaN first, ascending anchor index among equals, and NMS visiting the boxes in exactly that order.
 
     Returns (proposals (n,4) f32, fg_probs (n,1) f32) [+ a dict of intermediates].
     nms_fn: a cpu_nms(dets, thresh) callable to use instead of the C restatement (bench.py passes the reference's own
@@ -242,14 +246,23 @@ def proposal_layer(rpn_cls_prob, rpn_bbox_pred, img_info, train=False, feat_stri
     keep0 = filter_boxes(proposals, min_size)                                      # :147
     proposals = proposals[keep0]
     fg = prob[A:].transpose(1, 2, 0).reshape(-1, 1)[keep0]                          # :152-154
-    order = fg.ravel().argsort()[::-1]                                             # :158-165
+    if tie_rule == "ascending_index":
+        sc = fg.ravel()
+        isn = np.isnan(sc)
+        order = np.lexsort((np.arange(len(sc)), np.where(isn, 0.0, -sc.astype(np.float64)), ~isn))
+    else:
+        order = fg.ravel().argsort()[::-1]                                         # :158-165
     if pre > 0:
         order = order[:pre]                                                        # :167-168
     proposals = proposals[order]
     fg = fg[order]
     dets = np.hstack((proposals, fg))
     _t1 = _time.perf_counter()
-    keep = (nms_fn or cpu_nms)(dets, float(nms_thresh))                            # :178
+    if tie_rule == "ascending_index":                                              # cpu_nms.pyx:26 sorts again: hand it strictly decreasing stand-in scores
+        dets_nms = np.hstack((proposals, np.arange(len(fg), 0, -1, dtype=np.float32)[:, None])).astype(np.float32)
+        keep = (nms_fn or cpu_nms)(dets_nms, float(nms_thresh))
+    else:
+        keep = (nms_fn or cpu_nms)(dets, float(nms_thresh))                        # :178
     if stage_times is not None:
         stage_times["decode_sort"] = stage_times.get("decode_sort", 0.0) + (_t1 - _t0)
         stage_times["nms"] = stage_times.get("nms", 0.0) + (_time.perf_counter() - _t1)

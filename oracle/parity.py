@@ -89,7 +89,17 @@ def compare_forward(params, info, dbg, dev, layer_tol=1e-3, head_tol=1e-3):
     finally:
         O.EXP = exp_was
     rep["proposals_index_exact_given_device_maps_rounded_exp"] = bool(n == len(p3) and np.array_equal(dev["src_index"][:n], d3["src_index"].astype(np.int32)))
-    rep["rois_bit_exact_given_device_maps_rounded_exp"] = bool(n == len(p3) and np.array_equal(dev["rois"][:n], p3) and np.array_equal(dev["probs"][:n].ravel(), s3.ravel()))
+    # ... and with EQUAL scores ordered by the kernel's documented rule (ascending anchor index; NumPy's argsort leaves their order implementation-defined, in
+    # ProposalLayer and again inside cpu_nms): fp32 softmax scores of 20 000 anchors tie exactly a dozen times per image, and now and then both boxes of a tied
+    # pair survive NMS (2 of 144 size x seed x dtype cases in profiles/r06_size_sweep.txt) -- the lists then differ by that one swap
+    O.EXP = lambda v: np.exp(np.asarray(v, np.float64)).astype(np.float32)
+    try:
+        p4, s4, d4 = O.proposal_layer(dev["rpn_cls_prob"], dev["rpn_bbox_pred"], info, train=False, return_debug=True, tie_rule="ascending_index")
+    finally:
+        O.EXP = exp_was
+    rep["tied_scores_in_sorted_top"] = int((np.diff(d3["sorted_scores"].ravel()) == 0).sum())
+    rep["rois_bit_exact_given_device_maps_rounded_exp"] = bool(n == len(p4) and np.array_equal(dev["src_index"][:n], d4["src_index"].astype(np.int32))
+                                                               and np.array_equal(dev["rois"][:n], p4) and np.array_equal(dev["probs"][:n].ravel(), s4.ravel()))
     rep["min_abs_iou_minus_thresh_given_device_maps"] = nms_margins(d3["sorted_boxes"], d3["sorted_scores"])[0]
     # ... and from the IMAGE: how many of the device's RoIs are the oracle's own, position by position and as a set
     want_src = dbg["proposal_debug"]["src_index"].astype(np.int64)
@@ -121,8 +131,12 @@ def compare_forward(params, info, dbg, dev, layer_tol=1e-3, head_tol=1e-3):
         rep["end_to_end_cls_prob_rel_err"] = None
     worst_feat = max(v for v in (rep["layers_worst"], rep["conv5_3_rel_err"], rep["rpn_cls_prob_rel_err"], rep["rpn_bbox_pred_rel_err"]) if v is not None)
     # (index-exact under the platform-independent exp; under this host's NumPy exp too unless an IoU sits inside the exp's 4-ulp noise of the threshold)
-    exact = rep["proposals_index_exact_given_device_maps_rounded_exp"] and rep["rois_bit_exact_given_device_maps_rounded_exp"] and (
-        rep["proposals_index_exact_given_device_maps"] or rep["min_abs_iou_minus_thresh_given_device_maps"] <= 4e-6)
+    # (against NumPy's own order of equal scores: the same list, or the same list up to swaps inside groups of EQUAL scores)
+    got_i, want_i = dev["src_index"][:n].astype(np.int64), d3["src_index"].astype(np.int64)
+    swaps_only = bool(n == len(p3) and np.array_equal(np.sort(got_i), np.sort(want_i)) and np.array_equal(dev["probs"][:n].ravel(), s3.ravel()))
+    rep["differs_from_numpy_order_only_inside_tied_scores"] = bool(swaps_only and not rep["proposals_index_exact_given_device_maps_rounded_exp"])
+    exact = rep["rois_bit_exact_given_device_maps_rounded_exp"] and (rep["proposals_index_exact_given_device_maps_rounded_exp"] or swaps_only) and (
+        rep["proposals_index_exact_given_device_maps"] or rep["min_abs_iou_minus_thresh_given_device_maps"] <= 4e-6 or swaps_only)
     rep["ok"] = bool(worst_feat <= layer_tol and exact and rep["pool5_exact"]
                      and rep["cls_prob_rel_err"] <= head_tol and rep["pred_boxes_rel_err"] <= head_tol)
     rep["tolerances"] = {"features_rel": layer_tol, "head_rel": head_tol, "indices": "bit-exact", "pool5": "bit-exact"}

@@ -171,7 +171,40 @@ def check_proposals_golden(rt, case):
     got = host(rt, rois)[:n]
     assert np.allclose(got, want_p, rtol=5e-7, atol=1e-4), (case, np.abs(got - want_p).max())
     assert (host(rt, rois)[n:] == 0).all() and (host(rt, src)[n:] == -1).all()
+    # ... and against the oracle evaluated with that correctly rounded exp (and the kernel's order of equal scores): coordinates bit for bit
+    exp_was = O.EXP
+    O.EXP = lambda v: np.exp(np.asarray(v, np.float64)).astype(np.float32)
+    try:
+        p4, s4, d4 = O.proposal_layer(G["rpn_cls_prob"], G["rpn_bbox_pred"], G["img_info"], train=bool(G["train"]), pre_nms_top_n=pre, post_nms_top_n=post,
+                                      return_debug=True, tie_rule="ascending_index")
+    finally:
+        O.EXP = exp_was
+    assert np.array_equal(got, p4) and np.array_equal(got_src, d4["src_index"].astype(np.int32)), (case, np.abs(got - p4).max())
     return n
+
+
+def check_proposals_tied_scores(rt, fh=14, fw=14, seed=0):
+    """Equal scores (fp32 softmax outputs of 20 000 anchors tie exactly about a dozen times per image; NumPy's argsort leaves their order
+    implementation-defined, in proposal_layer.py:156-157 and again in cpu_nms.pyx:26): the kernels order them by ascending anchor index, in the
+    sort AND in the order NMS visits them -- the oracle's tie_rule="ascending_index".  Scores drawn from EIGHT values, so nearly everything ties."""
+    rs = np.random.RandomState(seed)
+    A = 9
+    fgv = rs.choice(np.linspace(0.1, 0.9, 8).astype(np.float32), size=(A, fh, fw))
+    prob = np.concatenate([1 - fgv, fgv], 0)[None].astype(np.float32)
+    pred = (rs.randn(1, 4 * A, fh, fw) * 0.3).astype(np.float32)
+    info = np.array([[fh * 16, fw * 16]], np.int32)
+    exp_was = O.EXP
+    O.EXP = lambda v: np.exp(np.asarray(v, np.float64)).astype(np.float32)
+    try:
+        for train, (pre, post) in ((False, (6000, 300)), (True, (12000, 2000)), (False, (50, 20))):
+            want_p, want_s, d = O.proposal_layer(prob, pred, info, train=train, pre_nms_top_n=pre, post_nms_top_n=post, return_debug=True, tie_rule="ascending_index")
+            rois, probs, n_out, src = rt.proposals(dev(rt, prob[0]), dev(rt, pred[0]), O.generate_anchors(), 16, fh * 16, fw * 16, 16.0, pre, post, 0.7, want_index=True)
+            n = int(host(rt, n_out)[0])
+            assert n == len(want_p), (n, len(want_p))
+            assert np.array_equal(host(rt, src)[:n], d["src_index"].astype(np.int32))
+            assert np.array_equal(host(rt, probs)[:n], want_s.ravel()) and np.array_equal(host(rt, rois)[:n], want_p)
+    finally:
+        O.EXP = exp_was
 
 
 PROPOSAL_EDGE_TAGS = ("posnan", "negnan", "infs", "negnan_inf", "negnan_train", "deltas")

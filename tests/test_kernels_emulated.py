@@ -67,6 +67,11 @@ def test_proposals_edge_goldens(rt):
     P.check_proposals_edge_goldens(rt)
 
 
+def test_proposals_tied_scores(rt):
+    """Equal scores: ascending anchor index, in the sort and in NMS's visiting order (the oracle's tie_rule="ascending_index"); everything bit for bit."""
+    P.check_proposals_tied_scores(rt)
+
+
 def test_nms_edge_goldens(rt):
     P.check_nms_edge_goldens(rt)
 

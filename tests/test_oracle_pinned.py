@@ -32,6 +32,28 @@ def test_proposal_layer(golden, case):
     assert np.array_equal(s, g["probs"])
 
 
+@pytest.mark.parametrize("case", PROPOSAL_CASES)
+def test_proposal_layer_tie_rule_is_a_refinement(golden, case):
+    """`tie_rule="ascending_index"` (the HIP path's documented order of EQUAL scores) only decides what NumPy's argsort leaves open: on the
+    reference-generated fixtures it returns the reference's lists, and on a constructed tie it returns the lower anchor index first."""
+    g = golden(case)
+    p, s, d = O.proposal_layer(g["rpn_cls_prob"], g["rpn_bbox_pred"], g["img_info"], train=bool(g["train"]), pre_nms_top_n=int(g["pre"]),
+                               post_nms_top_n=int(g["post"]), return_debug=True, tie_rule="ascending_index")
+    assert np.array_equal(p, g["proposals"]) and np.array_equal(s, g["probs"])
+    if case == PROPOSAL_CASES[0]:
+        # a constructed tie: every anchor at 0.25 but two far-apart ones at 0.9, zero deltas (the anchors themselves, clipped)
+        A = g["rpn_cls_prob"].shape[1] // 2
+        fh, fw = g["rpn_cls_prob"].shape[2:]
+        v = np.full(fh * fw * A, 0.25, np.float32)
+        lo, hi = 4, fh * fw * A - 5                      # anchor enumeration index = (y * fw + x) * A + a; both are mid-sized anchors
+        v[lo] = v[hi] = 0.9
+        prob = np.zeros_like(g["rpn_cls_prob"])
+        prob[0, A:] = v.reshape(fh, fw, A).transpose(2, 0, 1)
+        _, _, d2 = O.proposal_layer(prob, np.zeros_like(g["rpn_bbox_pred"]), g["img_info"], train=False, return_debug=True, tie_rule="ascending_index")
+        src = d2["keep0"][d2["order"]]
+        assert src[:2].tolist() == [lo, hi] and np.all(np.diff(src[2:]) > 0)      # the tied pair, then the 0.25 block, both in ascending index
+
+
 def test_cpu_nms(golden):
     g = golden("cpu_nms")
     for tag in ("n6000_t07", "n300_t03", "n1_t07", "n65_t05"):
