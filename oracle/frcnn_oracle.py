@@ -156,15 +156,27 @@ def keep_inside(anchors, img_info):
 
 
 # --------------------------------------------------------------------------- native routines
-def cpu_nms(dets, thresh):
-    """models/cpu_nms.pyx:18-69 (C restatement).  Returns a Python list of indices into dets."""
+def descending_order_ties_by_index(scores):
+    """The one platform-independent refinement of `scores.argsort()[::-1]`: descending score, every NaN first (where NumPy's sort puts them, reversed),
+    ascending index among equal keys -- the order the HIP kernels document (include/frcnn_hip.h).  NumPy's introsort leaves the order of equal keys open."""
+    sc = np.asarray(scores).ravel()
+    isn = np.isnan(sc)
+    return np.lexsort((np.arange(len(sc)), np.where(isn, 0.0, -sc.astype(np.float64)), ~isn))
+
+
+def cpu_nms(dets, thresh, tie_rule=None):
+    """models/cpu_nms.pyx:18-69 (C restatement).  Returns a Python list of indices into dets.
+    tie_rule="ascending_index": visit equal scores in ascending index (see descending_order_ties_by_index) instead of in NumPy's implementation-defined order."""
     dets = np.ascontiguousarray(dets)
     if dets.dtype != np.float32 or dets.ndim != 2:
         raise ValueError("Buffer dtype mismatch, expected 'float32_t'")     # Cython's own error class
     if not isinstance(thresh, float):
         raise TypeError("Argument 'thresh' has incorrect type (expected float)")
     n = dets.shape[0]
-    order = np.ascontiguousarray(dets[:, 4].argsort()[::-1].astype(np.int64))   # cpu_nms.pyx:26
+    if tie_rule == "ascending_index":
+        order = np.ascontiguousarray(descending_order_ties_by_index(dets[:, 4]).astype(np.int64))
+    else:
+        order = np.ascontiguousarray(dets[:, 4].argsort()[::-1].astype(np.int64))   # cpu_nms.pyx:26
     keep = np.empty(max(n, 1), dtype=np.int64)
     k = _lib().oracle_cpu_nms(_p(dets), n, _p(order), float(thresh), _p(keep))
     return [int(v) for v in keep[:k]]
@@ -247,9 +259,7 @@ def proposal_layer(rpn_cls_prob, rpn_bbox_pred, img_info, train=False, feat_stri
     proposals = proposals[keep0]
     fg = prob[A:].transpose(1, 2, 0).reshape(-1, 1)[keep0]                          # :152-154
     if tie_rule == "ascending_index":
-        sc = fg.ravel()
-        isn = np.isnan(sc)
-        order = np.lexsort((np.arange(len(sc)), np.where(isn, 0.0, -sc.astype(np.float64)), ~isn))
+        order = descending_order_ties_by_index(fg)
     else:
         order = fg.ravel().argsort()[::-1]                                         # :158-165
     if pre > 0:
@@ -258,9 +268,8 @@ def proposal_layer(rpn_cls_prob, rpn_bbox_pred, img_info, train=False, feat_stri
     fg = fg[order]
     dets = np.hstack((proposals, fg))
     _t1 = _time.perf_counter()
-    if tie_rule == "ascending_index":                                              # cpu_nms.pyx:26 sorts again: hand it strictly decreasing stand-in scores
-        dets_nms = np.hstack((proposals, np.arange(len(fg), 0, -1, dtype=np.float32)[:, None])).astype(np.float32)
-        keep = (nms_fn or cpu_nms)(dets_nms, float(nms_thresh))
+    if tie_rule == "ascending_index":                                              # cpu_nms.pyx:26 sorts again: the same rule there
+        keep = cpu_nms(dets.astype(np.float32), float(nms_thresh), tie_rule="ascending_index")
     else:
         keep = (nms_fn or cpu_nms)(dets, float(nms_thresh))                        # :178
     if stage_times is not None:

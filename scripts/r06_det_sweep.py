@@ -1,0 +1,52 @@
+"""Round 6 sweep: forward.py:85-101 from a uint8 image of many sizes -- frcnn_preprocess_u8 against the oracle's img_preprocessing, and postprocess.detections (per-class
+NMS 0.3 + confidence cut, frcnn_class_dets + frcnn_nms_batched) against 20 reference cpu_nms calls on the device's own cls_prob / pred_boxes, bit for bit."""
+import numpy as np
+import chainer_faster_rcnn_amd as pkg
+from chainer_faster_rcnn_amd import synthetic
+from chainer_faster_rcnn_amd.models import FasterRCNN
+from chainer_faster_rcnn_amd.postprocess import PIXEL_MEANS, detections, img_preprocessing
+from oracle import frcnn_oracle as O
+
+rt = pkg.runtime.default_runtime()
+params = synthetic.params(seed=1)
+model = FasterRCNN(runtime=rt)
+model.load_params(params)
+bad = 0
+for (h, w) in [(375, 500), (500, 375), (333, 500), (375, 625), (480, 640), (281, 500), (500, 500), (600, 1000), (1200, 1600), (200, 1000), (442, 500), (96, 128)]:
+    for seed in range(3):
+        img = np.random.RandomState(100 * seed + h).randint(0, 256, (h, w, 3)).astype(np.uint8)
+        x_o, scale_o = O.img_preprocessing(img, PIXEL_MEANS)
+        x_d, scale_d = img_preprocessing(img, runtime=rt)
+        same_shape = tuple(x_d.shape) == x_o.shape and scale_d == scale_o
+        pre_err = float(np.abs(rt.mem.to_numpy(x_d) - x_o).max()) if same_shape else float("nan")
+        H, W = x_o.shape[1:]
+        out = model.forward_device(x_d.reshape(1, 3, H, W), H, W)
+        n = int(rt.mem.to_numpy(out["n_out"])[0])
+        cp, pb = rt.mem.to_numpy(out["cls_prob"])[:n], rt.mem.to_numpy(out["pred_boxes"])[:n]
+        res = []
+        for conf in (0.0, 0.05):
+            got = detections(rt.mem.from_numpy(cp), rt.mem.from_numpy(pb), 0.3, conf, im_scale=scale_d, runtime=rt)
+            ok, tot, ties = True, 0, 0
+            explained = 0
+            for c in range(1, cp.shape[1]):
+                d = np.hstack((pb[:, 4 * c:4 * c + 4], cp[:, c:c + 1])).astype(np.float32)
+                ties += int(len(d) - len(np.unique(d[:, 4])))
+                d = d[O.cpu_nms(d, 0.3)]
+                d = d[d[:, -1] >= conf].copy()
+                d[:, :4] /= scale_d
+                if not np.array_equal(got[c], d):
+                    # NumPy's order of EQUAL class scores is implementation-defined (cpu_nms.pyx:26); the kernels' rule: ascending row index
+                    d2 = np.hstack((pb[:, 4 * c:4 * c + 4], cp[:, c:c + 1])).astype(np.float32)
+                    d2 = d2[O.cpu_nms(d2, 0.3, tie_rule="ascending_index")]
+                    d2 = d2[d2[:, -1] >= conf].copy()
+                    d2[:, :4] /= scale_d
+                    tie_explained = np.array_equal(got[c], d2)
+                    ok = ok and tie_explained
+                    explained += int(tie_explained)
+                tot += len(d)
+            res.append((ok, tot, ties, explained))
+        good = same_shape and pre_err <= 2e-4 and all(r[0] for r in res)
+        bad += 0 if good else 1
+        print("%4dx%-4d seed %d -> %dx%d scale %.4f: preprocess max abs err %.2e, n_rois %3d, detections exact (conf 0 / 0.05) %s / %s (%d / %d rows; %d tied class scores; classes equal only under the ascending-index tie rule: %d)%s"
+              % (h, w, seed, H, W, scale_o, pre_err, n, res[0][0], res[1][0], res[0][1], res[1][1], res[0][2], res[0][3] + res[1][3], "" if good else "   <-- MISMATCH"))
+print("MISMATCH cases:", bad)

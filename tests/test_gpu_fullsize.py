@@ -204,6 +204,44 @@ def test_image_to_detections_600x1000(rt):
     assert worst_box <= 5e-2 and worst_score <= 1e-4
 
 
+@pytest.mark.parametrize("h,w,seed", [(500, 375, 0), (333, 500, 1), (1200, 1600, 2), (200, 1000, 1), (96, 128, 0)])
+def test_image_to_detections_other_sizes(rt, h, w, seed):
+    """forward.py:85-101 from uint8 images of other shapes (portrait, a scale that is not a short binary fraction, a down-scaled and an up-scaled image, a
+    200 x 1000 strip that is not rescaled at all): the preprocessed image equals the oracle's, and the detections the device derives from its own class
+    probabilities / boxes are 20 reference cpu_nms calls on those arrays bit for bit -- under NumPy's own order of equal class scores, or, where two RoIs pooled
+    to the same bins and their scores tie (the strip), under the kernels' documented ascending-index order (profiles/r06_det_sweep.txt)."""
+    from chainer_faster_rcnn_amd import synthetic
+    from chainer_faster_rcnn_amd.models import FasterRCNN
+    from chainer_faster_rcnn_amd.postprocess import PIXEL_MEANS, detections, img_preprocessing
+    from oracle import frcnn_oracle as O
+    img = np.random.RandomState(100 * seed + h).randint(0, 256, (h, w, 3)).astype(np.uint8)
+    x_o, scale_o = O.img_preprocessing(img, PIXEL_MEANS)
+    x_d, scale_d = img_preprocessing(img, runtime=rt)
+    assert tuple(x_d.shape) == x_o.shape and scale_d == scale_o
+    assert float(np.abs(rt.mem.to_numpy(x_d) - x_o).max()) <= 2e-4
+    H, W = x_o.shape[1:]
+    model = FasterRCNN(runtime=rt)
+    model.load_params(synthetic.params(seed=1))
+    out = model.forward_device(x_d.reshape(1, 3, H, W), H, W)
+    n = int(rt.mem.to_numpy(out["n_out"])[0])
+    cp, pb = rt.mem.to_numpy(out["cls_prob"])[:n], rt.mem.to_numpy(out["pred_boxes"])[:n]
+    by_rule = 0
+    for conf in (0.0, 0.05):
+        got = detections(rt.mem.from_numpy(cp), rt.mem.from_numpy(pb), 0.3, conf, im_scale=scale_d, runtime=rt)
+        for c in range(1, cp.shape[1]):
+            d = np.hstack((pb[:, 4 * c:4 * c + 4], cp[:, c:c + 1])).astype(np.float32)
+            want = []
+            for rule in (None, "ascending_index"):
+                k = d[O.cpu_nms(d, 0.3, tie_rule=rule)]
+                k = k[k[:, -1] >= conf].copy()
+                k[:, :4] /= scale_d
+                want.append(k)
+            if not np.array_equal(got[c], want[0]):
+                assert len(np.unique(d[:, 4])) < len(d) and np.array_equal(got[c], want[1]), (conf, c)
+                by_rule += 1
+    _report("image_to_detections_%dx%d" % (h, w), {"n_rois": n, "scaled_to": [int(H), int(W)], "classes_equal_only_under_the_index_tie_rule": by_rule})
+
+
 def test_rpn_train_step_600x1000(rt):
     """configs[4] on one GPU: one RPN training step at 600 x 1000 -- loss within 1e-4; every conv weight-gradient KERNEL within 1e-4
     of a float64 accumulation of the very inputs it consumed; every gradient end to end (13 trunk convs, rpn_conv_3x3, both heads)
