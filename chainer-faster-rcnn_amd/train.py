@@ -730,7 +730,9 @@ class RCNNTrainer(_BucketedAllReduce):
         # rois: the (n, 4) proposals THIS step pooled -- a parity test must hand the oracle these, not the proposals of a second, inference-form forward: the
         # fused conv + ReLU + pool launches of the training forward (act 5) and of the inference forward (act 4) may run different decompositions (round 6:
         # pick_conv_config), i.e. conv5_3 agrees to the last bits but one, and near-tied proposals can then differ
-        return dict(losses=losses, n_rois=n, keep_inds=keep, masks=(m6, m7), rois=rois, head_acts=(a6, a7))       # head_acts: relu(fc6), relu(fc7) before dropout (the parity tests read the device's ReLU decisions off them)
+        return dict(losses=losses, n_rois=n, keep_inds=keep, masks=(m6, m7), rois=rois, head_acts=(a6, a7), layer_inputs=list(inputs) + [feat], roi_argmax=argmax)       # head_acts: relu(fc6), relu(fc7) before dropout (the parity tests read the device's ReLU decisions off them)
+        # layer_inputs / roi_argmax: every discrete decision of this step's forward pass (a fused pool's entry is its _PoolArg: the winning cell and the ReLU bit of
+        # every window; an unfused layer's successor input is its post-ReLU map; the arg-max cell of every RoI bin) -- the float64 arbiter of the parity tests imposes them
 
     def update(self):
         self._ensure_adopted()

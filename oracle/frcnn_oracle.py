@@ -792,7 +792,8 @@ def rcnn_loss_grads(cls_score, bbox_pred, labels, targets, delta=1.0):
     return np.float32(lc.item()), np.float32(lb.item()), np.float32(acc), s.grad.numpy(), b.grad.numpy()
 
 
-def rcnn_train_grads(p, x, rois, keep_inds, labels, targets, mask6, mask7, layers=None, spatial_scale=1.0 / 16, delta=1.0, float64=False, head_relu=None):
+def rcnn_train_grads(p, x, rois, keep_inds, labels, targets, mask6, mask7, layers=None, spatial_scale=1.0 / 16, delta=1.0, float64=False, head_relu=None,
+                     trunk_decisions=None, roi_argmax=None):
     """One rcnn_train-mode forward/backward of FasterRCNN (faster_rcnn.py:110-173) given the proposals (rois (R,4)), the
     ProposalTargetLayer output (keep_inds, labels = use_gt_boxes[:, -1], class-wise targets) and the two dropout masks
     (values 0 or 1/(1-ratio) [chainer-ext F.dropout]).  RoI pooling is a custom autograd function over the C oracle.
@@ -802,7 +803,12 @@ def rcnn_train_grads(p, x, rois, keep_inds, labels, targets, mask6, mask7, layer
     RoI pooling then picks its arg-max cells on the float64 map itself (same scan rule) and gathers / scatters in float64.
     head_relu = (r6, r7) boolean (R, hidden) arrays: IMPOSE these ReLU decisions on fc6 / fc7 instead of taking the pass's own (the device's, read off
     its activations: a pre-activation within summation noise of zero may take the other branch there -- one flipped unit moves fc6's bias gradient by
-    that unit's whole upstream gradient); the number of imposed decisions that differ from the pass's own is returned as a third value."""
+    that unit's whole upstream gradient); the number of imposed decisions that differ from the pass's own is returned as a third value.
+    trunk_decisions / roi_argmax (float64 + head_relu only): EVERY discrete decision of another forward pass imposed, as rpn_train_grads_given_decisions does for
+    the RPN step -- trunk_decisions[i] for layers[i]: a boolean (C, H, W) ReLU mask for a convolution that no pool follows, None for one a pool follows, and for a
+    pool a pair (winner, mask): the flat index h * W + w (int64, (C, OH, OW)) of each window's winning cell in the convolution's pre-pool map and "the pooled value is
+    positive" -- ReLU and first-maximum pooling as ONE decision per window; roi_argmax: (R, C, 7, 7) int, the arg-max cell of every RoI bin (-1 = empty bin).
+    What comes out is the exact float64 gradient of the function that pass evaluated; the third value is then a dict of flip counts per decision site."""
     import torch
     F = torch.nn.functional
     dt = torch.float64 if float64 else torch.float32
@@ -838,6 +844,7 @@ def rcnn_train_grads(p, x, rois, keep_inds, labels, targets, mask6, mask7, layer
                         y[r, :, ph, pw] = d[np.arange(C), a]
                         am[r, :, ph, pw] = (a // (we - ws) + hs) * W + (a % (we - ws) + ws)
             assert ((am32 < 0) == (am < 0)).all()
+            RoiPool.last_am = am
             ctx.am, ctx.shape = am, tuple(feat.shape)
             return torch.from_numpy(y)
 
@@ -858,10 +865,44 @@ def rcnn_train_grads(p, x, rois, keep_inds, labels, targets, mask6, mask7, layer
     h = _t(x).to(dt)
     layers = layers or ["conv1_1", "conv1_2", "pool", "conv2_1", "conv2_2", "pool", "conv3_1", "conv3_2", "conv3_3", "pool",
                         "conv4_1", "conv4_2", "conv4_3", "pool", "conv5_1", "conv5_2", "conv5_3"]
-    for l in layers:
-        h = F.max_pool2d(h, 2, 2, ceil_mode=True) if l == "pool" else F.relu(F.conv2d(h, tp["trunk/%s/W" % l], tp["trunk/%s/b" % l], padding=1))
+    site_flips = {}
+    if trunk_decisions is None:
+        for l in layers:
+            h = F.max_pool2d(h, 2, 2, ceil_mode=True) if l == "pool" else F.relu(F.conv2d(h, tp["trunk/%s/W" % l], tp["trunk/%s/b" % l], padding=1))
+    else:
+        assert float64 and head_relu is not None and len(trunk_decisions) == len(layers)
+        pre, npool = None, 0
+        for l, dec in zip(layers, trunk_decisions):
+            if l == "pool":
+                npool += 1
+                winner, mask = dec
+                widx = torch.from_numpy(np.ascontiguousarray(winner, dtype=np.int64))[None]
+                wmask = torch.from_numpy(np.ascontiguousarray(mask, dtype=bool))[None]
+                own_val, own_idx = F.max_pool2d(F.relu(pre.detach()), 2, 2, ceil_mode=True, return_indices=True)
+                own_mask = own_val > 0
+                # a window whose value is zero either way routes no gradient: only windows that are live on one side at least can differ
+                site_flips["pool%d" % npool] = int((((own_idx != widx) & (own_mask | wmask)) | (own_mask != wmask)).sum())
+                h = pre.flatten(2).gather(2, widx.flatten(2)).reshape(widx.shape) * wmask
+                pre = None
+                continue
+            pre = F.conv2d(h, tp["trunk/%s/W" % l], tp["trunk/%s/b" % l], padding=1)
+            if dec is None:
+                continue                                             # ReLU + pool decided together at the pool's entry
+            m = torch.from_numpy(np.ascontiguousarray(dec, dtype=bool)).reshape(pre.shape)
+            site_flips[l] = int((m != (pre.detach() > 0)).sum())
+            h = pre * m
     brois = np.concatenate([np.zeros((len(rois), 1), np.float32), np.asarray(rois, np.float32)], axis=1)
-    pool5 = RoiPool.apply(h, brois)
+    if roi_argmax is None:
+        pool5 = RoiPool.apply(h, brois)
+    else:
+        assert float64
+        am = torch.from_numpy(np.ascontiguousarray(roi_argmax, dtype=np.int64))           # (R, C, 7, 7)
+        with torch.no_grad():
+            own = RoiPool.apply(h.detach(), brois)                                          # (float64 branch: fills RoiPool.last_am)
+        site_flips["roi_argmax"] = int((RoiPool.last_am != am.numpy()).sum())
+        C_ = int(h.shape[1])
+        cidx = torch.arange(C_)[None, :, None, None].expand_as(am)
+        pool5 = h[0].flatten(1)[cidx, am.clamp(min=0)] * (am >= 0)
     flips = 0
     pre6 = F.linear(pool5.reshape(len(rois), -1), tp["fc6/W"], tp["fc6/b"])
     if head_relu is None:
@@ -883,6 +924,9 @@ def rcnn_train_grads(p, x, rois, keep_inds, labels, targets, mask6, mask7, layer
     lc, lb = _torch_rcnn_losses(cls_score[idx], bbox_pred[idx], labels, targets, delta)
     total = lc + lb
     total.backward()
+    if trunk_decisions is not None or roi_argmax is not None:
+        site_flips["fc6_fc7_relu"] = flips
+        return float(total.item()), {k: v.grad.numpy() for k, v in tp.items()}, site_flips
     if head_relu is not None:
         return float(total.item()), {k: v.grad.numpy() for k, v in tp.items()}, flips
     if float64:

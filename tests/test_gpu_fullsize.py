@@ -256,14 +256,30 @@ def test_rpn_train_step_600x1000(rt):
 def test_rcnn_train_step_600x1000(rt):
     """The stage-2 step (train_rcnn.py:35-78) at the size its 13.5 ms figure is measured at (VERDICT r04 missing #5): trunk -> RPN -> 300
     proposals -> ProposalTargetLayer -> RoI pooling with arg-max -> FC head with dropout -> losses -> backward to conv1_1.  Loss within 1e-4 of the oracle's
-    (fp32 AND float64); every gradient judged against the oracle's autograd run in FLOAT64 under the device's own fc6 / fc7 ReLU decisions: ASSERTED within 5e-3
-    (the trunk's ReLU / max-pool / RoI arg-max decisions stay free); which gradients exceed the tighter max(1e-3, 2 x torch_fp32_vs_f64) is REPORTED
-    (PARITY_EXCEED; tests/train_cases.py:check_rcnn_step prints the three-column table); at most 16 head-ReLU decisions may differ from the float64 pass's own; the SGD
-    update bit for bit."""
+    (fp32 AND float64); every gradient judged against the oracle's autograd run in FLOAT64 with EVERY discrete decision of the device's forward pass imposed
+    (trunk ReLU signs and pool winners read off the fused launches' arg-max bytes, the arg-max cell of every RoI bin, the fc6 / fc7 ReLU signs): ASSERTED within
+    1e-4 (round 6; measured ~1e-6) -- the device's arithmetic against the exact gradient of the function it evaluated; with the trunk's decisions left free the
+    distance is REPORTED (PARITY_EXCEED / PARITY_SITE_FLIPS; tests/train_cases.py:check_rcnn_step prints the four-column table) and bounded by 5e-3, or 2e-2 where
+    flips are counted; at most 16 head-ReLU decisions may differ from the float64 pass's own; the SGD update bit for bit."""
     import train_cases as T
     losses, worst = T.check_vgg_rcnn_step(rt, im_h=IM_H, im_w=IM_W, seed=0)
-    print("\nPARITY rcnn_train_600x1000 %s" % json.dumps({"losses": losses, "worst_grad_rel_err_vs_float64_autograd": float(worst)}))
-    assert losses["loss_rcnn"] > 0 and worst <= 5e-3
+    print("\nPARITY rcnn_train_600x1000 %s" % json.dumps({"losses": losses, "worst_grad_rel_err_vs_float64_autograd_given_the_device_decisions": float(worst)}))
+    assert losses["loss_rcnn"] > 0 and worst <= 1e-4
+
+
+@pytest.mark.parametrize("step,im_h,im_w,seed", [("rpn", 800, 600, 1), ("rcnn", 450, 642, 3)])
+def test_train_steps_other_image_sizes(rt, step, im_h, im_w, seed):
+    """Both training steps at sizes other than 600 x 1000 (a portrait 800 x 600 image: 50 x 38 maps, ragged tiles in every fused conv + pool launch and its
+    backward; 450 x 642: odd at three pooling levels), same checks as the 600 x 1000 tests above -- loss, every gradient against the float64 arbiter, the update
+    bit for bit.  (scripts/r06_train_size_sweep.py ran all six step x size combinations: gpurun_out/r06_train_size_sweep.log.)"""
+    import train_cases as T
+    if step == "rpn":
+        losses, worst, _ = T.check_vgg_step(rt, im_h=im_h, im_w=im_w, seed=seed)
+        assert losses["rpn_loss"] > 0
+    else:
+        losses, worst = T.check_vgg_rcnn_step(rt, im_h=im_h, im_w=im_w, seed=seed)
+        assert losses["loss_rcnn"] > 0 and worst <= 1e-4
+    print("\nPARITY %s_train_%dx%d %s" % (step, im_h, im_w, json.dumps({"losses": losses, "worst_grad_rel_err_vs_float64_autograd": float(worst)})))
 
 
 def test_rpn_train_step_600x1000_split_products(rt):
