@@ -726,3 +726,9 @@ def test_conv_wgrad_f32s(rt):
     P.check_conv_wgrad_f32s(rt, 3, 64, 61, 97, seed=1)
     P.check_conv_wgrad_f32s(rt, 128, 256, 75, 125, seed=2)
     P.check_conv_wgrad_f32s(rt, 512, 512, 38, 63, seed=3)
+
+
+def test_trainers_across_image_sizes(rt):
+    """A differently sized image every iteration (what train_rpn.py / train_rcnn.py feed): each step equals a new trainer's, bit for bit."""
+    import train_cases as T
+    assert T.check_trainers_across_image_sizes(rt, sizes=((48, 64), (64, 48), (41, 57), (48, 64), (200, 150), (48, 64))) == 6

@@ -623,3 +623,9 @@ def test_trainer_snapshot_fixture_and_resume(rt, tmp_path):
 def test_rpn_train_step_small_split_products(rt):
     """The same step with the forward and input-gradient convolutions on split tensors (csrc/conv_f32s.hip, training forms)."""
     T.check_small_step(rt, conv_math="split")
+
+
+def test_trainers_across_image_sizes(rt):
+    """A differently sized image every iteration (what train_rpn.py / train_rcnn.py feed): each step equals a new trainer's, bit for bit."""
+    import train_cases as T
+    assert T.check_trainers_across_image_sizes(rt) == 3

@@ -423,3 +423,55 @@ def check_vgg_rcnn_step(rt, im_h=160, im_w=224, seed=0, conv_math="mfma"):
     model = FasterRCNN(runtime=rt)
     model.load_params(params)
     return check_rcnn_step(rt, model, params, LAYERS, x, gt, info, 16, seed, conv_math=conv_math)
+
+
+def check_trainers_across_image_sizes(rt, sizes=((40, 56), (56, 40), (40, 56))):
+    """train_rpn.py / train_rcnn.py feed a differently sized image every iteration (VOC: 600 x 800, 800 x 600, 600 x 901 ...): a trainer that has stepped on other
+    sizes must give, on the next image, exactly what a NEW trainer gives from the same parameters -- workspaces, kept maps and cached state are functions of the
+    current image only.  Both trainers on the narrow trunk; losses bit for bit, the RPN step's gradients bit for bit (every reduction of that step has a fixed
+    order), the stage-2 step's to rounding (its RoI-pooling backward adds with float atomics)."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.train import RPNTrainer, RCNNTrainer
+    rs = np.random.RandomState(5)
+    params = small_params()
+    params.update(small_head_params(rs))
+    images = []
+    for (h, w) in sizes:
+        x = rs.randn(1, 3, h, w).astype(np.float32)
+        gt = P.gt_case(rs, 3, h, w)
+        gt[0, :, 2] = np.minimum(gt[0, :, 0] + rs.uniform(10, 30, 3), w - 1)
+        gt[0, :, 3] = np.minimum(gt[0, :, 1] + rs.uniform(10, 30, 3), h - 1)
+        images.append((x, gt, np.array([[h, w]], dtype=np.int32)))
+
+    def rpn_trainer():
+        return RPNTrainer(build_small(rt, params))
+
+    def rcnn_trainer():
+        model = build_small(rt, params)
+        for n in ("fc6", "fc7", "cls_score", "bbox_pred"):
+            getattr(model, n).set(params[n + "/W"], params[n + "/b"])
+        model.RPN.proposal_layer.RPN_MIN_SIZE = 4
+        model.RPN.proposal_layer._min_size = 4
+        model.rcnn_train = True
+        return RCNNTrainer(model)                                  # masks from NumPy's global stream, re-seeded before every step below
+
+    # one long-lived instance (no update between the steps: the parameters stay a new trainer's) against one new instance per image
+    for tag, make in (("rpn", rpn_trainer), ("rcnn", rcnn_trainer)):
+        old = make()
+        for i, (x, gt, info) in enumerate(images):
+            np.random.seed(100 + i)
+            lo = old.losses_host(old.forward_backward(Variable(x), Variable(info), Variable(gt)))
+            g_old = rt.mem.to_numpy(old.G).copy()
+            new = make()
+            np.random.seed(100 + i)
+            ln = new.losses_host(new.forward_backward(Variable(x), Variable(info), Variable(gt)))
+            assert lo == ln, (tag, i, lo, ln)
+            g_new = rt.mem.to_numpy(new.G)
+            if tag == "rpn":
+                assert np.array_equal(g_old, g_new), (tag, i, float(np.abs(g_old - g_new).max()))
+            else:
+                # the stage-2 backward pass is NOT bit-reproducible from run to run on the GPU: roi_pool_bwd_runs_kernel adds the 300 RoIs' bin gradients into its
+                # LDS planes with float atomics, in whatever order its sixteen waves arrive (include/frcnn_hip.h states it; the reference's CPU loop is RoI-major) --
+                # rounding-level differences (measured 1.4e-6 of the largest entry between two NEW trainers on the same image), nothing size-dependent
+                assert np.abs(g_old - g_new).max() <= 2e-5 * np.abs(g_new).max(), (tag, i, float(np.abs(g_old - g_new).max()))
+    return len(images)
