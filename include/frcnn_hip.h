@@ -160,6 +160,10 @@ int frcnn_roi_pool_fwd_blk_bf16(const uint16_t *x_blk, int C, int H, int W, cons
 int frcnn_roi_pool_fwd(const float *x, int C, int H, int W, const float *rois, int R, int outh, int outw,
                        float spatial_scale, float *y, int32_t *argmax, void *workspace,
                        size_t workspace_bytes, void *stream);
+/* backward (Chainer roi_pooling_2d backward_cpu: dx[c, argmax] += dy over every (roi, c, bin) with argmax >= 0): the sums are accumulated with float atomics
+ * (in LDS planes for maps up to 38 x 64 cells, in memory beyond), so their ORDER -- the reference's loop is RoI-major -- and with it the last bits of dx are
+ * not fixed from run to run (measured: 1.4e-6 of the largest entry between two runs of a stage-2 step; tests/train_cases.py:check_trainers_across_image_sizes).
+ * Every other reduction of the two training steps has a fixed order. */
 int frcnn_roi_pool_bwd(const float *dy, const int32_t *argmax, int R, int C, int H, int W, int outh,
                        int outw, float *dx, void *stream);
 
