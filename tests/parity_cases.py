@@ -1213,6 +1213,33 @@ def check_detections(rt, R=300, ncls=21, seed=0):
         assert np.array_equal(got[c], d), c
         total += len(d)
     assert total > 0
+    # special values through the same path (forward.py:48-58 on whatever the head produced): a NaN class score of either sign ranks first in cpu_nms
+    # (cpu_nms.pyx:26), suppresses what it overlaps, and is then dropped by `>= conf`; +inf passes the cut, -inf does not; a NaN coordinate poisons the IoUs of its
+    # row (cpu_nms.pyx:12-16's max / min are not symmetric in NaN); equal scores: ascending row index (the oracle's tie_rule)
+    prob2, boxes2 = prob.copy(), boxes.copy()
+    prob2[5, 1] = np.float32(np.nan)
+    prob2[9, 2] = np.array([0xFFC00000], np.uint32).view(np.float32)[0]
+    prob2[11, 3], prob2[12, 3] = np.float32(np.inf), np.float32(-np.inf)
+    boxes2[20, 4 * 4] = np.float32(np.nan)
+    boxes2[21, 4 * 5 + 3] = np.float32(np.nan)
+    prob2[30:40, 6] = np.float32(0.75)                                     # ten rows tie
+    boxes2[30:34, 4 * 6:4 * 6 + 4] = boxes2[30, 4 * 6:4 * 6 + 4]           # ... four of them on the same box
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        got = detections(dev(rt, prob2), dev(rt, boxes2), 0.3, 0.5, im_scale=1.6, runtime=rt)
+        for c in range(1, ncls):
+            d = np.hstack((boxes2[:, 4 * c:4 * c + 4], prob2[:, c:c + 1])).astype(np.float32)
+            d = d[O.cpu_nms(d, 0.3, tie_rule="ascending_index")]
+            d = d[d[:, -1] >= 0.5].copy()
+            d[:, :4] /= 1.6
+            assert got[c].shape == d.shape and np.array_equal(got[c].view(np.uint32), d.view(np.uint32)), (c, got[c][:3], d[:3])
+            if c not in (6,):                                              # no ties in this class: NumPy's own order gives the same list
+                e = np.hstack((boxes2[:, 4 * c:4 * c + 4], prob2[:, c:c + 1])).astype(np.float32)
+                e = e[O.cpu_nms(e, 0.3)]
+                e = e[e[:, -1] >= 0.5].copy()
+                e[:, :4] /= 1.6
+                assert np.array_equal(e.view(np.uint32), d.view(np.uint32)), c
 
 
 def check_linear_bf16(rt, M, N, K, relu, seed=0):

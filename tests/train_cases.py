@@ -425,7 +425,7 @@ def check_vgg_rcnn_step(rt, im_h=160, im_w=224, seed=0, conv_math="mfma"):
     return check_rcnn_step(rt, model, params, LAYERS, x, gt, info, 16, seed, conv_math=conv_math)
 
 
-def check_trainers_across_image_sizes(rt, sizes=((40, 56), (56, 40), (40, 56))):
+def check_trainers_across_image_sizes(rt, sizes=((40, 56), (56, 40))):
     """train_rpn.py / train_rcnn.py feed a differently sized image every iteration (VOC: 600 x 800, 800 x 600, 600 x 901 ...): a trainer that has stepped on other
     sizes must give, on the next image, exactly what a NEW trainer gives from the same parameters -- workspaces, kept maps and cached state are functions of the
     current image only.  Both trainers on the narrow trunk; losses bit for bit, the RPN step's gradients bit for bit (every reduction of that step has a fixed
