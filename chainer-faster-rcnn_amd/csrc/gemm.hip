@@ -133,7 +133,11 @@ linear_mfma_f32_kernel(const float *__restrict__ x, const float *__restrict__ w,
 // g) on 16 distinct bank slots.  A lane reads ONE float4 per operand for FOUR MFMA k-steps: lanes 0-31 take group 2j, lanes 32-63
 // group 2j+1, and k-step t of the quad contracts element t of both -- i.e. k = 8j+t and 8j+4+t; A and B use the same map, so the
 // product is the same sum in a different (fixed) order.  4x fewer LDS instructions per MFMA than the b32 fragment reads.
-template <int AM>
+// TRN (round 6; the default where N % 4 == 0, FRCNN_LINEAR_F32_TRN=0 switches it off): the MFMA's operands swapped -- A = the weight value, B = the x value -- so the
+// accumulator tile is the transpose (register r of lane l = output COLUMN (r & 3) + 8 (r >> 2) + 4 khalf of output ROW l31: the same two products per
+// element and k-step, summed by the same instruction) and four consecutive registers are four consecutive floats of one slab row: 16-byte slab stores
+// (csrc/linear_bf16.hip's form; bit-identical results).
+template <int AM, bool TRN = false>
 __global__ void __launch_bounds__(256, 2)
 linear_dma_f32_kernel(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ part, int M, int N, int K,
                       int k_per_split) {
@@ -207,7 +211,7 @@ linear_dma_f32_kernel(const float *__restrict__ x, const float *__restrict__ w, 
                 for (int i = 0; i < AM; ++i) {
                     const float4 aq = a[j & 1][i];
                     const float av = t == 0 ? aq.x : (t == 1 ? aq.y : (t == 2 ? aq.z : aq.w));
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[i], 0, 0, 0);
+                    acc[i] = TRN ? __builtin_amdgcn_mfma_f32_32x32x2f32(bv[t], av, acc[i], 0, 0, 0) : __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[t], acc[i], 0, 0, 0);
                 }
         }
         frcnn_wait_vmcnt<0>();
@@ -215,6 +219,21 @@ linear_dma_f32_kernel(const float *__restrict__ x, const float *__restrict__ w, 
         cur ^= 1;
     }
     float *out = part + (size_t)blockIdx.z * M * N;
+    if constexpr (TRN) {
+        // lane = slab row m, registers 4 g .. 4 g + 3 = columns n0 + 32 wave + 8 g + 4 khalf .. + 3 (N % 4 == 0: a quad lies inside N or outside)
+        const frcnn_buf_t pbuf = frcnn_make_buf(out, (uint32_t)((size_t)M * N * 4));
+#pragma unroll
+        for (int i = 0; i < AM; ++i) {
+            const int m = m0 + 32 * i + l31;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nn = n0 + wave * 32 + 8 * g + 4 * khalf;
+                const uint32_t off = (m < M && nn < N) ? (uint32_t)(m * N + nn) * 4u : kBufOob;
+                frcnn_buf_store_f32x4_soff<0>(pbuf, off, 0u, make_float4(acc[i][4 * g], acc[i][4 * g + 1], acc[i][4 * g + 2], acc[i][4 * g + 3]));
+            }
+        }
+        return;
+    }
     const int n = n0 + wave * 32 + l31;
     if (n < N) {
 #pragma unroll
@@ -283,7 +302,11 @@ int frcnn_linear_f32(const float *x, const float *w, const float *bias, float *y
     float *part = direct ? y : (float *)workspace;
     const dim3 grid(p.nblocks, p.mblocks, p.splits);
     const bool dma = (K % kBK) == 0 && (size_t)M * K * 4 < (1ull << 31) && (size_t)N * K * 4 < (1ull << 31) && !frcnn_tune("FRCNN_LINEAR_NODMA");
-    if (dma && p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_f32_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    const bool trn = dma && (N & 3) == 0 && (size_t)M * N * 4 < (1ull << 31) && frcnn_tune_int("FRCNN_LINEAR_F32_TRN", 1) != 0;      // (A/B hook)
+    if (trn && p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_f32_kernel<5, true>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    else if (trn && p.am == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_f32_kernel<3, true>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    else if (trn) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_f32_kernel<1, true>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
+    else if (dma && p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_f32_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     else if (dma && p.am == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_f32_kernel<3>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     else if (dma) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_dma_f32_kernel<1>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);
     else if (p.am == 5) hipLaunchKernelGGL(HIP_KERNEL_NAME(linear_mfma_f32_kernel<5>), grid, dim3(256), 0, stream, x, w, part, M, N, K, p.k_per_split);

@@ -463,6 +463,11 @@ def check_linear(rt, M, N, K, relu, seed=0, bias=True):
     got = host(rt, rt.linear(dev(rt, x), dev(rt, w), dev(rt, b) if bias else None, relu=relu))
     err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-6)
     assert got.shape == want.shape and err < 1e-4, (M, N, K, err)
+    # the two accumulator orientations of the LDS-DMA kernel (default where N % 4 == 0: MFMA operands swapped, 16-byte slab stores): bit for bit
+    from chainer_faster_rcnn_amd import tuning
+    with tuning.override(FRCNN_LINEAR_F32_TRN="0"):
+        got0 = host(rt, rt.linear(dev(rt, x), dev(rt, w), dev(rt, b) if bias else None, relu=relu))
+    assert np.array_equal(got0, got), (M, N, K)
 
 
 def check_head_decode(rt, R=37, ncls=21, seed=0):
