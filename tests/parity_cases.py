@@ -61,6 +61,27 @@ def check_nms_edges(rt):
     assert O.cpu_nms(d, 0.0) == host(rt, rt.nms(dev(rt, d), 0.0)[0])[:1].tolist() == [2]
 
 
+def check_nms_random_box_sets(rt, sizes=(1, 2, 63, 64, 65, 129), seeds=(0, 1)):
+    """frcnn_nms against cpu_nms.pyx's arithmetic on random box sets: sparse and crowded, scores from a continuum and from seven values (ties everywhere: the
+    kernels visit equal scores in ascending index -- the oracle's tie_rule; without ties NumPy's own order gives the same list), thresholds 0.3 / 0.5 / 0.7.
+    (scripts/r06_nms_sweep.py ran 396 such cases up to n = 12000 on the MI355X.)"""
+    for n in sizes:
+        for seed in seeds:
+            rs = np.random.RandomState(1000 * seed + n)
+            for dens, tied in ((0.3, False), (3.0, True), (30.0, True)):
+                span = max(60.0, np.sqrt(n / dens) * 40.0)
+                xy = rs.uniform(0, span, (n, 2))
+                sc = rs.choice(np.linspace(0.05, 0.95, 7), n) if tied else rs.uniform(0, 1, n)
+                d = np.hstack([xy, xy + rs.uniform(8, 120, (n, 2)), sc[:, None]]).astype(np.float32)
+                for thr in (0.3, 0.5, 0.7):
+                    want = O.cpu_nms(d, thr, tie_rule="ascending_index")
+                    keep, cnt = rt.nms(dev(rt, d), thr)
+                    k = int(host(rt, cnt)[0])
+                    assert host(rt, keep)[:k].tolist() == want, (n, seed, dens, tied, thr)
+                    if len(np.unique(d[:, 4])) == n:
+                        assert O.cpu_nms(d, thr) == want
+
+
 def check_gpu_nms_ffi(rt, tags=("n6000_t07", "n300_t03", "n65_t05", "n1_t07")):
     """`_nms` with the reference's exact C signature (models/gpu_nms.hpp:9-10) through the gpu_nms.pyx-shaped binding: host arrays
     in, list out, equal to the reference's cpu_nms on the reference-generated golden vectors -- including threshold 0.3, where

@@ -732,3 +732,9 @@ def test_trainers_across_image_sizes(rt):
     """A differently sized image every iteration (what train_rpn.py / train_rcnn.py feed): each step equals a new trainer's, bit for bit."""
     import train_cases as T
     assert T.check_trainers_across_image_sizes(rt, sizes=((48, 64), (64, 48), (41, 57), (48, 64), (200, 150), (48, 64))) == 6
+
+
+def test_nms_random_box_sets(rt):
+    """Random box sets, sparse to crowded, with and without tied scores, three thresholds: the reference's keep lists."""
+    P.check_nms_random_box_sets(rt)
+    P.check_nms_random_box_sets(rt, sizes=(1000, 4097, 12000), seeds=(0,))

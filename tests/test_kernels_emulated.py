@@ -578,3 +578,8 @@ def test_vgg16_bf16_trunk_with_the_conv1_pair_launch(rt, monkeypatch):
     col = {}
     trunk(x, collect=col)
     assert "conv1_1" in col and "pool1" in col
+
+
+def test_nms_random_box_sets(rt):
+    """Random box sets, sparse to crowded, with and without tied scores, three thresholds: the reference's keep lists."""
+    P.check_nms_random_box_sets(rt)
