@@ -54,8 +54,14 @@ class AnchorTargetLayer(ProposalLayer):
         rt = self.rt
         gt = rt.asarray(unwrap(gt_boxes), "f32")
         gt = gt[0] if len(gt.shape) == 3 else gt
+        # anchor_target_layer.py:188-190: `overlaps.argmax(axis=1)` / `argmax(axis=0)` on an image without a ground-truth box, or one too small for any anchor
+        # to lie inside it, is NumPy's "attempt to get argmax of an empty sequence" -- the reference raises, so does this
+        if int(gt.shape[0]) == 0:
+            raise ValueError("attempt to get argmax of an empty sequence")
         inds, n_in, labels, targets, _ = rt.anchor_target(self._anchors, int(feat_h), int(feat_w), self._feat_stride, im_h, im_w, gt)
         n = int(rt.mem.to_numpy(n_in)[0])
+        if n == 0:
+            raise ValueError("attempt to get argmax of an empty sequence")
         host_labels = self.subsample(rt.mem.to_numpy(labels[:n]))
         labels = rt.mem.from_numpy(host_labels)
         return labels, targets[:n], inds[:n], n, self._num_anchors * int(feat_h) * int(feat_w)

@@ -539,6 +539,19 @@ def check_anchor_target(rt, fh, fw, im_h, im_w, G, seed=0):
     return n
 
 
+def check_anchor_target_empty_cases(rt):
+    """anchor_target_layer.py:188-190 on an image without ground truth, or too small for any anchor to lie inside: NumPy's ValueError in the reference
+    (checked against the live class: oracle/ref_harness) -- and in the mirror."""
+    import pytest
+    from chainer_faster_rcnn_amd.models.anchor_target_layer import AnchorTargetLayer
+    atl = AnchorTargetLayer(runtime=rt)
+    for gt, fh, fw, im_h, im_w in ((np.zeros((1, 0, 5), np.float32), 14, 14, 224, 224), (np.array([[[10, 10, 50, 50, 1]]], np.float32), 6, 8, 96, 128)):
+        with pytest.raises(ValueError, match="empty sequence"):
+            O.anchor_target_layer(fh, fw, gt, np.array([[im_h, im_w]], np.int32))
+        with pytest.raises(ValueError, match="empty sequence"):
+            atl.forward_device(fh, fw, dev(rt, gt), im_h, im_w)
+
+
 def check_rpn_loss(rt, fh=14, fw=14, im=224, G=3, seed=0):
     rs = np.random.RandomState(seed)
     gt = gt_case(rs, G, im, im)

@@ -738,3 +738,8 @@ def test_nms_random_box_sets(rt):
     """Random box sets, sparse to crowded, with and without tied scores, three thresholds: the reference's keep lists."""
     P.check_nms_random_box_sets(rt)
     P.check_nms_random_box_sets(rt, sizes=(1000, 4097, 12000), seeds=(0,))
+
+
+def test_anchor_target_empty_cases(rt):
+    """No ground-truth box / no anchor inside the image: the reference's ValueError."""
+    P.check_anchor_target_empty_cases(rt)

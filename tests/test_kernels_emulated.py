@@ -583,3 +583,8 @@ def test_vgg16_bf16_trunk_with_the_conv1_pair_launch(rt, monkeypatch):
 def test_nms_random_box_sets(rt):
     """Random box sets, sparse to crowded, with and without tied scores, three thresholds: the reference's keep lists."""
     P.check_nms_random_box_sets(rt)
+
+
+def test_anchor_target_empty_cases(rt):
+    """No ground-truth box / no anchor inside the image: the reference's ValueError."""
+    P.check_anchor_target_empty_cases(rt)
