@@ -629,3 +629,26 @@ def test_trainers_across_image_sizes(rt):
     """A differently sized image every iteration (what train_rpn.py / train_rcnn.py feed): each step equals a new trainer's, bit for bit."""
     import train_cases as T
     assert T.check_trainers_across_image_sizes(rt) == 2
+
+
+def test_an_image_without_proposals_gives_empty_outputs(rt):
+    """An image on which no proposal survives ProposalLayer's min-size filter (proposal_layer.py:146-148: every clipped box is smaller than 16 px): the
+    reference ends with zero RoIs, i.e. (0, 21) / (0, 84) outputs -- so does the mirror's `model(img, img_info)`, through RoI pooling and the head on no rows."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    rs = np.random.RandomState(0)
+    params = T.small_params()
+    params.update(T.small_head_params(rs))
+    model = T.build_small(rt, params)
+    for n in ("fc6", "fc7", "cls_score", "bbox_pred"):
+        getattr(model, n).set(params[n + "/W"], params[n + "/b"])
+    model.rpn_train = False
+    x = rs.randn(1, 3, 8, 8).astype(np.float32)
+    cls_prob, boxes = model(Variable(x), Variable(np.array([[8, 8]], np.int32)))
+    assert tuple(cls_prob.shape) == (0, 21) and tuple(boxes.shape) == (0, 84)
+    out = model.forward_device(rt.mem.from_numpy(x), 8, 8)
+    assert int(rt.mem.to_numpy(out["n_out"])[0]) == 0 and not rt.mem.to_numpy(out["rois"]).any()
+    # the oracle agrees that nothing survives
+    from oracle import frcnn_oracle as O
+    p, s = O.proposal_layer(np.zeros((1, 18, 2, 2), np.float32), np.zeros((1, 36, 2, 2), np.float32), np.array([[8, 8]], np.int32), feat_stride=4,
+                            anchor_scales=(2, 4, 8))
+    assert p.shape == (0, 4)
