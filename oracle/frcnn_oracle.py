@@ -744,6 +744,7 @@ def proposal_target_layer(proposals, gt_boxes, num_classes=21, rng=np.random):
     `rng.choice` is drawn exactly as the reference draws np.random.choice (:107-108, :121-122)."""
     FG_THRESH, BG_HI, BG_LO, ROIS, FG_FRAC = 0.5, 0.5, 0.1, 128, 0.25            # :46-50
     n_fg_rois = int(FG_FRAC * ROIS)
+    assert len(proposals) > 0 and proposals.ndim == 2 and proposals.shape[1] == 4       # :62-64 (_check_data_type_forward; CHAINER_TYPE_CHECK on, the default)
     gt = gt_boxes[0]
     overlaps = bbox_overlaps(np.ascontiguousarray(proposals, dtype=np.float64),
                              np.ascontiguousarray(gt[:, :4], dtype=np.float64))   # anchor_target_layer.py:183-185

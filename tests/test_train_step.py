@@ -652,3 +652,39 @@ def test_an_image_without_proposals_gives_empty_outputs(rt):
     p, s = O.proposal_layer(np.zeros((1, 18, 2, 2), np.float32), np.zeros((1, 36, 2, 2), np.float32), np.array([[8, 8]], np.int32), feat_stride=4,
                             anchor_scales=(2, 4, 8))
     assert p.shape == (0, 4)
+
+
+def test_proposal_target_layer_edge_behaviour(rt):
+    """ProposalTargetLayer where the reference raises or returns nothing (checked against the live class when /root/reference is present: oracle/ref_harness):
+    no ground-truth box -> NumPy's ValueError (argmax of an empty sequence, proposal_target_layer.py:91); no proposal -> the type check's AssertionError (:62); a
+    ground truth that overlaps no proposal by 0.1 -> an EMPTY sample ((0, 5), (0, 84), (0,)) -- mirror, oracle and reference alike."""
+    from chainer_faster_rcnn_amd.chainer_compat import Variable
+    from chainer_faster_rcnn_amd.models.proposal_target_layer import ProposalTargetLayer
+    from oracle import frcnn_oracle as O
+    from oracle import ref_harness as rh
+    rs = np.random.RandomState(0)
+    props = np.abs(rs.randn(20, 4)).astype(np.float32) * 50
+    props[:, 2:] += props[:, :2] + 20
+    gt1 = np.array([[[10, 10, 60, 60, 3]]], np.float32)
+    far = np.array([[[900, 900, 960, 960, 3]]], np.float32)
+    ref = rh.load() if rh.available() else None
+
+    def run(which, p, gt):
+        np.random.seed(1)
+        if which == "mirror":
+            return [rt.mem.to_numpy(o) for o in ProposalTargetLayer(16, [0.5, 1, 2], [8, 16, 32], 21, runtime=rt)(p, Variable(gt))]
+        if which == "oracle":
+            return list(O.proposal_target_layer(p, gt))
+        return list(ref.ProposalTargetLayer(16, [0.5, 1, 2], [8, 16, 32], 21)(p, ref.Variable(gt)))
+    impls = ["mirror", "oracle"] + (["reference"] if ref is not None else [])
+    for which in impls:
+        with pytest.raises(ValueError, match="empty sequence"):
+            run(which, props, np.zeros((1, 0, 5), np.float32))
+        with pytest.raises(AssertionError):
+            run(which, np.zeros((0, 4), np.float32), gt1)
+        out = run(which, props, far)
+        assert [tuple(o.shape) for o in out] == [(0, 5), (0, 84), (0,)], which
+    base = run("oracle", props, gt1)
+    for which in impls:
+        out = run(which, props, gt1)
+        assert all(np.array_equal(a, b) for a, b in zip(out, base)), which
