@@ -336,7 +336,7 @@ def _small_full_model(rt, conv_dtype="f32", head_dtype="f32", seed=0):
     return model, params
 
 
-def _step_inputs(seed=0, h=28, w=40):
+def _step_inputs(seed=0, h=40, w=56):       # (28 x 40 holds no anchor of scale >= 2 entirely: the reference raises there, and since round 6 so does the mirror)
     import parity_cases as P
     rs = np.random.RandomState(seed)
     x = rs.randn(1, 3, h, w).astype(np.float32)
