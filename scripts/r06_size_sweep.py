@@ -12,12 +12,13 @@ from oracle import parity
 rt = pkg.runtime.default_runtime()
 params = synthetic.params(seed=1)
 dtype = sys.argv[1] if len(sys.argv) > 1 else "f32"
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 model = FasterRCNN(runtime=rt, conv_dtype=dtype, head_dtype=dtype)
 model.load_params(params)
 sizes = [(600, 1000), (800, 600), (600, 901), (450, 642), (600, 800), (1000, 600), (224, 224), (600, 600), (562, 1000), (600, 999), (601, 903), (333, 500)]
 bad = 0
 for (h, w) in sizes:
-    for seed in range(3):
+    for seed in range(seed0, seed0 + 3):
         x = synthetic.image(seed=seed, h=h, w=w)
         info = np.array([[h, w]], dtype=np.int32)
         dev = parity.device_forward_host(rt, model, rt.mem.from_numpy(x), h, w)
