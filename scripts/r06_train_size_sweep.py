@@ -6,7 +6,7 @@ import chainer_faster_rcnn_amd as pkg
 import train_cases as T
 
 rt = pkg.runtime.default_runtime()
-cases = [(800, 600, 1), (600, 901, 2), (450, 642, 3)]
+cases = [(800, 600, 1), (600, 901, 2), (450, 642, 3)] if len(sys.argv) < 2 else [(600, 800, 4), (562, 1000, 5), (600, 600, 6), (1000, 600, 7)]
 bad = 0
 for (h, w, seed) in cases:
     for name, fn in (("rpn", T.check_vgg_step), ("rcnn", T.check_vgg_rcnn_step)):
