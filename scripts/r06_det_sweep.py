@@ -1,5 +1,6 @@
 """Round 6 sweep: forward.py:85-101 from a uint8 image of many sizes -- frcnn_preprocess_u8 against the oracle's img_preprocessing, and postprocess.detections (per-class
 NMS 0.3 + confidence cut, frcnn_class_dets + frcnn_nms_batched) against 20 reference cpu_nms calls on the device's own cls_prob / pred_boxes, bit for bit."""
+import sys
 import numpy as np
 import chainer_faster_rcnn_amd as pkg
 from chainer_faster_rcnn_amd import synthetic
@@ -13,7 +14,7 @@ model = FasterRCNN(runtime=rt)
 model.load_params(params)
 bad = 0
 for (h, w) in [(375, 500), (500, 375), (333, 500), (375, 625), (480, 640), (281, 500), (500, 500), (600, 1000), (1200, 1600), (200, 1000), (442, 500), (96, 128)]:
-    for seed in range(3):
+    for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 0, (int(sys.argv[1]) if len(sys.argv) > 1 else 0) + 3):
         img = np.random.RandomState(100 * seed + h).randint(0, 256, (h, w, 3)).astype(np.uint8)
         x_o, scale_o = O.img_preprocessing(img, PIXEL_MEANS)
         x_d, scale_d = img_preprocessing(img, runtime=rt)
